@@ -1,0 +1,162 @@
+/*
+ * seqkit_hip.h — C-ABI of the MI355X (gfx950) implementation of seqkit's per-read hot path.
+ *
+ * The reference (annalam/seqkit v0.8.0, Rust) has no FFI/plugin interface: every command is a
+ * `while read_line` loop with the arithmetic inlined.  This header is the seam a
+ * host (the reference's Rust `fasta`/`sam` binaries, or this repo's C++ ones) binds to replace the
+ * inlined per-read arithmetic.  Each entry point cites the reference lines it replaces; paths are
+ * relative to the reference tree.  INTEGRATION.md shows the Rust `extern "C"` block.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns SK_OK (0) or a negative SK_ERR_* code and
+ *    never throws or aborts; sk_last_error() gives the message for the last failure on that ctx.
+ *  - one sk_ctx per GPU; a ctx is used by one host thread at a time; a ctx owns one HIP stream.
+ *  - read batches are fixed-stride SoA: row r of a byte matrix lives at base + r*stride, only its first
+ *    len[r] bytes are data (len == NULL: every row holds exactly `stride` bytes).  Bytes past len[r]
+ *    are ignored on input; on output (masked sequence) they are unspecified.
+ *  - functions without suffix take HOST pointers and are synchronous (they stage through device
+ *    workspace owned by the ctx).  `_dev` functions take DEVICE pointers, enqueue on the ctx stream
+ *    and return immediately; sk_sync() waits.  Device byte matrices must be 16-byte aligned.
+ *  - there is no CPU fallback: without a usable GPU sk_create() fails and nothing else can be called.
+ */
+#ifndef SEQKIT_HIP_H
+#define SEQKIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_OK            0
+#define SK_ERR_INVALID  (-1)   /* bad argument (NULL, negative size, misaligned device pointer, ...) */
+#define SK_ERR_HIP      (-2)   /* HIP runtime failure; sk_last_error() has hipGetErrorString          */
+#define SK_ERR_NO_DEVICE (-3)  /* no gfx950-capable device at that index                              */
+#define SK_ERR_STATE    (-4)   /* call order (e.g. demux before sk_set_barcodes)                      */
+#define SK_ERR_NOMEM    (-5)
+
+/* assignment codes written by the demultiplex entry points (src/fasta_demultiplex.rs:168-194) */
+#define SK_ASSIGN_NONE      (-1)   /* lowest_diff > max_diff                                   */
+#define SK_ASSIGN_AMBIGUOUS (-2)   /* lowest_diff <= max_diff but best != equally_fine sample  */
+
+#define SK_MAX_BARCODE_LEN 255
+#define SK_MAX_SAMPLES     32767
+
+typedef struct sk_ctx sk_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int  sk_version(void);                                   /* 0x00MMmmpp */
+int  sk_device_count(void);                              /* number of visible HIP devices (>= 0) */
+int  sk_create(int device_id, sk_ctx **out);
+void sk_destroy(sk_ctx *ctx);
+const char *sk_last_error(const sk_ctx *ctx);            /* ctx may be NULL: last sk_create failure */
+int  sk_sync(sk_ctx *ctx);                               /* wait for everything enqueued on the ctx stream */
+void *sk_stream(sk_ctx *ctx);                            /* the ctx's hipStream_t, for interop */
+
+/* ---- device / pinned memory for hosts that do not link HIP themselves ------------------------ */
+int sk_malloc_device(sk_ctx *ctx, size_t bytes, void **out);
+int sk_free_device(sk_ctx *ctx, void *p);
+int sk_malloc_pinned(sk_ctx *ctx, size_t bytes, void **out);
+int sk_free_pinned(sk_ctx *ctx, void *p);
+int sk_copy_h2d(sk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* async on ctx stream */
+int sk_copy_d2h(sk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* async on ctx stream */
+
+/* ---- sample sheet -> barcode table -------------------------------------------------------------
+ * Replaces the per-read walk over `samples[s].barcode` (src/fasta_demultiplex.rs:157-158, Sample
+ * :23-28, sheet rules :58-104 stay on the host).  table = S rows of L bytes, sheet order.  Candidate
+ * bytes 'N' and 'U' are wildcards (src/fasta_demultiplex.rs:273).  max_diff is the reference's
+ * MAX_BARCODE_DIFFERENCE = 1 (:168).  Resets the counters.                                        */
+int sk_set_barcodes(sk_ctx *ctx, const uint8_t *table, int S, int L, int max_diff);
+
+/* ---- D1+D2+D3: barcode_diff + best-match loop + decision ----------------------------------------
+ * src/fasta_demultiplex.rs:269-277, :154-166, :168-194.  bc = n observed barcodes of exactly L bytes,
+ * row stride bc_stride >= L.  Outputs (each nullable except assign): assign[r] = sample index, or
+ * SK_ASSIGN_NONE / SK_ASSIGN_AMBIGUOUS; lowest_diff[r] (saturates at 255; 255 when S == 0);
+ * first_idx[r] = best_sample, last_idx[r] = equally_fine_sample.  Adds to the ctx counters.         */
+int sk_demux_assign(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n,
+                    int32_t *assign, uint8_t *lowest_diff, int16_t *first_idx, int16_t *last_idx);
+int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n,
+                        int32_t *assign, uint8_t *lowest_diff, int16_t *first_idx, int16_t *last_idx,
+                        uint64_t *counts /* device u64[S+3], NULL = ctx counters */);
+
+/* ---- T1: 3' running-sum quality trim --------------------------------------------------------------
+ * src/fasta_trim_by_quality.rs:28-42.  qual rows are the quality line after trim_end(); writes
+ * lowest_k[r] in [0, len[r]] (0 means the reference emits "N\n+\n!\n", :44-45).                      */
+int sk_trim_by_quality(sk_ctx *ctx, const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                       uint8_t min_baseq, uint16_t *lowest_k);
+int sk_trim_by_quality_dev(sk_ctx *ctx, const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                           uint8_t min_baseq, uint16_t *lowest_k);
+
+/* ---- M1: mask bases whose Phred+33 quality is below min_baseq ------------------------------------
+ * src/fasta_mask_by_quality.rs:40-43 (byte form, i.e. ASCII lines; the host keeps non-ASCII lines).
+ * out_seq may equal seq (in place).                                                                  */
+int sk_mask_by_quality(sk_ctx *ctx, uint8_t *seq /* in/out */, const uint8_t *qual, const uint16_t *len,
+                       int stride, int64_t n, uint8_t min_baseq);
+int sk_mask_by_quality_dev(sk_ctx *ctx, const uint8_t *seq, const uint8_t *qual, int stride, int64_t n,
+                           uint8_t min_baseq, uint8_t *out_seq);
+
+/* ---- fused per-read pass: demultiplex (+ add barcode) + trim by quality + mask by quality ---------
+ * One pass over a batch of n clusters with 1 or 2 mates.  `add barcode` (src/fasta_add_barcode.rs:
+ * 19-44) is realised by handing the index read's bases over as the bc column instead of round-tripping
+ * them through the header text; header handling (D4/D5) stays on the host.  Any of the three parts can
+ * be switched off by leaving its outputs NULL:
+ *   demultiplex : bc != NULL           -> assign (+ optional lowest_diff/first_idx/last_idx, counters)
+ *   trim        : mate.lowest_k != NULL
+ *   mask        : mate.out_seq  != NULL (may alias mate.seq)
+ * The same struct serves the host and the _dev entry point.                                          */
+typedef struct {
+	const uint8_t  *seq;        /* n x stride  (needed only for mask)           */
+	const uint8_t  *qual;       /* n x stride                                   */
+	const uint16_t *len;        /* n, or NULL = all rows are `stride` long      */
+	uint8_t        *out_seq;    /* n x stride masked bases, or NULL             */
+	uint16_t       *lowest_k;   /* n, or NULL                                   */
+} sk_mate;
+
+typedef struct {
+	int64_t  n;                 /* clusters in the batch                        */
+	int      n_mates;           /* 1 (single end) or 2 (paired end)             */
+	int      stride;            /* row stride of seq/qual/out_seq, both mates   */
+	uint8_t  min_baseq;         /* threshold for trim and mask                  */
+	sk_mate  mate[2];
+	const uint8_t *bc;          /* n x bc_stride observed barcodes, or NULL     */
+	int      bc_stride;
+	int32_t *assign;            /* n                                            */
+	uint8_t *lowest_diff;       /* n or NULL                                    */
+	int16_t *first_idx;         /* n or NULL                                    */
+	int16_t *last_idx;          /* n or NULL                                    */
+	uint64_t *counts;           /* _dev only: device u64[S+3] or NULL = ctx's   */
+} sk_fused_args;
+
+int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
+int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
+
+/* ---- counters: sample.total_reads[S], total_reads, identified_reads (+ ambiguous) -----------------
+ * src/fasta_demultiplex.rs:108-109,169,177-178.  Layout u64[S+3]: per-sample counts, then [S] total,
+ * [S+1] identified, [S+2] ambiguous.  These are the only cross-shard state of the path; a multi-GPU
+ * host sums them with one all-reduce (sk_counts_device_ptr gives the device buffer to reduce).       */
+int sk_counts_reset(sk_ctx *ctx);
+int sk_counts_get(sk_ctx *ctx, uint64_t *counts /* host, S+3 */);
+void *sk_counts_device_ptr(sk_ctx *ctx);
+
+/* ---- S1 + H1: BAM flag counters and |TLEN| histogram -----------------------------------------------
+ * src/sam_statistics.rs:63-69 (counters[0]=total, [1]=aligned, [2]=duplicate) and
+ * src/sam_fragment_lengths.rs:29-43 (hist[0..max_frag], *hist_total = records histogrammed).  Inputs
+ * are the BAM fixed-core fields as SoA columns (flag@14, refID@0, next_refID@20, tlen@28 of the 32-byte
+ * core).  Results are ADDED to the caller's arrays.  The --reads=N early stop (:42) is order dependent
+ * and stays on the host.  counters or hist may be NULL to skip that half.                             */
+int sk_bam_flag_tlen(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                     const int32_t *tlen, int64_t n, int32_t max_frag,
+                     uint64_t counters[3], uint64_t *hist, uint64_t *hist_total);
+/* out = device u64[3 + 1 + (max_frag+1)]: counters, hist_total, hist; ADDED to. */
+int sk_bam_flag_tlen_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                         const int32_t *tlen, int64_t n, int32_t max_frag, uint64_t *out);
+
+/* ---- timing on the ctx stream (hipEvents), so a host without HIP can time device work -------------- */
+int sk_timer_start(sk_ctx *ctx);
+int sk_timer_stop(sk_ctx *ctx, float *ms);               /* records, synchronises, returns elapsed ms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,412 @@
+/*
+ * fasta_oracle — ORACLE restatement of the reference's `fasta` subcommands on the hot
+ * path, line-at-a-time, single-threaded, same loops as the cited source.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see seqkit_oracle.h).
+ *
+ *   fasta trim by quality <fastq_file> <min_baseq>      src/fasta_trim_by_quality.rs:10-50
+ *   fasta mask by quality <fastq_file> <min_baseq>      src/fasta_mask_by_quality.rs:11-47
+ *   fasta add barcode <fastq_file> <barcode_file>       src/fasta_add_barcode.rs:11-45
+ *   fasta demultiplex [options] <sheet> <fq1> [<fq2>]   src/fasta_demultiplex.rs:30-265
+ * dispatch: src/fasta_main.rs:61-76.
+ */
+#include "cli_common.h"
+
+static const char *USAGE_TOP =
+"\nUsage:\n"
+"  fasta check <fasta/fastq>\n"
+"  fasta to raw <fasta/fastq>\n"
+"  fasta add base qualities <fasta> <baseq>\n"
+"  fasta remove base qualities <fastq>\n"
+"  fasta simplify read ids <fastq_file>\n"
+"  fasta interleave <fastq_1> <fastq_2>\n"
+"  fasta deinterleave <interleaved_fastq> <out_prefix>\n"
+"  fasta split into anchors <fastq> <anchor_len>\n"
+"  fasta trim <fastq_file>\n"
+"  fasta trim by quality <fastq_file> <min_baseq>\n"
+"  fasta mask by quality <fastq_file> <min_baseq>\n"
+"  fasta gc content <genome.fa> <regions.bed>\n"
+"  fasta add barcode <fastq_file> <barcode_file> <barcode_format>\n"
+"  fasta extract dual umi <interleaved_fastq>\n"
+"  fasta convert basespace <fastq_file>\n"
+"  fasta demultiplex <sample_sheet> <fastq_1> <fastq_2>\n"
+"  fasta demultiplex spe <sample_sheet> <fastq_1> <fastq_2>\n"
+"  fasta statistics <fastq_file>\n";
+
+static const char *USAGE_TRIM = "\nUsage:\n  fasta trim by quality <fastq_file> <min_baseq>\n";
+static const char *USAGE_MASK = "\nUsage:\n  fasta mask by quality <fastq_file> <min_baseq>\n";
+static const char *USAGE_ADDBC = "\nUsage:\n  fasta add barcode <fastq_file> <barcode_file>\n";
+static const char *USAGE_DEMUX =
+"\nUsage:\n"
+"  fasta demultiplex [options] <sample_sheet> <fastq_1> [<fastq_2>]\n"
+"\n"
+"Options:\n"
+"  --parallel      Use pigz (parallel gzip) for compression\n"
+"  --index1=FASTQ  Path to FASTQ file containing the first index (optional)\n"
+"  --index2=FASTQ  Path to FASTQ file containing the second index (optional)\n"
+"  --dry-run=N     Analyze N reads and generate table of indexes found in the run\n"
+"\n"
+"Splits a pooled FASTQ file into multiple individual FASTQ files, based on a\n"
+"sample sheet. Each read in the pooled FASTQ file must carry a BC:xxxxxxxx\n"
+"field in its header.\n";
+
+/* ---------------------------------------------------------------------------------- */
+/* src/fasta_trim_by_quality.rs:10-50 */
+static int trim_by_quality(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 4, NULL, 0, pos, &npos, 2) || npos != 2)
+		oc_error("Invalid arguments.\n%s", USAGE_TRIM);
+	oc_reader fq = oc_reader_open(pos[0]);                                     /* :12 */
+	uint64_t mb;
+	if (!oc_parse_uint(pos[1], 255, &mb)) oc_panic("min_baseq.parse::<u8>().unwrap()"); /* :13 */
+	uint8_t min_baseq = (uint8_t)mb;
+
+	oc_str line = {0}, seq = {0}, qual = {0};
+	while (oc_read_line(&fq, &line)) {                                         /* :19 */
+		if (!oc_starts_with(&line, '@')) oc_error("Invalid FASTQ format encountered."); /* :20-22 */
+		fwrite(line.p, 1, line.n, stdout);                                     /* :23 */
+		oc_read_line(&fq, &seq);                                               /* :24 */
+		oc_read_line(&fq, &line);                                              /* :25 */
+		oc_read_line(&fq, &qual);                                              /* :26 */
+
+		uint32_t n = (uint32_t)orc_trim_end_len(qual.p, qual.n);               /* :31 */
+		uint32_t lowest_k = orc_trim_lowest_k(qual.p, n, min_baseq);           /* :28-42 */
+
+		if (lowest_k == 0) {                                                   /* :44-45 */
+			fputs("N\n+\n!\n", stdout);
+		} else {                                                               /* :47 */
+			/* &seq[..lowest_k] / &qual[..lowest_k]: byte slices; out of range or a cut
+			 * inside a multi-byte char panics. */
+			if (lowest_k > seq.n) oc_panic("byte index out of range of `seq`");
+			if (lowest_k < seq.n && (seq.p[lowest_k] & 0xC0) == 0x80) oc_panic("seq slice not on a char boundary");
+			if (lowest_k < qual.n && (qual.p[lowest_k] & 0xC0) == 0x80) oc_panic("qual slice not on a char boundary");
+			fwrite(seq.p, 1, lowest_k, stdout);
+			fputs("\n+\n", stdout);
+			fwrite(qual.p, 1, lowest_k, stdout);
+			fputc('\n', stdout);
+		}
+	}
+	return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+static size_t u8_char_len(uint8_t b) { return b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4; }
+static uint32_t u8_decode(const uint8_t *s, size_t l)
+{
+	if (l == 1) return s[0];
+	if (l == 2) return ((uint32_t)(s[0] & 0x1F) << 6) | (s[1] & 0x3F);
+	if (l == 3) return ((uint32_t)(s[0] & 0x0F) << 12) | ((uint32_t)(s[1] & 0x3F) << 6) | (s[2] & 0x3F);
+	return ((uint32_t)(s[0] & 0x07) << 18) | ((uint32_t)(s[1] & 0x3F) << 12) | ((uint32_t)(s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+}
+
+/* src/fasta_mask_by_quality.rs:11-47 */
+static int mask_by_quality(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 4, NULL, 0, pos, &npos, 2) || npos != 2)
+		oc_error("Invalid arguments.\n%s", USAGE_MASK);
+	oc_reader fq = oc_reader_open(pos[0]);                                     /* :13 */
+	uint64_t mb;
+	if (!oc_parse_uint(pos[1], 255, &mb)) oc_panic("min_baseq.parse::<u8>().unwrap()"); /* :14 */
+	uint8_t min_baseq = (uint8_t)mb;
+
+	oc_str seq = {0}, bq = {0}, line = {0}, output = {0};
+	while (oc_read_line(&fq, &line)) {                                         /* :20 */
+		if (!oc_starts_with(&line, '@')) oc_error("Invalid FASTQ format encountered."); /* :21-23 */
+		oc_assign(&output, line.p, line.n);                                    /* :25-26 */
+		oc_read_line(&fq, &seq);                                               /* :28 */
+		oc_read_line(&fq, &line);                                              /* :29 */
+		oc_read_line(&fq, &bq);                                                /* :30 */
+		if (seq.n && seq.p[seq.n - 1] == '\n') seq.n--;                        /* :32 */
+		if (bq.n && bq.p[bq.n - 1] == '\n') bq.n--;                            /* :33 */
+		if (seq.n != bq.n)                                                     /* :35-37 */
+			oc_error("Read sequence and base qualities are of different length.");
+		/* :40-43 — seq.chars().zip(qual.chars()); `qual as u8` keeps the low 8 bits of
+		 * the code point; for pure-ASCII lines this is the byte loop of orc_mask_bytes. */
+		size_t i = 0, j = 0;
+		while (i < seq.n && j < bq.n) {
+			size_t li = u8_char_len(seq.p[i]), lj = u8_char_len(bq.p[j]);
+			uint8_t q = (uint8_t)u8_decode(bq.p + j, lj);
+			if ((uint8_t)(q - (uint8_t)33) < min_baseq) oc_append(&output, "N", 1);
+			else oc_append(&output, seq.p + i, li);
+			i += li; j += lj;
+		}
+		oc_append(&output, "\n+\n", 3);                                        /* :44 */
+		oc_append(&output, bq.p, bq.n);
+		oc_append(&output, "\n", 1);
+		fwrite(output.p, 1, output.n, stdout);                                 /* :45 */
+	}
+	return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* src/fasta_add_barcode.rs:11-45 */
+static int add_barcode(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 3, NULL, 0, pos, &npos, 2) || npos != 2)
+		oc_error("Invalid arguments.\n%s", USAGE_ADDBC);
+	oc_reader fq = oc_reader_open(pos[0]);
+	oc_reader bf = oc_reader_open(pos[1]);
+	oc_str header = {0}, barcode = {0}, line = {0};
+	for (;;) {
+		oc_read_line(&bf, &header);                                            /* :20 */
+		if (oc_starts_with(&header, '@')) {                                    /* :21-24 */
+			oc_read_line(&bf, &barcode);
+			oc_read_line(&bf, &line);
+			oc_read_line(&bf, &line);
+		} else if (oc_starts_with(&header, '>')) {                             /* :25-27 */
+			oc_read_line(&bf, &barcode);
+		}                              /* exhausted barcode file: `barcode` keeps its old value */
+		if (!oc_read_line(&fq, &header)) break;                                /* :29-31 */
+		size_t hl = orc_trim_end_len(header.p, header.n);
+		size_t bl = orc_trim_end_len(barcode.p, barcode.n);
+		fwrite(header.p, 1, hl, stdout);                                       /* :33 */
+		fputs(" BC:", stdout);
+		fwrite(barcode.p, 1, bl, stdout);
+		fputc('\n', stdout);
+		if (oc_starts_with(&header, '@')) {                                    /* :35-38 */
+			for (int k = 0; k < 3; k++) { oc_read_line(&fq, &line); fwrite(line.p, 1, line.n, stdout); }
+		} else if (oc_starts_with(&header, '>')) {                             /* :39-40 */
+			oc_read_line(&fq, &line); fwrite(line.p, 1, line.n, stdout);
+		} else {                                                               /* :41-43 */
+			oc_error("Invalid FASTQ line:\n%s", (const char *)header.p);
+		}
+	}
+	return 0;
+}
+
+/* ---------------------------------------------------------------------------------- */
+typedef struct {
+	oc_str name, barcode;
+	FILE *out[2];
+	uint64_t total_reads;
+} sample_t;
+
+typedef struct { oc_str bc; uint64_t count; } extra_t;
+
+/* src/fasta_demultiplex.rs:30-265 */
+static int demultiplex(int argc, char **argv)
+{
+	oc_opt opts[4] = {
+		{"--parallel", 0, NULL}, {"--index1", 1, NULL}, {"--index2", 1, NULL}, {"--dry-run", 1, NULL}};
+	const char *pos[3]; int npos;
+	if (!oc_parse(argc, argv, 2, opts, 4, pos, &npos, 3) || npos < 2)
+		oc_error("Invalid arguments.\n%s", USAGE_DEMUX);
+	int parallel = opts[0].value != NULL;                                      /* :32 */
+	uint64_t dry_run = 0;                                                      /* :33-36 */
+	const char *dr = opts[3].value ? opts[3].value : "";
+	if (!oc_parse_uint(dr, UINT64_MAX, &dry_run)) dry_run = 0;
+	if (dry_run == 0 && dr[0] != 0) oc_error("In --dry-run=N, N must be 64-bit positive integer.");
+
+	oc_reader fastq[2]; int nfastq = 0;                                        /* :41-46 */
+	fastq[nfastq++] = oc_reader_open(pos[1]);
+	if (npos == 3 && pos[2][0] != 0) fastq[nfastq++] = oc_reader_open(pos[2]);
+	int paired_end = nfastq == 2;
+
+	oc_reader index_fastq[2]; int nindex = 0;                                  /* :49-55 */
+	if (opts[1].value && opts[1].value[0]) index_fastq[nindex++] = oc_reader_open(opts[1].value);
+	if (opts[2].value && opts[2].value[0]) index_fastq[nindex++] = oc_reader_open(opts[2].value);
+
+	fputs("Reading sample sheet...\n", stderr);                                /* :58 */
+	oc_reader sheet = oc_reader_open(pos[0]);
+	sample_t *samples = NULL; int S = 0, capS = 0;
+	oc_str line = {0};
+	size_t barcode_len = 0;
+	while (oc_read_line(&sheet, &line)) {                                      /* :63 */
+		if (oc_starts_with(&line, '#')) continue;                              /* :64 */
+		size_t off = orc_trim_start_off(line.p, line.n);                       /* :65 line.trim() */
+		size_t tl = orc_trim_end_len(line.p + off, line.n - off);
+		const uint8_t *t = line.p + off;
+		/* split('\t'): cols[0], cols[1] */
+		const uint8_t *tab1 = (const uint8_t *)memchr(t, '\t', tl);
+		if (!tab1) continue;                                                   /* :66 cols.len() < 2 */
+		size_t c0 = (size_t)(tab1 - t);
+		const uint8_t *c1p = tab1 + 1;
+		size_t rest = tl - c0 - 1;
+		const uint8_t *tab2 = (const uint8_t *)memchr(c1p, '\t', rest);
+		size_t c1 = tab2 ? (size_t)(tab2 - c1p) : rest;
+		if (S == capS) { capS = capS ? capS * 2 : 16; samples = (sample_t *)realloc(samples, sizeof(sample_t) * capS); }
+		sample_t *sm = &samples[S];
+		memset(sm, 0, sizeof(*sm));
+		oc_assign(&sm->name, t, c0);
+		if (c1 == 0) oc_error("Sample %s has no barcode.", (const char *)sm->name.p);     /* :68 */
+		if (barcode_len == 0) barcode_len = c1;                                /* :69-70 */
+		else if (c1 != barcode_len) oc_error("Barcodes in sample sheet must all be of same length."); /* :71-73 */
+		oc_assign(&sm->barcode, c1p, c1);
+		if (dry_run > 0) {                                                     /* :77-78 */
+		} else if (paired_end) {                                               /* :79-83 */
+			char path[4096];
+			snprintf(path, sizeof path, "%s_1.fq.gz", (const char *)sm->name.p);
+			sm->out[0] = oc_gzip_writer(path, parallel);
+			snprintf(path, sizeof path, "%s_2.fq.gz", (const char *)sm->name.p);
+			sm->out[1] = oc_gzip_writer(path, parallel);
+		} else {                                                               /* :84-87 */
+			char path[4096];
+			snprintf(path, sizeof path, "%s.fq.gz", (const char *)sm->name.p);
+			sm->out[0] = oc_gzip_writer(path, parallel);
+		}
+		S++;
+	}
+
+	for (int s = 0; s < S; s++)                                                /* :98-104 */
+		for (int k = s + 1; k < S; k++)
+			if (samples[s].name.n == samples[k].name.n &&
+			    memcmp(samples[s].name.p, samples[k].name.p, samples[s].name.n) == 0)
+				oc_error("Sample %s is listed multiple times in sample sheet.", (const char *)samples[s].name.p);
+
+	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single"); /* :106-107 */
+	uint64_t total_reads = 0, identified_reads = 0;
+	extra_t *extra = NULL; size_t nextra = 0, capextra = 0;
+
+	oc_str header = {0}, barcode = {0}, umi = {0};
+	while (oc_read_line(&fastq[0], &header)) {                                 /* :117 */
+		if (!oc_starts_with(&header, '@'))                                     /* :118-120 */
+			oc_error("Invalid FASTQ header line:\n%s", (const char *)header.p);
+		oc_clear(&barcode);                                                    /* :123 */
+		if (nindex > 0) {                                                      /* :126-136 */
+			for (int f = 0; f < nindex; f++) {
+				if (barcode.n) oc_append(&barcode, "+", 1);
+				oc_read_line(&index_fastq[f], &line);
+				if (!oc_starts_with(&line, '@')) oc_panic("assertion failed: line.starts_with('@')");
+				oc_read_line(&index_fastq[f], &line);
+				oc_append(&barcode, line.p, orc_trim_end_len(line.p, line.n));
+				oc_read_line(&index_fastq[f], &line);
+				if (!oc_starts_with(&line, '+')) oc_panic("assertion failed: line.starts_with('+')");
+				oc_read_line(&index_fastq[f], &line);
+			}
+		} else {                                                               /* :137-146 */
+			size_t st, en;
+			if (!orc_find_bc_field(header.p, header.n, &st, &en)) oc_error("No BC:xxxx field found.");
+			oc_append(&barcode, header.p + st + 4, en - (st + 4));
+			oc_drain(&header, st, en);
+		}
+		if (barcode.n != barcode_len)                                          /* :148-150 */
+			oc_error("Sequenced barcode %s is of different length (%zu nt) than barcodes in the sample sheet (%zu nt).",
+			         barcode.n ? (const char *)barcode.p : "", barcode.n, barcode_len);
+
+		/* :154-166 — restated inline (the table is not contiguous here) */
+		size_t best_sample = 0, equally_fine_sample = 0;
+		uint64_t lowest_diff = UINT64_MAX;
+		for (int s = 0; s < S; s++) {
+			uint64_t diff = orc_barcode_diff(barcode.p, samples[s].barcode.p, barcode.n);
+			if (diff < lowest_diff) { lowest_diff = diff; best_sample = (size_t)s; equally_fine_sample = (size_t)s; }
+			else if (diff == lowest_diff) equally_fine_sample = (size_t)s;
+		}
+
+		const uint64_t MAX_BARCODE_DIFFERENCE = 1;                             /* :168 */
+		total_reads += 1;                                                      /* :169 */
+		int write_read_out = 0;
+		if (lowest_diff <= MAX_BARCODE_DIFFERENCE) {                           /* :172 */
+			if (best_sample == equally_fine_sample) {                          /* :173-179 */
+				identified_reads += 1;
+				samples[best_sample].total_reads += 1;
+				write_read_out = !(dry_run > 0);
+			} else {                                                           /* :181-189 */
+				fprintf(stderr, "WARNING: Sequenced barcode %s was an equally good match (%llu mismatches) for samples %s (%s) and %s (%s), and was therefore not assigned to any sample.\n",
+				        (const char *)barcode.p, (unsigned long long)lowest_diff,
+				        (const char *)samples[best_sample].name.p, (const char *)samples[best_sample].barcode.p,
+				        (const char *)samples[equally_fine_sample].name.p, (const char *)samples[equally_fine_sample].barcode.p);
+			}
+		} else if (dry_run > 0) {                                              /* :190-194 */
+			size_t e = 0;
+			for (; e < nextra; e++)
+				if (extra[e].bc.n == barcode.n && memcmp(extra[e].bc.p, barcode.p, barcode.n) == 0) break;
+			if (e == nextra) {
+				if (nextra == capextra) { capextra = capextra ? capextra * 2 : 64; extra = (extra_t *)realloc(extra, sizeof(extra_t) * capextra); }
+				memset(&extra[nextra], 0, sizeof(extra_t));
+				oc_assign(&extra[nextra].bc, barcode.p, barcode.n);
+				nextra++;
+			}
+			extra[e].count += 1;
+		}
+
+		if (write_read_out) {                                                  /* :196 */
+			sample_t *sm = &samples[best_sample];
+			oc_clear(&umi);                                                    /* :200-203 (chars().zip(chars())) */
+			{
+				size_t i = 0, j = 0;
+				while (i < sm->barcode.n && j < barcode.n) {
+					size_t li = u8_char_len(sm->barcode.p[i]), lj = u8_char_len(barcode.p[j]);
+					if (li == 1 && sm->barcode.p[i] == 'U') oc_append(&umi, barcode.p + j, lj);
+					i += li; j += lj;
+				}
+			}
+			fwrite(header.p, 1, orc_trim_end_len(header.p, header.n), sm->out[0]);   /* :206 */
+			if (umi.n) { fputs(" UMI:", sm->out[0]); fwrite(umi.p, 1, umi.n, sm->out[0]); } /* :207 */
+			fputc('\n', sm->out[0]);                                           /* :208 */
+			for (int k = 0; k < 3; k++) {                                      /* :209-212 */
+				oc_read_line(&fastq[0], &line);
+				fwrite(line.p, 1, line.n, sm->out[0]);
+			}
+			if (paired_end) {                                                  /* :215 */
+				oc_read_line(&fastq[1], &line);                                /* :216 */
+				if (nindex == 0) {                                             /* :219-227 */
+					size_t st, en;
+					if (orc_find_bc_field(line.p, line.n, &st, &en) && en > 0) oc_drain(&line, st, en);
+				}
+				fwrite(line.p, 1, orc_trim_end_len(line.p, line.n), sm->out[1]);      /* :229 */
+				if (umi.n) { fputs(" UMI:", sm->out[1]); fwrite(umi.p, 1, umi.n, sm->out[1]); } /* :230-232 */
+				fputc('\n', sm->out[1]);                                       /* :233 */
+				for (int k = 0; k < 3; k++) {                                  /* :234-237 */
+					oc_read_line(&fastq[1], &line);
+					fwrite(line.p, 1, line.n, sm->out[1]);
+				}
+			}
+		} else {                                                               /* :239-246 */
+			for (int k = 0; k < 3; k++) oc_read_line(&fastq[0], &line);
+			if (paired_end) for (int k = 0; k < 4; k++) oc_read_line(&fastq[1], &line);
+		}
+		if (dry_run > 0 && total_reads >= dry_run) break;                      /* :248 */
+	}
+
+	if (dry_run > 0) {                                                         /* :251-261 */
+		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);
+		size_t ne = (size_t)S + nextra;
+		/* entries = samples (sheet order) then extra_barcodes (HashMap order: arbitrary in
+		 * the reference; first-seen order here).  Stable ascending sort by count, then
+		 * reverse(). */
+		typedef struct { const uint8_t *label; uint64_t count; size_t ord; } ent_t;
+		ent_t *ents = (ent_t *)malloc(sizeof(ent_t) * (ne ? ne : 1));
+		for (int s = 0; s < S; s++) { ents[s].label = samples[s].name.p; ents[s].count = samples[s].total_reads; ents[s].ord = (size_t)s; }
+		for (size_t e = 0; e < nextra; e++) { ents[S + e].label = extra[e].bc.p; ents[S + e].count = extra[e].count; ents[S + e].ord = (size_t)S + e; }
+		for (size_t a = 1; a < ne; a++) {          /* insertion sort = stable */
+			ent_t x = ents[a]; size_t b = a;
+			while (b > 0 && ents[b - 1].count > x.count) { ents[b] = ents[b - 1]; b--; }
+			ents[b] = x;
+		}
+		/* &entries[0..100] panics when there are fewer than 100 entries (:258) */
+		if (ne < 100) oc_panic("range end index 100 out of range for slice");
+		for (size_t a = 0; a < 100; a++) {
+			ent_t *x = &ents[ne - 1 - a];
+			printf("- %s: %llu\n", (const char *)x->label, (unsigned long long)x->count);
+		}
+	}
+
+	char pct[64];                                                              /* :263-264 */
+	oc_fmt_pct(pct, sizeof pct, (double)identified_reads / (double)total_reads * 100.0);
+	fprintf(stderr, "%llu / %llu (%s%%) clusters carried a barcode matching one of the provided samples.\n",
+	        (unsigned long long)identified_reads, (unsigned long long)total_reads, pct);
+	return 0;
+}
+
+/* src/fasta_main.rs:42-82 (only the hot-path arms are restated) */
+int main(int argc, char **argv)
+{
+	int rc;
+	if (argc >= 4 && !strcmp(argv[1], "trim") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
+		rc = trim_by_quality(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "mask") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
+		rc = mask_by_quality(argc, argv);
+	else if (argc >= 3 && !strcmp(argv[1], "add") && !strcmp(argv[2], "barcode"))
+		rc = add_barcode(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "demultiplex"))
+		rc = demultiplex(argc, argv);
+	else {
+		fprintf(stderr, "%s\n", USAGE_TOP);
+		rc = 0;
+	}
+	fflush(stdout);
+	oc_wait_children();
+	return rc;
+}

@@ -1,0 +1,322 @@
+/*
+ * seqkit_oracle.c — CPU ORACLE (test infrastructure; see seqkit_oracle.h header note).
+ * PARITY UNPINNED against the reference binary; pinned only to the hand-derived
+ * known-answer vectors of SURVEY.md Appendix A (tests/golden/).
+ *
+ * Every function follows the cited reference lines one statement at a time; scalar,
+ * single-threaded, no SIMD tricks, so that it reads like the source it restates.
+ */
+#include "seqkit_oracle.h"
+
+#include <string.h>
+
+/* src/fasta_trim_by_quality.rs:28-42
+ *   total = lowest_total = -50; k = lowest_k = trim_end(qual).len()
+ *   while k > 0 { k -= 1; total += (qual[k] - 33u8) as i32 - min_baseq as i32;
+ *                 if total > 0 {break}; if total < lowest_total {lowest_total = total; lowest_k = k} }
+ * `qual[k] - 33u8` is u8 arithmetic: wraps in release builds.                        */
+uint32_t orc_trim_lowest_k(const uint8_t *qual, uint32_t n, uint8_t min_baseq)
+{
+	int32_t total = -50;
+	int32_t lowest_total = total;
+	uint32_t k = n;
+	uint32_t lowest_k = k;
+	while (k > 0) {
+		k -= 1;
+		uint8_t v = (uint8_t)(qual[k] - (uint8_t)33);
+		total += (int32_t)v - (int32_t)min_baseq;
+		if (total > 0) break;
+		if (total < lowest_total) {
+			lowest_total = total;
+			lowest_k = k;
+		}
+	}
+	return lowest_k;
+}
+
+/* src/fasta_mask_by_quality.rs:40-43
+ *   output.push(if qual as u8 - 33u8 < min_baseq { 'N' } else { base })               */
+void orc_mask_bytes(uint8_t *seq, const uint8_t *qual, uint32_t n, uint8_t min_baseq)
+{
+	for (uint32_t i = 0; i < n; i++) {
+		uint8_t v = (uint8_t)(qual[i] - (uint8_t)33);
+		if (v < min_baseq) seq[i] = 'N';
+	}
+}
+
+/* src/fasta_demultiplex.rs:269-277 */
+size_t orc_barcode_diff(const uint8_t *observed, const uint8_t *candidate, size_t len)
+{
+	size_t mismatches = 0;
+	for (size_t k = 0; k < len; k++) {
+		if (candidate[k] == 'N' || candidate[k] == 'U') continue;
+		if (observed[k] != candidate[k]) mismatches += 1;
+	}
+	return mismatches;
+}
+
+/* src/fasta_demultiplex.rs:154-166 */
+orc_match orc_best_match(const uint8_t *observed, const uint8_t *table, int S, int L)
+{
+	orc_match m;
+	m.best_sample = 0;
+	m.equally_fine = 0;
+	m.lowest_diff = UINT64_MAX;
+	for (int s = 0; s < S; s++) {
+		uint64_t diff = orc_barcode_diff(observed, table + (size_t)s * (size_t)L, (size_t)L);
+		if (diff < m.lowest_diff) {
+			m.lowest_diff = diff;
+			m.best_sample = (uint32_t)s;
+			m.equally_fine = (uint32_t)s;
+		} else if (diff == m.lowest_diff) {
+			m.equally_fine = (uint32_t)s;
+		}
+	}
+	return m;
+}
+
+/* src/fasta_demultiplex.rs:168-189 */
+int32_t orc_decide(orc_match m, uint64_t max_diff)
+{
+	if (m.lowest_diff <= max_diff) {
+		if (m.best_sample == m.equally_fine) return (int32_t)m.best_sample;
+		return ORC_AMBIGUOUS;
+	}
+	return ORC_NONE;
+}
+
+void orc_trim_batch(const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                    uint8_t min_baseq, uint16_t *lowest_k)
+{
+	for (int64_t r = 0; r < n; r++) {
+		uint32_t l = len ? len[r] : (uint32_t)stride;
+		lowest_k[r] = (uint16_t)orc_trim_lowest_k(qual + r * (int64_t)stride, l, min_baseq);
+	}
+}
+
+void orc_mask_batch(uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride,
+                    int64_t n, uint8_t min_baseq)
+{
+	for (int64_t r = 0; r < n; r++) {
+		uint32_t l = len ? len[r] : (uint32_t)stride;
+		orc_mask_bytes(seq + r * (int64_t)stride, qual + r * (int64_t)stride, l, min_baseq);
+	}
+}
+
+void orc_demux_batch(const uint8_t *table, int S, int L, int max_diff,
+                     const uint8_t *bc, int bc_stride, int64_t n,
+                     int32_t *assign, uint8_t *lowest_diff, int16_t *first_idx,
+                     int16_t *last_idx, uint64_t *counts)
+{
+	for (int64_t r = 0; r < n; r++) {
+		orc_match m = orc_best_match(bc + r * (int64_t)bc_stride, table, S, L);
+		int32_t code = orc_decide(m, (uint64_t)max_diff);
+		assign[r] = code;
+		if (lowest_diff) lowest_diff[r] = m.lowest_diff > 255 ? 255 : (uint8_t)m.lowest_diff;
+		if (first_idx) first_idx[r] = (int16_t)m.best_sample;
+		if (last_idx) last_idx[r] = (int16_t)m.equally_fine;
+		if (counts) {
+			counts[S] += 1;                                   /* total_reads += 1  :169 */
+			if (code >= 0) { counts[S + 1] += 1; counts[code] += 1; }   /* :177-178 */
+			else if (code == ORC_AMBIGUOUS) counts[S + 2] += 1;
+		}
+	}
+}
+
+/* src/sam_statistics.rs:63-69 and src/sam_fragment_lengths.rs:29-43.
+ * Flag predicates are the SAM-spec bits that rust-htslib 0.31's Record::is_* test. */
+#define F_PAIRED 0x1
+#define F_UNMAPPED 0x4
+#define F_MUNMAP 0x8
+#define F_FIRST 0x40
+#define F_SECONDARY 0x100
+#define F_DUP 0x400
+#define F_SUPPL 0x800
+
+static int frag_keep(uint16_t f, int32_t tid, int32_t mtid, int32_t tlen, int32_t max_frag,
+                     uint64_t *frag)
+{
+	if (!(f & F_PAIRED)) return 0;
+	if (!(f & F_FIRST)) return 0;
+	if ((f & F_UNMAPPED) || (f & F_MUNMAP)) return 0;
+	if ((f & F_DUP) || (f & F_SECONDARY)) return 0;
+	if (f & F_SUPPL) return 0;
+	if (tid != mtid) return 0;
+	/* insert_size().abs() as usize: i64 abs of a value that was i32 on disk */
+	int64_t t = (int64_t)tlen;
+	uint64_t a = (uint64_t)(t < 0 ? -t : t);
+	if (a > (uint64_t)(int64_t)max_frag) return 0;
+	*frag = a;
+	return 1;
+}
+
+void orc_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                       const int32_t *tlen, int64_t n, int32_t max_frag,
+                       uint64_t counters[3], uint64_t *hist, uint64_t *hist_total)
+{
+	for (int64_t i = 0; i < n; i++) {
+		uint16_t f = flag[i];
+		if (counters) {
+			if (!((f & F_SECONDARY) || (f & F_SUPPL))) {
+				counters[0] += 1;
+				if (!(f & F_UNMAPPED)) {
+					counters[1] += 1;
+					if (f & F_DUP) counters[2] += 1;
+				}
+			}
+		}
+		if (hist) {
+			uint64_t a;
+			if (frag_keep(f, tid[i], mtid[i], tlen[i], max_frag, &a)) {
+				if (hist_total) *hist_total += 1;
+				hist[a] += 1;
+			}
+		}
+	}
+}
+
+int64_t orc_fragment_lengths_stop(const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                                  const int32_t *tlen, int64_t n, int32_t max_frag,
+                                  uint64_t stop_after, uint64_t *hist, uint64_t *hist_total)
+{
+	uint64_t total = 0;
+	int64_t i = 0;
+	for (; i < n; i++) {
+		uint64_t a;
+		if (!frag_keep(flag[i], tid[i], mtid[i], tlen[i], max_frag, &a)) continue;
+		total += 1;
+		hist[a] += 1;
+		if (total >= stop_after) { i++; break; }
+	}
+	if (hist_total) *hist_total += total;
+	return i;
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Rust std text semantics                                                            */
+
+static int is_rust_whitespace(uint32_t c)
+{
+	if (c >= 0x09 && c <= 0x0D) return 1;
+	if (c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680) return 1;
+	if (c >= 0x2000 && c <= 0x200A) return 1;
+	if (c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000) return 1;
+	return 0;
+}
+
+/* decode the char that ENDS at s[n) (valid UTF-8 assumed); returns its byte length */
+static size_t utf8_prev(const uint8_t *s, size_t n, uint32_t *cp)
+{
+	size_t i = n - 1;
+	while (i > 0 && (s[i] & 0xC0) == 0x80 && n - i < 4) i--;
+	size_t l = n - i;
+	uint32_t c;
+	if (l == 1) c = s[i];
+	else if (l == 2) c = ((uint32_t)(s[i] & 0x1F) << 6) | (s[i + 1] & 0x3F);
+	else if (l == 3) c = ((uint32_t)(s[i] & 0x0F) << 12) | ((uint32_t)(s[i + 1] & 0x3F) << 6) | (s[i + 2] & 0x3F);
+	else c = ((uint32_t)(s[i] & 0x07) << 18) | ((uint32_t)(s[i + 1] & 0x3F) << 12) |
+	         ((uint32_t)(s[i + 2] & 0x3F) << 6) | (s[i + 3] & 0x3F);
+	*cp = c;
+	return l;
+}
+
+static size_t utf8_next(const uint8_t *s, size_t n, uint32_t *cp)
+{
+	uint8_t b = s[0];
+	size_t l = b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4;
+	if (l > n) l = n;
+	uint32_t c;
+	if (l == 1) c = b;
+	else if (l == 2) c = ((uint32_t)(b & 0x1F) << 6) | (s[1] & 0x3F);
+	else if (l == 3) c = ((uint32_t)(b & 0x0F) << 12) | ((uint32_t)(s[1] & 0x3F) << 6) | (s[2] & 0x3F);
+	else c = ((uint32_t)(b & 0x07) << 18) | ((uint32_t)(s[1] & 0x3F) << 12) |
+	         ((uint32_t)(s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+	*cp = c;
+	return l;
+}
+
+size_t orc_trim_end_len(const uint8_t *s, size_t n)
+{
+	while (n > 0) {
+		uint32_t c;
+		size_t l = utf8_prev(s, n, &c);
+		if (!is_rust_whitespace(c)) break;
+		n -= l;
+	}
+	return n;
+}
+
+size_t orc_trim_start_off(const uint8_t *s, size_t n)
+{
+	size_t off = 0;
+	while (off < n) {
+		uint32_t c;
+		size_t l = utf8_next(s + off, n - off, &c);
+		if (!is_rust_whitespace(c)) break;
+		off += l;
+	}
+	return off;
+}
+
+/* Well-formed UTF-8 per the Unicode standard table 3-7 (what core::str::from_utf8 accepts). */
+int orc_utf8_valid(const uint8_t *s, size_t n)
+{
+	size_t i = 0;
+	while (i < n) {
+		uint8_t b = s[i];
+		if (b < 0x80) { i++; continue; }
+		if (b >= 0xC2 && b <= 0xDF) {
+			if (i + 1 >= n || (s[i + 1] & 0xC0) != 0x80) return 0;
+			i += 2; continue;
+		}
+		if (b >= 0xE0 && b <= 0xEF) {
+			if (i + 2 >= n) return 0;
+			uint8_t c1 = s[i + 1], c2 = s[i + 2];
+			uint8_t lo = 0x80, hi = 0xBF;
+			if (b == 0xE0) lo = 0xA0;
+			if (b == 0xED) hi = 0x9F;
+			if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80) return 0;
+			i += 3; continue;
+		}
+		if (b >= 0xF0 && b <= 0xF4) {
+			if (i + 3 >= n) return 0;
+			uint8_t c1 = s[i + 1], c2 = s[i + 2], c3 = s[i + 3];
+			uint8_t lo = 0x80, hi = 0xBF;
+			if (b == 0xF0) lo = 0x90;
+			if (b == 0xF4) hi = 0x8F;
+			if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80 || (c3 & 0xC0) != 0x80) return 0;
+			i += 4; continue;
+		}
+		return 0;
+	}
+	return 1;
+}
+
+static int bc_class(uint8_t c)
+{
+	switch (c) {
+	case 'A': case 'C': case 'G': case 'T': case 'N':
+	case 'a': case 'c': case 'g': case 't': case 'n': case '+':
+		return 1;
+	default:
+		return 0;
+	}
+}
+
+/* regex crate semantics for a literal prefix followed by one greedy class repetition:
+ * the leftmost position where " BC:" is followed by >= 1 class byte; the match then
+ * extends over the whole run of class bytes.                                         */
+int orc_find_bc_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end)
+{
+	for (size_t i = 0; i + 5 <= n; i++) {
+		if (hdr[i] == ' ' && hdr[i + 1] == 'B' && hdr[i + 2] == 'C' && hdr[i + 3] == ':' &&
+		    bc_class(hdr[i + 4])) {
+			size_t e = i + 5;
+			while (e < n && bc_class(hdr[e])) e++;
+			*start = i;
+			*end = e;
+			return 1;
+		}
+	}
+	return 0;
+}

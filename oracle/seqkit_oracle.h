@@ -1,0 +1,99 @@
+/*
+ * seqkit_oracle.h — CPU ORACLE for the seqkit per-read hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (seqkit_amd/, the
+ * C-ABI library in include/seqkit_hip.h) never links, imports or executes anything
+ * under oracle/.
+ *
+ * PARITY UNPINNED: the reference (annalam/seqkit v0.8.0) is Rust, cannot be built in
+ * this image (no cargo/rustc, no crates), and ships no tests, golden vectors or
+ * fixtures for this path.  This file is a plain-C restatement of
+ * the reference's loops, written from the cited source lines; it is checked against
+ * the hand-derived known-answer vectors in tests/golden/ (SURVEY.md Appendix A), not
+ * against outputs of the reference binary.
+ *
+ * Citations are relative to /root/reference/.  Release-mode Rust semantics are
+ * assumed throughout (u8 subtraction wraps), which is what `cargo install` builds
+ * (README.md:28-30).
+ */
+#ifndef SEQKIT_ORACLE_H
+#define SEQKIT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- T1: src/fasta_trim_by_quality.rs:28-42 ------------------------------------ */
+/* qual = the quality line after Rust str::trim_end(); returns lowest_k in [0, n]. */
+uint32_t orc_trim_lowest_k(const uint8_t *qual, uint32_t n, uint8_t min_baseq);
+
+/* ---- M1: src/fasta_mask_by_quality.rs:40-43 (byte form; valid for ASCII lines) -- */
+void orc_mask_bytes(uint8_t *seq, const uint8_t *qual, uint32_t n, uint8_t min_baseq);
+
+/* ---- D1: src/fasta_demultiplex.rs:269-277 -------------------------------------- */
+size_t orc_barcode_diff(const uint8_t *observed, const uint8_t *candidate, size_t len);
+
+/* ---- D2: src/fasta_demultiplex.rs:154-166 -------------------------------------- */
+typedef struct {
+	uint64_t lowest_diff;      /* UINT64_MAX when S == 0 (usize::MAX) */
+	uint32_t best_sample;      /* first index attaining the minimum   */
+	uint32_t equally_fine;     /* last index attaining the minimum    */
+} orc_match;
+orc_match orc_best_match(const uint8_t *observed, const uint8_t *table /* S*L row-major */,
+                         int S, int L);
+
+/* ---- D3: src/fasta_demultiplex.rs:168-194 -------------------------------------- */
+/* assignment code: >= 0 sample index, ORC_NONE no sample within max_diff,
+ * ORC_AMBIGUOUS two or more samples equally close (read dropped).                  */
+#define ORC_NONE      (-1)
+#define ORC_AMBIGUOUS (-2)
+int32_t orc_decide(orc_match m, uint64_t max_diff);
+
+/* ---- batch (SoA, fixed stride) forms: same arithmetic over packed buffers ------- */
+/* row r lives at base + r*stride; only the first len[r] bytes are data; len == NULL
+ * means every row holds exactly `stride` bytes of data.                             */
+void orc_trim_batch(const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                    uint8_t min_baseq, uint16_t *lowest_k);
+void orc_mask_batch(uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride,
+                    int64_t n, uint8_t min_baseq);
+/* counts: S per-sample, then [S]=total, [S+1]=identified, [S+2]=ambiguous; ADDED to. */
+void orc_demux_batch(const uint8_t *table, int S, int L, int max_diff,
+                     const uint8_t *bc, int bc_stride, int64_t n,
+                     int32_t *assign, uint8_t *lowest_diff /* saturated at 255, nullable */,
+                     int16_t *first_idx /* nullable */, int16_t *last_idx /* nullable */,
+                     uint64_t *counts /* nullable */);
+
+/* ---- S1 + H1: src/sam_statistics.rs:63-69, src/sam_fragment_lengths.rs:29-43 ---- */
+/* counters[0]=total, [1]=aligned, [2]=duplicate (S1); hist[0..max_frag] (H1), and
+ * *hist_total = number of records that entered the histogram.  All ADDED to.        */
+void orc_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                       const int32_t *tlen, int64_t n, int32_t max_frag,
+                       uint64_t counters[3], uint64_t *hist, uint64_t *hist_total);
+/* H1 with the --reads=N early stop (src/sam_fragment_lengths.rs:42): returns the
+ * number of records consumed from the input before stopping.                        */
+int64_t orc_fragment_lengths_stop(const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
+                                  const int32_t *tlen, int64_t n, int32_t max_frag,
+                                  uint64_t stop_after, uint64_t *hist, uint64_t *hist_total);
+
+/* ---- text helpers that restate Rust std behaviour used on the path -------------- */
+/* str::trim_end(): length of s after removing trailing Unicode White_Space chars
+ * (U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F, 3000);
+ * s must be valid UTF-8.  Note 0x1C..0x1F are NOT whitespace for Rust.               */
+size_t orc_trim_end_len(const uint8_t *s, size_t n);
+/* str::trim(): returns new start offset, writes new length.                          */
+size_t orc_trim_start_off(const uint8_t *s, size_t n);
+/* 1 when s[0..n) is well-formed UTF-8 (what BufRead::read_line demands,
+ * src/common.rs:106-112).                                                            */
+int orc_utf8_valid(const uint8_t *s, size_t n);
+/* regex " BC:[ACGTNacgtn+]+" leftmost-first, greedy (src/fasta_demultiplex.rs:38,140):
+ * returns 1 and [*start,*end) of the whole match, else 0.                            */
+int orc_find_bc_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

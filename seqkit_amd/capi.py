@@ -1,0 +1,335 @@
+"""ctypes view of include/seqkit_hip.h.
+
+Nothing here computes: every method marshals numpy arrays (host entry points) or raw device
+addresses (``*_dev`` entry points, e.g. ``torch.Tensor.data_ptr()``) into the C-ABI.  There is
+deliberately no fallback path: if libseqkit_hip.so is absent or no gfx950 GPU is visible the
+constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+SK_ASSIGN_NONE = -1
+SK_ASSIGN_AMBIGUOUS = -2
+
+# every symbol include/seqkit_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "sk_version", "sk_device_count", "sk_create", "sk_destroy", "sk_last_error", "sk_sync", "sk_stream",
+    "sk_malloc_device", "sk_free_device", "sk_malloc_pinned", "sk_free_pinned", "sk_copy_h2d", "sk_copy_d2h",
+    "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
+    "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
+    "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
+    "sk_timer_start", "sk_timer_stop",
+]
+
+
+class SeqkitHipError(RuntimeError):
+    pass
+
+
+class _Mate(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p),
+                ("out_seq", C.c_void_p), ("lowest_k", C.c_void_p)]
+
+
+class _FusedArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_mates", C.c_int), ("stride", C.c_int), ("min_baseq", C.c_uint8),
+                ("mate", _Mate * 2), ("bc", C.c_void_p), ("bc_stride", C.c_int), ("assign", C.c_void_p),
+                ("lowest_diff", C.c_void_p), ("first_idx", C.c_void_p), ("last_idx", C.c_void_p),
+                ("counts", C.c_void_p)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libseqkit_hip.so (no GPU needed for this step) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SeqkitHipError(
+            f"{path} is missing: build it with `python -m seqkit_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for this library.")
+    lib = C.CDLL(path)
+    vp, i32, i64, u8 = C.c_void_p, C.c_int, C.c_int64, C.c_uint8
+    protos = {
+        "sk_version": (i32, []), "sk_device_count": (i32, []),
+        "sk_create": (i32, [i32, C.POINTER(vp)]), "sk_destroy": (None, [vp]),
+        "sk_last_error": (C.c_char_p, [vp]), "sk_sync": (i32, [vp]), "sk_stream": (vp, [vp]),
+        "sk_malloc_device": (i32, [vp, C.c_size_t, C.POINTER(vp)]), "sk_free_device": (i32, [vp, vp]),
+        "sk_malloc_pinned": (i32, [vp, C.c_size_t, C.POINTER(vp)]), "sk_free_pinned": (i32, [vp, vp]),
+        "sk_copy_h2d": (i32, [vp, vp, vp, C.c_size_t]), "sk_copy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "sk_set_barcodes": (i32, [vp, vp, i32, i32, i32]),
+        "sk_demux_assign": (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
+        "sk_demux_assign_dev": (i32, [vp, vp, i32, i64, vp, vp, vp, vp, vp]),
+        "sk_trim_by_quality": (i32, [vp, vp, vp, i32, i64, u8, vp]),
+        "sk_trim_by_quality_dev": (i32, [vp, vp, vp, i32, i64, u8, vp]),
+        "sk_mask_by_quality": (i32, [vp, vp, vp, vp, i32, i64, u8]),
+        "sk_mask_by_quality_dev": (i32, [vp, vp, vp, i32, i64, u8, vp]),
+        "sk_fused_pass": (i32, [vp, C.POINTER(_FusedArgs)]),
+        "sk_fused_pass_dev": (i32, [vp, C.POINTER(_FusedArgs)]),
+        "sk_counts_reset": (i32, [vp]), "sk_counts_get": (i32, [vp, vp]), "sk_counts_device_ptr": (vp, [vp]),
+        "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+        "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
+        "sk_timer_start": (i32, [vp]), "sk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
+    return None if a is None else a.ctypes.data
+
+
+def _mat(a, name: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2 or not a.flags.c_contiguous:
+        raise ValueError(f"{name} must be a C-contiguous uint8 matrix [n, stride]")
+    return a
+
+
+def _vec(a, dtype, n: int, name: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != dtype or a.ndim != 1 or a.shape[0] != n or not a.flags.c_contiguous:
+        raise ValueError(f"{name} must be a contiguous {np.dtype(dtype).name} vector of length {n}")
+    return a
+
+
+class Context:
+    """One sk_ctx: one GPU, one stream.  Mirrors the C-ABI call for call."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.sk_create(device, C.byref(h))
+        if rc != 0:
+            msg = self._lib.sk_last_error(None).decode()
+            raise SeqkitHipError(f"sk_create({device}) failed ({rc}): {msg}")
+        self._h = h
+        self.S = 0
+        self.L = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.sk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise SeqkitHipError(f"{what} failed ({rc}): {self._lib.sk_last_error(self._h).decode()}")
+
+    # ---- lifetime / memory --------------------------------------------------------------
+    def sync(self) -> None:
+        self._check(self._lib.sk_sync(self._h), "sk_sync")
+
+    def stream(self) -> int:
+        return int(self._lib.sk_stream(self._h) or 0)
+
+    def malloc_device(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.sk_malloc_device(self._h, nbytes, C.byref(p)), "sk_malloc_device")
+        return int(p.value)
+
+    def free_device(self, p: int) -> None:
+        self._check(self._lib.sk_free_device(self._h, p), "sk_free_device")
+
+    def copy_h2d(self, dst: int, src: np.ndarray) -> None:
+        self._check(self._lib.sk_copy_h2d(self._h, dst, src.ctypes.data, src.nbytes), "sk_copy_h2d")
+
+    def copy_d2h(self, dst: np.ndarray, src: int) -> None:
+        self._check(self._lib.sk_copy_d2h(self._h, dst.ctypes.data, src, dst.nbytes), "sk_copy_d2h")
+
+    def timer_start(self) -> None:
+        self._check(self._lib.sk_timer_start(self._h), "sk_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.sk_timer_stop(self._h, C.byref(ms)), "sk_timer_stop")
+        return float(ms.value)
+
+    # ---- barcodes -----------------------------------------------------------------------
+    def set_barcodes(self, table, max_diff: int = 1) -> None:
+        table = np.ascontiguousarray(table, dtype=np.uint8)
+        if table.ndim != 2:
+            raise ValueError("table must be [S, L] uint8")
+        S, L = table.shape
+        self._check(self._lib.sk_set_barcodes(self._h, _ptr(table) if S else None, S, L, max_diff), "sk_set_barcodes")
+        self.S, self.L = S, L
+
+    def counts_reset(self) -> None:
+        self._check(self._lib.sk_counts_reset(self._h), "sk_counts_reset")
+
+    def counts(self) -> np.ndarray:
+        out = np.zeros(self.S + 3, dtype=np.uint64)
+        self._check(self._lib.sk_counts_get(self._h, _ptr(out)), "sk_counts_get")
+        return out
+
+    def counts_device_ptr(self) -> int:
+        return int(self._lib.sk_counts_device_ptr(self._h) or 0)
+
+    # ---- host entry points --------------------------------------------------------------
+    def demux_assign(self, bc, want_detail: bool = True):
+        bc = _mat(bc, "bc")
+        n, bstride = bc.shape
+        assign = np.empty(n, dtype=np.int32)
+        low = np.empty(n, dtype=np.uint8) if want_detail else None
+        first = np.empty(n, dtype=np.int16) if want_detail else None
+        last = np.empty(n, dtype=np.int16) if want_detail else None
+        self._check(self._lib.sk_demux_assign(self._h, _ptr(bc), bstride, n, _ptr(assign), _ptr(low), _ptr(first),
+                                              _ptr(last)), "sk_demux_assign")
+        return assign, low, first, last
+
+    def trim_by_quality(self, qual, length, min_baseq: int) -> np.ndarray:
+        qual = _mat(qual, "qual")
+        n, stride = qual.shape
+        length = None if length is None else _vec(length, np.uint16, n, "len")
+        out = np.empty(n, dtype=np.uint16)
+        self._check(self._lib.sk_trim_by_quality(self._h, _ptr(qual), _ptr(length), stride, n, min_baseq, _ptr(out)),
+                    "sk_trim_by_quality")
+        return out
+
+    def mask_by_quality(self, seq, qual, length, min_baseq: int) -> np.ndarray:
+        """Returns the masked copy (the C entry point works in place on its seq argument)."""
+        seq = _mat(seq, "seq").copy()
+        qual = _mat(qual, "qual")
+        if seq.shape != qual.shape:
+            raise ValueError("seq and qual must have the same shape")
+        n, stride = seq.shape
+        length = None if length is None else _vec(length, np.uint16, n, "len")
+        self._check(self._lib.sk_mask_by_quality(self._h, _ptr(seq), _ptr(qual), _ptr(length), stride, n, min_baseq),
+                    "sk_mask_by_quality")
+        return seq
+
+    def fused_pass(self, mates, min_baseq: int, bc=None, want_detail: bool = False, do_mask: bool = True,
+                   do_trim: bool = True):
+        """mates: list of (seq, qual, len-or-None).  Returns dict with per-mate outputs and the assignment."""
+        a = _FusedArgs()
+        keep = []
+        n = None
+        stride = 0
+        res = {"out_seq": [], "lowest_k": []}
+        a.n_mates = len(mates)
+        for i, (seq, qual, length) in enumerate(mates):
+            qual = _mat(qual, "qual")
+            if n is None:
+                n, stride = qual.shape
+            if qual.shape != (n, stride):
+                raise ValueError("all mates must share [n, stride]")
+            a.mate[i].qual = _ptr(qual)
+            keep.append(qual)
+            if length is not None:
+                length = _vec(length, np.uint16, n, "len")
+                a.mate[i].len = _ptr(length)
+                keep.append(length)
+            if do_mask:
+                seq = _mat(seq, "seq")
+                out = np.empty_like(seq)
+                a.mate[i].seq = _ptr(seq)
+                a.mate[i].out_seq = _ptr(out)
+                keep.append(seq)
+                res["out_seq"].append(out)
+            if do_trim:
+                lk = np.empty(n, dtype=np.uint16)
+                a.mate[i].lowest_k = _ptr(lk)
+                res["lowest_k"].append(lk)
+        if bc is not None:
+            bc = _mat(bc, "bc")
+            if n is None:
+                n = bc.shape[0]
+            a.bc = _ptr(bc)
+            a.bc_stride = bc.shape[1]
+            res["assign"] = np.empty(n, dtype=np.int32)
+            a.assign = _ptr(res["assign"])
+            if want_detail:
+                res["lowest_diff"] = np.empty(n, dtype=np.uint8)
+                res["first_idx"] = np.empty(n, dtype=np.int16)
+                res["last_idx"] = np.empty(n, dtype=np.int16)
+                a.lowest_diff = _ptr(res["lowest_diff"])
+                a.first_idx = _ptr(res["first_idx"])
+                a.last_idx = _ptr(res["last_idx"])
+        a.n = n or 0
+        a.stride = stride
+        a.min_baseq = min_baseq
+        self._check(self._lib.sk_fused_pass(self._h, C.byref(a)), "sk_fused_pass")
+        return res
+
+    def bam_flag_tlen(self, flag, tid, mtid, tlen, max_frag: int = 5000):
+        n = len(flag)
+        flag = _vec(flag, np.uint16, n, "flag")
+        tid = _vec(tid, np.int32, n, "tid")
+        mtid = _vec(mtid, np.int32, n, "mtid")
+        tlen = _vec(tlen, np.int32, n, "tlen")
+        counters = np.zeros(3, dtype=np.uint64)
+        hist = np.zeros(max_frag + 1, dtype=np.uint64)
+        total = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sk_bam_flag_tlen(self._h, _ptr(flag), _ptr(tid), _ptr(mtid), _ptr(tlen), n, max_frag,
+                                               _ptr(counters), _ptr(hist), _ptr(total)), "sk_bam_flag_tlen")
+        return counters, hist, int(total[0])
+
+    # ---- device entry points (raw addresses) ---------------------------------------------
+    def fused_pass_dev(self, n: int, stride: int, min_baseq: int, mates, bc: int = 0, bc_stride: int = 0,
+                       assign: int = 0, lowest_diff: int = 0, first_idx: int = 0, last_idx: int = 0,
+                       counts: int = 0) -> None:
+        """mates: list of dicts with device addresses {seq, qual, len, out_seq, lowest_k} (0 = NULL)."""
+        a = _FusedArgs()
+        a.n, a.n_mates, a.stride, a.min_baseq = n, len(mates), stride, min_baseq
+        for i, m in enumerate(mates):
+            a.mate[i].seq = m.get("seq") or None
+            a.mate[i].qual = m.get("qual") or None
+            a.mate[i].len = m.get("len") or None
+            a.mate[i].out_seq = m.get("out_seq") or None
+            a.mate[i].lowest_k = m.get("lowest_k") or None
+        a.bc = bc or None
+        a.bc_stride = bc_stride
+        a.assign = assign or None
+        a.lowest_diff = lowest_diff or None
+        a.first_idx = first_idx or None
+        a.last_idx = last_idx or None
+        a.counts = counts or None
+        self._check(self._lib.sk_fused_pass_dev(self._h, C.byref(a)), "sk_fused_pass_dev")
+
+    def demux_assign_dev(self, bc: int, bc_stride: int, n: int, assign: int, lowest_diff: int = 0, first_idx: int = 0,
+                         last_idx: int = 0, counts: int = 0) -> None:
+        self._check(self._lib.sk_demux_assign_dev(self._h, bc, bc_stride, n, assign, lowest_diff or None,
+                                                  first_idx or None, last_idx or None, counts or None),
+                    "sk_demux_assign_dev")
+
+    def trim_by_quality_dev(self, qual: int, length: int, stride: int, n: int, min_baseq: int, lowest_k: int) -> None:
+        self._check(self._lib.sk_trim_by_quality_dev(self._h, qual, length or None, stride, n, min_baseq, lowest_k),
+                    "sk_trim_by_quality_dev")
+
+    def mask_by_quality_dev(self, seq: int, qual: int, stride: int, n: int, min_baseq: int, out_seq: int) -> None:
+        self._check(self._lib.sk_mask_by_quality_dev(self._h, seq, qual, stride, n, min_baseq, out_seq),
+                    "sk_mask_by_quality_dev")
+
+    def bam_flag_tlen_dev(self, flag: int, tid: int, mtid: int, tlen: int, n: int, max_frag: int, out: int) -> None:
+        self._check(self._lib.sk_bam_flag_tlen_dev(self._h, flag, tid, mtid, tlen, n, max_frag, out),
+                    "sk_bam_flag_tlen_dev")

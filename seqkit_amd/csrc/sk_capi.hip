@@ -1,0 +1,571 @@
+// sk_capi.hip — the C-ABI of include/seqkit_hip.h on top of the gfx950 kernels.
+// No CPU fallback lives here: without a GPU sk_create() fails and every other call needs a ctx.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/seqkit_hip.h"
+#include "sk_internal.h"
+
+struct sk_ctx {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::string err;
+	// barcode table
+	bool have_table = false;
+	int S = 0, L = 0, W = 0, max_diff = 1;
+	uint8_t *d_raw = nullptr;
+	uint32_t *d_onehot = nullptr;
+	uint8_t *d_lut = nullptr;
+	unsigned long long *d_counts = nullptr;    // u64[S+3]
+	// workspace for the host-pointer entry points
+	uint8_t *ws = nullptr;
+	size_t ws_bytes = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sk_ctx *c, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf; else g_create_err = buf;
+	return code;
+}
+
+#define SK_HIP(c, call)                                                                            \
+	do {                                                                                           \
+		hipError_t e_ = (call);                                                                    \
+		if (e_ != hipSuccess) return fail((c), SK_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+static int bind(sk_ctx *c)
+{
+	SK_HIP(c, hipSetDevice(c->device));
+	return SK_OK;
+}
+
+static int ensure_ws(sk_ctx *c, size_t bytes)
+{
+	if (bytes <= c->ws_bytes) return SK_OK;
+	if (c->ws) { SK_HIP(c, hipStreamSynchronize(c->stream)); SK_HIP(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+	size_t want = bytes + (bytes >> 2);
+	hipError_t e = hipMalloc((void **)&c->ws, want);
+	if (e != hipSuccess) { want = bytes; e = hipMalloc((void **)&c->ws, want); }
+	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "device workspace of %zu bytes: %s", want, hipGetErrorString(e));
+	c->ws_bytes = want;
+	return SK_OK;
+}
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+extern "C" {
+
+int sk_version(void) { return 0x000100; }
+
+int sk_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int sk_create(int device_id, sk_ctx **out)
+{
+	if (!out) return fail(nullptr, SK_ERR_INVALID, "sk_create: out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) return fail(nullptr, SK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+	if (device_id < 0 || device_id >= n) return fail(nullptr, SK_ERR_NO_DEVICE, "device %d out of range (0..%d)", device_id, n - 1);
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device_id);
+	if (e != hipSuccess) return fail(nullptr, SK_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(nullptr, SK_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code objects only", device_id, prop.gcnArchName);
+	sk_ctx *c = new sk_ctx();
+	c->device = device_id;
+	c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	e = hipSetDevice(device_id);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+	if (e != hipSuccess) { int r = fail(nullptr, SK_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete c; return r; }
+	*out = c;
+	return SK_OK;
+}
+
+void sk_destroy(sk_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->d_raw) (void)hipFree(c->d_raw);
+	if (c->d_onehot) (void)hipFree(c->d_onehot);
+	if (c->d_lut) (void)hipFree(c->d_lut);
+	if (c->d_counts) (void)hipFree(c->d_counts);
+	if (c->ws) (void)hipFree(c->ws);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+const char *sk_last_error(const sk_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int sk_sync(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	return SK_OK;
+}
+
+void *sk_stream(sk_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int sk_malloc_device(sk_ctx *c, size_t bytes, void **out)
+{
+	if (!c || !out) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	*out = nullptr;
+	hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	return SK_OK;
+}
+int sk_free_device(sk_ctx *c, void *p)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (p) SK_HIP(c, hipFree(p));
+	return SK_OK;
+}
+int sk_malloc_pinned(sk_ctx *c, size_t bytes, void **out)
+{
+	if (!c || !out) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	*out = nullptr;
+	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	return SK_OK;
+}
+int sk_free_pinned(sk_ctx *c, void *p)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (p) SK_HIP(c, hipHostFree(p));
+	return SK_OK;
+}
+int sk_copy_h2d(sk_ctx *c, void *dst, const void *src, size_t bytes)
+{
+	if (!c || (bytes && (!dst || !src))) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (bytes) SK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+	return SK_OK;
+}
+int sk_copy_d2h(sk_ctx *c, void *dst, const void *src, size_t bytes)
+{
+	if (!c || (bytes && (!dst || !src))) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (bytes) SK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+	return SK_OK;
+}
+
+// ---- barcode table ---------------------------------------------------------------------------------
+int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (S < 0 || S > SK_MAX_SAMPLES) return fail(c, SK_ERR_INVALID, "S = %d outside 0..%d", S, SK_MAX_SAMPLES);
+	if (L < 0 || L > SK_MAX_BARCODE_LEN || (S > 0 && L == 0)) return fail(c, SK_ERR_INVALID, "L = %d outside 1..%d", L, SK_MAX_BARCODE_LEN);
+	if (S > 0 && !table) return fail(c, SK_ERR_INVALID, "table is NULL");
+	if (max_diff < 0 || max_diff > 255) return fail(c, SK_ERR_INVALID, "max_diff = %d outside 0..255", max_diff);
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->d_raw) { SK_HIP(c, hipFree(c->d_raw)); c->d_raw = nullptr; }
+	if (c->d_onehot) { SK_HIP(c, hipFree(c->d_onehot)); c->d_onehot = nullptr; }
+	if (c->d_lut) { SK_HIP(c, hipFree(c->d_lut)); c->d_lut = nullptr; }
+	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
+	c->have_table = false;
+	c->S = S; c->L = L; c->max_diff = max_diff;
+	c->W = (L + 3) / 4;
+
+	SK_HIP(c, hipMalloc((void **)&c->d_raw, (size_t)S * L + 16));
+	if (S > 0) SK_HIP(c, hipMemcpy(c->d_raw, table, (size_t)S * L, hipMemcpyHostToDevice));
+
+	// one-hot re-coding: possible when every position uses <= 7 distinct non-wildcard bytes
+	bool onehot_ok = S > 0 && L <= sk::kMaxOneHotLen;
+	std::vector<uint8_t> lut((size_t)(L ? L : 1) * 256, 0x80);
+	std::vector<uint32_t> codes((size_t)(S ? S : 1) * (c->W ? c->W : 1), 0u);
+	for (int k = 0; k < L && onehot_ok; k++) {
+		int cls[256];
+		for (int b = 0; b < 256; b++) cls[b] = -1;
+		int ncls = 0;
+		for (int s = 0; s < S; s++) {
+			uint8_t b = table[(size_t)s * L + k];
+			if (b == 'N' || b == 'U') continue;                 // wildcards: src/fasta_demultiplex.rs:273
+			if (cls[b] < 0) { if (ncls == 7) { onehot_ok = false; break; } cls[b] = ncls++; }
+		}
+		if (!onehot_ok) break;
+		for (int b = 0; b < 256; b++) lut[(size_t)k * 256 + b] = (uint8_t)(0x80 | (cls[b] >= 0 ? (1 << cls[b]) : 0));
+		for (int s = 0; s < S; s++) {
+			uint8_t b = table[(size_t)s * L + k];
+			uint32_t code = (b == 'N' || b == 'U') ? 0x80u : (1u << cls[b]);
+			codes[(size_t)s * c->W + (k >> 2)] |= code << (8 * (k & 3));
+		}
+	}
+	if (onehot_ok) {
+		SK_HIP(c, hipMalloc((void **)&c->d_lut, lut.size()));
+		SK_HIP(c, hipMemcpy(c->d_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
+		SK_HIP(c, hipMalloc((void **)&c->d_onehot, codes.size() * 4 + 64));
+		SK_HIP(c, hipMemcpy(c->d_onehot, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
+	}
+	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
+	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
+	SK_HIP(c, hipDeviceSynchronize());     // the ctx stream is non-blocking: make the uploads visible to it
+	c->have_table = true;
+	return SK_OK;
+}
+
+static sk::BarcodeDev table_of(const sk_ctx *c)
+{
+	sk::BarcodeDev t;
+	t.raw = c->d_raw; t.onehot = c->d_onehot; t.lut = c->d_lut;
+	t.S = c->S; t.L = c->L; t.W = c->W; t.max_diff = c->max_diff;
+	return t;
+}
+
+int sk_counts_reset(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipMemsetAsync(c->d_counts, 0, (size_t)(c->S + 3) * 8, c->stream));
+	return SK_OK;
+}
+
+int sk_counts_get(sk_ctx *c, uint64_t *counts)
+{
+	if (!c || !counts) return SK_ERR_INVALID;
+	if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipMemcpyAsync(counts, c->d_counts, (size_t)(c->S + 3) * 8, hipMemcpyDeviceToHost, c->stream));
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	return SK_OK;
+}
+
+void *sk_counts_device_ptr(sk_ctx *c) { return (c && c->have_table) ? (void *)c->d_counts : nullptr; }
+
+// ---- fused pass ------------------------------------------------------------------------------------
+static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
+{
+	if (!a) return fail(c, SK_ERR_INVALID, "args is NULL");
+	if (a->n < 0) return fail(c, SK_ERR_INVALID, "n = %lld is negative", (long long)a->n);
+	if (a->n_mates < 0 || a->n_mates > 2) return fail(c, SK_ERR_INVALID, "n_mates = %d outside 0..2", a->n_mates);
+	bool any = false;
+	for (int m = 0; m < a->n_mates; m++) {
+		const sk_mate &mt = a->mate[m];
+		if (!mt.out_seq && !mt.lowest_k) continue;
+		any = true;
+		if (a->stride <= 0 || a->stride > 65535) return fail(c, SK_ERR_INVALID, "stride = %d outside 1..65535", a->stride);
+		if (!mt.qual) return fail(c, SK_ERR_INVALID, "mate %d: qual is NULL", m);
+		if (mt.out_seq && !mt.seq) return fail(c, SK_ERR_INVALID, "mate %d: out_seq given without seq", m);
+		if (dev && (!aligned16(mt.qual) || (mt.out_seq && (!aligned16(mt.seq) || !aligned16(mt.out_seq)))))
+			return fail(c, SK_ERR_INVALID, "mate %d: device byte matrices must be 16-byte aligned", m);
+	}
+	if (a->bc) {
+		if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
+		if (a->bc_stride < c->L || a->bc_stride <= 0) return fail(c, SK_ERR_INVALID, "bc_stride = %d is below the barcode length %d", a->bc_stride, c->L);
+		if (a->bc_stride > sk::kMaxTileStride) return fail(c, SK_ERR_INVALID, "bc_stride = %d above %d", a->bc_stride, sk::kMaxTileStride);
+		if (!a->assign) return fail(c, SK_ERR_INVALID, "assign is NULL");
+		if (dev && !aligned16(a->bc)) return fail(c, SK_ERR_INVALID, "bc must be 16-byte aligned");
+	} else if (!any) {
+		return fail(c, SK_ERR_INVALID, "nothing to do: no bc, no out_seq, no lowest_k");
+	}
+	return SK_OK;
+}
+
+static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
+{
+	sk::TileArgs t;
+	memset(&t, 0, sizeof t);
+	t.n = a->n; t.n_mates = a->n_mates; t.stride = a->stride;
+	t.qc = sk::make_qual_consts(a->min_baseq);
+	for (int m = 0; m < a->n_mates; m++) {
+		t.mate[m].seq = a->mate[m].seq; t.mate[m].qual = a->mate[m].qual; t.mate[m].len = a->mate[m].len;
+		t.mate[m].out_seq = a->mate[m].out_seq; t.mate[m].lowest_k = a->mate[m].lowest_k;
+	}
+	t.bc = a->bc; t.bc_stride = a->bc_stride;
+	if (a->bc) t.table = table_of(c);
+	t.assign = a->assign; t.lowest_diff = a->lowest_diff; t.first_idx = a->first_idx; t.last_idx = a->last_idx;
+	t.counts = a->counts ? (unsigned long long *)a->counts : c->d_counts;
+	return t;
+}
+
+int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = check_fused(c, a, true)) return r;
+	if (int r = bind(c)) return r;
+	if (a->n == 0) return SK_OK;
+	sk::TileArgs t = tile_args_of(c, a);
+	SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+// Host-pointer form: chunks of rows are staged through the device workspace.
+int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = check_fused(c, a, false)) return r;
+	if (int r = bind(c)) return r;
+	if (a->n == 0) return SK_OK;
+	const int64_t stride = a->stride;
+	// bytes of workspace per row
+	size_t per_row = 0;
+	for (int m = 0; m < a->n_mates; m++) {
+		const sk_mate &mt = a->mate[m];
+		if (!mt.out_seq && !mt.lowest_k) continue;
+		per_row += (size_t)stride;                         // qual
+		if (mt.out_seq) per_row += 2 * (size_t)stride;     // seq + out
+		if (mt.len) per_row += 2;
+		if (mt.lowest_k) per_row += 2;
+	}
+	if (a->bc) per_row += (size_t)a->bc_stride + 4 + 1 + 2 + 2;
+	int64_t chunk = (int64_t)((size_t)(192u << 20) / (per_row ? per_row : 1));
+	chunk &= ~(int64_t)63;
+	if (chunk < 64) chunk = 64;
+	if (chunk > a->n) chunk = (a->n + 63) & ~(int64_t)63;
+	if (int r = ensure_ws(c, (size_t)chunk * per_row + 64 * 256)) return r;
+
+	for (int64_t r0 = 0; r0 < a->n; r0 += chunk) {
+		const int64_t nr = (a->n - r0) < chunk ? (a->n - r0) : chunk;
+		uint8_t *p = c->ws;
+		auto carve = [&](size_t bytes) { uint8_t *q = p; p += up256(bytes); return q; };
+		sk_fused_args d = *a;
+		d.n = nr; d.counts = nullptr;
+		for (int m = 0; m < a->n_mates; m++) {
+			const sk_mate &mt = a->mate[m];
+			sk_mate &dm = d.mate[m];
+			dm = sk_mate{nullptr, nullptr, nullptr, nullptr, nullptr};
+			if (!mt.out_seq && !mt.lowest_k) continue;
+			uint8_t *dq = carve((size_t)nr * stride);
+			SK_HIP(c, hipMemcpyAsync(dq, mt.qual + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
+			dm.qual = dq;
+			if (mt.out_seq) {
+				uint8_t *ds = carve((size_t)nr * stride);
+				SK_HIP(c, hipMemcpyAsync(ds, mt.seq + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
+				dm.seq = ds;
+				dm.out_seq = carve((size_t)nr * stride);
+			}
+			if (mt.len) {
+				uint16_t *dl = (uint16_t *)carve((size_t)nr * 2);
+				SK_HIP(c, hipMemcpyAsync(dl, mt.len + r0, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+				dm.len = dl;
+			}
+			if (mt.lowest_k) dm.lowest_k = (uint16_t *)carve((size_t)nr * 2);
+		}
+		if (a->bc) {
+			uint8_t *db = carve((size_t)nr * a->bc_stride);
+			SK_HIP(c, hipMemcpyAsync(db, a->bc + r0 * a->bc_stride, (size_t)nr * a->bc_stride, hipMemcpyHostToDevice, c->stream));
+			d.bc = db;
+			d.assign = (int32_t *)carve((size_t)nr * 4);
+			d.lowest_diff = a->lowest_diff ? carve((size_t)nr) : nullptr;
+			d.first_idx = a->first_idx ? (int16_t *)carve((size_t)nr * 2) : nullptr;
+			d.last_idx = a->last_idx ? (int16_t *)carve((size_t)nr * 2) : nullptr;
+		}
+		sk::TileArgs t = tile_args_of(c, &d);
+		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
+		for (int m = 0; m < a->n_mates; m++) {
+			const sk_mate &mt = a->mate[m];
+			const sk_mate &dm = d.mate[m];
+			if (mt.out_seq) SK_HIP(c, hipMemcpyAsync(mt.out_seq + r0 * stride, dm.out_seq, (size_t)nr * stride, hipMemcpyDeviceToHost, c->stream));
+			if (mt.lowest_k) SK_HIP(c, hipMemcpyAsync(mt.lowest_k + r0, dm.lowest_k, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
+		}
+		if (a->bc) {
+			SK_HIP(c, hipMemcpyAsync(a->assign + r0, d.assign, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+			if (a->lowest_diff) SK_HIP(c, hipMemcpyAsync(a->lowest_diff + r0, d.lowest_diff, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+			if (a->first_idx) SK_HIP(c, hipMemcpyAsync(a->first_idx + r0, d.first_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
+			if (a->last_idx) SK_HIP(c, hipMemcpyAsync(a->last_idx + r0, d.last_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
+		}
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	return SK_OK;
+}
+
+// ---- single-operation entry points are thin views of the fused pass ----------------------------------
+int sk_demux_assign_dev(sk_ctx *c, const uint8_t *bc, int bc_stride, int64_t n, int32_t *assign, uint8_t *lowest_diff,
+                        int16_t *first_idx, int16_t *last_idx, uint64_t *counts)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!bc && n > 0) return fail(c, SK_ERR_INVALID, "bc is NULL");
+	sk_fused_args a;
+	memset(&a, 0, sizeof a);
+	a.n = n; a.n_mates = 0; a.bc = bc; a.bc_stride = bc_stride; a.assign = assign;
+	a.lowest_diff = lowest_diff; a.first_idx = first_idx; a.last_idx = last_idx; a.counts = counts;
+	if (n == 0) return SK_OK;
+	return sk_fused_pass_dev(c, &a);
+}
+
+int sk_demux_assign(sk_ctx *c, const uint8_t *bc, int bc_stride, int64_t n, int32_t *assign, uint8_t *lowest_diff,
+                    int16_t *first_idx, int16_t *last_idx)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!bc && n > 0) return fail(c, SK_ERR_INVALID, "bc is NULL");
+	sk_fused_args a;
+	memset(&a, 0, sizeof a);
+	a.n = n; a.n_mates = 0; a.bc = bc; a.bc_stride = bc_stride; a.assign = assign;
+	a.lowest_diff = lowest_diff; a.first_idx = first_idx; a.last_idx = last_idx;
+	if (n == 0) return SK_OK;
+	return sk_fused_pass(c, &a);
+}
+
+static void one_mate(sk_fused_args &a, const uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                     uint8_t min_baseq, uint8_t *out_seq, uint16_t *lowest_k)
+{
+	memset(&a, 0, sizeof a);
+	a.n = n; a.n_mates = 1; a.stride = stride; a.min_baseq = min_baseq;
+	a.mate[0].seq = seq; a.mate[0].qual = qual; a.mate[0].len = len; a.mate[0].out_seq = out_seq; a.mate[0].lowest_k = lowest_k;
+}
+
+int sk_trim_by_quality_dev(sk_ctx *c, const uint8_t *qual, const uint16_t *len, int stride, int64_t n, uint8_t min_baseq, uint16_t *lowest_k)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n == 0) return SK_OK;
+	if (!lowest_k) return fail(c, SK_ERR_INVALID, "lowest_k is NULL");
+	sk_fused_args a;
+	one_mate(a, nullptr, qual, len, stride, n, min_baseq, nullptr, lowest_k);
+	return sk_fused_pass_dev(c, &a);
+}
+
+int sk_trim_by_quality(sk_ctx *c, const uint8_t *qual, const uint16_t *len, int stride, int64_t n, uint8_t min_baseq, uint16_t *lowest_k)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n == 0) return SK_OK;
+	if (!lowest_k) return fail(c, SK_ERR_INVALID, "lowest_k is NULL");
+	sk_fused_args a;
+	one_mate(a, nullptr, qual, len, stride, n, min_baseq, nullptr, lowest_k);
+	return sk_fused_pass(c, &a);
+}
+
+int sk_mask_by_quality_dev(sk_ctx *c, const uint8_t *seq, const uint8_t *qual, int stride, int64_t n, uint8_t min_baseq, uint8_t *out_seq)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0 || stride <= 0) return fail(c, SK_ERR_INVALID, "n = %lld, stride = %d", (long long)n, stride);
+	if (n == 0) return SK_OK;
+	if (!seq || !qual || !out_seq) return fail(c, SK_ERR_INVALID, "seq, qual or out_seq is NULL");
+	if (!aligned16(seq) || !aligned16(qual) || !aligned16(out_seq)) return fail(c, SK_ERR_INVALID, "device byte matrices must be 16-byte aligned");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_mask_flat(seq, qual, out_seq, n * (int64_t)stride, sk::make_qual_consts(min_baseq), c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_mask_by_quality(sk_ctx *c, uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride, int64_t n, uint8_t min_baseq)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0 || stride <= 0) return fail(c, SK_ERR_INVALID, "n = %lld, stride = %d", (long long)n, stride);
+	if (n == 0) return SK_OK;
+	if (!seq || !qual) return fail(c, SK_ERR_INVALID, "seq or qual is NULL");
+	(void)len;   // pad bytes of the output are unspecified: the whole matrix is one byte stream
+	if (int r = bind(c)) return r;
+	const int64_t total = n * (int64_t)stride;
+	int64_t chunk = (int64_t)64 << 20;
+	if (chunk > total) chunk = (total + 15) & ~(int64_t)15;
+	if (int r = ensure_ws(c, (size_t)up256((size_t)chunk) * 3)) return r;
+	uint8_t *ds = c->ws, *dq = c->ws + up256((size_t)chunk), *dout = c->ws + 2 * up256((size_t)chunk);
+	sk::QualConsts qc = sk::make_qual_consts(min_baseq);
+	for (int64_t o = 0; o < total; o += chunk) {
+		const int64_t nb = (total - o) < chunk ? (total - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(ds, seq + o, (size_t)nb, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dq, qual + o, (size_t)nb, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, sk::launch_mask_flat(ds, dq, dout, nb, qc, c->n_cu, c->stream));
+		SK_HIP(c, hipMemcpyAsync(seq + o, dout, (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	return SK_OK;
+}
+
+// ---- BAM -------------------------------------------------------------------------------------------
+int sk_bam_flag_tlen_dev(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                         int64_t n, int32_t max_frag, uint64_t *out)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0 || max_frag < 0) return fail(c, SK_ERR_INVALID, "n = %lld, max_frag = %d", (long long)n, max_frag);
+	if (n == 0) return SK_OK;
+	if (!flag || !tid || !mtid || !tlen || !out) return fail(c, SK_ERR_INVALID, "NULL column or out");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bam_flag_tlen(flag, tid, mtid, tlen, n, max_frag, (unsigned long long *)out, 1, 1, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_bam_flag_tlen(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                     int64_t n, int32_t max_frag, uint64_t counters[3], uint64_t *hist, uint64_t *hist_total)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0 || max_frag < 0) return fail(c, SK_ERR_INVALID, "n = %lld, max_frag = %d", (long long)n, max_frag);
+	if (n == 0) return SK_OK;
+	if (!flag) return fail(c, SK_ERR_INVALID, "flag is NULL");
+	if (hist && (!tid || !mtid || !tlen)) return fail(c, SK_ERR_INVALID, "histogram needs tid, mtid and tlen");
+	if (!counters && !hist) return fail(c, SK_ERR_INVALID, "nothing to do");
+	if (int r = bind(c)) return r;
+	const size_t nout = 4 + (hist ? (size_t)max_frag + 1 : 0);
+	int64_t chunk = 8 << 20;
+	if (chunk > n) chunk = n;
+	const size_t cols = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4);
+	if (int r = ensure_ws(c, cols + up256(nout * 8))) return r;
+	uint8_t *p = c->ws;
+	uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
+	int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+	int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+	int32_t *dtlen = (int32_t *)p; p += up256((size_t)chunk * 4);
+	unsigned long long *dout = (unsigned long long *)p;
+	SK_HIP(c, hipMemsetAsync(dout, 0, nout * 8, c->stream));
+	for (int64_t o = 0; o < n; o += chunk) {
+		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		if (hist) {
+			SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+			SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+			SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		}
+		SK_HIP(c, sk::launch_bam_flag_tlen(dflag, dtid, dmtid, dtlen, nr, max_frag, dout, counters ? 1 : 0, hist ? 1 : 0, c->n_cu, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	std::vector<uint64_t> h(nout);
+	SK_HIP(c, hipMemcpy(h.data(), dout, nout * 8, hipMemcpyDeviceToHost));
+	if (counters) for (int i = 0; i < 3; i++) counters[i] += h[i];
+	if (hist) {
+		if (hist_total) *hist_total += h[3];
+		for (size_t i = 0; i <= (size_t)max_frag; i++) hist[i] += h[4 + i];
+	}
+	return SK_OK;
+}
+
+// ---- timing ----------------------------------------------------------------------------------------
+int sk_timer_start(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipEventRecord(c->ev0, c->stream));
+	return SK_OK;
+}
+
+int sk_timer_stop(sk_ctx *c, float *ms)
+{
+	if (!c || !ms) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipEventRecord(c->ev1, c->stream));
+	SK_HIP(c, hipEventSynchronize(c->ev1));
+	SK_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+	return SK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// sk_internal.h — shared between the C-ABI layer (sk_capi.hip) and the gfx950 kernels (sk_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sk {
+
+constexpr int kWave = 64;             // gfx950 wavefront; one read tile = 64 reads = one wave
+constexpr int kTileRows = 64;
+constexpr int kLdsPad = 16;           // bytes kept free before and after the LDS tile image
+constexpr int kMaxTileStride = 960;   // 64 rows x 960 B + pads + histogram <= 64 KiB of LDS
+constexpr int kMaxOneHotLen = 32;     // barcode length served by the one-hot popcount matcher (W <= 8 dwords)
+constexpr int kKeyBits = 11;          // trim scan packs (U << 11 | j); rows up to 2047 bytes
+constexpr int kMaxLdsHist = 1024;     // per-wave LDS histogram entries (S+3) before falling back to global atomics
+constexpr int kAssignNone = -1;       // SK_ASSIGN_NONE
+constexpr int kAssignAmbiguous = -2;  // SK_ASSIGN_AMBIGUOUS
+
+// Quality threshold as packed-byte constants (see sk_kernels.hip: lowq_flags).
+struct QualConsts {
+	uint32_t cl2;      // splat of (256 - t2) & 0x7f
+	uint32_t c72;      // 0x80808080 when (256 - t2) >= 128 else 0
+	int mode;          // 0: min_baseq == 0 (never masks); 1: g1 & ~g2; 2: g1; 3: g1 | ~g2
+	int min_baseq;
+};
+QualConsts make_qual_consts(int min_baseq);
+
+struct MateDev {
+	const uint8_t *seq;
+	const uint8_t *qual;
+	const uint16_t *len;
+	uint8_t *out_seq;
+	uint16_t *lowest_k;
+};
+
+struct BarcodeDev {
+	const uint8_t *raw;        // S x L sheet bytes
+	const uint32_t *onehot;    // S x W candidate codes (one-hot class bit, 0x80 wildcard), or nullptr
+	const uint8_t *lut;        // L x 256 observed byte -> (class bit | 0x80), or nullptr
+	int S, L, W, max_diff;
+};
+
+struct TileArgs {
+	int64_t n;
+	int n_mates;
+	int stride;
+	QualConsts qc;
+	MateDev mate[2];
+	const uint8_t *bc;
+	int bc_stride;
+	BarcodeDev table;
+	int32_t *assign;
+	uint8_t *lowest_diff;
+	int16_t *first_idx;
+	int16_t *last_idx;
+	unsigned long long *counts;     // device u64[S+3]
+};
+
+// launchers (all asynchronous on `st`); return hipError_t of the launch
+hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st);
+hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *out, int64_t bytes,
+                            const QualConsts &qc, int n_cu, hipStream_t st);
+hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                                int64_t n, int32_t max_frag, unsigned long long *out, int want_counters, int want_hist,
+                                int n_cu, hipStream_t st);
+
+}  // namespace sk

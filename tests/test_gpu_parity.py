@@ -1,0 +1,291 @@
+"""GPU: the HIP path, called through the C-ABI, against the CPU oracle — bit-exact (all integer/byte work)."""
+import numpy as np
+import pytest
+
+from seqkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def b(s: str) -> bytes:
+    return s.encode("latin-1")
+
+
+def rows(strings, stride=None):
+    L = max(len(s) for s in strings)
+    stride = stride or max(L, 1)
+    m = np.full((len(strings), stride), ord("~"), dtype=np.uint8)
+    ln = np.zeros(len(strings), dtype=np.uint16)
+    for i, s in enumerate(strings):
+        m[i, :len(s)] = np.frombuffer(s, dtype=np.uint8)
+        ln[i] = len(s)
+    return m, ln
+
+
+# ---- golden vectors through the GPU ------------------------------------------------------------------
+def test_trim_kat_gpu(ctx, golden):
+    g = golden["trim_by_quality"]
+    qual, ln = rows([b(c["qual"]) for c in g["cases"]])
+    got = ctx.trim_by_quality(qual, ln, g["min_baseq"])
+    assert list(map(int, got)) == [c["lowest_k"] for c in g["cases"]]
+
+
+def test_mask_kat_gpu(ctx, golden):
+    for c in golden["mask_by_quality"]["cases"]:
+        seq, ln = rows([b(c["seq"])])
+        qual, _ = rows([b(c["qual"])])
+        out = ctx.mask_by_quality(seq, qual, ln, c["min_baseq"])
+        assert out[0, :ln[0]].tobytes() == b(c["out"]), c
+
+
+def test_demux_kat_gpu(ctx, golden):
+    g = golden["demultiplex"]
+    for c in g["cases"]:
+        table = np.array([list(b(x)) for x in c["sheet"]], dtype=np.uint8)
+        ctx.set_barcodes(table, g["max_diff"])
+        bc = np.array([list(b(c["observed"]))], dtype=np.uint8)
+        assign, low, first, last = ctx.demux_assign(bc)
+        assert (int(low[0]), int(first[0]), int(last[0]), int(assign[0])) == (c["lowest_diff"], c["first"], c["last"], c["assign"]), c
+
+
+def test_bam_kat_gpu(ctx, golden):
+    g = golden["bam"]
+    counters, hist, total = ctx.bam_flag_tlen(np.array(g["flags"], dtype=np.uint16), np.array(g["tid"], dtype=np.int32),
+                                              np.array(g["mtid"], dtype=np.int32), np.array(g["tlen"], dtype=np.int32), 5000)
+    assert list(map(int, counters)) == [g["total"], g["aligned"], g["duplicate"]]
+    assert {str(i): int(hist[i]) for i in np.nonzero(hist)[0]} == g["hist_nonzero"] and total == 1
+
+
+# ---- trim -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("min_baseq", [0, 2, 20, 30, 41, 255])
+def test_trim_cfg2_classes(ctx, oracle, min_baseq):
+    """cfg 2 shape (150 bp, forced classes) at every threshold of SURVEY.md §8(d)."""
+    _, qual = synth.make_reads(20000, 150, seed=2)
+    qual = synth.add_forced_classes(qual, seed=2)
+    got = ctx.trim_by_quality(qual, None, min_baseq)
+    assert np.array_equal(got, oracle.trim_batch(qual, None, min_baseq))
+
+
+@pytest.mark.parametrize("stride,n", [(1, 70), (3, 129), (37, 1000), (150, 4097), (151, 333), (250, 2000), (960, 130), (1000, 70), (2100, 65)])
+def test_trim_ragged_random_bytes(ctx, oracle, stride, n):
+    """Any stride (LDS tile path up to 960, row-per-thread path above), ragged lengths incl. 0 and 1, arbitrary bytes."""
+    rng = np.random.default_rng(stride * 1000 + n)
+    qual = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+    ln = synth.ragged_lengths(n, stride, seed=stride)
+    for m in (0, 7, 20, 200, 255):
+        got = ctx.trim_by_quality(qual, ln, m)
+        assert np.array_equal(got, oracle.trim_batch(qual, ln, m)), (stride, n, m)
+    got = ctx.trim_by_quality(qual, None, 20)
+    assert np.array_equal(got, oracle.trim_batch(qual, None, 20))
+
+
+def test_trim_low_entropy_ties(ctx, oracle):
+    """Many exact ties and zero increments: the rightmost-minimum rule and the early break."""
+    rng = np.random.default_rng(5)
+    qual = (rng.integers(0, 3, size=(5000, 150)) * 1 + 33 + 19).astype(np.uint8)     # Q19..Q21 around the threshold
+    assert np.array_equal(ctx.trim_by_quality(qual, None, 20), oracle.trim_batch(qual, None, 20))
+    qual[:] = 33 + 20
+    assert np.array_equal(ctx.trim_by_quality(qual, None, 20), oracle.trim_batch(qual, None, 20))
+
+
+def test_trim_empty_batch(ctx):
+    assert ctx.trim_by_quality(np.zeros((0, 150), dtype=np.uint8), None, 20).shape == (0,)
+
+
+# ---- mask -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("min_baseq", [0, 1, 20, 95, 96, 222, 223, 224, 255])
+def test_mask_all_threshold_modes(ctx, oracle, min_baseq):
+    """Every packed-compare mode (none / [33,33+m) / q>=33 / wrapped interval), every byte value."""
+    rng = np.random.default_rng(min_baseq)
+    n, stride = 3000, 150
+    seq = synth.BASES[rng.integers(0, 4, size=(n, stride))]
+    qual = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+    qual[0, :] = np.arange(150, dtype=np.uint8)
+    qual[1, :106] = np.arange(150, 256, dtype=np.uint8)
+    got = ctx.mask_by_quality(seq, qual, None, min_baseq)
+    assert np.array_equal(got, oracle.mask_batch(seq, qual, None, min_baseq))
+
+
+@pytest.mark.parametrize("n,stride", [(1, 1), (1, 15), (3, 17), (64, 150), (65, 150), (1000, 33), (10000, 150), (70, 1000)])
+def test_mask_cfg1_shapes(ctx, oracle, n, stride):
+    """cfg 1 (10 k x 150 bp, min_baseq 20) and odd sizes whose byte count is not a multiple of 16."""
+    seq, qual = synth.make_reads(n, stride, seed=1)
+    got = ctx.mask_by_quality(seq, qual, None, 20)
+    assert np.array_equal(got, oracle.mask_batch(seq, qual, None, 20))
+
+
+# ---- demultiplex -------------------------------------------------------------------------------------------
+def check_demux(ctx, oracle, table, bc, max_diff=1):
+    ctx.set_barcodes(table, max_diff)
+    assign, low, first, last = ctx.demux_assign(bc)
+    e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, max_diff)
+    assert np.array_equal(assign, e_assign)
+    assert np.array_equal(low, e_low)
+    assert np.array_equal(first, e_first)
+    assert np.array_equal(last, e_last)
+    assert np.array_equal(ctx.counts(), e_counts)
+    return e_counts
+
+
+def test_demux_cfg3_single_index(ctx, oracle):
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    bc, _ = synth.observe_barcodes(table, 200000, seed=3)
+    counts = check_demux(ctx, oracle, table, bc)
+    S = 16
+    assert counts[:S].sum() == counts[S + 1] and counts[S] == 200000
+
+
+def test_demux_cfg4_dual_index(ctx, oracle):
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    assert table.shape == (96, 17)
+    bc, _ = synth.observe_barcodes(table, 100001, seed=4, halves=2)
+    counts = check_demux(ctx, oracle, table, bc)
+    assert counts[:96].sum() == counts[97]
+
+
+def test_demux_ambiguity_wildcards_and_umi_columns(ctx, oracle):
+    """cfg 3 parity sheet: two barcodes at distance 2 (forces ambiguity), an N column, a UUUU block, duplicates."""
+    table = np.array([list(b"ACGTACGTAAAA"), list(b"ACGTACGAAAAT"), list(b"TTNTTTTTUUUU"), list(b"GGGGGGGGUUUU"),
+                      list(b"CCCCCCCCCCCC"), list(b"CCCCCCCCCCCC")], dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    src = table[rng.integers(0, 6, size=50000)].copy()
+    alphabet = np.frombuffer(b"ACGTNU+acgt", dtype=np.uint8)
+    for _ in range(2):
+        hit = rng.random(src.shape[0]) < 0.5
+        pos = rng.integers(0, 12, size=src.shape[0])
+        src[hit, pos[hit]] = alphabet[rng.integers(0, alphabet.size, size=int(hit.sum()))]
+    counts = check_demux(ctx, oracle, table, src)
+    assert counts[6 + 2] > 0          # ambiguity did occur
+
+
+@pytest.mark.parametrize("max_diff", [0, 2, 17])
+def test_demux_other_max_diff(ctx, oracle, max_diff):
+    table = synth.make_sheet(16, 8, dual=False, seed=11)
+    bc = synth.BASES[np.random.default_rng(11).integers(0, 4, size=(30000, 8))]
+    check_demux(ctx, oracle, table, bc, max_diff)
+
+
+def test_demux_byte_path_many_classes(ctx, oracle):
+    """More than 7 distinct sheet bytes at a position -> byte-for-byte matcher; also arbitrary bytes and a long barcode."""
+    rng = np.random.default_rng(12)
+    table = rng.integers(32, 127, size=(40, 9), dtype=np.uint8)
+    bc = table[rng.integers(0, 40, size=20000)].copy()
+    hit = rng.random(20000) < 0.6
+    bc[hit, rng.integers(0, 9, size=20000)[hit]] = rng.integers(0, 256, size=int(hit.sum()), dtype=np.uint8)
+    check_demux(ctx, oracle, table, bc)
+    table = synth.BASES[rng.integers(0, 4, size=(10, 40))]            # L = 40 > one-hot limit
+    bc = table[rng.integers(0, 10, size=5000)].copy()
+    bc[:, 5] = ord("A")
+    check_demux(ctx, oracle, table, bc)
+
+
+def test_demux_strided_rows_and_tail(ctx, oracle):
+    """bc_stride > L (padded rows) and a row count that is not a multiple of the 64-row tile."""
+    table = synth.make_sheet(16, 8, dual=False, seed=13)
+    bc8, _ = synth.observe_barcodes(table, 777, seed=13)
+    bc = np.full((777, 12), ord("#"), dtype=np.uint8)
+    bc[:, :8] = bc8
+    ctx.set_barcodes(table, 1)
+    assign, low, first, last = ctx.demux_assign(bc)
+    e = oracle.demux_batch(table, bc8, 1)
+    assert np.array_equal(assign, e[0]) and np.array_equal(low, e[1]) and np.array_equal(first, e[2]) and np.array_equal(last, e[3])
+
+
+def test_demux_single_sample_and_empty_sheet(ctx, oracle):
+    table = np.array([list(b"ACGTACGT")], dtype=np.uint8)
+    bc = synth.BASES[np.random.default_rng(14).integers(0, 4, size=(1000, 8))]
+    bc[:10] = table[0]
+    check_demux(ctx, oracle, table, bc)
+    empty = np.zeros((0, 8), dtype=np.uint8)
+    ctx.set_barcodes(empty, 1)
+    assign, low, first, last = ctx.demux_assign(bc)
+    e = oracle.demux_batch(empty, bc, 1)
+    assert np.array_equal(assign, e[0]) and (assign == -1).all() and np.array_equal(low, e[1])
+
+
+def test_counters_accumulate_and_reset(ctx, oracle):
+    table = synth.make_sheet(16, 8, dual=False, seed=15)
+    bc, _ = synth.observe_barcodes(table, 5000, seed=15)
+    ctx.set_barcodes(table, 1)
+    ctx.demux_assign(bc)
+    ctx.demux_assign(bc)
+    e = oracle.demux_batch(table, bc, 1)[4]
+    assert np.array_equal(ctx.counts(), 2 * e)
+    ctx.counts_reset()
+    assert ctx.counts().sum() == 0
+
+
+# ---- fused pass ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("paired", [False, True])
+def test_fused_pass_matches_the_three_commands(ctx, oracle, paired):
+    """cfg 4 shape: add barcode + demultiplex + trim + mask in one pass == the separate oracle steps."""
+    n, L = 30011, 150
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, n, seed=21, halves=2)
+    mates = []
+    for mi in range(2 if paired else 1):
+        seq, qual = synth.make_reads(n, L, seed=30 + mi)
+        qual = synth.add_forced_classes(qual, seed=40 + mi)
+        mates.append((seq, qual, None))
+    ctx.set_barcodes(table, 1)
+    r = ctx.fused_pass(mates, 20, bc=bc, want_detail=True)
+    e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, 1)
+    assert np.array_equal(r["assign"], e_assign) and np.array_equal(r["lowest_diff"], e_low)
+    assert np.array_equal(r["first_idx"], e_first) and np.array_equal(r["last_idx"], e_last)
+    assert np.array_equal(ctx.counts(), e_counts)
+    for mi, (seq, qual, _) in enumerate(mates):
+        assert np.array_equal(r["lowest_k"][mi], oracle.trim_batch(qual, None, 20))
+        assert np.array_equal(r["out_seq"][mi], oracle.mask_batch(seq, qual, None, 20))
+
+
+def test_fused_pass_ragged(ctx, oracle):
+    n, L = 5003, 101
+    seq, qual = synth.make_reads(n, L, seed=50)
+    ln = synth.ragged_lengths(n, L, seed=50)
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    bc, _ = synth.observe_barcodes(table, n, seed=51)
+    ctx.set_barcodes(table, 1)
+    r = ctx.fused_pass([(seq, qual, ln)], 25, bc=bc)
+    assert np.array_equal(r["assign"], oracle.demux_batch(table, bc, 1)[0])
+    assert np.array_equal(r["lowest_k"][0], oracle.trim_batch(qual, ln, 25))
+    exp = oracle.mask_batch(seq, qual, ln, 25)
+    for i in range(n):          # bytes past len[r] are unspecified on output
+        assert np.array_equal(r["out_seq"][0][i, :ln[i]], exp[i, :ln[i]])
+
+
+def test_fused_pass_multichunk_host_staging(ctx, oracle):
+    """More rows than one staging chunk of the host entry point (192 MiB of workspace per chunk)."""
+    n, L = 700000, 150
+    rng = np.random.default_rng(60)
+    qual = rng.integers(33, 75, size=(n, L), dtype=np.uint8)
+    seq = synth.BASES[rng.integers(0, 4, size=(n, L))]
+    r = ctx.fused_pass([(seq, qual, None)], 20)
+    assert np.array_equal(r["lowest_k"][0], oracle.trim_batch(qual, None, 20))
+    assert np.array_equal(r["out_seq"][0], oracle.mask_batch(seq, qual, None, 20))
+
+
+# ---- BAM ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,max_frag", [(1, 5000), (1000, 5000), (300001, 5000), (50000, 100), (50000, 0), (20000, 20000)])
+def test_bam_flag_tlen(ctx, oracle, n, max_frag):
+    flag, tid, mtid, tlen = synth.make_bam_cores(n, seed=5)
+    if n > 10:
+        tlen[3] = -2147483648
+        tlen[4] = 2147483647
+        flag[3] = flag[4] = 0x1 | 0x40
+        mtid[3], mtid[4] = tid[3], tid[4]
+    c, h, t = ctx.bam_flag_tlen(flag, tid, mtid, tlen, max_frag)
+    ec, eh, et = oracle.bam_flag_tlen(flag, tid, mtid, tlen, max_frag)
+    assert np.array_equal(c, ec) and np.array_equal(h, eh) and t == et
+    assert int(h.sum()) == t
+
+
+# ---- error behaviour of the boundary ---------------------------------------------------------------------------
+def test_errors_are_codes_not_crashes(ctx):
+    import seqkit_amd
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        ctx.set_barcodes(np.zeros((2, 300), dtype=np.uint8))          # L > 255
+    ctx.set_barcodes(np.array([list(b"ACGTACGT")], dtype=np.uint8))
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        ctx.demux_assign(np.zeros((4, 5), dtype=np.uint8))            # bc_stride < L
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        seqkit_amd.Context(4096)                                      # no such device
