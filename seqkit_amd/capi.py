@@ -45,19 +45,19 @@ class _FusedArgs(C.Structure):
                 ("counts", C.c_void_p)]
 
 
-_lib = None
+_libs: dict = {}
 
 
 def library_path() -> str:
     return _build.LIB_PATH
 
 
-def load_library() -> C.CDLL:
-    """dlopen libseqkit_hip.so (no GPU needed for this step) and declare the prototypes."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libseqkit_hip.so (no GPU needed for this step) and declare the prototypes.
+    `path` selects another build of the same C-ABI (A/B timing of kernel variants in one process)."""
+    path = path or library_path()
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise SeqkitHipError(
             f"{path} is missing: build it with `python -m seqkit_amd.build` (hipcc --offload-arch=gfx950). "
@@ -89,7 +89,7 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -114,8 +114,8 @@ def _vec(a, dtype, n: int, name: str) -> np.ndarray:
 class Context:
     """One sk_ctx: one GPU, one stream.  Mirrors the C-ABI call for call."""
 
-    def __init__(self, device: int = 0):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
         h = C.c_void_p()
         rc = self._lib.sk_create(device, C.byref(h))
         if rc != 0:

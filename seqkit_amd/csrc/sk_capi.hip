@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,8 @@ struct sk_ctx {
 	uint8_t *d_raw = nullptr;
 	uint32_t *d_onehot = nullptr;
 	uint8_t *d_lut = nullptr;
+	uint8_t *d_bs = nullptr;
+	int bs_bytes = 0, bs_mm_off = 0, G = 0;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
@@ -113,6 +116,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_raw) (void)hipFree(c->d_raw);
 	if (c->d_onehot) (void)hipFree(c->d_onehot);
 	if (c->d_lut) (void)hipFree(c->d_lut);
+	if (c->d_bs) (void)hipFree(c->d_bs);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -193,6 +197,8 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	if (c->d_raw) { SK_HIP(c, hipFree(c->d_raw)); c->d_raw = nullptr; }
 	if (c->d_onehot) { SK_HIP(c, hipFree(c->d_onehot)); c->d_onehot = nullptr; }
 	if (c->d_lut) { SK_HIP(c, hipFree(c->d_lut)); c->d_lut = nullptr; }
+	if (c->d_bs) { SK_HIP(c, hipFree(c->d_bs)); c->d_bs = nullptr; }
+	c->bs_bytes = c->bs_mm_off = c->G = 0;
 	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
 	c->have_table = false;
 	c->S = S; c->L = L; c->max_diff = max_diff;
@@ -202,7 +208,7 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	if (S > 0) SK_HIP(c, hipMemcpy(c->d_raw, table, (size_t)S * L, hipMemcpyHostToDevice));
 
 	// one-hot re-coding: possible when every position uses <= 7 distinct non-wildcard bytes
-	bool onehot_ok = S > 0 && L <= sk::kMaxOneHotLen;
+	bool onehot_ok = S > 0 && L <= sk::kMaxOneHotLen && !getenv("SK_NO_ONEHOT");
 	std::vector<uint8_t> lut((size_t)(L ? L : 1) * 256, 0x80);
 	std::vector<uint32_t> codes((size_t)(S ? S : 1) * (c->W ? c->W : 1), 0u);
 	for (int k = 0; k < L && onehot_ok; k++) {
@@ -228,6 +234,40 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 		SK_HIP(c, hipMalloc((void **)&c->d_onehot, codes.size() * 4 + 64));
 		SK_HIP(c, hipMemcpy(c->d_onehot, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
 	}
+	// bit-sliced matcher: possible when the whole sheet uses <= 7 distinct non-wildcard bytes and L <= 31
+	{
+		int cls[256];
+		for (int b = 0; b < 256; b++) cls[b] = -1;
+		int ncls = 0;
+		bool ok = S > 0 && L <= sk::kMaxBitSlicedLen && !getenv("SK_NO_BITSLICE");
+		for (int s = 0; s < S && ok; s++)
+			for (int k = 0; k < L; k++) {
+				uint8_t b = table[(size_t)s * L + k];
+				if (b == 'N' || b == 'U') continue;
+				if (cls[b] < 0) { if (ncls == 7) { ok = false; break; } cls[b] = ncls++; }
+			}
+		const int G = (S + 31) / 32;
+		const int mm_off = 256 + ((G * 4 + 15) & ~15);
+		const size_t bytes = (size_t)mm_off + (size_t)L * 8 * G * 4;
+		if (ok && bytes <= (size_t)sk::kMaxBitSlicedBytes) {
+			std::vector<uint8_t> blob(bytes, 0);
+			for (int b = 0; b < 256; b++) blob[b] = (uint8_t)(cls[b] >= 0 ? cls[b] : 7);
+			uint32_t *valid = (uint32_t *)(blob.data() + 256);
+			uint32_t *mm = (uint32_t *)(blob.data() + mm_off);
+			for (int s = 0; s < S; s++) {
+				valid[s >> 5] |= 1u << (s & 31);
+				for (int k = 0; k < L; k++) {
+					uint8_t b = table[(size_t)s * L + k];
+					if (b == 'N' || b == 'U') continue;                  // wildcard: never a mismatch
+					for (int cc = 0; cc < 8; cc++)
+						if (cc != cls[b]) mm[((size_t)k * 8 + cc) * G + (s >> 5)] |= 1u << (s & 31);
+				}
+			}
+			SK_HIP(c, hipMalloc((void **)&c->d_bs, bytes));
+			SK_HIP(c, hipMemcpy(c->d_bs, blob.data(), bytes, hipMemcpyHostToDevice));
+			c->bs_bytes = (int)bytes; c->bs_mm_off = mm_off; c->G = G;
+		}
+	}
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx stream is non-blocking: make the uploads visible to it
@@ -239,6 +279,7 @@ static sk::BarcodeDev table_of(const sk_ctx *c)
 {
 	sk::BarcodeDev t;
 	t.raw = c->d_raw; t.onehot = c->d_onehot; t.lut = c->d_lut;
+	t.bs = c->d_bs; t.bs_bytes = c->bs_bytes; t.bs_mm_off = c->bs_mm_off; t.G = c->G;
 	t.S = c->S; t.L = c->L; t.W = c->W; t.max_diff = c->max_diff;
 	return t;
 }

@@ -36,8 +36,18 @@ struct BarcodeDev {
 	const uint8_t *raw;        // S x L sheet bytes
 	const uint32_t *onehot;    // S x W candidate codes (one-hot class bit, 0x80 wildcard), or nullptr
 	const uint8_t *lut;        // L x 256 observed byte -> (class bit | 0x80), or nullptr
+	// bit-sliced matcher tables (one blob, copied to LDS by every workgroup), or nullptr:
+	//   [0,256)            byte -> class id 0..6 (a byte the sheet uses) or 7 (any other byte)
+	//   [256, 256+4G)      valid-candidate mask, G = ceil(S/32) dwords (padded to 16 bytes)
+	//   [mm_off, ...)      MM[k][class][g]: bit s%32 of dword g=s/32 set <=> candidate s counts a mismatch at
+	//                      position k when the observed byte has that class
+	const uint8_t *bs;
+	int bs_bytes, bs_mm_off, G;
 	int S, L, W, max_diff;
 };
+
+constexpr int kMaxBitSlicedLen = 31;     // 5 counter planes
+constexpr int kMaxBitSlicedBytes = 24 * 1024;
 
 struct TileArgs {
 	int64_t n;

@@ -17,10 +17,14 @@
 // Reference semantics restated per function: see the citations (paths relative to the reference tree).
 #include "sk_internal.h"
 
+#include <cstdlib>
+
 namespace sk {
 
 typedef uint32_t u32;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;   // AMDGPU constant address space
 
 constexpr u32 kLo7 = 0x7f7f7f7fu;
 constexpr u32 kHi1 = 0x80808080u;
@@ -33,11 +37,12 @@ QualConsts make_qual_consts(int m)
 	if (m == 0) { q.mode = 0; return q; }
 	int t2;
 	if (33 + m <= 255) { q.mode = 1; t2 = 33 + m; }          // mask iff 33 <= q < 33+m
-	else if (33 + m == 256) { q.mode = 2; t2 = 1; }           // mask iff q >= 33
-	else { q.mode = 3; t2 = 33 + m - 256; }                   // mask iff q >= 33 or q < t2 (wrapped interval)
+	else if (33 + m == 256) { q.mode = 3; t2 = 1; }           // mask iff q >= 33
+	else { q.mode = 4; t2 = 33 + m - 256; }                   // mask iff q >= 33 or q < t2 (wrapped interval)
 	int c2 = 256 - t2;
 	q.cl2 = (u32)(c2 & 0x7f) * 0x01010101u;
 	q.c72 = (c2 & 0x80) ? kHi1 : 0u;
+	if (q.mode == 1 && !(c2 & 0x80)) q.mode = 2;              // bit 7 of the addend decides or / and in the carry
 	return q;
 }
 
@@ -50,16 +55,17 @@ QualConsts make_qual_consts(int m)
 //   g2                             bit 7 = [q >= t2]   (carry of q + (256 - t2), generic majority form)
 // mask flag F (bit 7 of each byte) = [(q-33) mod 256 < min_baseq]   src/fasta_mask_by_quality.rs:42
 // ---------------------------------------------------------------------------------------------------
+// MODE: 0 never masks (min_baseq 0) | 1 g1 & ~g2, c72 set | 2 g1 & ~g2, c72 clear | 3 g1 | 4 g1 | ~g2 (c72 set)
 template <int MODE>
-__device__ __forceinline__ u32 lowq_flags(u32 q, u32 ql, u32 t1, u32 cl2, u32 c72)
+__device__ __forceinline__ u32 lowq_flags(u32 q, u32 ql, u32 t1, u32 cl2)
 {
 	if (MODE == 0) return 0u;
 	u32 g1 = q | t1;
-	if (MODE == 2) return g1;
+	if (MODE == 3) return g1;
 	u32 t2 = ql + cl2;
-	u32 g2 = (q & c72) | ((q | c72) & t2);
-	if (MODE == 1) return g1 & ~g2;
-	return g1 | ~g2;
+	u32 g2 = (MODE == 2) ? (q & t2) : (q | t2);
+	if (MODE == 4) return g1 | ~g2;
+	return g1 & ~g2;
 }
 
 // out byte i = flagged ? 'N' : s byte i, via one v_perm_b32: selector i picks s, 4+i picks 'N'.
@@ -72,24 +78,14 @@ __device__ __forceinline__ u32 mask_select(u32 s, u32 F)
 __device__ __forceinline__ u32 sub33(u32 q, u32 t1) { return t1 ^ (~q & kHi1); }
 
 template <int MODE>
-__device__ __forceinline__ void mask_dword4(const u32x4 &q, const u32x4 &s, u32 cl2, u32 c72, u32x4 &out, u32x4 &vq)
+__device__ __forceinline__ void mask_dword4(const u32x4 &q, const u32x4 &s, u32 cl2, u32x4 &out, u32x4 &vq)
 {
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		u32 ql = q[i] & kLo7;
 		u32 t1 = ql + 0x5f5f5f5fu;
 		vq[i] = sub33(q[i], t1);
-		out[i] = mask_select(s[i], lowq_flags<MODE>(q[i], ql, t1, cl2, c72));
-	}
-}
-
-__device__ __forceinline__ void mask_dword4_rt(int mode, const u32x4 &q, const u32x4 &s, u32 cl2, u32 c72, u32x4 &out, u32x4 &vq)
-{
-	switch (mode) {   // wave-uniform
-	case 0: mask_dword4<0>(q, s, cl2, c72, out, vq); break;
-	case 1: mask_dword4<1>(q, s, cl2, c72, out, vq); break;
-	case 2: mask_dword4<2>(q, s, cl2, c72, out, vq); break;
-	default: mask_dword4<3>(q, s, cl2, c72, out, vq); break;
+		out[i] = mask_select(s[i], lowq_flags<MODE>(q[i], ql, t1, cl2));
 	}
 }
 
@@ -110,7 +106,7 @@ __device__ __forceinline__ void store_tail(uint8_t *p, const u32x4 &v, int valid
 // ---------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void mask_flat_kernel(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                                                        uint8_t *__restrict__ out, int64_t bytes, u32 cl2, u32 c72)
+                                                        uint8_t *__restrict__ out, int64_t bytes, u32 cl2)
 {
 	const int64_t nchunk = (bytes + 15) >> 4;
 	const int64_t step = (int64_t)gridDim.x * blockDim.x;
@@ -120,13 +116,13 @@ __global__ __launch_bounds__(256) void mask_flat_kernel(const uint8_t *__restric
 		if (off + 16 <= bytes) {
 			q = *reinterpret_cast<const u32x4 *>(qual + off);
 			s = *reinterpret_cast<const u32x4 *>(seq + off);
-			mask_dword4<MODE>(q, s, cl2, c72, o, vq);
+			mask_dword4<MODE>(q, s, cl2, o, vq);
 			*reinterpret_cast<u32x4 *>(out + off) = o;
 		} else {
 			int valid = (int)(bytes - off);
 			q = load_tail(qual + off, valid);
 			s = load_tail(seq + off, valid);
-			mask_dword4<MODE>(q, s, cl2, c72, o, vq);
+			mask_dword4<MODE>(q, s, cl2, o, vq);
 			store_tail(out + off, o, valid);
 		}
 	}
@@ -140,10 +136,11 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 	int64_t want = (nchunk + 255) / 256;
 	int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
 	switch (qc.mode) {
-	case 0: mask_flat_kernel<0><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2, qc.c72); break;
-	case 1: mask_flat_kernel<1><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2, qc.c72); break;
-	case 2: mask_flat_kernel<2><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2, qc.c72); break;
-	default: mask_flat_kernel<3><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2, qc.c72); break;
+	case 0: mask_flat_kernel<0><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
+	case 1: mask_flat_kernel<1><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
+	case 2: mask_flat_kernel<2><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
+	case 3: mask_flat_kernel<3><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
+	default: mask_flat_kernel<4><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
 	}
 	return hipGetLastError();
 }
@@ -160,13 +157,17 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 // Packing K_j = U_j*2^11 + j turns "strictly smaller U, earliest j" into one signed min; K_0 = 0 is the
 // initial state (lowest_total = -50, lowest_k = n).  |U| <= 255*2047 keeps K inside int32.
 // ---------------------------------------------------------------------------------------------------
+// The four running sums inside a dword come from v_dot4_u32_u8 with byte-select multipliers, so they are
+// independent of each other (no 4-deep add chain) and cost one VALU op per byte.
+template <bool UNIFORM_LEN>
 __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
 	int a = end & ~3;
 	u32 hi = *reinterpret_cast<const u32 *>(tile + a);
-	int T = 0, best = 0;
+	u32 T = 0;
+	int best = 0;
 	bool alive = active;
 	const int ndw = (maxlen + 3) >> 2;
 	for (int jj = 0; jj < ndw; jj++) {
@@ -174,13 +175,21 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 		u32 lo = *reinterpret_cast<const u32 *>(tile + a);
 		u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);       // bytes [end-4(jj+1), end-4jj) of the image
 		hi = lo;
+		u32 Ts[4];
+		Ts[0] = __builtin_amdgcn_udot4(d, 0x01000000u, T, false);
+		Ts[1] = __builtin_amdgcn_udot4(d, 0x01010000u, T, false);
+		Ts[2] = __builtin_amdgcn_udot4(d, 0x01010100u, T, false);
+		Ts[3] = __builtin_amdgcn_udot4(d, 0x01010101u, T, false);
+		T = Ts[3];
 #pragma unroll
-		for (int i = 3; i >= 0; i--) {
-			const int j = 4 * jj + (4 - i);                   // bytes consumed so far, wave-uniform
+		for (int i = 0; i < 4; i++) {
+			const int j = 4 * jj + i + 1;                     // bytes consumed so far, wave-uniform
 			const int jm = j * m;                             // scalar
-			T += (int)((d >> (8 * i)) & 0xffu);
-			alive = alive && (j <= len) && (T <= 50 + jm);
-			int K = T * (1 << kKeyBits) + (j - jm * (1 << kKeyBits));
+			bool ok = (int)Ts[i] <= 50 + jm;
+			if (!UNIFORM_LEN) ok = ok && (j <= len);
+			else ok = ok && (j <= maxlen);                    // scalar condition: only the last dword can fail it
+			alive = alive && ok;
+			int K = (int)Ts[i] * (1 << kKeyBits) + (j - jm * (1 << kKeyBits));
 			best = alive ? min(best, K) : best;
 		}
 		if (__ballot(alive) == 0ull) break;
@@ -229,13 +238,16 @@ __device__ __forceinline__ int trim_scan_wide(const uint8_t *tile, int row_start
 // Then popcount(obs_code & cand_code) == 1 exactly when the position does NOT count as a mismatch
 // (equal bytes, or wildcard), so mismatches = L - popcount over the W code dwords.
 // first argmin = max over s of (matches<<16 | 0xffff-s); last argmin = max of (matches<<16 | s).
+// The candidate codes sit in the workgroup's LDS (one copy for its 8 waves, rows padded to WP dwords so
+// the wave-uniform reads are aligned ds_read_b128/b64 broadcasts).
 // ---------------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void match_onehot(const u32 *__restrict__ cand, int S, const u32 (&o)[W], u32 &keyF, u32 &keyL)
+template <int W, int WP>
+__device__ __forceinline__ void match_onehot(const u32 *cand_lds, int S, const u32 (&o)[W], u32 &keyF, u32 &keyL)
 {
 	keyF = 0u; keyL = 0u;
+#pragma unroll 4
 	for (int s = 0; s < S; s++) {
-		const u32 *c = cand + (size_t)s * W;       // wave-uniform address: scalar loads
+		const u32 *c = cand_lds + s * WP;
 		u32 pc = 0;
 #pragma unroll
 		for (int w = 0; w < W; w++) pc += (u32)__builtin_popcount(o[w] & c[w]);
@@ -244,8 +256,10 @@ __device__ __forceinline__ void match_onehot(const u32 *__restrict__ cand, int S
 	}
 }
 
+__host__ __device__ constexpr int padded_w(int w) { return w <= 1 ? 1 : w <= 2 ? 2 : w <= 4 ? 4 : 8; }
+
 template <int W>
-__device__ __forceinline__ void demux_row_onehot(const uint8_t *tile, int row_start, const BarcodeDev &t,
+__device__ __forceinline__ void demux_row_onehot(const uint8_t *tile, int row_start, const BarcodeDev &t, const u32 *cand_lds,
                                                  int &diff, int &first, int &last)
 {
 	// raw observed bytes: W dwords starting at a misaligned LDS address
@@ -267,19 +281,73 @@ __device__ __forceinline__ void demux_row_onehot(const uint8_t *tile, int row_st
 		o[w] = code;
 	}
 	u32 keyF, keyL;
-	match_onehot<W>(t.onehot, t.S, o, keyF, keyL);
+	match_onehot<W, padded_w(W)>(cand_lds, t.S, o, keyF, keyL);
 	diff = t.L - (int)(keyF >> 16);
 	first = (int)(0xffffu - (keyF & 0xffffu));
 	last = (int)(keyL & 0xffffu);
 }
 
-// byte-for-byte form: any sheet alphabet, any length
-__device__ __forceinline__ void demux_row_bytes(const uint8_t *tile, int row_start, const BarcodeDev &t,
+// ---------------------------------------------------------------------------------------------------
+// Bit-sliced form of D1+D2 (the fast path).  Instead of walking the S candidates per read, walk the L
+// positions: MM[k][class of the observed byte at k] is an S-bit vector with bit s set when candidate s
+// counts a mismatch there (its byte is not a wildcard and differs).  The per-candidate mismatch counts
+// are then the column sums of L such vectors, kept as 5 bit planes per 32 candidates and accumulated
+// three positions at a time with carry-save adders (v_xor / v_bfi / v_and).  The minimum and its first /
+// last candidate come out of the planes MSB-first: keep the candidates whose plane bit is 0 when any
+// such candidate survives.  ~13 VALU ops per 3 positions per 32 candidates instead of ~14 per candidate.
+// ---------------------------------------------------------------------------------------------------
+#define SK_MAJ(a, b, c) ((((a) ^ (b)) & (c)) | (~((a) ^ (b)) & (a)))      /* -> v_xor + v_bfi */
+
+template <int GB>
+__device__ __forceinline__ void demux_row_bitsliced(const uint8_t *row, const uint8_t *bs, int mm_off, int G, int g0, int L,
+                                                    int &best, int &first, int &last)
+{
+	const uint8_t *cls = bs;
+	const u32 *valid = reinterpret_cast<const u32 *>(bs + 256);
+	const u32 *mm = reinterpret_cast<const u32 *>(bs + mm_off);
+	u32 P0[GB], P1[GB], P2[GB], P3[GB], P4[GB];
+#pragma unroll
+	for (int g = 0; g < GB; g++) P0[g] = P1[g] = P2[g] = P3[g] = P4[g] = 0u;
+	for (int k = 0; k < L; k += 3) {
+		const u32 *r0 = mm + ((k * 8 + (int)cls[row[k]]) * G + g0);
+		const bool h1 = k + 1 < L, h2 = k + 2 < L;                       // wave-uniform
+		const u32 *r1 = mm + (((k + 1) * 8 + (int)cls[row[h1 ? k + 1 : k]]) * G + g0);
+		const u32 *r2 = mm + (((k + 2) * 8 + (int)cls[row[h2 ? k + 2 : k]]) * G + g0);
+#pragma unroll
+		for (int g = 0; g < GB; g++) {
+			const u32 x0 = r0[g], x1 = h1 ? r1[g] : 0u, x2 = h2 ? r2[g] : 0u;
+			const u32 sm = x0 ^ x1 ^ x2, cr = SK_MAJ(x0, x1, x2);          // weights 1 and 2
+			const u32 c0 = P0[g] & sm;  P0[g] ^= sm;
+			const u32 c1 = SK_MAJ(P1[g], c0, cr);  P1[g] ^= c0 ^ cr;
+			const u32 c2 = P2[g] & c1;  P2[g] ^= c1;
+			const u32 c3 = P3[g] & c2;  P3[g] ^= c2;
+			P4[g] ^= c3;
+		}
+	}
+#pragma unroll
+	for (int g = 0; g < GB; g++) {
+		u32 cand = valid[g0 + g];
+		int d = 0;
+		u32 t;
+		t = cand & ~P4[g]; d = 2 * d + (t ? 0 : 1); cand = t ? t : cand;
+		t = cand & ~P3[g]; d = 2 * d + (t ? 0 : 1); cand = t ? t : cand;
+		t = cand & ~P2[g]; d = 2 * d + (t ? 0 : 1); cand = t ? t : cand;
+		t = cand & ~P1[g]; d = 2 * d + (t ? 0 : 1); cand = t ? t : cand;
+		t = cand & ~P0[g]; d = 2 * d + (t ? 0 : 1); cand = t ? t : cand;
+		const int f = (g0 + g) * 32 + __builtin_ctz(cand);
+		const int l = (g0 + g) * 32 + 31 - __builtin_clz(cand);
+		if (d < best) { best = d; first = f; last = l; }
+		else if (d == best) last = l;
+	}
+}
+
+// byte-for-byte form: any sheet alphabet, any length; sheet bytes come from the LDS copy
+__device__ __forceinline__ void demux_row_bytes(const uint8_t *tile, int row_start, const BarcodeDev &t, const uint8_t *raw_lds,
                                                 int &diff, int &first, int &last)
 {
 	int lowest = 0x7fffffff; first = 0; last = 0;
 	for (int s = 0; s < t.S; s++) {
-		const uint8_t *c = t.raw + (size_t)s * t.L;
+		const uint8_t *c = raw_lds + s * t.L;
 		int d = 0;
 		for (int k = 0; k < t.L; k++) {
 			uint8_t cb = c[k];
@@ -293,151 +361,303 @@ __device__ __forceinline__ void demux_row_bytes(const uint8_t *tile, int row_sta
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The tile pass: one wavefront per 64-row tile, persistent over tiles.
+// The tile pass: one wavefront per 64-row tile, persistent over tiles; a workgroup is NW wavefronts that
+// share nothing but the read-only matcher tables and the per-sample histogram in LDS.
 // ---------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint8_t sk_smem[];
 
+// Hand-off between the lanes of ONE wave through its private LDS tile.  DS operations of a wave are
+// executed in issue order, so no s_barrier is needed (and none is wanted: the waves of a workgroup must
+// drift apart so that their stream / scan / match phases overlap); the fence only pins compiler order.
 __device__ __forceinline__ void wave_lds_fence()
 {
-	// single-wave workgroup: LDS operations of one wave complete in order; this keeps the compiler from
-	// moving LDS reads above the LDS writes of other lanes and waits for the writes to land.
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct LdsPlan {
+	int table_bytes;     // matcher tables (bit-sliced blob, one-hot codes or raw sheet bytes), rounded to 16
+	int hist_off;        // u32[S+3]
+	int tiles_off;       // first wave's tile slot (includes the front pad)
+	int tile_slot;       // bytes per wave: front pad + 64*row_bytes rounded to 16 + back pad
+	int use_lds_hist;
+};
+
+// copy the matcher tables into the workgroup's LDS and clear its histogram (all threads; ends with a barrier)
+__device__ __forceinline__ void stage_tables(const BarcodeDev &t, const LdsPlan &lp, u32 *hist)
+{
+	if (t.bs != nullptr) {
+		const u32 *src = reinterpret_cast<const u32 *>(t.bs);
+		u32 *dst = reinterpret_cast<u32 *>(sk_smem);
+		for (int i = threadIdx.x; i < (t.bs_bytes >> 2); i += blockDim.x) dst[i] = src[i];
+	} else if (t.onehot != nullptr) {
+		const int wp = padded_w(t.W);
+		u32 *dst = reinterpret_cast<u32 *>(sk_smem);
+		for (int i = threadIdx.x; i < t.S * wp; i += blockDim.x) {
+			const int s = i / wp, w = i - s * wp;
+			dst[i] = (w < t.W) ? t.onehot[s * t.W + w] : 0u;
+		}
+	} else {
+		for (int i = threadIdx.x; i < t.S * t.L; i += blockDim.x) sk_smem[i] = t.raw[i];
+	}
+	if (lp.use_lds_hist)
+		for (int i = threadIdx.x; i < t.S + 3; i += blockDim.x) hist[i] = 0u;
 	__syncthreads();
 }
 
-__global__ __launch_bounds__(64) void tile_pass_kernel(const TileArgs a, int hist_off, int use_lds_hist)
-{
-	const int lane = threadIdx.x;
-	uint8_t *tile = sk_smem + kLdsPad;
-	u32 *hist = reinterpret_cast<u32 *>(sk_smem + hist_off);
-	const int S = a.table.S;
-	const bool do_demux = a.bc != nullptr;
+// D3 (src/fasta_demultiplex.rs:168-194) + outputs + counters for one lane's read
+struct WaveCounts { u32 total, ident, ambig; };
 
-	if (do_demux && use_lds_hist) {
-		for (int i = lane; i < S; i += kWave) hist[i] = 0u;
+__device__ __forceinline__ void demux_commit(const TileArgs &a, const LdsPlan &lp, u32 *hist, int64_t r, bool active,
+                                             int diff, int first, int last, WaveCounts &wc)
+{
+	const int S = a.table.S;
+	int code = kAssignNone;
+	if (S > 0 && diff <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
+	if (active) {
+		a.assign[r] = code;
+		if (a.lowest_diff) a.lowest_diff[r] = (uint8_t)(diff > 255 ? 255 : diff);
+		if (a.first_idx) a.first_idx[r] = (int16_t)first;
+		if (a.last_idx) a.last_idx[r] = (int16_t)last;
+		if (code >= 0) {
+			if (lp.use_lds_hist) atomicAdd(&hist[code], 1u);
+			else atomicAdd(&a.counts[code], 1ull);
+		}
 	}
-	u32 n_total = 0, n_ident = 0, n_ambig = 0;      // wave-uniform
+	wc.total += (u32)__popcll(__ballot(active));
+	wc.ident += (u32)__popcll(__ballot(active && code >= 0));
+	wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+}
+
+__device__ __forceinline__ void flush_counts(const TileArgs &a, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc)
+{
+	const int S = a.table.S;
+	if (lp.use_lds_hist) {
+		if (lane == 0) {
+			if (wc.total) atomicAdd(&hist[S], wc.total);
+			if (wc.ident) atomicAdd(&hist[S + 1], wc.ident);
+			if (wc.ambig) atomicAdd(&hist[S + 2], wc.ambig);
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < S + 3; i += blockDim.x) {
+			u32 c = hist[i];
+			if (c) atomicAdd(&a.counts[i], (unsigned long long)c);
+		}
+	} else if (lane == 0) {
+		if (wc.total) atomicAdd(&a.counts[S], (unsigned long long)wc.total);
+		if (wc.ident) atomicAdd(&a.counts[S + 1], (unsigned long long)wc.ident);
+		if (wc.ambig) atomicAdd(&a.counts[S + 2], (unsigned long long)wc.ambig);
+	}
+}
+
+// One (tile, mate) item is streamed as 1 KiB chunks.  The loads of two chunks are always in flight per wave
+// (register slots R0/R1), INCLUDING across the scan and barcode phases: the last two issue slots of an item
+// already fetch the first two chunks of the wave's next item, so HBM requests keep flowing while the wave
+// does its LDS/VALU work.  Only loads run ahead; the LDS image is written when a chunk is consumed, so one
+// LDS tile per wave is enough.
+//   MODE  : packed-compare mode of the quality threshold (QualConsts::mode)
+//   DEMUX : the barcode phase is part of the pass, bit-sliced matcher with G <= 4 (S <= 128) and
+//           64*bc_stride <= 2048; every other demultiplex shape runs as demux_tile_kernel beside this one
+template <int MODE, bool DEMUX>
+__global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	const int nwave = blockDim.x >> 6;
+	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
+	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
+	if (DEMUX) stage_tables(a.table, lp, hist);
+	WaveCounts wc = {0u, 0u, 0u};
 
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int stride = a.stride;
 	const int64_t total_bytes = a.n * (int64_t)stride;
 	const int m = a.qc.min_baseq;
-	const u32 cl2 = a.qc.cl2, c72 = a.qc.c72;
-	const int mode = a.qc.mode;
+	const u32 cl2 = a.qc.cl2;
 
-	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+	// active mates (those with any output), as explicit scalars so that nothing is indexed at run time
+	int nam = 0;
+	MateDev am0 = a.mate[0], am1 = a.mate[1];
+	{
+		const bool act0 = a.n_mates > 0 && (a.mate[0].out_seq || a.mate[0].lowest_k);
+		const bool act1 = a.n_mates > 1 && (a.mate[1].out_seq || a.mate[1].lowest_k);
+		if (act0 && act1) nam = 2;
+		else if (act0) nam = 1;
+		else if (act1) { nam = 1; am0 = a.mate[1]; }
+	}
+	const int64_t tstep = (int64_t)gridDim.x * nwave;
+	const int64_t bc_total = DEMUX ? a.n * (int64_t)a.bc_stride : 0;
+	const int nchunk2 = (((kTileRows * stride + 1023) >> 10) + 1) & ~1;      // chunks per full tile, rounded up to even
+
+	// issue the loads of chunk c of item (t, k) into a register slot
+	auto issue = [&](int64_t t, int k, int c, u32x4 &q, u32x4 &sq) {
+		if (t >= ntiles) return;
+		const MateDev &mt = k ? am1 : am0;
+		const int64_t row0 = t * kTileRows;
+		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
+		const int off = c * (kWave * 16) + lane * 16;
+		if (off >= rows * stride) return;
+		const int64_t g = row0 * (int64_t)stride + off;
+		if (g + 16 <= total_bytes) {
+			q = *reinterpret_cast<const u32x4 *>(mt.qual + g);
+			if (mt.out_seq) sq = *reinterpret_cast<const u32x4 *>(mt.seq + g);
+		} else {
+			const int valid = (int)(total_bytes - g);
+			q = load_tail(mt.qual + g, valid);
+			if (mt.out_seq) sq = load_tail(mt.seq + g, valid);
+		}
+	};
+	// consume a slot: mask -> global store, (q-33) bytes -> LDS image
+	auto consume = [&](int64_t t, int k, int c, const u32x4 &q, const u32x4 &sq) {
+		const MateDev &mt = k ? am1 : am0;
+		const int64_t row0 = t * kTileRows;
+		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
+		const int off = c * (kWave * 16) + lane * 16;
+		if (off >= rows * stride) return;
+		const int64_t g = row0 * (int64_t)stride + off;
+		u32x4 o, vq;
+		mask_dword4<MODE>(q, sq, cl2, o, vq);
+		if (mt.out_seq) {
+			if (g + 16 <= total_bytes) *reinterpret_cast<u32x4 *>(mt.out_seq + g) = o;
+			else store_tail(mt.out_seq + g, o, (int)(total_bytes - g));
+		}
+		if (mt.lowest_k) *reinterpret_cast<u32x4 *>(tile + off) = vq;
+	};
+
+	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	u32x4 q0 = {0u, 0u, 0u, 0u}, s0 = q0, q1 = q0, s1 = q0;
+	issue(t, 0, 0, q0, s0);
+	issue(t, 0, 1, q1, s1);
+	for (; t < ntiles; t += tstep) {
 		const int64_t row0 = t * kTileRows;
 		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
 		const bool active = lane < rows;
 
-		for (int mi = 0; mi < a.n_mates; mi++) {
-			const MateDev &mt = a.mate[mi];
-			const bool do_mask = mt.out_seq != nullptr;
-			const bool do_trim = mt.lowest_k != nullptr;
-			if (!do_mask && !do_trim) continue;
-			const int64_t base = row0 * (int64_t)stride;
-			const int tile_bytes = rows * stride;
+		// the tile's observed barcodes are fetched now and only looked at in the barcode phase
+		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
+		if (DEMUX) {
+			const int64_t g0 = row0 * (int64_t)a.bc_stride + lane * 16;
+			const int nb = rows * a.bc_stride;
+			if (lane * 16 < nb) bcv0 = (g0 + 16 <= bc_total) ? *reinterpret_cast<const u32x4 *>(a.bc + g0) : load_tail(a.bc + g0, (int)(bc_total - g0));
+			if (1024 + lane * 16 < nb) bcv1 = (g0 + 1040 <= bc_total) ? *reinterpret_cast<const u32x4 *>(a.bc + g0 + 1024) : load_tail(a.bc + g0 + 1024, (int)(bc_total - g0 - 1024));
+		}
 
-			// ---- stream phase: 16 B per lane, 1 KiB per wave instruction -------------------------
-			for (int off = lane * 16; off < tile_bytes; off += kWave * 16) {
-				const int64_t g = base + off;
-				u32x4 q, s = {0u, 0u, 0u, 0u}, o, vq;
-				const bool full = (g + 16 <= total_bytes);
-				if (full) {
-					q = *reinterpret_cast<const u32x4 *>(mt.qual + g);
-					if (do_mask) s = *reinterpret_cast<const u32x4 *>(mt.seq + g);
-				} else {
-					const int valid = (int)(total_bytes - g);
-					q = load_tail(mt.qual + g, valid);
-					if (do_mask) s = load_tail(mt.seq + g, valid);
-				}
-				mask_dword4_rt(mode, q, s, cl2, c72, o, vq);
-				if (do_mask) {
-					if (full) *reinterpret_cast<u32x4 *>(mt.out_seq + g) = o;
-					else store_tail(mt.out_seq + g, o, (int)(total_bytes - g));
-				}
-				if (do_trim) *reinterpret_cast<u32x4 *>(tile + off) = vq;
+		for (int k = 0; k < nam; k++) {
+			const MateDev &mt = k ? am1 : am0;
+			// the item after this one: the other mate of this tile, or the first mate of the wave's next tile
+			const int64_t tn = (k + 1 < nam) ? t : t + tstep;
+			const int kn = (k + 1 < nam) ? k + 1 : 0;
+			int len = stride;
+			if (mt.len != nullptr && mt.lowest_k != nullptr && active) len = (int)mt.len[row0 + lane];
+
+			// ---- stream phase: 16 B per lane, 1 KiB per wave instruction, two chunks in flight ------------
+			for (int c = 0; c < nchunk2; c += 2) {
+				consume(t, k, c, q0, s0);
+				if (c + 2 < nchunk2) issue(t, k, c + 2, q0, s0); else issue(tn, kn, 0, q0, s0);
+				consume(t, k, c + 1, q1, s1);
+				if (c + 3 < nchunk2) issue(t, k, c + 3, q1, s1); else issue(tn, kn, 1, q1, s1);
 			}
 
-			// ---- scan phase: lane r walks row r of the LDS image from its 3' end -------------------
-			if (do_trim) {
+			// ---- scan phase: lane r walks row r of the LDS image from its 3' end --------------------------
+			if (mt.lowest_k != nullptr) {
 				wave_lds_fence();
-				int len = stride;
-				if (mt.len != nullptr && active) len = (int)mt.len[row0 + lane];
-				int k;
-				if (stride < (1 << kKeyBits)) k = trim_scan_packed(tile, lane * stride, len, stride, m, active);
-				else k = trim_scan_wide(tile, lane * stride, len, stride, m, active);
-				if (active) mt.lowest_k[row0 + lane] = (uint16_t)k;
+				int kk;
+				if (stride >= (1 << kKeyBits)) kk = trim_scan_wide(tile, lane * stride, len, stride, m, active);
+				else if (mt.len != nullptr) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, m, active);
+				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, m, active);
+				if (active) mt.lowest_k[row0 + lane] = (uint16_t)kk;
 				wave_lds_fence();
 			}
 		}
 
-		// ---- barcode phase ---------------------------------------------------------------------------
-		if (do_demux) {
+		// ---- barcode phase (bit-sliced matcher) -----------------------------------------------------------
+		if (DEMUX) {
 			const int bstride = a.bc_stride;
-			const int64_t base = row0 * (int64_t)bstride;
-			const int tile_bytes = rows * bstride;
-			const int64_t bc_total = a.n * (int64_t)bstride;
-			for (int off = lane * 16; off < tile_bytes; off += kWave * 16) {
-				const int64_t g = base + off;
-				u32x4 v;
-				if (g + 16 <= bc_total) v = *reinterpret_cast<const u32x4 *>(a.bc + g);
-				else v = load_tail(a.bc + g, (int)(bc_total - g));
-				*reinterpret_cast<u32x4 *>(tile + off) = v;
-			}
+			if (lane * 16 < rows * bstride) *reinterpret_cast<u32x4 *>(tile + lane * 16) = bcv0;
+			if (1024 + lane * 16 < rows * bstride) *reinterpret_cast<u32x4 *>(tile + 1024 + lane * 16) = bcv1;
 			wave_lds_fence();
-			int diff = 255, first = 0, last = 0;
-			if (S > 0) {
-				const int rs = lane * bstride;
-				if (a.table.onehot != nullptr) {
-					switch (a.table.W) {   // wave-uniform
-					case 1: demux_row_onehot<1>(tile, rs, a.table, diff, first, last); break;
-					case 2: demux_row_onehot<2>(tile, rs, a.table, diff, first, last); break;
-					case 3: demux_row_onehot<3>(tile, rs, a.table, diff, first, last); break;
-					case 4: demux_row_onehot<4>(tile, rs, a.table, diff, first, last); break;
-					case 5: demux_row_onehot<5>(tile, rs, a.table, diff, first, last); break;
-					case 6: demux_row_onehot<6>(tile, rs, a.table, diff, first, last); break;
-					case 7: demux_row_onehot<7>(tile, rs, a.table, diff, first, last); break;
-					default: demux_row_onehot<8>(tile, rs, a.table, diff, first, last); break;
-					}
-				} else {
-					demux_row_bytes(tile, rs, a.table, diff, first, last);
-				}
+			int best = 0x7fffffff, first = 0, last = 0;
+			const uint8_t *row = tile + lane * bstride;
+			switch (a.table.G) {   // wave-uniform
+			case 1: demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, 1, 0, a.table.L, best, first, last); break;
+			case 2: demux_row_bitsliced<2>(row, sk_smem, a.table.bs_mm_off, 2, 0, a.table.L, best, first, last); break;
+			case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
+			default: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
 			}
-			// D3: src/fasta_demultiplex.rs:168-194
-			int code = kAssignNone;
-			if (S > 0 && diff <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
-			if (active) {
-				const int64_t r = row0 + lane;
-				a.assign[r] = code;
-				if (a.lowest_diff) a.lowest_diff[r] = (uint8_t)(diff > 255 ? 255 : diff);
-				if (a.first_idx) a.first_idx[r] = (int16_t)first;
-				if (a.last_idx) a.last_idx[r] = (int16_t)last;
-				if (code >= 0) {
-					if (use_lds_hist) atomicAdd(&hist[code], 1u);
-					else atomicAdd(&a.counts[code], 1ull);
-				}
-			}
-			n_total += (u32)__popcll(__ballot(active));
-			n_ident += (u32)__popcll(__ballot(active && code >= 0));
-			n_ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+			demux_commit(a, lp, hist, row0 + lane, active, best, first, last, wc);
 			wave_lds_fence();
 		}
 	}
+	if (DEMUX) flush_counts(a, lp, hist, lane, wc);
+}
 
-	if (do_demux) {
-		if (use_lds_hist) {
-			wave_lds_fence();
-			for (int i = lane; i < S; i += kWave) {
-				u32 c = hist[i];
-				if (c) atomicAdd(&a.counts[i], (unsigned long long)c);
+// Standalone demultiplex pass: every matcher (bit-sliced with any group count, one-hot popcount, byte
+// compare), any bc_stride the LDS tile can hold.  One wave per 64-row tile as above.
+__global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const LdsPlan lp)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = threadIdx.x >> 6;
+	const int nwave = blockDim.x >> 6;
+	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
+	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
+	const u32 *cand_lds = reinterpret_cast<const u32 *>(sk_smem);
+	stage_tables(a.table, lp, hist);
+	WaveCounts wc = {0u, 0u, 0u};
+	const int S = a.table.S;
+	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int bstride = a.bc_stride;
+	const int64_t bc_total = a.n * (int64_t)bstride;
+	for (int64_t t = (int64_t)blockIdx.x * nwave + wave; t < ntiles; t += (int64_t)gridDim.x * nwave) {
+		const int64_t row0 = t * kTileRows;
+		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
+		const bool active = lane < rows;
+		const int64_t base = row0 * (int64_t)bstride;
+		const int tile_bytes = rows * bstride;
+		for (int off = lane * 16; off < tile_bytes; off += kWave * 16) {
+			const int64_t g = base + off;
+			u32x4 v;
+			if (g + 16 <= bc_total) v = *reinterpret_cast<const u32x4 *>(a.bc + g);
+			else v = load_tail(a.bc + g, (int)(bc_total - g));
+			*reinterpret_cast<u32x4 *>(tile + off) = v;
+		}
+		wave_lds_fence();
+		int diff = 255, first = 0, last = 0;
+		if (S > 0) {
+			const int rs = lane * bstride;
+			if (a.table.bs != nullptr) {
+				int best = 0x7fffffff;
+				const uint8_t *row = tile + rs;
+				switch (a.table.G) {   // wave-uniform
+				case 1: demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, 1, 0, a.table.L, best, first, last); break;
+				case 2: demux_row_bitsliced<2>(row, sk_smem, a.table.bs_mm_off, 2, 0, a.table.L, best, first, last); break;
+				case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
+				case 4: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
+				default:
+					for (int g0 = 0; g0 < a.table.G; g0++)
+						demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, a.table.G, g0, a.table.L, best, first, last);
+					break;
+				}
+				diff = best;
+			} else if (a.table.onehot != nullptr) {
+				switch (a.table.W) {   // wave-uniform
+				case 1: demux_row_onehot<1>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 2: demux_row_onehot<2>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 3: demux_row_onehot<3>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 4: demux_row_onehot<4>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 5: demux_row_onehot<5>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 6: demux_row_onehot<6>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				case 7: demux_row_onehot<7>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				default: demux_row_onehot<8>(tile, rs, a.table, cand_lds, diff, first, last); break;
+				}
+			} else {
+				demux_row_bytes(tile, rs, a.table, sk_smem, diff, first, last);
 			}
 		}
-		if (lane == 0) {
-			if (n_total) atomicAdd(&a.counts[S], (unsigned long long)n_total);
-			if (n_ident) atomicAdd(&a.counts[S + 1], (unsigned long long)n_ident);
-			if (n_ambig) atomicAdd(&a.counts[S + 2], (unsigned long long)n_ambig);
-		}
+		demux_commit(a, lp, hist, row0 + lane, active, diff, first, last, wc);
+		wave_lds_fence();
 	}
+	flush_counts(a, lp, hist, lane, wc);
 }
 
 // rows too long for an LDS tile: one thread per row straight from global memory (correct, not fast)
@@ -458,13 +678,64 @@ __global__ __launch_bounds__(256) void trim_rows_global_kernel(const uint8_t *__
 	}
 }
 
+// LDS layout + workgroup shape for a tile kernel; the grid comes from the occupancy API so that every
+// workgroup of the persistent grid is resident (a queued workgroup would run its whole share of tiles late).
+static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_bytes, bool with_tables, int max_nw, int n_cu, hipStream_t st)
+{
+	static const int kLdsPerCu = 160 * 1024;
+	LdsPlan lp{};
+	lp.table_bytes = 0;
+	if (with_tables) {
+		int tb = b.table.bs ? b.table.bs_bytes : b.table.onehot ? b.table.S * padded_w(b.table.W) * 4 : b.table.S * b.table.L;
+		lp.table_bytes = (tb + 15) & ~15;
+	}
+	lp.use_lds_hist = (with_tables && b.table.S + 3 <= kMaxLdsHist) ? 1 : 0;
+	lp.hist_off = lp.table_bytes;
+	lp.tiles_off = (lp.hist_off + (lp.use_lds_hist ? (b.table.S + 3) * 4 : 0) + 15) & ~15;
+	lp.tile_slot = kLdsPad + ((kTileRows * row_bytes + 15) & ~15) + kLdsPad;
+	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
+	if (e != hipSuccess) return e;
+	static const int env_nw = getenv("SK_TILE_WAVES") ? atoi(getenv("SK_TILE_WAVES")) : 0;      // tuning knob (tools/ablate.py)
+	int best_nw = 0, best_wg = 0, best_waves = 0;
+	for (int nw = max_nw; nw >= 1; nw >>= 1) {
+		if (env_nw && nw != env_nw && env_nw <= max_nw) continue;
+		const int lds = lp.tiles_off + nw * lp.tile_slot;
+		if (lds > kLdsPerCu) continue;
+		int wg = 0;
+		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
+		if (e != hipSuccess) return e;
+		if (wg * nw > best_waves) { best_waves = wg * nw; best_nw = nw; best_wg = wg; }
+	}
+	if (best_waves == 0) return hipErrorInvalidValue;
+	const int lds = lp.tiles_off + best_nw * lp.tile_slot;
+	int64_t ntiles = (b.n + kTileRows - 1) / kTileRows;
+	int64_t want = (ntiles + best_nw - 1) / best_nw;
+	int64_t cap = (int64_t)n_cu * best_wg;
+	int grid = (int)(want < cap ? want : cap);
+	TileArgs bb = b;
+	void *kargs[] = {(void *)&bb, (void *)&lp};
+	return hipLaunchKernel(fn, dim3(grid), dim3(kWave * best_nw), kargs, lds, st);
+}
+
+template <bool DEMUX>
+static const void *tile_pass_fn(int mode)
+{
+	switch (mode) {
+	case 0: return reinterpret_cast<const void *>(tile_pass_kernel<0, DEMUX>);
+	case 1: return reinterpret_cast<const void *>(tile_pass_kernel<1, DEMUX>);
+	case 2: return reinterpret_cast<const void *>(tile_pass_kernel<2, DEMUX>);
+	case 3: return reinterpret_cast<const void *>(tile_pass_kernel<3, DEMUX>);
+	default: return reinterpret_cast<const void *>(tile_pass_kernel<4, DEMUX>);
+	}
+}
+
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
 	TileArgs b = a;
-	// rows that do not fit an LDS tile: trim falls back to the row-per-thread kernel, mask to the flat one
 	bool any_mate = false;
 	for (int mi = 0; mi < b.n_mates; mi++) any_mate = any_mate || b.mate[mi].out_seq || b.mate[mi].lowest_k;
+	// rows that do not fit an LDS tile: trim falls back to the row-per-thread kernel, mask to the flat one
 	if (any_mate && b.stride > kMaxTileStride) {
 		for (int mi = 0; mi < b.n_mates; mi++) {
 			MateDev &mt = b.mate[mi];
@@ -481,25 +752,26 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			}
 			mt.out_seq = nullptr; mt.lowest_k = nullptr;
 		}
-		if (!b.bc) return hipSuccess;
+		any_mate = false;
 	}
+	// the barcode phase rides in the tile pass when the bit-sliced matcher applies (S <= 128) and the tile's
+	// barcodes fit two 1 KiB register chunks; otherwise it is its own launch beside the mate pass
+	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 &&
+	                        !getenv("SK_NO_FUSED_DEMUX");
+	if (b.bc && !fuse_demux) {
+		hipError_t e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
+		if (e != hipSuccess) return e;
+	}
+	if (!any_mate) return hipSuccess;
 	int row_bytes = 0;
 	for (int mi = 0; mi < b.n_mates; mi++)
-		if (b.mate[mi].lowest_k || b.mate[mi].out_seq) row_bytes = b.stride;
-	if (b.bc && b.bc_stride > row_bytes) row_bytes = b.bc_stride;
-	int tile_bytes = (kTileRows * row_bytes + 15) & ~15;
-	int hist_off = kLdsPad + tile_bytes + kLdsPad;
-	int use_lds_hist = (b.bc && b.table.S + 3 <= kMaxLdsHist) ? 1 : 0;
-	int lds = hist_off + (use_lds_hist ? (b.table.S + 3) * 4 : 0);
-	lds = (lds + 15) & ~15;
-	int per_cu = (160 * 1024) / lds;
-	if (per_cu > 16) per_cu = 16;
-	if (per_cu < 1) per_cu = 1;
-	int64_t ntiles = (b.n + kTileRows - 1) / kTileRows;
-	int64_t cap = (int64_t)n_cu * per_cu;
-	int grid = (int)(ntiles < cap ? ntiles : cap);
-	tile_pass_kernel<<<grid, kWave, lds, st>>>(b, hist_off, use_lds_hist);
-	return hipGetLastError();
+		if (b.mate[mi].lowest_k) row_bytes = b.stride;          // only the trim scan needs the LDS image
+	if (fuse_demux) {
+		if (b.bc_stride > row_bytes) row_bytes = b.bc_stride;
+		return plan_and_launch(tile_pass_fn<true>(b.qc.mode), b, row_bytes, true, 8, n_cu, st);
+	}
+	b.bc = nullptr;
+	return plan_and_launch(tile_pass_fn<false>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

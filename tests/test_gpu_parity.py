@@ -127,6 +127,44 @@ def check_demux(ctx, oracle, table, bc, max_diff=1):
     return e_counts
 
 
+@pytest.fixture(params=["bitsliced", "onehot", "bytes"])
+def demux_path(request, monkeypatch):
+    """Force each of the three matcher implementations (bit-sliced planes / one-hot popcount / byte compare)."""
+    if request.param in ("onehot", "bytes"):
+        monkeypatch.setenv("SK_NO_BITSLICE", "1")
+    if request.param == "bytes":
+        monkeypatch.setenv("SK_NO_ONEHOT", "1")
+    return request.param
+
+
+def test_demux_all_matchers_agree(ctx, oracle, demux_path):
+    for S, dual, seed in ((16, False, 3), (96, True, 4), (33, False, 5), (150, True, 6)):
+        table = synth.make_sheet(S, 8, dual=dual, seed=seed)
+        bc, _ = synth.observe_barcodes(table, 20011, seed=seed, halves=2 if dual else 1)
+        bc[::7, 3] = ord("N")
+        bc[::11, 0] = ord("x")
+        check_demux(ctx, oracle, table, bc)
+    # wildcards, duplicates, '+' and a lone sample
+    table = np.array([list(b"ACGTNNGT+AAUU"), list(b"ACGTACGT+AAUU"), list(b"TTTTTTTT+CCCC"), list(b"TTTTTTTT+CCCC")], dtype=np.uint8)
+    rng = np.random.default_rng(77)
+    bc = table[rng.integers(0, 4, size=9000)].copy()
+    hit = rng.random(9000) < 0.7
+    bc[hit, rng.integers(0, 13, size=9000)[hit]] = np.frombuffer(b"ACGTN+U", dtype=np.uint8)[rng.integers(0, 7, size=int(hit.sum()))]
+    check_demux(ctx, oracle, table, bc)
+    check_demux(ctx, oracle, table[:1], bc, max_diff=3)
+
+
+def test_demux_many_samples_generic_groups(ctx, oracle):
+    """S = 700 (22 groups of 32: the generic group loop of the bit-sliced matcher) and S = 2000 (tables too big for LDS)."""
+    rng = np.random.default_rng(88)
+    for S in (700, 2000):
+        table = synth.BASES[rng.integers(0, 4, size=(S, 10))]
+        bc = table[rng.integers(0, S, size=30000)].copy()
+        hit = rng.random(30000) < 0.5
+        bc[hit, rng.integers(0, 10, size=30000)[hit]] = synth.BASES[rng.integers(0, 4, size=int(hit.sum()))]
+        check_demux(ctx, oracle, table, bc)
+
+
 def test_demux_cfg3_single_index(ctx, oracle):
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     bc, _ = synth.observe_barcodes(table, 200000, seed=3)
