@@ -18,14 +18,14 @@ def main():
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        ours = [r for r in rows if r["Name"].startswith("sk::")]
-        other_ns = sum(int(r["TotalDurationNs"]) for r in rows if not r["Name"].startswith("sk::"))
+        ours = [r for r in rows if ("sk::" in r["Name"])]
+        other_ns = sum(int(r["TotalDurationNs"]) for r in rows if not ("sk::" in r["Name"]))
         with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
             for r in ours:
                 w.writerow(r)
-            w.writerow({"Name": "(all other kernels: torch data generation, copies, fills)", "Calls": sum(int(r["Calls"]) for r in rows if not r["Name"].startswith("sk::")),
+            w.writerow({"Name": "(all other kernels: torch data generation, copies, fills)", "Calls": sum(int(r["Calls"]) for r in rows if not ("sk::" in r["Name"])),
                         "TotalDurationNs": other_ns})
     if trace:
         seen = {}
@@ -35,7 +35,7 @@ def main():
             w.writeheader()
             for r in rd:
                 k = r["Kernel_Name"]
-                if not k.startswith("sk::"):
+                if "sk::" not in k:
                     continue
                 seen[k] = seen.get(k, 0) + 1
                 if seen[k] <= 8:
