@@ -89,6 +89,27 @@ __device__ __forceinline__ void mask_dword4(const u32x4 &q, const u32x4 &s, u32 
 	}
 }
 
+// 16-byte accesses of the read-once / write-once byte matrices (SK_NT: bit 0 = nontemporal loads, bit 1 = stores)
+#ifndef SK_NT
+#define SK_NT 3
+#endif
+__device__ __forceinline__ u32x4 stream_load(const uint8_t *p)
+{
+#if SK_NT & 1
+	return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+#else
+	return *reinterpret_cast<const u32x4 *>(p);
+#endif
+}
+__device__ __forceinline__ void stream_store(uint8_t *p, const u32x4 &v)
+{
+#if SK_NT & 2
+	__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+#else
+	*reinterpret_cast<u32x4 *>(p) = v;
+#endif
+}
+
 // byte-granular load/store of a 16-byte chunk that crosses the end of the matrix
 __device__ __forceinline__ u32x4 load_tail(const uint8_t *p, int valid)
 {
@@ -382,6 +403,7 @@ struct LdsPlan {
 	int tiles_off;       // first wave's tile slot (includes the front pad)
 	int tile_slot;       // bytes per wave: front pad + 64*row_bytes rounded to 16 + back pad
 	int use_lds_hist;
+	int stagger;         // start-up stagger of the waves, in s_sleep(127) units per phase slot (0 = none)
 };
 
 // copy the matcher tables into the workgroup's LDS and clear its histogram (all threads; ends with a barrier)
@@ -456,14 +478,36 @@ __device__ __forceinline__ void flush_counts(const TileArgs &a, const LdsPlan &l
 // already fetch the first two chunks of the wave's next item, so HBM requests keep flowing while the wave
 // does its LDS/VALU work.  Only loads run ahead; the LDS image is written when a chunk is consumed, so one
 // LDS tile per wave is enough.
+//
+// Every global access in this kernel is an UNCONDITIONAL raw-buffer instruction: each (tile, array) gets its
+// own buffer descriptor whose num_records is the tile's valid byte count, and the hardware range check clips
+// what falls outside (per dword for 16-byte accesses, measured on gfx950: tools/micro/bufclip.hip).  Loads
+// that would run past the tile return zeros, stores are dropped, absent optional arrays get a zero-record
+// descriptor.  With no branch around any VMEM instruction the compiler's s_waitcnt vmcnt(N) counts are exact,
+// which is what keeps the two register slots genuinely in flight.  Loads use records rounded UP to a dword
+// (they may read up to 3 bytes past the end of a matrix), 16-byte stores use records rounded DOWN to a dword;
+// the <= 3 bytes of a matrix whose size is not a multiple of 4 are finished by mask_tail_kernel.
 //   MODE  : packed-compare mode of the quality threshold (QualConsts::mode)
 //   DEMUX : the barcode phase is part of the pass, bit-sliced matcher with G <= 4 (S <= 128) and
 //           64*bc_stride <= 2048; every other demultiplex shape runs as demux_tile_kernel beside this one
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#ifndef SK_SLOTS
+#define SK_SLOTS 2
+#endif
+constexpr int kSlots = SK_SLOTS;                      // 1 KiB chunk loads in flight per wave and stream
+constexpr int kAuxStream = (SK_NT & 1) ? 2 : 0;      // nt on the read-once streams
+constexpr int kAuxStreamSt = (SK_NT & 2) ? 2 : 0;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int records)
+{
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(static_cast<const uint8_t *>(p)) + (p ? byte_off : 0), 0, p ? records : 0, 0x00020000);
+}
+
 template <int MODE, bool DEMUX>
 __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
-	const int wave = threadIdx.x >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction: make it an SGPR
 	const int nwave = blockDim.x >> 6;
 	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
@@ -472,7 +516,6 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int stride = a.stride;
-	const int64_t total_bytes = a.n * (int64_t)stride;
 	const int m = a.qc.min_baseq;
 	const u32 cl2 = a.qc.cl2;
 
@@ -487,48 +530,37 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 		else if (act1) { nam = 1; am0 = a.mate[1]; }
 	}
 	const int64_t tstep = (int64_t)gridDim.x * nwave;
-	const int64_t bc_total = DEMUX ? a.n * (int64_t)a.bc_stride : 0;
-	const int nchunk2 = (((kTileRows * stride + 1023) >> 10) + 1) & ~1;      // chunks per full tile, rounded up to even
+	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + kSlots - 1) / kSlots * kSlots;   // chunks per full tile, rounded up to the slot count
+	const int voff = lane * 16;
 
-	// issue the loads of chunk c of item (t, k) into a register slot
-	auto issue = [&](int64_t t, int k, int c, u32x4 &q, u32x4 &sq) {
-		if (t >= ntiles) return;
+	// descriptors of the two input streams of item (t, k); a tile past the end gets zero records
+	auto in_rsrc = [&](int64_t t, int k, rsrc_t &rq, rsrc_t &rs) {
 		const MateDev &mt = k ? am1 : am0;
-		const int64_t row0 = t * kTileRows;
-		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
-		const int off = c * (kWave * 16) + lane * 16;
-		if (off >= rows * stride) return;
-		const int64_t g = row0 * (int64_t)stride + off;
-		if (g + 16 <= total_bytes) {
-			q = *reinterpret_cast<const u32x4 *>(mt.qual + g);
-			if (mt.out_seq) sq = *reinterpret_cast<const u32x4 *>(mt.seq + g);
-		} else {
-			const int valid = (int)(total_bytes - g);
-			q = load_tail(mt.qual + g, valid);
-			if (mt.out_seq) sq = load_tail(mt.seq + g, valid);
-		}
-	};
-	// consume a slot: mask -> global store, (q-33) bytes -> LDS image
-	auto consume = [&](int64_t t, int k, int c, const u32x4 &q, const u32x4 &sq) {
-		const MateDev &mt = k ? am1 : am0;
-		const int64_t row0 = t * kTileRows;
-		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
-		const int off = c * (kWave * 16) + lane * 16;
-		if (off >= rows * stride) return;
-		const int64_t g = row0 * (int64_t)stride + off;
-		u32x4 o, vq;
-		mask_dword4<MODE>(q, sq, cl2, o, vq);
-		if (mt.out_seq) {
-			if (g + 16 <= total_bytes) *reinterpret_cast<u32x4 *>(mt.out_seq + g) = o;
-			else store_tail(mt.out_seq + g, o, (int)(total_bytes - g));
-		}
-		if (mt.lowest_k) *reinterpret_cast<u32x4 *>(tile + off) = vq;
+		const bool ok = t < ntiles;
+		const int64_t row0 = ok ? t * kTileRows : 0;
+		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
+		const int nb = (rows * stride + 3) & ~3;
+		rq = make_rsrc(mt.qual, row0 * (int64_t)stride, nb);
+		rs = make_rsrc(mt.out_seq ? mt.seq : nullptr, row0 * (int64_t)stride, nb);
 	};
 
 	int64_t t = (int64_t)blockIdx.x * nwave + wave;
-	u32x4 q0 = {0u, 0u, 0u, 0u}, s0 = q0, q1 = q0, s1 = q0;
-	issue(t, 0, 0, q0, s0);
-	issue(t, 0, 1, q1, s1);
+	// Waves that start together run their stream / scan phases in lockstep, which leaves HBM idle during every
+	// scan.  Spread the start of the 16 waves of a CU over one item period (16 phase slots); the offsets persist
+	// because every wave has the same period.
+	if (lp.stagger > 0) {
+		const int slot = (wave * 2 + (int)(blockIdx.x & 1) + (int)((blockIdx.x >> 1) & 7) * 5) & 15;
+		for (int i = 0; i < slot * lp.stagger; i++) __builtin_amdgcn_s_sleep(127);
+	}
+	rsrc_t rq, rs;
+	in_rsrc(t, 0, rq, rs);
+	u32x4 qv[kSlots], sv[kSlots];
+#pragma unroll
+	for (int i = 0; i < kSlots; i++) {
+		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + i * 1024, 0, kAuxStream);
+		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
+	}
+
 	for (; t < ntiles; t += tstep) {
 		const int64_t row0 = t * kTileRows;
 		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
@@ -537,36 +569,54 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 		// the tile's observed barcodes are fetched now and only looked at in the barcode phase
 		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
 		if (DEMUX) {
-			const int64_t g0 = row0 * (int64_t)a.bc_stride + lane * 16;
-			const int nb = rows * a.bc_stride;
-			if (lane * 16 < nb) bcv0 = (g0 + 16 <= bc_total) ? *reinterpret_cast<const u32x4 *>(a.bc + g0) : load_tail(a.bc + g0, (int)(bc_total - g0));
-			if (1024 + lane * 16 < nb) bcv1 = (g0 + 1040 <= bc_total) ? *reinterpret_cast<const u32x4 *>(a.bc + g0 + 1024) : load_tail(a.bc + g0 + 1024, (int)(bc_total - g0 - 1024));
+			const rsrc_t rb = make_rsrc(a.bc, row0 * (int64_t)a.bc_stride, (rows * a.bc_stride + 3) & ~3);
+			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, 0);
+			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, 0);
 		}
 
 		for (int k = 0; k < nam; k++) {
 			const MateDev &mt = k ? am1 : am0;
+			const bool do_trim = mt.lowest_k != nullptr;
+			const int nb = rows * stride;
+			const rsrc_t ro = make_rsrc(mt.out_seq, row0 * (int64_t)stride, nb & ~3);
+			const rsrc_t rk = make_rsrc(mt.lowest_k, row0 * 2, rows * 2);
+			const rsrc_t rl = make_rsrc(do_trim ? mt.len : nullptr, row0 * 2, rows * 2);
 			// the item after this one: the other mate of this tile, or the first mate of the wave's next tile
 			const int64_t tn = (k + 1 < nam) ? t : t + tstep;
 			const int kn = (k + 1 < nam) ? k + 1 : 0;
-			int len = stride;
-			if (mt.len != nullptr && mt.lowest_k != nullptr && active) len = (int)mt.len[row0 + lane];
+			rsrc_t nq, ns;
+			in_rsrc(tn, kn, nq, ns);
+			int len_ld = (int)__builtin_amdgcn_raw_buffer_load_b16(rl, lane * 2, 0, 0);
+			// Materialise the length NOW: it is the youngest load at this point and the slots R0/R1 it queues
+			// behind are needed immediately anyway.  Left to its first use after the chunk loop, the wait would be
+			// an uncounted vmcnt(0) that drains the next item's prefetch right before the scan.
+			asm volatile("" : "+v"(len_ld));
 
 			// ---- stream phase: 16 B per lane, 1 KiB per wave instruction, two chunks in flight ------------
-			for (int c = 0; c < nchunk2; c += 2) {
-				consume(t, k, c, q0, s0);
-				if (c + 2 < nchunk2) issue(t, k, c + 2, q0, s0); else issue(tn, kn, 0, q0, s0);
-				consume(t, k, c + 1, q1, s1);
-				if (c + 3 < nchunk2) issue(t, k, c + 3, q1, s1); else issue(tn, kn, 1, q1, s1);
+			for (int c = 0; c < nchunkp; c += kSlots) {
+				const bool last = c + kSlots >= nchunkp;
+#pragma unroll
+				for (int i = 0; i < kSlots; i++) {
+					const int off = (c + i) * 1024 + voff;
+					u32x4 o, vq;
+					mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
+					__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
+					if (do_trim && off < nb) *reinterpret_cast<u32x4 *>(tile + off) = vq;
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + kSlots * 1024, 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + kSlots * 1024, 0, kAuxStream);
+				}
 			}
+			rq = nq; rs = ns;
 
 			// ---- scan phase: lane r walks row r of the LDS image from its 3' end --------------------------
-			if (mt.lowest_k != nullptr) {
+			if (do_trim) {
 				wave_lds_fence();
+				const int len = (mt.len != nullptr) ? len_ld : stride;
 				int kk;
 				if (stride >= (1 << kKeyBits)) kk = trim_scan_wide(tile, lane * stride, len, stride, m, active);
 				else if (mt.len != nullptr) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, m, active);
 				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, m, active);
-				if (active) mt.lowest_k[row0 + lane] = (uint16_t)kk;
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, rk, lane * 2, 0, 0);
 				wave_lds_fence();
 			}
 		}
@@ -574,8 +624,8 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 		// ---- barcode phase (bit-sliced matcher) -----------------------------------------------------------
 		if (DEMUX) {
 			const int bstride = a.bc_stride;
-			if (lane * 16 < rows * bstride) *reinterpret_cast<u32x4 *>(tile + lane * 16) = bcv0;
-			if (1024 + lane * 16 < rows * bstride) *reinterpret_cast<u32x4 *>(tile + 1024 + lane * 16) = bcv1;
+			if (voff < rows * bstride) *reinterpret_cast<u32x4 *>(tile + voff) = bcv0;
+			if (1024 + voff < rows * bstride) *reinterpret_cast<u32x4 *>(tile + 1024 + voff) = bcv1;
 			wave_lds_fence();
 			int best = 0x7fffffff, first = 0, last = 0;
 			const uint8_t *row = tile + lane * bstride;
@@ -585,11 +635,28 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 			case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
 			default: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
 			}
-			demux_commit(a, lp, hist, row0 + lane, active, best, first, last, wc);
+			// D3 (src/fasta_demultiplex.rs:168-194) with descriptor-clipped stores
+			int code = kAssignNone;
+			if (best <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), make_rsrc(a.lowest_diff, row0, rows), lane, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, make_rsrc(a.first_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, make_rsrc(a.last_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
+			if (active && code >= 0) atomicAdd(&hist[code], 1u);
+			wc.total += (u32)__popcll(__ballot(active));
+			wc.ident += (u32)__popcll(__ballot(active && code >= 0));
+			wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
 			wave_lds_fence();
 		}
 	}
 	if (DEMUX) flush_counts(a, lp, hist, lane, wc);
+}
+
+// the last (n*stride mod 4) bytes of a matrix, which the dword-clipped 16-byte stores of the tile pass leave out
+__global__ void mask_tail_kernel(const uint8_t *seq, const uint8_t *qual, uint8_t *out, int64_t total, int m)
+{
+	const int64_t i = (total & ~(int64_t)3) + threadIdx.x;
+	if (i < total) out[i] = ((uint8_t)(qual[i] - 33) < m) ? (uint8_t)'N' : seq[i];
 }
 
 // Standalone demultiplex pass: every matcher (bit-sliced with any group count, one-hot popcount, byte
@@ -597,7 +664,7 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
-	const int wave = threadIdx.x >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction: make it an SGPR
 	const int nwave = blockDim.x >> 6;
 	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
@@ -704,6 +771,8 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 		int wg = 0;
 		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
 		if (e != hipSuccess) return e;
+		static const int env_wg = getenv("SK_TILE_WGS") ? atoi(getenv("SK_TILE_WGS")) : 0;     // tuning knob: cap on workgroups per CU
+		if (env_wg > 0 && wg > env_wg) wg = env_wg;
 		if (wg * nw > best_waves) { best_waves = wg * nw; best_nw = nw; best_wg = wg; }
 	}
 	if (best_waves == 0) return hipErrorInvalidValue;
@@ -712,6 +781,12 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 	int64_t want = (ntiles + best_nw - 1) / best_nw;
 	int64_t cap = (int64_t)n_cu * best_wg;
 	int grid = (int)(want < cap ? want : cap);
+	// Optional start-up stagger of the waves (SK_STAGGER = s_sleep(127) units per phase slot).  Off by default: it
+	// moved the fused pass by -10 % .. +6 % depending on where the waves' phases happened to settle.
+	{
+		static const int env_st = getenv("SK_STAGGER") ? atoi(getenv("SK_STAGGER")) : 0;
+		lp.stagger = env_st > 0 ? env_st : 0;
+	}
 	TileArgs bb = b;
 	void *kargs[] = {(void *)&bb, (void *)&lp};
 	return hipLaunchKernel(fn, dim3(grid), dim3(kWave * best_nw), kargs, lds, st);
@@ -766,6 +841,10 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	int row_bytes = 0;
 	for (int mi = 0; mi < b.n_mates; mi++)
 		if (b.mate[mi].lowest_k) row_bytes = b.stride;          // only the trim scan needs the LDS image
+	const int64_t total = b.n * (int64_t)b.stride;
+	if (total & 3)
+		for (int mi = 0; mi < b.n_mates; mi++)
+			if (b.mate[mi].out_seq) mask_tail_kernel<<<1, 4, 0, st>>>(b.mate[mi].seq, b.mate[mi].qual, b.mate[mi].out_seq, total, b.qc.min_baseq);
 	if (fuse_demux) {
 		if (b.bc_stride > row_bytes) row_bytes = b.bc_stride;
 		return plan_and_launch(tile_pass_fn<true>(b.qc.mode), b, row_bytes, true, 8, n_cu, st);
