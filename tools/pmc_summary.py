@@ -11,8 +11,8 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if k.startswith("sk::"):
-                acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "sk::" in k:
+                acc[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):
