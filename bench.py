@@ -97,7 +97,7 @@ def main():
     import torch.distributed as dist
 
     import seqkit_amd
-    from seqkit_amd import synth
+    from seqkit_amd import shard, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
@@ -133,8 +133,7 @@ def main():
                                assign=assign.data_ptr(), counts=counts.data_ptr())
             if ev is not None:
                 ev[1].record(stream)
-            if world > 1:
-                dist.all_reduce(counts)                      # the path's only cross-shard state
+            shard.reduce_counts(counts)                      # the path's only cross-shard state (no-op at N=1)
 
     def fence():
         if world > 1:
