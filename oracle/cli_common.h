@@ -8,6 +8,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <spawn.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -147,17 +148,18 @@ static FILE *oc_gzip_writer(const char *path, int use_pigz)
 	if (fd < 0) oc_error("Cannot open file %s for writing.", path);
 	int pp[2];
 	const char *prog = use_pigz ? "pigz" : "gzip";
-	if (pipe(pp) != 0) oc_error("Cannot start %s process.", prog);
-	pid_t pid = fork();
-	if (pid < 0) oc_error("Cannot start %s process.", prog);
-	if (pid == 0) {
-		dup2(pp[0], 0); dup2(fd, 1);
-		close(fd); close(pp[0]); close(pp[1]);
-		/* other writers' pipe ends must not stay open in this child */
-		for (int k = 3; k < 4096; k++) close(k);
-		execlp(prog, prog, "-c", (char *)NULL);
-		_exit(127);
-	}
+	if (pipe2(pp, O_CLOEXEC) != 0) oc_error("Cannot start %s process.", prog);
+	/* Command::spawn() fails in the parent when the program does not exist: posix_spawnp reports that too */
+	posix_spawn_file_actions_t fa;
+	posix_spawn_file_actions_init(&fa);
+	posix_spawn_file_actions_adddup2(&fa, pp[0], 0);
+	posix_spawn_file_actions_adddup2(&fa, fd, 1);
+	char *const av[] = {(char *)prog, (char *)"-c", NULL};
+	pid_t pid;
+	extern char **environ;
+	int rc = posix_spawnp(&pid, prog, &fa, NULL, av, environ);
+	posix_spawn_file_actions_destroy(&fa);
+	if (rc != 0) oc_error("Cannot start %s process.", prog);
 	close(fd); close(pp[0]);
 	if (oc_nchildren < 1024) oc_children[oc_nchildren++] = pid;
 	FILE *f = fdopen(pp[1], "wb");

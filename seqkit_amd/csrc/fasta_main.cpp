@@ -1,0 +1,514 @@
+// fasta — the `fasta` binary of the reference for its per-read hot path, with the per-read arithmetic done by
+// the MI355X library behind include/seqkit_hip.h.  Same command words, arguments, stdin/stdout/file surface,
+// messages and exit codes as the reference (dispatch: src/fasta_main.rs:61-76):
+//
+//   fasta trim by quality <fastq_file> <min_baseq>                 src/fasta_trim_by_quality.rs:10-50
+//   fasta mask by quality <fastq_file> <min_baseq>                 src/fasta_mask_by_quality.rs:11-47
+//   fasta add barcode <fastq_file> <barcode_file>                  src/fasta_add_barcode.rs:11-45
+//   fasta demultiplex [options] <sample_sheet> <fastq_1> [<fastq_2>]   src/fasta_demultiplex.rs:30-265
+//
+// The host owns parsing and I/O and keeps the reference's record-at-a-time ORDER of effects: records are
+// gathered into batches (fixed-stride SoA), the batch goes through the C-ABI, and the results are emitted
+// in input order; an input error that the reference would hit at record i is raised after records < i have
+// been emitted, exactly where the reference would have stopped.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "host_common.h"
+
+using host::error;
+using host::panic;
+
+static const char *USAGE_TOP =
+	"\nUsage:\n"
+	"  fasta check <fasta/fastq>\n"
+	"  fasta to raw <fasta/fastq>\n"
+	"  fasta add base qualities <fasta> <baseq>\n"
+	"  fasta remove base qualities <fastq>\n"
+	"  fasta simplify read ids <fastq_file>\n"
+	"  fasta interleave <fastq_1> <fastq_2>\n"
+	"  fasta deinterleave <interleaved_fastq> <out_prefix>\n"
+	"  fasta split into anchors <fastq> <anchor_len>\n"
+	"  fasta trim <fastq_file>\n"
+	"  fasta trim by quality <fastq_file> <min_baseq>\n"
+	"  fasta mask by quality <fastq_file> <min_baseq>\n"
+	"  fasta gc content <genome.fa> <regions.bed>\n"
+	"  fasta add barcode <fastq_file> <barcode_file> <barcode_format>\n"
+	"  fasta extract dual umi <interleaved_fastq>\n"
+	"  fasta convert basespace <fastq_file>\n"
+	"  fasta demultiplex <sample_sheet> <fastq_1> <fastq_2>\n"
+	"  fasta demultiplex spe <sample_sheet> <fastq_1> <fastq_2>\n"
+	"  fasta statistics <fastq_file>\n";
+static const char *USAGE_TRIM = "\nUsage:\n  fasta trim by quality <fastq_file> <min_baseq>\n";
+static const char *USAGE_MASK = "\nUsage:\n  fasta mask by quality <fastq_file> <min_baseq>\n";
+static const char *USAGE_ADDBC = "\nUsage:\n  fasta add barcode <fastq_file> <barcode_file>\n";
+static const char *USAGE_DEMUX =
+	"\nUsage:\n"
+	"  fasta demultiplex [options] <sample_sheet> <fastq_1> [<fastq_2>]\n"
+	"\n"
+	"Options:\n"
+	"  --parallel      Use pigz (parallel gzip) for compression\n"
+	"  --index1=FASTQ  Path to FASTQ file containing the first index (optional)\n"
+	"  --index2=FASTQ  Path to FASTQ file containing the second index (optional)\n"
+	"  --dry-run=N     Analyze N reads and generate table of indexes found in the run\n"
+	"\n"
+	"Splits a pooled FASTQ file into multiple individual FASTQ files, based on a\n"
+	"sample sheet. Each read in the pooled FASTQ file must carry a BC:xxxxxxxx\n"
+	"field in its header.\n";
+
+static const size_t kBatchBytes = 192u << 20;      // SoA bytes per batch
+static const size_t kBatchRecords = 1u << 18;
+static const size_t kMaxRow = 65535;               // len is u16 at the C-ABI
+
+static void check(int rc, const char *what)
+{
+	if (rc != SK_OK) error("%s failed: %s", what, sk_last_error(host::gpu()));
+}
+
+static uint8_t parse_min_baseq(const std::string &s)
+{
+	uint64_t v;
+	if (!host::parse_uint(s.c_str(), 255, v)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (min_baseq)");
+	return (uint8_t)v;
+}
+
+// a batch of rows packed at a fixed stride
+struct Matrix {
+	std::vector<uint8_t> data;
+	int stride = 1;
+	void pack(const std::vector<const std::string *> &rows, const std::vector<size_t> &lens)
+	{
+		size_t mx = 1;
+		for (size_t l : lens) mx = std::max(mx, l);
+		stride = (int)mx;
+		data.assign(rows.size() * mx, 0);
+		for (size_t r = 0; r < rows.size(); r++) memcpy(data.data() + r * mx, rows[r]->data(), lens[r]);
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// fasta trim by quality
+// ---------------------------------------------------------------------------------------------------------
+struct TrimRec { std::string header, seq, qual; size_t n; bool body; };
+
+static int trim_by_quality(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_TRIM);
+	host::LineReader fq(pos[0]);                                            // :12
+	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :13
+	std::string plus;
+	bool done = false;
+	const char *pending = nullptr;
+	while (!done) {
+		std::vector<TrimRec> recs;
+		size_t maxn = 1;
+		while (recs.size() < kBatchRecords && (recs.size() + 1) * maxn <= kBatchBytes) {
+			TrimRec r;
+			r.body = false; r.n = 0;
+			if (!fq.read_line(r.header)) { done = true; if (fq.bad_utf8()) pending = "I/O error while reading from file."; break; }   // :19
+			if (r.header[0] != '@') { pending = "Invalid FASTQ format encountered."; done = true; break; }           // :20-22
+			// :23 prints the header before the rest of the record is read
+			fq.read_line(r.seq);                                            // :24  (EOF leaves an empty string)
+			if (!fq.bad_utf8()) fq.read_line(plus);                         // :25
+			if (!fq.bad_utf8()) fq.read_line(r.qual);                       // :26
+			if (fq.bad_utf8()) { recs.push_back(std::move(r)); pending = "I/O error while reading from file."; done = true; break; }
+			r.body = true;
+			r.n = host::trim_end_len(r.qual);                               // :31
+			if (r.n > kMaxRow) { pending = "Read longer than 65535 bases: not supported by this build."; done = true; break; }
+			maxn = std::max(maxn, r.n);
+			recs.push_back(std::move(r));
+		}
+		// the batch through the C-ABI: T1, src/fasta_trim_by_quality.rs:28-42
+		std::vector<const std::string *> rows;
+		std::vector<size_t> lens;
+		for (auto &r : recs) if (r.body) { rows.push_back(&r.qual); lens.push_back(r.n); }
+		std::vector<uint16_t> lowest_k(rows.size());
+		if (!rows.empty()) {
+			Matrix q;
+			q.pack(rows, lens);
+			std::vector<uint16_t> len16(lens.begin(), lens.end());
+			check(sk_trim_by_quality(host::gpu(), q.data.data(), len16.data(), q.stride, (int64_t)rows.size(), min_baseq, lowest_k.data()), "sk_trim_by_quality");
+		}
+		size_t k = 0;
+		for (auto &r : recs) {
+			host::out().write(r.header);
+			if (!r.body) break;
+			const size_t lk = lowest_k[k++];
+			if (lk == 0) {                                                  // :44-45
+				host::out().write("N\n+\n!\n", 6);
+			} else {                                                        // :47 — byte slices of seq and qual
+				if (lk > r.seq.size()) panic("byte index out of range of `seq`");
+				if (lk < r.seq.size() && ((uint8_t)r.seq[lk] & 0xC0) == 0x80) panic("byte index is not a char boundary (seq)");
+				if (lk < r.qual.size() && ((uint8_t)r.qual[lk] & 0xC0) == 0x80) panic("byte index is not a char boundary (qual)");
+				host::out().write(r.seq.data(), lk);
+				host::out().write("\n+\n", 3);
+				host::out().write(r.qual.data(), lk);
+				host::out().write("\n", 1);
+			}
+		}
+	}
+	if (pending) error("%s", pending);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fasta mask by quality
+// ---------------------------------------------------------------------------------------------------------
+struct MaskRec { std::string header, seq, qual; bool ascii; };
+
+static size_t u8len(uint8_t b) { return b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4; }
+static uint32_t u8cp(const uint8_t *p, size_t l)
+{
+	if (l == 1) return p[0];
+	if (l == 2) return ((uint32_t)(p[0] & 0x1F) << 6) | (p[1] & 0x3F);
+	if (l == 3) return ((uint32_t)(p[0] & 0x0F) << 12) | ((uint32_t)(p[1] & 0x3F) << 6) | (p[2] & 0x3F);
+	return ((uint32_t)(p[0] & 0x07) << 18) | ((uint32_t)(p[1] & 0x3F) << 12) | ((uint32_t)(p[2] & 0x3F) << 6) | (p[3] & 0x3F);
+}
+
+static int mask_by_quality(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_MASK);
+	host::LineReader fq(pos[0]);                                            // :13
+	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :14
+	std::string plus;
+	bool done = false;
+	const char *pending = nullptr;
+	while (!done) {
+		std::vector<MaskRec> recs;
+		size_t maxn = 1;
+		while (recs.size() < kBatchRecords && (recs.size() + 1) * maxn * 2 <= kBatchBytes) {
+			MaskRec r;
+			if (!fq.read_line(r.header)) { done = true; if (fq.bad_utf8()) pending = "I/O error while reading from file."; break; }   // :20
+			if (r.header[0] != '@') { pending = "Invalid FASTQ format encountered."; done = true; break; }           // :21-23
+			fq.read_line(r.seq);                                            // :28
+			if (!fq.bad_utf8()) fq.read_line(plus);                         // :29
+			if (!fq.bad_utf8()) fq.read_line(r.qual);                       // :30
+			if (fq.bad_utf8()) { pending = "I/O error while reading from file."; done = true; break; }
+			if (!r.seq.empty() && r.seq.back() == '\n') r.seq.pop_back();   // :32
+			if (!r.qual.empty() && r.qual.back() == '\n') r.qual.pop_back();// :33
+			if (r.seq.size() != r.qual.size()) { pending = "Read sequence and base qualities are of different length."; done = true; break; }   // :35-37
+			r.ascii = host::is_ascii(r.seq) && host::is_ascii(r.qual);
+			if (r.seq.size() > kMaxRow) { pending = "Read longer than 65535 bases: not supported by this build."; done = true; break; }
+			maxn = std::max(maxn, r.seq.size());
+			recs.push_back(std::move(r));
+		}
+		// M1 through the C-ABI (byte form; ASCII records only): src/fasta_mask_by_quality.rs:40-43
+		std::vector<const std::string *> srows, qrows;
+		std::vector<size_t> lens;
+		for (auto &r : recs) if (r.ascii) { srows.push_back(&r.seq); qrows.push_back(&r.qual); lens.push_back(r.seq.size()); }
+		Matrix s, q;
+		if (!srows.empty()) {
+			s.pack(srows, lens);
+			q.pack(qrows, lens);
+			std::vector<uint16_t> len16(lens.begin(), lens.end());
+			check(sk_mask_by_quality(host::gpu(), s.data.data(), q.data.data(), len16.data(), s.stride, (int64_t)srows.size(), min_baseq), "sk_mask_by_quality");
+		}
+		size_t k = 0;
+		std::string masked;
+		for (auto &r : recs) {
+			host::out().write(r.header);                                    // :25-26
+			if (r.ascii) {
+				host::out().write(reinterpret_cast<const char *>(s.data.data()) + k * (size_t)s.stride, r.seq.size());
+				k++;
+			} else {
+				// :40-43 iterate chars, and `qual as u8` keeps the low byte of the code point: text semantics that are not
+				// a byte operation, so records with non-ASCII lines stay on the host
+				masked.clear();
+				const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data()), *qp = reinterpret_cast<const uint8_t *>(r.qual.data());
+				size_t i = 0, j = 0;
+				while (i < r.seq.size() && j < r.qual.size()) {
+					const size_t li = u8len(sp[i]), lj = u8len(qp[j]);
+					const uint8_t qb = (uint8_t)u8cp(qp + j, lj);
+					if ((uint8_t)(qb - 33) < min_baseq) masked.push_back('N');
+					else masked.append(r.seq, i, li);
+					i += li; j += lj;
+				}
+				host::out().write(masked);
+			}
+			host::out().write("\n+\n", 3);                                   // :44
+			host::out().write(r.qual);
+			host::out().write("\n", 1);
+		}
+	}
+	if (pending) error("%s", pending);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fasta add barcode — no arithmetic: pure stream work, restated statement by statement
+// ---------------------------------------------------------------------------------------------------------
+static int add_barcode(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 3, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_ADDBC);
+	host::LineReader fq(pos[0]), bf(pos[1]);
+	std::string header, barcode, line;
+	auto rd = [](host::LineReader &r, std::string &s) {
+		const bool ok = r.read_line(s);
+		if (r.bad_utf8()) error("I/O error while reading from file.");
+		return ok;
+	};
+	for (;;) {
+		rd(bf, header);                                                     // :20
+		if (!header.empty() && header[0] == '@') { rd(bf, barcode); rd(bf, line); rd(bf, line); }   // :21-24
+		else if (!header.empty() && header[0] == '>') { rd(bf, barcode); }  // :25-27  (exhausted file: `barcode` keeps its value)
+		if (!rd(fq, header)) break;                                         // :29-31
+		host::out().write(header.data(), host::trim_end_len(header));       // :33
+		host::out().write(" BC:", 4);
+		host::out().write(barcode.data(), host::trim_end_len(barcode));
+		host::out().write("\n", 1);
+		if (header[0] == '@') { for (int k = 0; k < 3; k++) { rd(fq, line); host::out().write(line); } }   // :35-38
+		else if (header[0] == '>') { rd(fq, line); host::out().write(line); }                             // :39-40
+		else error("Invalid FASTQ line:\n%s", header.c_str());              // :41-43
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fasta demultiplex
+// ---------------------------------------------------------------------------------------------------------
+struct Sample {
+	std::string name, barcode;
+	std::unique_ptr<host::GzWriter> out[2];
+	uint64_t total_reads = 0;
+};
+
+struct Cluster {
+	std::string header, l2, l3, l4;           // mate 1 (header with the BC field already removed in header mode)
+	std::string m2[4];                        // mate 2, raw lines
+	std::string barcode;
+};
+
+static std::vector<Sample> *g_samples = nullptr;
+static void close_outputs()
+{
+	if (!g_samples) return;
+	for (auto &s : *g_samples) for (auto &o : s.out) if (o) o->close();
+}
+
+static int demultiplex(int argc, char **argv)
+{
+	std::vector<host::Opt> opts = {{"--parallel", false, false, ""}, {"--index1", true, false, ""}, {"--index2", true, false, ""}, {"--dry-run", true, false, ""}};
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 3) || pos.size() < 2) error("Invalid arguments.\n%s", USAGE_DEMUX);
+	uint64_t dry_run = 0;                                                   // :33-36
+	if (!host::parse_uint(opts[3].value.c_str(), UINT64_MAX, dry_run)) dry_run = 0;
+	if (dry_run == 0 && !opts[3].value.empty()) error("In --dry-run=N, N must be 64-bit positive integer.");
+
+	std::vector<std::unique_ptr<host::LineReader>> fastq, index_fastq;      // :41-55
+	fastq.emplace_back(new host::LineReader(pos[1]));
+	if (pos.size() == 3 && !pos[2].empty()) fastq.emplace_back(new host::LineReader(pos[2]));
+	const bool paired_end = fastq.size() == 2;
+	if (!opts[1].value.empty()) index_fastq.emplace_back(new host::LineReader(opts[1].value));
+	if (!opts[2].value.empty()) index_fastq.emplace_back(new host::LineReader(opts[2].value));
+	auto rd = [](host::LineReader &r, std::string &s) {
+		const bool ok = r.read_line(s);
+		if (r.bad_utf8()) { close_outputs(); error("I/O error while reading from file."); }
+		return ok;
+	};
+
+	fputs("Reading sample sheet...\n", stderr);                             // :58
+	std::vector<Sample> samples;
+	g_samples = &samples;
+	host::at_exit_flush(close_outputs);
+	size_t barcode_len = 0;
+	{
+		host::LineReader sheet(pos[0]);
+		std::string line;
+		while (rd(sheet, line)) {                                           // :63
+			if (line[0] == '#') continue;                                   // :64
+			const size_t off = host::trim_start_off(line);                  // :65 line.trim().split('\t')
+			const std::string t = line.substr(off, host::trim_end_len(line) > off ? host::trim_end_len(line) - off : 0);
+			const size_t tab1 = t.find('\t');
+			if (tab1 == std::string::npos) continue;                        // :66
+			const size_t tab2 = t.find('\t', tab1 + 1);
+			Sample sm;
+			sm.name = t.substr(0, tab1);
+			sm.barcode = t.substr(tab1 + 1, tab2 == std::string::npos ? std::string::npos : tab2 - tab1 - 1);
+			if (sm.barcode.empty()) error("Sample %s has no barcode.", sm.name.c_str());                 // :68
+			if (barcode_len == 0) barcode_len = sm.barcode.size();          // :69-70
+			else if (sm.barcode.size() != barcode_len) error("Barcodes in sample sheet must all be of same length.");   // :71-73
+			if (dry_run > 0) {
+			} else if (paired_end) {                                        // :79-83
+				sm.out[0].reset(new host::GzWriter(sm.name + "_1.fq.gz"));
+				sm.out[1].reset(new host::GzWriter(sm.name + "_2.fq.gz"));
+			} else {                                                        // :84-87
+				sm.out[0].reset(new host::GzWriter(sm.name + ".fq.gz"));
+			}
+			samples.push_back(std::move(sm));
+		}
+	}
+	for (size_t s = 0; s < samples.size(); s++)                             // :98-104
+		for (size_t k = s + 1; k < samples.size(); k++)
+			if (samples[s].name == samples[k].name) error("Sample %s is listed multiple times in sample sheet.", samples[s].name.c_str());
+
+	const int S = (int)samples.size();
+	if (S > SK_MAX_SAMPLES) error("Sample sheet has more than %d samples: not supported by this build.", SK_MAX_SAMPLES);
+	if (barcode_len > SK_MAX_BARCODE_LEN) error("Barcodes longer than %d bytes are not supported by this build.", SK_MAX_BARCODE_LEN);
+	{
+		std::vector<uint8_t> table((size_t)S * barcode_len);
+		for (int s = 0; s < S; s++) memcpy(table.data() + (size_t)s * barcode_len, samples[s].barcode.data(), barcode_len);
+		check(sk_set_barcodes(host::gpu(), table.data(), S, (int)barcode_len, 1 /* MAX_BARCODE_DIFFERENCE :168 */), "sk_set_barcodes");
+	}
+
+	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single");     // :106-107
+	uint64_t total_reads = 0, identified_reads = 0;
+	std::unordered_map<std::string, uint64_t> extra_barcodes;
+	std::vector<std::string> extra_order;            // first-seen order (the reference's HashMap order is arbitrary)
+
+	bool done = false;
+	std::string pending;                             // error text to raise after the batch
+	int pending_code = 255;
+	std::string line, umi;
+	while (!done) {
+		// ---- gather a batch of clusters (all lines are consumed here; :239-246 consumes them for unassigned reads too)
+		std::vector<Cluster> cl;
+		size_t want = kBatchRecords;
+		if (dry_run > 0) want = (size_t)std::min<uint64_t>(want, dry_run - total_reads);
+		while (cl.size() < want) {
+			Cluster c;
+			if (!rd(*fastq[0], c.header)) { done = true; break; }           // :117
+			if (c.header[0] != '@') { pending = "Invalid FASTQ header line:\n" + c.header; done = true; break; }   // :118-120
+			if (!index_fastq.empty()) {                                     // :126-136
+				bool bad = false;
+				for (auto &ifq : index_fastq) {
+					if (!c.barcode.empty()) c.barcode += "+";
+					rd(*ifq, line);
+					if (line.empty() || line[0] != '@') { pending = "assertion failed: line.starts_with('@')"; pending_code = 101; bad = true; break; }
+					rd(*ifq, line);
+					c.barcode.append(line, 0, host::trim_end_len(line));
+					rd(*ifq, line);
+					if (line.empty() || line[0] != '+') { pending = "assertion failed: line.starts_with('+')"; pending_code = 101; bad = true; break; }
+					rd(*ifq, line);
+				}
+				if (bad) { done = true; break; }
+			} else {                                                        // :137-146
+				size_t st, en;
+				if (!host::find_bc_field(c.header, st, en)) { pending = "No BC:xxxx field found."; done = true; break; }
+				c.barcode.assign(c.header, st + 4, en - st - 4);
+				c.header.erase(st, en - st);
+			}
+			if (c.barcode.size() != barcode_len) {                          // :148-150
+				char buf[512];
+				snprintf(buf, sizeof buf, "Sequenced barcode %s is of different length (%zu nt) than barcodes in the sample sheet (%zu nt).",
+				         c.barcode.c_str(), c.barcode.size(), barcode_len);
+				pending = buf; done = true; break;
+			}
+			rd(*fastq[0], c.l2); rd(*fastq[0], c.l3); rd(*fastq[0], c.l4);
+			if (paired_end) for (int k = 0; k < 4; k++) rd(*fastq[1], c.m2[k]);
+			cl.push_back(std::move(c));
+		}
+
+		// ---- D1+D2+D3 for the batch through the C-ABI: src/fasta_demultiplex.rs:154-194,269-277
+		const size_t nb = cl.size();
+		std::vector<int32_t> assign(nb);
+		std::vector<uint8_t> lowest(nb);
+		std::vector<int16_t> first(nb), last(nb);
+		if (nb > 0 && barcode_len > 0) {
+			std::vector<uint8_t> bc(nb * barcode_len);
+			for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * barcode_len, cl[i].barcode.data(), barcode_len);
+			check(sk_demux_assign(host::gpu(), bc.data(), (int)barcode_len, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
+		} else {
+			std::fill(assign.begin(), assign.end(), SK_ASSIGN_NONE);        // empty sheet: lowest_diff stays usize::MAX
+		}
+
+		// ---- emit in input order ---------------------------------------------------------------------------------
+		for (size_t i = 0; i < nb; i++) {
+			Cluster &c = cl[i];
+			total_reads += 1;                                               // :169
+			bool write_read_out = false;
+			if (assign[i] >= 0) {                                           // :173-179
+				identified_reads += 1;
+				samples[assign[i]].total_reads += 1;
+				write_read_out = !(dry_run > 0);
+			} else if (assign[i] == SK_ASSIGN_AMBIGUOUS) {                  // :181-189
+				const Sample &a = samples[first[i]], &b = samples[last[i]];
+				fprintf(stderr, "WARNING: Sequenced barcode %s was an equally good match (%u mismatches) for samples %s (%s) and %s (%s), and was therefore not assigned to any sample.\n",
+				        c.barcode.c_str(), (unsigned)lowest[i], a.name.c_str(), a.barcode.c_str(), b.name.c_str(), b.barcode.c_str());
+			} else if (dry_run > 0) {                                       // :190-194
+				auto it = extra_barcodes.find(c.barcode);
+				if (it == extra_barcodes.end()) { extra_barcodes.emplace(c.barcode, 1); extra_order.push_back(c.barcode); }
+				else it->second += 1;
+			}
+			if (!write_read_out) continue;
+			Sample &sm = samples[assign[i]];
+			umi.clear();                                                    // :200-203 (chars().zip(chars()))
+			{
+				const uint8_t *sp = reinterpret_cast<const uint8_t *>(sm.barcode.data()), *bp = reinterpret_cast<const uint8_t *>(c.barcode.data());
+				size_t a = 0, b = 0;
+				while (a < sm.barcode.size() && b < c.barcode.size()) {
+					const size_t la = u8len(sp[a]), lb = u8len(bp[b]);
+					if (la == 1 && sp[a] == 'U') umi.append(c.barcode, b, lb);
+					a += la; b += lb;
+				}
+			}
+			sm.out[0]->write(c.header.data(), host::trim_end_len(c.header));   // :206
+			if (!umi.empty()) { sm.out[0]->write(" UMI:", 5); sm.out[0]->write(umi); }   // :207
+			sm.out[0]->write("\n", 1);                                      // :208
+			sm.out[0]->write(c.l2); sm.out[0]->write(c.l3); sm.out[0]->write(c.l4);      // :209-212
+			if (paired_end) {                                               // :215-237
+				std::string &h2 = c.m2[0];
+				if (index_fastq.empty()) {
+					size_t st, en;
+					if (host::find_bc_field(h2, st, en)) h2.erase(st, en - st);
+				}
+				sm.out[1]->write(h2.data(), host::trim_end_len(h2));
+				if (!umi.empty()) { sm.out[1]->write(" UMI:", 5); sm.out[1]->write(umi); }
+				sm.out[1]->write("\n", 1);
+				sm.out[1]->write(c.m2[1]); sm.out[1]->write(c.m2[2]); sm.out[1]->write(c.m2[3]);
+			}
+		}
+		if (dry_run > 0 && total_reads >= dry_run) done = true;             // :248
+	}
+	if (!pending.empty()) {
+		close_outputs();
+		if (pending_code == 101) panic(pending.c_str());
+		error("%s", pending.c_str());
+	}
+
+	if (dry_run > 0) {                                                      // :251-261
+		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);
+		struct Ent { const std::string *label; uint64_t count; };
+		std::vector<Ent> ents;
+		for (auto &s : samples) ents.push_back({&s.name, s.total_reads});
+		for (auto &b : extra_order) ents.push_back({&b, extra_barcodes[b]});
+		std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.count < b.count; });
+		std::reverse(ents.begin(), ents.end());
+		// The reference slices entries[0..100] and panics when there are fewer than 100 entries (:258); this build
+		// prints the entries there are (documented deviation).
+		const size_t lim = std::min<size_t>(100, ents.size());
+		for (size_t i = 0; i < lim; i++) {
+			char buf[64];
+			snprintf(buf, sizeof buf, ": %llu\n", (unsigned long long)ents[i].count);
+			host::out().write("- ", 2); host::out().write(*ents[i].label); host::out().write(buf, strlen(buf));
+		}
+	}
+	close_outputs();
+	host::out().flush();
+	fprintf(stderr, "%llu / %llu (%s%%) clusters carried a barcode matching one of the provided samples.\n",      // :263-264
+	        (unsigned long long)identified_reads, (unsigned long long)total_reads,
+	        host::fmt_pct((double)identified_reads / (double)total_reads * 100.0).c_str());
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	int rc = 0;
+	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
+	if (argc >= 4 && is(1, "trim") && is(2, "by") && is(3, "quality")) rc = trim_by_quality(argc, argv);
+	else if (argc >= 4 && is(1, "mask") && is(2, "by") && is(3, "quality")) rc = mask_by_quality(argc, argv);
+	else if (argc >= 3 && is(1, "add") && is(2, "barcode")) rc = add_barcode(argc, argv);
+	else if (argc >= 2 && is(1, "demultiplex")) rc = demultiplex(argc, argv);
+	else fprintf(stderr, "%s\n", USAGE_TOP);
+	host::out().flush();
+	return rc;
+}

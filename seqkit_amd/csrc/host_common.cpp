@@ -1,0 +1,314 @@
+// host_common.cpp — see host_common.h.
+#include "host_common.h"
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cerrno>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+namespace host {
+
+static void (*g_flush)() = nullptr;
+void at_exit_flush(void (*fn)()) { g_flush = fn; }
+
+// error! of src/common.rs:11-16: eprint!("ERROR: "); eprintln!(...); exit(-1)
+void error(const char *fmt, ...)
+{
+	if (g_flush) g_flush();
+	out().flush();
+	fputs("ERROR: ", stderr);
+	va_list ap;
+	va_start(ap, fmt);
+	vfprintf(stderr, fmt, ap);
+	va_end(ap);
+	fputc('\n', stderr);
+	fflush(stderr);
+	_exit(255);
+}
+
+void panic(const char *what)
+{
+	if (g_flush) g_flush();
+	out().flush();
+	fprintf(stderr, "thread 'main' panicked: %s\n", what);
+	fflush(stderr);
+	_exit(101);
+}
+
+// ---- UTF-8 / whitespace --------------------------------------------------------------------------------
+bool utf8_valid(const uint8_t *s, size_t n)
+{
+	size_t i = 0;
+	while (i < n) {
+		const uint8_t b = s[i];
+		if (b < 0x80) { i++; continue; }
+		size_t need;
+		uint8_t lo = 0x80, hi = 0xBF;
+		if (b >= 0xC2 && b <= 0xDF) need = 1;
+		else if (b >= 0xE0 && b <= 0xEF) { need = 2; if (b == 0xE0) lo = 0xA0; if (b == 0xED) hi = 0x9F; }
+		else if (b >= 0xF0 && b <= 0xF4) { need = 3; if (b == 0xF0) lo = 0x90; if (b == 0xF4) hi = 0x8F; }
+		else return false;
+		if (i + need >= n) return false;                 // continuation bytes i+1 .. i+need must exist
+		if (s[i + 1] < lo || s[i + 1] > hi) return false;
+		for (size_t k = 2; k <= need; k++)
+			if ((s[i + k] & 0xC0) != 0x80) return false;
+		i += need + 1;
+	}
+	return true;
+}
+
+static bool rust_ws(uint32_t c)
+{
+	return (c >= 0x09 && c <= 0x0D) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+	       c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+
+static uint32_t decode(const uint8_t *p, size_t l)
+{
+	if (l == 1) return p[0];
+	if (l == 2) return ((uint32_t)(p[0] & 0x1F) << 6) | (p[1] & 0x3F);
+	if (l == 3) return ((uint32_t)(p[0] & 0x0F) << 12) | ((uint32_t)(p[1] & 0x3F) << 6) | (p[2] & 0x3F);
+	return ((uint32_t)(p[0] & 0x07) << 18) | ((uint32_t)(p[1] & 0x3F) << 12) | ((uint32_t)(p[2] & 0x3F) << 6) | (p[3] & 0x3F);
+}
+
+size_t trim_end_len(const std::string &s)
+{
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(s.data());
+	size_t n = s.size();
+	while (n > 0) {
+		size_t i = n - 1;
+		while (i > 0 && (p[i] & 0xC0) == 0x80 && n - i < 4) i--;
+		if (!rust_ws(decode(p + i, n - i))) break;
+		n = i;
+	}
+	return n;
+}
+
+size_t trim_start_off(const std::string &s)
+{
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(s.data());
+	size_t off = 0, n = s.size();
+	while (off < n) {
+		const uint8_t b = p[off];
+		size_t l = b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4;
+		if (l > n - off) l = n - off;
+		if (!rust_ws(decode(p + off, l))) break;
+		off += l;
+	}
+	return off;
+}
+
+bool is_ascii(const std::string &s)
+{
+	for (unsigned char c : s)
+		if (c >= 0x80) return false;
+	return true;
+}
+
+static bool bc_class(char c)
+{
+	switch (c) {
+	case 'A': case 'C': case 'G': case 'T': case 'N': case 'a': case 'c': case 'g': case 't': case 'n': case '+': return true;
+	default: return false;
+	}
+}
+
+// src/fasta_demultiplex.rs:38 — literal " BC:" followed by a greedy run (>= 1) of the class; leftmost match
+bool find_bc_field(const std::string &h, size_t &start, size_t &end)
+{
+	const size_t n = h.size();
+	for (size_t i = 0; i + 5 <= n; i++) {
+		if (h[i] == ' ' && h[i + 1] == 'B' && h[i + 2] == 'C' && h[i + 3] == ':' && bc_class(h[i + 4])) {
+			size_t e = i + 5;
+			while (e < n && bc_class(h[e])) e++;
+			start = i; end = e;
+			return true;
+		}
+	}
+	return false;
+}
+
+bool parse_uint(const char *s, uint64_t max, uint64_t &out)
+{
+	if (*s == '+') s++;
+	if (!*s) return false;
+	uint64_t v = 0;
+	for (; *s; s++) {
+		if (*s < '0' || *s > '9') return false;
+		const uint64_t d = (uint64_t)(*s - '0');
+		if (v > (max - d) / 10) return false;
+		v = v * 10 + d;
+	}
+	out = v;
+	return true;
+}
+
+std::string fmt_pct(double v)
+{
+	char buf[64];
+	if (std::isnan(v)) return "NaN";
+	if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+	snprintf(buf, sizeof buf, "%.1f", v);
+	return buf;
+}
+
+// ---- docopt grammar ------------------------------------------------------------------------------------
+bool parse_args(int argc, char **argv, int first, std::vector<Opt> &opts, std::vector<std::string> &pos, size_t max_pos)
+{
+	bool only_pos = false;
+	for (int i = first; i < argc; i++) {
+		const char *a = argv[i];
+		if (!only_pos && strcmp(a, "--") == 0) { only_pos = true; continue; }
+		if (!only_pos && a[0] == '-' && a[1] == '-') {
+			const char *eq = strchr(a, '=');
+			const size_t nl = eq ? (size_t)(eq - a) : strlen(a);
+			int hit = -1, nh = 0;
+			for (size_t k = 0; k < opts.size(); k++) {
+				if (strlen(opts[k].name) == nl && strncmp(opts[k].name, a, nl) == 0) { hit = (int)k; nh = 1; break; }
+				if (strncmp(opts[k].name, a, nl) == 0) { hit = (int)k; nh++; }
+			}
+			if (nh != 1) return false;
+			Opt &o = opts[hit];
+			if (o.takes_value) {
+				if (eq) o.value = eq + 1;
+				else if (i + 1 < argc) o.value = argv[++i];
+				else return false;
+			} else if (eq) {
+				return false;
+			}
+			o.present = true;
+			continue;
+		}
+		if (!only_pos && a[0] == '-' && a[1] != 0) return false;      // the grammar has no short options
+		if (pos.size() >= max_pos) return false;
+		pos.push_back(a);
+	}
+	return true;
+}
+
+// ---- LineReader ------------------------------------------------------------------------------------------
+LineReader::LineReader(const std::string &path)
+{
+	// src/common.rs:88-103: "-" = stdin, "*.gz" = gzip stream, anything else is read as it is
+	if (path == "-") {
+		fd_ = 0;
+	} else {
+		fd_ = open(path.c_str(), O_RDONLY);
+		if (fd_ < 0) error("Cannot open file %s for reading.", path.c_str());
+		if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+			gz_ = gzdopen(fd_, "rb");                 // inflates every member of the file, like `gunzip -c`
+			if (!gz_) error("Cannot start gunzip process.");
+			gzbuffer(gz_, 1 << 18);
+		}
+	}
+	buf_.resize(1 << 18);
+}
+
+LineReader::~LineReader()
+{
+	if (gz_) gzclose(gz_);
+	else if (fd_ > 0) close(fd_);
+}
+
+bool LineReader::fill()
+{
+	if (eof_) return false;
+	ssize_t r;
+	if (gz_) {
+		r = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+	} else {
+		do { r = read(fd_, buf_.data(), buf_.size()); } while (r < 0 && errno == EINTR);
+	}
+	if (r < 0) error("I/O error while reading from file.");
+	pos_ = 0;
+	end_ = (size_t)r;
+	if (r == 0) { eof_ = true; return false; }
+	return true;
+}
+
+bool LineReader::read_line(std::string &line)
+{
+	line.clear();
+	if (bad_) return false;
+	for (;;) {
+		if (pos_ == end_ && !fill()) break;
+		const uint8_t *p = buf_.data() + pos_;
+		const uint8_t *nl = static_cast<const uint8_t *>(memchr(p, '\n', end_ - pos_));
+		if (nl) {
+			line.append(reinterpret_cast<const char *>(p), (size_t)(nl - p) + 1);
+			pos_ += (size_t)(nl - p) + 1;
+			break;
+		}
+		line.append(reinterpret_cast<const char *>(p), end_ - pos_);
+		pos_ = end_;
+	}
+	if (!line.empty() && !utf8_valid(reinterpret_cast<const uint8_t *>(line.data()), line.size())) {
+		bad_ = true;
+		line.clear();
+		return false;
+	}
+	return !line.empty();
+}
+
+// ---- GzWriter --------------------------------------------------------------------------------------------
+GzWriter::GzWriter(const std::string &path)
+{
+	gz_ = gzopen(path.c_str(), "wb6");
+	if (!gz_) error("Cannot open file %s for writing.", path.c_str());
+	gzbuffer(gz_, 1 << 18);
+}
+GzWriter::~GzWriter() { close(); }
+void GzWriter::write(const char *p, size_t n)
+{
+	while (n > 0) {
+		const unsigned c = n > (1u << 30) ? (1u << 30) : (unsigned)n;
+		if (gzwrite(gz_, p, c) <= 0) return;      // write errors are ignored like the reference (#![allow(unused_must_use)])
+		p += c; n -= c;
+	}
+}
+void GzWriter::close()
+{
+	if (gz_) { gzclose(gz_); gz_ = nullptr; }
+}
+
+// ---- stdout ------------------------------------------------------------------------------------------------
+void Out::write(const char *p, size_t n)
+{
+	buf_.append(p, n);
+	if (buf_.size() >= (1u << 20)) flush();
+}
+void Out::flush()
+{
+	size_t off = 0;
+	while (off < buf_.size()) {
+		const ssize_t w = ::write(1, buf_.data() + off, buf_.size() - off);
+		if (w <= 0) break;
+		off += (size_t)w;
+	}
+	buf_.clear();
+}
+Out &out()
+{
+	static Out o;
+	return o;
+}
+
+// ---- GPU ---------------------------------------------------------------------------------------------------
+sk_ctx *gpu()
+{
+	static sk_ctx *ctx = nullptr;
+	if (!ctx) {
+		int dev = 0;
+		if (const char *e = getenv("SEQKIT_GPU")) dev = atoi(e);
+		const int rc = sk_create(dev, &ctx);
+		if (rc != SK_OK) error("No usable MI355X for the seqkit HIP path (%s); this build has no CPU fallback.", sk_last_error(nullptr));
+	}
+	return ctx;
+}
+
+}  // namespace host

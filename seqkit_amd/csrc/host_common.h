@@ -1,0 +1,88 @@
+// host_common.h — host-side plumbing of the `fasta` / `sam` binaries that sit above the C-ABI.
+//
+// Mirrors the reference's src/common.rs for the hot-path commands: the error!/exit(-1) convention
+// (:11-16), docopt-style argument grammar (:18-22), FileReader (:83-112: "-" = stdin, "*.gz" = gzip
+// stream, strict line reads that demand valid UTF-8) and GzipWriter (:49-81).  Differences that do not
+// change any byte a user can observe: gzip streams are read and written in-process with zlib instead of
+// through `gunzip`/`gzip` child processes, and output is buffered.
+#pragma once
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "seqkit_hip.h"
+
+namespace host {
+
+// ---- process exit conventions ------------------------------------------------------------------------
+[[noreturn]] void error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));   // "ERROR: ...\n", status 255
+[[noreturn]] void panic(const char *what);                                              // a Rust panic: status 101
+void at_exit_flush(void (*fn)());                                                       // run before error()/panic() exit
+
+// ---- Rust std text semantics used on the path --------------------------------------------------------
+bool utf8_valid(const uint8_t *s, size_t n);             // what BufRead::read_line accepts
+size_t trim_end_len(const std::string &s);               // str::trim_end(): Unicode White_Space (0x1C..0x1F are NOT)
+size_t trim_start_off(const std::string &s);             // offset after leading White_Space
+bool is_ascii(const std::string &s);
+bool find_bc_field(const std::string &h, size_t &start, size_t &end);   // regex " BC:[ACGTNacgtn+]+", leftmost-first
+bool parse_uint(const char *s, uint64_t max, uint64_t &out);            // str::parse::<uN>(): [+]digits, no overflow
+std::string fmt_pct(double v);                           // "{:.1}" incl. NaN / inf spellings
+
+// ---- argument grammar ----------------------------------------------------------------------------------
+struct Opt { const char *name; bool takes_value; bool present; std::string value; };
+// long options only (unique-prefix match, --o=v and --o v, "--" ends options, "-" is a positional)
+bool parse_args(int argc, char **argv, int first, std::vector<Opt> &opts, std::vector<std::string> &pos, size_t max_pos);
+
+// ---- line reader -----------------------------------------------------------------------------------------
+class LineReader {
+public:
+	explicit LineReader(const std::string &path);        // exits with the reference's message when it cannot open
+	~LineReader();
+	LineReader(const LineReader &) = delete;
+	LineReader &operator=(const LineReader &) = delete;
+	// read_line: clears `line`, reads through '\n' (kept); false at EOF.  Invalid UTF-8 sets bad_utf8() and
+	// returns false: the caller finishes the records read so far, then reports the I/O error like the reference.
+	bool read_line(std::string &line);
+	bool bad_utf8() const { return bad_; }
+private:
+	bool fill();
+	gzFile gz_ = nullptr;
+	int fd_ = -1;
+	std::vector<uint8_t> buf_;
+	size_t pos_ = 0, end_ = 0;
+	bool eof_ = false, bad_ = false;
+};
+
+// ---- gzip writer (one per output file) -----------------------------------------------------------------
+class GzWriter {
+public:
+	explicit GzWriter(const std::string &path);          // "Cannot open file {} for writing."
+	~GzWriter();
+	GzWriter(const GzWriter &) = delete;
+	GzWriter &operator=(const GzWriter &) = delete;
+	void write(const char *p, size_t n);
+	void write(const std::string &s) { write(s.data(), s.size()); }
+	void close();
+private:
+	gzFile gz_ = nullptr;
+};
+
+// ---- buffered stdout -----------------------------------------------------------------------------------
+class Out {
+public:
+	void write(const char *p, size_t n);
+	void write(const std::string &s) { write(s.data(), s.size()); }
+	void flush();
+private:
+	std::string buf_;
+};
+Out &out();
+
+// ---- the GPU context (created on first use; no CPU fallback) -------------------------------------------
+sk_ctx *gpu();
+
+}  // namespace host

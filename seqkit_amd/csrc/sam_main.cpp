@@ -1,0 +1,327 @@
+// sam — the `sam` binary of the reference for `sam statistics` and `sam fragment lengths`, with the per-record
+// flag / TLEN reduction done by the MI355X library behind include/seqkit_hip.h (dispatch: src/sam_main.rs:50-53).
+//
+//   sam statistics [--on-target=BED] <bam_file>                         src/sam_statistics.rs:14-116
+//   sam fragment lengths [--max-frag-size=F] [--reads=N] <bam_file>     src/sam_fragment_lengths.rs:14-48
+//
+// The reference reads BAM through rust-htslib; this host walks the BGZF/BAM container itself (SAMv1 §4.2: BGZF is a
+// series of gzip members; after the header every record is block_size:u32 + a 32-byte fixed core) and hands the core
+// columns flag / refID / next_refID / tlen to the device as SoA batches.  Order-dependent pieces stay here, as
+// SURVEY.md §8(e) lists them: the --reads=N early stop and the --on-target sweep (S2, not part of the device path).
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_common.h"
+
+using host::error;
+using host::panic;
+
+static const char *USAGE_TOP =
+	"\nUsage:\n"
+	"  sam merge <bam_files>...\n  sam consensus <bam_file>\n  sam count <bam_file> <regions.bed>\n  sam coverage histogram <bam_file>\n"
+	"  sam fragments <bam_file>\n  sam fragment lengths <bam_file>\n  sam mark duplicates <bam_file>\n  sam minimize <bam_file>\n"
+	"  sam statistics <bam_file>\n  sam subsample <bam_file> <fraction>  \n  sam tags from qname <bam_file>\n  sam qname from tags <bam_file>\n"
+	"  sam trim qnames <bam_file>  \n\nExtract reads from BAM files:  \n  sam to fasta <bam_file> <out_prefix>\n  sam to fastq <bam_file> <out_prefix>  \n"
+	"  sam to interleaved fasta <bam_file>\n  sam to interleaved fastq <bam_file>\n  sam to interleaved raw <bam_file>\n  sam to raw <bam_file> <out_prefix>\n";
+static const char *USAGE_STATS =
+	"\nUsage:\n  sam statistics [options] <bam_file>\n\nOptions:\n  --on-target=BED   Count on-target% for regions in BED file [optional]\n";
+static const char *USAGE_FRAG =
+	"\nUsage:\n  sam fragment lengths [options] <bam_file>\n\nOptions:\n"
+	"  --max-frag-size=F     Maximum fragment size [default: 5000]\n"
+	"  --reads=N             Finish after analyzing this many reads [default: Inf]\n";
+
+static void check(int rc, const char *what)
+{
+	if (rc != SK_OK) error("%s failed: %s", what, sk_last_error(host::gpu()));
+}
+
+// ---- BGZF/BAM container walk ---------------------------------------------------------------------------------
+struct BamCore { int32_t tid, pos; uint16_t flag; int32_t mtid, mpos, tlen, end_pos; };
+
+class BamStream {
+public:
+	explicit BamStream(const std::string &path) : path_(path)
+	{
+		if (path == "-") gz_ = gzdopen(0, "rb");
+		else gz_ = gzopen(path.c_str(), "rb");
+		if (!gz_) {
+			if (path == "-") error("Failed to read BAM file from standard input.");
+			error("Cannot open BAM file '%s'", path.c_str());
+		}
+		gzbuffer(gz_, 1 << 20);
+		uint8_t h[8];
+		if (!get(h, 8) || memcmp(h, "BAM\1", 4) != 0) open_fail();
+		skip(le32(h + 4));
+		if (!get(h, 4)) open_fail();
+		const uint32_t n_ref = le32(h);
+		for (uint32_t i = 0; i < n_ref; i++) {
+			if (!get(h, 4)) open_fail();
+			const uint32_t l_name = le32(h);
+			std::string name(l_name, '\0');
+			if (l_name && !get(reinterpret_cast<uint8_t *>(&name[0]), l_name)) open_fail();
+			if (!name.empty() && name.back() == '\0') name.pop_back();
+			names.push_back(name);
+			if (!get(h, 4)) open_fail();
+		}
+	}
+	~BamStream() { if (gz_) gzclose(gz_); }
+	// next record; want_end computes cigar().end_pos() (needed only by the on-target sweep for unpaired reads)
+	bool next(BamCore &c, bool want_end)
+	{
+		uint8_t h[4];
+		const int r = gzread(gz_, h, 4);
+		if (r == 0) return false;
+		if (r < 0) error("Invalid BAM record.");
+		if (r != 4) error("BAM file ended prematurely.");
+		const uint32_t block_size = le32(h);
+		if (block_size < 32) error("Invalid BAM record.");
+		uint8_t core[32];
+		need(core, 32);
+		c.tid = (int32_t)le32(core + 0);
+		c.pos = (int32_t)le32(core + 4);
+		const uint32_t l_read_name = core[8];
+		const uint32_t n_cigar = (uint32_t)core[12] | ((uint32_t)core[13] << 8);
+		c.flag = (uint16_t)(core[14] | (core[15] << 8));
+		c.mtid = (int32_t)le32(core + 20);
+		c.mpos = (int32_t)le32(core + 24);
+		c.tlen = (int32_t)le32(core + 28);
+		c.end_pos = c.pos;
+		uint32_t rest = block_size - 32;
+		if (want_end && rest >= l_read_name + 4 * n_cigar) {
+			var_.resize(l_read_name + 4 * n_cigar);
+			need(var_.data(), var_.size());
+			rest -= (uint32_t)var_.size();
+			int64_t e = c.pos;
+			for (uint32_t k = 0; k < n_cigar; k++) {
+				const uint32_t op = le32(var_.data() + l_read_name + 4 * k);
+				const uint32_t code = op & 15, len = op >> 4;
+				if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) e += len;   // M D N = X consume the reference
+			}
+			c.end_pos = (int32_t)e;
+		}
+		skip(rest);
+		return true;
+	}
+	std::vector<std::string> names;
+private:
+	[[noreturn]] void open_fail() { error("Cannot open BAM file '%s'", path_.c_str()); }
+	static uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+	bool get(uint8_t *dst, size_t n)
+	{
+		size_t got = 0;
+		while (got < n) {
+			const int r = gzread(gz_, dst + got, (unsigned)(n - got));
+			if (r <= 0) return false;
+			got += (size_t)r;
+		}
+		return true;
+	}
+	void need(uint8_t *dst, size_t n)
+	{
+		size_t got = 0;
+		while (got < n) {
+			const int r = gzread(gz_, dst + got, (unsigned)(n - got));
+			if (r < 0) error("Invalid BAM record.");
+			if (r == 0) error("BAM file ended prematurely.");
+			got += (size_t)r;
+		}
+	}
+	void skip(uint32_t n)
+	{
+		uint8_t buf[1 << 14];
+		while (n) {
+			const uint32_t c = n > sizeof buf ? (uint32_t)sizeof buf : n;
+			need(buf, c);
+			n -= c;
+		}
+	}
+	std::string path_;
+	gzFile gz_ = nullptr;
+	std::vector<uint8_t> var_;
+};
+
+static const size_t kBatch = 4u << 20;
+
+struct Columns {
+	std::vector<uint16_t> flag;
+	std::vector<int32_t> tid, mtid, tlen, pos, mpos, end_pos;
+	void clear() { flag.clear(); tid.clear(); mtid.clear(); tlen.clear(); pos.clear(); mpos.clear(); end_pos.clear(); }
+	void push(const BamCore &c, bool extra)
+	{
+		flag.push_back(c.flag); tid.push_back(c.tid); mtid.push_back(c.mtid); tlen.push_back(c.tlen);
+		if (extra) { pos.push_back(c.pos); mpos.push_back(c.mpos); end_pos.push_back(c.end_pos); }
+	}
+};
+
+static std::string expand_home(const std::string &path)      // PathArgs::get_path, src/common.rs:28-38
+{
+	if (!path.empty() && path[0] == '~')
+		if (const char *home = getenv("HOME")) return std::string(home) + path.substr(1);
+	return path;
+}
+
+// ---- sam statistics ----------------------------------------------------------------------------------------------
+struct Region { int64_t start, end; };
+
+static int statistics(int argc, char **argv)
+{
+	std::vector<host::Opt> opts = {{"--on-target", true, false, ""}};
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_STATS);
+	const std::string bam_path = expand_home(pos[0]), targets_path = expand_home(opts[0].value);     // :17-18
+	const int64_t max_frag_len = 5000;                                                                 // :19
+	BamStream bam(bam_path);
+
+	std::vector<std::vector<Region>> target_regions;                                                   // :26-54
+	if (!targets_path.empty()) {
+		fputs("Reading target regions into memory...\n", stderr);
+		target_regions.resize(bam.names.size());
+		host::LineReader bed(targets_path);
+		std::string line;
+		for (;;) {
+			const bool ok = bed.read_line(line);
+			if (bed.bad_utf8()) error("I/O error while reading from file.");
+			if (!ok) break;
+			const size_t off = host::trim_start_off(line), end = host::trim_end_len(line);
+			if (end <= off || line[0] == '#') continue;                                                // :37
+			const std::string t = line.substr(off, end - off);
+			std::vector<std::string> cols;
+			size_t a = 0;
+			for (;;) { const size_t b = t.find('\t', a); cols.push_back(t.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; }
+			if (cols.size() < 3) error("Invalid line in BED file %s:\n%s", targets_path.c_str(), line.c_str());
+			int tid = -1;
+			for (size_t k = 0; k < bam.names.size(); k++) if (bam.names[k] == cols[0]) { tid = (int)k; break; }
+			if (tid < 0) error("Chromosome %s is listed in target region BED file, but is not found in BAM file.", cols[0].c_str());
+			uint64_t s, e;
+			if (!host::parse_uint(cols[1].c_str(), INT64_MAX, s) || !host::parse_uint(cols[2].c_str(), INT64_MAX, e)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (BED)");
+			target_regions[tid].push_back({(int64_t)s + 1, (int64_t)e});                               // :44-47
+		}
+		for (auto &v : target_regions) std::sort(v.begin(), v.end(), [](const Region &a, const Region &b) { return a.start < b.start; });   // :51-53
+	}
+	const bool on_target = !target_regions.empty();
+
+	uint64_t counters[3] = {0, 0, 0};
+	uint64_t total_fragments = 0, on_target_fragments = 0;
+	Columns col;
+	BamCore c;
+	bool more = true;
+	while (more) {
+		col.clear();
+		while (col.flag.size() < kBatch && (more = bam.next(c, on_target))) col.push(c, on_target);
+		const int64_t n = (int64_t)col.flag.size();
+		if (n == 0) break;
+		// S1 on the device: src/sam_statistics.rs:63-69
+		check(sk_bam_flag_tlen(host::gpu(), col.flag.data(), nullptr, nullptr, nullptr, n, 0, counters, nullptr, nullptr), "sk_bam_flag_tlen");
+		if (!on_target) continue;
+		// S2 (--on-target) stays on the host: src/sam_statistics.rs:72-106
+		for (int64_t i = 0; i < n; i++) {
+			const uint16_t f = col.flag[i];
+			if ((f & 0x100) || (f & 0x800)) continue;
+			if (f & 0x4) continue;
+			int64_t start, end;
+			if (f & 0x1) {
+				if (f & 0x8) continue;
+				if (col.tid[i] != col.mtid[i]) continue;
+				if (col.pos[i] > col.mpos[i] || (col.pos[i] == col.mpos[i] && !(f & 0x40))) continue;
+				int64_t tl = col.tlen[i];
+				if (tl < 0) tl = -tl;
+				if (tl > max_frag_len) continue;
+				start = (int64_t)col.pos[i] + 1;
+				end = start + tl;
+			} else {
+				start = (int64_t)col.pos[i] + 1;
+				end = (int64_t)col.end_pos[i] + 1;
+			}
+			total_fragments += 1;
+			if (col.tid[i] < 0 || (size_t)col.tid[i] >= target_regions.size()) panic("index out of bounds: target_regions[tid]");
+			for (const Region &r : target_regions[col.tid[i]]) {
+				if (start <= r.end && end >= r.start) { on_target_fragments += 1; break; }
+				if (r.start > end) break;
+			}
+		}
+	}
+	char buf[256];                                                                                     // :109-115
+	snprintf(buf, sizeof buf, "Total reads: %llu\n", (unsigned long long)counters[0]);
+	host::out().write(buf, strlen(buf));
+	snprintf(buf, sizeof buf, "Aligned reads: %llu (%s%% of all reads)\n", (unsigned long long)counters[1],
+	         host::fmt_pct((double)counters[1] / (double)counters[0] * 100.0).c_str());
+	host::out().write(buf, strlen(buf));
+	snprintf(buf, sizeof buf, "Duplicate reads: %llu (%s%% of aligned reads)\n", (unsigned long long)counters[2],
+	         host::fmt_pct((double)counters[2] / (double)counters[1] * 100.0).c_str());
+	host::out().write(buf, strlen(buf));
+	if (on_target) {
+		snprintf(buf, sizeof buf, "On-target: %s%%\n", host::fmt_pct((double)on_target_fragments / (double)total_fragments * 100.0).c_str());
+		host::out().write(buf, strlen(buf));
+	}
+	return 0;
+}
+
+// ---- sam fragment lengths ---------------------------------------------------------------------------------------
+static bool frag_keep(uint16_t f, int32_t tid, int32_t mtid, int32_t tlen, uint64_t max_frag, uint64_t &frag)   // :30-38
+{
+	if ((f & (0x1 | 0x40 | 0x4 | 0x8 | 0x400 | 0x100 | 0x800)) != (0x1 | 0x40)) return false;
+	if (tid != mtid) return false;
+	const int64_t t = tlen;
+	frag = (uint64_t)(t < 0 ? -t : t);
+	return frag <= max_frag;
+}
+
+static int fragment_lengths(int argc, char **argv)
+{
+	std::vector<host::Opt> opts = {{"--max-frag-size", true, false, "5000"}, {"--reads", true, false, "Inf"}};
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 3, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_FRAG);
+	uint64_t max_frag = 5000, stop = UINT64_MAX;
+	if (!host::parse_uint(opts[0].value.c_str(), UINT64_MAX, max_frag)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--max-frag-size)");   // :19-20
+	if (opts[1].value != "Inf" && !host::parse_uint(opts[1].value.c_str(), UINT64_MAX, stop)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--reads)");   // :21-25
+	// |tlen| is at most 2^31, so bins above that can never be hit; the device interface takes an int32 bin count
+	if (max_frag > 200000000ull) error("--max-frag-size above 200000000 is not supported by this build.");
+	std::vector<uint64_t> hist(max_frag + 1, 0);                                                       // :27
+	uint64_t total = 0;
+	BamStream bam(pos[0]);                                                                            // :30
+	Columns col;
+	BamCore c;
+	bool more = true, stopped = false;
+	while (more && !stopped) {
+		col.clear();
+		while (col.flag.size() < kBatch && (more = bam.next(c, false))) col.push(c, false);
+		const int64_t n = (int64_t)col.flag.size();
+		if (n == 0) break;
+		// H1 on the device: src/sam_fragment_lengths.rs:29-43
+		std::vector<uint64_t> bh(max_frag + 1, 0);
+		uint64_t bt = 0;
+		check(sk_bam_flag_tlen(host::gpu(), col.flag.data(), col.tid.data(), col.mtid.data(), col.tlen.data(), n, (int32_t)max_frag, nullptr, bh.data(), &bt), "sk_bam_flag_tlen");
+		if (total + bt < stop) {
+			for (size_t i = 0; i <= max_frag; i++) hist[i] += bh[i];
+			total += bt;
+		} else {
+			// the --reads=N stop (:42) falls inside this batch: it depends on input order, so the batch is walked here
+			for (int64_t i = 0; i < n; i++) {
+				uint64_t frag;
+				if (!frag_keep(col.flag[i], col.tid[i], col.mtid[i], col.tlen[i], max_frag, frag)) continue;
+				total += 1;
+				hist[frag] += 1;
+				if (total >= stop) { stopped = true; break; }
+			}
+		}
+	}
+	char buf[64];
+	for (uint64_t size = 1; size < max_frag + 1; size++) {                                             // :45-47
+		snprintf(buf, sizeof buf, "%llu\t%llu\n", (unsigned long long)size, (unsigned long long)hist[size]);
+		host::out().write(buf, strlen(buf));
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	int rc = 0;
+	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
+	if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
+	else if (argc >= 3 && is(1, "fragment") && is(2, "lengths")) rc = fragment_lengths(argc, argv);
+	else fprintf(stderr, "%s\n", USAGE_TOP);
+	host::out().flush();
+	return rc;
+}
