@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Device-resident rates of every BASELINE.json config on one GPU + the PCIe-inclusive rate of the host entry point.
+usage: python tools/rates.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import seqkit_amd  # noqa: E402
+from seqkit_amd import synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+ctx = seqkit_amd.Context(0)
+g = torch.Generator(device=dev)
+g.manual_seed(7)
+
+
+def timeit(name, fn, units, bytes_per_unit, iters=10, rounds=5):
+    for _ in range(2):
+        fn()
+    ctx.sync()
+    ts = []
+    for _ in range(rounds):
+        ctx.timer_start()
+        for _ in range(iters):
+            fn()
+        ts.append(ctx.timer_stop() / iters)
+    ms = sorted(ts)[len(ts) // 2]
+    print(f"{name:58s} {ms:9.4f} ms  {units / ms / 1e3:10.1f} M units/s  {units * bytes_per_unit / ms / 1e6:8.1f} GB/s ({units * bytes_per_unit / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+
+
+# cfg 2: trim by quality, 1M x 150 (and 16M for a bandwidth-sized run)
+for n in (1_000_000, 16_000_000):
+    q = torch.randint(35, 74, (n, 150), dtype=torch.uint8, device=dev, generator=g)
+    lk = torch.empty((n,), dtype=torch.int16, device=dev)
+    timeit(f"cfg2 trim by quality {n} x 150bp (152 B/read)", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
+    s = torch.randint(65, 85, (n, 150), dtype=torch.uint8, device=dev, generator=g)
+    o = torch.empty_like(s)
+    timeit(f"cfg1-shape mask by quality {n} x 150bp (450 B/read)", lambda: ctx.mask_by_quality_dev(s.data_ptr(), q.data_ptr(), 150, n, 20, o.data_ptr()), n, 450)
+    del q, lk, s, o
+
+# cfg 3: demultiplex 10M x 8bp, 16 barcodes
+n = 10_000_000
+table = synth.make_sheet(16, 8, dual=False, seed=3)
+ctx.set_barcodes(table, 1)
+bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
+bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+assign = torch.empty((n,), dtype=torch.int32, device=dev)
+timeit("cfg3 demultiplex 10M x 8bp, 16 barcodes (12 B/read)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+table = synth.make_sheet(96, 8, dual=True, seed=4)
+ctx.set_barcodes(table, 1)
+bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+timeit("demultiplex only 10M x 17ch, 96 dual-index (21 B/pair)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
+del bc, assign
+
+# cfg 5: BAM flag + TLEN, 200M records
+n = 200_000_000
+flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
+flag = torch.from_numpy(flag_np.view(np.int16)).to(dev).repeat(100)
+tid = torch.from_numpy(tid_np).to(dev).repeat(100)
+mtid = torch.from_numpy(mtid_np).to(dev).repeat(100)
+tlen = torch.from_numpy(tlen_np).to(dev).repeat(100)
+out = torch.zeros((4 + 5001,), dtype=torch.int64, device=dev)
+timeit("cfg5 sam statistics + fragment lengths 200M records (14 B)", lambda: ctx.bam_flag_tlen_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 5000, out.data_ptr()), n, 14, iters=3, rounds=3)
+del flag, tid, mtid, tlen
+
+# PCIe-inclusive: the host entry point on pageable numpy buffers (staging + H2D + kernel + D2H)
+n = 2_000_000
+seq, qual, bcd = bench.gen_shard(torch, dev, n, table, seed=9, chunk=1_000_000)
+h = [(seq[i].cpu().numpy(), qual[i].cpu().numpy(), None) for i in range(2)]
+hbc = bcd.cpu().numpy()
+ctx.fused_pass(h, 20, bc=hbc)
+t0 = time.perf_counter()
+for _ in range(3):
+    ctx.fused_pass(h, 20, bc=hbc)
+dt = (time.perf_counter() - t0) / 3
+print(f"host entry point sk_fused_pass, {n} pairs from pageable host memory: {dt * 1e3:.1f} ms  {n / dt / 1e6:.2f} M pairs/s  {925 * n / dt / 1e9:.2f} GB/s (PCIe-inclusive)")
