@@ -858,6 +858,49 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 // src/sam_statistics.rs:63-69; src/sam_fragment_lengths.rs:29-43.
 // out = u64[3 counters][1 hist_total][max_frag+1 bins]
 // ---------------------------------------------------------------------------------------------------
+// per-record work shared by both BAM kernels
+struct BamAcc { u32 total, aligned, dup, hist; };
+
+__device__ __forceinline__ void bam_record(u32 f, int32_t tid, int32_t mtid, int32_t tl, bool valid, int32_t max_frag, int want_counters,
+                                           int want_hist, int lds_bins, u32 *lh, unsigned long long *out, BamAcc &acc)
+{
+	if (want_counters) {
+		const bool primary = valid && (f & (0x100u | 0x800u)) == 0u;                       // src/sam_statistics.rs:64
+		const bool mapped = primary && !(f & 0x4u);                                         // :66
+		acc.total += primary ? 1u : 0u;
+		acc.aligned += mapped ? 1u : 0u;
+		acc.dup += (mapped && (f & 0x400u)) ? 1u : 0u;                                      // :69
+	}
+	if (want_hist) {
+		// paired, first, both mapped, not dup/secondary/supplementary, same reference: src/sam_fragment_lengths.rs:30-37
+		const bool flags_ok = valid && (f & (0x1u | 0x40u | 0x4u | 0x8u | 0x400u | 0x100u | 0x800u)) == (0x1u | 0x40u);
+		// |tlen| as insert_size().abs() on i64: INT32_MIN maps to 2^31, above any max_frag
+		const u32 af = tl < 0 ? (u32)0 - (u32)tl : (u32)tl;
+		if (flags_ok && tid == mtid && af <= (u32)max_frag) {
+			acc.hist += 1u;
+			if ((int)af < lds_bins) atomicAdd(&lh[af], 1u);
+			else atomicAdd(&out[4 + af], 1ull);
+		}
+	}
+}
+
+__device__ __forceinline__ void bam_flush(const BamAcc &acc, u32 *wg_cnt, u32 *lh, int lds_bins, unsigned long long *out)
+{
+	if (acc.total) atomicAdd(&wg_cnt[0], acc.total);
+	if (acc.aligned) atomicAdd(&wg_cnt[1], acc.aligned);
+	if (acc.dup) atomicAdd(&wg_cnt[2], acc.dup);
+	if (acc.hist) atomicAdd(&wg_cnt[3], acc.hist);
+	__syncthreads();
+	if (threadIdx.x < 4 && wg_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)wg_cnt[threadIdx.x]);
+	for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) {
+		u32 c = lh[i];
+		if (c) atomicAdd(&out[4 + i], (unsigned long long)c);
+	}
+}
+
+// S1 + H1, 8 records per lane and iteration: the four columns arrive as 16-byte buffer loads (1 + 2 + 2 + 2 per
+// lane = 7 KiB per wave in flight), clipped by per-iteration descriptors, so there is no tail branch around a load.
+// Columns must be 16-byte aligned (anything else takes bam_flag_tlen_scalar_kernel).
 __global__ __launch_bounds__(256) void bam_flag_tlen_kernel(const uint16_t *__restrict__ flag, const int32_t *__restrict__ tid,
                                                             const int32_t *__restrict__ mtid, const int32_t *__restrict__ tlen,
                                                             int64_t n, int32_t max_frag, unsigned long long *__restrict__ out,
@@ -868,43 +911,49 @@ __global__ __launch_bounds__(256) void bam_flag_tlen_kernel(const uint16_t *__re
 	if (threadIdx.x < 4) wg_cnt[threadIdx.x] = 0u;
 	for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) lh[i] = 0u;
 	__syncthreads();
+	BamAcc acc = {0u, 0u, 0u, 0u};
+	const int64_t per_it = (int64_t)blockDim.x * 8;                       // records per workgroup iteration
+	for (int64_t base = (int64_t)blockIdx.x * per_it; base < n; base += (int64_t)gridDim.x * per_it) {
+		const int64_t left = n - base;
+		const int nrec = (int)(left < per_it ? left : per_it);
+		const rsrc_t rf = make_rsrc(flag, base * 2, (nrec * 2 + 3) & ~3);
+		const rsrc_t rt = make_rsrc(want_hist ? tid : nullptr, base * 4, nrec * 4);
+		const rsrc_t rm = make_rsrc(want_hist ? mtid : nullptr, base * 4, nrec * 4);
+		const rsrc_t rl = make_rsrc(want_hist ? tlen : nullptr, base * 4, nrec * 4);
+		const int r0 = threadIdx.x * 8;
+		const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rf, r0 * 2, 0, 0);
+		const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rt, r0 * 4, 0, 0), t1 = __builtin_amdgcn_raw_buffer_load_b128(rt, r0 * 4 + 16, 0, 0);
+		const u32x4 m0 = __builtin_amdgcn_raw_buffer_load_b128(rm, r0 * 4, 0, 0), m1 = __builtin_amdgcn_raw_buffer_load_b128(rm, r0 * 4 + 16, 0, 0);
+		const u32x4 l0 = __builtin_amdgcn_raw_buffer_load_b128(rl, r0 * 4, 0, 0), l1 = __builtin_amdgcn_raw_buffer_load_b128(rl, r0 * 4 + 16, 0, 0);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const u32 fj = (f[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+			const int32_t tj = (int32_t)(j < 4 ? t0[j & 3] : t1[j & 3]);
+			const int32_t mj = (int32_t)(j < 4 ? m0[j & 3] : m1[j & 3]);
+			const int32_t lj = (int32_t)(j < 4 ? l0[j & 3] : l1[j & 3]);
+			bam_record(fj, tj, mj, lj, r0 + j < nrec, max_frag, want_counters, want_hist, lds_bins, lh, out, acc);
+		}
+	}
+	bam_flush(acc, wg_cnt, lh, lds_bins, out);
+}
 
-	u32 c_total = 0, c_aligned = 0, c_dup = 0, c_hist = 0;
-	const int64_t step = (int64_t)gridDim.x * blockDim.x;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-		const u32 f = flag[i];
-		if (want_counters) {
-			const bool primary = (f & (0x100u | 0x800u)) == 0u;
-			const bool mapped = primary && !(f & 0x4u);
-			c_total += primary ? 1u : 0u;
-			c_aligned += mapped ? 1u : 0u;
-			c_dup += (mapped && (f & 0x400u)) ? 1u : 0u;
-		}
-		if (want_hist) {
-			// paired, first, both mapped, not dup/secondary/supplementary, same reference
-			const bool flags_ok = (f & (0x1u | 0x40u | 0x4u | 0x8u | 0x400u | 0x100u | 0x800u)) == (0x1u | 0x40u);
-			if (flags_ok && tid[i] == mtid[i]) {
-				const int32_t tl = tlen[i];
-				// |tlen| in 64-bit like insert_size().abs(): INT32_MIN maps to 2^31 > any max_frag
-				const u32 af = tl < 0 ? (u32)0 - (u32)tl : (u32)tl;
-				if (af <= (u32)max_frag) {
-					c_hist += 1u;
-					if ((int)af < lds_bins) atomicAdd(&lh[af], 1u);
-					else atomicAdd(&out[4 + af], 1ull);
-				}
-			}
-		}
-	}
-	if (c_total) atomicAdd(&wg_cnt[0], c_total);
-	if (c_aligned) atomicAdd(&wg_cnt[1], c_aligned);
-	if (c_dup) atomicAdd(&wg_cnt[2], c_dup);
-	if (c_hist) atomicAdd(&wg_cnt[3], c_hist);
+// the same reduction with one record per lane and plain loads: columns of any alignment
+__global__ __launch_bounds__(256) void bam_flag_tlen_scalar_kernel(const uint16_t *__restrict__ flag, const int32_t *__restrict__ tid,
+                                                                   const int32_t *__restrict__ mtid, const int32_t *__restrict__ tlen,
+                                                                   int64_t n, int32_t max_frag, unsigned long long *__restrict__ out,
+                                                                   int want_counters, int want_hist, int lds_bins)
+{
+	u32 *lh = reinterpret_cast<u32 *>(sk_smem);
+	__shared__ u32 wg_cnt[4];
+	if (threadIdx.x < 4) wg_cnt[threadIdx.x] = 0u;
+	for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) lh[i] = 0u;
 	__syncthreads();
-	if (threadIdx.x < 4 && wg_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)wg_cnt[threadIdx.x]);
-	for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) {
-		u32 c = lh[i];
-		if (c) atomicAdd(&out[4 + i], (unsigned long long)c);
-	}
+	BamAcc acc = {0u, 0u, 0u, 0u};
+	const int64_t step = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+		bam_record(flag[i], want_hist ? tid[i] : 0, want_hist ? mtid[i] : 0, want_hist ? tlen[i] : 0, true, max_frag, want_counters, want_hist,
+		           lds_bins, lh, out, acc);
+	bam_flush(acc, wg_cnt, lh, lds_bins, out);
 }
 
 hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
@@ -914,9 +963,16 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
 	if (n <= 0) return hipSuccess;
 	int64_t bins = want_hist ? (int64_t)max_frag + 1 : 0;
 	int lds_bins = (int)(bins < 15360 ? bins : 15360);     // 60 KiB of LDS at most
-	int64_t want = (n + 255) / 256;
-	int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
-	bam_flag_tlen_kernel<<<grid, 256, lds_bins * 4, st>>>(flag, tid, mtid, tlen, n, max_frag, out, want_counters, want_hist, lds_bins);
+	const bool aligned = (((uintptr_t)flag | (want_hist ? ((uintptr_t)tid | (uintptr_t)mtid | (uintptr_t)tlen) : 0)) & 15u) == 0;
+	if (aligned) {
+		int64_t want = (n + 2047) / 2048;
+		int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
+		bam_flag_tlen_kernel<<<grid, 256, lds_bins * 4, st>>>(flag, tid, mtid, tlen, n, max_frag, out, want_counters, want_hist, lds_bins);
+	} else {
+		int64_t want = (n + 255) / 256;
+		int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
+		bam_flag_tlen_scalar_kernel<<<grid, 256, lds_bins * 4, st>>>(flag, tid, mtid, tlen, n, max_frag, out, want_counters, want_hist, lds_bins);
+	}
 	return hipGetLastError();
 }
 

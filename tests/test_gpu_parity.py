@@ -317,6 +317,31 @@ def test_bam_flag_tlen(ctx, oracle, n, max_frag):
     assert int(h.sum()) == t
 
 
+def test_bam_dev_entry_point_aligned_and_unaligned_columns(ctx, oracle):
+    """_dev entry point (device memory through the C-ABI's own helpers): 16-byte aligned columns take the vectorised
+    kernel, offset columns the scalar one."""
+    n = 100003
+    flag, tid, mtid, tlen = synth.make_bam_cores(n + 8, seed=6)
+    cols = [flag, tid, mtid, tlen]
+    dptr = [ctx.malloc_device(c.nbytes) for c in cols]
+    dout = ctx.malloc_device((4 + 5001) * 8)
+    try:
+        for c, d in zip(cols, dptr):
+            ctx.copy_h2d(d, c)
+        for off in (0, 3):
+            zero = np.zeros(4 + 5001, dtype=np.uint64)
+            ctx.copy_h2d(dout, zero)
+            ctx.bam_flag_tlen_dev(dptr[0] + 2 * off, dptr[1] + 4 * off, dptr[2] + 4 * off, dptr[3] + 4 * off, n, 5000, dout)
+            got = np.empty(4 + 5001, dtype=np.uint64)
+            ctx.copy_d2h(got, dout)
+            ctx.sync()
+            ec, eh, et = oracle.bam_flag_tlen(flag[off:off + n], tid[off:off + n], mtid[off:off + n], tlen[off:off + n], 5000)
+            assert np.array_equal(got[:3], ec) and int(got[3]) == et and np.array_equal(got[4:], eh), off
+    finally:
+        for d in dptr + [dout]:
+            ctx.free_device(d)
+
+
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
 def test_errors_are_codes_not_crashes(ctx):
     import seqkit_amd
