@@ -200,10 +200,26 @@ static int mask_by_quality(int argc, char **argv)
 			maxn = std::max(maxn, r.seq.size());
 			recs.push_back(std::move(r));
 		}
-		// M1 through the C-ABI (byte form; ASCII records only): src/fasta_mask_by_quality.rs:40-43
+		// M1 through the C-ABI: src/fasta_mask_by_quality.rs:40-43.  The reference zips chars() and takes `qual as u8`
+		// (the low byte of the code point).  ASCII records go as they are; for a record with multi-byte characters the
+		// host only does the text part — one row element per CHAR (a placeholder base, the low byte of the quality
+		// char) — so the threshold arithmetic still runs on the device, and the flagged positions are mapped back.
+		std::vector<std::string> cseq(recs.size()), cqual(recs.size());
 		std::vector<const std::string *> srows, qrows;
 		std::vector<size_t> lens;
-		for (auto &r : recs) if (r.ascii) { srows.push_back(&r.seq); qrows.push_back(&r.qual); lens.push_back(r.seq.size()); }
+		for (size_t i = 0; i < recs.size(); i++) {
+			MaskRec &r = recs[i];
+			if (r.ascii) { srows.push_back(&r.seq); qrows.push_back(&r.qual); lens.push_back(r.seq.size()); continue; }
+			const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data()), *qp = reinterpret_cast<const uint8_t *>(r.qual.data());
+			size_t a = 0, b = 0;
+			while (a < r.seq.size() && b < r.qual.size()) {
+				const size_t la = u8len(sp[a]), lb = u8len(qp[b]);
+				cseq[i].push_back('.');
+				cqual[i].push_back((char)(uint8_t)u8cp(qp + b, lb));
+				a += la; b += lb;
+			}
+			srows.push_back(&cseq[i]); qrows.push_back(&cqual[i]); lens.push_back(cseq[i].size());
+		}
 		Matrix s, q;
 		if (!srows.empty()) {
 			s.pack(srows, lens);
@@ -215,24 +231,22 @@ static int mask_by_quality(int argc, char **argv)
 		std::string masked;
 		for (auto &r : recs) {
 			host::out().write(r.header);                                    // :25-26
+			const char *row = reinterpret_cast<const char *>(s.data.data()) + k * (size_t)s.stride;
 			if (r.ascii) {
-				host::out().write(reinterpret_cast<const char *>(s.data.data()) + k * (size_t)s.stride, r.seq.size());
-				k++;
+				host::out().write(row, r.seq.size());
 			} else {
-				// :40-43 iterate chars, and `qual as u8` keeps the low byte of the code point: text semantics that are not
-				// a byte operation, so records with non-ASCII lines stay on the host
 				masked.clear();
-				const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data()), *qp = reinterpret_cast<const uint8_t *>(r.qual.data());
-				size_t i = 0, j = 0;
-				while (i < r.seq.size() && j < r.qual.size()) {
-					const size_t li = u8len(sp[i]), lj = u8len(qp[j]);
-					const uint8_t qb = (uint8_t)u8cp(qp + j, lj);
-					if ((uint8_t)(qb - 33) < min_baseq) masked.push_back('N');
-					else masked.append(r.seq, i, li);
-					i += li; j += lj;
+				const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data());
+				size_t a = 0;
+				for (size_t c = 0; c < lens[k]; c++) {
+					const size_t la = u8len(sp[a]);
+					if (row[c] == 'N') masked.push_back('N');
+					else masked.append(r.seq, a, la);
+					a += la;
 				}
 				host::out().write(masked);
 			}
+			k++;
 			host::out().write("\n+\n", 3);                                   // :44
 			host::out().write(r.qual);
 			host::out().write("\n", 1);

@@ -10,6 +10,11 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
 
 namespace host {
 
@@ -255,25 +260,170 @@ bool LineReader::read_line(std::string &line)
 	return !line.empty();
 }
 
-// ---- GzWriter --------------------------------------------------------------------------------------------
-GzWriter::GzWriter(const std::string &path)
+// ---- GzWriter: block-parallel gzip ------------------------------------------------------------------------
+namespace {
+
+struct Job { GzWriter::Impl *w; uint64_t seq; std::string data; };
+
+struct Pool {
+	std::mutex m;
+	std::condition_variable cv_job, cv_room;
+	std::deque<Job> q;
+	std::vector<std::thread> threads;
+	size_t in_flight = 0, max_in_flight = 0;
+	bool stop = false;
+	void start();
+	void submit(Job &&j);
+	void run();
+	~Pool();
+};
+
+Pool &pool()
 {
-	gz_ = gzopen(path.c_str(), "wb6");
-	if (!gz_) error("Cannot open file %s for writing.", path.c_str());
-	gzbuffer(gz_, 1 << 18);
+	static Pool p;
+	return p;
 }
-GzWriter::~GzWriter() { close(); }
-void GzWriter::write(const char *p, size_t n)
+
+constexpr size_t kGzBlock = 512u << 10;      // uncompressed bytes per gzip member
+
+}  // namespace
+
+struct GzWriter::Impl {
+	int fd = -1;
+	std::string buf;
+	uint64_t next_submit = 0;
+	// completion side (guarded by m)
+	std::mutex m;
+	std::condition_variable cv;
+	uint64_t next_write = 0;
+	std::map<uint64_t, std::string> ready;
+	void completed(uint64_t seq, std::string &&comp)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		ready.emplace(seq, std::move(comp));
+		// write every block that is next in line (this thread does the I/O for them)
+		for (auto it = ready.find(next_write); it != ready.end(); it = ready.find(next_write)) {
+			const std::string &c = it->second;
+			size_t off = 0;
+			while (off < c.size()) {
+				const ssize_t w = ::write(fd, c.data() + off, c.size() - off);
+				if (w <= 0) break;                   // write errors are ignored like the reference (#![allow(unused_must_use)])
+				off += (size_t)w;
+			}
+			ready.erase(it);
+			next_write++;
+		}
+		cv.notify_all();
+	}
+};
+
+static std::string gzip_member(const std::string &in)
 {
-	while (n > 0) {
-		const unsigned c = n > (1u << 30) ? (1u << 30) : (unsigned)n;
-		if (gzwrite(gz_, p, c) <= 0) return;      // write errors are ignored like the reference (#![allow(unused_must_use)])
-		p += c; n -= c;
+	z_stream z;
+	memset(&z, 0, sizeof z);
+	deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
+	std::string out;
+	out.resize(deflateBound(&z, in.size()) + 32);
+	z.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(in.data()));
+	z.avail_in = (uInt)in.size();
+	z.next_out = reinterpret_cast<Bytef *>(&out[0]);
+	z.avail_out = (uInt)out.size();
+	deflate(&z, Z_FINISH);
+	out.resize(out.size() - z.avail_out);
+	deflateEnd(&z);
+	return out;
+}
+
+void Pool::start()
+{
+	if (!threads.empty()) return;
+	unsigned n = std::thread::hardware_concurrency();
+	if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
+	if (n < 1) n = 1;
+	if (n > 64) n = 64;
+	max_in_flight = (size_t)n * 4;
+	for (unsigned i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+}
+
+void Pool::submit(Job &&j)
+{
+	std::unique_lock<std::mutex> lk(m);
+	start();
+	cv_room.wait(lk, [this] { return in_flight < max_in_flight; });     // bounds memory
+	in_flight++;
+	q.push_back(std::move(j));
+	cv_job.notify_one();
+}
+
+void Pool::run()
+{
+	for (;;) {
+		Job j;
+		{
+			std::unique_lock<std::mutex> lk(m);
+			cv_job.wait(lk, [this] { return stop || !q.empty(); });
+			if (q.empty()) return;
+			j = std::move(q.front());
+			q.pop_front();
+		}
+		std::string comp = gzip_member(j.data);
+		j.w->completed(j.seq, std::move(comp));
+		{
+			std::unique_lock<std::mutex> lk(m);
+			in_flight--;
+			cv_room.notify_one();
+		}
 	}
 }
+
+Pool::~Pool()
+{
+	{
+		std::unique_lock<std::mutex> lk(m);
+		stop = true;
+		cv_job.notify_all();
+	}
+	for (auto &t : threads) t.join();
+}
+
+GzWriter::GzWriter(const std::string &path) : impl_(new Impl)
+{
+	impl_->fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+	if (impl_->fd < 0) { delete impl_; impl_ = nullptr; error("Cannot open file %s for writing.", path.c_str()); }
+}
+
+GzWriter::~GzWriter()
+{
+	close();
+	delete impl_;
+}
+
+void GzWriter::write(const char *p, size_t n)
+{
+	if (!impl_ || impl_->fd < 0) return;
+	impl_->buf.append(p, n);
+	if (impl_->buf.size() >= kGzBlock) {
+		Job j{impl_, impl_->next_submit++, std::move(impl_->buf)};
+		impl_->buf.clear();
+		impl_->buf.reserve(kGzBlock + 4096);
+		pool().submit(std::move(j));
+	}
+}
+
 void GzWriter::close()
 {
-	if (gz_) { gzclose(gz_); gz_ = nullptr; }
+	if (!impl_ || impl_->fd < 0) return;
+	// an empty file still gets one (empty) member, like `gzip -c < /dev/null`
+	if (!impl_->buf.empty() || impl_->next_submit == 0) {
+		Job j{impl_, impl_->next_submit++, std::move(impl_->buf)};
+		pool().submit(std::move(j));
+	}
+	{
+		std::unique_lock<std::mutex> lk(impl_->m);
+		impl_->cv.wait(lk, [this] { return impl_->next_write == impl_->next_submit; });
+	}
+	::close(impl_->fd);
+	impl_->fd = -1;
 }
 
 // ---- stdout ------------------------------------------------------------------------------------------------

@@ -58,6 +58,9 @@ private:
 };
 
 // ---- gzip writer (one per output file) -----------------------------------------------------------------
+// Replaces GzipWriter (src/common.rs:49-81: an unbuffered pipe into one `gzip`/`pigz` child per file).  Output is cut
+// into blocks that a shared pool of threads deflates into independent gzip members (a valid .gz is any concatenation
+// of members; `gunzip`/zlib read them transparently); each file's members are written in submission order.
 class GzWriter {
 public:
 	explicit GzWriter(const std::string &path);          // "Cannot open file {} for writing."
@@ -66,9 +69,10 @@ public:
 	GzWriter &operator=(const GzWriter &) = delete;
 	void write(const char *p, size_t n);
 	void write(const std::string &s) { write(s.data(), s.size()); }
-	void close();
+	void close();                                        // flush, wait for this file's blocks, close the descriptor
+	struct Impl;
 private:
-	gzFile gz_ = nullptr;
+	Impl *impl_;
 };
 
 // ---- buffered stdout -----------------------------------------------------------------------------------

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""End-to-end (file -> stdout/files) wall time of the C++ hosts vs the oracle CLI on the GPU box.  Host/PCIe/zlib bound:
+reported separately from the kernel numbers, never as bench.py's value."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+from seqkit_amd import build, synth  # noqa: E402
+
+orc.build()
+build.build_all()
+FASTA = os.path.join(build.BINDIR, "fasta")
+n_block, reps = 100_000, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+d = tempfile.mkdtemp(prefix="sk_e2e_")
+seq, qual = synth.make_reads(n_block, 150, seed=1)
+table = synth.make_sheet(96, 8, dual=True, seed=4)
+bc, _ = synth.observe_barcodes(table, n_block, seed=4, halves=2)
+headers = [f"@SIM:1:{i} 1:N:0".encode() + b" BC:" + bc[i].tobytes() for i in range(n_block)]
+block = synth.fastq_text(seq, qual, headers=headers)
+fq = os.path.join(d, "in.fq")
+with open(fq, "wb") as f:
+    for _ in range(reps):
+        f.write(block)
+sheet = os.path.join(d, "sheet.tsv")
+with open(sheet, "wb") as f:
+    for i in range(96):
+        f.write(f"S{i:02d}\t".encode() + table[i].tobytes() + b"\n")
+n = n_block * reps
+print(f"{n} reads, {os.path.getsize(fq) / 1e6:.0f} MB FASTQ")
+
+
+def t(cmd, cwd):
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return time.perf_counter() - t0, r.returncode
+
+
+for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("mask by quality", ["mask", "by", "quality", fq, "20"]),
+                   ("demultiplex (96 samples, gz out)", ["demultiplex", sheet, fq])):
+    for label, binary in (("hip", FASTA), ("oracle", orc.FASTA_BIN)):
+        w = os.path.join(d, label + name.split()[0])
+        os.makedirs(w, exist_ok=True)
+        dt, rc = t([binary] + args, w)
+        print(f"{name:34s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
