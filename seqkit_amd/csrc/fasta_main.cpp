@@ -80,87 +80,99 @@ static uint8_t parse_min_baseq(const std::string &s)
 struct Matrix {
 	std::vector<uint8_t> data;
 	int stride = 1;
-	void pack(const std::vector<const std::string *> &rows, const std::vector<size_t> &lens)
+	void pack(const std::vector<host::Line> &rows)
 	{
 		size_t mx = 1;
-		for (size_t l : lens) mx = std::max(mx, l);
+		for (const host::Line &l : rows) mx = std::max(mx, l.n);
 		stride = (int)mx;
 		data.assign(rows.size() * mx, 0);
-		for (size_t r = 0; r < rows.size(); r++) memcpy(data.data() + r * mx, rows[r]->data(), lens[r]);
+		for (size_t r = 0; r < rows.size(); r++) memcpy(data.data() + r * mx, rows[r].p, rows[r].n);
 	}
 };
 
+static bool line_utf8_ok(const host::Line &l) { return host::utf8_valid(reinterpret_cast<const uint8_t *>(l.p), l.n); }
+
 // ---------------------------------------------------------------------------------------------------------
-// fasta trim by quality
+// fasta trim by quality — one block of whole records (src/fasta_trim_by_quality.rs:19-49)
 // ---------------------------------------------------------------------------------------------------------
-struct TrimRec { std::string header, seq, qual; size_t n; bool body; };
+struct TrimRec { host::Line header, seq, qual; size_t qual_line; bool body; };
+
+static void trim_block(const char *data, size_t n, uint8_t min_baseq, host::BlockResult &res)
+{
+	host::BlockLines bl(data, n);
+	std::vector<TrimRec> recs;
+	std::vector<host::Line> rows;
+	recs.reserve(n / 300 + 4);
+	for (;;) {
+		TrimRec r;
+		r.body = false;
+		r.header = bl.next();                                               // :19
+		if (r.header.n == 0) break;
+		if (!line_utf8_ok(r.header)) { res.err = "I/O error while reading from file."; break; }
+		if (r.header.p[0] != '@') { res.err = "Invalid FASTQ format encountered."; break; }                  // :20-22
+		// :23 prints the header before the rest of the record is read
+		r.seq = bl.next();                                                  // :24  (past the end: an empty string)
+		host::Line plus = bl.next();                                        // :25
+		r.qual = bl.next();                                                 // :26
+		if (!line_utf8_ok(r.seq) || !line_utf8_ok(plus) || !line_utf8_ok(r.qual)) {
+			recs.push_back(r);                                              // its header is out already
+			res.err = "I/O error while reading from file.";
+			break;
+		}
+		r.body = true;
+		r.qual_line = r.qual.n;
+		r.qual.n = host::trim_end_len(r.qual.p, r.qual.n);                  // :31  n = qual.trim_end().len()
+		if (r.qual.n > kMaxRow) { res.err = "Read longer than 65535 bases: not supported by this build."; break; }
+		rows.push_back(r.qual);
+		recs.push_back(r);
+	}
+	// T1 through the C-ABI: src/fasta_trim_by_quality.rs:28-42
+	std::vector<uint16_t> lowest_k(rows.size());
+	if (!rows.empty()) {
+		Matrix q;
+		q.pack(rows);
+		std::vector<uint16_t> len16(rows.size());
+		for (size_t i = 0; i < rows.size(); i++) len16[i] = (uint16_t)rows[i].n;
+		std::lock_guard<std::mutex> lk(host::gpu_mutex());
+		check(sk_trim_by_quality(host::gpu(), q.data.data(), len16.data(), q.stride, (int64_t)rows.size(), min_baseq, lowest_k.data()), "sk_trim_by_quality");
+	}
+	res.out.reserve(n + 16);
+	size_t k = 0;
+	for (const TrimRec &r : recs) {
+		res.out.append(r.header.p, r.header.n);
+		if (!r.body) break;
+		const size_t lk = lowest_k[k++];
+		if (lk == 0) {                                                      // :44-45
+			res.out.append("N\n+\n!\n", 6);
+		} else {                                                            // :47 — byte slices of seq and qual
+			const char *why = nullptr;
+			if (lk > r.seq.n) why = "byte index out of range of `seq`";
+			else if (lk < r.seq.n && ((uint8_t)r.seq.p[lk] & 0xC0) == 0x80) why = "byte index is not a char boundary (seq)";
+			else if (lk < r.qual_line && ((uint8_t)r.qual.p[lk] & 0xC0) == 0x80) why = "byte index is not a char boundary (qual)";
+			if (why) { res.err = why; res.err_code = 101; break; }
+			res.out.append(r.seq.p, lk);
+			res.out.append("\n+\n", 3);
+			res.out.append(r.qual.p, lk);
+			res.out.push_back('\n');
+		}
+	}
+}
 
 static int trim_by_quality(int argc, char **argv)
 {
 	std::vector<host::Opt> opts;
 	std::vector<std::string> pos;
 	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_TRIM);
-	host::LineReader fq(pos[0]);                                            // :12
+	{ host::LineReader probe(pos[0]); }                                     // :12  FileReader::new comes before the parse (error order)
 	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :13
-	std::string plus;
-	bool done = false;
-	const char *pending = nullptr;
-	while (!done) {
-		std::vector<TrimRec> recs;
-		size_t maxn = 1;
-		while (recs.size() < kBatchRecords && (recs.size() + 1) * maxn <= kBatchBytes) {
-			TrimRec r;
-			r.body = false; r.n = 0;
-			if (!fq.read_line(r.header)) { done = true; if (fq.bad_utf8()) pending = "I/O error while reading from file."; break; }   // :19
-			if (r.header[0] != '@') { pending = "Invalid FASTQ format encountered."; done = true; break; }           // :20-22
-			// :23 prints the header before the rest of the record is read
-			fq.read_line(r.seq);                                            // :24  (EOF leaves an empty string)
-			if (!fq.bad_utf8()) fq.read_line(plus);                         // :25
-			if (!fq.bad_utf8()) fq.read_line(r.qual);                       // :26
-			if (fq.bad_utf8()) { recs.push_back(std::move(r)); pending = "I/O error while reading from file."; done = true; break; }
-			r.body = true;
-			r.n = host::trim_end_len(r.qual);                               // :31
-			if (r.n > kMaxRow) { pending = "Read longer than 65535 bases: not supported by this build."; done = true; break; }
-			maxn = std::max(maxn, r.n);
-			recs.push_back(std::move(r));
-		}
-		// the batch through the C-ABI: T1, src/fasta_trim_by_quality.rs:28-42
-		std::vector<const std::string *> rows;
-		std::vector<size_t> lens;
-		for (auto &r : recs) if (r.body) { rows.push_back(&r.qual); lens.push_back(r.n); }
-		std::vector<uint16_t> lowest_k(rows.size());
-		if (!rows.empty()) {
-			Matrix q;
-			q.pack(rows, lens);
-			std::vector<uint16_t> len16(lens.begin(), lens.end());
-			check(sk_trim_by_quality(host::gpu(), q.data.data(), len16.data(), q.stride, (int64_t)rows.size(), min_baseq, lowest_k.data()), "sk_trim_by_quality");
-		}
-		size_t k = 0;
-		for (auto &r : recs) {
-			host::out().write(r.header);
-			if (!r.body) break;
-			const size_t lk = lowest_k[k++];
-			if (lk == 0) {                                                  // :44-45
-				host::out().write("N\n+\n!\n", 6);
-			} else {                                                        // :47 — byte slices of seq and qual
-				if (lk > r.seq.size()) panic("byte index out of range of `seq`");
-				if (lk < r.seq.size() && ((uint8_t)r.seq[lk] & 0xC0) == 0x80) panic("byte index is not a char boundary (seq)");
-				if (lk < r.qual.size() && ((uint8_t)r.qual[lk] & 0xC0) == 0x80) panic("byte index is not a char boundary (qual)");
-				host::out().write(r.seq.data(), lk);
-				host::out().write("\n+\n", 3);
-				host::out().write(r.qual.data(), lk);
-				host::out().write("\n", 1);
-			}
-		}
-	}
-	if (pending) error("%s", pending);
+	host::run_block_pipeline(pos[0], 4, [min_baseq](const char *d, size_t n, bool, host::BlockResult &res) { trim_block(d, n, min_baseq, res); });
 	return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fasta mask by quality
+// fasta mask by quality — one block of whole records (src/fasta_mask_by_quality.rs:20-46)
 // ---------------------------------------------------------------------------------------------------------
-struct MaskRec { std::string header, seq, qual; bool ascii; };
+struct MaskRec { host::Line header, seq, qual; bool ascii; size_t row; };
 
 static size_t u8len(uint8_t b) { return b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4; }
 static uint32_t u8cp(const uint8_t *p, size_t l)
@@ -171,88 +183,92 @@ static uint32_t u8cp(const uint8_t *p, size_t l)
 	return ((uint32_t)(p[0] & 0x07) << 18) | ((uint32_t)(p[1] & 0x3F) << 12) | ((uint32_t)(p[2] & 0x3F) << 6) | (p[3] & 0x3F);
 }
 
+static void mask_block(const char *data, size_t n, uint8_t min_baseq, host::BlockResult &res)
+{
+	host::BlockLines bl(data, n);
+	std::vector<MaskRec> recs;
+	std::vector<host::Line> srows, qrows;
+	std::vector<std::string> cseq, cqual;                                   // per-char rows of records with multi-byte chars
+	cseq.reserve(16); cqual.reserve(16);
+	recs.reserve(n / 300 + 4);
+	for (;;) {
+		MaskRec r;
+		r.header = bl.next();                                               // :20
+		if (r.header.n == 0) break;
+		if (!line_utf8_ok(r.header)) { res.err = "I/O error while reading from file."; break; }
+		if (r.header.p[0] != '@') { res.err = "Invalid FASTQ format encountered."; break; }                  // :21-23
+		r.seq = bl.next();                                                  // :28
+		host::Line plus = bl.next();                                        // :29
+		r.qual = bl.next();                                                 // :30
+		if (!line_utf8_ok(r.seq) || !line_utf8_ok(plus) || !line_utf8_ok(r.qual)) { res.err = "I/O error while reading from file."; break; }
+		if (r.seq.n && r.seq.p[r.seq.n - 1] == '\n') r.seq.n--;             // :32
+		if (r.qual.n && r.qual.p[r.qual.n - 1] == '\n') r.qual.n--;         // :33
+		if (r.seq.n != r.qual.n) { res.err = "Read sequence and base qualities are of different length."; break; }   // :35-37
+		if (r.seq.n > kMaxRow) { res.err = "Read longer than 65535 bases: not supported by this build."; break; }
+		r.ascii = host::is_ascii(r.seq.p, r.seq.n) && host::is_ascii(r.qual.p, r.qual.n);
+		recs.push_back(r);
+	}
+	// M1 through the C-ABI: src/fasta_mask_by_quality.rs:40-43.  The reference zips chars() and takes `qual as u8` (the
+	// low byte of the code point).  ASCII records go as they are; for a record with multi-byte characters the host only
+	// does the text part — one row element per CHAR (a placeholder base, the low byte of the quality char) — so the
+	// threshold arithmetic still runs on the device, and the flagged positions are mapped back.
+	size_t nspecial = 0;
+	for (const MaskRec &r : recs) nspecial += r.ascii ? 0 : 1;
+	cseq.reserve(nspecial); cqual.reserve(nspecial);
+	for (MaskRec &r : recs) {
+		r.row = srows.size();
+		if (r.ascii) { srows.push_back(r.seq); qrows.push_back(r.qual); continue; }
+		cseq.emplace_back(); cqual.emplace_back();
+		const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.p), *qp = reinterpret_cast<const uint8_t *>(r.qual.p);
+		size_t a = 0, b = 0;
+		while (a < r.seq.n && b < r.qual.n) {
+			const size_t la = u8len(sp[a]), lb = u8len(qp[b]);
+			cseq.back().push_back('.');
+			cqual.back().push_back((char)(uint8_t)u8cp(qp + b, lb));
+			a += la; b += lb;
+		}
+		srows.push_back({cseq.back().data(), cseq.back().size()});
+		qrows.push_back({cqual.back().data(), cqual.back().size()});
+	}
+	Matrix s, q;
+	if (!srows.empty()) {
+		s.pack(srows);
+		q.pack(qrows);
+		std::vector<uint16_t> len16(srows.size());
+		for (size_t i = 0; i < srows.size(); i++) len16[i] = (uint16_t)srows[i].n;
+		std::lock_guard<std::mutex> lk(host::gpu_mutex());
+		check(sk_mask_by_quality(host::gpu(), s.data.data(), q.data.data(), len16.data(), s.stride, (int64_t)srows.size(), min_baseq), "sk_mask_by_quality");
+	}
+	res.out.reserve(n + 16);
+	for (const MaskRec &r : recs) {
+		res.out.append(r.header.p, r.header.n);                             // :25-26
+		const char *row = reinterpret_cast<const char *>(s.data.data()) + r.row * (size_t)s.stride;
+		if (r.ascii) {
+			res.out.append(row, r.seq.n);
+		} else {
+			const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.p);
+			size_t a = 0;
+			for (size_t c = 0; c < srows[r.row].n; c++) {
+				const size_t la = u8len(sp[a]);
+				if (row[c] == 'N') res.out.push_back('N');
+				else res.out.append(r.seq.p + a, la);
+				a += la;
+			}
+		}
+		res.out.append("\n+\n", 3);                                          // :44
+		res.out.append(r.qual.p, r.qual.n);
+		res.out.push_back('\n');
+	}
+}
+
 static int mask_by_quality(int argc, char **argv)
 {
 	std::vector<host::Opt> opts;
 	std::vector<std::string> pos;
 	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_MASK);
-	host::LineReader fq(pos[0]);                                            // :13
+	{ host::LineReader probe(pos[0]); }                                     // :13
 	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :14
-	std::string plus;
-	bool done = false;
-	const char *pending = nullptr;
-	while (!done) {
-		std::vector<MaskRec> recs;
-		size_t maxn = 1;
-		while (recs.size() < kBatchRecords && (recs.size() + 1) * maxn * 2 <= kBatchBytes) {
-			MaskRec r;
-			if (!fq.read_line(r.header)) { done = true; if (fq.bad_utf8()) pending = "I/O error while reading from file."; break; }   // :20
-			if (r.header[0] != '@') { pending = "Invalid FASTQ format encountered."; done = true; break; }           // :21-23
-			fq.read_line(r.seq);                                            // :28
-			if (!fq.bad_utf8()) fq.read_line(plus);                         // :29
-			if (!fq.bad_utf8()) fq.read_line(r.qual);                       // :30
-			if (fq.bad_utf8()) { pending = "I/O error while reading from file."; done = true; break; }
-			if (!r.seq.empty() && r.seq.back() == '\n') r.seq.pop_back();   // :32
-			if (!r.qual.empty() && r.qual.back() == '\n') r.qual.pop_back();// :33
-			if (r.seq.size() != r.qual.size()) { pending = "Read sequence and base qualities are of different length."; done = true; break; }   // :35-37
-			r.ascii = host::is_ascii(r.seq) && host::is_ascii(r.qual);
-			if (r.seq.size() > kMaxRow) { pending = "Read longer than 65535 bases: not supported by this build."; done = true; break; }
-			maxn = std::max(maxn, r.seq.size());
-			recs.push_back(std::move(r));
-		}
-		// M1 through the C-ABI: src/fasta_mask_by_quality.rs:40-43.  The reference zips chars() and takes `qual as u8`
-		// (the low byte of the code point).  ASCII records go as they are; for a record with multi-byte characters the
-		// host only does the text part — one row element per CHAR (a placeholder base, the low byte of the quality
-		// char) — so the threshold arithmetic still runs on the device, and the flagged positions are mapped back.
-		std::vector<std::string> cseq(recs.size()), cqual(recs.size());
-		std::vector<const std::string *> srows, qrows;
-		std::vector<size_t> lens;
-		for (size_t i = 0; i < recs.size(); i++) {
-			MaskRec &r = recs[i];
-			if (r.ascii) { srows.push_back(&r.seq); qrows.push_back(&r.qual); lens.push_back(r.seq.size()); continue; }
-			const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data()), *qp = reinterpret_cast<const uint8_t *>(r.qual.data());
-			size_t a = 0, b = 0;
-			while (a < r.seq.size() && b < r.qual.size()) {
-				const size_t la = u8len(sp[a]), lb = u8len(qp[b]);
-				cseq[i].push_back('.');
-				cqual[i].push_back((char)(uint8_t)u8cp(qp + b, lb));
-				a += la; b += lb;
-			}
-			srows.push_back(&cseq[i]); qrows.push_back(&cqual[i]); lens.push_back(cseq[i].size());
-		}
-		Matrix s, q;
-		if (!srows.empty()) {
-			s.pack(srows, lens);
-			q.pack(qrows, lens);
-			std::vector<uint16_t> len16(lens.begin(), lens.end());
-			check(sk_mask_by_quality(host::gpu(), s.data.data(), q.data.data(), len16.data(), s.stride, (int64_t)srows.size(), min_baseq), "sk_mask_by_quality");
-		}
-		size_t k = 0;
-		std::string masked;
-		for (auto &r : recs) {
-			host::out().write(r.header);                                    // :25-26
-			const char *row = reinterpret_cast<const char *>(s.data.data()) + k * (size_t)s.stride;
-			if (r.ascii) {
-				host::out().write(row, r.seq.size());
-			} else {
-				masked.clear();
-				const uint8_t *sp = reinterpret_cast<const uint8_t *>(r.seq.data());
-				size_t a = 0;
-				for (size_t c = 0; c < lens[k]; c++) {
-					const size_t la = u8len(sp[a]);
-					if (row[c] == 'N') masked.push_back('N');
-					else masked.append(r.seq, a, la);
-					a += la;
-				}
-				host::out().write(masked);
-			}
-			k++;
-			host::out().write("\n+\n", 3);                                   // :44
-			host::out().write(r.qual);
-			host::out().write("\n", 1);
-		}
-	}
-	if (pending) error("%s", pending);
+	host::run_block_pipeline(pos[0], 4, [min_baseq](const char *d, size_t n, bool, host::BlockResult &res) { mask_block(d, n, min_baseq, res); });
 	return 0;
 }
 

@@ -11,7 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <algorithm>
 #include <deque>
+#include <future>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -449,16 +452,148 @@ Out &out()
 }
 
 // ---- GPU ---------------------------------------------------------------------------------------------------
+std::mutex &gpu_mutex()
+{
+	static std::mutex m;
+	return m;
+}
+
 sk_ctx *gpu()
 {
 	static sk_ctx *ctx = nullptr;
-	if (!ctx) {
+	static std::once_flag once;
+	std::call_once(once, [] {
 		int dev = 0;
 		if (const char *e = getenv("SEQKIT_GPU")) dev = atoi(e);
 		const int rc = sk_create(dev, &ctx);
 		if (rc != SK_OK) error("No usable MI355X for the seqkit HIP path (%s); this build has no CPU fallback.", sk_last_error(nullptr));
-	}
+	});
 	return ctx;
+}
+
+size_t trim_end_len(const char *p, size_t n)
+{
+	// fast path: ASCII tail
+	while (n > 0) {
+		const uint8_t b = (uint8_t)p[n - 1];
+		if (b >= 0x80) return trim_end_len(std::string(p, n));
+		if (!((b >= 0x09 && b <= 0x0D) || b == 0x20)) break;
+		n--;
+	}
+	return n;
+}
+
+bool is_ascii(const char *p, size_t n)
+{
+	for (size_t i = 0; i < n; i++)
+		if ((uint8_t)p[i] >= 0x80) return false;
+	return true;
+}
+
+// ---- block pipeline ------------------------------------------------------------------------------------------
+namespace {
+
+// raw byte source with the FileReader path rules (src/common.rs:88-103)
+struct RawSource {
+	gzFile gz = nullptr;
+	int fd = -1;
+	explicit RawSource(const std::string &path)
+	{
+		if (path == "-") { fd = 0; return; }
+		fd = open(path.c_str(), O_RDONLY);
+		if (fd < 0) error("Cannot open file %s for reading.", path.c_str());
+		if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+			gz = gzdopen(fd, "rb");
+			if (!gz) error("Cannot start gunzip process.");
+			gzbuffer(gz, 1 << 20);
+		}
+	}
+	~RawSource() { if (gz) gzclose(gz); else if (fd > 0) close(fd); }
+	size_t read_some(char *dst, size_t n)
+	{
+		ssize_t r;
+		if (gz) r = gzread(gz, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+		else do { r = read(fd, dst, n); } while (r < 0 && errno == EINTR);
+		if (r < 0) error("I/O error while reading from file.");
+		return (size_t)r;
+	}
+};
+
+}  // namespace
+
+void run_block_pipeline(const std::string &path, int lines_per_record, const BlockFn &fn)
+{
+	RawSource src(path);
+	size_t block_bytes = 8u << 20;
+	unsigned nthreads = std::thread::hardware_concurrency();
+	if (const char *e = getenv("SEQKIT_THREADS")) nthreads = (unsigned)atoi(e);
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 32) nthreads = 32;
+	if (const char *e = getenv("SEQKIT_BLOCK_BYTES")) block_bytes = (size_t)atoll(e);      // tests use tiny blocks
+
+	struct Pending { std::shared_ptr<std::string> data; std::future<std::shared_ptr<BlockResult>> fut; };
+	std::deque<Pending> inflight;
+	auto drain_one = [&]() -> bool {      // returns false when the pipeline must stop (error raised)
+		std::shared_ptr<BlockResult> r = inflight.front().fut.get();
+		inflight.pop_front();
+		out().write(r->out);
+		if (!r->err.empty()) {
+			for (auto &p : inflight) p.fut.wait();
+			if (r->err_code == 101) panic(r->err.c_str());
+			error("%s", r->err.c_str());
+		}
+		return true;
+	};
+
+	std::string carry;
+	bool eof = false;
+	while (!eof) {
+		// fill one block: previous carry + fresh bytes, then cut after the last newline that completes a record
+		auto blk = std::make_shared<std::string>();
+		blk->swap(carry);
+		const size_t start = blk->size();
+		blk->resize(start + block_bytes);
+		size_t got = 0;
+		while (got < block_bytes) {
+			const size_t r = src.read_some(&(*blk)[start + got], block_bytes - got);
+			if (r == 0) { eof = true; break; }
+			got += r;
+		}
+		blk->resize(start + got);
+		size_t cut = blk->size();
+		if (!eof) {
+			// count newlines; keep whole records only
+			size_t lines = 0, last_rec_end = 0;
+			const char *p = blk->data(), *e = p + blk->size();
+			while (p < e) {
+				const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)));
+				if (!nl) break;
+				lines++;
+				p = nl + 1;
+				if (lines % (size_t)lines_per_record == 0) last_rec_end = (size_t)(p - blk->data());
+			}
+			cut = last_rec_end;
+			if (cut == 0) {                    // a record larger than the block: grow and retry
+				carry.swap(*blk);
+				block_bytes *= 2;
+				continue;
+			}
+			carry.assign(*blk, cut, std::string::npos);
+			blk->resize(cut);
+		}
+		if (blk->empty() && eof) break;
+		const bool last = eof;
+		Pending pd;
+		pd.data = blk;
+		pd.fut = std::async(std::launch::async, [blk, last, &fn]() {
+			auto res = std::make_shared<BlockResult>();
+			fn(blk->data(), blk->size(), last, *res);
+			return res;
+		});
+		inflight.push_back(std::move(pd));
+		while (inflight.size() >= nthreads) drain_one();
+	}
+	while (!inflight.empty()) drain_one();
 }
 
 }  // namespace host

@@ -11,6 +11,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,5 +91,38 @@ Out &out();
 
 // ---- the GPU context (created on first use; no CPU fallback) -------------------------------------------
 sk_ctx *gpu();
+// a ctx is used by one thread at a time: worker threads take this lock around their sk_* calls
+std::mutex &gpu_mutex();
+
+// ---- block-parallel record pipeline (the ingest half of SURVEY.md §8f f1) ------------------------------
+// The input is cut into blocks of whole records (`lines_per_record` lines each; only the last block may end in a
+// partial record), blocks are processed by worker threads, and their outputs are written to stdout in input order.
+// A block that hits an input error fills `err` (and `err_code`: 255 error!, 101 panic) after the output of the
+// records before it; the pipeline writes that output, stops, and raises the error — the same point the
+// record-at-a-time reference would have reached.
+struct BlockResult { std::string out; std::string err; int err_code = 255; };
+using BlockFn = std::function<void(const char *data, size_t n, bool last_block, BlockResult &res)>;
+void run_block_pipeline(const std::string &path, int lines_per_record, const BlockFn &fn);
+
+// one line of a block: [p, p+n) including its '\n' when present; n == 0 past the end of the block (EOF semantics)
+struct Line { const char *p; size_t n; };
+class BlockLines {
+public:
+	BlockLines(const char *data, size_t n) : cur_(data), end_(data + n) {}
+	Line next()
+	{
+		if (cur_ == end_) return {cur_, 0};
+		const char *nl = static_cast<const char *>(memchr(cur_, '\n', (size_t)(end_ - cur_)));
+		const char *e = nl ? nl + 1 : end_;
+		Line l{cur_, (size_t)(e - cur_)};
+		cur_ = e;
+		return l;
+	}
+	bool at_end() const { return cur_ == end_; }
+private:
+	const char *cur_, *end_;
+};
+size_t trim_end_len(const char *p, size_t n);
+bool is_ascii(const char *p, size_t n);
 
 }  // namespace host

@@ -62,6 +62,27 @@ def test_trim_cli_kat_and_quirks(bins, tmp_path, golden):
     both(bins, "fasta", ["trim", "by", "quality", "-", "20"], tmp_path, stdin=text)
 
 
+def test_trim_and_mask_cli_many_small_blocks(bins, tmp_path, monkeypatch):
+    """The block-parallel pipeline with blocks of a few records (and one record larger than a block): same bytes, same
+    error point as the record-at-a-time oracle."""
+    monkeypatch.setenv("SEQKIT_BLOCK_BYTES", "700")
+    monkeypatch.setenv("SEQKIT_THREADS", "5")
+    text = ragged_fastq(1500, 150, seed=12) + b"@big\n" + b"A" * 5000 + b"\n+\n" + b"I" * 5000 + b"\n" + ragged_fastq(300, 60, seed=13)
+    fq = tmp_path / "b.fq"
+    fq.write_bytes(text)
+    both(bins, "fasta", ["trim", "by", "quality", str(fq), "20"], tmp_path)
+    both(bins, "fasta", ["mask", "by", "quality", str(fq), "20"], tmp_path)
+    both(bins, "fasta", ["mask", "by", "quality", "-", "30"], tmp_path, stdin=text)
+    bad = text[:200000] + b"oops not a header\nAC\n+\nII\n" + text[200000:]
+    cut = bad.rfind(b"\n@", 0, 200000) + 1
+    bad = text[:cut] + b"oops not a header\nAC\n+\nII\n" + text[cut:]
+    fq.write_bytes(bad)
+    a, *_ = both(bins, "fasta", ["trim", "by", "quality", str(fq), "20"], tmp_path)
+    assert a[0] == 255 and a[2] == b"ERROR: Invalid FASTQ format encountered.\n" and len(a[1]) > 10000
+    a, *_ = both(bins, "fasta", ["mask", "by", "quality", str(fq), "20"], tmp_path)
+    assert a[0] == 255
+
+
 def test_trim_cli_errors_mid_stream(bins, tmp_path):
     fq = tmp_path / "e.fq"
     fq.write_bytes(b"@r1\nACGT\n+\nIIII\nnot a header\nACGT\n+\nIIII\n")
