@@ -18,6 +18,8 @@
 #include "sk_internal.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace sk {
 
@@ -760,20 +762,42 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 	lp.hist_off = lp.table_bytes;
 	lp.tiles_off = (lp.hist_off + (lp.use_lds_hist ? (b.table.S + 3) * 4 : 0) + 15) & ~15;
 	lp.tile_slot = kLdsPad + ((kTileRows * row_bytes + 15) & ~15) + kLdsPad;
-	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
+	// the shape search (occupancy queries, LDS opt-in) is cached per (device, kernel, LDS layout): small batches from
+	// the command-line hosts launch thousands of times with the same shape
+	struct Shape { int dev; const void *fn; int tiles_off, tile_slot, max_nw, nw, wg; };
+	static std::mutex cache_m;
+	static std::vector<Shape> cache;
+	static const int env_nw = getenv("SK_TILE_WAVES") ? atoi(getenv("SK_TILE_WAVES")) : 0;      // tuning knobs (tools/ablate.py)
+	static const int env_wg = getenv("SK_TILE_WGS") ? atoi(getenv("SK_TILE_WGS")) : 0;
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
-	static const int env_nw = getenv("SK_TILE_WAVES") ? atoi(getenv("SK_TILE_WAVES")) : 0;      // tuning knob (tools/ablate.py)
 	int best_nw = 0, best_wg = 0, best_waves = 0;
-	for (int nw = max_nw; nw >= 1; nw >>= 1) {
-		if (env_nw && nw != env_nw && env_nw <= max_nw) continue;
-		const int lds = lp.tiles_off + nw * lp.tile_slot;
-		if (lds > kLdsPerCu) continue;
-		int wg = 0;
-		e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
+	{
+		std::lock_guard<std::mutex> lk(cache_m);
+		for (const Shape &c : cache)
+			if (c.dev == dev && c.fn == fn && c.tiles_off == lp.tiles_off && c.tile_slot == lp.tile_slot && c.max_nw == max_nw) {
+				best_nw = c.nw; best_wg = c.wg; best_waves = c.nw * c.wg;
+				break;
+			}
+	}
+	if (best_waves == 0) {
+		e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
 		if (e != hipSuccess) return e;
-		static const int env_wg = getenv("SK_TILE_WGS") ? atoi(getenv("SK_TILE_WGS")) : 0;     // tuning knob: cap on workgroups per CU
-		if (env_wg > 0 && wg > env_wg) wg = env_wg;
-		if (wg * nw > best_waves) { best_waves = wg * nw; best_nw = nw; best_wg = wg; }
+		for (int nw = max_nw; nw >= 1; nw >>= 1) {
+			if (env_nw && nw != env_nw && env_nw <= max_nw) continue;
+			const int lds = lp.tiles_off + nw * lp.tile_slot;
+			if (lds > kLdsPerCu) continue;
+			int wg = 0;
+			e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
+			if (e != hipSuccess) return e;
+			if (env_wg > 0 && wg > env_wg) wg = env_wg;
+			if (wg * nw > best_waves) { best_waves = wg * nw; best_nw = nw; best_wg = wg; }
+		}
+		if (best_waves > 0) {
+			std::lock_guard<std::mutex> lk(cache_m);
+			cache.push_back({dev, fn, lp.tiles_off, lp.tile_slot, max_nw, best_nw, best_wg});
+		}
 	}
 	if (best_waves == 0) return hipErrorInvalidValue;
 	const int lds = lp.tiles_off + best_nw * lp.tile_slot;
@@ -831,8 +855,8 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	}
 	// the barcode phase rides in the tile pass when the bit-sliced matcher applies (S <= 128) and the tile's
 	// barcodes fit two 1 KiB register chunks; otherwise it is its own launch beside the mate pass
-	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 &&
-	                        !getenv("SK_NO_FUSED_DEMUX");
+	static const bool env_no_fuse = getenv("SK_NO_FUSED_DEMUX") != nullptr;
+	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 && !env_no_fuse;
 	if (b.bc && !fuse_demux) {
 		hipError_t e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		if (e != hipSuccess) return e;
