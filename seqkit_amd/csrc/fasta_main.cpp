@@ -327,9 +327,17 @@ static void close_outputs()
 
 static int demultiplex(int argc, char **argv)
 {
-	std::vector<host::Opt> opts = {{"--parallel", false, false, ""}, {"--index1", true, false, ""}, {"--index2", true, false, ""}, {"--dry-run", true, false, ""}};
+	// --mask-by-quality=Q / --trim-by-quality=Q are extensions of this build (not in the reference's usage text): every
+	// written record additionally goes through `fasta mask by quality Q` and/or `fasta trim by quality Q`, computed in
+	// the same device pass as the barcode assignment (sk_fused_pass) instead of by piping each sample file through them.
+	std::vector<host::Opt> opts = {{"--parallel", false, false, ""}, {"--index1", true, false, ""}, {"--index2", true, false, ""}, {"--dry-run", true, false, ""},
+	                               {"--mask-by-quality", true, false, ""}, {"--trim-by-quality", true, false, ""}};
 	std::vector<std::string> pos;
 	if (!host::parse_args(argc, argv, 2, opts, pos, 3) || pos.size() < 2) error("Invalid arguments.\n%s", USAGE_DEMUX);
+	const bool do_mask = opts[4].present, do_trim = opts[5].present;
+	const uint8_t mask_q = do_mask ? parse_min_baseq(opts[4].value) : 0, trim_q = do_trim ? parse_min_baseq(opts[5].value) : 0;
+	if (do_mask && do_trim && mask_q != trim_q) error("--mask-by-quality and --trim-by-quality must use the same threshold in one pass.");
+	const bool fused = do_mask || do_trim;
 	uint64_t dry_run = 0;                                                   // :33-36
 	if (!host::parse_uint(opts[3].value.c_str(), UINT64_MAX, dry_run)) dry_run = 0;
 	if (dry_run == 0 && !opts[3].value.empty()) error("In --dry-run=N, N must be 64-bit positive integer.");
@@ -443,13 +451,77 @@ static int demultiplex(int argc, char **argv)
 		std::vector<int32_t> assign(nb);
 		std::vector<uint8_t> lowest(nb);
 		std::vector<int16_t> first(nb), last(nb);
-		if (nb > 0 && barcode_len > 0) {
-			std::vector<uint8_t> bc(nb * barcode_len);
-			for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * barcode_len, cl[i].barcode.data(), barcode_len);
+		std::vector<uint8_t> bc(nb * barcode_len);
+		for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * barcode_len, cl[i].barcode.data(), barcode_len);
+		// fused mode: the mates' bases and qualities ride in the same pass (M1 + T1 next to D1-D3)
+		const int nm = paired_end ? 2 : 1;
+		Matrix mseq[2], mqual[2], mout[2];
+		std::vector<uint16_t> mlen[2], mlk[2];
+		if (nb > 0 && fused) {
+			// common stride for both mates (sk_fused_args has one stride)
+			size_t stride = 1;
+			for (int m = 0; m < nm; m++)
+				for (size_t i = 0; i < nb; i++) {
+					const std::string &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
+					stride = std::max(stride, std::max(sl.size(), ql.size()));
+				}
+			sk_fused_args fa;
+			memset(&fa, 0, sizeof fa);
+			fa.n = (int64_t)nb; fa.n_mates = nm; fa.stride = (int)stride; fa.min_baseq = do_mask ? mask_q : trim_q;
+			if (stride > kMaxRow) { close_outputs(); error("Read longer than 65535 bases: not supported by this build."); }
+			for (int m = 0; m < nm; m++) {
+				mseq[m].data.assign(nb * stride, 0);
+				mqual[m].data.assign(nb * stride, 0);
+				mlen[m].resize(nb);
+				mlk[m].resize(nb);
+				for (size_t i = 0; i < nb; i++) {
+					const std::string &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
+					const size_t ls = sl.size() - ((!sl.empty() && sl.back() == '\n') ? 1 : 0), lq = ql.size() - ((!ql.empty() && ql.back() == '\n') ? 1 : 0);
+					memcpy(mseq[m].data.data() + i * stride, sl.data(), ls);
+					memcpy(mqual[m].data.data() + i * stride, ql.data(), lq);
+					mlen[m][i] = (uint16_t)std::min(host::trim_end_len(ql), lq);      // trim: n = qual.trim_end().len()
+				}
+				mseq[m].stride = mqual[m].stride = (int)stride;
+				mout[m].data.resize(nb * stride);
+				mout[m].stride = (int)stride;
+				fa.mate[m].seq = mseq[m].data.data(); fa.mate[m].qual = mqual[m].data.data(); fa.mate[m].len = mlen[m].data();
+				fa.mate[m].out_seq = do_mask ? mout[m].data.data() : nullptr;
+				fa.mate[m].lowest_k = do_trim ? mlk[m].data() : nullptr;
+			}
+			if (barcode_len > 0) {
+				fa.bc = bc.data(); fa.bc_stride = (int)barcode_len; fa.assign = assign.data();
+				fa.lowest_diff = lowest.data(); fa.first_idx = first.data(); fa.last_idx = last.data();
+			} else {
+				std::fill(assign.begin(), assign.end(), SK_ASSIGN_NONE);
+			}
+			check(sk_fused_pass(host::gpu(), &fa), "sk_fused_pass");
+		} else if (nb > 0 && barcode_len > 0) {
 			check(sk_demux_assign(host::gpu(), bc.data(), (int)barcode_len, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
 		} else {
 			std::fill(assign.begin(), assign.end(), SK_ASSIGN_NONE);        // empty sheet: lowest_diff stays usize::MAX
 		}
+		// body of one written record: verbatim lines, or the lines `mask by quality` then `trim by quality` would print
+		auto emit_body = [&](host::GzWriter &w, const std::string &sl, const std::string &pl, const std::string &ql, size_t i, int m) {
+			if (!fused) { w.write(sl); w.write(pl); w.write(ql); return; }
+			std::string seq_cur = sl, qual_cur = ql;
+			if (do_mask) {                                                  // src/fasta_mask_by_quality.rs:32-45
+				const size_t ls = sl.size() - ((!sl.empty() && sl.back() == '\n') ? 1 : 0), lq = ql.size() - ((!ql.empty() && ql.back() == '\n') ? 1 : 0);
+				if (ls != lq) { close_outputs(); error("Read sequence and base qualities are of different length."); }
+				if (!host::is_ascii(sl) || !host::is_ascii(ql)) { close_outputs(); error("Non-ASCII read lines are not supported together with --mask-by-quality."); }
+				seq_cur.assign(reinterpret_cast<const char *>(mout[m].data.data()) + i * (size_t)mout[m].stride, ls);
+				seq_cur.push_back('\n');
+				qual_cur.assign(ql, 0, lq);
+				qual_cur.push_back('\n');
+			}
+			if (do_trim) {                                                  // src/fasta_trim_by_quality.rs:44-48
+				const size_t lk = mlk[m][i];
+				if (lk == 0) { w.write("N\n+\n!\n", 6); return; }
+				if (lk > seq_cur.size()) { close_outputs(); panic("byte index out of range of `seq`"); }
+				w.write(seq_cur.data(), lk); w.write("\n+\n", 3); w.write(qual_cur.data(), lk); w.write("\n", 1);
+			} else {
+				w.write(seq_cur); w.write("+\n", 2); w.write(qual_cur);
+			}
+		};
 
 		// ---- emit in input order ---------------------------------------------------------------------------------
 		for (size_t i = 0; i < nb; i++) {
@@ -484,7 +556,7 @@ static int demultiplex(int argc, char **argv)
 			sm.out[0]->write(c.header.data(), host::trim_end_len(c.header));   // :206
 			if (!umi.empty()) { sm.out[0]->write(" UMI:", 5); sm.out[0]->write(umi); }   // :207
 			sm.out[0]->write("\n", 1);                                      // :208
-			sm.out[0]->write(c.l2); sm.out[0]->write(c.l3); sm.out[0]->write(c.l4);      // :209-212
+			emit_body(*sm.out[0], c.l2, c.l3, c.l4, i, 0);                      // :209-212
 			if (paired_end) {                                               // :215-237
 				std::string &h2 = c.m2[0];
 				if (index_fastq.empty()) {
@@ -494,7 +566,7 @@ static int demultiplex(int argc, char **argv)
 				sm.out[1]->write(h2.data(), host::trim_end_len(h2));
 				if (!umi.empty()) { sm.out[1]->write(" UMI:", 5); sm.out[1]->write(umi); }
 				sm.out[1]->write("\n", 1);
-				sm.out[1]->write(c.m2[1]); sm.out[1]->write(c.m2[2]); sm.out[1]->write(c.m2[3]);
+				emit_body(*sm.out[1], c.m2[1], c.m2[2], c.m2[3], i, 1);
 			}
 		}
 		if (dry_run > 0 && total_reads >= dry_run) done = true;             // :248

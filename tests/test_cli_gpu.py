@@ -201,6 +201,41 @@ def test_demultiplex_index_files_and_dry_run(bins, tmp_path):
     assert sorted(a[1].splitlines()) == sorted(b[1].splitlines()) and len(a[1].splitlines()) == 100
 
 
+@pytest.mark.parametrize("mode", ["mask", "trim", "both"])
+def test_demultiplex_fused_extension_equals_the_piped_commands(bins, tmp_path, mode):
+    """--mask-by-quality / --trim-by-quality (extensions): one fused device pass must give what the reference gives by
+    piping every per-sample file through `fasta mask by quality` and then `fasta trim by quality`."""
+    import gzip
+    sheet, files, table, bc = demux_inputs(tmp_path, 3000, True, True, seed=21)
+    # ragged mates with awkward qualities
+    for m, f in enumerate(files):
+        seq, qual = synth.make_reads(3000, 70, seed=30 + m)
+        qual = synth.add_forced_classes(qual, seed=31 + m)
+        ln = synth.ragged_lengths(3000, 70, seed=32)
+        ln[ln == 0] = 1
+        headers = [f"@SIM:{i} {m + 1}:N:0".encode() + b" BC:" + bc[i].tobytes() for i in range(3000)]
+        open(f, "wb").write(synth.fastq_text(seq, qual, headers=headers, lengths=ln))
+    ext = {"mask": ["--mask-by-quality=20"], "trim": ["--trim-by-quality", "20"], "both": ["--mask-by-quality=20", "--trim-by-quality=20"]}[mode]
+    da, db = tmp_path / "fused", tmp_path / "piped"
+    da.mkdir()
+    db.mkdir()
+    a = cu.run(bins["fasta"][0], ["demultiplex"] + ext + [sheet] + files, cwd=da)
+    b = cu.run(bins["fasta"][1], ["demultiplex", sheet] + files, cwd=db)
+    assert a[0] == b[0] == 0 and a[2] == b[2]
+    got = cu.gunzip_dir(da)
+    ref = cu.gunzip_dir(db)
+    assert sorted(got) == sorted(ref) and sum(map(len, ref.values())) > 100000
+    for name, text in ref.items():
+        tmp = tmp_path / "stage.fq"
+        for cmd in (["mask", "by", "quality"] if mode in ("mask", "both") else None, ["trim", "by", "quality"] if mode in ("trim", "both") else None):
+            if cmd is None:
+                continue
+            tmp.write_bytes(text)
+            rc, text, err = cu.run(bins["fasta"][1], cmd + [str(tmp), "20"], cwd=tmp_path)
+            assert rc == 0, err
+        assert got[name] == text, name
+
+
 def test_demultiplex_errors(bins, tmp_path):
     sheet = tmp_path / "s.tsv"
     sheet.write_bytes(b"A\tACGTACGT\nB\tTTTTGGGG\n")
