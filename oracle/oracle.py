@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
         _lib.orc_trim_end_len.restype = C.c_size_t
         _lib.orc_trim_end_len.argtypes = [C.c_char_p, C.c_size_t]
+        _lib.orc_trim_start_off.restype = C.c_size_t
+        _lib.orc_trim_start_off.argtypes = [C.c_char_p, C.c_size_t]
         _lib.orc_utf8_valid.restype = i32
         _lib.orc_utf8_valid.argtypes = [C.c_char_p, C.c_size_t]
         _lib.orc_find_bc_field.restype = i32

@@ -119,3 +119,81 @@ def test_block_parallel_gzip_writer(hip_lib, tmp_path):
                 import numpy as np
                 k = np.arange(total, dtype=np.int64)
                 assert np.array_equal(np.frombuffer(got, dtype=np.uint8), (65 + (k * (i + 3)) % 23).astype(np.uint8))
+
+
+def _build_cpp(tmp_path, name, extra=()):
+    import os
+    import subprocess
+    from seqkit_amd import build
+    exe = tmp_path / name
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I", os.path.join(build.REPO, "include"), "-I", build.CSRC, "-o", str(exe),
+                    os.path.join(build.REPO, "tests", "cpp", name + ".cpp"), os.path.join(build.CSRC, "host_common.cpp"),
+                    "-L", build.LIBDIR, "-lseqkit_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lz", *extra], check=True)
+    return exe
+
+
+def test_host_text_helpers_vs_oracle_under_asan(hip_lib, oracle, tmp_path):
+    """trim_end / trim / UTF-8 validation / ` BC:` scanner: the host's implementation (ASan+UBSan build) against the oracle's,
+    on random byte strings biased towards whitespace, multi-byte characters and BC fields."""
+    import random
+    import subprocess
+    exe = _build_cpp(tmp_path, "host_text_test")
+    rnd = random.Random(1234)
+    code_points = [0x85, 0xA0, 0x1680, 0x2000, 0x200A, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000, 0x200B, 0xE9, 0x20AC, 0x1F600]
+    controls = [9, 10, 13, 11, 12, 0x1C, 0x1F, 32]
+    pieces = [bytes([c]) for c in controls] + [chr(c).encode() for c in code_points] + \
+             [bytes([0xFF]), bytes([0xC0, 0xAF]), bytes([0xE2, 0x82]), bytes([0xED, 0xA0, 0x80]), bytes([0xF4, 0x90, 0x80, 0x80]),
+              b" BC:", b" BC:ACGT", b"BC:", b"ACGTN+acgtn", b"@r1", b"x", b"A", b":", b" "]
+    cases = [b"", b" ", bytes([10]), b" BC:", b" BC:A", b"@r BC:X BC:ACGT+TT extra" + bytes([10])]
+    for _ in range(4000):
+        cases.append(b"".join(rnd.choice(pieces) for _ in range(rnd.randint(0, 9))))
+    for _ in range(1000):
+        cases.append(bytes(rnd.randrange(256) for _ in range(rnd.randint(0, 12))))
+    out = subprocess.run([str(exe)], input=chr(10).join(c.hex() for c in cases).encode() + bytes([10]), stdout=subprocess.PIPE, check=True,
+                         env={"ASAN_OPTIONS": "detect_leaks=0"}).stdout.decode().splitlines()
+    assert len(out) == len(cases)
+    for c, line in zip(cases, out):
+        ok, te, ts, asc, b0, b1 = map(int, line.split())
+        assert bool(ok) == oracle.utf8_valid(c), c
+        assert bool(asc) == all(x < 128 for x in c)
+        if ok:
+            assert te == oracle.trim_end_len(c), c
+            assert ts == int(oracle.lib().orc_trim_start_off(c, len(c))), c
+        hit = oracle.find_bc_field(c)
+        assert (b0, b1) == (hit if hit else (-1, -1)), c
+
+
+def test_oracle_cli_under_asan(oracle, tmp_path, golden):
+    """The oracle CLIs rebuilt with ASan+UBSan run the golden flows clean (the checker itself must be sound)."""
+    import os
+    import shutil
+    import subprocess
+    NL = bytes([10])
+    TAB = bytes([9])
+    src = os.path.dirname(oracle.LIB)
+    d = tmp_path / "orc_asan"
+    d.mkdir()
+    for f in ("seqkit_oracle.c", "seqkit_oracle.h", "cli_common.h", "fasta_oracle_main.c", "sam_oracle_main.c", "Makefile"):
+        shutil.copy(os.path.join(src, f), d / f)
+    subprocess.run(["make", "-C", str(d), "CFLAGS=-O1 -g -std=c11 -D_GNU_SOURCE -fPIC -Wno-unused-function -fsanitize=address,undefined -fno-sanitize-recover=undefined",
+                    "fasta_oracle", "sam_oracle"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    g = golden["trim_by_quality"]
+    fq = tmp_path / "k.fq"
+    fq.write_bytes(b"".join(b"@r%d" % i + NL + c["seq"].encode("latin-1") + NL + b"+" + NL + c["qual"].encode("latin-1") + NL for i, c in enumerate(g["cases"])) + b"@eof" + NL + b"AC")
+    for cmd in (["trim", "by", "quality", str(fq), "20"], ["mask", "by", "quality", str(fq), "20"], ["add", "barcode", str(fq), str(fq)]):
+        a = subprocess.run([str(d / "fasta_oracle")] + cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([oracle.FASTA_BIN] + cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert a.returncode == b.returncode and a.stdout == b.stdout, (cmd, a.stderr[-400:])
+    sheet = tmp_path / "s.tsv"
+    sheet.write_bytes(b"A" + TAB + b"ACGTUUUU" + NL + b"B" + TAB + b"TTTTUUUU" + NL)
+    fq.write_bytes(NL.join([b"@r1 BC:ACGTTTGA", b"ACGT", b"+", b"IIII", b"@r2 BC:GGGGGGGG x", b"AC", b"+", b"II", b""]))
+    w = tmp_path / "w"
+    w.mkdir()
+    a = subprocess.run([str(d / "fasta_oracle"), "demultiplex", str(sheet), str(fq)], cwd=w, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b"1 / 2 (50.0%)" in a.stderr, a.stderr
+    bam = tmp_path / "t.bam"
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(tid=0, mtid=0, flag=99, tlen=180, pos=1, mpos=100)])
+    a = subprocess.run([str(d / "sam_oracle"), "fragment", "lengths", "--max-frag-size=200", str(bam)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and (b"180" + TAB + b"1" + NL) in a.stdout, a.stderr
