@@ -87,6 +87,11 @@ def gen_shard(torch, dev, n, table_np, seed, chunk):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON).  Everything else that writes to fd 1 — RCCL's version banner comes out
+    # of C stdio at exit, torch warnings, ... — is sent to stderr; the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,13 +113,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         try:
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm (xGMI between the GPUs of the node)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # nccl == RCCL on ROCm (xGMI links)
             backend = "nccl"
         except Exception as e:                              # keep the bench alive if RCCL cannot come up: counts via gloo
             sys.stderr.write(f"[bench] RCCL init failed ({e}); falling back to gloo for the count reduce\n")
             if dist.is_initialized():
                 dist.destroy_process_group()
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
             backend = "gloo"
 
     ctx = seqkit_amd.Context(local_rank)                    # raises if libseqkit_hip.so is missing
@@ -233,7 +238,7 @@ def main():
             "parity_sample_ok": parity,
             "identified_frac": round(float(total_counts[S + 1]) / float(total_counts[S]), 4),
         }
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
     if backend is not None:
         dist.destroy_process_group()
