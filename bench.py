@@ -41,11 +41,13 @@ def parse():
     ap.add_argument("--pairs", type=int, default=62_500_000, help="clusters per GPU (default: configs[3] / 8)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="clusters timed on the CPU oracle (0 = skip)")
     ap.add_argument("--gen-chunk", type=int, default=2_000_000)
+    ap.add_argument("--arena", type=int, default=-1, help="experimental: carve all matrices from ONE allocation, staggered by this many bytes")
     return ap.parse_args()
 
 
-def gen_shard(torch, dev, n, table_np, seed, chunk):
-    """Synthetic shard on the device (SURVEY.md §8d cfg 4 distributions), generated chunk by chunk."""
+def gen_shard(torch, dev, n, table_np, seed, chunk, into=None):
+    """Synthetic shard on the device (SURVEY.md §8d cfg 4 distributions), generated chunk by chunk.
+    `into` = (seq[2], qual[2], bc) preallocated uint8 tensors to fill instead of allocating."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     u8 = torch.uint8
@@ -53,9 +55,12 @@ def gen_shard(torch, dev, n, table_np, seed, chunk):
     alphabet = torch.tensor(list(b"ACGTN"), dtype=u8, device=dev)
     table = torch.tensor(table_np, dtype=u8, device=dev)
     mu = 36.0 - 16.0 * (torch.arange(L_READ, device=dev, dtype=torch.float32) / (L_READ - 1)) ** 2
-    seq = [torch.empty((n, L_READ), dtype=u8, device=dev) for _ in range(2)]
-    qual = [torch.empty((n, L_READ), dtype=u8, device=dev) for _ in range(2)]
-    bc = torch.empty((n, L_BC), dtype=u8, device=dev)
+    if into is not None:
+        seq, qual, bc = into
+    else:
+        seq = [torch.empty((n, L_READ), dtype=u8, device=dev) for _ in range(2)]
+        qual = [torch.empty((n, L_READ), dtype=u8, device=dev) for _ in range(2)]
+        bc = torch.empty((n, L_BC), dtype=u8, device=dev)
     for r0 in range(0, n, chunk):
         m = min(chunk, n - r0)
         for mi in range(2):
@@ -127,10 +132,24 @@ def main():
     ctx.set_barcodes(table, 1)
 
     n = args.pairs
-    seq, qual, bc = gen_shard(torch, dev, n, table, seed=4000 + rank, chunk=args.gen_chunk)
-    out_seq = [torch.empty_like(seq[0]) for _ in range(2)]
-    lowest_k = [torch.empty((n,), dtype=torch.int16, device=dev) for _ in range(2)]     # raw u16 storage
-    assign = torch.empty((n,), dtype=torch.int32, device=dev)
+    if args.arena >= 0:
+        sizes = [n * L_READ] * 4 + [n * L_BC] + [n * L_READ] * 2 + [n * 2] * 2 + [n * 4]
+        step = [(sz + args.arena + 4095) // 4096 * 4096 for sz in sizes]
+        arena = torch.empty(sum(step) + 4096, dtype=torch.uint8, device=dev)
+        offs = [sum(step[:i]) for i in range(len(step))]
+        cut = [arena[o:o + sz] for o, sz in zip(offs, sizes)]
+        seq = [cut[0].view(n, L_READ), cut[2].view(n, L_READ)]
+        qual = [cut[1].view(n, L_READ), cut[3].view(n, L_READ)]
+        bc = cut[4].view(n, L_BC)
+        out_seq = [cut[5].view(n, L_READ), cut[6].view(n, L_READ)]
+        lowest_k = [cut[7].view(torch.int16), cut[8].view(torch.int16)]
+        assign = cut[9].view(torch.int32)
+        gen_shard(torch, dev, n, table, seed=4000 + rank, chunk=args.gen_chunk, into=(seq, qual, bc))
+    else:
+        seq, qual, bc = gen_shard(torch, dev, n, table, seed=4000 + rank, chunk=args.gen_chunk)
+        out_seq = [torch.empty_like(seq[0]) for _ in range(2)]
+        lowest_k = [torch.empty((n,), dtype=torch.int16, device=dev) for _ in range(2)]     # raw u16 storage
+        assign = torch.empty((n,), dtype=torch.int32, device=dev)
     counts = torch.zeros((S_SAMPLES + 3,), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 

@@ -254,6 +254,46 @@ def test_counters_accumulate_and_reset(ctx, oracle):
 
 
 # ---- fused pass ---------------------------------------------------------------------------------------------
+@pytest.fixture(params=["phases", "interleaved", "blocked-tiles", "interleaved+blocked"])
+def pass_variant(request, monkeypatch):
+    """The two tile-pass kernels (stream/scan phases vs scan interleaved with the stream) and both tile-to-wave maps."""
+    if "interleaved" in request.param:
+        monkeypatch.setenv("SK_PASS2", "1")
+    if "blocked" in request.param:
+        monkeypatch.setenv("SK_TILE_MAP", "1")
+    return request.param
+
+
+def test_tile_pass_variants(ctx, oracle, pass_variant):
+    for n, L, paired in ((30011, 150, True), (777, 150, False), (5003, 101, True), (64 * 300 + 1, 33, True)):
+        table = synth.make_sheet(96, 8, dual=True, seed=4)
+        bc, _ = synth.observe_barcodes(table, n, seed=n, halves=2)
+        ln = synth.ragged_lengths(n, L, seed=n) if n == 5003 else None
+        mates = []
+        for mi in range(2 if paired else 1):
+            seq, qual = synth.make_reads(n, L, seed=70 + mi)
+            mates.append((seq, synth.add_forced_classes(qual, seed=80 + mi), ln))
+        ctx.set_barcodes(table, 1)
+        r = ctx.fused_pass(mates, 20, bc=bc, want_detail=True)
+        e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, 1)
+        assert np.array_equal(r["assign"], e_assign) and np.array_equal(r["lowest_diff"], e_low)
+        assert np.array_equal(r["first_idx"], e_first) and np.array_equal(r["last_idx"], e_last)
+        assert np.array_equal(ctx.counts(), e_counts)
+        for mi, (seq, qual, _) in enumerate(mates):
+            assert np.array_equal(r["lowest_k"][mi], oracle.trim_batch(qual, ln, 20))
+            exp = oracle.mask_batch(seq, qual, ln, 20)
+            if ln is None:
+                assert np.array_equal(r["out_seq"][mi], exp)
+            else:
+                for i in range(0, n, 7):
+                    assert np.array_equal(r["out_seq"][mi][i, :ln[i]], exp[i, :ln[i]])
+        # trim alone and mask+trim without barcodes go through the same kernels
+        assert np.array_equal(ctx.trim_by_quality(mates[0][1], ln, 30), oracle.trim_batch(mates[0][1], ln, 30))
+        r2 = ctx.fused_pass(mates, 2)
+        assert np.array_equal(r2["lowest_k"][-1], oracle.trim_batch(mates[-1][1], ln, 2))
+
+
+
 @pytest.mark.parametrize("paired", [False, True])
 def test_fused_pass_matches_the_three_commands(ctx, oracle, paired):
     """cfg 4 shape: add barcode + demultiplex + trim + mask in one pass == the separate oracle steps."""

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 import seqkit_amd  # noqa: E402
 from seqkit_amd import synth  # noqa: E402
 
-n = 8_000_000
+n = int(os.environ.get('N', '8000000'))
 L, LB = 150, 17
 dev = torch.device("cuda", 0)
 ctx = seqkit_amd.Context(0)
