@@ -152,6 +152,16 @@ int sk_bam_flag_tlen(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, cons
 int sk_bam_flag_tlen_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
                          const int32_t *tlen, int64_t n, int32_t max_frag, uint64_t *out);
 
+/* ---- f2: `sam fragments` record filter ---------------------------------------------------------------------
+ * src/sam_fragments.rs:27-38: keep the forward mate of a converging, mapped, primary, non-duplicate, QC-passing pair on
+ * one reference whose |tlen| lies in [min_size, max_size].  keep_bits: (n+7)/8 bytes, bit j of byte k <=> record 8k+j;
+ * *kept is ADDED to.  The BED line of a kept record (:41) is text and stays on the host.  Columns must be 16-byte
+ * aligned for the _dev form.                                                                                */
+int sk_bam_fragments(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                     int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept);
+int sk_bam_fragments_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                         int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept);
+
 /* ---- timing on the ctx stream (hipEvents), so a host without HIP can time device work -------------- */
 int sk_timer_start(sk_ctx *ctx);
 int sk_timer_stop(sk_ctx *ctx, float *ms);               /* records, synchronises, returns elapsed ms */

@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
         _lib.orc_bam_flag_tlen.argtypes = [vp, vp, vp, vp, i64, C.c_int32, vp, vp, vp]
         _lib.orc_fragment_lengths_stop.restype = i64
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
+        _lib.orc_fragments_keep.restype = i64
+        _lib.orc_fragments_keep.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
         _lib.orc_trim_end_len.restype = C.c_size_t
         _lib.orc_trim_end_len.argtypes = [C.c_char_p, C.c_size_t]
         _lib.orc_trim_start_off.restype = C.c_size_t
@@ -126,6 +128,13 @@ def bam_flag_tlen(flag, tid, mtid, tlen, max_frag: int = 5000):
     total = np.zeros(1, dtype=np.uint64)
     lib().orc_bam_flag_tlen(_p(flag), _p(tid), _p(mtid), _p(tlen), n, max_frag, _p(counters), _p(hist), _p(total))
     return counters, hist, int(total[0])
+
+
+def fragments_keep(flag, tid, mtid, tlen, min_size: int = 0, max_size: int = 5000) -> np.ndarray:
+    n = len(flag)
+    keep = np.zeros(n, dtype=np.uint8)
+    lib().orc_fragments_keep(_p(flag), _p(tid), _p(mtid), _p(tlen), n, min_size, max_size, _p(keep))
+    return keep
 
 
 def trim_end_len(s: bytes) -> int:

@@ -72,6 +72,9 @@ static long bgzf_read(bgzf_t *b, void *dst, size_t n)
 static uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+static char **g_ref_names = NULL;
+static uint32_t g_n_ref = 0;
+
 static void bam_read_header(bgzf_t *b, const char *path)
 {
 	uint8_t h[8];
@@ -81,14 +84,18 @@ static void bam_read_header(bgzf_t *b, const char *path)
 	while (l_text) { size_t c = l_text > sizeof buf ? sizeof buf : l_text; if (bgzf_read(b, buf, c) != (long)c) oc_error("Cannot open BAM file '%s'", path); l_text -= (uint32_t)c; }
 	if (bgzf_read(b, h, 4) != 4) oc_error("Cannot open BAM file '%s'", path);
 	uint32_t n_ref = le32(h);
+	g_n_ref = n_ref;
+	g_ref_names = (char **)calloc(n_ref ? n_ref : 1, sizeof(char *));
 	for (uint32_t i = 0; i < n_ref; i++) {
 		if (bgzf_read(b, h, 4) != 4) oc_error("Cannot open BAM file '%s'", path);
-		uint32_t l_name = le32(h) + 4;    /* name + l_ref */
-		while (l_name) { size_t c = l_name > sizeof buf ? sizeof buf : l_name; if (bgzf_read(b, buf, c) != (long)c) oc_error("Cannot open BAM file '%s'", path); l_name -= (uint32_t)c; }
+		uint32_t l_name = le32(h);
+		g_ref_names[i] = (char *)calloc(l_name + 1, 1);
+		if (l_name && bgzf_read(b, g_ref_names[i], l_name) != (long)l_name) oc_error("Cannot open BAM file '%s'", path);
+		if (bgzf_read(b, h, 4) != 4) oc_error("Cannot open BAM file '%s'", path);      /* l_ref */
 	}
 }
 
-typedef struct { uint16_t flag; int32_t tid, mtid, tlen; } core_t;
+typedef struct { uint16_t flag; int32_t tid, mtid, tlen, pos; } core_t;
 
 /* 1 = record, 0 = clean end of file; errors exit like src/common.rs:150-154 */
 static int bam_next(bgzf_t *b, core_t *c)
@@ -105,6 +112,7 @@ static int bam_next(bgzf_t *b, core_t *c)
 	if (r < 0) oc_error("Invalid BAM record.");
 	if (r != 32) oc_error("BAM file ended prematurely.");
 	c->tid = (int32_t)le32(core + 0);
+	c->pos = (int32_t)le32(core + 4);
 	c->flag = le16(core + 14);
 	c->mtid = (int32_t)le32(core + 20);
 	c->tlen = (int32_t)le32(core + 28);
@@ -175,10 +183,51 @@ static int fragment_lengths(int argc, char **argv)
 	return 0;
 }
 
+static const char *USAGE_FRAGMENTS =
+"\nUsage:\n  sam fragments [options] <bam_file>\n\nOptions:\n"
+"  --min-size=N     Minimum fragment size [default: 0]\n"
+"  --max-size=N     Maximum fragment size [default: 5000]\n";
+
+/* str::parse::<i64>(): optional sign, digits */
+static int parse_i64(const char *s, int64_t *out)
+{
+	int neg = 0;
+	if (*s == '+' || *s == '-') { neg = *s == '-'; s++; }
+	uint64_t v;
+	if (!oc_parse_uint(s, neg ? 9223372036854775808ULL : 9223372036854775807ULL, &v)) return 0;
+	*out = neg ? (int64_t)(0 - v) : (int64_t)v;
+	return 1;
+}
+
+/* src/sam_fragments.rs:14-43 */
+static int fragments(int argc, char **argv)
+{
+	oc_opt opts[2] = {{"--min-size", 1, NULL}, {"--max-size", 1, NULL}};
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 2, opts, 2, pos, &npos, 1) || npos != 1)
+		oc_error("Invalid arguments.\n%s", USAGE_FRAGMENTS);
+	int64_t min_size = 0, max_size = 5000;
+	if (opts[0].value && !parse_i64(opts[0].value, &min_size)) oc_panic("--min-size parse().unwrap()");
+	if (opts[1].value && !parse_i64(opts[1].value, &max_size)) oc_panic("--max-size parse().unwrap()");
+	bgzf_t *b = (bgzf_t *)malloc(sizeof(bgzf_t));
+	bgzf_open(b, pos[0]);
+	bam_read_header(b, pos[0]);
+	core_t c;
+	while (bam_next(b, &c)) {
+		uint8_t keep;
+		if (!orc_fragments_keep(&c.flag, &c.tid, &c.mtid, &c.tlen, 1, min_size, max_size, &keep)) continue;
+		if (c.tid < 0 || (uint32_t)c.tid >= g_n_ref) oc_panic("index out of bounds: chr_names[tid]");
+		int64_t t = c.tlen; if (t < 0) t = -t;
+		printf("%s\t%lld\t%lld\n", g_ref_names[c.tid], (long long)c.pos, (long long)c.pos + (long long)t);   /* :41 */
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	int rc;
-	if (argc >= 2 && !strcmp(argv[1], "statistics")) rc = statistics(argc, argv);
+	if (argc >= 2 && !strcmp(argv[1], "fragments")) rc = fragments(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "statistics")) rc = statistics(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "fragment") && !strcmp(argv[2], "lengths")) rc = fragment_lengths(argc, argv);
 	else { fprintf(stderr, "%s\n", USAGE_TOP); rc = 0; }
 	fflush(stdout);

@@ -192,6 +192,30 @@ int64_t orc_fragment_lengths_stop(const uint16_t *flag, const int32_t *tid, cons
 	return i;
 }
 
+/* src/sam_fragments.rs:27-38 */
+int64_t orc_fragments_keep(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                           int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep)
+{
+	int64_t kept = 0;
+	for (int64_t i = 0; i < n; i++) {
+		uint16_t f = flag[i];
+		keep[i] = 0;
+		if (!(f & F_PAIRED)) continue;                              /* :28 */
+		if ((f & F_UNMAPPED) || (f & F_MUNMAP)) continue;           /* :29 */
+		if ((f & F_DUP) || (f & F_SECONDARY)) continue;             /* :30 */
+		if (f & F_SUPPL) continue;                                  /* :31 */
+		if (tid[i] != mtid[i]) continue;                            /* :32 */
+		if ((f & 0x10) || !(f & 0x20)) continue;                    /* :33 is_reverse || !is_mate_reverse */
+		if (f & 0x200) continue;                                    /* :34 quality check failed */
+		int64_t t = (int64_t)tlen[i];
+		int64_t frag = t < 0 ? -t : t;                              /* :37 */
+		if (frag > max_size || frag < min_size) continue;           /* :38 */
+		keep[i] = 1;
+		kept++;
+	}
+	return kept;
+}
+
 /* ---------------------------------------------------------------------------------- */
 /* Rust std text semantics                                                            */
 

@@ -79,6 +79,12 @@ int64_t orc_fragment_lengths_stop(const uint16_t *flag, const int32_t *tid, cons
                                   const int32_t *tlen, int64_t n, int32_t max_frag,
                                   uint64_t stop_after, uint64_t *hist, uint64_t *hist_total);
 
+/* ---- f2: src/sam_fragments.rs:27-41 ------------------------------------------------ */
+/* keep[i] = 1 when record i is the forward mate of a converging, mapped, primary, non-duplicate, QC-passing pair on
+ * one reference whose |tlen| lies in [min_size, max_size]; returns the number kept.  */
+int64_t orc_fragments_keep(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                           int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep);
+
 /* ---- text helpers that restate Rust std behaviour used on the path -------------- */
 /* str::trim_end(): length of s after removing trailing Unicode White_Space chars
  * (U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F, 3000);

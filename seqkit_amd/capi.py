@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
-    "sk_timer_start", "sk_timer_stop",
+    "sk_bam_fragments", "sk_bam_fragments_dev", "sk_timer_start", "sk_timer_stop",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_counts_reset": (i32, [vp]), "sk_counts_get": (i32, [vp, vp]), "sk_counts_device_ptr": (vp, [vp]),
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
+        "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
+        "sk_bam_fragments_dev": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_timer_start": (i32, [vp]), "sk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in protos.items():
@@ -293,6 +295,24 @@ class Context:
         self._check(self._lib.sk_bam_flag_tlen(self._h, _ptr(flag), _ptr(tid), _ptr(mtid), _ptr(tlen), n, max_frag,
                                                _ptr(counters), _ptr(hist), _ptr(total)), "sk_bam_flag_tlen")
         return counters, hist, int(total[0])
+
+    def bam_fragments(self, flag, tid, mtid, tlen, min_size: int = 0, max_size: int = 5000):
+        """keep[n] (0/1) and the number kept: src/sam_fragments.rs:27-38."""
+        n = len(flag)
+        flag = _vec(flag, np.uint16, n, "flag")
+        tid = _vec(tid, np.int32, n, "tid")
+        mtid = _vec(mtid, np.int32, n, "mtid")
+        tlen = _vec(tlen, np.int32, n, "tlen")
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        kept = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sk_bam_fragments(self._h, _ptr(flag), _ptr(tid), _ptr(mtid), _ptr(tlen), n, min_size, max_size,
+                                               _ptr(bits), _ptr(kept)), "sk_bam_fragments")
+        return np.unpackbits(bits, bitorder="little")[:n], int(kept[0])
+
+    def bam_fragments_dev(self, flag: int, tid: int, mtid: int, tlen: int, n: int, min_size: int, max_size: int, keep_bits: int,
+                          kept: int) -> None:
+        self._check(self._lib.sk_bam_fragments_dev(self._h, flag, tid, mtid, tlen, n, min_size, max_size, keep_bits, kept),
+                    "sk_bam_fragments_dev")
 
     # ---- device entry points (raw addresses) ---------------------------------------------
     def fused_pass_dev(self, n: int, stride: int, min_baseq: int, mates, bc: int = 0, bc_stride: int = 0,

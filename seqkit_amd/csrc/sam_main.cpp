@@ -3,6 +3,7 @@
 //
 //   sam statistics [--on-target=BED] <bam_file>                         src/sam_statistics.rs:14-116
 //   sam fragment lengths [--max-frag-size=F] [--reads=N] <bam_file>     src/sam_fragment_lengths.rs:14-48
+//   sam fragments [--min-size=N] [--max-size=N] <bam_file>              src/sam_fragments.rs:14-43   (§8f f2)
 //
 // The reference reads BAM through rust-htslib; this host walks the BGZF/BAM container itself (SAMv1 §4.2: BGZF is a
 // series of gzip members; after the header every record is block_size:u32 + a 32-byte fixed core) and hands the core
@@ -315,11 +316,66 @@ static int fragment_lengths(int argc, char **argv)
 	return 0;
 }
 
+// ---- sam fragments ---------------------------------------------------------------------------
+static const char *USAGE_FRAGMENTS =
+	"\nUsage:\n  sam fragments [options] <bam_file>\n\nOptions:\n"
+	"  --min-size=N     Minimum fragment size [default: 0]\n"
+	"  --max-size=N     Maximum fragment size [default: 5000]\n";
+
+static bool parse_i64(const std::string &s, int64_t &out)          // str::parse::<i64>()
+{
+	const char *p = s.c_str();
+	bool neg = false;
+	if (*p == '+' || *p == '-') { neg = *p == '-'; p++; }
+	uint64_t v;
+	if (!host::parse_uint(p, neg ? 9223372036854775808ull : 9223372036854775807ull, v)) return false;
+	out = neg ? (int64_t)(0 - v) : (int64_t)v;
+	return true;
+}
+
+static int fragments(int argc, char **argv)                        // src/sam_fragments.rs:14-43
+{
+	std::vector<host::Opt> opts = {{"--min-size", true, false, "0"}, {"--max-size", true, false, "5000"}};
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_FRAGMENTS);
+	int64_t min_size, max_size;
+	if (!parse_i64(opts[0].value, min_size)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--min-size)");   // :17
+	if (!parse_i64(opts[1].value, max_size)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--max-size)");   // :18
+	BamStream bam(pos[0]);
+	Columns col;
+	BamCore c;
+	bool more = true;
+	std::vector<uint8_t> bits;
+	char buf[128];
+	while (more) {
+		col.clear();
+		while (col.flag.size() < kBatch && (more = bam.next(c, false))) col.push(c, true);
+		const int64_t n = (int64_t)col.flag.size();
+		if (n == 0) break;
+		bits.assign((size_t)(n + 7) / 8, 0);
+		uint64_t kept = 0;
+		// the record filter on the device: src/sam_fragments.rs:27-38
+		check(sk_bam_fragments(host::gpu(), col.flag.data(), col.tid.data(), col.mtid.data(), col.tlen.data(), n, min_size, max_size, bits.data(), &kept), "sk_bam_fragments");
+		if (kept == 0) continue;
+		for (int64_t i = 0; i < n; i++) {
+			if (!(bits[(size_t)i >> 3] >> (i & 7) & 1)) continue;
+			if (col.tid[i] < 0 || (size_t)col.tid[i] >= bam.names.size()) panic("index out of bounds: chr_names[tid]");
+			int64_t t = col.tlen[i];
+			if (t < 0) t = -t;
+			snprintf(buf, sizeof buf, "\t%lld\t%lld\n", (long long)col.pos[i], (long long)col.pos[i] + (long long)t);      // :41
+			host::out().write(bam.names[col.tid[i]]);
+			host::out().write(buf, strlen(buf));
+		}
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	int rc = 0;
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
-	if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
+	if (argc >= 2 && is(1, "fragments")) rc = fragments(argc, argv);
+	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else if (argc >= 3 && is(1, "fragment") && is(2, "lengths")) rc = fragment_lengths(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);
 	host::out().flush();

@@ -590,6 +590,56 @@ int sk_bam_flag_tlen(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	return SK_OK;
 }
 
+// ---- f2: sam fragments filter ----------------------------------------------------------------------------------
+int sk_bam_fragments_dev(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                         int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (n == 0) return SK_OK;
+	if (!flag || !tid || !mtid || !tlen || !keep_bits || !kept) return fail(c, SK_ERR_INVALID, "NULL column or output");
+	if (!aligned16(flag) || !aligned16(tid) || !aligned16(mtid) || !aligned16(tlen)) return fail(c, SK_ERR_INVALID, "columns must be 16-byte aligned");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bam_fragments(flag, tid, mtid, tlen, n, min_size, max_size, keep_bits, (unsigned long long *)kept, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
+                     int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (n == 0) return SK_OK;
+	if (!flag || !tid || !mtid || !tlen || !keep_bits) return fail(c, SK_ERR_INVALID, "NULL column or output");
+	if (int r = bind(c)) return r;
+	int64_t chunk = 8 << 20;
+	if (chunk > n) chunk = (n + 7) & ~(int64_t)7;
+	const size_t need = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4) + up256((size_t)chunk / 8 + 8) + 256;
+	if (int r = ensure_ws(c, need)) return r;
+	uint8_t *p = c->ws;
+	uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
+	int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+	int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+	int32_t *dtlen = (int32_t *)p; p += up256((size_t)chunk * 4);
+	uint8_t *dbits = p; p += up256((size_t)chunk / 8 + 8);
+	unsigned long long *dkept = (unsigned long long *)p;
+	SK_HIP(c, hipMemsetAsync(dkept, 0, 8, c->stream));
+	for (int64_t o = 0; o < n; o += chunk) {      // chunk is a multiple of 8 records: byte-aligned in keep_bits
+		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, sk::launch_bam_fragments(dflag, dtid, dmtid, dtlen, nr, min_size, max_size, dbits, dkept, c->n_cu, c->stream));
+		SK_HIP(c, hipMemcpyAsync(keep_bits + o / 8, dbits, (size_t)((nr + 7) / 8), hipMemcpyDeviceToHost, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	uint64_t k = 0;
+	SK_HIP(c, hipMemcpy(&k, dkept, 8, hipMemcpyDeviceToHost));
+	if (kept) *kept += k;
+	return SK_OK;
+}
+
 // ---- timing ----------------------------------------------------------------------------------------
 int sk_timer_start(sk_ctx *c)
 {

@@ -73,4 +73,7 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
                                 int64_t n, int32_t max_frag, unsigned long long *out, int want_counters, int want_hist,
                                 int n_cu, hipStream_t st);
 
+hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
+                                int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st);
+
 }  // namespace sk

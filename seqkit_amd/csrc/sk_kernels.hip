@@ -1250,6 +1250,64 @@ __global__ __launch_bounds__(256) void bam_flag_tlen_scalar_kernel(const uint16_
 	bam_flush(acc, wg_cnt, lh, lds_bins, out);
 }
 
+// f2: src/sam_fragments.rs:27-38 — the forward mate of a converging, mapped, primary, non-duplicate, QC-passing pair on
+// one reference with min_size <= |tlen| <= max_size.  Output is a bit mask (bit j of byte k <=> record 8k+j): each lane
+// decides its 8 consecutive records and stores one byte; the host turns set bits into BED lines (:41).
+__global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__restrict__ flag, const int32_t *__restrict__ tid,
+                                                            const int32_t *__restrict__ mtid, const int32_t *__restrict__ tlen,
+                                                            int64_t n, u32 min_size, u32 max_size, uint8_t *__restrict__ keep_bits,
+                                                            unsigned long long *__restrict__ kept)
+{
+	u32 count = 0;
+	const int64_t per_it = (int64_t)blockDim.x * 8;
+	for (int64_t base = (int64_t)blockIdx.x * per_it; base < n; base += (int64_t)gridDim.x * per_it) {
+		const int64_t left = n - base;
+		const int nrec = (int)(left < per_it ? left : per_it);
+		const rsrc_t rf = make_rsrc(flag, base * 2, (nrec * 2 + 3) & ~3);
+		const rsrc_t rt = make_rsrc(tid, base * 4, nrec * 4);
+		const rsrc_t rm = make_rsrc(mtid, base * 4, nrec * 4);
+		const rsrc_t rl = make_rsrc(tlen, base * 4, nrec * 4);
+		const rsrc_t ro = make_rsrc(keep_bits, base >> 3, (nrec + 7) >> 3);
+		const int r0 = threadIdx.x * 8;
+		const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rf, r0 * 2, 0, 0);
+		const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rt, r0 * 4, 0, 0), t1 = __builtin_amdgcn_raw_buffer_load_b128(rt, r0 * 4 + 16, 0, 0);
+		const u32x4 m0 = __builtin_amdgcn_raw_buffer_load_b128(rm, r0 * 4, 0, 0), m1 = __builtin_amdgcn_raw_buffer_load_b128(rm, r0 * 4 + 16, 0, 0);
+		const u32x4 l0 = __builtin_amdgcn_raw_buffer_load_b128(rl, r0 * 4, 0, 0), l1 = __builtin_amdgcn_raw_buffer_load_b128(rl, r0 * 4 + 16, 0, 0);
+		u32 bits = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const u32 fj = (f[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+			const int32_t tj = (int32_t)(j < 4 ? t0[j & 3] : t1[j & 3]);
+			const int32_t mj = (int32_t)(j < 4 ? m0[j & 3] : m1[j & 3]);
+			const int32_t lj = (int32_t)(j < 4 ? l0[j & 3] : l1[j & 3]);
+			// paired, both mapped, not dup / secondary / supplementary / QC-fail, this mate forward, mate reverse
+			const bool flags_ok = (fj & (0x1u | 0x4u | 0x8u | 0x400u | 0x100u | 0x800u | 0x10u | 0x20u | 0x200u)) == (0x1u | 0x20u);
+			const u32 af = lj < 0 ? (u32)0 - (u32)lj : (u32)lj;
+			const bool keep = (r0 + j < nrec) && flags_ok && tj == mj && af >= min_size && af <= max_size;
+			bits |= keep ? (1u << j) : 0u;
+		}
+		__builtin_amdgcn_raw_buffer_store_b8((uint8_t)bits, ro, threadIdx.x, 0, 0);
+		count += (u32)__builtin_popcount(bits);
+	}
+	// one atomic per wave
+	for (int off = 32; off > 0; off >>= 1) count += __shfl_down(count, off, 64);
+	if ((threadIdx.x & 63) == 0 && count) atomicAdd(kept, (unsigned long long)count);
+}
+
+hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
+                                int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	// |tlen| <= 2^31: clamp the i64 window of the reference into that range (an empty window keeps nothing)
+	const int64_t lo = min_size < 0 ? 0 : min_size, hi = max_size > 0x80000000ll ? 0x80000000ll : max_size;
+	const u32 ulo = lo > 0x80000000ll ? 0xffffffffu : (u32)lo, uhi = hi < 0 ? 0u : (u32)hi;
+	const bool empty = hi < 0 || lo > hi;
+	int64_t want = (n + 2047) / 2048;
+	int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
+	bam_fragments_kernel<<<grid, 256, 0, st>>>(flag, tid, mtid, tlen, n, empty ? 1u : ulo, empty ? 0u : uhi, keep_bits, kept);
+	return hipGetLastError();
+}
+
 hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                                 int64_t n, int32_t max_frag, unsigned long long *out, int want_counters, int want_hist,
                                 int n_cu, hipStream_t st)

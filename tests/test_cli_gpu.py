@@ -283,6 +283,19 @@ def test_sam_statistics_and_fragment_lengths_cli(bins, tmp_path, golden):
     assert a[1] == b"Total reads: 4\nAligned reads: 3 (75.0% of all reads)\nDuplicate reads: 1 (33.3% of aligned reads)\n"
 
 
+def test_sam_fragments_cli(bins, tmp_path):
+    bam = tmp_path / "f.bam"
+    make_bam(str(bam), 20000, seed=15)
+    a, *_ = both(bins, "sam", ["fragments", str(bam)], tmp_path)
+    assert a[0] == 0 and a[1].count(b"\n") > 100 and a[1].split(b"\n")[0].count(b"\t") == 2
+    both(bins, "sam", ["fragments", "--min-size=150", "--max-size", "200", str(bam)], tmp_path)
+    both(bins, "sam", ["fragments", "--max-size=-1", str(bam)], tmp_path)
+    a, *_ = both(bins, "sam", ["fragments", "--min-size=abc", str(bam)], tmp_path, same_stderr=False)
+    assert a[0] == 101
+    a, *_ = both(bins, "sam", ["fragments"], tmp_path)
+    assert a[0] == 255
+
+
 def test_sam_edge_cases(bins, tmp_path):
     bam = tmp_path / "e.bam"
     cu.write_bam(str(bam), [("chr1", 1000)], [])                              # no records: NaN percentages

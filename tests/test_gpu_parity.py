@@ -382,6 +382,20 @@ def test_bam_dev_entry_point_aligned_and_unaligned_columns(ctx, oracle):
             ctx.free_device(d)
 
 
+@pytest.mark.parametrize("n,lo,hi", [(1, 0, 5000), (100003, 0, 5000), (65536, 100, 300), (5000, -5, 10**12), (5000, 400, 100), (777, 0, 0)])
+def test_bam_fragments_filter(ctx, oracle, n, lo, hi):
+    """f2, src/sam_fragments.rs:27-38: the keep mask and the count against the oracle, incl. empty and unbounded windows."""
+    flag, tid, mtid, tlen = synth.make_bam_cores(n, seed=n)
+    flag ^= (np.random.default_rng(n).random(n) < 0.05).astype(np.uint16) * 0x200     # some QC failures
+    if n > 10:
+        tlen[5] = -2147483648
+        flag[5] = 0x1 | 0x20
+        mtid[5] = tid[5]
+    keep, kept = ctx.bam_fragments(flag, tid, mtid, tlen, lo, hi)
+    exp = oracle.fragments_keep(flag, tid, mtid, tlen, lo, hi)
+    assert np.array_equal(keep, exp) and kept == int(exp.sum())
+
+
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
 def test_errors_are_codes_not_crashes(ctx):
     import seqkit_amd

@@ -68,7 +68,10 @@ mtid = torch.from_numpy(mtid_np).to(dev).repeat(100)
 tlen = torch.from_numpy(tlen_np).to(dev).repeat(100)
 out = torch.zeros((4 + 5001,), dtype=torch.int64, device=dev)
 timeit("cfg5 sam statistics + fragment lengths 200M records (14 B)", lambda: ctx.bam_flag_tlen_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 5000, out.data_ptr()), n, 14, iters=3, rounds=3)
-del flag, tid, mtid, tlen
+bits = torch.zeros((n // 8 + 8,), dtype=torch.uint8, device=dev)
+kept = torch.zeros((1,), dtype=torch.int64, device=dev)
+timeit("f2 sam fragments filter 200M records (14 B)", lambda: ctx.bam_fragments_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 0, 5000, bits.data_ptr(), kept.data_ptr()), n, 14.125, iters=3, rounds=3)
+del flag, tid, mtid, tlen, bits
 
 # PCIe-inclusive: the host entry point on pageable numpy buffers (staging + H2D + kernel + D2H)
 n = 2_000_000
