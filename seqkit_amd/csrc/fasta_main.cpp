@@ -13,7 +13,10 @@
 // been emitted, exactly where the reference would have stopped.
 #include <algorithm>
 #include <cstring>
+#include <deque>
+#include <future>
 #include <memory>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -312,9 +315,31 @@ struct Sample {
 	uint64_t total_reads = 0;
 };
 
-struct Cluster {
-	std::string header, l2, l3, l4;           // mate 1 (header with the BC field already removed in header mode)
-	std::string m2[4];                        // mate 2, raw lines
+// ---- one block of clusters (all input files cut at the same record count) -> per-sample text -----------------------
+struct DemuxCfg {
+	std::vector<Sample> *samples;
+	size_t barcode_len;
+	bool paired_end;
+	int nindex;
+	bool do_mask, do_trim;
+	uint8_t q;
+	bool dry_run;
+};
+
+struct DemuxOut {
+	size_t nclusters = 0;                          // clusters the reference would have counted (total_reads) in this block
+	uint64_t identified = 0;
+	std::vector<uint64_t> per_sample;
+	std::string warn;                              // stderr text, in cluster order
+	std::vector<std::string> out1, out2;           // per sample
+	std::vector<std::pair<std::string, uint64_t>> extras;     // dry run: unmatched barcodes in first-seen order
+	std::string err;
+	int err_code = 255;
+};
+
+struct ClusterV {
+	host::Line h, l2, l3, l4, m2[4];
+	size_t bc_st = 0, bc_en = 0;                   // header mode: the " BC:..." field inside h
 	std::string barcode;
 };
 
@@ -324,6 +349,204 @@ static void close_outputs()
 	if (!g_samples) return;
 	for (auto &s : *g_samples) for (auto &o : s.out) if (o) o->close();
 }
+
+static inline size_t strip_nl(const host::Line &l) { return l.n - ((l.n && l.p[l.n - 1] == '\n') ? 1 : 0); }
+
+static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, fastq2, index1, index2 */, DemuxOut &res)
+{
+	std::vector<Sample> &samples = *cfg.samples;
+	const int S = (int)samples.size();
+	const size_t L = cfg.barcode_len;
+	const bool fused = cfg.do_mask || cfg.do_trim;
+	res.per_sample.assign(S, 0);
+	if (!cfg.dry_run) { res.out1.resize(S); if (cfg.paired_end) res.out2.resize(S); }
+	host::BlockLines f1(blk[0].data(), blk[0].size()), f2(blk[1].data(), blk[1].size());
+	host::BlockLines ix[2] = {host::BlockLines(blk[2].data(), blk[2].size()), host::BlockLines(blk[3].data(), blk[3].size())};
+	auto bad = [&](const host::Line &l) { return !line_utf8_ok(l); };
+
+	// ---- gather (src/fasta_demultiplex.rs:117-150; all lines of a cluster are consumed here, :239-246 does it for
+	// unassigned reads too)
+	std::vector<ClusterV> cl;
+	cl.reserve(blk[0].size() / 200 + 4);
+	for (;;) {
+		ClusterV c;
+		c.h = f1.next();                                                    // :117
+		if (c.h.n == 0) break;
+		if (bad(c.h)) { res.err = "I/O error while reading from file."; break; }
+		if (c.h.p[0] != '@') { res.err = "Invalid FASTQ header line:\n" + std::string(c.h.p, c.h.n); break; }   // :118-120
+		bool stop = false;
+		if (cfg.nindex > 0) {                                               // :126-136
+			for (int f = 0; f < cfg.nindex && !stop; f++) {
+				if (!c.barcode.empty()) c.barcode += "+";
+				host::Line a = ix[f].next();
+				if (bad(a)) { res.err = "I/O error while reading from file."; stop = true; break; }
+				if (a.n == 0 || a.p[0] != '@') { res.err = "assertion failed: line.starts_with('@')"; res.err_code = 101; stop = true; break; }
+				host::Line b = ix[f].next();
+				if (bad(b)) { res.err = "I/O error while reading from file."; stop = true; break; }
+				c.barcode.append(b.p, host::trim_end_len(b.p, b.n));
+				host::Line d = ix[f].next();
+				if (bad(d)) { res.err = "I/O error while reading from file."; stop = true; break; }
+				if (d.n == 0 || d.p[0] != '+') { res.err = "assertion failed: line.starts_with('+')"; res.err_code = 101; stop = true; break; }
+				host::Line e = ix[f].next();
+				if (bad(e)) { res.err = "I/O error while reading from file."; stop = true; break; }
+			}
+		} else {                                                            // :137-146
+			const std::string hs(c.h.p, c.h.n);
+			if (!host::find_bc_field(hs, c.bc_st, c.bc_en)) { res.err = "No BC:xxxx field found."; stop = true; }
+			else c.barcode.assign(hs, c.bc_st + 4, c.bc_en - c.bc_st - 4);
+		}
+		if (stop) break;
+		if (c.barcode.size() != L) {                                        // :148-150
+			char buf[512];
+			snprintf(buf, sizeof buf, "Sequenced barcode %s is of different length (%zu nt) than barcodes in the sample sheet (%zu nt).",
+			         c.barcode.c_str(), c.barcode.size(), L);
+			res.err = buf;
+			break;
+		}
+		c.l2 = f1.next(); c.l3 = f1.next(); c.l4 = f1.next();
+		if (bad(c.l2) || bad(c.l3) || bad(c.l4)) { res.err = "I/O error while reading from file."; break; }
+		if (cfg.paired_end) {
+			for (int k = 0; k < 4; k++) c.m2[k] = f2.next();
+			if (bad(c.m2[0]) || bad(c.m2[1]) || bad(c.m2[2]) || bad(c.m2[3])) { res.err = "I/O error while reading from file."; break; }
+		}
+		cl.push_back(std::move(c));
+	}
+
+	// ---- D1+D2+D3 (and, fused, M1 + T1 of both mates) for the block through the C-ABI ------------------------------
+	const size_t nb = cl.size();
+	res.nclusters = nb;
+	std::vector<int32_t> assign(nb, SK_ASSIGN_NONE);                        // empty sheet: lowest_diff stays usize::MAX
+	std::vector<uint8_t> lowest(nb);
+	std::vector<int16_t> first(nb), last(nb);
+	std::vector<uint8_t> bc(nb * L);
+	for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * L, cl[i].barcode.data(), L);
+	const int nm = cfg.paired_end ? 2 : 1;
+	Matrix mseq[2], mqual[2], mout[2];
+	std::vector<uint16_t> mlen[2], mlk[2];
+	if (nb > 0 && fused) {
+		size_t stride = 1;
+		for (size_t i = 0; i < nb; i++) {
+			stride = std::max(stride, std::max(cl[i].l2.n, cl[i].l4.n));
+			if (cfg.paired_end) stride = std::max(stride, std::max(cl[i].m2[1].n, cl[i].m2[3].n));
+		}
+		if (stride > kMaxRow) { res.err = "Read longer than 65535 bases: not supported by this build."; res.nclusters = 0; return; }
+		sk_fused_args fa;
+		memset(&fa, 0, sizeof fa);
+		fa.n = (int64_t)nb; fa.n_mates = nm; fa.stride = (int)stride; fa.min_baseq = cfg.q;
+		for (int m = 0; m < nm; m++) {
+			mseq[m].data.assign(nb * stride, 0);
+			mqual[m].data.assign(nb * stride, 0);
+			mlen[m].resize(nb);
+			mlk[m].resize(nb);
+			for (size_t i = 0; i < nb; i++) {
+				const host::Line &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
+				const size_t ls = strip_nl(sl), lq = strip_nl(ql);
+				memcpy(mseq[m].data.data() + i * stride, sl.p, ls);
+				memcpy(mqual[m].data.data() + i * stride, ql.p, lq);
+				mlen[m][i] = (uint16_t)std::min(host::trim_end_len(ql.p, ql.n), lq);      // trim: n = qual.trim_end().len()
+			}
+			mout[m].data.resize(nb * stride);
+			mout[m].stride = (int)stride;
+			fa.mate[m].seq = mseq[m].data.data(); fa.mate[m].qual = mqual[m].data.data(); fa.mate[m].len = mlen[m].data();
+			fa.mate[m].out_seq = cfg.do_mask ? mout[m].data.data() : nullptr;
+			fa.mate[m].lowest_k = cfg.do_trim ? mlk[m].data() : nullptr;
+		}
+		if (L > 0) {
+			fa.bc = bc.data(); fa.bc_stride = (int)L; fa.assign = assign.data();
+			fa.lowest_diff = lowest.data(); fa.first_idx = first.data(); fa.last_idx = last.data();
+		}
+		std::lock_guard<std::mutex> lk(host::gpu_mutex());
+		check(sk_fused_pass(host::gpu(), &fa), "sk_fused_pass");
+	} else if (nb > 0 && L > 0) {
+		std::lock_guard<std::mutex> lk(host::gpu_mutex());
+		check(sk_demux_assign(host::gpu(), bc.data(), (int)L, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
+	}
+
+	// body of one written record: verbatim lines, or the lines `mask by quality` then `trim by quality` would print
+	auto emit_body = [&](std::string &w, const host::Line &sl, const host::Line &pl, const host::Line &ql, size_t i, int m) -> bool {
+		if (!fused) { w.append(sl.p, sl.n); w.append(pl.p, pl.n); w.append(ql.p, ql.n); return true; }
+		const size_t ls = strip_nl(sl), lq = strip_nl(ql);
+		const char *seq_p = sl.p, *qual_p = ql.p;
+		size_t seq_n = sl.n;                                                // current seq line incl. its newline (trim-only view)
+		if (cfg.do_mask) {                                                  // src/fasta_mask_by_quality.rs:32-45
+			if (ls != lq) { res.err = "Read sequence and base qualities are of different length."; return false; }
+			if (!host::is_ascii(sl.p, sl.n) || !host::is_ascii(ql.p, ql.n)) { res.err = "Non-ASCII read lines are not supported together with --mask-by-quality."; return false; }
+			seq_p = reinterpret_cast<const char *>(mout[m].data.data()) + i * (size_t)mout[m].stride;
+			seq_n = ls + 1;                                                 // masked bases + the newline mask prints
+		}
+		if (cfg.do_trim) {                                                  // src/fasta_trim_by_quality.rs:44-48
+			const size_t lk = mlk[m][i];
+			if (lk == 0) { w.append("N\n+\n!\n", 6); return true; }
+			if (lk > seq_n) { res.err = "byte index out of range of `seq`"; res.err_code = 101; return false; }
+			w.append(seq_p, lk);                                            // &seq[..lowest_k] of the current seq line
+			w.append("\n+\n", 3);
+			w.append(qual_p, lk);
+			w.push_back('\n');
+		} else {
+			w.append(seq_p, ls); w.push_back('\n');
+			w.append("+\n", 2);
+			w.append(qual_p, lq); w.push_back('\n');
+		}
+		return true;
+	};
+
+	// ---- emit in input order (src/fasta_demultiplex.rs:168-238) ------------------------------------------------------
+	std::unordered_map<std::string, size_t> extra_idx;
+	std::string umi;
+	char wbuf[1024];
+	for (size_t i = 0; i < nb; i++) {
+		ClusterV &c = cl[i];
+		bool write_read_out = false;
+		if (assign[i] >= 0) {                                               // :173-179
+			res.identified += 1;
+			res.per_sample[assign[i]] += 1;
+			write_read_out = !cfg.dry_run;
+		} else if (assign[i] == SK_ASSIGN_AMBIGUOUS) {                      // :181-189
+			const Sample &a = samples[first[i]], &b = samples[last[i]];
+			snprintf(wbuf, sizeof wbuf, "WARNING: Sequenced barcode %s was an equally good match (%u mismatches) for samples %s (%s) and %s (%s), and was therefore not assigned to any sample.\n",
+			         c.barcode.c_str(), (unsigned)lowest[i], a.name.c_str(), a.barcode.c_str(), b.name.c_str(), b.barcode.c_str());
+			res.warn += wbuf;
+		} else if (cfg.dry_run) {                                           // :190-194
+			auto it = extra_idx.find(c.barcode);
+			if (it == extra_idx.end()) { extra_idx.emplace(c.barcode, res.extras.size()); res.extras.emplace_back(c.barcode, 1); }
+			else res.extras[it->second].second += 1;
+		}
+		if (!write_read_out) continue;
+		const Sample &sm = samples[assign[i]];
+		umi.clear();                                                        // :200-203 (chars().zip(chars()))
+		{
+			const uint8_t *sp = reinterpret_cast<const uint8_t *>(sm.barcode.data()), *bp = reinterpret_cast<const uint8_t *>(c.barcode.data());
+			size_t a = 0, b = 0;
+			while (a < sm.barcode.size() && b < c.barcode.size()) {
+				const size_t la = u8len(sp[a]), lb = u8len(bp[b]);
+				if (la == 1 && sp[a] == 'U') umi.append(c.barcode, b, lb);
+				a += la; b += lb;
+			}
+		}
+		// header with the BC field drained (:145), then trim_end (:206)
+		auto emit_header = [&](std::string &w, const host::Line &h, bool drain, size_t st, size_t en) {
+			const size_t before = w.size();
+			if (drain) { w.append(h.p, st); w.append(h.p + en, h.n - en); }
+			else w.append(h.p, h.n);
+			w.resize(before + host::trim_end_len(w.data() + before, w.size() - before));
+			if (!umi.empty()) { w.append(" UMI:", 5); w.append(umi); }       // :207
+			w.push_back('\n');                                              // :208
+		};
+		std::string &w1 = res.out1[assign[i]];
+		emit_header(w1, c.h, cfg.nindex == 0, c.bc_st, c.bc_en);
+		if (!emit_body(w1, c.l2, c.l3, c.l4, i, 0)) { res.nclusters = i; return; }           // :209-212
+		if (cfg.paired_end) {                                               // :215-237
+			std::string &w2 = res.out2[assign[i]];
+			size_t st = 0, en = 0;
+			bool drain = false;
+			if (cfg.nindex == 0) drain = host::find_bc_field(std::string(c.m2[0].p, c.m2[0].n), st, en);
+			emit_header(w2, c.m2[0], drain, st, en);
+			if (!emit_body(w2, c.m2[1], c.m2[2], c.m2[3], i, 1)) { res.nclusters = i; return; }
+		}
+	}
+}
+
+static const size_t kDemuxBlockRecords = 1u << 15;
 
 static int demultiplex(int argc, char **argv)
 {
@@ -337,22 +560,19 @@ static int demultiplex(int argc, char **argv)
 	const bool do_mask = opts[4].present, do_trim = opts[5].present;
 	const uint8_t mask_q = do_mask ? parse_min_baseq(opts[4].value) : 0, trim_q = do_trim ? parse_min_baseq(opts[5].value) : 0;
 	if (do_mask && do_trim && mask_q != trim_q) error("--mask-by-quality and --trim-by-quality must use the same threshold in one pass.");
-	const bool fused = do_mask || do_trim;
 	uint64_t dry_run = 0;                                                   // :33-36
 	if (!host::parse_uint(opts[3].value.c_str(), UINT64_MAX, dry_run)) dry_run = 0;
 	if (dry_run == 0 && !opts[3].value.empty()) error("In --dry-run=N, N must be 64-bit positive integer.");
 
-	std::vector<std::unique_ptr<host::LineReader>> fastq, index_fastq;      // :41-55
-	fastq.emplace_back(new host::LineReader(pos[1]));
-	if (pos.size() == 3 && !pos[2].empty()) fastq.emplace_back(new host::LineReader(pos[2]));
-	const bool paired_end = fastq.size() == 2;
-	if (!opts[1].value.empty()) index_fastq.emplace_back(new host::LineReader(opts[1].value));
-	if (!opts[2].value.empty()) index_fastq.emplace_back(new host::LineReader(opts[2].value));
-	auto rd = [](host::LineReader &r, std::string &s) {
-		const bool ok = r.read_line(s);
-		if (r.bad_utf8()) { close_outputs(); error("I/O error while reading from file."); }
-		return ok;
-	};
+	// :41-55 — FileReader::new for the reads and the index files (open errors come before the sheet is read)
+	std::vector<std::unique_ptr<host::RecordBlocks>> files(4);
+	{ host::LineReader probe(pos[1]); }
+	files[0].reset(new host::RecordBlocks(pos[1], 4));
+	const bool paired_end = pos.size() == 3 && !pos[2].empty();
+	if (paired_end) { { host::LineReader probe(pos[2]); } files[1].reset(new host::RecordBlocks(pos[2], 4)); }
+	int nindex = 0;
+	for (int k = 1; k <= 2; k++)
+		if (!opts[k].value.empty()) { { host::LineReader probe(opts[k].value); } files[2 + nindex].reset(new host::RecordBlocks(opts[k].value, 4)); nindex++; }
 
 	fputs("Reading sample sheet...\n", stderr);                             // :58
 	std::vector<Sample> samples;
@@ -362,10 +582,13 @@ static int demultiplex(int argc, char **argv)
 	{
 		host::LineReader sheet(pos[0]);
 		std::string line;
-		while (rd(sheet, line)) {                                           // :63
+		for (;;) {
+			const bool ok = sheet.read_line(line);                          // :63
+			if (sheet.bad_utf8()) { close_outputs(); error("I/O error while reading from file."); }
+			if (!ok) break;
 			if (line[0] == '#') continue;                                   // :64
-			const size_t off = host::trim_start_off(line);                  // :65 line.trim().split('\t')
-			const std::string t = line.substr(off, host::trim_end_len(line) > off ? host::trim_end_len(line) - off : 0);
+			const size_t off = host::trim_start_off(line), end = host::trim_end_len(line);      // :65 line.trim().split('\t')
+			const std::string t = line.substr(off, end > off ? end - off : 0);
 			const size_t tab1 = t.find('\t');
 			if (tab1 == std::string::npos) continue;                        // :66
 			const size_t tab2 = t.find('\t', tab1 + 1);
@@ -403,179 +626,62 @@ static int demultiplex(int argc, char **argv)
 	std::unordered_map<std::string, uint64_t> extra_barcodes;
 	std::vector<std::string> extra_order;            // first-seen order (the reference's HashMap order is arbitrary)
 
-	bool done = false;
-	std::string pending;                             // error text to raise after the batch
-	int pending_code = 255;
-	std::string line, umi;
-	while (!done) {
-		// ---- gather a batch of clusters (all lines are consumed here; :239-246 consumes them for unassigned reads too)
-		std::vector<Cluster> cl;
-		size_t want = kBatchRecords;
-		if (dry_run > 0) want = (size_t)std::min<uint64_t>(want, dry_run - total_reads);
-		while (cl.size() < want) {
-			Cluster c;
-			if (!rd(*fastq[0], c.header)) { done = true; break; }           // :117
-			if (c.header[0] != '@') { pending = "Invalid FASTQ header line:\n" + c.header; done = true; break; }   // :118-120
-			if (!index_fastq.empty()) {                                     // :126-136
-				bool bad = false;
-				for (auto &ifq : index_fastq) {
-					if (!c.barcode.empty()) c.barcode += "+";
-					rd(*ifq, line);
-					if (line.empty() || line[0] != '@') { pending = "assertion failed: line.starts_with('@')"; pending_code = 101; bad = true; break; }
-					rd(*ifq, line);
-					c.barcode.append(line, 0, host::trim_end_len(line));
-					rd(*ifq, line);
-					if (line.empty() || line[0] != '+') { pending = "assertion failed: line.starts_with('+')"; pending_code = 101; bad = true; break; }
-					rd(*ifq, line);
-				}
-				if (bad) { done = true; break; }
-			} else {                                                        // :137-146
-				size_t st, en;
-				if (!host::find_bc_field(c.header, st, en)) { pending = "No BC:xxxx field found."; done = true; break; }
-				c.barcode.assign(c.header, st + 4, en - st - 4);
-				c.header.erase(st, en - st);
-			}
-			if (c.barcode.size() != barcode_len) {                          // :148-150
-				char buf[512];
-				snprintf(buf, sizeof buf, "Sequenced barcode %s is of different length (%zu nt) than barcodes in the sample sheet (%zu nt).",
-				         c.barcode.c_str(), c.barcode.size(), barcode_len);
-				pending = buf; done = true; break;
-			}
-			rd(*fastq[0], c.l2); rd(*fastq[0], c.l3); rd(*fastq[0], c.l4);
-			if (paired_end) for (int k = 0; k < 4; k++) rd(*fastq[1], c.m2[k]);
-			cl.push_back(std::move(c));
-		}
+	DemuxCfg cfg{&samples, barcode_len, paired_end, nindex, do_mask, do_trim, do_mask ? mask_q : trim_q, dry_run > 0};
+	unsigned nthreads = std::thread::hardware_concurrency();
+	if (const char *e = getenv("SEQKIT_THREADS")) nthreads = (unsigned)atoi(e);
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 16) nthreads = 16;
+	if (dry_run > 0) nthreads = 1;                   // the --dry-run=N stop (:248) depends on the running count
+	size_t block_records = kDemuxBlockRecords;
+	if (const char *e = getenv("SEQKIT_BLOCK_RECORDS")) block_records = (size_t)atoll(e);     // tests use tiny blocks
 
-		// ---- D1+D2+D3 for the batch through the C-ABI: src/fasta_demultiplex.rs:154-194,269-277
-		const size_t nb = cl.size();
-		std::vector<int32_t> assign(nb);
-		std::vector<uint8_t> lowest(nb);
-		std::vector<int16_t> first(nb), last(nb);
-		std::vector<uint8_t> bc(nb * barcode_len);
-		for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * barcode_len, cl[i].barcode.data(), barcode_len);
-		// fused mode: the mates' bases and qualities ride in the same pass (M1 + T1 next to D1-D3)
-		const int nm = paired_end ? 2 : 1;
-		Matrix mseq[2], mqual[2], mout[2];
-		std::vector<uint16_t> mlen[2], mlk[2];
-		if (nb > 0 && fused) {
-			// common stride for both mates (sk_fused_args has one stride)
-			size_t stride = 1;
-			for (int m = 0; m < nm; m++)
-				for (size_t i = 0; i < nb; i++) {
-					const std::string &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
-					stride = std::max(stride, std::max(sl.size(), ql.size()));
-				}
-			sk_fused_args fa;
-			memset(&fa, 0, sizeof fa);
-			fa.n = (int64_t)nb; fa.n_mates = nm; fa.stride = (int)stride; fa.min_baseq = do_mask ? mask_q : trim_q;
-			if (stride > kMaxRow) { close_outputs(); error("Read longer than 65535 bases: not supported by this build."); }
-			for (int m = 0; m < nm; m++) {
-				mseq[m].data.assign(nb * stride, 0);
-				mqual[m].data.assign(nb * stride, 0);
-				mlen[m].resize(nb);
-				mlk[m].resize(nb);
-				for (size_t i = 0; i < nb; i++) {
-					const std::string &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
-					const size_t ls = sl.size() - ((!sl.empty() && sl.back() == '\n') ? 1 : 0), lq = ql.size() - ((!ql.empty() && ql.back() == '\n') ? 1 : 0);
-					memcpy(mseq[m].data.data() + i * stride, sl.data(), ls);
-					memcpy(mqual[m].data.data() + i * stride, ql.data(), lq);
-					mlen[m][i] = (uint16_t)std::min(host::trim_end_len(ql), lq);      // trim: n = qual.trim_end().len()
-				}
-				mseq[m].stride = mqual[m].stride = (int)stride;
-				mout[m].data.resize(nb * stride);
-				mout[m].stride = (int)stride;
-				fa.mate[m].seq = mseq[m].data.data(); fa.mate[m].qual = mqual[m].data.data(); fa.mate[m].len = mlen[m].data();
-				fa.mate[m].out_seq = do_mask ? mout[m].data.data() : nullptr;
-				fa.mate[m].lowest_k = do_trim ? mlk[m].data() : nullptr;
+	struct Pending { std::shared_ptr<std::vector<std::string>> data; std::future<std::shared_ptr<DemuxOut>> fut; };
+	std::deque<Pending> inflight;
+	auto drain_one = [&]() {
+		std::shared_ptr<DemuxOut> r = inflight.front().fut.get();
+		inflight.pop_front();
+		fputs(r->warn.c_str(), stderr);
+		total_reads += r->nclusters;                                        // :169
+		identified_reads += r->identified;
+		for (int s = 0; s < S; s++) samples[s].total_reads += r->per_sample[s];
+		if (!cfg.dry_run)
+			for (int s = 0; s < S; s++) {
+				if (!r->out1[s].empty()) samples[s].out[0]->write(r->out1[s]);
+				if (paired_end && !r->out2[s].empty()) samples[s].out[1]->write(r->out2[s]);
 			}
-			if (barcode_len > 0) {
-				fa.bc = bc.data(); fa.bc_stride = (int)barcode_len; fa.assign = assign.data();
-				fa.lowest_diff = lowest.data(); fa.first_idx = first.data(); fa.last_idx = last.data();
-			} else {
-				std::fill(assign.begin(), assign.end(), SK_ASSIGN_NONE);
-			}
-			check(sk_fused_pass(host::gpu(), &fa), "sk_fused_pass");
-		} else if (nb > 0 && barcode_len > 0) {
-			check(sk_demux_assign(host::gpu(), bc.data(), (int)barcode_len, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
-		} else {
-			std::fill(assign.begin(), assign.end(), SK_ASSIGN_NONE);        // empty sheet: lowest_diff stays usize::MAX
+		for (auto &e : r->extras) {
+			auto it = extra_barcodes.find(e.first);
+			if (it == extra_barcodes.end()) { extra_barcodes.emplace(e.first, e.second); extra_order.push_back(e.first); }
+			else it->second += e.second;
 		}
-		// body of one written record: verbatim lines, or the lines `mask by quality` then `trim by quality` would print
-		auto emit_body = [&](host::GzWriter &w, const std::string &sl, const std::string &pl, const std::string &ql, size_t i, int m) {
-			if (!fused) { w.write(sl); w.write(pl); w.write(ql); return; }
-			std::string seq_cur = sl, qual_cur = ql;
-			if (do_mask) {                                                  // src/fasta_mask_by_quality.rs:32-45
-				const size_t ls = sl.size() - ((!sl.empty() && sl.back() == '\n') ? 1 : 0), lq = ql.size() - ((!ql.empty() && ql.back() == '\n') ? 1 : 0);
-				if (ls != lq) { close_outputs(); error("Read sequence and base qualities are of different length."); }
-				if (!host::is_ascii(sl) || !host::is_ascii(ql)) { close_outputs(); error("Non-ASCII read lines are not supported together with --mask-by-quality."); }
-				seq_cur.assign(reinterpret_cast<const char *>(mout[m].data.data()) + i * (size_t)mout[m].stride, ls);
-				seq_cur.push_back('\n');
-				qual_cur.assign(ql, 0, lq);
-				qual_cur.push_back('\n');
-			}
-			if (do_trim) {                                                  // src/fasta_trim_by_quality.rs:44-48
-				const size_t lk = mlk[m][i];
-				if (lk == 0) { w.write("N\n+\n!\n", 6); return; }
-				if (lk > seq_cur.size()) { close_outputs(); panic("byte index out of range of `seq`"); }
-				w.write(seq_cur.data(), lk); w.write("\n+\n", 3); w.write(qual_cur.data(), lk); w.write("\n", 1);
-			} else {
-				w.write(seq_cur); w.write("+\n", 2); w.write(qual_cur);
-			}
-		};
+		if (!r->err.empty()) {
+			for (auto &p : inflight) p.fut.wait();
+			close_outputs();
+			if (r->err_code == 101) panic(r->err.c_str());
+			error("%s", r->err.c_str());
+		}
+	};
 
-		// ---- emit in input order ---------------------------------------------------------------------------------
-		for (size_t i = 0; i < nb; i++) {
-			Cluster &c = cl[i];
-			total_reads += 1;                                               // :169
-			bool write_read_out = false;
-			if (assign[i] >= 0) {                                           // :173-179
-				identified_reads += 1;
-				samples[assign[i]].total_reads += 1;
-				write_read_out = !(dry_run > 0);
-			} else if (assign[i] == SK_ASSIGN_AMBIGUOUS) {                  // :181-189
-				const Sample &a = samples[first[i]], &b = samples[last[i]];
-				fprintf(stderr, "WARNING: Sequenced barcode %s was an equally good match (%u mismatches) for samples %s (%s) and %s (%s), and was therefore not assigned to any sample.\n",
-				        c.barcode.c_str(), (unsigned)lowest[i], a.name.c_str(), a.barcode.c_str(), b.name.c_str(), b.barcode.c_str());
-			} else if (dry_run > 0) {                                       // :190-194
-				auto it = extra_barcodes.find(c.barcode);
-				if (it == extra_barcodes.end()) { extra_barcodes.emplace(c.barcode, 1); extra_order.push_back(c.barcode); }
-				else it->second += 1;
-			}
-			if (!write_read_out) continue;
-			Sample &sm = samples[assign[i]];
-			umi.clear();                                                    // :200-203 (chars().zip(chars()))
-			{
-				const uint8_t *sp = reinterpret_cast<const uint8_t *>(sm.barcode.data()), *bp = reinterpret_cast<const uint8_t *>(c.barcode.data());
-				size_t a = 0, b = 0;
-				while (a < sm.barcode.size() && b < c.barcode.size()) {
-					const size_t la = u8len(sp[a]), lb = u8len(bp[b]);
-					if (la == 1 && sp[a] == 'U') umi.append(c.barcode, b, lb);
-					a += la; b += lb;
-				}
-			}
-			sm.out[0]->write(c.header.data(), host::trim_end_len(c.header));   // :206
-			if (!umi.empty()) { sm.out[0]->write(" UMI:", 5); sm.out[0]->write(umi); }   // :207
-			sm.out[0]->write("\n", 1);                                      // :208
-			emit_body(*sm.out[0], c.l2, c.l3, c.l4, i, 0);                      // :209-212
-			if (paired_end) {                                               // :215-237
-				std::string &h2 = c.m2[0];
-				if (index_fastq.empty()) {
-					size_t st, en;
-					if (host::find_bc_field(h2, st, en)) h2.erase(st, en - st);
-				}
-				sm.out[1]->write(h2.data(), host::trim_end_len(h2));
-				if (!umi.empty()) { sm.out[1]->write(" UMI:", 5); sm.out[1]->write(umi); }
-				sm.out[1]->write("\n", 1);
-				emit_body(*sm.out[1], c.m2[1], c.m2[2], c.m2[3], i, 1);
-			}
+	for (;;) {
+		size_t want = block_records;
+		if (dry_run > 0) {
+			if (total_reads >= dry_run) break;                              // :248
+			want = (size_t)std::min<uint64_t>(want, dry_run - total_reads);
 		}
-		if (dry_run > 0 && total_reads >= dry_run) done = true;             // :248
+		auto data = std::make_shared<std::vector<std::string>>(4);
+		if (!files[0]->next(want, (*data)[0])) break;                       // :117 — the loop is driven by fastq_1
+		for (int f = 1; f < 4; f++) if (files[f]) files[f]->next(want, (*data)[f]);
+		Pending pd;
+		pd.data = data;
+		pd.fut = std::async(std::launch::async, [data, &cfg]() {
+			auto res = std::make_shared<DemuxOut>();
+			demux_block(cfg, data->data(), *res);
+			return res;
+		});
+		inflight.push_back(std::move(pd));
+		while (inflight.size() >= nthreads) drain_one();
 	}
-	if (!pending.empty()) {
-		close_outputs();
-		if (pending_code == 101) panic(pending.c_str());
-		error("%s", pending.c_str());
-	}
+	while (!inflight.empty()) drain_one();
 
 	if (dry_run > 0) {                                                      // :251-261
 		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);

@@ -1,6 +1,7 @@
 // host_common.cpp — see host_common.h.
 #include "host_common.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -320,8 +321,38 @@ struct GzWriter::Impl {
 	}
 };
 
+// libdeflate (when the shared object is on the box; it ships no headers here, so the four entry points are declared by
+// hand) compresses the same gzip members ~2-3x faster than zlib at the same level; zlib is the fallback.
+struct Deflater {
+	void *(*alloc)(int) = nullptr;
+	void (*free_)(void *) = nullptr;
+	size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+	size_t (*bound)(void *, size_t) = nullptr;
+	Deflater()
+	{
+		if (getenv("SEQKIT_NO_LIBDEFLATE")) return;
+		void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+		if (!h) return;
+		alloc = reinterpret_cast<void *(*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
+		free_ = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_compressor"));
+		compress = reinterpret_cast<size_t (*)(void *, const void *, size_t, void *, size_t)>(dlsym(h, "libdeflate_gzip_compress"));
+		bound = reinterpret_cast<size_t (*)(void *, size_t)>(dlsym(h, "libdeflate_gzip_compress_bound"));
+		if (!alloc || !free_ || !compress || !bound) alloc = nullptr;
+	}
+};
+
 static std::string gzip_member(const std::string &in)
 {
+	static const Deflater ld;
+	if (ld.alloc) {
+		thread_local void *comp = ld.alloc(6);
+		if (comp) {
+			std::string out;
+			out.resize(ld.bound(comp, in.size()));
+			const size_t n = ld.compress(comp, in.data(), in.size(), &out[0], out.size());
+			if (n > 0) { out.resize(n); return out; }
+		}
+	}
 	z_stream z;
 	memset(&z, 0, sizeof z);
 	deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
@@ -520,6 +551,49 @@ struct RawSource {
 };
 
 }  // namespace
+
+struct RecordBlocks::Impl {
+	RawSource src;
+	int lpr;
+	std::string buf;
+	size_t scan = 0, lines = 0;
+	bool eof = false;
+	Impl(const std::string &path, int l) : src(path), lpr(l) {}
+};
+
+RecordBlocks::RecordBlocks(const std::string &path, int lines_per_record) : impl_(new Impl(path, lines_per_record)) {}
+RecordBlocks::~RecordBlocks() { delete impl_; }
+
+bool RecordBlocks::next(size_t nrec, std::string &blk)
+{
+	Impl &m = *impl_;
+	blk.clear();
+	const size_t want_lines = nrec * (size_t)m.lpr;
+	size_t cut = std::string::npos;
+	for (;;) {
+		// count newlines in what is buffered
+		while (m.scan < m.buf.size() && m.lines < want_lines) {
+			const char *p = m.buf.data() + m.scan;
+			const char *nl = static_cast<const char *>(memchr(p, '\n', m.buf.size() - m.scan));
+			if (!nl) { m.scan = m.buf.size(); break; }
+			m.scan = (size_t)(nl - m.buf.data()) + 1;
+			m.lines++;
+		}
+		if (m.lines >= want_lines) { cut = m.scan; break; }
+		if (m.eof) { cut = m.buf.size(); break; }
+		const size_t old = m.buf.size(), chunk = 4u << 20;
+		m.buf.resize(old + chunk);
+		const size_t r = m.src.read_some(&m.buf[old], chunk);
+		m.buf.resize(old + r);
+		if (r == 0) m.eof = true;
+	}
+	if (cut == 0) return false;
+	blk.assign(m.buf, 0, cut);
+	m.buf.erase(0, cut);
+	m.scan = 0;
+	m.lines = 0;
+	return true;
+}
 
 void run_block_pipeline(const std::string &path, int lines_per_record, const BlockFn &fn)
 {

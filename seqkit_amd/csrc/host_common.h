@@ -104,6 +104,20 @@ struct BlockResult { std::string out; std::string err; int err_code = 255; };
 using BlockFn = std::function<void(const char *data, size_t n, bool last_block, BlockResult &res)>;
 void run_block_pipeline(const std::string &path, int lines_per_record, const BlockFn &fn);
 
+// A file read as blocks of whole records (`lines_per_record` lines each): next() returns up to `nrec` records; the last
+// block of a file may end in a partial record.  Several files are kept in lockstep by asking each for the same nrec.
+class RecordBlocks {
+public:
+	RecordBlocks(const std::string &path, int lines_per_record);
+	~RecordBlocks();
+	RecordBlocks(const RecordBlocks &) = delete;
+	RecordBlocks &operator=(const RecordBlocks &) = delete;
+	bool next(size_t nrec, std::string &blk);            // false (and blk empty) at end of file
+	struct Impl;
+private:
+	Impl *impl_;
+};
+
 // one line of a block: [p, p+n) including its '\n' when present; n == 0 past the end of the block (EOF semantics)
 struct Line { const char *p; size_t n; };
 class BlockLines {

@@ -142,9 +142,12 @@ def demux_inputs(tmp_path, n, paired, dual, seed, umi=False):
     return str(sheet), files, table, bc
 
 
-@pytest.mark.parametrize("paired,dual", [(False, False), (True, True)])
-def test_demultiplex_header_mode(bins, tmp_path, paired, dual):
-    sheet, files, table, bc = demux_inputs(tmp_path, 4000, paired, dual, seed=3)
+@pytest.mark.parametrize("paired,dual,block", [(False, False, None), (True, True, None), (True, True, "37"), (False, True, "1")])
+def test_demultiplex_header_mode(bins, tmp_path, monkeypatch, paired, dual, block):
+    if block:                                   # many tiny record blocks through the parallel pipeline
+        monkeypatch.setenv("SEQKIT_BLOCK_RECORDS", block)
+        monkeypatch.setenv("SEQKIT_THREADS", "7")
+    sheet, files, table, bc = demux_inputs(tmp_path, 4000 if block != "1" else 300, paired, dual, seed=3)
     a, b, da, _ = both(bins, "fasta", ["demultiplex", sheet] + files, tmp_path)
     assert a[0] == 0 and b"clusters carried a barcode matching" in a[2]
     outs = cu.gunzip_dir(da)
@@ -236,7 +239,10 @@ def test_demultiplex_fused_extension_equals_the_piped_commands(bins, tmp_path, m
         assert got[name] == text, name
 
 
-def test_demultiplex_errors(bins, tmp_path):
+@pytest.mark.parametrize("block", [None, "3"])
+def test_demultiplex_errors(bins, tmp_path, monkeypatch, block):
+    if block:
+        monkeypatch.setenv("SEQKIT_BLOCK_RECORDS", block)
     sheet = tmp_path / "s.tsv"
     sheet.write_bytes(b"A\tACGTACGT\nB\tTTTTGGGG\n")
     fq = tmp_path / "r.fq"

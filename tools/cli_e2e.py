@@ -35,15 +35,25 @@ n = n_block * reps
 print(f"{n} reads, {os.path.getsize(fq) / 1e6:.0f} MB FASTQ")
 
 
+import resource  # noqa: E402
+
+
 def t(cmd, cwd):
+    r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
     r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return time.perf_counter() - t0, r.returncode
+    dt = time.perf_counter() - t0
+    r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    print(f"    cpu user {r1.ru_utime - r0.ru_utime:.1f} s sys {r1.ru_stime - r0.ru_stime:.1f} s", flush=True)
+    return dt, r.returncode
 
 
+ONLY = os.environ.get("E2E_ONLY", "")
 for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("mask by quality", ["mask", "by", "quality", fq, "20"]),
                    ("demultiplex (96 samples, gz out)", ["demultiplex", sheet, fq])):
-    for label, binary in (("hip", FASTA), ("oracle", orc.FASTA_BIN)):
+    if ONLY and ONLY not in name:
+        continue
+    for label, binary in (("hip", FASTA),) if os.environ.get("E2E_NO_ORACLE") else (("hip", FASTA), ("oracle", orc.FASTA_BIN)):
         w = os.path.join(d, label + name.split()[0])
         os.makedirs(w, exist_ok=True)
         dt, rc = t([binary] + args, w)
