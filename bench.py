@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--pairs", type=int, default=62_500_000, help="clusters per GPU (default: configs[3] / 8)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="clusters timed on the CPU oracle (0 = skip)")
     ap.add_argument("--gen-chunk", type=int, default=2_000_000)
-    ap.add_argument("--arena", type=int, default=0,
+    ap.add_argument("--arena", type=int, default=-1,
                     help="carve every matrix of the shard from ONE allocation (made first), 4 KiB-aligned and staggered by this many bytes; "
                          "-1 = one torch allocation per matrix")
     return ap.parse_args()
