@@ -162,6 +162,29 @@ int sk_bam_fragments(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, cons
 int sk_bam_fragments_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                          int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept);
 
+/* ---- f3: barcode census -----------------------------------------------------------------------------------
+ * The HashMap<String, u64> of src/fasta_demultiplex.rs:190-194 (dry run: barcodes that matched no sample) and of
+ * src/fasta_statistics.rs:23-27 (every BC: field), kept as a hash table in HBM that lives in the ctx.
+ * bc is the SoA barcode matrix of sk_demux_assign: row r at bc + r*bc_stride, the barcode in its first L bytes,
+ * ended early by a NUL.  L <= 31, bc_stride <= 64, alphabet ACGTNacgtn+ (what the reference's regexes admit); a row holding any
+ * other byte is not counted and is reported in stats[2] (the host keeps such rows in its own map).  When assign is
+ * not NULL only rows with assign[r] == SK_ASSIGN_NONE are counted (:190).  row_base + r is remembered as the first
+ * occurrence of a barcode, so that results can be listed in first-seen order whatever the launch order was.    */
+typedef struct sk_census_entry {
+	char barcode[32];              /* NUL-terminated */
+	uint64_t count;
+	int64_t first_row;
+} sk_census_entry;
+int sk_census_reset(sk_ctx *ctx);                                 /* empty census (creates it on first use) */
+int sk_census_add(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base);
+int sk_census_add_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base);
+/* stats[0] distinct barcodes, [1] rows counted, [2] rows rejected, [3] table slots */
+int sk_census_stats(sk_ctx *ctx, uint64_t stats[4]);
+/* hist[b] = number of distinct barcodes whose count c has floor(log2(c)) == b: lets a caller pick min_count */
+int sk_census_count_hist(sk_ctx *ctx, uint64_t hist[64]);
+/* barcodes with count >= min_count in first-seen order; at most cap are written, *total = how many qualify */
+int sk_census_entries(sk_ctx *ctx, uint64_t min_count, sk_census_entry *out, uint64_t cap, uint64_t *total);
+
 /* ---- timing on the ctx stream (hipEvents), so a host without HIP can time device work -------------- */
 int sk_timer_start(sk_ctx *ctx);
 int sk_timer_stop(sk_ctx *ctx, float *ms);               /* records, synchronises, returns elapsed ms */

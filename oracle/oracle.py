@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
         _lib.orc_fragments_keep.restype = i64
         _lib.orc_fragments_keep.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
+        _lib.orc_census.restype = i64
+        _lib.orc_census.argtypes = [vp, i32, i32, i64, vp, i64, vp]
+        _lib.orc_free.restype = None
+        _lib.orc_free.argtypes = [vp]
         _lib.orc_trim_end_len.restype = C.c_size_t
         _lib.orc_trim_end_len.argtypes = [C.c_char_p, C.c_size_t]
         _lib.orc_trim_start_off.restype = C.c_size_t
@@ -150,3 +154,23 @@ def find_bc_field(h: bytes):
     if lib().orc_find_bc_field(h, len(h), C.byref(st), C.byref(en)):
         return int(st.value), int(en.value)
     return None
+
+
+def census(bc: np.ndarray, L: int | None = None, assign=None, row_base: int = 0):
+    """[(barcode bytes, count, first_row)] in first-seen order (f3)."""
+    bc = np.ascontiguousarray(bc, dtype=np.uint8)
+    n, stride = bc.shape
+    if assign is not None:
+        assign = np.ascontiguousarray(assign, dtype=np.int32)
+    out = C.c_void_p()
+    k = lib().orc_census(_p(bc), stride, stride if L is None else L, n, _p(assign) if assign is not None else None, row_base,
+                         C.byref(out))
+    if k < 0:
+        raise RuntimeError("orc_census failed")
+    dt = np.dtype([("barcode", "S32"), ("count", np.uint64), ("first_row", np.int64)])
+    res = []
+    if k:
+        arr = np.frombuffer((C.c_char * (k * dt.itemsize)).from_address(out.value), dtype=dt).copy()
+        res = [(bytes(e["barcode"]), int(e["count"]), int(e["first_row"])) for e in arr]
+    lib().orc_free(out)
+    return res

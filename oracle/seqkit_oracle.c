@@ -8,6 +8,7 @@
  */
 #include "seqkit_oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 /* src/fasta_trim_by_quality.rs:28-42
@@ -344,3 +345,77 @@ int orc_find_bc_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end)
 	}
 	return 0;
 }
+
+static int bc_class_stats(uint8_t c) { return c != '+' && bc_class(c); }
+
+int orc_find_bc_field_stats(const uint8_t *hdr, size_t n, size_t *start, size_t *end)
+{
+	for (size_t i = 0; i + 5 <= n; i++) {
+		if (hdr[i] == ' ' && hdr[i + 1] == 'B' && hdr[i + 2] == 'C' && hdr[i + 3] == ':' &&
+		    bc_class_stats(hdr[i + 4])) {
+			size_t e = i + 5;
+			while (e < n && bc_class_stats(hdr[e])) e++;
+			*start = i;
+			*end = e;
+			return 1;
+		}
+	}
+	return 0;
+}
+
+/* f3: string-keyed counting map, entries kept in insertion order */
+static uint64_t fnv1a(const char *s)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (; *s; s++) { h ^= (uint8_t)*s; h *= 1099511628211ull; }
+	return h;
+}
+
+int64_t orc_census(const uint8_t *bc, int stride, int L, int64_t n, const int32_t *assign,
+                   int64_t row_base, orc_census_entry **out)
+{
+	size_t cap = 1024, used = 0, ecap = 256;
+	int64_t *slot = malloc(cap * sizeof *slot);
+	orc_census_entry *ent = malloc(ecap * sizeof *ent);
+	*out = NULL;
+	if (!slot || !ent || L < 0 || L > 31) { free(slot); free(ent); return -1; }
+	for (size_t i = 0; i < cap; i++) slot[i] = -1;
+	for (int64_t r = 0; r < n; r++) {
+		if (assign && assign[r] != ORC_NONE) continue;
+		char key[32];
+		int k = 0;
+		const uint8_t *row = bc + r * (int64_t)stride;
+		while (k < L && row[k] != 0) { key[k] = (char)row[k]; k++; }
+		memset(key + k, 0, sizeof key - (size_t)k);
+		size_t i = fnv1a(key) & (cap - 1);
+		while (slot[i] >= 0 && memcmp(ent[slot[i]].barcode, key, 32) != 0) i = (i + 1) & (cap - 1);
+		if (slot[i] >= 0) { ent[slot[i]].count++; continue; }
+		if (used == ecap) {
+			ecap *= 2;
+			orc_census_entry *ne = realloc(ent, ecap * sizeof *ent);
+			if (!ne) { free(slot); free(ent); return -1; }
+			ent = ne;
+		}
+		memcpy(ent[used].barcode, key, 32);
+		ent[used].count = 1;
+		ent[used].first_row = row_base + r;
+		slot[i] = (int64_t)used++;
+		if (used * 2 > cap) {                          /* rehash at load 1/2 */
+			cap *= 2;
+			int64_t *ns = realloc(slot, cap * sizeof *slot);
+			if (!ns) { free(slot); free(ent); return -1; }
+			slot = ns;
+			for (size_t j = 0; j < cap; j++) slot[j] = -1;
+			for (size_t e = 0; e < used; e++) {
+				size_t j = fnv1a(ent[e].barcode) & (cap - 1);
+				while (slot[j] >= 0) j = (j + 1) & (cap - 1);
+				slot[j] = (int64_t)e;
+			}
+		}
+	}
+	free(slot);
+	*out = ent;
+	return (int64_t)used;
+}
+
+void orc_free(void *p) { free(p); }

@@ -99,6 +99,26 @@ int orc_utf8_valid(const uint8_t *s, size_t n);
  * returns 1 and [*start,*end) of the whole match, else 0.                            */
 int orc_find_bc_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
 
+/* " BC:[ACGTNacgtn]+" — the `fasta statistics` variant without '+' (src/fasta_statistics.rs:16). */
+int orc_find_bc_field_stats(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
+
+/* ---- f3: HashMap<String, u64> census --------------------------------------------------
+ * src/fasta_demultiplex.rs:190-194 and src/fasta_statistics.rs:23-27: one
+ * `*map.entry(barcode).or_insert(0) += 1` per read.  Rows are bc + r*stride; the barcode is
+ * the first L bytes, ended early by a NUL.  With assign != NULL only rows whose code is
+ * ORC_NONE are counted (:190).  Returns the number of distinct barcodes and, in *out, one
+ * malloc()ed entry per barcode in first-seen order (free with orc_free).  Rust's HashMap
+ * iterates in a random order, so the order among equal counts in the reference's printed
+ * tables is unspecified; first-seen order is this repository's canonical choice.          */
+typedef struct {
+	char barcode[32];          /* NUL-terminated; L <= 31 */
+	uint64_t count;
+	int64_t first_row;
+} orc_census_entry;
+int64_t orc_census(const uint8_t *bc, int stride, int L, int64_t n, const int32_t *assign,
+                   int64_t row_base, orc_census_entry **out);
+void orc_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,9 @@ EXPORTED_SYMBOLS = [
     "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
-    "sk_bam_fragments", "sk_bam_fragments_dev", "sk_timer_start", "sk_timer_stop",
+    "sk_bam_fragments", "sk_bam_fragments_dev",
+    "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
+    "sk_timer_start", "sk_timer_stop",
 ]
 
 
@@ -85,6 +87,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
         "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_bam_fragments_dev": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
+        "sk_census_reset": (i32, [vp]),
+        "sk_census_add": (i32, [vp, vp, i32, i32, i64, vp, i64]),
+        "sk_census_add_dev": (i32, [vp, vp, i32, i32, i64, vp, i64]),
+        "sk_census_stats": (i32, [vp, vp]),
+        "sk_census_count_hist": (i32, [vp, vp]),
+        "sk_census_entries": (i32, [vp, C.c_uint64, vp, C.c_uint64, vp]),
         "sk_timer_start": (i32, [vp]), "sk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in protos.items():
@@ -313,6 +321,43 @@ class Context:
                           kept: int) -> None:
         self._check(self._lib.sk_bam_fragments_dev(self._h, flag, tid, mtid, tlen, n, min_size, max_size, keep_bits, kept),
                     "sk_bam_fragments_dev")
+
+    # ---- f3: barcode census ----------------------------------------------------------------
+    def census_reset(self) -> None:
+        self._check(self._lib.sk_census_reset(self._h), "sk_census_reset")
+
+    def census_add(self, bc, L: int | None = None, assign=None, row_base: int = 0) -> None:
+        """bc: uint8 [n, bc_stride] host matrix (rows NUL-padded); assign: optional int32[n]."""
+        bc = np.ascontiguousarray(bc, dtype=np.uint8)
+        n, stride = bc.shape
+        if assign is not None:
+            assign = _vec(assign, np.int32, n, "assign")
+        self._check(self._lib.sk_census_add(self._h, _ptr(bc), stride, stride if L is None else L, n,
+                                            _ptr(assign) if assign is not None else None, row_base), "sk_census_add")
+
+    def census_add_dev(self, bc: int, bc_stride: int, L: int, n: int, assign: int = 0, row_base: int = 0) -> None:
+        self._check(self._lib.sk_census_add_dev(self._h, bc, bc_stride, L, n, assign or None, row_base), "sk_census_add_dev")
+
+    def census_stats(self) -> dict:
+        s = np.zeros(4, dtype=np.uint64)
+        self._check(self._lib.sk_census_stats(self._h, _ptr(s)), "sk_census_stats")
+        return {"distinct": int(s[0]), "counted": int(s[1]), "rejected": int(s[2]), "slots": int(s[3])}
+
+    def census_count_hist(self):
+        h = np.zeros(64, dtype=np.uint64)
+        self._check(self._lib.sk_census_count_hist(self._h, _ptr(h)), "sk_census_count_hist")
+        return h
+
+    def census_entries(self, min_count: int = 1, cap: int | None = None):
+        """[(barcode bytes, count, first_row)] in first-seen order, and how many barcodes qualified in all."""
+        if cap is None:
+            cap = self.census_stats()["distinct"]
+        dt = np.dtype([("barcode", "S32"), ("count", np.uint64), ("first_row", np.int64)])
+        out = np.zeros(max(cap, 1), dtype=dt)
+        total = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.sk_census_entries(self._h, min_count, _ptr(out), cap, _ptr(total)), "sk_census_entries")
+        k = min(cap, int(total[0]))
+        return [(bytes(e["barcode"]), int(e["count"]), int(e["first_row"])) for e in out[:k]], int(total[0])
 
     # ---- device entry points (raw addresses) ---------------------------------------------
     def fused_pass_dev(self, n: int, stride: int, min_baseq: int, mates, bc: int = 0, bc_stride: int = 0,

@@ -30,6 +30,7 @@ struct sk_ctx {
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
+	sk::Census *census = nullptr;
 };
 
 static thread_local std::string g_create_err;
@@ -119,6 +120,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_bs) (void)hipFree(c->d_bs);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->ws) (void)hipFree(c->ws);
+	if (c->census) sk::census_destroy(c->census);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -637,6 +639,98 @@ int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	uint64_t k = 0;
 	SK_HIP(c, hipMemcpy(&k, dkept, 8, hipMemcpyDeviceToHost));
 	if (kept) *kept += k;
+	return SK_OK;
+}
+
+// ---- f3: barcode census ----------------------------------------------------------------------------------------
+static_assert(sizeof(sk_census_entry) == sizeof(sk::CensusEntry), "sk_census_entry layout");
+
+static int census_ready(sk_ctx *c)
+{
+	if (c->census) return SK_OK;
+	SK_HIP(c, sk::census_create(&c->census, c->stream));
+	return SK_OK;
+}
+
+int sk_census_reset(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (!c->census) return census_ready(c);
+	SK_HIP(c, sk::census_reset(c->census, c->stream));
+	return SK_OK;
+}
+
+static int census_check(sk_ctx *c, const uint8_t *bc, int bc_stride, int L, int64_t n)
+{
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (L < 0 || L > sk::kMaxCensusLen) return fail(c, SK_ERR_INVALID, "census barcode length %d (0..%d)", L, sk::kMaxCensusLen);
+	if (bc_stride < L || bc_stride < 1 || bc_stride > 64) return fail(c, SK_ERR_INVALID, "bc_stride = %d (1..64), L = %d", bc_stride, L);
+	if (n > 0 && !bc) return fail(c, SK_ERR_INVALID, "bc is NULL");
+	return SK_OK;
+}
+
+int sk_census_add_dev(sk_ctx *c, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = census_check(c, bc, bc_stride, L, n)) return r;
+	if (n == 0) return SK_OK;
+	if (!aligned16(bc)) return fail(c, SK_ERR_INVALID, "bc must be 16-byte aligned");
+	if (int r = bind(c)) return r;
+	if (int r = census_ready(c)) return r;
+	SK_HIP(c, sk::census_add(c->census, bc, bc_stride, L, n, assign, row_base, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_census_add(sk_ctx *c, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = census_check(c, bc, bc_stride, L, n)) return r;
+	if (n == 0) return SK_OK;
+	if (int r = bind(c)) return r;
+	if (int r = census_ready(c)) return r;
+	int64_t chunk = (int64_t)((64u << 20) / (size_t)(bc_stride + 4));
+	if (chunk > n) chunk = n;
+	if (int r = ensure_ws(c, up256((size_t)chunk * bc_stride) + up256((size_t)chunk * 4))) return r;
+	uint8_t *dbc = c->ws;
+	int32_t *dassign = (int32_t *)(c->ws + up256((size_t)chunk * bc_stride));
+	for (int64_t o = 0; o < n; o += chunk) {
+		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(dbc, bc + o * (int64_t)bc_stride, (size_t)nr * bc_stride, hipMemcpyHostToDevice, c->stream));
+		if (assign) SK_HIP(c, hipMemcpyAsync(dassign, assign + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, sk::census_add(c->census, dbc, bc_stride, L, nr, assign ? dassign : nullptr, row_base + o, c->n_cu, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	return SK_OK;
+}
+
+int sk_census_stats(sk_ctx *c, uint64_t stats[4])
+{
+	if (!c || !stats) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (int r = census_ready(c)) return r;
+	uint64_t s[4];
+	SK_HIP(c, sk::census_stats(c->census, s, c->stream));
+	if (s[3] != 0) return fail(c, SK_ERR_HIP, "census table overflow (%llu rows lost)", (unsigned long long)s[3]);
+	stats[0] = s[0]; stats[1] = s[1]; stats[2] = s[2]; stats[3] = sk::census_slots(c->census);
+	return SK_OK;
+}
+
+int sk_census_count_hist(sk_ctx *c, uint64_t hist[64])
+{
+	if (!c || !hist) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (int r = census_ready(c)) return r;
+	SK_HIP(c, sk::census_count_hist(c->census, hist, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_census_entries(sk_ctx *c, uint64_t min_count, sk_census_entry *out, uint64_t cap, uint64_t *total)
+{
+	if (!c || !total || (cap && !out)) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;
+	if (int r = census_ready(c)) return r;
+	SK_HIP(c, sk::census_entries(c->census, min_count, reinterpret_cast<sk::CensusEntry *>(out), cap, total, c->n_cu, c->stream));
 	return SK_OK;
 }
 

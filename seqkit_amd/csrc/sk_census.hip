@@ -1,0 +1,543 @@
+// sk_census.hip — barcode census on gfx950: how often does each distinct barcode occur?
+//
+// Reference behaviour served (row f3 of SURVEY.md §8):
+//   src/fasta_demultiplex.rs:190-194   `*extra_barcodes.entry(barcode).or_insert(0) += 1`  (dry run, unmatched reads)
+//   src/fasta_statistics.rs:23-27      `*sample_barcodes.entry(sample_barcode).or_insert(0) += 1`
+// Both are a HashMap<String, u64> fed one barcode per read.  Here the map is an open-addressing table in HBM
+// keyed by the barcode packed at 4 bits per character, in front of which every workgroup keeps a small LDS
+// table: the barcodes that dominate a run (the sample sheet's, plus their one-error neighbours) are counted
+// with LDS atomics and reach HBM once per workgroup instead of once per read.
+//
+// Key: the alphabet is what the reference's regexes admit, " BC:[ACGTNacgtn+]+" — 11 symbols, code 1..11, code 0
+// ends the barcode.  Nibble 0 of the low word is the marker 0xF (so a key is never 0, the empty-slot value);
+// characters 0..14 follow in the low word, 15..30 in the high word: 31 characters at most.  The high word is
+// stored inverted so that 0 means "claimed but not published yet" on a table that is cleared with memset.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "sk_internal.h"
+
+namespace sk {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+struct CensusSlot {          // 32 bytes, one HBM sector pair
+	u64 klo;                 // 0 = empty
+	u64 khi_inv;             // ~khi; 0 = owner has not published the high word yet
+	u64 count;
+	u64 first_inv;           // ~(lowest row index seen): atomicMax keeps the first occurrence
+};
+
+struct Census {
+	CensusSlot *tab = nullptr;
+	u64 slots = 0;           // power of two
+	u64 *stats = nullptr;    // device u64[kCensusStats]
+	u64 distinct = 0;        // host mirror of stats[0], valid after sync_stats()
+	u64 *scratch = nullptr;  // device: entry compaction output / histogram
+	size_t scratch_bytes = 0;
+};
+
+constexpr int kCensusStats = 4;          // [0] distinct keys, [1] rows counted, [2] rows rejected, [3] probe overflows
+constexpr u64 kInitialSlots = 1ull << 24;   // 512 MiB: two launches' worth of all-new keys before the first rehash
+constexpr int64_t kCensusChunk = 1 << 24;   // most rows per launch; the table is grown between launches so that it is never
+constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
+constexpr int kLdsSlots = 2048;
+constexpr int kLdsProbes = 4;
+constexpr u32 kMaxProbes = 1u << 16;
+
+struct LdsSlot {             // 32 bytes
+	u64 klo;
+	u64 khi_inv;
+	u64 first_inv;
+	u32 count;
+	u32 pad;
+};
+
+// 32-bit mix of the four key words; the HBM table uses the low bits, the LDS table the high bits
+__device__ __forceinline__ u32 census_hash(u64 klo, u64 khi)
+{
+	const u32 w0 = (u32)klo, w1 = (u32)(klo >> 32), w2 = (u32)khi, w3 = (u32)(khi >> 32);
+	u32 h = w0 * 0x9E3779B1u ^ __builtin_rotateleft32(w1, 13) * 0x85EBCA77u ^ w2 * 0xC2B2AE3Du ^ __builtin_rotateleft32(w3, 7) * 0x27D4EB2Fu;
+	h ^= h >> 15;
+	h *= 0x2C1B3C6Du;
+	h ^= h >> 12;
+	h *= 0x297A2D39u;
+	h ^= h >> 15;
+	return h;
+}
+
+// byte -> 4-bit code; 0 for NUL (end of barcode), 15 for a byte outside the alphabet.  The kernel reads this
+// from a 256-byte table in LDS.
+__host__ __device__ inline u32 census_code(u32 b)
+{
+	switch (b) {
+	case 0: return 0;
+	case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; case 'N': return 5;
+	case 'a': return 6; case 'c': return 7; case 'g': return 8; case 't': return 9; case 'n': return 10;
+	case '+': return 11;
+	default: return 15;
+	}
+}
+
+// add (cnt, first) for one key to the HBM table; returns false when the probe budget ran out.  The three words
+// of a slot are fetched together (one round trip); on the usual path — the key is already there — the two
+// updates that follow are fire-and-forget atomics.
+__device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+{
+	const u64 want = ~khi;
+	u64 idx = (u64)census_hash(klo, khi) & mask;
+	u32 probes = 0;
+	while (probes < kMaxProbes) {
+		CensusSlot *s = tab + idx;
+		u64 k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == 0) {
+			k = atomicCAS(&s->klo, 0ull, klo);
+			if (k == 0) {
+				__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				claimed++;
+				k = klo;
+				v = want;
+			} else {
+				v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			f = 0;
+		}
+		if (k == klo) {
+			if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }      // owner is between its CAS and its store: look again
+			if (v == want) {
+				atomicAdd(&s->count, cnt);
+				if (f < first_inv) atomicMax(&s->first_inv, first_inv);
+				return true;
+			}
+		}
+		idx = (idx + 1) & mask;
+		probes++;
+	}
+	return false;
+}
+
+extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
+
+struct CensusArgs {
+	const uint8_t *bc;
+	int bc_stride;
+	int L;
+	int64_t n;
+	const int32_t *assign;    // nullable: count row r only when assign[r] == SK_ASSIGN_NONE
+	int64_t row_base;
+	CensusSlot *tab;
+	u64 mask;
+	u64 *stats;
+};
+
+constexpr int kCensusWaves = 8;           // waves per workgroup: they share the LDS table
+constexpr int kCensusMaxStride = 64;      // 64 rows x 64 B = 4 KiB per wave tile = 4 x 16 B per lane
+
+__device__ __forceinline__ void census_wave_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct CensusTileRegs { uint4 v[4]; int32_t code; };
+
+// The 64 rows of tile t are one contiguous, 16-byte aligned byte range: 16 bytes per lane and step, as unconditional
+// raw-buffer loads whose descriptor ends at the tile's last valid dword (the hardware drops what lies beyond it, so
+// like the tile pass this may read up to 3 bytes past the end of the matrix).
+__device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t, int lane, CensusTileRegs &rg)
+{
+	const int64_t total = a.n * (int64_t)a.bc_stride;
+	const int64_t base = t * 64 * (int64_t)a.bc_stride;
+	const int64_t rem = total - base;
+	const int bytes = (int)(rem < 64 * (int64_t)a.bc_stride ? rem : 64 * (int64_t)a.bc_stride);
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.bc) + base, 0, (bytes + 3) & ~3, 0x00020000);
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int off = lane * 16 + k * 1024;
+		if (k * 1024 < 64 * a.bc_stride) {          // wave-uniform
+			const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+			memcpy(&rg.v[k], &v, 16);
+		}
+	}
+	const int64_t r = t * 64 + lane;
+	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign), 0, a.assign ? (int)(a.n * 4 > 0x7ffffffc ? 0x7ffffffc : a.n * 4) : 0, 0x00020000);
+	rg.code = kAssignNone;
+	if (a.assign != nullptr) rg.code = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(r * 4), 0, 0);
+}
+
+// One row per lane, one 64-row tile per wave and step.  A wave keeps the next tile's bytes in registers while it
+// works on the current one (its private LDS tile), so the only workgroup barriers are the two around the loop.
+// Keys are counted in the workgroup's LDS table; a key that finds no room there within kLdsProbes slots goes
+// straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
+__global__ __launch_bounds__(kCensusWaves * 64, 2) void census_kernel(const CensusArgs a, const int tile_slot)
+{
+	LdsSlot *lt = reinterpret_cast<LdsSlot *>(census_smem);
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int nwave = blockDim.x >> 6;
+	uint8_t *lut = census_smem + kLdsSlots * sizeof(LdsSlot);
+	uint8_t *tile = lut + 256 + (size_t)wave * tile_slot;
+	for (int i = tid; i < kLdsSlots * (int)(sizeof(LdsSlot) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+	if (tid < 256) lut[tid] = (uint8_t)census_code((u32)tid);
+	__syncthreads();
+
+	const int stride = a.bc_stride;
+	const int64_t ntiles = (a.n + 63) / 64;
+	const int64_t step = (int64_t)gridDim.x * nwave;
+	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
+	CensusTileRegs rg;
+	bool pend = false;
+	u64 pklo = 0, pkhi = 0, pfirst = 0;
+	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	if (t < ntiles) census_load_tile(a, t, lane, rg);
+	for (; t < ntiles; t += step) {
+		const int bytes = 64 * stride;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int off = lane * 16 + k * 1024;
+			if (off < bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];
+		}
+		const int32_t code = rg.code;
+		census_wave_fence();
+		if (t + step < ntiles) census_load_tile(a, t + step, lane, rg);       // in flight while this tile is counted
+		const int64_t r = t * 64 + lane;
+		bool fresh = false;
+		u64 nklo = 0, nkhi = 0, nfirst = 0;
+		if (r < a.n && code == kAssignNone) {
+			// the row as dwords: aligned LDS reads funnel-shifted to the row's first byte
+			const int rs = lane * stride;
+			const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
+			const u32 sh = (u32)rs & 3u;
+			u32 kw[4] = {0u, 0u, 0u, 0u};
+			u32 live = 0xFu;
+			u32 lo = t32[0];
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				if (4 * q < a.L) {                                   // wave-uniform
+					const u32 hi = t32[q + 1];
+					const u32 x = __builtin_amdgcn_alignbyte(hi, lo, sh);
+					lo = hi;
+#pragma unroll
+					for (int b = 0; b < 4; b++) {
+						const int j = 4 * q + b;
+						if (j < kMaxCensusLen) {
+							const u32 c = lut[(x >> (8 * b)) & 0xFFu] & live;
+							if (c == 0u) live = 0u;                      // bytes after the first NUL are padding
+							kw[(j + 1) >> 3] |= c << (4 * ((j + 1) & 7));
+						}
+					}
+				}
+			}
+			// characters L.. of the last dword are not part of the barcode: clear them, then add the marker nibble
+			u32 any15 = 0u;
+#pragma unroll
+			for (int w = 0; w < 4; w++) {
+				const int keep = a.L + 1 - 8 * w;                      // nibbles of this word that hold characters (wave-uniform)
+				kw[w] &= keep >= 8 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (4 * keep)) - 1u));
+				any15 |= kw[w] & (kw[w] >> 1) & (kw[w] >> 2) & (kw[w] >> 3) & 0x11111111u;
+			}
+			kw[0] |= 0xFu;
+			const u64 klo = (u64)kw[0] | ((u64)kw[1] << 32), khi = (u64)kw[2] | ((u64)kw[3] << 32);
+			const bool bad = any15 != 0u;                                // some nibble is 15: a byte outside the alphabet
+			if (bad) rejected++;
+			else {
+				counted++;
+				const u64 first_inv = ~(u64)(a.row_base + r);
+				const u64 want = ~khi;
+				u32 idx = (census_hash(klo, khi) >> 16) & (kLdsSlots - 1);
+				bool done = false;
+				for (int p = 0; p < kLdsProbes && !done;) {
+					LdsSlot *s = lt + idx;
+					u64 k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					u64 v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					u64 f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (k == 0) {
+						k = atomicCAS(&s->klo, 0ull, klo);
+						if (k == 0) {
+							__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							k = klo;
+							v = want;
+						} else {
+							v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						}
+						f = 0;
+					}
+					if (k == klo && v == 0) continue;                    // claimed, high word not published yet: look again
+					if (k == klo && v == want) {
+						atomicAdd(&s->count, 1u);
+						if (f < first_inv) atomicMax(&s->first_inv, first_inv);
+						done = true;
+					} else {
+						idx = (idx + 1) & (kLdsSlots - 1);
+						p++;
+					}
+				}
+				if (!done) { fresh = true; nklo = klo; nkhi = khi; nfirst = first_inv; }
+			}
+		}
+		// Keys the LDS table had no room for wait in their lane's registers until enough lanes hold one: the HBM
+		// insert is a chain of dependent round trips, worth paying for many keys at once rather than for a few.
+		if (__any(fresh && pend)) {
+			if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
+			pend = false;
+		}
+		if (fresh) { pend = true; pklo = nklo; pkhi = nkhi; pfirst = nfirst; }
+		if (__popcll(__ballot(pend)) >= 32) {
+			if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
+			pend = false;
+		}
+		census_wave_fence();
+	}
+	if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
+	__syncthreads();
+	// merge the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of them
+	// hold (the frequent ones) are not hit by all of them at the same moment
+	for (int i0 = tid; i0 < kLdsSlots; i0 += blockDim.x) {
+		const int i = (i0 + (int)blockIdx.x * 67) & (kLdsSlots - 1);
+		const LdsSlot s = lt[i];
+		if (s.klo != 0 && !census_insert(a.tab, a.mask, s.klo, ~s.khi_inv, (u64)s.count, s.first_inv, claimed)) overflow += s.count;
+	}
+	// one atomic per wave and statistic
+	for (int o = 32; o > 0; o >>= 1) {
+		claimed += __shfl_xor(claimed, o);
+		counted += __shfl_xor(counted, o);
+		rejected += __shfl_xor(rejected, o);
+		overflow += __shfl_xor(overflow, o);
+	}
+	if (lane == 0) {
+		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
+		if (counted) atomicAdd(&a.stats[1], (u64)counted);
+		if (rejected) atomicAdd(&a.stats[2], (u64)rejected);
+		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
+	}
+}
+
+// grow: re-insert every slot of the old table into the new one
+__global__ __launch_bounds__(256) void census_rehash_kernel(const CensusSlot *old_tab, u64 old_slots, CensusSlot *tab, u64 mask, u64 *stats)
+{
+	u32 claimed = 0, overflow = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += (u64)gridDim.x * blockDim.x) {
+		const CensusSlot s = old_tab[i];
+		if (s.klo != 0 && !census_insert(tab, mask, s.klo, ~s.khi_inv, s.count, s.first_inv, claimed)) overflow++;
+	}
+	if (overflow) atomicAdd(&stats[3], (u64)overflow);
+}
+
+// hist[b] += 1 for every key whose count has floor(log2(count)) == b
+__global__ __launch_bounds__(256) void census_hist_kernel(const CensusSlot *tab, u64 slots, u64 *hist)
+{
+	__shared__ u32 lh[64];
+	if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+	__syncthreads();
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
+		const u64 klo = tab[i].klo, c = tab[i].count;
+		if (klo != 0 && c != 0) atomicAdd(&lh[63 - __clzll(c)], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)lh[threadIdx.x]);
+}
+
+// out[0] = number of entries written; entries (4 x u64 each, the slot as stored) follow from out + 4
+__global__ __launch_bounds__(256) void census_compact_kernel(const CensusSlot *tab, u64 slots, u64 min_count, u64 *out, u64 cap)
+{
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
+		const CensusSlot s = tab[i];
+		if (s.klo != 0 && s.count >= min_count && s.count != 0) {
+			const u64 at = atomicAdd(&out[0], 1ull);
+			if (at < cap) {
+				u64 *e = out + 4 + at * 4;
+				e[0] = s.klo; e[1] = s.khi_inv; e[2] = s.count; e[3] = s.first_inv;
+			}
+		}
+	}
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+
+static hipError_t census_alloc_table(Census *cs, u64 slots, hipStream_t st)
+{
+	hipError_t e = hipMalloc((void **)&cs->tab, slots * sizeof(CensusSlot));
+	if (e != hipSuccess) { cs->tab = nullptr; return e; }
+	cs->slots = slots;
+	return hipMemsetAsync(cs->tab, 0, slots * sizeof(CensusSlot), st);
+}
+
+hipError_t census_create(Census **out, hipStream_t st)
+{
+	Census *cs = new Census();
+	hipError_t e = hipMalloc((void **)&cs->stats, kCensusStats * sizeof(u64));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
+	if (e == hipSuccess) e = census_alloc_table(cs, kInitialSlots, st);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e != hipSuccess) { census_destroy(cs); return e; }
+	*out = cs;
+	return hipSuccess;
+}
+
+void census_destroy(Census *cs)
+{
+	if (!cs) return;
+	if (cs->tab) (void)hipFree(cs->tab);
+	if (cs->stats) (void)hipFree(cs->stats);
+	if (cs->scratch) (void)hipFree(cs->scratch);
+	delete cs;
+}
+
+hipError_t census_reset(Census *cs, hipStream_t st)
+{
+	hipError_t e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
+	if (e == hipSuccess) e = hipMemsetAsync(cs->tab, 0, cs->slots * sizeof(CensusSlot), st);
+	cs->distinct = 0;
+	return e;
+}
+
+hipError_t census_stats(Census *cs, uint64_t out[4], hipStream_t st)
+{
+	u64 h[kCensusStats];
+	hipError_t e = hipMemcpyAsync(h, cs->stats, sizeof h, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return e;
+	cs->distinct = h[0];
+	for (int i = 0; i < kCensusStats; i++) out[i] = h[i];
+	return hipSuccess;
+}
+
+uint64_t census_slots(const Census *cs) { return cs->slots; }
+
+// make room for `incoming` more keys at a load factor of at most 1/2
+static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t st)
+{
+	const u64 need = 2 * (cs->distinct + incoming);
+	if (need <= cs->slots) return hipSuccess;
+	u64 slots = cs->slots;
+	while (slots < need) slots <<= 1;
+	if (slots > (1ull << 32)) return hipErrorOutOfMemory;      // the hash is 32 bits wide (and this would be a 128 GiB table)
+	CensusSlot *old_tab = cs->tab;
+	const u64 old_slots = cs->slots;
+	hipError_t e = census_alloc_table(cs, slots, st);
+	if (e != hipSuccess) { cs->tab = old_tab; cs->slots = old_slots; return e; }
+	census_rehash_kernel<<<n_cu * 8, 256, 0, st>>>(old_tab, old_slots, cs->tab, slots - 1, cs->stats);
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	(void)hipFree(old_tab);
+	return e;
+}
+
+hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
+                      int n_cu, hipStream_t st)
+{
+	if (bc_stride > kCensusMaxStride) return hipErrorInvalidValue;
+	const int tile_slot = (64 * bc_stride + 15) & ~15;
+	const size_t lds = kLdsSlots * sizeof(LdsSlot) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
+	int64_t nr = 0;
+	for (int64_t o = 0; o < n; o += nr) {
+		// The launch must not be able to fill the table beyond one half even if every row is a new key.  When
+		// the bound on the key count says it could, fetch the exact count; then either take a smaller bite
+		// (at least kCensusMinChunk rows: launches have a fixed cost) or grow the table.
+		nr = (n - o) < kCensusChunk ? (n - o) : kCensusChunk;
+		hipError_t e = hipSuccess;
+		if (2 * (cs->distinct + (u64)nr) > cs->slots) {
+			uint64_t s[4];
+			e = census_stats(cs, s, st);
+			if (e != hipSuccess) return e;
+			const int64_t room = (int64_t)(cs->slots / 2) - (int64_t)cs->distinct;
+			const int64_t least = nr < kCensusMinChunk ? nr : kCensusMinChunk;
+			if (room >= least) nr = nr < room ? nr : room;
+			else e = census_reserve(cs, (u64)nr, n_cu, st);
+			if (e != hipSuccess) return e;
+		}
+		cs->distinct += (u64)nr;                              // upper bound until the next census_stats()
+		CensusArgs a;
+		a.bc = bc + o * (int64_t)bc_stride;
+		a.bc_stride = bc_stride;
+		a.L = L;
+		a.n = nr;
+		a.assign = assign ? assign + o : nullptr;
+		a.row_base = row_base + o;
+		a.tab = cs->tab;
+		a.mask = cs->slots - 1;
+		a.stats = cs->stats;
+		const int64_t groups = (nr + 64 * kCensusWaves - 1) / (64 * kCensusWaves);
+		int grid = n_cu * (lds <= 80 * 1024 ? 2 : 1);
+		if (grid > groups) grid = (int)groups;
+		census_kernel<<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot);
+		e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
+}
+
+static hipError_t census_scratch(Census *cs, size_t bytes)
+{
+	if (bytes <= cs->scratch_bytes) return hipSuccess;
+	if (cs->scratch) { (void)hipFree(cs->scratch); cs->scratch = nullptr; cs->scratch_bytes = 0; }
+	hipError_t e = hipMalloc((void **)&cs->scratch, bytes);
+	if (e == hipSuccess) cs->scratch_bytes = bytes;
+	return e;
+}
+
+hipError_t census_count_hist(Census *cs, uint64_t hist[64], int n_cu, hipStream_t st)
+{
+	hipError_t e = census_scratch(cs, 64 * sizeof(u64));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 64 * sizeof(u64), st);
+	if (e != hipSuccess) return e;
+	census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->scratch);
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(hist, cs->scratch, 64 * sizeof(u64), hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	return e;
+}
+
+// entries with count >= min_count, at most cap of them, ordered by first occurrence; *total = how many qualify
+hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint64_t cap, uint64_t *total, int n_cu, hipStream_t st)
+{
+	uint64_t s[4];
+	hipError_t e = census_stats(cs, s, st);
+	if (e != hipSuccess) return e;
+	const u64 room = std::min<u64>(cap, s[0]);
+	e = census_scratch(cs, (4 + room * 4) * sizeof(u64));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 4 * sizeof(u64), st);
+	if (e != hipSuccess) return e;
+	census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, min_count ? min_count : 1, cs->scratch, room);
+	e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	u64 found = 0;
+	e = hipMemcpyAsync(&found, cs->scratch, sizeof found, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return e;
+	*total = found;
+	const u64 got = std::min<u64>(found, room);
+	std::vector<u64> raw(got * 4);
+	if (got) {
+		e = hipMemcpy(raw.data(), cs->scratch + 4, got * 4 * sizeof(u64), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return e;
+	}
+	std::vector<u64> order(got);
+	for (u64 i = 0; i < got; i++) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](u64 x, u64 y) { return raw[x * 4 + 3] > raw[y * 4 + 3]; });   // first_inv descending = first ascending
+	static const char kAlphabet[] = "\0ACGTNacgtn+????";
+	for (u64 i = 0; i < got; i++) {
+		const u64 *r = &raw[order[i] * 4];
+		const u64 klo = r[0], khi = ~r[1];
+		CensusEntry &en = out[i];
+		memset(en.barcode, 0, sizeof en.barcode);
+		for (int j = 0; j < 31; j++) {
+			const u32 c = (u32)((j < 15 ? klo >> (4 * (j + 1)) : khi >> (4 * (j - 15))) & 15u);
+			if (c == 0) break;
+			en.barcode[j] = kAlphabet[c];
+		}
+		en.count = r[2];
+		en.first_row = (int64_t)~r[3];
+	}
+	return hipSuccess;
+}
+
+}  // namespace sk

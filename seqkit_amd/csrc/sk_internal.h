@@ -76,4 +76,22 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
 hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
                                 int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st);
 
+// ---- barcode census (sk_census.hip) ----
+struct Census;
+struct CensusEntry {            // == sk_census_entry of include/seqkit_hip.h
+	char barcode[32];           // NUL-terminated
+	uint64_t count;
+	int64_t first_row;
+};
+hipError_t census_create(Census **out, hipStream_t st);
+void census_destroy(Census *cs);
+hipError_t census_reset(Census *cs, hipStream_t st);
+hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
+                      int n_cu, hipStream_t st);
+hipError_t census_stats(Census *cs, uint64_t out[4], hipStream_t st);
+uint64_t census_slots(const Census *cs);
+hipError_t census_count_hist(Census *cs, uint64_t hist[64], int n_cu, hipStream_t st);
+hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint64_t cap, uint64_t *total, int n_cu, hipStream_t st);
+constexpr int kMaxCensusLen = 31;
+
 }  // namespace sk

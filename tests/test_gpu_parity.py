@@ -397,6 +397,112 @@ def test_bam_fragments_filter(ctx, oracle, n, lo, hi):
 
 
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
+# ---- f3: barcode census ------------------------------------------------------------------------------------
+def census_rows(strings, stride):
+    m = np.zeros((len(strings), stride), dtype=np.uint8)
+    for i, s in enumerate(strings):
+        m[i, :len(s)] = np.frombuffer(s, dtype=np.uint8)
+    return m
+
+
+def random_barcodes(n, L, stride, n_hot, hot_frac, seed, alphabet=b"ACGTN"):
+    """n rows: a few dominant barcodes (the sheet), the rest random — the shape of a demultiplex dry run."""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    hot = alpha[rng.integers(0, len(alpha), size=(n_hot, L))]
+    m = np.zeros((n, stride), dtype=np.uint8)
+    m[:, :L] = alpha[rng.integers(0, len(alpha), size=(n, L))]
+    pick = rng.random(n) < hot_frac
+    m[pick, :L] = hot[rng.integers(0, n_hot, size=int(pick.sum()))]
+    return m
+
+
+def test_census_small_known(ctx, oracle):
+    bc = census_rows([b"ACGT", b"ACG", b"ACGT", b"", b"TTTTTTTT", b"ACG", b"acgtn+AC", b"ACGT"], 8)
+    ctx.census_reset()
+    ctx.census_add(bc)
+    got, total = ctx.census_entries()
+    assert total == 5
+    assert got == [(b"ACGT", 3, 0), (b"ACG", 2, 1), (b"", 1, 3), (b"TTTTTTTT", 1, 4), (b"acgtn+AC", 1, 6)]
+    assert got == oracle.census(bc)
+    st = ctx.census_stats()
+    assert (st["distinct"], st["counted"], st["rejected"]) == (5, 8, 0)
+    hist = ctx.census_count_hist()
+    assert [int(x) for x in hist[:3]] == [3, 2, 0]            # counts 1,1,1 | 2,3
+    assert ctx.census_entries(min_count=2)[0] == [(b"ACGT", 3, 0), (b"ACG", 2, 1)]
+    got, total = ctx.census_entries(min_count=1, cap=2)       # cap < qualifying: total still says how many there are
+    assert total == 5 and len(got) == 2
+    ctx.census_reset()
+    assert ctx.census_stats()["distinct"] == 0 and ctx.census_entries()[0] == []
+
+
+@pytest.mark.parametrize("n,L,stride,n_hot,hot_frac", [(1, 8, 8, 1, 0.0), (255, 17, 17, 4, 0.5), (70000, 17, 24, 96, 0.9),
+                                                       (300000, 8, 8, 96, 0.5), (200000, 31, 32, 10, 0.2), (100000, 6, 16, 3, 0.0)])
+def test_census_matches_oracle(ctx, oracle, n, L, stride, n_hot, hot_frac):
+    bc = random_barcodes(n, L, stride, n_hot, hot_frac, seed=n + L, alphabet=b"ACGTNacgtn+")
+    ctx.census_reset()
+    ctx.census_add(bc, L=L)
+    got, total = ctx.census_entries()
+    want = oracle.census(bc, L=L)
+    assert total == len(want) and got == want
+    st = ctx.census_stats()
+    assert st["counted"] == n and st["rejected"] == 0 and sum(c for _, c, _ in got) == n
+
+
+def test_census_only_unassigned_rows_batches_and_row_base(ctx, oracle):
+    """The dry-run use (src/fasta_demultiplex.rs:190): only reads with no sample within max_diff are counted; fed in
+    batches, in any order, the first-seen index is still the smallest global row."""
+    n = 50000
+    table = synth.make_sheet(96, 8, seed=5)
+    bc, _ = synth.observe_barcodes(table, n, seed=6, p_exact=0.5, p_sub=0.2)
+    ctx.set_barcodes(table, 1)
+    assign = ctx.demux_assign(bc)[0]
+    want = oracle.census(bc, assign=assign)
+    assert 0 < len(want) < n
+    ctx.census_reset()
+    cuts = [0, 7, 20000, 20001, 43210, n]
+    for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        ctx.census_add(bc[lo:hi], assign=assign[lo:hi], row_base=lo)
+    got, _ = ctx.census_entries()
+    assert got == want
+    assert ctx.census_stats()["counted"] == int((assign == -1).sum())
+
+
+def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle):
+    bc = census_rows([b"ACGT", b"AC-T", b"ACGU", b"ACGT", b"AC\0XX"], 5)       # bytes after the first NUL are padding
+    ctx.census_reset()
+    ctx.census_add(bc, L=5)
+    st = ctx.census_stats()
+    assert (st["distinct"], st["counted"], st["rejected"]) == (2, 3, 2)
+    assert ctx.census_entries()[0] == [(b"ACGT", 2, 0), (b"AC", 1, 4)]
+    from seqkit_amd.capi import SeqkitHipError
+    with pytest.raises(SeqkitHipError):
+        ctx.census_add(np.zeros((4, 40), dtype=np.uint8), L=32)
+
+
+def test_census_grows_past_its_first_table(ctx, oracle):
+    """More distinct barcodes than half the initial table: the table is rehashed between launches, nothing is lost."""
+    n = 9_000_000
+    rng = np.random.default_rng(11)
+    vals = rng.integers(0, 4 ** 15, size=n, dtype=np.int64)
+    digits = (vals[:, None] >> (2 * np.arange(15))) & 3
+    bc = np.zeros((n, 16), dtype=np.uint8)
+    bc[:, :15] = np.frombuffer(b"ACGT", dtype=np.uint8)[digits]
+    ctx.census_reset()
+    slots0 = ctx.census_stats()["slots"]
+    ctx.census_add(bc, L=15)
+    st = ctx.census_stats()
+    uniq, first, counts = np.unique(vals, return_index=True, return_counts=True)
+    assert st["distinct"] == len(uniq) and st["counted"] == n and st["slots"] > slots0 and st["slots"] >= 2 * st["distinct"]
+    got, total = ctx.census_entries(min_count=2)
+    order = np.argsort(first[counts >= 2], kind="stable")
+    assert total == int((counts >= 2).sum())
+    assert [(c, f) for _, c, f in got] == [(int(c), int(f)) for c, f in zip(counts[counts >= 2][order], first[counts >= 2][order])]
+    hist = ctx.census_count_hist()
+    assert int(hist.sum()) == len(uniq) and int(hist[0]) == int((counts == 1).sum())
+    ctx.census_reset()
+
+
 def test_errors_are_codes_not_crashes(ctx):
     import seqkit_amd
     with pytest.raises(seqkit_amd.SeqkitHipError):
