@@ -66,6 +66,52 @@ static void oc_append(oc_str *s, const void *b, size_t n)
 }
 static void oc_assign(oc_str *s, const void *b, size_t n) { oc_clear(s); oc_append(s, b, n); }
 static int oc_starts_with(const oc_str *s, char c) { return s->n > 0 && s->p[0] == (uint8_t)c; }
+/* ---- HashMap<String, u64> with `*map.entry(key).or_insert(0) += 1` ------------------------
+ * entries are kept in first-seen order (Rust's HashMap iterates in an arbitrary order; see
+ * oracle/seqkit_oracle.h, orc_census).                                                    */
+typedef struct { oc_str key; uint64_t count; } oc_count;
+typedef struct { oc_count *ent; size_t n, cap; int64_t *slot; size_t nslot; } oc_countmap;
+
+static uint64_t oc_hash(const uint8_t *p, size_t n)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+	return h;
+}
+static void oc_countmap_rehash(oc_countmap *m, size_t nslot)
+{
+	free(m->slot);
+	m->slot = (int64_t *)malloc(nslot * sizeof *m->slot);
+	if (!m->slot) { fputs("oracle: out of memory\n", stderr); exit(2); }
+	m->nslot = nslot;
+	for (size_t i = 0; i < nslot; i++) m->slot[i] = -1;
+	for (size_t e = 0; e < m->n; e++) {
+		size_t i = oc_hash(m->ent[e].key.p, m->ent[e].key.n) & (nslot - 1);
+		while (m->slot[i] >= 0) i = (i + 1) & (nslot - 1);
+		m->slot[i] = (int64_t)e;
+	}
+}
+static void oc_countmap_add(oc_countmap *m, const uint8_t *key, size_t n)
+{
+	if (m->nslot == 0) oc_countmap_rehash(m, 1024);
+	size_t i = oc_hash(key, n) & (m->nslot - 1);
+	while (m->slot[i] >= 0) {
+		oc_count *e = &m->ent[m->slot[i]];
+		if (e->key.n == n && memcmp(e->key.p, key, n) == 0) { e->count += 1; return; }
+		i = (i + 1) & (m->nslot - 1);
+	}
+	if (m->n == m->cap) {
+		m->cap = m->cap ? m->cap * 2 : 256;
+		m->ent = (oc_count *)realloc(m->ent, m->cap * sizeof *m->ent);
+		if (!m->ent) { fputs("oracle: out of memory\n", stderr); exit(2); }
+	}
+	memset(&m->ent[m->n], 0, sizeof(oc_count));
+	oc_assign(&m->ent[m->n].key, key, n);
+	m->ent[m->n].count = 1;
+	m->slot[i] = (int64_t)m->n++;
+	if (m->n * 2 > m->nslot) oc_countmap_rehash(m, m->nslot * 2);
+}
+
 /* String::drain(start..end) */
 static void oc_drain(oc_str *s, size_t start, size_t end)
 {

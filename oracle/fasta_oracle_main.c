@@ -33,6 +33,7 @@ static const char *USAGE_TOP =
 "  fasta statistics <fastq_file>\n";
 
 static const char *USAGE_TRIM = "\nUsage:\n  fasta trim by quality <fastq_file> <min_baseq>\n";
+static const char *USAGE_STATS = "\nUsage:\n  fasta statistics <fastq_file>\n";
 static const char *USAGE_MASK = "\nUsage:\n  fasta mask by quality <fastq_file> <min_baseq>\n";
 static const char *USAGE_ADDBC = "\nUsage:\n  fasta add barcode <fastq_file> <barcode_file>\n";
 static const char *USAGE_DEMUX =
@@ -183,7 +184,66 @@ typedef struct {
 	uint64_t total_reads;
 } sample_t;
 
-typedef struct { oc_str bc; uint64_t count; } extra_t;
+
+/* `entries.sort_by_key(|x| x.1); entries.reverse(); for ... in &entries[0..100]`
+ * (src/fasta_statistics.rs:45-50, src/fasta_demultiplex.rs:255-260).  entries come in as
+ * samples (sheet order) then map entries (HashMap order: arbitrary in the reference,
+ * first-seen order here).  Stable ascending sort by count (merge sort, like Rust's), then
+ * reverse().                                                                            */
+typedef struct { const uint8_t *label; uint64_t count; } oc_entry;
+
+static void entry_merge_sort(oc_entry *a, oc_entry *tmp, size_t n)
+{
+	if (n < 2) return;
+	size_t h = n / 2;
+	entry_merge_sort(a, tmp, h);
+	entry_merge_sort(a + h, tmp, n - h);
+	size_t i = 0, j = h, k = 0;
+	while (i < h && j < n) tmp[k++] = (a[j].count < a[i].count) ? a[j++] : a[i++];
+	while (i < h) tmp[k++] = a[i++];
+	while (j < n) tmp[k++] = a[j++];
+	memcpy(a, tmp, n * sizeof *a);
+}
+
+static void print_most_frequent(oc_entry *ents, size_t ne)
+{
+	oc_entry *tmp = (oc_entry *)malloc(sizeof(oc_entry) * (ne ? ne : 1));
+	entry_merge_sort(ents, tmp, ne);
+	free(tmp);
+	/* &entries[0..100] panics when there are fewer than 100 entries */
+	if (ne < 100) oc_panic("range end index 100 out of range for slice");
+	for (size_t a = 0; a < 100; a++) {
+		oc_entry *x = &ents[ne - 1 - a];
+		printf("- %s: %llu\n", (const char *)x->label, (unsigned long long)x->count);
+	}
+}
+
+/* src/fasta_statistics.rs:12-51 */
+static int statistics(int argc, char **argv)
+{
+	const char *pos[1];
+	int npos = 0;
+	if (!oc_parse(argc, argv, 2, NULL, 0, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_STATS);
+	oc_reader fastq = oc_reader_open(pos[0]);                                   /* :14 */
+	uint64_t total_records = 0;
+	oc_countmap sample_barcodes = {0};
+	oc_str line = {0}, skip = {0};
+	while (oc_read_line(&fastq, &line)) {                                      /* :22 */
+		size_t st, en;
+		if (orc_find_bc_field_stats(line.p, line.n, &st, &en))                 /* :24-27 */
+			oc_countmap_add(&sample_barcodes, line.p + st + 4, en - st - 4);
+		if (oc_starts_with(&line, '@')) { for (int k = 0; k < 3; k++) oc_read_line(&fastq, &skip); }    /* :30-31 */
+		else if (oc_starts_with(&line, '>')) oc_read_line(&fastq, &skip);      /* :32-33 */
+		else oc_error("Invalid FASTQ header:\n%s", (const char *)line.p);      /* :34-36 */
+		total_records += 1;                                                    /* :38 */
+	}
+	printf("Total sequence records: %llu\n", (unsigned long long)total_records);        /* :41 */
+	printf("Most frequent sample barcodes:\n");                                /* :43 */
+	oc_entry *ents = (oc_entry *)malloc(sizeof(oc_entry) * (sample_barcodes.n ? sample_barcodes.n : 1));
+	for (size_t e = 0; e < sample_barcodes.n; e++) { ents[e].label = sample_barcodes.ent[e].key.p; ents[e].count = sample_barcodes.ent[e].count; }
+	print_most_frequent(ents, sample_barcodes.n);
+	return 0;
+}
 
 /* src/fasta_demultiplex.rs:30-265 */
 static int demultiplex(int argc, char **argv)
@@ -257,7 +317,7 @@ static int demultiplex(int argc, char **argv)
 
 	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single"); /* :106-107 */
 	uint64_t total_reads = 0, identified_reads = 0;
-	extra_t *extra = NULL; size_t nextra = 0, capextra = 0;
+	oc_countmap extra_barcodes = {0};                                          /* :110 */
 
 	oc_str header = {0}, barcode = {0}, umi = {0};
 	while (oc_read_line(&fastq[0], &header)) {                                 /* :117 */
@@ -309,16 +369,7 @@ static int demultiplex(int argc, char **argv)
 				        (const char *)samples[equally_fine_sample].name.p, (const char *)samples[equally_fine_sample].barcode.p);
 			}
 		} else if (dry_run > 0) {                                              /* :190-194 */
-			size_t e = 0;
-			for (; e < nextra; e++)
-				if (extra[e].bc.n == barcode.n && memcmp(extra[e].bc.p, barcode.p, barcode.n) == 0) break;
-			if (e == nextra) {
-				if (nextra == capextra) { capextra = capextra ? capextra * 2 : 64; extra = (extra_t *)realloc(extra, sizeof(extra_t) * capextra); }
-				memset(&extra[nextra], 0, sizeof(extra_t));
-				oc_assign(&extra[nextra].bc, barcode.p, barcode.n);
-				nextra++;
-			}
-			extra[e].count += 1;
+			oc_countmap_add(&extra_barcodes, barcode.p, barcode.n);
 		}
 
 		if (write_read_out) {                                                  /* :196 */
@@ -362,25 +413,11 @@ static int demultiplex(int argc, char **argv)
 
 	if (dry_run > 0) {                                                         /* :251-261 */
 		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);
-		size_t ne = (size_t)S + nextra;
-		/* entries = samples (sheet order) then extra_barcodes (HashMap order: arbitrary in
-		 * the reference; first-seen order here).  Stable ascending sort by count, then
-		 * reverse(). */
-		typedef struct { const uint8_t *label; uint64_t count; size_t ord; } ent_t;
-		ent_t *ents = (ent_t *)malloc(sizeof(ent_t) * (ne ? ne : 1));
-		for (int s = 0; s < S; s++) { ents[s].label = samples[s].name.p; ents[s].count = samples[s].total_reads; ents[s].ord = (size_t)s; }
-		for (size_t e = 0; e < nextra; e++) { ents[S + e].label = extra[e].bc.p; ents[S + e].count = extra[e].count; ents[S + e].ord = (size_t)S + e; }
-		for (size_t a = 1; a < ne; a++) {          /* insertion sort = stable */
-			ent_t x = ents[a]; size_t b = a;
-			while (b > 0 && ents[b - 1].count > x.count) { ents[b] = ents[b - 1]; b--; }
-			ents[b] = x;
-		}
-		/* &entries[0..100] panics when there are fewer than 100 entries (:258) */
-		if (ne < 100) oc_panic("range end index 100 out of range for slice");
-		for (size_t a = 0; a < 100; a++) {
-			ent_t *x = &ents[ne - 1 - a];
-			printf("- %s: %llu\n", (const char *)x->label, (unsigned long long)x->count);
-		}
+		size_t ne = (size_t)S + extra_barcodes.n;
+		oc_entry *ents = (oc_entry *)malloc(sizeof(oc_entry) * (ne ? ne : 1));
+		for (int s = 0; s < S; s++) { ents[s].label = samples[s].name.p; ents[s].count = samples[s].total_reads; }
+		for (size_t e = 0; e < extra_barcodes.n; e++) { ents[S + e].label = extra_barcodes.ent[e].key.p; ents[S + e].count = extra_barcodes.ent[e].count; }
+		print_most_frequent(ents, ne);
 	}
 
 	char pct[64];                                                              /* :263-264 */
@@ -402,6 +439,8 @@ int main(int argc, char **argv)
 		rc = add_barcode(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "demultiplex"))
 		rc = demultiplex(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "statistics"))
+		rc = statistics(argc, argv);
 	else {
 		fprintf(stderr, "%s\n", USAGE_TOP);
 		rc = 0;

@@ -49,6 +49,7 @@ static const char *USAGE_TOP =
 static const char *USAGE_TRIM = "\nUsage:\n  fasta trim by quality <fastq_file> <min_baseq>\n";
 static const char *USAGE_MASK = "\nUsage:\n  fasta mask by quality <fastq_file> <min_baseq>\n";
 static const char *USAGE_ADDBC = "\nUsage:\n  fasta add barcode <fastq_file> <barcode_file>\n";
+static const char *USAGE_STATS = "\nUsage:\n  fasta statistics <fastq_file>\n";
 static const char *USAGE_DEMUX =
 	"\nUsage:\n"
 	"  fasta demultiplex [options] <sample_sheet> <fastq_1> [<fastq_2>]\n"
@@ -315,6 +316,141 @@ struct Sample {
 	uint64_t total_reads = 0;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// f3: barcode census — the HashMap<String, u64> of src/fasta_statistics.rs:19,26 and src/fasta_demultiplex.rs:110,193
+// lives on the device (sk_census_*); barcodes the device table cannot key (longer than 31 characters, or bytes outside
+// ACGTNacgtn+, which only index files can bring) are counted here.
+// ---------------------------------------------------------------------------------------------------------
+static const int kCensusStride = 32;
+static const size_t kCensusMaxLen = 31;
+
+static bool census_keyable(const char *p, size_t n)
+{
+	if (n > kCensusMaxLen) return false;
+	for (size_t i = 0; i < n; i++) {
+		switch (p[i]) {
+		case 'A': case 'C': case 'G': case 'T': case 'N': case 'a': case 'c': case 'g': case 't': case 'n': case '+': break;
+		default: return false;
+		}
+	}
+	return true;
+}
+
+struct CensusEnt { std::string label; uint64_t count; int64_t first; };
+
+struct HostCensus {                                  // what the device table cannot key
+	std::unordered_map<std::string, size_t> idx;
+	std::vector<CensusEnt> ents;
+	void add(const std::string &bc, int64_t first, uint64_t count = 1)
+	{
+		auto it = idx.find(bc);
+		if (it == idx.end()) { idx.emplace(bc, ents.size()); ents.push_back({bc, count, first}); }
+		else { ents[it->second].count += count; ents[it->second].first = std::min(ents[it->second].first, first); }
+	}
+};
+
+// Every barcode that can be among the `need` most frequent ones, in first-seen order.  A small census is fetched
+// whole; from a large one only the barcodes whose count reaches the power of two that still leaves `need` of them.
+static std::vector<CensusEnt> census_fetch(const HostCensus &hc, size_t need)
+{
+	std::vector<CensusEnt> all;
+	sk_ctx *ctx = host::gpu();
+	uint64_t st[4] = {0, 0, 0, 0};
+	check(sk_census_stats(ctx, st), "sk_census_stats");
+	uint64_t min_count = 1, expect = st[0];
+	if (st[0] > (1u << 20)) {
+		uint64_t hist[64];
+		check(sk_census_count_hist(ctx, hist), "sk_census_count_hist");
+		uint64_t above = 0;
+		for (int b = 63; b >= 0; b--) {
+			above += hist[b];
+			if (above >= need || b == 0) { min_count = 1ull << b; expect = above; break; }
+		}
+	}
+	std::vector<sk_census_entry> dev(expect);
+	uint64_t total = 0;
+	check(sk_census_entries(ctx, min_count, dev.data(), dev.size(), &total), "sk_census_entries");
+	if (total != expect) error("census changed while it was read (%llu != %llu).", (unsigned long long)total, (unsigned long long)expect);
+	all.reserve(dev.size() + hc.ents.size());
+	for (const sk_census_entry &e : dev) all.push_back({e.barcode, e.count, e.first_row});
+	for (const CensusEnt &e : hc.ents) all.push_back(e);
+	std::stable_sort(all.begin(), all.end(), [](const CensusEnt &a, const CensusEnt &b) { return a.first < b.first; });
+	return all;
+}
+
+// `entries.sort_by_key(|x| x.1); entries.reverse(); for ... in &entries[0..100]` (src/fasta_statistics.rs:45-50,
+// src/fasta_demultiplex.rs:255-260).  The reference's entries come out of a HashMap in arbitrary order, so the order
+// among equal counts is unspecified there; here they start in first-seen order.  The reference panics when there are
+// fewer than 100 entries; this build prints the entries there are (documented deviation).
+static void print_most_frequent(std::vector<CensusEnt> &ents)
+{
+	std::stable_sort(ents.begin(), ents.end(), [](const CensusEnt &a, const CensusEnt &b) { return a.count < b.count; });
+	std::reverse(ents.begin(), ents.end());
+	const size_t lim = std::min<size_t>(100, ents.size());
+	for (size_t i = 0; i < lim; i++) {
+		char buf[64];
+		snprintf(buf, sizeof buf, ": %llu\n", (unsigned long long)ents[i].count);
+		host::out().write("- ", 2); host::out().write(ents[i].label); host::out().write(buf, strlen(buf));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fasta statistics (src/fasta_statistics.rs:12-51)
+// ---------------------------------------------------------------------------------------------------------
+static int statistics(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_STATS);
+	host::LineReader fastq(pos[0]);                                         // :14
+	check(sk_census_reset(host::gpu()), "sk_census_reset");
+	size_t kBatch = 1u << 20;
+	if (const char *e = getenv("SEQKIT_BLOCK_RECORDS")) kBatch = std::max<size_t>(1, (size_t)atoll(e));     // tests use tiny batches
+	std::vector<uint8_t> rows(kBatch * kCensusStride, 0);
+	size_t nrows = 0;
+	int64_t row_base = 0;                                                   // census rows handed to the device so far
+	HostCensus longs;
+	auto flush = [&]() {
+		if (nrows == 0) return;
+		check(sk_census_add(host::gpu(), rows.data(), kCensusStride, (int)kCensusMaxLen, (int64_t)nrows, nullptr, row_base), "sk_census_add");
+		memset(rows.data(), 0, nrows * kCensusStride);
+		row_base += (int64_t)nrows;
+		nrows = 0;
+	};
+	uint64_t total_records = 0;
+	std::string line, skip;
+	auto read = [&](std::string &l) {                                      // FileReader::read_line (src/common.rs:106-112)
+		const bool ok = fastq.read_line(l);
+		if (fastq.bad_utf8()) error("I/O error while reading from file.");
+		return ok;
+	};
+	while (read(line)) {                                                    // :22
+		size_t st = 0, en = 0;
+		if (host::find_bc_field(line, st, en, false)) {                     // :24-27
+			const char *bc = line.data() + st + 4;
+			const size_t n = en - st - 4;
+			if (n <= kCensusMaxLen) {
+				memcpy(rows.data() + nrows * kCensusStride, bc, n);
+				if (++nrows == kBatch) flush();
+			} else {
+				longs.add(std::string(bc, n), row_base + (int64_t)nrows);
+			}
+		}
+		if (line[0] == '@') { for (int k = 0; k < 3; k++) read(skip); }     // :30-31
+		else if (line[0] == '>') read(skip);                                // :32-33
+		else error("Invalid FASTQ header:\n%s", line.c_str());              // :34-36
+		total_records += 1;                                                 // :38
+	}
+	flush();
+	char buf[96];
+	snprintf(buf, sizeof buf, "Total sequence records: %llu\n", (unsigned long long)total_records);       // :41
+	host::out().write(buf, strlen(buf));
+	host::out().write("Most frequent sample barcodes:\n");                  // :43
+	std::vector<CensusEnt> ents = census_fetch(longs, 100);
+	print_most_frequent(ents);
+	return 0;
+}
+
 // ---- one block of clusters (all input files cut at the same record count) -> per-sample text -----------------------
 struct DemuxCfg {
 	std::vector<Sample> *samples;
@@ -332,7 +468,7 @@ struct DemuxOut {
 	std::vector<uint64_t> per_sample;
 	std::string warn;                              // stderr text, in cluster order
 	std::vector<std::string> out1, out2;           // per sample
-	std::vector<std::pair<std::string, uint64_t>> extras;     // dry run: unmatched barcodes in first-seen order
+	HostCensus extras;                             // dry run: unmatched barcodes the device census cannot key
 	std::string err;
 	int err_code = 255;
 };
@@ -352,7 +488,7 @@ static void close_outputs()
 
 static inline size_t strip_nl(const host::Line &l) { return l.n - ((l.n && l.p[l.n - 1] == '\n') ? 1 : 0); }
 
-static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, fastq2, index1, index2 */, DemuxOut &res)
+static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, fastq2, index1, index2 */, uint64_t base /* clusters before this block */, DemuxOut &res)
 {
 	std::vector<Sample> &samples = *cfg.samples;
 	const int S = (int)samples.size();
@@ -461,6 +597,12 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 		std::lock_guard<std::mutex> lk(host::gpu_mutex());
 		check(sk_demux_assign(host::gpu(), bc.data(), (int)L, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
 	}
+	// :190-194 — in a dry run the barcodes that matched no sample are counted: on the device, from the same matrix
+	const bool dev_census = cfg.dry_run && L > 0 && L <= kCensusMaxLen;
+	if (dev_census && nb > 0) {
+		std::lock_guard<std::mutex> lk(host::gpu_mutex());
+		check(sk_census_add(host::gpu(), bc.data(), (int)L, (int)L, (int64_t)nb, assign.data(), (int64_t)base), "sk_census_add");
+	}
 
 	// body of one written record: verbatim lines, or the lines `mask by quality` then `trim by quality` would print
 	auto emit_body = [&](std::string &w, const host::Line &sl, const host::Line &pl, const host::Line &ql, size_t i, int m) -> bool {
@@ -491,7 +633,6 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 	};
 
 	// ---- emit in input order (src/fasta_demultiplex.rs:168-238) ------------------------------------------------------
-	std::unordered_map<std::string, size_t> extra_idx;
 	std::string umi;
 	char wbuf[1024];
 	for (size_t i = 0; i < nb; i++) {
@@ -507,9 +648,7 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 			         c.barcode.c_str(), (unsigned)lowest[i], a.name.c_str(), a.barcode.c_str(), b.name.c_str(), b.barcode.c_str());
 			res.warn += wbuf;
 		} else if (cfg.dry_run) {                                           // :190-194
-			auto it = extra_idx.find(c.barcode);
-			if (it == extra_idx.end()) { extra_idx.emplace(c.barcode, res.extras.size()); res.extras.emplace_back(c.barcode, 1); }
-			else res.extras[it->second].second += 1;
+			if (!dev_census || !census_keyable(c.barcode.data(), c.barcode.size())) res.extras.add(c.barcode, (int64_t)(base + i));
 		}
 		if (!write_read_out) continue;
 		const Sample &sm = samples[assign[i]];
@@ -623,8 +762,8 @@ static int demultiplex(int argc, char **argv)
 
 	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single");     // :106-107
 	uint64_t total_reads = 0, identified_reads = 0;
-	std::unordered_map<std::string, uint64_t> extra_barcodes;
-	std::vector<std::string> extra_order;            // first-seen order (the reference's HashMap order is arbitrary)
+	HostCensus extra_barcodes;                       // dry run: what the device census cannot key
+	if (dry_run > 0) check(sk_census_reset(host::gpu()), "sk_census_reset");
 
 	DemuxCfg cfg{&samples, barcode_len, paired_end, nindex, do_mask, do_trim, do_mask ? mask_q : trim_q, dry_run > 0};
 	unsigned nthreads = std::thread::hardware_concurrency();
@@ -649,11 +788,7 @@ static int demultiplex(int argc, char **argv)
 				if (!r->out1[s].empty()) samples[s].out[0]->write(r->out1[s]);
 				if (paired_end && !r->out2[s].empty()) samples[s].out[1]->write(r->out2[s]);
 			}
-		for (auto &e : r->extras) {
-			auto it = extra_barcodes.find(e.first);
-			if (it == extra_barcodes.end()) { extra_barcodes.emplace(e.first, e.second); extra_order.push_back(e.first); }
-			else it->second += e.second;
-		}
+		for (auto &e : r->extras.ents) extra_barcodes.add(e.label, e.first, e.count);
 		if (!r->err.empty()) {
 			for (auto &p : inflight) p.fut.wait();
 			close_outputs();
@@ -662,6 +797,7 @@ static int demultiplex(int argc, char **argv)
 		}
 	};
 
+	uint64_t submitted = 0;
 	for (;;) {
 		size_t want = block_records;
 		if (dry_run > 0) {
@@ -673,9 +809,11 @@ static int demultiplex(int argc, char **argv)
 		for (int f = 1; f < 4; f++) if (files[f]) files[f]->next(want, (*data)[f]);
 		Pending pd;
 		pd.data = data;
-		pd.fut = std::async(std::launch::async, [data, &cfg]() {
+		const uint64_t base = submitted;
+		submitted += want;                           // a short block is the last one
+		pd.fut = std::async(std::launch::async, [data, base, &cfg]() {
 			auto res = std::make_shared<DemuxOut>();
-			demux_block(cfg, data->data(), *res);
+			demux_block(cfg, data->data(), base, *res);
 			return res;
 		});
 		inflight.push_back(std::move(pd));
@@ -685,20 +823,11 @@ static int demultiplex(int argc, char **argv)
 
 	if (dry_run > 0) {                                                      // :251-261
 		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);
-		struct Ent { const std::string *label; uint64_t count; };
-		std::vector<Ent> ents;
-		for (auto &s : samples) ents.push_back({&s.name, s.total_reads});
-		for (auto &b : extra_order) ents.push_back({&b, extra_barcodes[b]});
-		std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.count < b.count; });
-		std::reverse(ents.begin(), ents.end());
-		// The reference slices entries[0..100] and panics when there are fewer than 100 entries (:258); this build
-		// prints the entries there are (documented deviation).
-		const size_t lim = std::min<size_t>(100, ents.size());
-		for (size_t i = 0; i < lim; i++) {
-			char buf[64];
-			snprintf(buf, sizeof buf, ": %llu\n", (unsigned long long)ents[i].count);
-			host::out().write("- ", 2); host::out().write(*ents[i].label); host::out().write(buf, strlen(buf));
-		}
+		std::vector<CensusEnt> ents;                                        // :254-255 samples first, then the extras
+		for (size_t k = 0; k < samples.size(); k++) ents.push_back({samples[k].name, samples[k].total_reads, (int64_t)k - (int64_t)samples.size()});
+		std::vector<CensusEnt> extras = census_fetch(extra_barcodes, 100);
+		ents.insert(ents.end(), extras.begin(), extras.end());
+		print_most_frequent(ents);
 	}
 	close_outputs();
 	host::out().flush();
@@ -716,6 +845,7 @@ int main(int argc, char **argv)
 	else if (argc >= 4 && is(1, "mask") && is(2, "by") && is(3, "quality")) rc = mask_by_quality(argc, argv);
 	else if (argc >= 3 && is(1, "add") && is(2, "barcode")) rc = add_barcode(argc, argv);
 	else if (argc >= 2 && is(1, "demultiplex")) rc = demultiplex(argc, argv);
+	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);
 	host::out().flush();
 	return rc;

@@ -128,13 +128,14 @@ static bool bc_class(char c)
 }
 
 // src/fasta_demultiplex.rs:38 — literal " BC:" followed by a greedy run (>= 1) of the class; leftmost match
-bool find_bc_field(const std::string &h, size_t &start, size_t &end)
+bool find_bc_field(const std::string &h, size_t &start, size_t &end, bool allow_plus)
 {
 	const size_t n = h.size();
+	auto cls = [allow_plus](char c) { return bc_class(c) && (allow_plus || c != '+'); };
 	for (size_t i = 0; i + 5 <= n; i++) {
-		if (h[i] == ' ' && h[i + 1] == 'B' && h[i + 2] == 'C' && h[i + 3] == ':' && bc_class(h[i + 4])) {
+		if (h[i] == ' ' && h[i + 1] == 'B' && h[i + 2] == 'C' && h[i + 3] == ':' && cls(h[i + 4])) {
 			size_t e = i + 5;
-			while (e < n && bc_class(h[e])) e++;
+			while (e < n && cls(h[e])) e++;
 			start = i; end = e;
 			return true;
 		}

@@ -31,7 +31,9 @@ bool utf8_valid(const uint8_t *s, size_t n);             // what BufRead::read_l
 size_t trim_end_len(const std::string &s);               // str::trim_end(): Unicode White_Space (0x1C..0x1F are NOT)
 size_t trim_start_off(const std::string &s);             // offset after leading White_Space
 bool is_ascii(const std::string &s);
-bool find_bc_field(const std::string &h, size_t &start, size_t &end);   // regex " BC:[ACGTNacgtn+]+", leftmost-first
+// regex " BC:[ACGTNacgtn+]+", leftmost-first (src/fasta_demultiplex.rs:38); allow_plus = false is the
+// " BC:[ACGTNacgtn]+" of src/fasta_statistics.rs:16
+bool find_bc_field(const std::string &h, size_t &start, size_t &end, bool allow_plus = true);
 bool parse_uint(const char *s, uint64_t max, uint64_t &out);            // str::parse::<uN>(): [+]digits, no overflow
 std::string fmt_pct(double v);                           // "{:.1}" incl. NaN / inf spellings
 

@@ -10,8 +10,9 @@ FASTA = os.path.join(REPO, "seqkit_amd", "bin", "fasta")
 SAM = os.path.join(REPO, "seqkit_amd", "bin", "sam")
 
 
-def run(binary, args, cwd=None, stdin=None):
-    r = subprocess.run([binary] + list(args), cwd=cwd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+def run(binary, args, cwd=None, stdin=None, env=None):
+    e = dict(os.environ, **env) if env else None
+    r = subprocess.run([binary] + list(args), cwd=cwd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=e)
     return r.returncode, r.stdout, r.stderr
 
 
