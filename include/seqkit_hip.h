@@ -162,6 +162,19 @@ int sk_bam_fragments(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, cons
 int sk_bam_fragments_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                          int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept);
 
+/* ---- f4: `sam to fastq` sequence() ---------------------------------------------------------------------------
+ * src/sam_to_fastq.rs:31-59: the bases of BAM records as ASCII — codes 1,2,4,8 -> A,C,G,T, anything else N; records
+ * with flag & 0x10 come out reverse-complemented; a base whose quality is below min_baseq (the reference passes 10,
+ * :103) is N.  SoA layout: row r of seq4 at seq4 + r*seq4_stride holds the record's packed bases exactly as BAM stores
+ * them (two per byte, even positions in the high nibble); rows of qual (raw phred bytes) and out at + r*stride.
+ * stride and seq4_stride must be multiples of 4 with 2*seq4_stride >= stride; len NULL = every row holds `stride`
+ * bases; flag is the BAM flag column.  Bytes of out past a row's length are unspecified.  Pairing mates by qname
+ * and the text around the bases (:96-149) stay on the host.                                                     */
+int sk_bam_sequence(sk_ctx *ctx, const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride,
+                    const uint16_t *len, const uint16_t *flag, int64_t n, uint8_t min_baseq, uint8_t *out);
+int sk_bam_sequence_dev(sk_ctx *ctx, const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride,
+                        const uint16_t *len, const uint16_t *flag, int64_t n, uint8_t min_baseq, uint8_t *out);
+
 /* ---- f3: barcode census -----------------------------------------------------------------------------------
  * The HashMap<String, u64> of src/fasta_demultiplex.rs:190-194 (dry run: barcodes that matched no sample) and of
  * src/fasta_statistics.rs:23-27 (every BC: field), kept as a hash table in HBM that lives in the ctx.

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
         _lib.orc_fragments_keep.restype = i64
         _lib.orc_fragments_keep.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
+        _lib.orc_bam_sequence_batch.restype = None
+        _lib.orc_bam_sequence_batch.argtypes = [vp, i32, vp, i32, vp, vp, i64, u8, vp]
         _lib.orc_census.restype = i64
         _lib.orc_census.argtypes = [vp, i32, i32, i64, vp, i64, vp]
         _lib.orc_free.restype = None
@@ -66,6 +68,8 @@ def lib() -> C.CDLL:
         _lib.orc_trim_start_off.argtypes = [C.c_char_p, C.c_size_t]
         _lib.orc_utf8_valid.restype = i32
         _lib.orc_utf8_valid.argtypes = [C.c_char_p, C.c_size_t]
+        _lib.orc_find_bc_field_stats.restype = i32
+        _lib.orc_find_bc_field_stats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _lib.orc_find_bc_field.restype = i32
         _lib.orc_find_bc_field.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     return _lib
@@ -156,6 +160,13 @@ def find_bc_field(h: bytes):
     return None
 
 
+def find_bc_field_stats(h: bytes):
+    st, en = C.c_size_t(), C.c_size_t()
+    if lib().orc_find_bc_field_stats(h, len(h), C.byref(st), C.byref(en)):
+        return int(st.value), int(en.value)
+    return None
+
+
 def census(bc: np.ndarray, L: int | None = None, assign=None, row_base: int = 0):
     """[(barcode bytes, count, first_row)] in first-seen order (f3)."""
     bc = np.ascontiguousarray(bc, dtype=np.uint8)
@@ -174,3 +185,15 @@ def census(bc: np.ndarray, L: int | None = None, assign=None, row_base: int = 0)
         res = [(bytes(e["barcode"]), int(e["count"]), int(e["first_row"])) for e in arr]
     lib().orc_free(out)
     return res
+
+
+def bam_sequence_batch(seq4: np.ndarray, qual: np.ndarray, length, flag: np.ndarray, min_baseq: int = 10) -> np.ndarray:
+    """f4: ASCII bases [n, stride] (bytes past a row's length are left 0)."""
+    seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    flag = np.ascontiguousarray(flag, dtype=np.uint16)
+    n, stride = qual.shape
+    ln = None if length is None else np.ascontiguousarray(length, dtype=np.uint16)
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lib().orc_bam_sequence_batch(_p(seq4), seq4.shape[1], _p(qual), stride, _p(ln) if ln is not None else None, _p(flag), n, min_baseq, _p(out))
+    return out

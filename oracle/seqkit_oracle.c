@@ -419,3 +419,52 @@ int64_t orc_census(const uint8_t *bc, int stride, int L, int64_t n, const int32_
 }
 
 void orc_free(void *p) { free(p); }
+
+/* ---- f4: src/sam_to_fastq.rs:31-59 ------------------------------------------------- */
+static uint8_t encoded_base(const uint8_t *seq4, uint32_t k)
+{
+	return (uint8_t)((seq4[k / 2] >> (4 * (1 - (k & 1)))) & 15);     /* rust-htslib Seq::encoded_base */
+}
+
+void orc_bam_sequence(const uint8_t *seq4, const uint8_t *qual, uint32_t l, int reverse,
+                      uint8_t min_baseq, uint8_t *out)
+{
+	uint32_t o = 0;
+	if (reverse) {                                                   /* :36-46 */
+		for (uint32_t k = l; k-- > 0;) {
+			if (qual[k] < min_baseq) out[o++] = 'N';
+			else {
+				switch (encoded_base(seq4, k)) {
+				case 1: out[o++] = 'T'; break;
+				case 2: out[o++] = 'G'; break;
+				case 4: out[o++] = 'C'; break;
+				case 8: out[o++] = 'A'; break;
+				default: out[o++] = 'N'; break;
+				}
+			}
+		}
+	} else {                                                         /* :47-57 */
+		for (uint32_t k = 0; k < l; k++) {
+			if (qual[k] < min_baseq) out[o++] = 'N';
+			else {
+				switch (encoded_base(seq4, k)) {
+				case 1: out[o++] = 'A'; break;
+				case 2: out[o++] = 'C'; break;
+				case 4: out[o++] = 'G'; break;
+				case 8: out[o++] = 'T'; break;
+				default: out[o++] = 'N'; break;
+				}
+			}
+		}
+	}
+}
+
+void orc_bam_sequence_batch(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride,
+                            const uint16_t *len, const uint16_t *flag, int64_t n,
+                            uint8_t min_baseq, uint8_t *out)
+{
+	for (int64_t r = 0; r < n; r++)
+		orc_bam_sequence(seq4 + r * (int64_t)seq4_stride, qual + r * (int64_t)stride,
+		                 len ? len[r] : (uint32_t)stride, (flag[r] & 0x10) != 0, min_baseq,
+		                 out + r * (int64_t)stride);
+}

@@ -85,6 +85,21 @@ int64_t orc_fragment_lengths_stop(const uint16_t *flag, const int32_t *tid, cons
 int64_t orc_fragments_keep(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                            int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep);
 
+/* ---- f4: src/sam_to_fastq.rs:31-59 sequence() --------------------------------------- */
+/* seq4 = the BAM record's packed bases (two per byte, base k in the HIGH nibble of byte
+ * k/2 when k is even: rust-htslib Seq::encoded_base), qual = its l raw phred bytes,
+ * reverse = flag & 0x10.  out gets l ASCII bases: 1,2,4,8 -> A,C,G,T (anything else N);
+ * a reverse-strand record is emitted reverse-complemented; a base whose quality is below
+ * min_baseq is N.  (The caller appends qualities in STORED order even for reverse reads,
+ * src/sam_to_fastq.rs:107-110 — that is the reference's behaviour and is kept.)          */
+void orc_bam_sequence(const uint8_t *seq4, const uint8_t *qual, uint32_t l, int reverse,
+                      uint8_t min_baseq, uint8_t *out);
+/* SoA batch: row r of seq4 at seq4 + r*seq4_stride, of qual/out at + r*stride; len NULL =
+ * every row holds `stride` bases; flag = the BAM flag column.                             */
+void orc_bam_sequence_batch(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride,
+                            const uint16_t *len, const uint16_t *flag, int64_t n,
+                            uint8_t min_baseq, uint8_t *out);
+
 /* ---- text helpers that restate Rust std behaviour used on the path -------------- */
 /* str::trim_end(): length of s after removing trailing Unicode White_Space chars
  * (U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F, 3000);

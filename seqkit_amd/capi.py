@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
-    "sk_bam_fragments", "sk_bam_fragments_dev",
+    "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
     "sk_timer_start", "sk_timer_stop",
 ]
@@ -87,6 +87,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
         "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_bam_fragments_dev": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
+        "sk_bam_sequence": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, C.c_uint8, vp]),
+        "sk_bam_sequence_dev": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, C.c_uint8, vp]),
         "sk_census_reset": (i32, [vp]),
         "sk_census_add": (i32, [vp, vp, i32, i32, i64, vp, i64]),
         "sk_census_add_dev": (i32, [vp, vp, i32, i32, i64, vp, i64]),
@@ -321,6 +323,26 @@ class Context:
                           kept: int) -> None:
         self._check(self._lib.sk_bam_fragments_dev(self._h, flag, tid, mtid, tlen, n, min_size, max_size, keep_bits, kept),
                     "sk_bam_fragments_dev")
+
+    # ---- f4: sam to fastq sequence() ---------------------------------------------------------
+    def bam_sequence(self, seq4, qual, length, flag, min_baseq: int = 10) -> np.ndarray:
+        """ASCII bases [n, stride]: src/sam_to_fastq.rs:31-59 (bytes past a row's length are unspecified)."""
+        seq4 = _mat(seq4, "seq4")
+        qual = _mat(qual, "qual")
+        n, stride = qual.shape
+        if seq4.shape[0] != n:
+            raise ValueError("seq4 and qual must have the same number of rows")
+        ln = None if length is None else _vec(length, np.uint16, n, "length")
+        flag = _vec(flag, np.uint16, n, "flag")
+        out = np.zeros((n, stride), dtype=np.uint8)
+        self._check(self._lib.sk_bam_sequence(self._h, _ptr(seq4), seq4.shape[1], _ptr(qual), stride, _ptr(ln), _ptr(flag), n, min_baseq,
+                                              _ptr(out)), "sk_bam_sequence")
+        return out
+
+    def bam_sequence_dev(self, seq4: int, seq4_stride: int, qual: int, stride: int, length: int, flag: int, n: int, min_baseq: int,
+                         out: int) -> None:
+        self._check(self._lib.sk_bam_sequence_dev(self._h, seq4, seq4_stride, qual, stride, length or None, flag, n, min_baseq, out),
+                    "sk_bam_sequence_dev")
 
     # ---- f3: barcode census ----------------------------------------------------------------
     def census_reset(self) -> None:

@@ -642,6 +642,57 @@ int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	return SK_OK;
 }
 
+// ---- f4: sam to fastq sequence() ---------------------------------------------------------------------------------
+static int bam_sequence_check(sk_ctx *c, const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *flag, int64_t n,
+                              uint8_t *out)
+{
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (stride < 4 || (stride & 3) || seq4_stride < 4 || (seq4_stride & 3) || 2 * (int64_t)seq4_stride < stride || stride > 65532)
+		return fail(c, SK_ERR_INVALID, "stride = %d, seq4_stride = %d: multiples of 4 with 2*seq4_stride >= stride wanted", stride, seq4_stride);
+	if (n > 0 && (!seq4 || !qual || !flag || !out)) return fail(c, SK_ERR_INVALID, "NULL matrix or column");
+	return SK_OK;
+}
+
+int sk_bam_sequence_dev(sk_ctx *c, const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len,
+                        const uint16_t *flag, int64_t n, uint8_t min_baseq, uint8_t *out)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bam_sequence_check(c, seq4, seq4_stride, qual, stride, flag, n, out)) return r;
+	if (n == 0) return SK_OK;
+	if (((uintptr_t)seq4 | (uintptr_t)qual | (uintptr_t)out) & 3u) return fail(c, SK_ERR_INVALID, "matrices must be 4-byte aligned");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bam_sequence(seq4, seq4_stride, qual, stride, len, flag, n, min_baseq, out, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_bam_sequence(sk_ctx *c, const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len,
+                    const uint16_t *flag, int64_t n, uint8_t min_baseq, uint8_t *out)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = bam_sequence_check(c, seq4, seq4_stride, qual, stride, flag, n, out)) return r;
+	if (n == 0) return SK_OK;
+	if (int r = bind(c)) return r;
+	const size_t per_row = (size_t)seq4_stride + 2 * (size_t)stride + 4;
+	int64_t chunk = (int64_t)((128u << 20) / per_row);
+	if (chunk < 1) chunk = 1;
+	if (chunk > n) chunk = n;
+	const size_t b_seq = up256((size_t)chunk * seq4_stride), b_q = up256((size_t)chunk * stride), b_col = up256((size_t)chunk * 2);
+	if (int r = ensure_ws(c, b_seq + 2 * b_q + 2 * b_col)) return r;
+	uint8_t *dseq = c->ws, *dq = dseq + b_seq, *dout = dq + b_q;
+	uint16_t *dlen = (uint16_t *)(dout + b_q), *dflag = (uint16_t *)(dout + b_q + b_col);
+	for (int64_t o = 0; o < n; o += chunk) {
+		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(dseq, seq4 + o * (int64_t)seq4_stride, (size_t)nr * seq4_stride, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dq, qual + o * (int64_t)stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
+		if (len) SK_HIP(c, hipMemcpyAsync(dlen, len + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, sk::launch_bam_sequence(dseq, seq4_stride, dq, stride, len ? dlen : nullptr, dflag, nr, min_baseq, dout, c->n_cu, c->stream));
+		SK_HIP(c, hipMemcpyAsync(out + o * (int64_t)stride, dout, (size_t)nr * stride, hipMemcpyDeviceToHost, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	return SK_OK;
+}
+
 // ---- f3: barcode census ----------------------------------------------------------------------------------------
 static_assert(sizeof(sk_census_entry) == sizeof(sk::CensusEntry), "sk_census_entry layout");
 

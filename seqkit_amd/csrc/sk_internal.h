@@ -76,6 +76,9 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
 hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
                                 int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st);
 
+hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
+                               int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st);
+
 // ---- barcode census (sk_census.hip) ----
 struct Census;
 struct CensusEntry {            // == sk_census_entry of include/seqkit_hip.h

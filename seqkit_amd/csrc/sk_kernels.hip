@@ -1294,6 +1294,109 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 	if ((threadIdx.x & 63) == 0 && count) atomicAdd(kept, (unsigned long long)count);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// f4: `sam to fastq` sequence() (src/sam_to_fastq.rs:31-59) — BAM 4-bit bases -> ASCII, reverse-complemented for
+// reverse-strand records, 'N' where the quality is below min_baseq.  One thread per output dword (4 bases); a
+// workgroup walks tiles of 64 rows, whose lengths and flags it keeps in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr u32 kN4 = 0x4E4E4E4Eu;      // "NNNN"
+
+// four 4-bit codes, one per byte -> ASCII: codes 1,2,4,8 -> the four bytes of tbl, anything else 'N'
+__device__ __forceinline__ u32 bases_from_codes(u32 nib, u32 tbl)
+{
+	const u32 c1 = tbl & 0xFFu, c2 = (tbl >> 8) & 0xFFu, c4 = (tbl >> 16) & 0xFFu, c8 = tbl >> 24;
+	const u32 lo = 0x4E00004Eu | (c1 << 8) | (c2 << 16);         // codes 0..3: N c1 c2 N
+	const u32 hi = 0x4E4E4E00u | c4;                               // codes 4..7: c4 N N N
+	const u32 sel = nib & 0x07070707u;
+	const u32 r_low = __builtin_amdgcn_perm(hi, lo, sel);          // right for codes 0..7
+	const u32 r_high = __builtin_amdgcn_perm(kN4, 0x4E4E4E00u | c8, sel);   // right for codes 8..15: c8 N N N N N N N
+	const u32 is_high = ((nib >> 3) & 0x01010101u) * 0xFFu;
+	return (r_high & is_high) | (r_low & ~is_high);
+}
+
+// 0xFF in every byte where q < m (unsigned), else 0x00
+__device__ __forceinline__ u32 bytes_below(u32 q, u32 m4)
+{
+	const u32 d = (q | kHi1) - (m4 & ~kHi1);                       // per byte, no borrow: bit 7 = (q & 0x7f) >= (m & 0x7f)
+	const u32 lt = ((~q & m4) | (~(q ^ m4) & ~d)) & kHi1;
+	return (lt >> 7) * 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
+                                                           int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
+                                                           int64_t n, u32 m4, u32 inv_dpr, uint8_t *__restrict__ out)
+{
+	__shared__ u32 row_info[64];                                   // len | reverse << 16
+	const int dpr = stride >> 2, sw = seq4_stride >> 2;
+	const int64_t ntiles = (n + 63) / 64;
+	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const int64_t row0 = t * 64;
+		const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
+		__syncthreads();
+		if ((int)threadIdx.x < rows) {
+			const int64_t r = row0 + threadIdx.x;
+			const u32 l = len ? (u32)len[r] : (u32)stride;
+			row_info[threadIdx.x] = l | (((u32)flag[r] >> 4) & 1u) << 16;
+		}
+		__syncthreads();
+		const u32 total = (u32)rows * (u32)dpr;
+		for (u32 e = threadIdx.x; e < total; e += blockDim.x) {
+			const u32 rl = inv_dpr ? __umulhi(e, inv_dpr) : e / (u32)dpr;
+			const int j = (int)(e - rl * (u32)dpr);
+			const u32 info = row_info[rl];
+			const int l = (int)(info & 0xFFFFu);
+			const int64_t r = row0 + rl;
+			const u32 *q32 = reinterpret_cast<const u32 *>(qual + r * (int64_t)stride);
+			const u32 *s32 = reinterpret_cast<const u32 *>(seq4 + r * (int64_t)seq4_stride);
+			u32 nib, q, tbl;
+			if (!(info >> 16)) {                                   // :47-57 stored order
+				tbl = 0x54474341u;                                 // 1,2,4,8 -> A C G T
+				q = q32[j];
+				const u32 s16 = (s32[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;       // bytes 2j, 2j+1: bases 4j..4j+3, high nibble first
+				nib = ((s16 >> 4) & 0x0Fu) | ((s16 & 0x0Fu) << 8) | ((s16 << 4) & 0x0F0000u) | ((s16 & 0x0F00u) << 16);
+			} else {                                               // :36-46 reverse complement
+				tbl = 0x41434754u;                                 // 1,2,4,8 -> T G C A
+				const int s0 = l - 4 - 4 * j;                      // output bytes 0..3 come from source positions s0+3 .. s0
+				if (s0 >= 0) {
+					const int qd = s0 >> 2, qd1 = (qd + 1 < dpr) ? qd + 1 : dpr - 1;
+					q = __builtin_bswap32(__builtin_amdgcn_alignbyte(q32[qd1], q32[qd], (u32)s0 & 3u));
+					const int a = s0 >> 1, sd = a >> 2, sd1 = (sd + 1 < sw) ? sd + 1 : sw - 1;
+					const u32 x = __builtin_amdgcn_alignbyte(s32[sd1], s32[sd], (u32)a & 3u);
+					const u32 w = __builtin_bswap32(x) >> 8;       // bytes a, a+1, a+2 as one big-endian number: 6 nibbles in base order
+					const u32 v = w >> (8 - 4 * (s0 & 1));         // low 16 bits: source nibbles s0+3 (bits 0..3) .. s0 (bits 12..15)
+					nib = (v & 0xFu) | ((v & 0xF0u) << 4) | ((v & 0xF00u) << 8) | ((v & 0xF000u) << 12);
+				} else {                                           // the row's last (partial) output dword
+					nib = 0u; q = 0u;
+					const uint8_t *q8 = reinterpret_cast<const uint8_t *>(q32), *s8 = reinterpret_cast<const uint8_t *>(s32);
+					for (int b = 0; b < 4; b++) {
+						const int k = l - 1 - 4 * j - b;
+						if (k >= 0) {
+							q |= (u32)q8[k] << (8 * b);
+							nib |= (((u32)s8[k >> 1] >> (4 * (1 - (k & 1)))) & 15u) << (8 * b);
+						}
+					}
+				}
+			}
+			const u32 bases = bases_from_codes(nib, tbl);
+			const u32 low = bytes_below(q, m4);
+			reinterpret_cast<u32 *>(out + r * (int64_t)stride)[j] = (kN4 & low) | (bases & ~low);
+		}
+	}
+}
+
+hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
+                               int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	const u32 dpr = (u32)stride >> 2;
+	// r = e / dpr as a multiply-high: exact while e * dpr < 2^32, and e < 64 * dpr
+	const u32 inv = (dpr < 8192u) ? (u32)(((1ull << 32) + dpr - 1) / dpr) : 0u;
+	const int64_t ntiles = (n + 63) / 64;
+	const int grid = (int)(ntiles < (int64_t)n_cu * 8 ? ntiles : (int64_t)n_cu * 8);
+	bam_sequence_kernel<<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, (u32)(min_baseq & 0xFF) * 0x01010101u, dpr == 1 ? 0u : inv, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
                                 int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st)
 {

@@ -397,6 +397,71 @@ def test_bam_fragments_filter(ctx, oracle, n, lo, hi):
 
 
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
+# ---- f4: sam to fastq sequence() -----------------------------------------------------------------------------
+def bam_rows(n, stride, seed, seq4_stride=None, iupac_frac=0.1):
+    """Random BAM-style rows: packed 4-bit codes (mostly 1/2/4/8, some ambiguity codes), raw phred 0..60 with a few 255,
+    ragged lengths including 0, flags with and without 0x10."""
+    rng = np.random.default_rng(seed)
+    seq4_stride = seq4_stride or (stride // 2 + 3) // 4 * 4
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, size=(n, seq4_stride * 2))]
+    amb = rng.random((n, seq4_stride * 2)) < iupac_frac
+    codes[amb] = rng.integers(0, 16, size=int(amb.sum()), dtype=np.uint8)
+    seq4 = ((codes[:, 0::2] << 4) | codes[:, 1::2]).astype(np.uint8)
+    qual = rng.integers(0, 61, size=(n, stride), dtype=np.uint8)
+    qual[rng.random((n, stride)) < 0.01] = 255
+    ln = rng.integers(0, stride + 1, size=n).astype(np.uint16)
+    ln[rng.random(n) < 0.3] = stride
+    flag = rng.choice(np.array([0, 16, 83, 99, 147, 163, 4, 1040], dtype=np.uint16), size=n)
+    return np.ascontiguousarray(seq4), qual, ln, flag
+
+
+def assert_rows_equal(got, want, ln):
+    cols = np.arange(got.shape[1])[None, :]
+    valid = cols < ln[:, None].astype(np.int64)
+    assert np.array_equal(got[valid], want[valid])
+
+
+def test_bam_sequence_kat_gpu(ctx, golden):
+    from tests.test_oracle_kat import bam_sequence_case
+    g = golden["bam_sequence"]
+    for c in g["cases"]:
+        seq4, qual, ln, flag = bam_sequence_case(c)
+        out = ctx.bam_sequence(seq4, qual, ln, flag, g["min_baseq"])
+        assert out[0, :ln[0]].tobytes() == c["out"].encode(), c
+
+
+@pytest.mark.parametrize("n,stride,seq4_stride", [(1, 4, 4), (63, 8, 4), (65, 12, 8), (1000, 152, 76), (3000, 152, 80), (257, 100, 52),
+                                                  (70, 252, 128), (40, 40000, 20000)])
+def test_bam_sequence_matches_oracle(ctx, oracle, n, stride, seq4_stride):
+    seq4, qual, ln, flag = bam_rows(n, stride, seed=n + stride, seq4_stride=seq4_stride)
+    for m in (10, 0, 31, 200, 255):
+        got = ctx.bam_sequence(seq4, qual, ln, flag, m)
+        assert_rows_equal(got, oracle.bam_sequence_batch(seq4, qual, ln, flag, m), ln)
+    got = ctx.bam_sequence(seq4, qual, None, flag, 10)               # len NULL: every row is full
+    assert np.array_equal(got, oracle.bam_sequence_batch(seq4, qual, None, flag, 10))
+
+
+def test_bam_sequence_every_length_and_strand(ctx, oracle):
+    """Every length 0..40 on both strands: the reverse path's funnel shifts and its partial last dword."""
+    stride = 40
+    lens = np.repeat(np.arange(0, 41, dtype=np.uint16), 2)
+    seq4, qual, _, _ = bam_rows(len(lens), stride, seed=77, iupac_frac=0.2)
+    flag = np.tile(np.array([0, 16], dtype=np.uint16), 41)
+    got = ctx.bam_sequence(seq4, qual, lens, flag, 10)
+    assert_rows_equal(got, oracle.bam_sequence_batch(seq4, qual, lens, flag, 10), lens)
+
+
+def test_bam_sequence_multichunk_and_errors(ctx, oracle):
+    seq4, qual, ln, flag = bam_rows(700000, 152, seed=5)           # > 128 MiB of staging: several chunks
+    got = ctx.bam_sequence(seq4, qual, ln, flag, 10)
+    assert_rows_equal(got, oracle.bam_sequence_batch(seq4, qual, ln, flag, 10), ln)
+    from seqkit_amd.capi import SeqkitHipError
+    with pytest.raises(SeqkitHipError):
+        ctx.bam_sequence(np.zeros((2, 4), np.uint8), np.zeros((2, 10), np.uint8), None, np.zeros(2, np.uint16))     # stride not a multiple of 4
+    with pytest.raises(SeqkitHipError):
+        ctx.bam_sequence(np.zeros((2, 4), np.uint8), np.zeros((2, 12), np.uint8), None, np.zeros(2, np.uint16))     # seq4 rows too short
+
+
 # ---- f3: barcode census ------------------------------------------------------------------------------------
 def census_rows(strings, stride):
     m = np.zeros((len(strings), stride), dtype=np.uint8)

@@ -109,6 +109,38 @@ def test_bam_kat(oracle, golden):
     assert nz == g["hist_nonzero"] and total == 1
 
 
+def bam_sequence_case(c, stride=8):
+    raw = bytes.fromhex(c["seq4_hex"])
+    seq4 = np.zeros((1, stride // 2), dtype=np.uint8)
+    seq4[0, :len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    qual = np.zeros((1, stride), dtype=np.uint8)
+    qual[0, :len(c["qual"])] = c["qual"]
+    return seq4, qual, np.array([len(c["qual"])], dtype=np.uint16), np.array([c["flag"]], dtype=np.uint16)
+
+
+def test_bam_sequence_kat(oracle, golden):
+    g = golden["bam_sequence"]
+    for c in g["cases"]:
+        seq4, qual, ln, flag = bam_sequence_case(c)
+        out = oracle.bam_sequence_batch(seq4, qual, ln, flag, g["min_baseq"])
+        assert out[0, :ln[0]].tobytes() == c["out"].encode(), c
+
+
+def test_census_kat(oracle, golden, tmp_path):
+    g = golden["census"]
+    rows = []
+    for h, want in zip(g["headers"], g["barcodes"]):
+        m = oracle.find_bc_field_stats(h.encode())
+        got = None if m is None else h.encode()[m[0] + 4:m[1]].decode()
+        assert got == want, h
+        if got is not None:
+            rows.append(got.encode())
+    bc = np.zeros((len(rows), 8), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        bc[i, :len(r)] = np.frombuffer(r, dtype=np.uint8)
+    assert [[k.decode(), c] for k, c, _ in oracle.census(bc)] == g["counts_first_seen"]
+
+
 @pytest.mark.parametrize("m", [0, 2, 20, 30, 41, 223, 224, 255])
 def test_trim_closed_form(oracle, m):
     """The suffix-sum closed form of SURVEY.md §8(a) T1 (what the GPU kernel computes) equals the loop."""
