@@ -16,7 +16,47 @@
 
 #include "cli_common.h"
 
-static const char *USAGE_TOP = "\nUsage:\n  sam statistics <bam_file>\n  sam fragment lengths <bam_file>\n";
+/* src/sam_main.rs:16-39, trailing blanks included */
+static const char *USAGE_TOP =
+"\nUsage:\n"
+"  sam merge <bam_files>...\n"
+"  sam consensus <bam_file>\n"
+"  sam count <bam_file> <regions.bed>\n"
+"  sam coverage histogram <bam_file>\n"
+"  sam fragments <bam_file>\n"
+"  sam fragment lengths <bam_file>\n"
+"  sam mark duplicates <bam_file>\n"
+"  sam minimize <bam_file>\n"
+"  sam statistics <bam_file>\n"
+"  sam subsample <bam_file> <fraction>  \n"
+"  sam tags from qname <bam_file>\n"
+"  sam qname from tags <bam_file>\n"
+"  sam trim qnames <bam_file>  \n"
+"\n"
+"Extract reads from BAM files:  \n"
+"  sam to fasta <bam_file> <out_prefix>\n"
+"  sam to fastq <bam_file> <out_prefix>  \n"
+"  sam to interleaved fasta <bam_file>\n"
+"  sam to interleaved fastq <bam_file>\n"
+"  sam to interleaved raw <bam_file>\n"
+"  sam to raw <bam_file> <out_prefix>\n";
+static const char *USAGE_TO =
+"\nUsage:\n"
+"  sam to raw <bam_file> <out_prefix>\n"
+"  sam to fasta <bam_file> <out_prefix>\n"
+"  sam to fastq <bam_file> <out_prefix>\n"
+"  sam to interleaved raw <bam_file>\n"
+"  sam to interleaved fasta <bam_file>\n"
+"  sam to interleaved fastq <bam_file>\n"
+"\n"
+"These commands convert BAM files into FASTQ, FASTA, or raw sequence-per-line\n"
+"format. Both name-sorted and position-sorted BAM files are supported,\n"
+"but memory usage can reach several GB for position-sorted BAM files.\n"
+"\n"
+"Output is written into files whose name is derived based on output prefix\n"
+"and format. For example, with output format FASTQ and prefix \"sample\",\n"
+"paired end reads are written into files sample_1.fq.gz and sample_2.fq.gz,\n"
+"and orphan reads are written into sample.fq.gz.\n";
 static const char *USAGE_STATS =
 "\nUsage:\n  sam statistics [options] <bam_file>\n\nOptions:\n"
 "  --on-target=BED   Count on-target% for regions in BED file [optional]\n";
@@ -223,13 +263,207 @@ static int fragments(int argc, char **argv)
 	return 0;
 }
 
+/* ---- f4: sam to raw|fasta|fastq (src/sam_to_fastq.rs:61-149) ------------------------------ */
+/* whole record: the fixed core and everything after it (qname, cigar, seq, qual, aux) */
+typedef struct { core_t c; uint32_t l_read_name, n_cigar, l_seq; oc_str body; } record_t;
+
+static int bam_next_full(bgzf_t *b, record_t *rec)
+{
+	uint8_t h[4];
+	long r = bgzf_read(b, h, 4);
+	if (r == 0) return 0;
+	if (r < 0) oc_error("Invalid BAM record.");
+	if (r != 4) oc_error("BAM file ended prematurely.");
+	uint32_t block_size = le32(h);
+	if (block_size < 32) oc_error("Invalid BAM record.");
+	uint8_t core[32];
+	r = bgzf_read(b, core, 32);
+	if (r < 0) oc_error("Invalid BAM record.");
+	if (r != 32) oc_error("BAM file ended prematurely.");
+	rec->c.tid = (int32_t)le32(core + 0);
+	rec->c.pos = (int32_t)le32(core + 4);
+	rec->l_read_name = core[8];
+	rec->n_cigar = le16(core + 12);
+	rec->c.flag = le16(core + 14);
+	rec->l_seq = le32(core + 16);
+	rec->c.mtid = (int32_t)le32(core + 20);
+	rec->c.tlen = (int32_t)le32(core + 28);
+	uint32_t rest = block_size - 32;
+	/* htslib bam_read1: a record whose variable part cannot hold its own fields is invalid */
+	if (rec->l_read_name < 1 || rec->l_seq > 0x7fffffffu ||
+	    (uint64_t)rec->n_cigar * 4 + rec->l_read_name + (((uint64_t)rec->l_seq + 1) >> 1) + rec->l_seq > rest)
+		oc_error("Invalid BAM record.");
+	oc_clear(&rec->body);
+	oc_reserve(&rec->body, (size_t)rest + 1);
+	r = bgzf_read(b, rec->body.p, rest);
+	if (r < 0) oc_error("Invalid BAM record.");
+	if (r != (long)rest) oc_error("BAM file ended prematurely.");
+	rec->body.n = rest;
+	return 1;
+}
+
+/* HashMap<Box<str>, Box<str>> with insert / remove; iteration in insertion order (the
+ * reference's order is arbitrary; see seqkit_oracle.h, orc_census)                       */
+typedef struct { oc_str key, val; uint64_t seq; int live; } pend_t;
+typedef struct { pend_t *ent; size_t n, cap; int64_t *slot; size_t nslot; size_t nlive; uint64_t next_seq; } pendmap;
+
+static void pendmap_rehash(pendmap *m, size_t nslot)
+{
+	/* drop dead entries, then index the live ones */
+	size_t w = 0;
+	for (size_t e = 0; e < m->n; e++) {
+		if (m->ent[e].live) { if (w != e) { pend_t t = m->ent[w]; m->ent[w] = m->ent[e]; m->ent[e] = t; } w++; }
+	}
+	for (size_t e = w; e < m->n; e++) { free(m->ent[e].key.p); free(m->ent[e].val.p); memset(&m->ent[e], 0, sizeof(pend_t)); }
+	m->n = w;
+	free(m->slot);
+	m->slot = (int64_t *)malloc(nslot * sizeof *m->slot);
+	m->nslot = nslot;
+	for (size_t i = 0; i < nslot; i++) m->slot[i] = -1;
+	for (size_t e = 0; e < m->n; e++) {
+		size_t i = oc_hash(m->ent[e].key.p, m->ent[e].key.n) & (nslot - 1);
+		while (m->slot[i] >= 0) i = (i + 1) & (nslot - 1);
+		m->slot[i] = (int64_t)e;
+	}
+}
+static pend_t *pendmap_find(pendmap *m, const uint8_t *key, size_t n)
+{
+	if (m->nslot == 0) return NULL;
+	size_t i = oc_hash(key, n) & (m->nslot - 1);
+	while (m->slot[i] >= 0) {
+		pend_t *e = &m->ent[m->slot[i]];
+		if (e->live && e->key.n == n && memcmp(e->key.p, key, n) == 0) return e;
+		i = (i + 1) & (m->nslot - 1);
+	}
+	return NULL;
+}
+static void pendmap_insert(pendmap *m, const uint8_t *key, size_t kn, const oc_str *val)
+{
+	pend_t *e = pendmap_find(m, key, kn);
+	if (e) { oc_assign(&e->val, val->p, val->n); return; }            /* HashMap::insert replaces the value */
+	if (m->nslot == 0 || (m->n + 1) * 2 > m->nslot) pendmap_rehash(m, m->nslot ? (m->nlive * 4 > m->nslot ? m->nslot * 2 : m->nslot) : 1024);
+	if (m->n == m->cap) {
+		m->cap = m->cap ? m->cap * 2 : 256;
+		m->ent = (pend_t *)realloc(m->ent, m->cap * sizeof *m->ent);
+		memset(m->ent + m->n, 0, (m->cap - m->n) * sizeof *m->ent);
+	}
+	e = &m->ent[m->n];
+	oc_assign(&e->key, key, kn);
+	oc_assign(&e->val, val->p, val->n);
+	e->seq = m->next_seq++;
+	e->live = 1;
+	size_t i = oc_hash(key, kn) & (m->nslot - 1);
+	while (m->slot[i] >= 0) i = (i + 1) & (m->nslot - 1);
+	m->slot[i] = (int64_t)m->n++;
+	m->nlive++;
+}
+static void pendmap_remove(pendmap *m, pend_t *e) { e->live = 0; m->nlive--; }
+
+typedef enum { RAW, FASTA, FASTQ } outfmt;
+
+static int is_char_boundary(const oc_str *s, size_t i) { return i == s->n || (i < s->n && (s->p[i] & 0xC0) != 0x80); }
+
+/* src/sam_to_fastq.rs:138-149; out == NULL is io::sink() */
+static void write_read(FILE *out, outfmt format, const uint8_t *qname, size_t qn, const oc_str *seq)
+{
+	if (format == FASTQ) {
+		size_t seq_len = (seq->n - 1) / 2;                                       /* :141 */
+		if (!is_char_boundary(seq, seq_len) || !is_char_boundary(seq, seq_len + 1)) oc_panic("byte index is not a char boundary");
+		if (!out) return;
+		fputc('@', out); fwrite(qname, 1, qn, out); fputc('\n', out);
+		fwrite(seq->p, 1, seq_len, out); fputs("\n+\n", out);
+		fwrite(seq->p + seq_len + 1, 1, seq->n - seq_len - 1, out); fputc('\n', out);
+	} else if (format == FASTA) {
+		if (!out) return;
+		fputc('>', out); fwrite(qname, 1, qn, out); fputc('\n', out);
+		fwrite(seq->p, 1, seq->n, out); fputc('\n', out);
+	} else {
+		if (!out) return;
+		fwrite(seq->p, 1, seq->n, out); fputc('\n', out);
+	}
+}
+
+static int to_reads(int argc, char **argv)
+{
+	/* docopt: `sam to (raw|fasta|fastq) <bam_file> <out_prefix>` | `sam to interleaved (raw|fasta|fastq) <bam_file>` */
+	int interleaved = argc >= 4 && !strcmp(argv[2], "interleaved");
+	const char *fmtw = argv[interleaved ? 3 : 2];
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, interleaved ? 4 : 3, NULL, 0, pos, &npos, 2) || npos != (interleaved ? 1 : 2))
+		oc_error("Invalid arguments.\n%s", USAGE_TO);
+	outfmt format = !strcmp(fmtw, "raw") ? RAW : !strcmp(fmtw, "fasta") ? FASTA : FASTQ;      /* :68-71 */
+	FILE *out_1, *out_2, *out_single;
+	if (interleaved) { out_1 = stdout; out_2 = stdout; out_single = NULL; }                   /* :74-78 */
+	else {                                                                                     /* :79-86 */
+		const char *ext = format == RAW ? "seq" : format == FASTA ? "fa" : "fq";
+		char path[4096];
+		snprintf(path, sizeof path, "%s_1.%s.gz", pos[1], ext); out_1 = oc_gzip_writer(path, 0);
+		snprintf(path, sizeof path, "%s_2.%s.gz", pos[1], ext); out_2 = oc_gzip_writer(path, 0);
+		snprintf(path, sizeof path, "%s.%s.gz", pos[1], ext); out_single = oc_gzip_writer(path, 0);
+	}
+	bgzf_t *b = (bgzf_t *)malloc(sizeof(bgzf_t));                                             /* :96 */
+	bgzf_open(b, pos[0]);
+	bam_read_header(b, pos[0]);
+	pendmap reads_1 = {0}, reads_2 = {0};
+	record_t rec;
+	memset(&rec, 0, sizeof rec);
+	oc_str read_seq = {0}, bases = {0};
+	while (bam_next_full(b, &rec)) {                                                           /* :101 */
+		if (rec.c.flag & 0x100 || rec.c.flag & 0x800) continue;                               /* :102 */
+		const uint8_t *qname = rec.body.p;
+		size_t qn = rec.l_read_name - 1;                                                       /* rust-htslib qname(): without the final NUL */
+		if (!orc_utf8_valid(qname, qn)) oc_panic("called `Result::unwrap()` on an `Err` value: Utf8Error");   /* :104 */
+		const uint8_t *seq4 = rec.body.p + rec.l_read_name + 4 * (size_t)rec.n_cigar;
+		const uint8_t *qual = seq4 + (rec.l_seq + 1) / 2;
+		oc_clear(&bases);
+		oc_reserve(&bases, rec.l_seq + 1);
+		orc_bam_sequence(seq4, qual, rec.l_seq, (rec.c.flag & 0x10) != 0, 10, bases.p);        /* :105 */
+		oc_assign(&read_seq, bases.p, rec.l_seq);
+		if (format == FASTQ) {                                                                 /* :107-112 */
+			oc_append(&read_seq, "|", 1);
+			for (uint32_t k = 0; k < rec.l_seq; k++) {
+				uint8_t ch = (uint8_t)(33 + qual[k]);                                          /* u8 arithmetic wraps (release build) */
+				if (ch < 0x80) oc_append(&read_seq, &ch, 1);
+				else { uint8_t u[2] = {(uint8_t)(0xC0 | (ch >> 6)), (uint8_t)(0x80 | (ch & 0x3F))}; oc_append(&read_seq, u, 2); }   /* char::from(u8) pushed as UTF-8 */
+			}
+		}
+		if (!(rec.c.flag & 0x1)) {                                                             /* :114-115 */
+			write_read(out_single, format, qname, qn, &read_seq);
+		} else if (rec.c.flag & 0x40) {                                                        /* :116-122 */
+			pend_t *mate = pendmap_find(&reads_2, qname, qn);
+			if (mate) {
+				write_read(out_1, format, qname, qn, &read_seq);
+				write_read(out_2, format, qname, qn, &mate->val);
+				pendmap_remove(&reads_2, mate);
+			} else pendmap_insert(&reads_1, qname, qn, &read_seq);
+		} else if (rec.c.flag & 0x80) {                                                        /* :123-130 */
+			pend_t *mate = pendmap_find(&reads_1, qname, qn);
+			if (mate) {
+				write_read(out_1, format, qname, qn, &mate->val);
+				write_read(out_2, format, qname, qn, &read_seq);
+				pendmap_remove(&reads_1, mate);
+			} else pendmap_insert(&reads_2, qname, qn, &read_seq);
+		}
+	}
+	/* :133-137 orphans: reads_1 then reads_2 */
+	pendmap *maps[2] = {&reads_1, &reads_2};
+	for (int k = 0; k < 2; k++)
+		for (size_t e = 0; e < maps[k]->n; e++)                                                /* entries are stored in insertion order */
+			if (maps[k]->ent[e].live) write_read(out_single, format, maps[k]->ent[e].key.p, maps[k]->ent[e].key.n, &maps[k]->ent[e].val);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	int rc;
 	if (argc >= 2 && !strcmp(argv[1], "fragments")) rc = fragments(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "statistics")) rc = statistics(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "fragment") && !strcmp(argv[2], "lengths")) rc = fragment_lengths(argc, argv);
+	else if (argc >= 3 && !strcmp(argv[1], "to") && (!strcmp(argv[2], "raw") || !strcmp(argv[2], "fasta") || !strcmp(argv[2], "fastq"))) rc = to_reads(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "to") && !strcmp(argv[2], "interleaved") &&
+	         (!strcmp(argv[3], "raw") || !strcmp(argv[3], "fasta") || !strcmp(argv[3], "fastq"))) rc = to_reads(argc, argv);
 	else { fprintf(stderr, "%s\n", USAGE_TOP); rc = 0; }
 	fflush(stdout);
+	oc_wait_children();
 	return rc;
 }

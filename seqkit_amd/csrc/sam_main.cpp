@@ -4,6 +4,7 @@
 //   sam statistics [--on-target=BED] <bam_file>                         src/sam_statistics.rs:14-116
 //   sam fragment lengths [--max-frag-size=F] [--reads=N] <bam_file>     src/sam_fragment_lengths.rs:14-48
 //   sam fragments [--min-size=N] [--max-size=N] <bam_file>              src/sam_fragments.rs:14-43   (§8f f2)
+//   sam to [interleaved] raw|fasta|fastq <bam_file> [<out_prefix>]      src/sam_to_fastq.rs:61-149   (§8f f4)
 //
 // The reference reads BAM through rust-htslib; this host walks the BGZF/BAM container itself (SAMv1 §4.2: BGZF is a
 // series of gzip members; after the header every record is block_size:u32 + a 32-byte fixed core) and hands the core
@@ -11,7 +12,9 @@
 // SURVEY.md §8(e) lists them: the --reads=N early stop and the --on-target sweep (S2, not part of the device path).
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "host_common.h"
@@ -54,7 +57,7 @@ public:
 		gzbuffer(gz_, 1 << 20);
 		uint8_t h[8];
 		if (!get(h, 8) || memcmp(h, "BAM\1", 4) != 0) open_fail();
-		skip(le32(h + 4));
+		if (!skip(le32(h + 4))) open_fail();
 		if (!get(h, 4)) open_fail();
 		const uint32_t n_ref = le32(h);
 		for (uint32_t i = 0; i < n_ref; i++) {
@@ -68,18 +71,23 @@ public:
 		}
 	}
 	~BamStream() { if (gz_) gzclose(gz_); }
+	// Record errors ("BAM file ended prematurely." / "Invalid BAM record.", src/common.rs:150-154) end the stream: next()
+	// returns false and the caller, once it has written what the records before the error produce, calls
+	// raise_deferred() — the point the record-at-a-time reference would have reached.
+	void raise_deferred() const { if (!err_.empty()) error("%s", err_.c_str()); }
 	// next record; want_end computes cigar().end_pos() (needed only by the on-target sweep for unpaired reads)
 	bool next(BamCore &c, bool want_end)
 	{
+		if (!err_.empty()) return false;
 		uint8_t h[4];
 		const int r = gzread(gz_, h, 4);
 		if (r == 0) return false;
-		if (r < 0) error("Invalid BAM record.");
-		if (r != 4) error("BAM file ended prematurely.");
+		if (r < 0) return rd_fail("Invalid BAM record.");
+		if (r != 4) return rd_fail("BAM file ended prematurely.");
 		const uint32_t block_size = le32(h);
-		if (block_size < 32) error("Invalid BAM record.");
+		if (block_size < 32) return rd_fail("Invalid BAM record.");
 		uint8_t core[32];
-		need(core, 32);
+		if (!need(core, 32)) return false;
 		c.tid = (int32_t)le32(core + 0);
 		c.pos = (int32_t)le32(core + 4);
 		const uint32_t l_read_name = core[8];
@@ -92,7 +100,7 @@ public:
 		uint32_t rest = block_size - 32;
 		if (want_end && rest >= l_read_name + 4 * n_cigar) {
 			var_.resize(l_read_name + 4 * n_cigar);
-			need(var_.data(), var_.size());
+			if (!need(var_.data(), var_.size())) return false;
 			rest -= (uint32_t)var_.size();
 			int64_t e = c.pos;
 			for (uint32_t k = 0; k < n_cigar; k++) {
@@ -102,7 +110,38 @@ public:
 			}
 			c.end_pos = (int32_t)e;
 		}
-		skip(rest);
+		return skip(rest);
+	}
+	// next record with its variable part (qname, cigar, packed bases, qualities, aux) in `body`
+	struct Var { uint32_t l_read_name, n_cigar, l_seq; };
+	bool next_full(BamCore &c, Var &v, std::vector<uint8_t> &body)
+	{
+		if (!err_.empty()) return false;
+		uint8_t h[4];
+		const int r = gzread(gz_, h, 4);
+		if (r == 0) return false;
+		if (r < 0) return rd_fail("Invalid BAM record.");
+		if (r != 4) return rd_fail("BAM file ended prematurely.");
+		const uint32_t block_size = le32(h);
+		if (block_size < 32) return rd_fail("Invalid BAM record.");
+		uint8_t core[32];
+		if (!need(core, 32)) return false;
+		c.tid = (int32_t)le32(core + 0);
+		c.pos = (int32_t)le32(core + 4);
+		v.l_read_name = core[8];
+		v.n_cigar = (uint32_t)core[12] | ((uint32_t)core[13] << 8);
+		c.flag = (uint16_t)(core[14] | (core[15] << 8));
+		v.l_seq = le32(core + 16);
+		c.mtid = (int32_t)le32(core + 20);
+		c.mpos = (int32_t)le32(core + 24);
+		c.tlen = (int32_t)le32(core + 28);
+		c.end_pos = c.pos;
+		const uint32_t rest = block_size - 32;
+		// htslib bam_read1: a record whose variable part cannot hold its own fields is invalid
+		if (v.l_read_name < 1 || v.l_seq > 0x7fffffffu ||
+		    (uint64_t)v.n_cigar * 4 + v.l_read_name + (((uint64_t)v.l_seq + 1) >> 1) + v.l_seq > rest) return rd_fail("Invalid BAM record.");
+		body.resize(rest);
+		if (rest && !need(body.data(), rest)) return false;
 		return true;
 	}
 	std::vector<std::string> names;
@@ -119,25 +158,29 @@ private:
 		}
 		return true;
 	}
-	void need(uint8_t *dst, size_t n)
+	bool rd_fail(const char *msg) { err_ = msg; return false; }
+	bool need(uint8_t *dst, size_t n)
 	{
 		size_t got = 0;
 		while (got < n) {
 			const int r = gzread(gz_, dst + got, (unsigned)(n - got));
-			if (r < 0) error("Invalid BAM record.");
-			if (r == 0) error("BAM file ended prematurely.");
+			if (r < 0) return rd_fail("Invalid BAM record.");
+			if (r == 0) return rd_fail("BAM file ended prematurely.");
 			got += (size_t)r;
 		}
+		return true;
 	}
-	void skip(uint32_t n)
+	bool skip(uint32_t n)
 	{
 		uint8_t buf[1 << 14];
 		while (n) {
 			const uint32_t c = n > sizeof buf ? (uint32_t)sizeof buf : n;
-			need(buf, c);
+			if (!need(buf, c)) return false;
 			n -= c;
 		}
+		return true;
 	}
+	std::string err_;
 	std::string path_;
 	gzFile gz_ = nullptr;
 	std::vector<uint8_t> var_;
@@ -243,6 +286,7 @@ static int statistics(int argc, char **argv)
 			}
 		}
 	}
+	bam.raise_deferred();
 	char buf[256];                                                                                     // :109-115
 	snprintf(buf, sizeof buf, "Total reads: %llu\n", (unsigned long long)counters[0]);
 	host::out().write(buf, strlen(buf));
@@ -308,6 +352,7 @@ static int fragment_lengths(int argc, char **argv)
 			}
 		}
 	}
+	if (!stopped) bam.raise_deferred();
 	char buf[64];
 	for (uint64_t size = 1; size < max_frag + 1; size++) {                                             // :45-47
 		snprintf(buf, sizeof buf, "%llu\t%llu\n", (unsigned long long)size, (unsigned long long)hist[size]);
@@ -367,6 +412,184 @@ static int fragments(int argc, char **argv)                        // src/sam_fr
 			host::out().write(buf, strlen(buf));
 		}
 	}
+	bam.raise_deferred();
+	return 0;
+}
+
+// ---- sam to raw|fasta|fastq -----------------------------------------------------------------
+static const char *USAGE_TO =
+	"\nUsage:\n"
+	"  sam to raw <bam_file> <out_prefix>\n"
+	"  sam to fasta <bam_file> <out_prefix>\n"
+	"  sam to fastq <bam_file> <out_prefix>\n"
+	"  sam to interleaved raw <bam_file>\n"
+	"  sam to interleaved fasta <bam_file>\n"
+	"  sam to interleaved fastq <bam_file>\n"
+	"\n"
+	"These commands convert BAM files into FASTQ, FASTA, or raw sequence-per-line\n"
+	"format. Both name-sorted and position-sorted BAM files are supported,\n"
+	"but memory usage can reach several GB for position-sorted BAM files.\n"
+	"\n"
+	"Output is written into files whose name is derived based on output prefix\n"
+	"and format. For example, with output format FASTQ and prefix \"sample\",\n"
+	"paired end reads are written into files sample_1.fq.gz and sample_2.fq.gz,\n"
+	"and orphan reads are written into sample.fq.gz.\n";
+
+enum class OutFmt { RAW, FASTA, FASTQ };
+
+// one of the three destinations of write_reads (:92-93): a gzip file, stdout, or io::sink()
+struct ReadSink {
+	std::unique_ptr<host::GzWriter> gz;
+	bool to_stdout = false;
+	void write(const char *p, size_t n)
+	{
+		if (gz) gz->write(p, n);
+		else if (to_stdout) host::out().write(p, n);
+	}
+	void write(const std::string &s) { write(s.data(), s.size()); }
+};
+
+static bool char_boundary(const std::string &s, size_t i) { return i == s.size() || (i < s.size() && ((uint8_t)s[i] & 0xC0) != 0x80); }
+
+static void write_read(ReadSink &out, OutFmt format, const std::string &qname, const std::string &seq)       // :138-149
+{
+	if (format == OutFmt::FASTQ) {
+		const size_t seq_len = (seq.size() - 1) / 2;                                                          // :141
+		if (!char_boundary(seq, seq_len) || !char_boundary(seq, seq_len + 1)) panic("byte index is not a char boundary");
+		out.write("@", 1); out.write(qname); out.write("\n", 1);
+		out.write(seq.data(), seq_len); out.write("\n+\n", 3);
+		out.write(seq.data() + seq_len + 1, seq.size() - seq_len - 1); out.write("\n", 1);
+	} else if (format == OutFmt::FASTA) {
+		out.write(">", 1); out.write(qname); out.write("\n", 1); out.write(seq); out.write("\n", 1);
+	} else {
+		out.write(seq); out.write("\n", 1);
+	}
+}
+
+// HashMap<Box<str>, Box<str>> (:98-99) whose leftovers are listed in insertion order (the reference's order is arbitrary)
+struct PendingReads {
+	struct Val { std::string seq; uint64_t order; };
+	std::unordered_map<std::string, Val> map;
+	uint64_t next = 0;
+	void insert(const std::string &qname, std::string &&seq)
+	{
+		auto it = map.find(qname);
+		if (it != map.end()) it->second.seq = std::move(seq);           // HashMap::insert replaces the value
+		else map.emplace(qname, Val{std::move(seq), next++});
+	}
+	std::vector<const std::pair<const std::string, Val> *> in_order() const
+	{
+		std::vector<const std::pair<const std::string, Val> *> v;
+		v.reserve(map.size());
+		for (const auto &kv : map) v.push_back(&kv);
+		std::sort(v.begin(), v.end(), [](auto a, auto b) { return a->second.order < b->second.order; });
+		return v;
+	}
+};
+
+static ReadSink g_sinks[3];
+static void close_sinks() { for (auto &s : g_sinks) if (s.gz) s.gz->close(); }
+
+static int to_reads(int argc, char **argv)
+{
+	const bool interleaved = argc >= 4 && strcmp(argv[2], "interleaved") == 0;
+	const char *fmtw = argv[interleaved ? 3 : 2];
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, interleaved ? 4 : 3, opts, pos, 2) || pos.size() != (interleaved ? 1u : 2u)) error("Invalid arguments.\n%s", USAGE_TO);
+	const OutFmt format = !strcmp(fmtw, "raw") ? OutFmt::RAW : !strcmp(fmtw, "fasta") ? OutFmt::FASTA : OutFmt::FASTQ;      // :68-71
+	ReadSink &out_1 = g_sinks[0], &out_2 = g_sinks[1], &out_single = g_sinks[2];
+	if (interleaved) { out_1.to_stdout = true; out_2.to_stdout = true; }                                    // :74-78
+	else {                                                                                                   // :79-86
+		const char *ext = format == OutFmt::RAW ? "seq" : format == OutFmt::FASTA ? "fa" : "fq";
+		out_1.gz.reset(new host::GzWriter(pos[1] + "_1." + ext + ".gz"));
+		out_2.gz.reset(new host::GzWriter(pos[1] + "_2." + ext + ".gz"));
+		out_single.gz.reset(new host::GzWriter(pos[1] + "." + ext + ".gz"));
+		host::at_exit_flush(close_sinks);
+	}
+	BamStream bam(pos[0]);                                                                                   // :96
+	PendingReads reads_1, reads_2;
+
+	// a batch of primary records: their bases go through sequence() on the device (:31-59), the rest is text
+	struct Rec { std::string qname; uint16_t flag; uint32_t l_seq; size_t off4, offq; };
+	std::vector<Rec> recs;
+	std::vector<uint8_t> body, raw4, rawq, m4, mq, mout;
+	std::vector<uint16_t> lens, flags;
+	const size_t kBatchBytes = 48u << 20;
+	BamCore c;
+	BamStream::Var v;
+	bool more = true;
+	std::string read_seq;
+	while (more) {
+		recs.clear(); raw4.clear(); rawq.clear();
+		uint32_t max_len = 0;
+		while ((more = bam.next_full(c, v, body))) {                                                         // :101
+			if ((c.flag & 0x100) || (c.flag & 0x800)) continue;                                              // :102
+			if (v.l_seq > 65532) error("Read longer than 65532 bases: not supported by this build.");
+			Rec r;
+			r.qname.assign(reinterpret_cast<const char *>(body.data()), v.l_read_name - 1);                  // rust-htslib qname(): without the final NUL
+			r.flag = c.flag;
+			r.l_seq = v.l_seq;
+			const uint8_t *seq4 = body.data() + v.l_read_name + 4 * (size_t)v.n_cigar, *qual = seq4 + (v.l_seq + 1) / 2;
+			r.off4 = raw4.size(); r.offq = rawq.size();
+			raw4.insert(raw4.end(), seq4, seq4 + (v.l_seq + 1) / 2);
+			rawq.insert(rawq.end(), qual, qual + v.l_seq);
+			recs.push_back(std::move(r));
+			max_len = std::max(max_len, v.l_seq);
+			if ((recs.size() + 1) * (size_t)(((max_len + 3) & ~3u) + 4) * 3 > kBatchBytes) break;
+		}
+		const size_t n = recs.size();
+		if (n == 0) continue;
+		const size_t stride = std::max<size_t>(4, (max_len + 3) & ~(size_t)3), stride4 = std::max<size_t>(4, (stride / 2 + 3) & ~(size_t)3);
+		m4.assign(n * stride4, 0); mq.assign(n * stride, 0); mout.resize(n * stride);
+		lens.resize(n); flags.resize(n);
+		for (size_t i = 0; i < n; i++) {
+			memcpy(m4.data() + i * stride4, raw4.data() + recs[i].off4, (recs[i].l_seq + 1) / 2);
+			memcpy(mq.data() + i * stride, rawq.data() + recs[i].offq, recs[i].l_seq);
+			lens[i] = (uint16_t)recs[i].l_seq;
+			flags[i] = recs[i].flag;
+		}
+		check(sk_bam_sequence(host::gpu(), m4.data(), (int)stride4, mq.data(), (int)stride, lens.data(), flags.data(), (int64_t)n, 10 /* :105 */, mout.data()),
+		      "sk_bam_sequence");
+		for (size_t i = 0; i < n; i++) {
+			const Rec &r = recs[i];
+			if (!host::utf8_valid(reinterpret_cast<const uint8_t *>(r.qname.data()), r.qname.size())) {     // :104 str::from_utf8(..).unwrap()
+				close_sinks();
+				panic("called `Result::unwrap()` on an `Err` value: Utf8Error");
+			}
+			read_seq.assign(reinterpret_cast<const char *>(mout.data() + i * stride), r.l_seq);
+			if (format == OutFmt::FASTQ) {                                                                   // :107-112
+				read_seq.push_back('|');
+				const uint8_t *q = rawq.data() + r.offq;
+				for (uint32_t k = 0; k < r.l_seq; k++) {
+					const uint8_t ch = (uint8_t)(33 + q[k]);                                                 // u8 arithmetic wraps (release build)
+					if (ch < 0x80) read_seq.push_back((char)ch);
+					else { read_seq.push_back((char)(0xC0 | (ch >> 6))); read_seq.push_back((char)(0x80 | (ch & 0x3F))); }   // char::from(u8) as UTF-8
+				}
+			}
+			if (!(r.flag & 0x1)) {                                                                           // :114-115
+				write_read(out_single, format, r.qname, read_seq);
+			} else if (r.flag & 0x40) {                                                                      // :116-122
+				auto it = reads_2.map.find(r.qname);
+				if (it != reads_2.map.end()) {
+					write_read(out_1, format, r.qname, read_seq);
+					write_read(out_2, format, r.qname, it->second.seq);
+					reads_2.map.erase(it);
+				} else reads_1.insert(r.qname, std::string(read_seq));
+			} else if (r.flag & 0x80) {                                                                      // :123-130
+				auto it = reads_1.map.find(r.qname);
+				if (it != reads_1.map.end()) {
+					write_read(out_1, format, r.qname, it->second.seq);
+					write_read(out_2, format, r.qname, read_seq);
+					reads_1.map.erase(it);
+				} else reads_2.insert(r.qname, std::string(read_seq));
+			}
+		}
+	}
+	bam.raise_deferred();
+	for (const PendingReads *m : {&reads_1, &reads_2})                                                       // :133-137
+		for (const auto *kv : m->in_order()) write_read(out_single, format, kv->first, kv->second.seq);
+	close_sinks();
 	return 0;
 }
 
@@ -377,6 +600,8 @@ int main(int argc, char **argv)
 	if (argc >= 2 && is(1, "fragments")) rc = fragments(argc, argv);
 	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else if (argc >= 3 && is(1, "fragment") && is(2, "lengths")) rc = fragment_lengths(argc, argv);
+	else if (argc >= 3 && is(1, "to") && (is(2, "raw") || is(2, "fasta") || is(2, "fastq"))) rc = to_reads(argc, argv);
+	else if (argc >= 4 && is(1, "to") && is(2, "interleaved") && (is(3, "raw") || is(3, "fasta") || is(3, "fastq"))) rc = to_reads(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);
 	host::out().flush();
 	return rc;

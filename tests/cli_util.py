@@ -34,7 +34,9 @@ def bgzf_block(data: bytes) -> bytes:
 
 
 def write_bam(path, refs, records, truncate=None):
-    """refs: [(name, length)], records: dicts with tid,pos,flag,mtid,mpos,tlen,name,cigar[(op,len)],seq_len."""
+    """refs: [(name, length)], records: dicts with tid,pos,flag,mtid,mpos,tlen,name,cigar[(op,len)],seq_len; optional
+    `codes` (one 4-bit BAM base code per base) and `qual` (raw phred per base) give the record real bases; `name` may be
+    bytes."""
     raw = b"BAM\1"
     text = b"@HD\tVN:1.6\tSO:coordinate\n"
     raw += struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
@@ -42,13 +44,19 @@ def write_bam(path, refs, records, truncate=None):
         nb = name.encode() + b"\0"
         raw += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
     for r in records:
-        name = r.get("name", "q").encode() + b"\0"
-        cigar = r.get("cigar", [(0, r.get("seq_len", 10))])
-        l_seq = r.get("seq_len", 10)
+        name = r.get("name", "q")
+        name = (name if isinstance(name, bytes) else name.encode()) + b"\0"
+        codes = r.get("codes")
+        l_seq = len(codes) if codes is not None else r.get("seq_len", 10)
+        cigar = r.get("cigar", [(0, l_seq)])
         body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r.get("mapq", 60), 4680, len(cigar), r["flag"], l_seq,
                            r["mtid"], r["mpos"], r["tlen"])
         body += name + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar)
-        body += bytes((l_seq + 1) // 2) + bytes([30] * l_seq)
+        if codes is None:
+            body += bytes((l_seq + 1) // 2) + bytes([30] * l_seq)
+        else:
+            cs = list(codes) + [0]
+            body += bytes((cs[2 * k] << 4) | cs[2 * k + 1] for k in range((l_seq + 1) // 2)) + bytes(r.get("qual", [30] * l_seq))
         raw += struct.pack("<i", len(body)) + body
     if truncate is not None:
         raw = raw[:truncate]

@@ -443,3 +443,116 @@ def test_sam_statistics_on_target_host_sweep(bins, tmp_path):
             if s > end:
                 break
     assert out.splitlines()[-1] == f"On-target: {on / tot * 100:.1f}%".encode()
+
+
+# ---- f4: sam to raw|fasta|fastq ----------------------------------------------------------------------------------
+def reads_bam(path, n_pairs, seed, sort="name", **kw):
+    """Pairs (both strands), orphans, unpaired reads, secondary/supplementary records, ragged lengths incl. 0, ambiguity
+    codes, low and missing qualities; name-sorted (mates adjacent) or shuffled (mates far apart)."""
+    rng = np.random.default_rng(seed)
+    recs = []
+
+    def rec(name, flag):
+        ln = int(rng.integers(0, 70)) if rng.random() < 0.9 else 0
+        codes = [int(c) for c in np.array([1, 2, 4, 8])[rng.integers(0, 4, size=ln)]]
+        for k in range(ln):
+            if rng.random() < 0.05:
+                codes[k] = int(rng.integers(0, 16))
+        qual = [int(q) for q in rng.integers(0, 45, size=ln)]
+        if rng.random() < 0.05:
+            qual = [255] * ln                                         # qualities absent: 33 + 255 wraps to a space
+        return dict(tid=0, mtid=0, pos=int(rng.integers(0, 10000)), mpos=0, tlen=0, flag=flag, name=name, codes=codes, qual=qual)
+
+    for i in range(n_pairs):
+        name = f"pair{i}:{int(rng.integers(0, 1000))}"
+        rev1 = 16 if rng.random() < 0.5 else 0
+        u = rng.random()
+        if u < 0.8:
+            recs.append(rec(name, 1 | 64 | rev1))
+            recs.append(rec(name, 1 | 128 | (16 - rev1)))
+            if rng.random() < 0.1:
+                recs.append(rec(name, 1 | 64 | 256))                   # secondary alignment: skipped
+            if rng.random() < 0.1:
+                recs.append(rec(name, 1 | 128 | 2048))                 # supplementary: skipped
+        elif u < 0.87:
+            recs.append(rec(name, 1 | 64 | rev1))                      # orphan first mate
+        elif u < 0.94:
+            recs.append(rec(name, 1 | 128 | rev1))                     # orphan second mate
+        elif u < 0.97:
+            recs.append(rec(name, rev1))                               # unpaired
+        else:
+            recs.append(rec(name, 1 | rev1))                           # paired flag but neither first nor last: dropped
+    if sort != "name":
+        order = rng.permutation(len(recs))
+        recs = [recs[k] for k in order]
+    cu.write_bam(path, [("chr1", 100000)], recs, **kw)
+    return recs
+
+
+@pytest.mark.parametrize("fmt", ["raw", "fasta", "fastq"])
+@pytest.mark.parametrize("sort", ["name", "shuffled"])
+def test_sam_to_reads_cli(bins, tmp_path, fmt, sort):
+    bam = tmp_path / "r.bam"
+    reads_bam(str(bam), 3000, seed=31 + len(fmt), sort=sort)
+    a, _, da, _ = both(bins, "sam", ["to", fmt, str(bam), "out"], tmp_path)
+    ext = {"raw": "seq", "fasta": "fa", "fastq": "fq"}[fmt]
+    files = cu.gunzip_dir(da)
+    assert sorted(files) == sorted([f"out_1.{ext}.gz", f"out_2.{ext}.gz", f"out.{ext}.gz"])
+    assert files[f"out_1.{ext}.gz"].count(b"\n") == files[f"out_2.{ext}.gz"].count(b"\n") > 1000 and len(files[f"out.{ext}.gz"]) > 100
+    a, *_ = both(bins, "sam", ["to", "interleaved", fmt, str(bam)], tmp_path)
+    assert a[1].count(b"\n") == 2 * files[f"out_1.{ext}.gz"].count(b"\n")
+    both(bins, "sam", ["to", "interleaved", fmt, "-"], tmp_path, stdin=bam.read_bytes())
+
+
+def test_sam_to_reads_known_answer(bins, tmp_path):
+    bam = tmp_path / "k.bam"
+    recs = [
+        dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0, flag=1 | 64, name="p", codes=[1, 2, 4, 8, 15], qual=[30, 30, 5, 30, 30]),
+        dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0, flag=1 | 128 | 16, name="p", codes=[1, 2, 4, 8, 15], qual=[30, 30, 5, 30, 30]),
+        dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0, flag=0, name="single", codes=[8, 8], qual=[0, 255]),
+        dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0, flag=1 | 128, name="orphan2", codes=[2], qual=[40]),
+        dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0, flag=1 | 64, name="orphan1", codes=[4], qual=[9]),
+    ]
+    cu.write_bam(str(bam), [("chr1", 1000)], recs)
+    a, _, da, _ = both(bins, "sam", ["to", "fastq", str(bam), "x"], tmp_path)
+    f = cu.gunzip_dir(da)
+    # the reverse-strand mate is reverse-complemented, its qualities stay in stored order (src/sam_to_fastq.rs:107-110)
+    assert f["x_1.fq.gz"] == b"@p\nACNTN\n+\n??&??\n" and f["x_2.fq.gz"] == b"@p\nNANGT\n+\n??&??\n"
+    assert f["x.fq.gz"] == b"@single\nNT\n+\n! \n@orphan1\nN\n+\n*\n@orphan2\nC\n+\nI\n"      # reads_1 leftovers before reads_2
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fasta", str(bam)], tmp_path)
+    assert a[1] == b">p\nACNTN\n>p\nNANGT\n"
+    a, *_ = both(bins, "sam", ["to", "interleaved", "raw", str(bam)], tmp_path)
+    assert a[1] == b"ACNTN\nNANGT\n"
+
+
+def test_sam_to_reads_errors_and_quirks(bins, tmp_path):
+    bam = tmp_path / "q.bam"
+    base = dict(tid=0, mtid=0, pos=1, mpos=1, tlen=0)
+    # one quality >= 95: 33 + q is a two-byte char; (len - 1) / 2 still lands on the '|' (src/sam_to_fastq.rs:141)
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(base, flag=0, name="hi", codes=[1, 2, 4], qual=[100, 30, 30])])
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fastq", str(bam)], tmp_path)
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(base, flag=1 | 64, name="m", codes=[1], qual=[30]), dict(base, flag=1 | 128, name="m", codes=[1, 2, 4], qual=[100, 100, 100])])
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fastq", str(bam)], tmp_path, same_stderr=False)       # three of them: the slice is off
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(base, flag=0, name="a", codes=[1, 2], qual=[100, 101])])
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fastq", str(bam)], tmp_path, same_stderr=False)       # cut inside a char: panic
+    assert a[0] == 101
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(base, flag=1 | 64, name="ok", codes=[1], qual=[30]), dict(base, flag=1 | 128, name="ok", codes=[2], qual=[30]),
+                                              dict(base, flag=0, name=b"bad\xff", codes=[1], qual=[30])])
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fasta", str(bam)], tmp_path, same_stderr=False)       # qname is not UTF-8: unwrap() panics
+    assert a[0] == 101 and a[1] == b">ok\nA\n>ok\nC\n"
+    # a record repeated as first mate replaces the pending one (HashMap::insert)
+    cu.write_bam(str(bam), [("chr1", 1000)], [dict(base, flag=1 | 64, name="d", codes=[1], qual=[30]), dict(base, flag=1 | 64, name="d", codes=[2], qual=[30]),
+                                              dict(base, flag=1 | 128, name="d", codes=[4], qual=[30])])
+    a, *_ = both(bins, "sam", ["to", "interleaved", "raw", str(bam)], tmp_path)
+    assert a[1] == b"C\nG\n"
+    # truncated file: what the records before the cut produce is written, then the error
+    reads_bam(str(bam), 300, seed=3, truncate=9000)
+    a, *_ = both(bins, "sam", ["to", "interleaved", "fastq", str(bam)], tmp_path)
+    assert a[0] == 255 and a[2] == b"ERROR: BAM file ended prematurely.\n" and a[1].count(b"\n") > 40
+    both(bins, "sam", ["to", "fastq", str(bam), "t"], tmp_path)
+    make_bam(str(bam), 3000, seed=19, truncate=30000)
+    a, *_ = both(bins, "sam", ["fragments", str(bam)], tmp_path)                                            # same rule for sam fragments
+    assert a[0] == 255 and a[1].count(b"\n") > 5
+    for args in (["to", "fastq", str(bam)], ["to", "interleaved", "fastq"], ["to", "interleaved", "fastq", str(bam), "extra"], ["to", "fastq", "missing.bam", "o"],
+                 ["to", "bed", str(bam), "o"], ["to"], ["to", "fastq", "--x", str(bam), "o"]):
+        both(bins, "sam", args, tmp_path)
