@@ -427,16 +427,227 @@ static int demultiplex(int argc, char **argv)
 	return 0;
 }
 
+/* ---- f5: the per-read text commands -------------------------------------------------------- */
+static int is_boundary(const oc_str *s, size_t i) { return i == s->n || (i < s->n && (s->p[i] & 0xC0) != 0x80); }
+/* &s[a..b] */
+static void check_slice(const oc_str *s, size_t a, size_t b)
+{
+	if (a > b) oc_panic("slice index starts after its end");
+	if (b > s->n) oc_panic("byte index out of range of string slice");
+	if (!is_boundary(s, a) || !is_boundary(s, b)) oc_panic("byte index is not a char boundary");
+}
+static void put_str(const oc_str *s) { fwrite(s->p, 1, s->n, stdout); }
+
+static const char *USAGE_TRIMN =
+"\nUsage:\n  fasta trim [options] <fastq_file>\n\nOptions:\n"
+"  --first=N          Remove first N bases of each read [default: 0].\n"
+"  --last=N           Remove last N bases of each read [default: 0].\n";
+
+/* src/fasta_trim.rs:14-48 */
+static int trim_fixed(int argc, char **argv)
+{
+	oc_opt opts[2] = {{"--first", 1, NULL}, {"--last", 1, NULL}};
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 2, opts, 2, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_TRIMN);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :15 */
+	uint64_t remove_first, remove_last;
+	if (!oc_parse_uint(opts[0].value ? opts[0].value : "0", UINT64_MAX, &remove_first))
+		oc_error("N must be a non-negative integer in --first=N.");            /* :16-17 */
+	if (!oc_parse_uint(opts[1].value ? opts[1].value : "0", UINT64_MAX, &remove_last))
+		oc_error("N must be a non-negative integer in --last=N.");             /* :18-19 */
+	oc_str line = {0}, seq = {0}, qual = {0};
+	while (oc_read_line(&f, &line)) {                                          /* :24 */
+		if (!oc_starts_with(&line, '>') && !oc_starts_with(&line, '@'))
+			oc_error("Invalid FASTA/FASTQ format encountered.");               /* :25-27 */
+		oc_read_line(&f, &seq);                                                /* :29 */
+		uint64_t seq_len = orc_trim_end_len(seq.p, seq.n);                     /* :30 */
+		int keep = remove_first + remove_last < seq_len;                       /* :31 usize wraps in a release build */
+		if (keep) {                                                            /* :32 */
+			check_slice(&seq, remove_first, seq_len - remove_last);
+			put_str(&line);
+			fwrite(seq.p + remove_first, 1, seq_len - remove_last - remove_first, stdout);
+			fputc('\n', stdout);
+		} else {                                                               /* :34 */
+			put_str(&line);
+			fputc('\n', stdout);
+		}
+		if (oc_starts_with(&line, '@')) {                                      /* :37 */
+			oc_read_line(&f, &line);
+			oc_read_line(&f, &qual);
+			if (keep) {                                                        /* :41 */
+				check_slice(&qual, remove_first, seq_len - remove_last);
+				fputs("+\n", stdout);
+				fwrite(qual.p + remove_first, 1, seq_len - remove_last - remove_first, stdout);
+				fputc('\n', stdout);
+			} else fputs("+\n\n", stdout);                                     /* :43 */
+		}
+	}
+	return 0;
+}
+
+static const char *USAGE_UMI =
+"\nUsage:\n  fasta extract dual umi [options] <interleaved_fastq>\n\nOptions:\n"
+"  --first-bases=N   First N bases of read contain UMI bases [default: 0]\n";
+
+/* src/fasta_extract_dual_umi.rs:14-72 */
+static int extract_dual_umi(int argc, char **argv)
+{
+	oc_opt opts[1] = {{"--first-bases", 1, NULL}};
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 4, opts, 1, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_UMI);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :16 */
+	uint64_t first_bases;
+	if (!oc_parse_uint(opts[0].value ? opts[0].value : "0", UINT64_MAX, &first_bases))
+		oc_error("N must be a non-negative integer in --first-bases=N.");      /* :17-19 */
+	oc_str header_1 = {0}, header_2 = {0}, seq_1 = {0}, seq_2 = {0}, qual_1 = {0}, qual_2 = {0}, line = {0}, umi = {0};
+	while (oc_read_line(&f, &header_1)) {                                      /* :30 */
+		oc_clear(&umi);
+		int fastq_format = 0;
+		if (oc_starts_with(&header_1, '@')) fastq_format = 1;                  /* :33-35 */
+		else if (oc_starts_with(&header_1, '>')) fastq_format = 0;
+		else oc_error("Header is not valid FASTA/FASTQ:\n%s", (const char *)header_1.p);
+		if (fastq_format) {                                                    /* :37-47 */
+			oc_read_line(&f, &seq_1); oc_read_line(&f, &line); oc_read_line(&f, &qual_1);
+			oc_read_line(&f, &header_2); oc_read_line(&f, &seq_2); oc_read_line(&f, &line); oc_read_line(&f, &qual_2);
+			if (!oc_starts_with(&header_2, '@')) oc_error("Invalid FASTQ record found in input file.");
+		} else {                                                               /* :48-55 */
+			oc_read_line(&f, &seq_1); oc_read_line(&f, &header_2); oc_read_line(&f, &seq_2);
+			if (!oc_starts_with(&header_2, '>')) oc_error("Invalid FASTA record found in input file.");
+		}
+		check_slice(&seq_1, 0, first_bases);                                   /* :57 */
+		oc_append(&umi, seq_1.p, first_bases);
+		oc_append(&umi, "+", 1);                                               /* :58 */
+		check_slice(&seq_2, 0, first_bases);                                   /* :59 */
+		oc_append(&umi, seq_2.p, first_bases);
+		/* :61-70 — all arguments of print! are evaluated before it writes */
+		check_slice(&seq_1, first_bases, seq_1.n);
+		if (fastq_format) check_slice(&qual_1, first_bases, qual_1.n);
+		check_slice(&seq_2, first_bases, seq_2.n);
+		if (fastq_format) check_slice(&qual_2, first_bases, qual_2.n);
+		const oc_str *hs[2] = {&header_1, &header_2}, *ss[2] = {&seq_1, &seq_2}, *qs[2] = {&qual_1, &qual_2};
+		for (int k = 0; k < 2; k++) {
+			fwrite(hs[k]->p, 1, orc_trim_end_len(hs[k]->p, hs[k]->n), stdout);
+			fputs(" RX:", stdout); put_str(&umi); fputc('\n', stdout);
+			fwrite(ss[k]->p + first_bases, 1, ss[k]->n - first_bases, stdout);
+			if (fastq_format) { fputs("+\n", stdout); fwrite(qs[k]->p + first_bases, 1, qs[k]->n - first_bases, stdout); }
+		}
+	}
+	return 0;
+}
+
+static const char *USAGE_BASESPACE =
+"\nUsage:\n  fasta convert basespace <fastq_file>\n\nDescription:\n"
+"FASTQ files from Illumina Basespace typically display adapter barcodes at\n"
+"the end of the FASTQ header, and have read identifiers that end in /1 or /2.\n"
+"This tool replaces the read identifiers by simple consecutive integers, and\n"
+"places a \"BC:\" prefix in front of the barcode. An example FASTQ header in\n"
+"the output could look like this: @412435 BC:TAGCTACT\n";
+
+/* src/fasta_convert_basespace.rs:17-47 */
+static int convert_basespace(int argc, char **argv)
+{
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 3, NULL, 0, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_BASESPACE);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :19 */
+	uint64_t num_read_pairs = 0;
+	oc_str header = {0}, line = {0};
+	while (oc_read_line(&f, &header)) {                                        /* :25 */
+		num_read_pairs += 1;
+		printf("@%llu", (unsigned long long)num_read_pairs);                   /* :27 */
+		size_t end = orc_trim_end_len(header.p, header.n);                     /* :32 trim_end().split(':').last() */
+		size_t from = end;
+		while (from > 0 && header.p[from - 1] != ':') from--;
+		if (end > from) { fputs(" BC:", stdout); fwrite(header.p + from, 1, end - from, stdout); }    /* :33 */
+		fputc('\n', stdout);                                                   /* :34 */
+		if (oc_starts_with(&header, '@')) {                                    /* :36-39 */
+			for (int k = 0; k < 3; k++) { oc_read_line(&f, &line); put_str(&line); }
+		} else if (oc_starts_with(&header, '>')) {                             /* :40-41 */
+			oc_read_line(&f, &line); put_str(&line);
+		} else oc_error("Invalid FASTQ line:\n%s", (const char *)header.p);    /* :42-44 */
+	}
+	return 0;
+}
+
+static const char *USAGE_SIMPLIFY =
+"\nUsage:\n  fasta simplify read ids [options] <fastq_file>\n\nOptions:\n"
+"  --alphanumeric     Use letters a-z, A-Z and 0-9 in read identifiers\n"
+"  --discard-umi      Remove \"UMI:\" tags from read identifiers, if present\n";
+
+/* src/fasta_simplify_read_ids.rs:19-62 */
+static int simplify_read_ids(int argc, char **argv)
+{
+	oc_opt opts[2] = {{"--alphanumeric", 0, NULL}, {"--discard-umi", 0, NULL}};
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 4, opts, 2, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_SIMPLIFY);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :21 */
+	int discard_umi = opts[1].value != NULL;                                   /* :23 */
+	uint64_t read_num = 0;
+	oc_str line = {0};
+	while (oc_read_line(&f, &line)) {                                          /* :30 */
+		if (line.n == 0) continue;                                             /* :31 */
+		uint8_t prefix = line.p[0];                                            /* :33 chars().nth(0): a multi-byte char is neither */
+		if (prefix != '@' && prefix != '>') oc_error("Invalid FASTA/FASTQ format encountered.");   /* :34-36 */
+		read_num += 1;
+		printf("%c%llu", prefix, (unsigned long long)read_num);                /* :39 */
+		size_t st, en;
+		if (!discard_umi && orc_find_umi_field(line.p, line.n, &st, &en)) fwrite(line.p + st, 1, en - st, stdout);   /* :42-46 */
+		fputc('\n', stdout);                                                   /* :47 */
+		oc_read_line(&f, &line); put_str(&line);                               /* :50-51 */
+		if (prefix == '@') {                                                   /* :54-59 */
+			oc_read_line(&f, &line);
+			fputs("+\n", stdout);
+			oc_read_line(&f, &line); put_str(&line);
+		}
+	}
+	return 0;
+}
+
+static const char *USAGE_INTERLEAVE = "\nUsage:\n  fasta interleave <fastq_1> <fastq_2>\n";
+
+/* src/fasta_interleave.rs:9-35 */
+static int interleave(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 2, NULL, 0, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_INTERLEAVE);
+	oc_reader f1 = oc_reader_open(pos[0]);                                     /* :11 */
+	oc_reader f2 = oc_reader_open(pos[1]);                                     /* :12 */
+	oc_str line = {0};
+	while (oc_read_line(&f1, &line)) {                                         /* :15 */
+		int lines = 0;
+		if (oc_starts_with(&line, '@')) lines = 4;                             /* :16-18 */
+		else if (oc_starts_with(&line, '>')) lines = 2;
+		else oc_error("Line is not FASTA/FASTQ format: %s", (const char *)line.p);
+		put_str(&line);                                                        /* :19 */
+		for (int k = 0; k < lines - 1; k++) { oc_read_line(&f1, &line); put_str(&line); }   /* :20-22 */
+		oc_read_line(&f2, &line);                                              /* :24 */
+		if ((lines == 4 && !oc_starts_with(&line, '@')) || (lines == 2 && !oc_starts_with(&line, '>')))
+			oc_error("Input files do not share a consistent format.");         /* :25-28 */
+		put_str(&line);                                                        /* :29 */
+		for (int k = 0; k < lines - 1; k++) { oc_read_line(&f2, &line); put_str(&line); }   /* :30-32 */
+	}
+	return 0;
+}
+
 /* src/fasta_main.rs:42-82 (only the hot-path arms are restated) */
 int main(int argc, char **argv)
 {
 	int rc;
-	if (argc >= 4 && !strcmp(argv[1], "trim") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
+	if (argc >= 4 && !strcmp(argv[1], "simplify") && !strcmp(argv[2], "read") && !strcmp(argv[3], "ids"))
+		rc = simplify_read_ids(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "interleave"))
+		rc = interleave(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "trim") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
 		rc = trim_by_quality(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "trim"))
+		rc = trim_fixed(argc, argv);
 	else if (argc >= 4 && !strcmp(argv[1], "mask") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
 		rc = mask_by_quality(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "add") && !strcmp(argv[2], "barcode"))
 		rc = add_barcode(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "extract") && !strcmp(argv[2], "dual") && !strcmp(argv[3], "umi"))
+		rc = extract_dual_umi(argc, argv);
+	else if (argc >= 3 && !strcmp(argv[1], "convert") && !strcmp(argv[2], "basespace"))
+		rc = convert_basespace(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "demultiplex"))
 		rc = demultiplex(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "statistics"))

@@ -283,6 +283,26 @@ size_t orc_trim_start_off(const uint8_t *s, size_t n)
 	return off;
 }
 
+/* regex " UMI:[^\s]*" (src/fasta_simplify_read_ids.rs:26): leftmost " UMI:", then every
+ * char that is not Unicode White_Space.                                               */
+int orc_find_umi_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end)
+{
+	for (size_t i = 0; i + 5 <= n; i++) {
+		if (memcmp(hdr + i, " UMI:", 5) != 0) continue;
+		size_t e = i + 5;
+		while (e < n) {
+			uint32_t c;
+			size_t l = utf8_next(hdr + e, n - e, &c);
+			if (is_rust_whitespace(c)) break;
+			e += l;
+		}
+		*start = i;
+		*end = e;
+		return 1;
+	}
+	return 0;
+}
+
 /* Well-formed UTF-8 per the Unicode standard table 3-7 (what core::str::from_utf8 accepts). */
 int orc_utf8_valid(const uint8_t *s, size_t n)
 {

@@ -114,6 +114,8 @@ int orc_utf8_valid(const uint8_t *s, size_t n);
  * returns 1 and [*start,*end) of the whole match, else 0.                            */
 int orc_find_bc_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
 
+/* regex " UMI:[^\s]*" leftmost (src/fasta_simplify_read_ids.rs:26,43) */
+int orc_find_umi_field(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
 /* " BC:[ACGTNacgtn]+" — the `fasta statistics` variant without '+' (src/fasta_statistics.rs:16). */
 int orc_find_bc_field_stats(const uint8_t *hdr, size_t n, size_t *start, size_t *end);
 

@@ -837,13 +837,19 @@ static int demultiplex(int argc, char **argv)
 	return 0;
 }
 
+bool fasta_text_command(int argc, char **argv, bool before_trim_by_quality, int &rc);      // fasta_text.cpp
+
 int main(int argc, char **argv)
 {
 	int rc = 0;
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
-	if (argc >= 4 && is(1, "trim") && is(2, "by") && is(3, "quality")) rc = trim_by_quality(argc, argv);
+	// the order of src/fasta_main.rs:45-81 ("trim by quality" is tested before "trim")
+	if (fasta_text_command(argc, argv, true, rc)) {}
+	else if (argc >= 4 && is(1, "trim") && is(2, "by") && is(3, "quality")) rc = trim_by_quality(argc, argv);
+	else if (argc >= 2 && is(1, "trim")) fasta_text_command(argc, argv, false, rc);
 	else if (argc >= 4 && is(1, "mask") && is(2, "by") && is(3, "quality")) rc = mask_by_quality(argc, argv);
 	else if (argc >= 3 && is(1, "add") && is(2, "barcode")) rc = add_barcode(argc, argv);
+	else if (fasta_text_command(argc, argv, false, rc)) {}
 	else if (argc >= 2 && is(1, "demultiplex")) rc = demultiplex(argc, argv);
 	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);

@@ -112,6 +112,26 @@ size_t trim_start_off(const std::string &s)
 	return off;
 }
 
+// regex " UMI:[^\s]*" (src/fasta_simplify_read_ids.rs:26), leftmost; \s is Unicode White_Space
+bool find_umi_field(const std::string &h, size_t &start, size_t &end)
+{
+	const size_t at = h.find(" UMI:");
+	if (at == std::string::npos) return false;
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(h.data());
+	size_t e = at + 5;
+	const size_t n = h.size();
+	while (e < n) {
+		const uint8_t b = p[e];
+		size_t l = b < 0x80 ? 1 : (b >> 5) == 0x6 ? 2 : (b >> 4) == 0xE ? 3 : 4;
+		if (l > n - e) l = n - e;
+		if (rust_ws(decode(p + e, l))) break;
+		e += l;
+	}
+	start = at;
+	end = e;
+	return true;
+}
+
 bool is_ascii(const std::string &s)
 {
 	for (unsigned char c : s)

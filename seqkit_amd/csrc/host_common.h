@@ -34,6 +34,7 @@ bool is_ascii(const std::string &s);
 // regex " BC:[ACGTNacgtn+]+", leftmost-first (src/fasta_demultiplex.rs:38); allow_plus = false is the
 // " BC:[ACGTNacgtn]+" of src/fasta_statistics.rs:16
 bool find_bc_field(const std::string &h, size_t &start, size_t &end, bool allow_plus = true);
+bool find_umi_field(const std::string &h, size_t &start, size_t &end);  // regex " UMI:[^\s]*", leftmost
 bool parse_uint(const char *s, uint64_t max, uint64_t &out);            // str::parse::<uN>(): [+]digits, no overflow
 std::string fmt_pct(double v);                           // "{:.1}" incl. NaN / inf spellings
 

@@ -556,3 +556,4 @@ def test_sam_to_reads_errors_and_quirks(bins, tmp_path):
     for args in (["to", "fastq", str(bam)], ["to", "interleaved", "fastq"], ["to", "interleaved", "fastq", str(bam), "extra"], ["to", "fastq", "missing.bam", "o"],
                  ["to", "bed", str(bam), "o"], ["to"], ["to", "fastq", "--x", str(bam), "o"]):
         both(bins, "sam", args, tmp_path)
+

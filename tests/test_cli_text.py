@@ -1,0 +1,130 @@
+"""CPU: the per-read TEXT commands of the `fasta` host against the oracle CLI — same stdout, stderr
+and exit code.  They are line filters with no device work, so they run without a GPU."""
+import numpy as np
+import pytest
+
+from seqkit_amd import synth
+from tests import cli_util as cu
+
+
+@pytest.fixture(scope="module")
+def bins(hip_lib, oracle):
+    from seqkit_amd import build
+    build.build_hosts()
+    return {"fasta": (cu.FASTA, oracle.FASTA_BIN)}
+
+
+def both(bins, tool, args, tmp_path, stdin=None, same_stderr=True):
+    a = cu.run(bins[tool][0], args, cwd=tmp_path, stdin=stdin)
+    b = cu.run(bins[tool][1], args, cwd=tmp_path, stdin=stdin)
+    assert a[0] == b[0], (a[0], b[0], a[2][-500:], b[2][-500:])
+    assert a[1] == b[1]
+    if same_stderr:
+        assert a[2] == b[2]
+    return a, b
+
+
+def mixed_text(n, seed, fasta_every=0, umi=True):
+    """FASTQ (and, every `fasta_every`-th record, FASTA) records with Illumina-style headers, some with UMI: tags."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(0, 60))
+        seq = synth.BASES[rng.integers(0, 4, size=ln)].tobytes()
+        qual = bytes(rng.integers(33, 74, size=ln, dtype=np.uint8))
+        h = b"M01:23:FC:1:%d:%d:%d" % (i % 7, i, int(rng.integers(0, 99999)))
+        if umi and i % 3 == 0:
+            h += b" UMI:" + synth.BASES[rng.integers(0, 4, size=8)].tobytes() + b" tail"
+        h += b" 1:N:0:" + synth.BASES[rng.integers(0, 4, size=8)].tobytes()
+        if fasta_every and i % fasta_every == 0:
+            out.append(b">" + h + b"\n" + seq + b"\n")
+        else:
+            out.append(b"@" + h + b"\n" + seq + b"\n+" + (h if i % 5 == 0 else b"") + b"\n" + qual + b"\n")
+    return b"".join(out)
+
+
+def test_fasta_trim_fixed_cli(bins, tmp_path):
+    fq = tmp_path / "t.fq"
+    fq.write_bytes(mixed_text(2000, seed=1, fasta_every=4))
+    for args in ([], ["--first=3"], ["--last", "5"], ["--first=10", "--last=10"], ["--first=100"], ["--fi=1", "--la=1"], ["--first=+2"]):
+        both(bins, "fasta", ["trim"] + args + [str(fq)], tmp_path)
+    both(bins, "fasta", ["trim", "--first=3", "-"], tmp_path, stdin=fq.read_bytes())
+    # quirks: CRLF (trim_end drops the \r for the length only), quality shorter than the bases (slice panic after the
+    # header and bases are out), multi-byte characters cut in the middle, record cut off by end of file
+    fq.write_bytes(b"@a\nACGTACGT\r\n+\nIIIIIIII\r\n")
+    both(bins, "fasta", ["trim", "--first=1", "--last=1", str(fq)], tmp_path)
+    fq.write_bytes(b"@a\nACGTACGT\n+\nIII\n@b\nAC\n+\nII\n")
+    a, *_ = both(bins, "fasta", ["trim", "--first=1", str(fq)], tmp_path, same_stderr=False)
+    assert a[0] == 101 and a[1] == b"@a\nCGTACGT\n"
+    fq.write_bytes("@a\nA\u00e9GT\n+\nIIII\n".encode())
+    a, *_ = both(bins, "fasta", ["trim", "--first=2", str(fq)], tmp_path, same_stderr=False)
+    assert a[0] == 101 and a[1] == b""
+    fq.write_bytes(b"@a\nACGT")
+    both(bins, "fasta", ["trim", "--last=1", str(fq)], tmp_path)
+    fq.write_bytes(b"@a\nACGT\n+\nIIII\nbad\n")
+    both(bins, "fasta", ["trim", str(fq)], tmp_path)
+    for args in (["trim"], ["trim", "--first=x", str(fq)], ["trim", "--last=-1", str(fq)], ["trim", "--first=1", "missing.fq"], ["trim", "--first=x", "missing.fq"],
+                 ["trim", str(fq), "extra"], ["trim", "--first=18446744073709551616", str(fq)]):
+        both(bins, "fasta", args, tmp_path)
+    fq.write_bytes(b"@a\nACGT\n+\nIIII\n")
+    both(bins, "fasta", ["trim", "--first=18446744073709551615", "--last=3", str(fq)], tmp_path, same_stderr=False)   # usize addition wraps
+
+
+def test_fasta_extract_dual_umi_cli(bins, tmp_path):
+    a = mixed_text(1000, seed=2, umi=False)
+    recs = a.split(b"\n@M01")
+    inter = tmp_path / "i.fq"
+    inter.write_bytes(a)                                                     # consecutive records play the two mates
+    for args in ([], ["--first-bases=0"], ["--first-bases", "3"], ["--first=5"]):
+        both(bins, "fasta", ["extract", "dual", "umi"] + args + [str(inter)], tmp_path, same_stderr=False)
+    inter.write_bytes(b">a x \nACGTAC\n>a y\nTTGCAA\n>b\nAC\n>b\nGT\n")
+    x, *_ = both(bins, "fasta", ["extract", "dual", "umi", "--first-bases=2", str(inter)], tmp_path)
+    assert x[1] == b">a x RX:AC+TT\nGTAC\n>a y RX:AC+TT\nGCAA\n>b RX:AC+GT\n\n>b RX:AC+GT\n\n"
+    inter.write_bytes(b"@a\nACGTAC\n+\nIIIIII\n@a\nTTGCAA\n+\nJJJJJJ\n")
+    x, *_ = both(bins, "fasta", ["extract", "dual", "umi", "--first-bases=4", str(inter)], tmp_path)
+    assert x[1] == b"@a RX:ACGT+TTGC\nAC\n+\nII\n@a RX:ACGT+TTGC\nAA\n+\nJJ\n"
+    x, *_ = both(bins, "fasta", ["extract", "dual", "umi", "--first-bases=8", str(inter)], tmp_path, same_stderr=False)
+    assert x[0] == 101 and x[1] == b""                                       # seq_1[0..8] is out of range
+    inter.write_bytes(b"@a\nACGTAC\n+\nIIIIII\n>a\nTTGCAA\n")
+    both(bins, "fasta", ["extract", "dual", "umi", str(inter)], tmp_path)     # Invalid FASTQ record
+    inter.write_bytes(b">a\nACGTAC\n")
+    both(bins, "fasta", ["extract", "dual", "umi", str(inter)], tmp_path)     # mate missing
+    inter.write_bytes(b"a\nACGTAC\n")
+    both(bins, "fasta", ["extract", "dual", "umi", str(inter)], tmp_path)
+    for args in (["extract", "dual", "umi"], ["extract", "dual", "umi", "--first-bases=z", str(inter)], ["extract", "dual", "umi", "nofile"]):
+        both(bins, "fasta", args, tmp_path)
+
+
+def test_fasta_convert_basespace_simplify_interleave_cli(bins, tmp_path):
+    fq = tmp_path / "b.fq"
+    fq.write_bytes(mixed_text(1500, seed=3, fasta_every=6))
+    both(bins, "fasta", ["convert", "basespace", str(fq)], tmp_path)
+    both(bins, "fasta", ["simplify", "read", "ids", str(fq)], tmp_path)
+    both(bins, "fasta", ["simplify", "read", "ids", "--discard-umi", str(fq)], tmp_path)
+    both(bins, "fasta", ["simplify", "read", "ids", "--alphanumeric", "--disc", str(fq)], tmp_path)
+    fq2 = tmp_path / "b2.fq"
+    fq2.write_bytes(mixed_text(1500, seed=3, fasta_every=6).replace(b" 1:N:0:", b" 2:N:0:"))
+    a, *_ = both(bins, "fasta", ["interleave", str(fq), str(fq2)], tmp_path)
+    assert a[1].count(b"\n") == 2 * fq.read_bytes().count(b"\n")
+    # quirks
+    fq.write_bytes(b"@nocolon\nAC\n+\nII\n@x:y: \nAC\n+\nII\n>fa:TTTT  \nACGT\nbad:AAAA\nAC\n")
+    a, *_ = both(bins, "fasta", ["convert", "basespace", str(fq)], tmp_path)
+    assert a[0] == 255 and a[1] == b"@1 BC:@nocolon\nAC\n+\nII\n@2\nAC\n+\nII\n@3 BC:TTTT\nACGT\n@4 BC:AAAA\n"
+    fq.write_bytes("@r UMI:AC\u00a0GT x\nAC\n+x\nII\n>r2 UMI:\nAC\n@r3 UMI:\u00e9\u00e9 UMI:zz\nAC\n+\nII\n".encode())
+    a, *_ = both(bins, "fasta", ["simplify", "read", "ids", str(fq)], tmp_path)
+    assert a[1] == "@1 UMI:AC\nAC\n+\nII\n>2 UMI:\nAC\n@3 UMI:\u00e9\u00e9\nAC\n+\nII\n".encode()
+    fq.write_bytes(b"@r\nAC\n+\nII\n\n")
+    both(bins, "fasta", ["simplify", "read", "ids", str(fq)], tmp_path)       # a blank line is not a header
+    fq.write_bytes(b"@r\nAC")
+    both(bins, "fasta", ["simplify", "read", "ids", str(fq)], tmp_path)
+    fq.write_bytes(b"@a\nAC\n+\nII\n>b\nGG\n")
+    fq2.write_bytes(b"@a\nTT\n+\nJJ\n@b\nGG\n+\nII\n")
+    a, *_ = both(bins, "fasta", ["interleave", str(fq), str(fq2)], tmp_path)
+    assert a[0] == 255 and a[1] == b"@a\nAC\n+\nII\n@a\nTT\n+\nJJ\n>b\nGG\n"
+    fq2.write_bytes(b"@a\nTT\n+\nJJ\n")
+    both(bins, "fasta", ["interleave", str(fq), str(fq2)], tmp_path)          # second file runs out
+    fq.write_bytes(b"x\n")
+    both(bins, "fasta", ["interleave", str(fq), str(fq2)], tmp_path)
+    for args in (["interleave", str(fq)], ["interleave", str(fq), "missing.fq"], ["convert", "basespace"], ["convert", "basespace", "missing.fq"],
+                 ["simplify", "read", "ids"], ["simplify", "read", "ids", "--nope", str(fq)], ["simplify", "read"]):
+        both(bins, "fasta", args, tmp_path)
