@@ -628,14 +628,220 @@ static int interleave(int argc, char **argv)
 	return 0;
 }
 
-/* src/fasta_main.rs:42-82 (only the hot-path arms are restated) */
+static const char *USAGE_CHECK =
+"\nUsage:\n  fasta check <fasta/fastq>\n\nDescription:\n"
+"Checks that the input FASTA or FASTQ file is correctly formatted, and reports\n"
+"the line number if any malformatted lines are found.\n";
+
+/* ReaderWithMemory, src/fasta_check.rs:14-45: the last 10 lines and a line counter */
+typedef struct { oc_reader file; uint64_t lines_read; oc_str prev[10]; int nprev; } mem_reader;
+
+static int mem_read_line(mem_reader *r, oc_str *line)
+{
+	if (!oc_read_line(&r->file, line)) return 0;
+	if (r->nprev == 10) {
+		oc_str first = r->prev[0];
+		memmove(&r->prev[0], &r->prev[1], 9 * sizeof(oc_str));
+		r->prev[9] = first;
+		r->nprev = 9;
+	}
+	oc_assign(&r->prev[r->nprev++], line->p, line->n);
+	r->lines_read += 1;
+	return 1;
+}
+static const char *mem_history(mem_reader *r)
+{
+	static oc_str h;
+	oc_clear(&h);
+	oc_append(&h, "", 0);
+	for (int i = 0; i < r->nprev; i++) { oc_append(&h, r->prev[i].p, r->prev[i].n); oc_append(&h, "\n", 1); }
+	return (const char *)h.p;
+}
+
+/* src/fasta_check.rs:48-70 */
+static int check(int argc, char **argv)
+{
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 2, NULL, 0, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_CHECK);
+	static mem_reader fasta;
+	fasta.file = oc_reader_open(pos[0]);
+	oc_str line = {0};
+	while (mem_read_line(&fasta, &line)) {
+		if (oc_starts_with(&line, '>')) {
+			mem_read_line(&fasta, &line);
+		} else if (oc_starts_with(&line, '@')) {
+			mem_read_line(&fasta, &line);
+			mem_read_line(&fasta, &line);
+			if (!oc_starts_with(&line, '+'))
+				oc_error("Missing quality header prefix '+' on line %llu:\n%s\n", (unsigned long long)fasta.lines_read, mem_history(&fasta));
+			mem_read_line(&fasta, &line);
+		} else {
+			oc_error("Missing header prefix '>' or '@' on line %llu:\n%s\n", (unsigned long long)fasta.lines_read, mem_history(&fasta));
+		}
+	}
+	return 0;
+}
+
+static const char *USAGE_TO_RAW = "\nUsage:\n  fasta to raw <fasta_file>\n";
+
+/* src/fasta_to_raw.rs:9-29 */
+static int to_raw(int argc, char **argv)
+{
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 3, NULL, 0, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_TO_RAW);
+	oc_reader f = oc_reader_open(pos[0]);
+	oc_str line = {0};
+	while (oc_read_line(&f, &line)) {
+		if (oc_starts_with(&line, '>')) {
+			oc_read_line(&f, &line); put_str(&line);
+		} else if (oc_starts_with(&line, '@')) {
+			oc_read_line(&f, &line); put_str(&line);
+			oc_read_line(&f, &line);
+			oc_read_line(&f, &line);
+		} else oc_error("Invalid FASTA/FASTQ format encountered.");
+	}
+	return 0;
+}
+
+static const char *USAGE_ADD_BASEQ =
+"\nUsage:\n  fasta add base qualities <fasta> <baseq>\n\n"
+"Converts a FASTA file into a FASTQ file based on user-specified dummy base\nquality values.\n";
+
+/* src/fasta_add_base_qualities.rs:12-31 */
+static int add_base_qualities(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 4, NULL, 0, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_ADD_BASEQ);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :14 */
+	uint64_t baseq;
+	if (!oc_parse_uint(pos[1], 255, &baseq)) oc_error("Base quality must be between 0 - 255.");   /* :15-16 */
+	oc_str line = {0};
+	while (oc_read_line(&f, &line)) {
+		if (oc_starts_with(&line, '>')) {
+			fputc('@', stdout); fwrite(line.p + 1, 1, line.n - 1, stdout);      /* :21 */
+			oc_read_line(&f, &line);                                           /* :22 */
+			size_t seq_len = line.n - 1;                                       /* :23 wraps when the line is empty */
+			put_str(&line);                                                    /* :24 */
+			if (seq_len == (size_t)-1) oc_panic("capacity overflow");          /* :25 vec!(..; usize::MAX) */
+			uint8_t q = (uint8_t)(33 + baseq);                                 /* u8 addition wraps (release build) */
+			if (q >= 0x80 && seq_len > 0) oc_panic("called `Result::unwrap()` on an `Err` value: Utf8Error");
+			fputs("+\n", stdout);
+			for (size_t k = 0; k < seq_len; k++) fputc(q, stdout);
+			fputc('\n', stdout);
+		} else oc_error("Invalid FASTA format encountered.");                  /* :27-29 */
+	}
+	return 0;
+}
+
+static const char *USAGE_REMOVE_BASEQ = "\nUsage:\n  fasta remove base qualities <fastq_file>\n";
+
+/* src/fasta_remove_base_qualities.rs:9-27 */
+static int remove_base_qualities(int argc, char **argv)
+{
+	const char *pos[1]; int npos;
+	if (!oc_parse(argc, argv, 4, NULL, 0, pos, &npos, 1) || npos != 1) oc_error("Invalid arguments.\n%s", USAGE_REMOVE_BASEQ);
+	oc_reader f = oc_reader_open(pos[0]);
+	oc_str line = {0};
+	while (oc_read_line(&f, &line)) {
+		if (oc_starts_with(&line, '@')) {
+			fputc('>', stdout); fwrite(line.p + 1, 1, line.n - 1, stdout);      /* :16 */
+			oc_read_line(&f, &line); put_str(&line);                           /* :17-18 */
+			oc_read_line(&f, &line);                                           /* :20-21 */
+			oc_read_line(&f, &line);
+		} else oc_error("Invalid FASTQ format encountered.");                  /* :23-25 */
+	}
+	return 0;
+}
+
+static const char *USAGE_DEINTERLEAVE = "\nUsage:\n  fasta deinterleave <interleaved_fastq> <out_prefix>\n";
+
+/* src/fasta_deinterleave.rs:9-39 */
+static int deinterleave(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 2, NULL, 0, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_DEINTERLEAVE);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :11 */
+	char path[4096];
+	snprintf(path, sizeof path, "%s_1.fq.gz", pos[1]);
+	FILE *out_1 = oc_gzip_writer(path, 0);                                     /* :13-14 */
+	snprintf(path, sizeof path, "%s_2.fq.gz", pos[1]);
+	FILE *out_2 = oc_gzip_writer(path, 0);                                     /* :15-16 */
+	oc_str line = {0};
+	while (oc_read_line(&f, &line)) {                                          /* :19 */
+		int lines = 0;
+		if (oc_starts_with(&line, '@')) lines = 4;                             /* :20-22 */
+		else if (oc_starts_with(&line, '>')) lines = 2;
+		else oc_error("Line is not FASTA/FASTQ format: %s", (const char *)line.p);
+		fwrite(line.p, 1, line.n, out_1);                                      /* :23 */
+		for (int k = 0; k < lines - 1; k++) { oc_read_line(&f, &line); fwrite(line.p, 1, line.n, out_1); }   /* :24-26 */
+		oc_read_line(&f, &line);                                               /* :28 */
+		if ((lines == 4 && !oc_starts_with(&line, '@')) || (lines == 2 && !oc_starts_with(&line, '>')))
+			oc_error("Interleaved FASTA records are not in consistent format.");       /* :29-32 */
+		fwrite(line.p, 1, line.n, out_2);                                      /* :33 */
+		for (int k = 0; k < lines - 1; k++) { oc_read_line(&f, &line); fwrite(line.p, 1, line.n, out_2); }   /* :34-36 */
+	}
+	return 0;
+}
+
+static const char *USAGE_ANCHORS = "\nUsage:\n  fasta split into anchors <fastq> <anchor_len>\n";
+
+/* src/fasta_split_into_anchors.rs:10-45 */
+static int split_into_anchors(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 4, NULL, 0, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_ANCHORS);
+	oc_reader f = oc_reader_open(pos[0]);                                      /* :12 */
+	uint64_t anchor_len;
+	if (!oc_parse_uint(pos[1], UINT64_MAX, &anchor_len)) oc_error("<anchor_len> must be a positive integer.");   /* :13-14 */
+	uint64_t reads = 0;
+	oc_str header = {0}, seq = {0}, qual = {0}, line = {0};
+	while (oc_read_line(&f, &header)) {                                        /* :22 */
+		reads += 1;
+		oc_read_line(&f, &seq);                                                /* :25 */
+		uint64_t seq_len = orc_trim_end_len(seq.p, seq.n);                     /* :26 */
+		if (seq_len < anchor_len * 2) continue;                                /* :27 — the '+' and quality lines of a FASTQ record stay unread */
+		if (oc_starts_with(&header, '@')) {                                    /* :29-36 */
+			oc_read_line(&f, &line);
+			oc_read_line(&f, &qual);
+			check_slice(&seq, 0, anchor_len); check_slice(&qual, 0, anchor_len);
+			printf("@%llu\n", (unsigned long long)reads);
+			fwrite(seq.p, 1, anchor_len, stdout); fputs("\n+\n", stdout); fwrite(qual.p, 1, anchor_len, stdout); fputc('\n', stdout);
+			check_slice(&seq, seq_len - anchor_len, seq_len); check_slice(&qual, seq_len - anchor_len, seq_len);
+			printf("@%llu\n", (unsigned long long)reads);
+			fwrite(seq.p + seq_len - anchor_len, 1, anchor_len, stdout); fputs("\n+\n", stdout);
+			fwrite(qual.p + seq_len - anchor_len, 1, anchor_len, stdout); fputc('\n', stdout);
+		} else if (oc_starts_with(&header, '>')) {                             /* :37-39 */
+			check_slice(&seq, 0, anchor_len);
+			printf(">%llu\n", (unsigned long long)reads);
+			fwrite(seq.p, 1, anchor_len, stdout); fputc('\n', stdout);
+			check_slice(&seq, seq_len - anchor_len, seq_len);
+			printf(">%llu\n", (unsigned long long)reads);
+			fwrite(seq.p + seq_len - anchor_len, 1, anchor_len, stdout); fputc('\n', stdout);
+		} else oc_error("Header is not valid FASTA/FASTQ:\n%s", (const char *)header.p);   /* :40-42 */
+	}
+	return 0;
+}
+
+/* src/fasta_main.rs:42-82 (every arm but `fasta gc content`, which needs rust-bio's FASTA reader) */
 int main(int argc, char **argv)
 {
 	int rc;
-	if (argc >= 4 && !strcmp(argv[1], "simplify") && !strcmp(argv[2], "read") && !strcmp(argv[3], "ids"))
+	if (argc >= 2 && !strcmp(argv[1], "check"))
+		rc = check(argc, argv);
+	else if (argc >= 3 && !strcmp(argv[1], "to") && !strcmp(argv[2], "raw"))
+		rc = to_raw(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "add") && !strcmp(argv[2], "base") && !strcmp(argv[3], "qualities"))
+		rc = add_base_qualities(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "remove") && !strcmp(argv[2], "base") && !strcmp(argv[3], "qualities"))
+		rc = remove_base_qualities(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "simplify") && !strcmp(argv[2], "read") && !strcmp(argv[3], "ids"))
 		rc = simplify_read_ids(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "interleave"))
 		rc = interleave(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "deinterleave"))
+		rc = deinterleave(argc, argv);
+	else if (argc >= 4 && !strcmp(argv[1], "split") && !strcmp(argv[2], "into") && !strcmp(argv[3], "anchors"))
+		rc = split_into_anchors(argc, argv);
 	else if (argc >= 4 && !strcmp(argv[1], "trim") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
 		rc = trim_by_quality(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "trim"))

@@ -232,6 +232,204 @@ int interleave(int argc, char **argv)
 	return 0;
 }
 
+// ---- fasta check <fasta/fastq>                                                    src/fasta_check.rs:14-70 ----
+const char *USAGE_CHECK =
+	"\nUsage:\n  fasta check <fasta/fastq>\n\nDescription:\n"
+	"Checks that the input FASTA or FASTQ file is correctly formatted, and reports\n"
+	"the line number if any malformatted lines are found.\n";
+
+struct ReaderWithMemory {                                  // :14-45
+	host::LineReader file;
+	uint64_t lines_read = 0;
+	std::vector<std::string> prev_lines;                   // the last 10 lines
+	explicit ReaderWithMemory(const std::string &path) : file(path) {}
+	bool next(std::string &line)
+	{
+		if (!read_line(file, line)) return false;
+		prev_lines.push_back(line);
+		if (prev_lines.size() > 10) prev_lines.erase(prev_lines.begin());
+		lines_read += 1;
+		return true;
+	}
+	std::string history() const
+	{
+		std::string h;
+		for (const std::string &l : prev_lines) { h += l; h += "\n"; }
+		return h;
+	}
+};
+
+int check(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_CHECK);
+	ReaderWithMemory fasta(pos[0]);                                                         // :50
+	std::string line;
+	while (fasta.next(line)) {                                                              // :53
+		if (starts_with(line, '>')) {
+			fasta.next(line);
+		} else if (starts_with(line, '@')) {
+			fasta.next(line);
+			fasta.next(line);
+			if (!starts_with(line, '+'))                                                    // :59-62
+				error("Missing quality header prefix '+' on line %llu:\n%s\n", (unsigned long long)fasta.lines_read, fasta.history().c_str());
+			fasta.next(line);
+		} else {                                                                            // :64-67
+			error("Missing header prefix '>' or '@' on line %llu:\n%s\n", (unsigned long long)fasta.lines_read, fasta.history().c_str());
+		}
+	}
+	return 0;
+}
+
+// ---- fasta to raw <fasta_file>                                                   src/fasta_to_raw.rs:9-29 ----
+const char *USAGE_TO_RAW = "\nUsage:\n  fasta to raw <fasta_file>\n";
+
+int to_raw(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 3, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_TO_RAW);
+	host::LineReader fasta_file(pos[0]);
+	std::string line;
+	while (read_line(fasta_file, line)) {
+		if (starts_with(line, '>')) {                                                       // :15-17
+			read_line(fasta_file, line); put(line);
+		} else if (starts_with(line, '@')) {                                                // :18-23
+			read_line(fasta_file, line); put(line);
+			read_line(fasta_file, line);
+			read_line(fasta_file, line);
+		} else {
+			error("Invalid FASTA/FASTQ format encountered.");                               // :25
+		}
+	}
+	return 0;
+}
+
+// ---- fasta add base qualities <fasta> <baseq>                        src/fasta_add_base_qualities.rs:12-31 ----
+const char *USAGE_ADD_BASEQ =
+	"\nUsage:\n  fasta add base qualities <fasta> <baseq>\n\n"
+	"Converts a FASTA file into a FASTQ file based on user-specified dummy base\nquality values.\n";
+
+int add_base_qualities(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_ADD_BASEQ);
+	host::LineReader fasta_file(pos[0]);                                                    // :14
+	uint64_t baseq;
+	if (!host::parse_uint(pos[1].c_str(), 255, baseq)) error("Base quality must be between 0 - 255.");       // :15-16
+	const uint8_t q = (uint8_t)(33 + baseq);                                                // :26 u8 addition wraps in a release build
+	std::string line;
+	while (read_line(fasta_file, line)) {
+		if (!starts_with(line, '>')) error("Invalid FASTA format encountered.");            // :27-29
+		put("@"); put(line.data() + 1, line.size() - 1);                                    // :21
+		read_line(fasta_file, line);                                                        // :22
+		put(line);                                                                          // :24
+		if (line.empty()) panic("capacity overflow");                                       // :23 line.len() - 1 wraps to usize::MAX
+		const size_t seq_len = line.size() - 1;
+		if (q >= 0x80 && seq_len > 0) panic("called `Result::unwrap()` on an `Err` value: Utf8Error");       // :25 from_utf8(..).unwrap()
+		put("+\n"); put(std::string(seq_len, (char)q)); put("\n");
+	}
+	return 0;
+}
+
+// ---- fasta remove base qualities <fastq_file>                     src/fasta_remove_base_qualities.rs:9-27 ----
+const char *USAGE_REMOVE_BASEQ = "\nUsage:\n  fasta remove base qualities <fastq_file>\n";
+
+int remove_base_qualities(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 4, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_REMOVE_BASEQ);
+	host::LineReader fastq_file(pos[0]);
+	std::string line;
+	while (read_line(fastq_file, line)) {
+		if (!starts_with(line, '@')) error("Invalid FASTQ format encountered.");            // :23-25
+		put(">"); put(line.data() + 1, line.size() - 1);                                    // :16
+		read_line(fastq_file, line); put(line);                                             // :17-18
+		read_line(fastq_file, line);                                                        // :20-21
+		read_line(fastq_file, line);
+	}
+	return 0;
+}
+
+// ---- fasta deinterleave <interleaved_fastq> <out_prefix>                      src/fasta_deinterleave.rs:9-39 ----
+const char *USAGE_DEINTERLEAVE = "\nUsage:\n  fasta deinterleave <interleaved_fastq> <out_prefix>\n";
+
+host::GzWriter *g_deint[2] = {nullptr, nullptr};
+void close_deint() { for (auto *w : g_deint) if (w) w->close(); }
+
+int deinterleave(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_DEINTERLEAVE);
+	host::LineReader fastq(pos[0]);                                                         // :11
+	host::GzWriter out_1(pos[1] + "_1.fq.gz"), out_2(pos[1] + "_2.fq.gz");                  // :13-16
+	g_deint[0] = &out_1; g_deint[1] = &out_2;
+	host::at_exit_flush(close_deint);
+	std::string line;
+	while (read_line(fastq, line)) {                                                        // :19
+		int lines;
+		if (starts_with(line, '@')) lines = 4;                                              // :20-22
+		else if (starts_with(line, '>')) lines = 2;
+		else error("Line is not FASTA/FASTQ format: %s", line.c_str());
+		out_1.write(line);                                                                  // :23
+		for (int k = 0; k < lines - 1; k++) { read_line(fastq, line); out_1.write(line); }  // :24-26
+		read_line(fastq, line);                                                             // :28
+		if ((lines == 4 && !starts_with(line, '@')) || (lines == 2 && !starts_with(line, '>')))          // :29-32
+			error("Interleaved FASTA records are not in consistent format.");
+		out_2.write(line);                                                                  // :33
+		for (int k = 0; k < lines - 1; k++) { read_line(fastq, line); out_2.write(line); }  // :34-36
+	}
+	close_deint();
+	g_deint[0] = g_deint[1] = nullptr;
+	return 0;
+}
+
+// ---- fasta split into anchors <fastq> <anchor_len>                       src/fasta_split_into_anchors.rs:10-45 ----
+const char *USAGE_ANCHORS = "\nUsage:\n  fasta split into anchors <fastq> <anchor_len>\n";
+
+int split_into_anchors(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_ANCHORS);
+	host::LineReader fastq(pos[0]);                                                         // :12
+	uint64_t anchor_len;
+	if (!parse_usize(pos[1], anchor_len)) error("<anchor_len> must be a positive integer.");                 // :13-14
+	uint64_t reads = 0;
+	std::string header, seq, qual, line;
+	char buf[48];
+	while (read_line(fastq, header)) {                                                      // :22
+		reads += 1;
+		read_line(fastq, seq);                                                              // :25
+		const uint64_t seq_len = host::trim_end_len(seq);                                   // :26
+		// :27 — a FASTQ record that is too short is skipped WITHOUT reading its '+' and quality lines: the reference
+		// then takes those for the next record's header and bases.  (anchor_len * 2 wraps in a release build.)
+		if (seq_len < anchor_len * 2) continue;
+		if (starts_with(header, '@')) {                                                     // :29-36
+			read_line(fastq, line);
+			read_line(fastq, qual);
+			check_slice(seq, 0, anchor_len); check_slice(qual, 0, anchor_len);
+			snprintf(buf, sizeof buf, "@%llu\n", (unsigned long long)reads);
+			put(buf); put_slice(seq, 0, anchor_len); put("\n+\n"); put_slice(qual, 0, anchor_len); put("\n");
+			check_slice(seq, seq_len - anchor_len, seq_len); check_slice(qual, seq_len - anchor_len, seq_len);
+			put(buf); put_slice(seq, seq_len - anchor_len, seq_len); put("\n+\n"); put_slice(qual, seq_len - anchor_len, seq_len); put("\n");
+		} else if (starts_with(header, '>')) {                                              // :37-39
+			check_slice(seq, 0, anchor_len);
+			snprintf(buf, sizeof buf, ">%llu\n", (unsigned long long)reads);
+			put(buf); put_slice(seq, 0, anchor_len); put("\n");
+			check_slice(seq, seq_len - anchor_len, seq_len);
+			put(buf); put_slice(seq, seq_len - anchor_len, seq_len); put("\n");
+		} else {
+			error("Header is not valid FASTA/FASTQ:\n%s", header.c_str());                  // :40-42
+		}
+	}
+	return 0;
+}
+
 }  // namespace
 
 // dispatch in the order of src/fasta_main.rs:45-81; returns false when argv names none of these commands
@@ -239,8 +437,14 @@ bool fasta_text_command(int argc, char **argv, bool before_trim_by_quality, int 
 {
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
 	if (before_trim_by_quality) {
+		if (argc >= 2 && is(1, "check")) { rc = check(argc, argv); return true; }
+		if (argc >= 3 && is(1, "to") && is(2, "raw")) { rc = to_raw(argc, argv); return true; }
+		if (argc >= 4 && is(1, "add") && is(2, "base") && is(3, "qualities")) { rc = add_base_qualities(argc, argv); return true; }
+		if (argc >= 4 && is(1, "remove") && is(2, "base") && is(3, "qualities")) { rc = remove_base_qualities(argc, argv); return true; }
 		if (argc >= 4 && is(1, "simplify") && is(2, "read") && is(3, "ids")) { rc = simplify_read_ids(argc, argv); return true; }
 		if (argc >= 2 && is(1, "interleave")) { rc = interleave(argc, argv); return true; }
+		if (argc >= 2 && is(1, "deinterleave")) { rc = deinterleave(argc, argv); return true; }
+		if (argc >= 4 && is(1, "split") && is(2, "into") && is(3, "anchors")) { rc = split_into_anchors(argc, argv); return true; }
 		return false;
 	}
 	if (argc >= 2 && is(1, "trim")) { rc = trim(argc, argv); return true; }

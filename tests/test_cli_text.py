@@ -128,3 +128,91 @@ def test_fasta_convert_basespace_simplify_interleave_cli(bins, tmp_path):
     for args in (["interleave", str(fq)], ["interleave", str(fq), "missing.fq"], ["convert", "basespace"], ["convert", "basespace", "missing.fq"],
                  ["simplify", "read", "ids"], ["simplify", "read", "ids", "--nope", str(fq)], ["simplify", "read"]):
         both(bins, "fasta", args, tmp_path)
+
+
+def test_fasta_check_to_raw_and_base_qualities_cli(bins, tmp_path):
+    fq = tmp_path / "c.fq"
+    text = mixed_text(1200, seed=4, fasta_every=5)
+    fq.write_bytes(text)
+    a, _ = both(bins, "fasta", ["check", str(fq)], tmp_path)
+    assert a[0] == 0 and a[1] == b"" and a[2] == b""
+    both(bins, "fasta", ["to", "raw", str(fq)], tmp_path)
+    lines = text.split(b"\n")
+    fq.write_bytes(b"\n".join(lines[:40] + [b"oops"] + lines[40:]))          # a stray line: reported with the 10 lines before it
+    a, _ = both(bins, "fasta", ["check", str(fq)], tmp_path)
+    assert a[0] == 255 and a[2].startswith(b"ERROR: Missing ") and a[2].count(b"\n") >= 20
+    fq.write_bytes(b"@r\nACGT\nIIII\n+\n")
+    a, _ = both(bins, "fasta", ["check", str(fq)], tmp_path)
+    assert a[2] == b"ERROR: Missing quality header prefix '+' on line 3:\n@r\n\nACGT\n\nIIII\n\n\n\n"
+    fq.write_bytes(b"@r\nACGT\n")
+    both(bins, "fasta", ["check", str(fq)], tmp_path)                         # '+' line missing at end of file
+    fq.write_bytes(b"@r\nACGT\n+\nIIII\nx\n")
+    both(bins, "fasta", ["to", "raw", str(fq)], tmp_path)
+    # FASTA -> FASTQ -> FASTA
+    fa = tmp_path / "c.fa"
+    fa.write_bytes(b">s1 d\nACGTACGT\n>s2\n\n>s3\nAC")                     # last line without newline: one quality short
+    a, _ = both(bins, "fasta", ["add", "base", "qualities", str(fa), "30"], tmp_path)
+    assert a[1] == b"@s1 d\nACGTACGT\n+\n????????\n@s2\n\n+\n\n@s3\nAC+\n?\n"
+    both(bins, "fasta", ["add", "base", "qualities", str(fa), "0"], tmp_path)
+    both(bins, "fasta", ["add", "base", "qualities", str(fa), "94"], tmp_path)
+    a, _ = both(bins, "fasta", ["add", "base", "qualities", str(fa), "95"], tmp_path, same_stderr=False)     # 33 + 95 is not ASCII: from_utf8().unwrap()
+    assert a[0] == 101 and a[1] == b"@s1 d\nACGTACGT\n"
+    both(bins, "fasta", ["add", "base", "qualities", str(fa), "250"], tmp_path)                              # wraps to 27
+    for q in ("256", "-1", "x", ""):
+        both(bins, "fasta", ["add", "base", "qualities", str(fa), q], tmp_path)
+    fa.write_bytes(b">s1\n")
+    a, _ = both(bins, "fasta", ["add", "base", "qualities", str(fa), "30"], tmp_path, same_stderr=False)     # no sequence line at all
+    assert a[0] == 101 and a[1] == b"@s1\n"
+    fa.write_bytes(b"@s1\nAC\n")
+    both(bins, "fasta", ["add", "base", "qualities", str(fa), "30"], tmp_path)
+    fq.write_bytes(text)
+    a, _ = both(bins, "fasta", ["remove", "base", "qualities", str(fq)], tmp_path)                           # stops at the first FASTA record
+    assert a[0] == 255 and a[1].startswith(b"")
+    fq.write_bytes(mixed_text(500, seed=5))
+    a, _ = both(bins, "fasta", ["remove", "base", "qualities", str(fq)], tmp_path)
+    assert a[0] == 0 and a[1].count(b"\n") == 1000
+    for args in (["check"], ["check", "a", "b"], ["check", "missing"], ["to", "raw"], ["to", "raw", "missing"], ["add", "base", "qualities", str(fa)],
+                 ["add", "base", "qualities", "missing", "x"], ["remove", "base", "qualities"], ["remove", "base", "qualities", "missing"]):
+        both(bins, "fasta", args, tmp_path)
+
+
+def test_fasta_deinterleave_and_split_into_anchors_cli(bins, tmp_path):
+    import gzip
+    fq = tmp_path / "d.fq"
+    fq.write_bytes(mixed_text(1000, seed=6))
+    outs = {}
+    for k, d in enumerate(("hip", "orc")):
+        (tmp_path / d).mkdir()
+        r = cu.run(bins["fasta"][k], ["deinterleave", str(fq), "out"], cwd=tmp_path / d)
+        assert r[0] == 0 and r[1] == b"" and r[2] == b""
+        outs[d] = cu.gunzip_dir(tmp_path / d)
+    assert outs["hip"] == outs["orc"] and sorted(outs["hip"]) == ["out_1.fq.gz", "out_2.fq.gz"]
+    assert outs["hip"]["out_1.fq.gz"].count(b"\n") == outs["hip"]["out_2.fq.gz"].count(b"\n") == 2000
+    # interleave(deinterleave(x)) == x
+    for k in (1, 2):
+        (tmp_path / f"m{k}.fq").write_bytes(outs["hip"][f"out_{k}.fq.gz"])
+    a, _ = both(bins, "fasta", ["interleave", str(tmp_path / "m1.fq"), str(tmp_path / "m2.fq")], tmp_path)
+    assert a[1] == fq.read_bytes()
+    fq.write_bytes(b"@a\nAC\n+\nII\n>b\nAC\n")
+    for k, d in enumerate(("hip", "orc")):
+        r = cu.run(bins["fasta"][k], ["deinterleave", str(fq), "bad"], cwd=tmp_path / d)
+        assert r[0] == 255 and r[2] == b"ERROR: Interleaved FASTA records are not in consistent format.\n"
+        assert gzip.open(tmp_path / d / "bad_1.fq.gz").read() == b"@a\nAC\n+\nII\n" and gzip.open(tmp_path / d / "bad_2.fq.gz").read() == b""
+    for args in (["deinterleave", str(fq)], ["deinterleave", "missing", "p"]):
+        both(bins, "fasta", args, tmp_path)
+
+    fq.write_bytes(mixed_text(1500, seed=7, fasta_every=4))
+    for n in ("0", "5", "20", "31"):
+        both(bins, "fasta", ["split", "into", "anchors", str(fq), n], tmp_path)
+    fq.write_bytes(b"@a\nACGTACGTAC\n+\nABCDEFGHIJ\n>b\nTTTTGGGGCC\n@short\nACG\n+\nIII\n>c\nAAAACCCC\n")
+    a, _ = both(bins, "fasta", ["split", "into", "anchors", str(fq), "3"], tmp_path)
+    # the skipped short record leaves its '+' and quality lines unread: they are taken for the next header and bases
+    assert a[1].startswith(b"@1\nACG\n+\nABC\n@1\nTAC\n+\nHIJ\n>2\nTTT\n>2\nGCC\n")
+    fq.write_bytes(b"@a\nACGTACGT\n+\nIII\n")
+    a, _ = both(bins, "fasta", ["split", "into", "anchors", str(fq), "4"], tmp_path, same_stderr=False)      # quality shorter than the anchor
+    assert a[0] == 101 and a[1] == b"@1\nACGT\n+\nIII\n\n"         # the first anchor's slice still fits ("III\\n"); the second panics
+    fq.write_bytes(b"xa\nACGTACGT\n")
+    both(bins, "fasta", ["split", "into", "anchors", str(fq), "2"], tmp_path)
+    for args in (["split", "into", "anchors", str(fq)], ["split", "into", "anchors", str(fq), "x"], ["split", "into", "anchors", "missing", "3"],
+                 ["split", "into", "anchors", str(fq), "9223372036854775808"]):
+        both(bins, "fasta", args, tmp_path, same_stderr=False)
