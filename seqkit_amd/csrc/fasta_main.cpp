@@ -770,7 +770,6 @@ static int demultiplex(int argc, char **argv)
 	if (const char *e = getenv("SEQKIT_THREADS")) nthreads = (unsigned)atoi(e);
 	if (nthreads < 1) nthreads = 1;
 	if (nthreads > 16) nthreads = 16;
-	if (dry_run > 0) nthreads = 1;                   // the --dry-run=N stop (:248) depends on the running count
 	size_t block_records = kDemuxBlockRecords;
 	if (const char *e = getenv("SEQKIT_BLOCK_RECORDS")) block_records = (size_t)atoll(e);     // tests use tiny blocks
 
@@ -800,9 +799,9 @@ static int demultiplex(int argc, char **argv)
 	uint64_t submitted = 0;
 	for (;;) {
 		size_t want = block_records;
-		if (dry_run > 0) {
-			if (total_reads >= dry_run) break;                              // :248
-			want = (size_t)std::min<uint64_t>(want, dry_run - total_reads);
+		if (dry_run > 0) {                                                  // :248 — blocks are cut so that exactly N clusters are read
+			if (submitted >= dry_run) break;
+			want = (size_t)std::min<uint64_t>(want, dry_run - submitted);
 		}
 		auto data = std::make_shared<std::vector<std::string>>(4);
 		if (!files[0]->next(want, (*data)[0])) break;                       // :117 — the loop is driven by fastq_1

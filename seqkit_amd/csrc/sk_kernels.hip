@@ -1301,15 +1301,16 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 // ---------------------------------------------------------------------------------------------------
 constexpr u32 kN4 = 0x4E4E4E4Eu;      // "NNNN"
 
-// four 4-bit codes, one per byte -> ASCII: codes 1,2,4,8 -> the four bytes of tbl, anything else 'N'
-__device__ __forceinline__ u32 bases_from_codes(u32 nib, u32 tbl)
+// four 4-bit codes, one per byte -> ASCII: codes 1,2,4,8 -> A C G T (or their complements T G C A), anything else 'N'
+__device__ __forceinline__ u32 bases_from_codes(u32 nib, bool complement)
 {
-	const u32 c1 = tbl & 0xFFu, c2 = (tbl >> 8) & 0xFFu, c4 = (tbl >> 16) & 0xFFu, c8 = tbl >> 24;
-	const u32 lo = 0x4E00004Eu | (c1 << 8) | (c2 << 16);         // codes 0..3: N c1 c2 N
-	const u32 hi = 0x4E4E4E00u | c4;                               // codes 4..7: c4 N N N
+	// 8-entry byte tables indexed by the low 3 bits of the code; codes 8..15 use the second pair
+	const u32 lo = complement ? 0x4E47544Eu : 0x4E43414Eu;        // codes 0..3: N c1 c2 N    (c1 c2 = "AC" / "TG")
+	const u32 hi = complement ? 0x4E4E4E43u : 0x4E4E4E47u;        // codes 4..7: c4 N N N     (c4 = 'G' / 'C')
+	const u32 lo8 = complement ? 0x4E4E4E41u : 0x4E4E4E54u;       // codes 8..11: c8 N N N    (c8 = 'T' / 'A')
 	const u32 sel = nib & 0x07070707u;
-	const u32 r_low = __builtin_amdgcn_perm(hi, lo, sel);          // right for codes 0..7
-	const u32 r_high = __builtin_amdgcn_perm(kN4, 0x4E4E4E00u | c8, sel);   // right for codes 8..15: c8 N N N N N N N
+	const u32 r_low = __builtin_amdgcn_perm(hi, lo, sel);
+	const u32 r_high = __builtin_amdgcn_perm(kN4, lo8, sel);
 	const u32 is_high = ((nib >> 3) & 0x01010101u) * 0xFFu;
 	return (r_high & is_high) | (r_low & ~is_high);
 }
@@ -1322,6 +1323,12 @@ __device__ __forceinline__ u32 bytes_below(u32 q, u32 m4)
 	return (lt >> 7) * 0xFFu;
 }
 
+// Both strands run the same instructions.  Output bytes 4j..4j+3 of a row come from source positions s0..s0+3 with
+// s0 = 4j read forwards (stored order, :47-57) or s0 = len-4-4j read backwards (reverse complement, :36-46).  The four
+// quality bytes and the four base codes starting at s0 are fetched as aligned dwords and funnel-shifted into place,
+// and a byte permute whose selector depends on the strand puts them in output order.  Where s0 < 0 (the last,
+// partial dword of a reverse row) or s0 + 3 >= len, the bytes that fall outside the read land in output positions
+// >= len, which are unspecified; dword indices are clamped to the row so that no load leaves the matrix.
 __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
                                                            int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
                                                            int64_t n, u32 m4, u32 inv_dpr, uint8_t *__restrict__ out)
@@ -1345,39 +1352,26 @@ __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__rest
 			const int j = (int)(e - rl * (u32)dpr);
 			const u32 info = row_info[rl];
 			const int l = (int)(info & 0xFFFFu);
+			const bool rev = (info >> 16) != 0u;
 			const int64_t r = row0 + rl;
 			const u32 *q32 = reinterpret_cast<const u32 *>(qual + r * (int64_t)stride);
 			const u32 *s32 = reinterpret_cast<const u32 *>(seq4 + r * (int64_t)seq4_stride);
-			u32 nib, q, tbl;
-			if (!(info >> 16)) {                                   // :47-57 stored order
-				tbl = 0x54474341u;                                 // 1,2,4,8 -> A C G T
-				q = q32[j];
-				const u32 s16 = (s32[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;       // bytes 2j, 2j+1: bases 4j..4j+3, high nibble first
-				nib = ((s16 >> 4) & 0x0Fu) | ((s16 & 0x0Fu) << 8) | ((s16 << 4) & 0x0F0000u) | ((s16 & 0x0F00u) << 16);
-			} else {                                               // :36-46 reverse complement
-				tbl = 0x41434754u;                                 // 1,2,4,8 -> T G C A
-				const int s0 = l - 4 - 4 * j;                      // output bytes 0..3 come from source positions s0+3 .. s0
-				if (s0 >= 0) {
-					const int qd = s0 >> 2, qd1 = (qd + 1 < dpr) ? qd + 1 : dpr - 1;
-					q = __builtin_bswap32(__builtin_amdgcn_alignbyte(q32[qd1], q32[qd], (u32)s0 & 3u));
-					const int a = s0 >> 1, sd = a >> 2, sd1 = (sd + 1 < sw) ? sd + 1 : sw - 1;
-					const u32 x = __builtin_amdgcn_alignbyte(s32[sd1], s32[sd], (u32)a & 3u);
-					const u32 w = __builtin_bswap32(x) >> 8;       // bytes a, a+1, a+2 as one big-endian number: 6 nibbles in base order
-					const u32 v = w >> (8 - 4 * (s0 & 1));         // low 16 bits: source nibbles s0+3 (bits 0..3) .. s0 (bits 12..15)
-					nib = (v & 0xFu) | ((v & 0xF0u) << 4) | ((v & 0xF00u) << 8) | ((v & 0xF000u) << 12);
-				} else {                                           // the row's last (partial) output dword
-					nib = 0u; q = 0u;
-					const uint8_t *q8 = reinterpret_cast<const uint8_t *>(q32), *s8 = reinterpret_cast<const uint8_t *>(s32);
-					for (int b = 0; b < 4; b++) {
-						const int k = l - 1 - 4 * j - b;
-						if (k >= 0) {
-							q |= (u32)q8[k] << (8 * b);
-							nib |= (((u32)s8[k >> 1] >> (4 * (1 - (k & 1)))) & 15u) << (8 * b);
-						}
-					}
-				}
-			}
-			const u32 bases = bases_from_codes(nib, tbl);
+			const int s0 = rev ? l - 4 - 4 * j : 4 * j;
+			// qualities s0..s0+3, then output order
+			const int qd = s0 >> 2;
+			const int qa = qd < 0 ? 0 : qd, qb = qd + 1 < 0 ? 0 : (qd + 1 < dpr ? qd + 1 : dpr - 1);
+			const u32 xq = __builtin_amdgcn_alignbyte(q32[qb], q32[qa], (u32)s0 & 3u);
+			const u32 q = __builtin_amdgcn_perm(0u, xq, rev ? 0x00010203u : 0x03020100u);
+			// base codes s0..s0+3: bytes a, a+1, a+2 of the packed row as one big-endian number hold nibbles 2a..2a+5
+			const int a = s0 >> 1;
+			const int sd = a >> 2;
+			const int sa = sd < 0 ? 0 : sd, sb = sd + 1 < 0 ? 0 : (sd + 1 < sw ? sd + 1 : sw - 1);
+			const u32 x = __builtin_amdgcn_alignbyte(s32[sb], s32[sa], (u32)a & 3u);
+			const u32 w = __builtin_bswap32(x) >> 8;
+			const u32 v = w >> (8 - 4 * (s0 & 1));                 // low 16 bits: positions s0 (bits 12..15) .. s0+3 (bits 0..3)
+			const u32 back = (v & 0xFu) | ((v & 0xF0u) << 4) | ((v & 0xF00u) << 8) | ((v & 0xF000u) << 12);     // byte b = position s0+3-b
+			const u32 nib = __builtin_amdgcn_perm(0u, back, rev ? 0x03020100u : 0x00010203u);
+			const u32 bases = bases_from_codes(nib, rev);
 			const u32 low = bytes_below(q, m4);
 			reinterpret_cast<u32 *>(out + r * (int64_t)stride)[j] = (kN4 & low) | (bases & ~low);
 		}

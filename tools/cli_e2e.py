@@ -50,7 +50,8 @@ def t(cmd, cwd):
 
 ONLY = os.environ.get("E2E_ONLY", "")
 for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("mask by quality", ["mask", "by", "quality", fq, "20"]),
-                   ("demultiplex (96 samples, gz out)", ["demultiplex", sheet, fq])):
+                   ("demultiplex (96 samples, gz out)", ["demultiplex", sheet, fq]),
+                   ("demultiplex --dry-run (census)", ["demultiplex", f"--dry-run={n}", sheet, fq]), ("statistics (census)", ["statistics", fq])):
     if ONLY and ONLY not in name:
         continue
     for label, binary in (("hip", FASTA),) if os.environ.get("E2E_NO_ORACLE") else (("hip", FASTA), ("oracle", orc.FASTA_BIN)):
@@ -58,3 +59,48 @@ for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("m
         os.makedirs(w, exist_ok=True)
         dt, rc = t([binary] + args, w)
         print(f"{name:34s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
+
+
+# f4: sam to fastq on a BAM of paired 150 bp reads
+if not ONLY or ONLY in "sam to fastq":
+    import struct
+    import zlib
+    SAM = os.path.join(build.BINDIR, "sam")
+    n_bam = 100_000 * min(reps, 10)
+    rng = np.random.default_rng(3)
+    bam = os.path.join(d, "in.bam")
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+
+    def bgzf(data):
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+    with open(bam, "wb") as f:
+        text = b"@HD\tVN:1.6\n"
+        f.write(bgzf(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1 << 28)))
+        buf = bytearray()
+        for i in range(n_bam // 2):
+            for mate in (0, 1):
+                name = b"read%d\0" % i
+                nib = codes[rng.integers(0, 4, size=150)]
+                packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
+                q = rng.integers(2, 41, size=150, dtype=np.uint8).tobytes()
+                flag = 1 | (64 if mate == 0 else 128) | (16 if (i + mate) % 2 else 0)
+                body = struct.pack("<iiBBHHHiiii", 0, i, len(name), 60, 4680, 1, flag, 150, 0, i, 0) + name + struct.pack("<I", 150 << 4) + packed + q
+                buf += struct.pack("<i", len(body)) + body
+                if len(buf) > 60000:
+                    f.write(bgzf(bytes(buf[:60000])))
+                    del buf[:60000]
+        while buf:
+            f.write(bgzf(bytes(buf[:60000])))
+            del buf[:60000]
+        f.write(bgzf(b""))
+    print(f"{n_bam} BAM records, {os.path.getsize(bam) / 1e6:.0f} MB")
+    for label, binary in (("hip", SAM),) if os.environ.get("E2E_NO_ORACLE") else (("hip", SAM), ("oracle", orc.SAM_BIN)):
+        w = os.path.join(d, label + "sam")
+        os.makedirs(w, exist_ok=True)
+        dt, rc = t([binary, "to", "fastq", bam, "out"], w)
+        print(f"{'sam to fastq (gz out)':34s} {label:7s} {dt:7.2f} s  {n_bam / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
+        dt, rc = t([binary, "to", "interleaved", "fastq", bam], w)
+        print(f"{'sam to interleaved fastq':34s} {label:7s} {dt:7.2f} s  {n_bam / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)

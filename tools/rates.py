@@ -73,6 +73,18 @@ kept = torch.zeros((1,), dtype=torch.int64, device=dev)
 timeit("f2 sam fragments filter 200M records (14 B)", lambda: ctx.bam_fragments_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 0, 5000, bits.data_ptr(), kept.data_ptr()), n, 14.125, iters=3, rounds=3)
 del flag, tid, mtid, tlen, bits
 
+# f4: sam to fastq sequence(), 16M records x 152-base rows (0.5 + 1 + 1 B per base, + len and flag)
+n = 16_000_000
+s4 = torch.randint(0, 256, (n, 76), dtype=torch.uint8, device=dev, generator=g)
+q = torch.randint(0, 42, (n, 152), dtype=torch.uint8, device=dev, generator=g)
+ln = torch.full((n,), 150, dtype=torch.int16, device=dev)
+fl = (torch.randint(0, 2, (n,), dtype=torch.int16, device=dev, generator=g) * 16).contiguous()
+o = torch.empty_like(q)
+timeit("f4 sam to fastq sequence() 16M x 150 bases (384 B/record)", lambda: ctx.bam_sequence_dev(s4.data_ptr(), 76, q.data_ptr(), 152, ln.data_ptr(), fl.data_ptr(), n, 10, o.data_ptr()), n, 76 + 152 + 152 + 4)
+fl.zero_()
+timeit("f4 sequence(), forward strand only", lambda: ctx.bam_sequence_dev(s4.data_ptr(), 76, q.data_ptr(), 152, ln.data_ptr(), fl.data_ptr(), n, 10, o.data_ptr()), n, 76 + 152 + 152 + 4)
+del s4, q, ln, fl, o
+
 # PCIe-inclusive: the host entry point on pageable numpy buffers (staging + H2D + kernel + D2H)
 n = 2_000_000
 seq, qual, bcd = bench.gen_shard(torch, dev, n, table, seed=9, chunk=1_000_000)
