@@ -1296,8 +1296,8 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 
 // ---------------------------------------------------------------------------------------------------
 // f4: `sam to fastq` sequence() (src/sam_to_fastq.rs:31-59) — BAM 4-bit bases -> ASCII, reverse-complemented for
-// reverse-strand records, 'N' where the quality is below min_baseq.  One thread per output dword (4 bases); a
-// workgroup walks tiles of 64 rows, whose lengths and flags it keeps in LDS.
+// reverse-strand records, 'N' where the quality is below min_baseq.  One thread per 16 output bytes; a workgroup
+// walks tiles of 64 rows, whose lengths and strands it keeps in LDS.
 // ---------------------------------------------------------------------------------------------------
 constexpr u32 kN4 = 0x4E4E4E4Eu;      // "NNNN"
 
@@ -1315,26 +1315,39 @@ __device__ __forceinline__ u32 bases_from_codes(u32 nib, bool complement)
 	return (r_high & is_high) | (r_low & ~is_high);
 }
 
-// 0xFF in every byte where q < m (unsigned), else 0x00
+// 0xFF in every byte where q < m (unsigned), else 0x00; SMALL_M: m < 128, so a byte with its top bit set is never below
+template <bool SMALL_M>
 __device__ __forceinline__ u32 bytes_below(u32 q, u32 m4)
 {
 	const u32 d = (q | kHi1) - (m4 & ~kHi1);                       // per byte, no borrow: bit 7 = (q & 0x7f) >= (m & 0x7f)
-	const u32 lt = ((~q & m4) | (~(q ^ m4) & ~d)) & kHi1;
+	const u32 lt = SMALL_M ? (~(q | d) & kHi1) : (((~q & m4) | (~(q ^ m4) & ~d)) & kHi1);
 	return (lt >> 7) * 0xFFu;
+}
+
+// 16 bits, four codes with the first in the top nibble -> one code per byte, the FIRST code in byte 3
+__device__ __forceinline__ u32 spread_nibbles(u32 h)
+{
+	u32 x = (h | (h << 8)) & 0x00FF00FFu;
+	return (x | (x << 4)) & 0x0F0F0F0Fu;
 }
 
 // Both strands run the same instructions.  Output bytes 4j..4j+3 of a row come from source positions s0..s0+3 with
 // s0 = 4j read forwards (stored order, :47-57) or s0 = len-4-4j read backwards (reverse complement, :36-46).  The four
-// quality bytes and the four base codes starting at s0 are fetched as aligned dwords and funnel-shifted into place,
-// and a byte permute whose selector depends on the strand puts them in output order.  Where s0 < 0 (the last,
-// partial dword of a reverse row) or s0 + 3 >= len, the bytes that fall outside the read land in output positions
-// >= len, which are unspecified; dword indices are clamped to the row so that no load leaves the matrix.
+// quality bytes and the four base codes starting at s0 are fetched as aligned dwords through per-tile buffer
+// descriptors and funnel-shifted into place, and a byte permute whose selector depends on the strand puts them in
+// output order.  Where s0 < 0 (the last, partial dword of a reverse row) or s0 + 3 >= len, the bytes that fall outside
+// the read land in output positions >= len, which are unspecified; a dword that would start before the row is replaced
+// by the row's first one (the offset register must not go negative: the hardware range check adds the instruction's
+// immediate to it without wrapping), and what lies past the tile reads as 0.
+// (A 16-bytes-per-thread variant was measured and dropped: fewer VALU per byte, but its 16-byte lane pitch quarters
+// the coalescing of the dword loads and stores — 1.98 ms against 1.8 ms for 16 M x 150 bases.)
+template <bool SMALL_M>
 __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
                                                            int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
                                                            int64_t n, u32 m4, u32 inv_dpr, uint8_t *__restrict__ out)
 {
 	__shared__ u32 row_info[64];                                   // len | reverse << 16
-	const int dpr = stride >> 2, sw = seq4_stride >> 2;
+	const int dpr = stride >> 2;
 	const int64_t ntiles = (n + 63) / 64;
 	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
 		const int64_t row0 = t * 64;
@@ -1346,6 +1359,9 @@ __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__rest
 			row_info[threadIdx.x] = l | (((u32)flag[r] >> 4) & 1u) << 16;
 		}
 		__syncthreads();
+		const rsrc_t rq = make_rsrc(qual, row0 * (int64_t)stride, rows * stride);
+		const rsrc_t rs = make_rsrc(seq4, row0 * (int64_t)seq4_stride, rows * seq4_stride);
+		const rsrc_t ro = make_rsrc(out, row0 * (int64_t)stride, rows * stride);
 		const u32 total = (u32)rows * (u32)dpr;
 		for (u32 e = threadIdx.x; e < total; e += blockDim.x) {
 			const u32 rl = inv_dpr ? __umulhi(e, inv_dpr) : e / (u32)dpr;
@@ -1353,27 +1369,24 @@ __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__rest
 			const u32 info = row_info[rl];
 			const int l = (int)(info & 0xFFFFu);
 			const bool rev = (info >> 16) != 0u;
-			const int64_t r = row0 + rl;
-			const u32 *q32 = reinterpret_cast<const u32 *>(qual + r * (int64_t)stride);
-			const u32 *s32 = reinterpret_cast<const u32 *>(seq4 + r * (int64_t)seq4_stride);
-			const int s0 = rev ? l - 4 - 4 * j : 4 * j;
+			int s0 = rev ? l - 4 - 4 * j : 4 * j;
+			if (s0 < -4) s0 = -4;                                  // every byte of this dword is past the read already
 			// qualities s0..s0+3, then output order
-			const int qd = s0 >> 2;
-			const int qa = qd < 0 ? 0 : qd, qb = qd + 1 < 0 ? 0 : (qd + 1 < dpr ? qd + 1 : dpr - 1);
-			const u32 xq = __builtin_amdgcn_alignbyte(q32[qb], q32[qa], (u32)s0 & 3u);
-			const u32 q = __builtin_amdgcn_perm(0u, xq, rev ? 0x00010203u : 0x03020100u);
-			// base codes s0..s0+3: bytes a, a+1, a+2 of the packed row as one big-endian number hold nibbles 2a..2a+5
+			const int qrow = (int)rl * stride, qd = s0 >> 2;
+			const u32 q0 = __builtin_amdgcn_raw_buffer_load_b32(rq, qrow + 4 * (qd < 0 ? 0 : qd), 0, 0);
+			const u32 q1 = __builtin_amdgcn_raw_buffer_load_b32(rq, qrow + 4 * (qd + 1), 0, 0);
+			const u32 q = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(q1, q0, (u32)s0 & 3u), rev ? 0x00010203u : 0x03020100u);
+			// base codes s0..s0+3: bytes a, a+1, a+2 of the packed row as one big-endian number hold codes 2a..2a+5
 			const int a = s0 >> 1;
-			const int sd = a >> 2;
-			const int sa = sd < 0 ? 0 : sd, sb = sd + 1 < 0 ? 0 : (sd + 1 < sw ? sd + 1 : sw - 1);
-			const u32 x = __builtin_amdgcn_alignbyte(s32[sb], s32[sa], (u32)a & 3u);
-			const u32 w = __builtin_bswap32(x) >> 8;
-			const u32 v = w >> (8 - 4 * (s0 & 1));                 // low 16 bits: positions s0 (bits 12..15) .. s0+3 (bits 0..3)
-			const u32 back = (v & 0xFu) | ((v & 0xF0u) << 4) | ((v & 0xF00u) << 8) | ((v & 0xF000u) << 12);     // byte b = position s0+3-b
+			const int srow = (int)rl * seq4_stride, sd = a >> 2;
+			const u32 d0 = __builtin_amdgcn_raw_buffer_load_b32(rs, srow + 4 * (sd < 0 ? 0 : sd), 0, 0);
+			const u32 d1 = __builtin_amdgcn_raw_buffer_load_b32(rs, srow + 4 * (sd + 1), 0, 0);
+			const u32 w = __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, (u32)a & 3u)) >> 8;
+			const u32 back = spread_nibbles((w >> (8 - 4 * (s0 & 1))) & 0xFFFFu);       // byte b = code at position s0+3-b
 			const u32 nib = __builtin_amdgcn_perm(0u, back, rev ? 0x03020100u : 0x00010203u);
 			const u32 bases = bases_from_codes(nib, rev);
-			const u32 low = bytes_below(q, m4);
-			reinterpret_cast<u32 *>(out + r * (int64_t)stride)[j] = (kN4 & low) | (bases & ~low);
+			const u32 low = bytes_below<SMALL_M>(q, m4);
+			__builtin_amdgcn_raw_buffer_store_b32((kN4 & low) | (bases & ~low), ro, (int)rl * stride + 4 * j, 0, 0);
 		}
 	}
 }
@@ -1383,11 +1396,15 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 {
 	if (n <= 0) return hipSuccess;
 	const u32 dpr = (u32)stride >> 2;
-	// r = e / dpr as a multiply-high: exact while e * dpr < 2^32, and e < 64 * dpr
-	const u32 inv = (dpr < 8192u) ? (u32)(((1ull << 32) + dpr - 1) / dpr) : 0u;
+	// rl = e / dpr as a multiply-high: exact while e * dpr < 2^32, and e < 64 * dpr
+	const u32 inv = (dpr > 1 && dpr < 8192u) ? (u32)(((1ull << 32) + dpr - 1) / dpr) : 0u;
 	const int64_t ntiles = (n + 63) / 64;
 	const int grid = (int)(ntiles < (int64_t)n_cu * 8 ? ntiles : (int64_t)n_cu * 8);
-	bam_sequence_kernel<<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, (u32)(min_baseq & 0xFF) * 0x01010101u, dpr == 1 ? 0u : inv, out);
+	const u32 m4 = (u32)(min_baseq & 0xFF) * 0x01010101u;
+	if ((min_baseq & 0xFF) < 128)
+		bam_sequence_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
+	else
+		bam_sequence_kernel<false><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
 	return hipGetLastError();
 }
 
