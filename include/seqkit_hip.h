@@ -162,6 +162,26 @@ int sk_bam_fragments(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, cons
 int sk_bam_fragments_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                          int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept);
 
+/* ---- f2 (second half): `sam count` ---------------------------------------------------------------------------
+ * src/sam_count.rs:44-127.  sk_count_set_regions loads the BED regions grouped by BAM reference: regions of
+ * reference c are entries chr_off[c] .. chr_off[c+1]-1 of rstart/rend (0-based half-open, any order inside a
+ * group; they are sorted by start here, as :63 does) and ridx gives each entry's index in the caller's list of
+ * n_regions regions (n_entries <= n_regions: regions on chromosomes the BAM does not have are simply not entered);
+ * the n_regions counters (u32, like the reference's) are cleared.  sk_count_add runs, for every record, the filter
+ * chain (:46-50, :78-94), the fragment interval in the reference's u32 arithmetic (:75,97-107) and adds 1 to every
+ * region of the record's reference that the interval overlaps (:122-126).  Columns: flag, mapq, refID, next_refID,
+ * pos, next_pos, tlen of the BAM core and, for single_end only, cigar end_pos (NULL otherwise).  What depends on
+ * record order — the "not coordinate sorted" error (:70-72) and chr_names[tid] (:55) — is the caller's.            */
+int sk_count_set_regions(sk_ctx *ctx, int n_chr, const int32_t *chr_off, const uint32_t *rstart, const uint32_t *rend,
+                         const int32_t *ridx /* NULL = 0,1,2,... */, int64_t n_entries, int64_t n_regions);
+int sk_count_add(sk_ctx *ctx, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid,
+                 const int32_t *pos, const int32_t *mpos, const int32_t *tlen, const int32_t *end_pos, int64_t n,
+                 uint8_t min_mapq, uint32_t max_frag_len, int single_end, int center);
+int sk_count_add_dev(sk_ctx *ctx, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid,
+                     const int32_t *pos, const int32_t *mpos, const int32_t *tlen, const int32_t *end_pos, int64_t n,
+                     uint8_t min_mapq, uint32_t max_frag_len, int single_end, int center);
+int sk_count_get(sk_ctx *ctx, uint32_t *region_frags /* n_regions */);
+
 /* ---- f4: `sam to fastq` sequence() ---------------------------------------------------------------------------
  * src/sam_to_fastq.rs:31-59: the bases of BAM records as ASCII — codes 1,2,4,8 -> A,C,G,T, anything else N; records
  * with flag & 0x10 come out reverse-complemented; a base whose quality is below min_baseq (the reference passes 10,

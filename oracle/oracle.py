@@ -56,6 +56,12 @@ def lib() -> C.CDLL:
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
         _lib.orc_fragments_keep.restype = i64
         _lib.orc_fragments_keep.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
+        _lib.orc_count_state_init.restype = None
+        _lib.orc_count_state_init.argtypes = [vp]
+        _lib.orc_count_state_free.restype = None
+        _lib.orc_count_state_free.argtypes = [vp]
+        _lib.orc_count_batch.restype = i32
+        _lib.orc_count_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, C.c_int32, vp, vp, vp, i64, vp, vp]
         _lib.orc_bam_sequence_batch.restype = None
         _lib.orc_bam_sequence_batch.argtypes = [vp, i32, vp, i32, vp, vp, i64, u8, vp]
         _lib.orc_census.restype = i64
@@ -197,3 +203,32 @@ def bam_sequence_batch(seq4: np.ndarray, qual: np.ndarray, length, flag: np.ndar
     out = np.zeros((n, stride), dtype=np.uint8)
     lib().orc_bam_sequence_batch(_p(seq4), seq4.shape[1], _p(qual), stride, _p(ln) if ln is not None else None, _p(flag), n, min_baseq, _p(out))
     return out
+
+
+class _CountParams(C.Structure):
+    _fields_ = [("min_mapq", C.c_uint8), ("max_frag_len", C.c_uint32), ("single_end", C.c_int), ("count_centers", C.c_int)]
+
+
+class _CountState(C.Structure):
+    _fields_ = [("prev_chr", C.c_int32), ("prev_pos", C.c_int64), ("deque", C.c_void_p), ("front", C.c_int64), ("len", C.c_int64), ("cap", C.c_int64)]
+
+
+def count_batch(flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n_chr, rchr, rstart, rend, min_mapq=0, max_frag_len=5000, single_end=False,
+                center=False):
+    """src/sam_count.rs:44-127 over the records in order: (region_frags, code, where); code 1 = not coordinate sorted."""
+    n = len(flag)
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    flag, mapq = a(flag, np.uint16), a(mapq, np.uint8)
+    tid, mtid, pos, mpos, tlen = (a(x, np.int32) for x in (tid, mtid, pos, mpos, tlen))
+    end_pos = None if end_pos is None else a(end_pos, np.int32)
+    rchr, rstart, rend = a(rchr, np.int32), a(rstart, np.uint32), a(rend, np.uint32)
+    frags = np.zeros(max(len(rstart), 1), dtype=np.uint32)
+    p = _CountParams(min_mapq, max_frag_len, int(single_end), int(center))
+    st = _CountState()
+    lib().orc_count_state_init(C.byref(st))
+    where = C.c_int64(-1)
+    code = lib().orc_count_batch(C.byref(st), _p(flag), _p(mapq), _p(tid), _p(mtid), _p(pos), _p(mpos), _p(tlen),
+                                 _p(end_pos) if end_pos is not None else None, n, C.byref(p), n_chr, _p(rchr), _p(rstart), _p(rend),
+                                 len(rstart), _p(frags), C.byref(where))
+    lib().orc_count_state_free(C.byref(st))
+    return frags[:len(rstart)], code, int(where.value)

@@ -135,7 +135,7 @@ static void bam_read_header(bgzf_t *b, const char *path)
 	}
 }
 
-typedef struct { uint16_t flag; int32_t tid, mtid, tlen, pos; } core_t;
+typedef struct { uint16_t flag; int32_t tid, mtid, tlen, pos, mpos; } core_t;
 
 /* 1 = record, 0 = clean end of file; errors exit like src/common.rs:150-154 */
 static int bam_next(bgzf_t *b, core_t *c)
@@ -155,6 +155,7 @@ static int bam_next(bgzf_t *b, core_t *c)
 	c->pos = (int32_t)le32(core + 4);
 	c->flag = le16(core + 14);
 	c->mtid = (int32_t)le32(core + 20);
+	c->mpos = (int32_t)le32(core + 24);
 	c->tlen = (int32_t)le32(core + 28);
 	uint32_t rest = block_size - 32;
 	uint8_t buf[4096];
@@ -265,7 +266,7 @@ static int fragments(int argc, char **argv)
 
 /* ---- f4: sam to raw|fasta|fastq (src/sam_to_fastq.rs:61-149) ------------------------------ */
 /* whole record: the fixed core and everything after it (qname, cigar, seq, qual, aux) */
-typedef struct { core_t c; uint32_t l_read_name, n_cigar, l_seq; oc_str body; } record_t;
+typedef struct { core_t c; uint8_t mapq; uint32_t l_read_name, n_cigar, l_seq; oc_str body; } record_t;
 
 static int bam_next_full(bgzf_t *b, record_t *rec)
 {
@@ -283,10 +284,12 @@ static int bam_next_full(bgzf_t *b, record_t *rec)
 	rec->c.tid = (int32_t)le32(core + 0);
 	rec->c.pos = (int32_t)le32(core + 4);
 	rec->l_read_name = core[8];
+	rec->mapq = core[9];
 	rec->n_cigar = le16(core + 12);
 	rec->c.flag = le16(core + 14);
 	rec->l_seq = le32(core + 16);
 	rec->c.mtid = (int32_t)le32(core + 20);
+	rec->c.mpos = (int32_t)le32(core + 24);
 	rec->c.tlen = (int32_t)le32(core + 28);
 	uint32_t rest = block_size - 32;
 	/* htslib bam_read1: a record whose variable part cannot hold its own fields is invalid */
@@ -453,11 +456,125 @@ static int to_reads(int argc, char **argv)
 	return 0;
 }
 
+/* ---- sam count (src/sam_count.rs:20-130) ----------------------------------------------------- */
+static const char *USAGE_COUNT =
+"\nUsage:\n  sam count [options] <bam_file> <regions.bed>\n\nOptions:\n"
+"  --min-mapq=N      Only count reads with MAPQ \xe2\x89\xa5 threshold [default: 0]\n"
+"  --max-frag-len=N  Maximum allowed DNA fragment length [default: 5000]\n"
+"  --single-end      Count individual reads, rather than DNA fragments\n"
+"  --center          Only count fragments whose center is within a region\n"
+"\n"
+"Counts the number of DNA fragments (or single reads) in the input BAM file\n"
+"that overlap each region described in the input BED file. The BAM file must\n"
+"be position-sorted.\n";
+
+/* record with mapq and cigar end_pos (rust-htslib CigarStringView::end_pos: pos + reference-consuming ops) */
+static int bam_next_count(bgzf_t *b, core_t *c, uint8_t *mapq, int32_t *end_pos)
+{
+	static record_t rec;
+	if (!bam_next_full(b, &rec)) return 0;
+	*c = rec.c;
+	*mapq = rec.mapq;
+	int64_t e = rec.c.pos;
+	for (uint32_t k = 0; k < rec.n_cigar; k++) {
+		uint32_t op = le32(rec.body.p + rec.l_read_name + 4 * k);
+		uint32_t code = op & 15, len = op >> 4;
+		if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) e += len;
+	}
+	*end_pos = (int32_t)e;
+	return 1;
+}
+
+static int count(int argc, char **argv)
+{
+	oc_opt opts[4] = {{"--min-mapq", 1, NULL}, {"--max-frag-len", 1, NULL}, {"--single-end", 0, NULL}, {"--center", 0, NULL}};
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 2, opts, 4, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_COUNT);
+	uint64_t v;
+	orc_count_params p;
+	if (!oc_parse_uint(opts[0].value ? opts[0].value : "0", 255, &v)) oc_error("--min-mapq must be an integer between 0 - 255.");   /* :23-24 */
+	p.min_mapq = (uint8_t)v;
+	if (!oc_parse_uint(opts[1].value ? opts[1].value : "5000", 0xffffffffull, &v)) oc_error("--max-frag-len must be an integer.");   /* :25 */
+	p.max_frag_len = (uint32_t)v;
+	p.single_end = opts[2].value != NULL;                                      /* :26 */
+	p.count_centers = opts[3].value != NULL;                                   /* :27 */
+
+	fputs("Reading target regions from BED file...\n", stderr);                /* :30 */
+	/* read_regions, src/common.rs:198-219 */
+	oc_str *rchr_name = NULL; uint32_t *rstart = NULL, *rend = NULL; size_t nreg = 0, capreg = 0;
+	{
+		oc_reader bed = oc_reader_open(pos[1]);
+		oc_str line = {0};
+		while (oc_read_line(&bed, &line)) {
+			if (oc_starts_with(&line, '#')) continue;
+			size_t off = orc_trim_start_off(line.p, line.n), end = orc_trim_end_len(line.p, line.n);
+			if (end < off) end = off;
+			/* split('\t') */
+			size_t col_st[3] = {0, 0, 0}, col_en[3] = {0, 0, 0}; int ncol = 0;
+			size_t a = off;
+			for (;;) {
+				size_t b2 = a;
+				while (b2 < end && line.p[b2] != '\t') b2++;
+				if (ncol < 3) { col_st[ncol] = a; col_en[ncol] = b2; }
+				ncol++;
+				if (b2 >= end) break;
+				a = b2 + 1;
+			}
+			if (ncol < 3) oc_error("Invalid region in BED file:\n%s", (const char *)line.p);
+			if (nreg == capreg) {
+				capreg = capreg ? capreg * 2 : 256;
+				rchr_name = (oc_str *)realloc(rchr_name, capreg * sizeof(oc_str));
+				rstart = (uint32_t *)realloc(rstart, capreg * 4);
+				rend = (uint32_t *)realloc(rend, capreg * 4);
+			}
+			memset(&rchr_name[nreg], 0, sizeof(oc_str));
+			oc_assign(&rchr_name[nreg], line.p + col_st[0], col_en[0] - col_st[0]);
+			char num[64];
+			uint64_t s, e;
+			size_t l1 = col_en[1] - col_st[1], l2 = col_en[2] - col_st[2];
+			if (l1 >= sizeof num || l2 >= sizeof num) oc_panic("called `Result::unwrap()` on an `Err` value: ParseIntError");
+			memcpy(num, line.p + col_st[1], l1); num[l1] = 0;
+			if (!oc_parse_uint(num, 0xffffffffull, &s)) oc_panic("called `Result::unwrap()` on an `Err` value: ParseIntError");
+			memcpy(num, line.p + col_st[2], l2); num[l2] = 0;
+			if (!oc_parse_uint(num, 0xffffffffull, &e)) oc_panic("called `Result::unwrap()` on an `Err` value: ParseIntError");
+			rstart[nreg] = (uint32_t)s; rend[nreg] = (uint32_t)e;
+			nreg++;
+		}
+	}
+	uint32_t *region_frags = (uint32_t *)calloc(nreg ? nreg : 1, 4);           /* :32 */
+	fprintf(stderr, "Counting %s...\n", p.single_end ? "reads" : "DNA fragments");   /* :34-35 */
+	bgzf_t *b = (bgzf_t *)malloc(sizeof(bgzf_t));                              /* :36 */
+	bgzf_open(b, pos[0]);
+	bam_read_header(b, pos[0]);
+	for (uint32_t i = 0; i < g_n_ref; i++)                                     /* :37-38 from_utf8(name).unwrap() */
+		if (!orc_utf8_valid((const uint8_t *)g_ref_names[i], strlen(g_ref_names[i]))) oc_panic("called `Result::unwrap()` on an `Err` value: Utf8Error");
+	/* region -> BAM reference by name; a region list per reference is rebuilt whenever the chromosome changes (:52-67),
+	 * which orc_count_record does from rchr.  (With duplicate reference names only the first one gets the regions.) */
+	int32_t *rchr = (int32_t *)malloc((nreg ? nreg : 1) * 4);
+	for (size_t r = 0; r < nreg; r++) {
+		rchr[r] = -1;
+		for (uint32_t i = 0; i < g_n_ref; i++)
+			if (strlen(g_ref_names[i]) == rchr_name[r].n && memcmp(g_ref_names[i], rchr_name[r].p, rchr_name[r].n) == 0) { rchr[r] = (int32_t)i; break; }
+	}
+	orc_count_state st;
+	orc_count_state_init(&st);
+	core_t c; uint8_t mapq; int32_t end_pos;
+	while (bam_next_count(b, &c, &mapq, &end_pos)) {                           /* :45 */
+		int rc = orc_count_record(&st, c.flag, mapq, c.tid, c.mtid, c.pos, c.mpos, c.tlen, end_pos, &p, (int32_t)g_n_ref,
+		                          rchr, rstart, rend, (int64_t)nreg, region_frags);
+		if (rc == ORC_COUNT_UNSORTED) oc_error("Input BAM file is not coordinate sorted.");
+		if (rc == ORC_COUNT_BAD_TID) oc_panic("index out of bounds: chr_names[tid]");
+	}
+	for (size_t r = 0; r < nreg; r++) printf("%u\n", region_frags[r]);         /* :128-130 */
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	int rc;
 	if (argc >= 2 && !strcmp(argv[1], "fragments")) rc = fragments(argc, argv);
 	else if (argc >= 2 && !strcmp(argv[1], "statistics")) rc = statistics(argc, argv);
+	else if (argc >= 2 && !strcmp(argv[1], "count")) rc = count(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "fragment") && !strcmp(argv[2], "lengths")) rc = fragment_lengths(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "to") && (!strcmp(argv[2], "raw") || !strcmp(argv[2], "fasta") || !strcmp(argv[2], "fastq"))) rc = to_reads(argc, argv);
 	else if (argc >= 4 && !strcmp(argv[1], "to") && !strcmp(argv[2], "interleaved") &&

@@ -488,3 +488,99 @@ void orc_bam_sequence_batch(const uint8_t *seq4, int seq4_stride, const uint8_t 
 		                 len ? len[r] : (uint32_t)stride, (flag[r] & 0x10) != 0, min_baseq,
 		                 out + r * (int64_t)stride);
 }
+
+/* ---- f2 (second half): src/sam_count.rs ------------------------------------------------ */
+int orc_count_interval(uint16_t flag, uint8_t mapq, int32_t tid, int32_t mtid, int32_t pos, int32_t mpos,
+                       int32_t tlen, int32_t end_pos, const orc_count_params *p, uint32_t *start_out, uint32_t *end_out)
+{
+	if (flag & 0x4) return 0;                                          /* :46 is_unmapped */
+	if ((flag & 0x400) || (flag & 0x100)) return 0;                    /* :47 duplicate, secondary */
+	if (flag & 0x800) return 0;                                        /* :48 supplementary */
+	if (mapq < p->min_mapq) return 0;                                  /* :49 */
+	uint32_t start = (uint32_t)pos;                                    /* :75 */
+	uint32_t end;
+	if (p->single_end) {
+		end = (uint32_t)end_pos;                                       /* :77 */
+	} else {
+		if (!(flag & 0x1)) return 0;                                   /* :79 */
+		if (flag & 0x8) return 0;                                      /* :80 */
+		if (tid != mtid) return 0;                                     /* :81 */
+		if (pos > mpos || (pos == mpos && !(flag & 0x40))) return 0;   /* :91 */
+		int64_t ins = tlen;                                            /* :93 insert_size().abs() as u32 */
+		if (ins < 0) ins = -ins;
+		uint32_t insert_size = (uint32_t)ins;
+		if (insert_size < 20) return 0;                                /* :94 */
+		end = start + insert_size;                                     /* :96 (u32, wraps) */
+	}
+	if ((uint32_t)(end - start) > p->max_frag_len) return 0;           /* :99 */
+	if (p->count_centers) {                                            /* :103-107 */
+		uint32_t len = end - start;
+		start += len / 2;
+		end = start + 1;
+	}
+	*start_out = start;
+	*end_out = end;
+	return 1;
+}
+
+void orc_count_overlaps(const uint32_t *rstart, const uint32_t *rend, const int64_t *idx, int64_t nreg,
+                        uint32_t start, uint32_t end, uint32_t *region_frags)
+{
+	for (int64_t i = 0; i < nreg; i++) {                               /* :122-126 */
+		if (rstart[idx[i]] >= end) break;
+		if (rend[idx[i]] <= start) continue;
+		region_frags[idx[i]] += 1;
+	}
+}
+
+void orc_count_state_init(orc_count_state *st) { memset(st, 0, sizeof *st); st->prev_chr = -1; }
+void orc_count_state_free(orc_count_state *st) { free(st->deque); st->deque = NULL; }
+
+int orc_count_record(orc_count_state *st, uint16_t flag, uint8_t mapq, int32_t tid, int32_t mtid, int32_t pos,
+                     int32_t mpos, int32_t tlen, int32_t end_pos, const orc_count_params *p, int32_t n_chr,
+                     const int32_t *rchr, const uint32_t *rstart, const uint32_t *rend, int64_t n_regions,
+                     uint32_t *region_frags)
+{
+	if (flag & 0x4) return 0;                                          /* :46 */
+	if ((flag & 0x400) || (flag & 0x100)) return 0;                    /* :47 */
+	if (flag & 0x800) return 0;                                        /* :48 */
+	if (mapq < p->min_mapq) return 0;                                  /* :49 */
+	if (tid != st->prev_chr) {                                         /* :52-67 */
+		st->prev_chr = tid;
+		if (tid < 0 || tid >= n_chr) return ORC_COUNT_BAD_TID;         /* :55 chr_names[read.tid() as usize] */
+		if (st->cap < n_regions) {
+			st->cap = n_regions;
+			st->deque = (int64_t *)realloc(st->deque, (size_t)(n_regions ? n_regions : 1) * sizeof(int64_t));
+		}
+		st->front = 0; st->len = 0;
+		for (int64_t r = 0; r < n_regions; r++)                        /* :61-63 */
+			if (rchr[r] == tid) st->deque[st->len++] = r;
+		for (int64_t a = 1; a < st->len; a++) {                        /* :64 sort_by_key(start): stable */
+			int64_t x = st->deque[a], b = a;
+			while (b > 0 && rstart[st->deque[b - 1]] > rstart[x]) { st->deque[b] = st->deque[b - 1]; b--; }
+			st->deque[b] = x;
+		}
+	} else if ((int64_t)pos < st->prev_pos) {                          /* :69-72 */
+		return ORC_COUNT_UNSORTED;
+	}
+	st->prev_pos = pos;                                                /* :73 */
+	uint32_t start, end;                                               /* :75-107: the same statements as orc_count_interval */
+	if (!orc_count_interval(flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, p, &start, &end)) return 0;
+	while (st->len > 0 && rend[st->deque[st->front]] < (uint32_t)st->prev_pos) { st->front++; st->len--; }   /* :116-119 */
+	orc_count_overlaps(rstart, rend, st->deque + st->front, st->len, start, end, region_frags);            /* :122-126 */
+	return 0;
+}
+
+int orc_count_batch(orc_count_state *st, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid,
+                    const int32_t *mtid, const int32_t *pos, const int32_t *mpos, const int32_t *tlen,
+                    const int32_t *end_pos, int64_t n, const orc_count_params *p, int32_t n_chr,
+                    const int32_t *rchr, const uint32_t *rstart, const uint32_t *rend, int64_t n_regions,
+                    uint32_t *region_frags, int64_t *where)
+{
+	for (int64_t i = 0; i < n; i++) {
+		int rc = orc_count_record(st, flag[i], mapq[i], tid[i], mtid[i], pos[i], mpos[i], tlen[i], end_pos ? end_pos[i] : pos[i], p,
+		                          n_chr, rchr, rstart, rend, n_regions, region_frags);
+		if (rc) { if (where) *where = i; return rc; }
+	}
+	return 0;
+}

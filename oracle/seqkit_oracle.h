@@ -100,6 +100,45 @@ void orc_bam_sequence_batch(const uint8_t *seq4, int seq4_stride, const uint8_t 
                             const uint16_t *len, const uint16_t *flag, int64_t n,
                             uint8_t min_baseq, uint8_t *out);
 
+/* ---- f2 (second half): src/sam_count.rs:44-127, one record ---------------------------- */
+typedef struct {
+	uint8_t  min_mapq;          /* --min-mapq      */
+	uint32_t max_frag_len;      /* --max-frag-len  */
+	int      single_end;        /* --single-end    */
+	int      count_centers;     /* --center        */
+} orc_count_params;
+/* The per-record part of the loop: the filter chain (:46-50, :78-94), the fragment interval
+ * with the reference's u32 arithmetic (:75,97,99-107) — returns 0 when the record is skipped,
+ * else 1 with the 0-based half-open [*start, *end).  The chromosome bookkeeping and the
+ * sortedness check (:52-73) are the caller's.  end_pos = cigar().end_pos().               */
+int orc_count_interval(uint16_t flag, uint8_t mapq, int32_t tid, int32_t mtid, int32_t pos, int32_t mpos,
+                       int32_t tlen, int32_t end_pos, const orc_count_params *p, uint32_t *start, uint32_t *end);
+/* The overlap sweep of :113-126 over one chromosome's regions (indices sorted by start):
+ * region_frags[idx[i]] += 1 for every region with start < end and end > start_f.           */
+void orc_count_overlaps(const uint32_t *rstart, const uint32_t *rend, const int64_t *idx, int64_t nreg,
+                        uint32_t start, uint32_t end, uint32_t *region_frags);
+
+/* The whole loop body of src/sam_count.rs:45-126 for one record, with the state the loop
+ * carries (prev_chr, prev_pos, the deque of the current chromosome's regions).  rchr[r] is
+ * the index of the BAM reference whose name equals region r's chromosome, or -1.  Returns
+ * 0, ORC_COUNT_UNSORTED (:71 "Input BAM file is not coordinate sorted.") or
+ * ORC_COUNT_BAD_TID (:55 chr_names[tid] out of bounds: a Rust panic).                     */
+#define ORC_COUNT_UNSORTED 1
+#define ORC_COUNT_BAD_TID  2
+typedef struct { int32_t prev_chr; int64_t prev_pos; int64_t *deque; int64_t front, len, cap; } orc_count_state;
+void orc_count_state_init(orc_count_state *st);
+void orc_count_state_free(orc_count_state *st);
+int orc_count_record(orc_count_state *st, uint16_t flag, uint8_t mapq, int32_t tid, int32_t mtid, int32_t pos,
+                     int32_t mpos, int32_t tlen, int32_t end_pos, const orc_count_params *p, int32_t n_chr,
+                     const int32_t *rchr, const uint32_t *rstart, const uint32_t *rend, int64_t n_regions,
+                     uint32_t *region_frags);
+/* n records through orc_count_record; returns 0 or the first non-zero code (*where = its record) */
+int orc_count_batch(orc_count_state *st, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid,
+                    const int32_t *mtid, const int32_t *pos, const int32_t *mpos, const int32_t *tlen,
+                    const int32_t *end_pos, int64_t n, const orc_count_params *p, int32_t n_chr,
+                    const int32_t *rchr, const uint32_t *rstart, const uint32_t *rend, int64_t n_regions,
+                    uint32_t *region_frags, int64_t *where);
+
 /* ---- text helpers that restate Rust std behaviour used on the path -------------- */
 /* str::trim_end(): length of s after removing trailing Unicode White_Space chars
  * (U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F, 3000);

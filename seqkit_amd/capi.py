@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
+    "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
     "sk_timer_start", "sk_timer_stop",
 ]
@@ -89,6 +90,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_bam_fragments_dev": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_bam_sequence": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, C.c_uint8, vp]),
         "sk_bam_sequence_dev": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, C.c_uint8, vp]),
+        "sk_count_set_regions": (i32, [vp, i32, vp, vp, vp, vp, i64, i64]),
+        "sk_count_add": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_uint8, C.c_uint32, i32, i32]),
+        "sk_count_add_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_uint8, C.c_uint32, i32, i32]),
+        "sk_count_get": (i32, [vp, vp]),
         "sk_census_reset": (i32, [vp]),
         "sk_census_add": (i32, [vp, vp, i32, i32, i64, vp, i64]),
         "sk_census_add_dev": (i32, [vp, vp, i32, i32, i64, vp, i64]),
@@ -323,6 +328,33 @@ class Context:
                           kept: int) -> None:
         self._check(self._lib.sk_bam_fragments_dev(self._h, flag, tid, mtid, tlen, n, min_size, max_size, keep_bits, kept),
                     "sk_bam_fragments_dev")
+
+    # ---- f2 (second half): sam count -------------------------------------------------------
+    def count_set_regions(self, chr_off, rstart, rend, ridx=None, n_regions: int | None = None) -> None:
+        """Regions grouped by BAM reference: entries chr_off[c]..chr_off[c+1]-1 belong to reference c; ridx maps an entry
+        to its index in the caller's list of n_regions regions."""
+        chr_off = np.ascontiguousarray(chr_off, dtype=np.int32)
+        rstart = np.ascontiguousarray(rstart, dtype=np.uint32)
+        rend = np.ascontiguousarray(rend, dtype=np.uint32)
+        n = len(rstart)
+        ridx = None if ridx is None else np.ascontiguousarray(ridx, dtype=np.int32)
+        self._n_regions = n if n_regions is None else n_regions
+        self._check(self._lib.sk_count_set_regions(self._h, len(chr_off) - 1, _ptr(chr_off), _ptr(rstart), _ptr(rend), _ptr(ridx), n,
+                                                   self._n_regions), "sk_count_set_regions")
+
+    def count_add(self, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos=None, min_mapq: int = 0, max_frag_len: int = 5000,
+                  single_end: bool = False, center: bool = False) -> None:
+        n = len(flag)
+        cols = [_vec(flag, np.uint16, n, "flag"), _vec(mapq, np.uint8, n, "mapq")]
+        for name, col in (("tid", tid), ("mtid", mtid), ("pos", pos), ("mpos", mpos), ("tlen", tlen), ("end_pos", end_pos)):
+            cols.append(None if col is None else _vec(col, np.int32, n, name))
+        self._check(self._lib.sk_count_add(self._h, *[_ptr(c) for c in cols], n, min_mapq, max_frag_len, int(single_end), int(center)),
+                    "sk_count_add")
+
+    def count_get(self) -> np.ndarray:
+        out = np.zeros(max(self._n_regions, 1), dtype=np.uint32)
+        self._check(self._lib.sk_count_get(self._h, _ptr(out)), "sk_count_get")
+        return out[:self._n_regions]
 
     # ---- f4: sam to fastq sequence() ---------------------------------------------------------
     def bam_sequence(self, seq4, qual, length, flag, min_baseq: int = 10) -> np.ndarray:

@@ -4,6 +4,7 @@
 //   sam statistics [--on-target=BED] <bam_file>                         src/sam_statistics.rs:14-116
 //   sam fragment lengths [--max-frag-size=F] [--reads=N] <bam_file>     src/sam_fragment_lengths.rs:14-48
 //   sam fragments [--min-size=N] [--max-size=N] <bam_file>              src/sam_fragments.rs:14-43   (§8f f2)
+//   sam count [--min-mapq=N] [--max-frag-len=N] [--single-end] [--center] <bam_file> <regions.bed>   src/sam_count.rs:20-130 (§8f f2)
 //   sam to [interleaved] raw|fasta|fastq <bam_file> [<out_prefix>]      src/sam_to_fastq.rs:61-149   (§8f f4)
 //
 // The reference reads BAM through rust-htslib; this host walks the BGZF/BAM container itself (SAMv1 §4.2: BGZF is a
@@ -42,7 +43,7 @@ static void check(int rc, const char *what)
 }
 
 // ---- BGZF/BAM container walk ---------------------------------------------------------------------------------
-struct BamCore { int32_t tid, pos; uint16_t flag; int32_t mtid, mpos, tlen, end_pos; };
+struct BamCore { int32_t tid, pos; uint16_t flag; int32_t mtid, mpos, tlen, end_pos; uint8_t mapq; };
 
 class BamStream {
 public:
@@ -91,6 +92,7 @@ public:
 		c.tid = (int32_t)le32(core + 0);
 		c.pos = (int32_t)le32(core + 4);
 		const uint32_t l_read_name = core[8];
+		c.mapq = core[9];
 		const uint32_t n_cigar = (uint32_t)core[12] | ((uint32_t)core[13] << 8);
 		c.flag = (uint16_t)(core[14] | (core[15] << 8));
 		c.mtid = (int32_t)le32(core + 20);
@@ -129,6 +131,7 @@ public:
 		c.tid = (int32_t)le32(core + 0);
 		c.pos = (int32_t)le32(core + 4);
 		v.l_read_name = core[8];
+		c.mapq = core[9];
 		v.n_cigar = (uint32_t)core[12] | ((uint32_t)core[13] << 8);
 		c.flag = (uint16_t)(core[14] | (core[15] << 8));
 		v.l_seq = le32(core + 16);
@@ -416,6 +419,114 @@ static int fragments(int argc, char **argv)                        // src/sam_fr
 	return 0;
 }
 
+// ---- sam count (second half) --------------------------------------------------------------------
+static const char *USAGE_COUNT =
+	"\nUsage:\n  sam count [options] <bam_file> <regions.bed>\n\nOptions:\n"
+	"  --min-mapq=N      Only count reads with MAPQ \xe2\x89\xa5 threshold [default: 0]\n"
+	"  --max-frag-len=N  Maximum allowed DNA fragment length [default: 5000]\n"
+	"  --single-end      Count individual reads, rather than DNA fragments\n"
+	"  --center          Only count fragments whose center is within a region\n"
+	"\n"
+	"Counts the number of DNA fragments (or single reads) in the input BAM file\n"
+	"that overlap each region described in the input BED file. The BAM file must\n"
+	"be position-sorted.\n";
+
+static int count(int argc, char **argv)                            // src/sam_count.rs:20-130
+{
+	std::vector<host::Opt> opts = {{"--min-mapq", true, false, "0"}, {"--max-frag-len", true, false, "5000"}, {"--single-end", false, false, ""},
+	                               {"--center", false, false, ""}};
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 2, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_COUNT);
+	uint64_t v;
+	if (!host::parse_uint(opts[0].value.c_str(), 255, v)) error("--min-mapq must be an integer between 0 - 255.");       // :23-24
+	const uint8_t min_mapq = (uint8_t)v;
+	if (!host::parse_uint(opts[1].value.c_str(), 0xffffffffull, v)) error("--max-frag-len must be an integer.");          // :25
+	const uint32_t max_frag_len = (uint32_t)v;
+	const bool single_end = opts[2].present, count_centers = opts[3].present;                                              // :26-27
+
+	fputs("Reading target regions from BED file...\n", stderr);                                                            // :30
+	struct Reg { std::string chr; uint32_t start, end; };
+	std::vector<Reg> regions;                                                                                              // read_regions, src/common.rs:198-219
+	{
+		host::LineReader bed(pos[1]);
+		std::string line;
+		for (;;) {
+			const bool ok = bed.read_line(line);
+			if (bed.bad_utf8()) error("I/O error while reading from file.");
+			if (!ok) break;
+			if (!line.empty() && line[0] == '#') continue;
+			const size_t off = host::trim_start_off(line), end = host::trim_end_len(line);
+			const std::string t = end > off ? line.substr(off, end - off) : std::string();
+			std::vector<std::string> cols;
+			size_t a = 0;
+			for (;;) { const size_t b = t.find('\t', a); cols.push_back(t.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; }
+			if (cols.size() < 3) error("Invalid region in BED file:\n%s", line.c_str());
+			uint64_t s, e;
+			if (!host::parse_uint(cols[1].c_str(), 0xffffffffull, s) || !host::parse_uint(cols[2].c_str(), 0xffffffffull, e))
+				panic("called `Result::unwrap()` on an `Err` value: ParseIntError (BED)");
+			regions.push_back({cols[0], (uint32_t)s, (uint32_t)e});
+		}
+	}
+	fprintf(stderr, "Counting %s...\n", single_end ? "reads" : "DNA fragments");                                            // :34-35
+	BamStream bam(pos[0]);                                                                                                 // :36
+	for (const std::string &nm : bam.names)                                                                                // :37-38
+		if (!host::utf8_valid(reinterpret_cast<const uint8_t *>(nm.data()), nm.size())) panic("called `Result::unwrap()` on an `Err` value: Utf8Error");
+
+	// the regions of every BAM reference (:61-63), handed to the device once
+	{
+		const int n_chr = (int)bam.names.size();
+		std::vector<int32_t> chr_off(n_chr + 1, 0), ridx;
+		std::vector<uint32_t> rs, re;
+		for (int c = 0; c < n_chr; c++) {
+			for (size_t r = 0; r < regions.size(); r++)
+				if (regions[r].chr == bam.names[c]) { rs.push_back(regions[r].start); re.push_back(regions[r].end); ridx.push_back((int32_t)r); }
+			chr_off[c + 1] = (int32_t)rs.size();
+		}
+		check(sk_count_set_regions(host::gpu(), n_chr, chr_off.data(), rs.data(), re.data(), ridx.data(), (int64_t)rs.size(),
+		                           (int64_t)std::max(rs.size(), regions.size())), "sk_count_set_regions");
+	}
+
+	int32_t prev_chr = -1;                                                                                                 // :40-41
+	int64_t prev_pos = 0;
+	Columns col;
+	std::vector<uint8_t> mapq;
+	BamCore c;
+	bool more = true;
+	const char *stop = nullptr;                      // an order-dependent error met while reading: raised after the records before it
+	int stop_code = 255;
+	while (more && !stop) {
+		col.clear(); mapq.clear();
+		while (col.flag.size() < kBatch && (more = bam.next(c, single_end))) {
+			// :46-49 and the order checks :52-73 stay here: they depend on the records before
+			if (!((c.flag & 0x4) || (c.flag & 0x400) || (c.flag & 0x100) || (c.flag & 0x800) || c.mapq < min_mapq)) {
+				if (c.tid != prev_chr) {
+					prev_chr = c.tid;
+					if (c.tid < 0 || (size_t)c.tid >= bam.names.size()) { stop = "index out of bounds: chr_names[tid]"; stop_code = 101; break; }
+				} else if ((int64_t)c.pos < prev_pos) {
+					stop = "Input BAM file is not coordinate sorted."; break;                                              // :70-72
+				}
+				prev_pos = c.pos;
+			}
+			col.push(c, true);
+			mapq.push_back(c.mapq);
+		}
+		const int64_t n = (int64_t)col.flag.size();
+		if (n == 0) continue;
+		check(sk_count_add(host::gpu(), col.flag.data(), mapq.data(), col.tid.data(), col.mtid.data(), col.pos.data(), col.mpos.data(), col.tlen.data(),
+		                   single_end ? col.end_pos.data() : nullptr, n, min_mapq, max_frag_len, single_end ? 1 : 0, count_centers ? 1 : 0), "sk_count_add");
+	}
+	if (stop) { if (stop_code == 101) panic(stop); error("%s", stop); }
+	bam.raise_deferred();
+	std::vector<uint32_t> region_frags(std::max<size_t>(regions.size(), 1));
+	check(sk_count_get(host::gpu(), region_frags.data()), "sk_count_get");
+	char buf[32];
+	for (size_t r = 0; r < regions.size(); r++) {                                                                          // :128-130
+		snprintf(buf, sizeof buf, "%u\n", region_frags[r]);
+		host::out().write(buf, strlen(buf));
+	}
+	return 0;
+}
+
 // ---- sam to raw|fasta|fastq -----------------------------------------------------------------
 static const char *USAGE_TO =
 	"\nUsage:\n"
@@ -597,7 +708,8 @@ int main(int argc, char **argv)
 {
 	int rc = 0;
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
-	if (argc >= 2 && is(1, "fragments")) rc = fragments(argc, argv);
+	if (argc >= 2 && is(1, "count")) rc = count(argc, argv);
+	else if (argc >= 2 && is(1, "fragments")) rc = fragments(argc, argv);
 	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else if (argc >= 3 && is(1, "fragment") && is(2, "lengths")) rc = fragment_lengths(argc, argv);
 	else if (argc >= 3 && is(1, "to") && (is(2, "raw") || is(2, "fasta") || is(2, "fastq"))) rc = to_reads(argc, argv);

@@ -2,6 +2,7 @@
 // No CPU fallback lives here: without a GPU sk_create() fails and every other call needs a ctx.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,12 @@ struct sk_ctx {
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
 	sk::Census *census = nullptr;
+	// `sam count` region tables
+	int cnt_n_chr = 0;
+	int64_t cnt_n_regions = 0;
+	uint8_t *d_cnt = nullptr;          // one allocation: chr_off, rstart, rend, rpmax, ridx, counts
+	int32_t *d_chr_off = nullptr, *d_ridx = nullptr;
+	uint32_t *d_rstart = nullptr, *d_rend = nullptr, *d_rpmax = nullptr, *d_region_frags = nullptr;
 };
 
 static thread_local std::string g_create_err;
@@ -121,6 +128,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->census) sk::census_destroy(c->census);
+	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -639,6 +647,132 @@ int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	uint64_t k = 0;
 	SK_HIP(c, hipMemcpy(&k, dkept, 8, hipMemcpyDeviceToHost));
 	if (kept) *kept += k;
+	return SK_OK;
+}
+
+// ---- f2 (second half): sam count ---------------------------------------------------------------------------------
+int sk_count_set_regions(sk_ctx *c, int n_chr, const int32_t *chr_off, const uint32_t *rstart, const uint32_t *rend,
+                         const int32_t *ridx, int64_t n_entries, int64_t n_counts)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_chr < 0 || n_entries < 0 || n_counts < n_entries || n_counts > 0x7fffffff || !chr_off || (n_entries > 0 && (!rstart || !rend)))
+		return fail(c, SK_ERR_INVALID, "sk_count_set_regions: bad arguments");
+	const int64_t n_regions = n_entries;
+	if (chr_off[0] != 0 || chr_off[n_chr] != n_regions) return fail(c, SK_ERR_INVALID, "chr_off must run from 0 to n_entries");
+	for (int k = 0; k < n_chr; k++) if (chr_off[k] > chr_off[k + 1]) return fail(c, SK_ERR_INVALID, "chr_off must not decrease");
+	if (int r = bind(c)) return r;
+	// sort each reference's regions by start (stable, like :63) and take the running maximum of their ends
+	std::vector<int32_t> order((size_t)n_regions);
+	for (int64_t i = 0; i < n_regions; i++) order[(size_t)i] = (int32_t)i;
+	for (int k = 0; k < n_chr; k++)
+		std::stable_sort(order.begin() + chr_off[k], order.begin() + chr_off[k + 1], [&](int32_t x, int32_t y) { return rstart[x] < rstart[y]; });
+	std::vector<uint32_t> s((size_t)n_regions), e((size_t)n_regions), pm((size_t)n_regions);
+	std::vector<int32_t> ix((size_t)n_regions);
+	for (int k = 0; k < n_chr; k++) {
+		uint32_t run = 0;
+		for (int32_t i = chr_off[k]; i < chr_off[k + 1]; i++) {
+			const int32_t o = order[(size_t)i];
+			const int32_t orig = ridx ? ridx[o] : o;
+			s[(size_t)i] = rstart[o]; e[(size_t)i] = rend[o]; ix[(size_t)i] = orig;
+			if (orig < 0 || orig >= n_counts) return fail(c, SK_ERR_INVALID, "ridx out of range");
+			run = std::max(run, rend[o]);
+			pm[(size_t)i] = run;
+		}
+	}
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->d_cnt) { SK_HIP(c, hipFree(c->d_cnt)); c->d_cnt = nullptr; }
+	const size_t b_off = up256((size_t)(n_chr + 1) * 4), b_reg = up256((size_t)n_regions * 4 + 4), b_cnt = up256((size_t)n_counts * 4 + 4);
+	hipError_t he = hipMalloc((void **)&c->d_cnt, b_off + 4 * b_reg + b_cnt);
+	if (he != hipSuccess) { c->d_cnt = nullptr; return fail(c, SK_ERR_NOMEM, "region tables: %s", hipGetErrorString(he)); }
+	uint8_t *p = c->d_cnt;
+	c->d_chr_off = (int32_t *)p; p += b_off;
+	c->d_rstart = (uint32_t *)p; p += b_reg;
+	c->d_rend = (uint32_t *)p; p += b_reg;
+	c->d_rpmax = (uint32_t *)p; p += b_reg;
+	c->d_ridx = (int32_t *)p; p += b_reg;
+	c->d_region_frags = (uint32_t *)p;
+	SK_HIP(c, hipMemcpyAsync(c->d_chr_off, chr_off, (size_t)(n_chr + 1) * 4, hipMemcpyHostToDevice, c->stream));
+	if (n_regions) {
+		SK_HIP(c, hipMemcpyAsync(c->d_rstart, s.data(), (size_t)n_regions * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(c->d_rend, e.data(), (size_t)n_regions * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(c->d_rpmax, pm.data(), (size_t)n_regions * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(c->d_ridx, ix.data(), (size_t)n_regions * 4, hipMemcpyHostToDevice, c->stream));
+	}
+	SK_HIP(c, hipMemsetAsync(c->d_region_frags, 0, b_cnt, c->stream));
+	SK_HIP(c, hipStreamSynchronize(c->stream));              // the staging vectors go out of scope
+	c->cnt_n_chr = n_chr;
+	c->cnt_n_regions = n_counts;
+	return SK_OK;
+}
+
+static int count_args(sk_ctx *c, sk::CountArgs &a, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid,
+                      const int32_t *pos, const int32_t *mpos, const int32_t *tlen, const int32_t *end_pos, int64_t n,
+                      uint8_t min_mapq, uint32_t max_frag_len, int single_end, int center)
+{
+	if (!c->d_cnt) return fail(c, SK_ERR_INVALID, "sk_count_set_regions has not been called");
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (n > 0 && (!flag || !mapq || !tid || !pos || (single_end ? !end_pos : (!mtid || !mpos || !tlen)))) return fail(c, SK_ERR_INVALID, "NULL column");
+	a.flag = flag; a.mapq = mapq; a.tid = tid; a.mtid = mtid; a.pos = pos; a.mpos = mpos; a.tlen = tlen; a.end_pos = end_pos;
+	a.n = n; a.min_mapq = min_mapq; a.max_frag_len = max_frag_len; a.single_end = single_end ? 1 : 0; a.center = center ? 1 : 0;
+	a.n_chr = c->cnt_n_chr; a.chr_off = c->d_chr_off; a.rstart = c->d_rstart; a.rend = c->d_rend; a.rpmax = c->d_rpmax; a.ridx = c->d_ridx;
+	a.counts = c->d_region_frags;
+	return SK_OK;
+}
+
+int sk_count_add_dev(sk_ctx *c, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid, const int32_t *pos,
+                     const int32_t *mpos, const int32_t *tlen, const int32_t *end_pos, int64_t n, uint8_t min_mapq, uint32_t max_frag_len,
+                     int single_end, int center)
+{
+	if (!c) return SK_ERR_INVALID;
+	sk::CountArgs a;
+	if (int r = count_args(c, a, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n, min_mapq, max_frag_len, single_end, center)) return r;
+	if (n == 0) return SK_OK;
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bam_count(a, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_count_add(sk_ctx *c, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid, const int32_t *pos,
+                 const int32_t *mpos, const int32_t *tlen, const int32_t *end_pos, int64_t n, uint8_t min_mapq, uint32_t max_frag_len,
+                 int single_end, int center)
+{
+	if (!c) return SK_ERR_INVALID;
+	sk::CountArgs a;
+	if (int r = count_args(c, a, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n, min_mapq, max_frag_len, single_end, center)) return r;
+	if (n == 0) return SK_OK;
+	if (int r = bind(c)) return r;
+	int64_t chunk = 4 << 20;
+	if (chunk > n) chunk = n;
+	const size_t b2 = up256((size_t)chunk * 2), b1 = up256((size_t)chunk), b4 = up256((size_t)chunk * 4);
+	if (int r = ensure_ws(c, b2 + b1 + 6 * b4)) return r;
+	uint8_t *p = c->ws;
+	uint16_t *dflag = (uint16_t *)p; p += b2;
+	uint8_t *dmapq = p; p += b1;
+	int32_t *dcol[6];
+	for (int k = 0; k < 6; k++) { dcol[k] = (int32_t *)p; p += b4; }
+	const int32_t *hcol[6] = {tid, mtid, pos, mpos, tlen, end_pos};
+	for (int64_t o = 0; o < n; o += chunk) {
+		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dmapq, mapq + o, (size_t)nr, hipMemcpyHostToDevice, c->stream));
+		for (int k = 0; k < 6; k++)
+			if (hcol[k]) SK_HIP(c, hipMemcpyAsync(dcol[k], hcol[k] + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+		a.flag = dflag; a.mapq = dmapq; a.tid = dcol[0]; a.mtid = dcol[1]; a.pos = dcol[2]; a.mpos = dcol[3]; a.tlen = dcol[4]; a.end_pos = dcol[5];
+		a.n = nr;
+		SK_HIP(c, sk::launch_bam_count(a, c->n_cu, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+	}
+	return SK_OK;
+}
+
+int sk_count_get(sk_ctx *c, uint32_t *region_frags)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!c->d_cnt) return fail(c, SK_ERR_INVALID, "sk_count_set_regions has not been called");
+	if (c->cnt_n_regions > 0 && !region_frags) return fail(c, SK_ERR_INVALID, "region_frags is NULL");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->cnt_n_regions) SK_HIP(c, hipMemcpy(region_frags, c->d_region_frags, (size_t)c->cnt_n_regions * 4, hipMemcpyDeviceToHost));
 	return SK_OK;
 }
 

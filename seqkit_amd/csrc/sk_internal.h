@@ -76,6 +76,22 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
 hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen, int64_t n,
                                 int64_t min_size, int64_t max_size, uint8_t *keep_bits, unsigned long long *kept, int n_cu, hipStream_t st);
 
+// `sam count`: record columns + the region tables of sk_count_set_regions
+struct CountArgs {
+	const uint16_t *flag;
+	const uint8_t *mapq;
+	const int32_t *tid, *mtid, *pos, *mpos, *tlen, *end_pos;
+	int64_t n;
+	uint32_t min_mapq, max_frag_len;
+	int single_end, center;
+	int n_chr;
+	const int32_t *chr_off;        // n_chr + 1 offsets into the sorted region arrays
+	const uint32_t *rstart, *rend, *rpmax;
+	const int32_t *ridx;           // sorted position -> region index of the caller
+	uint32_t *counts;
+};
+hipError_t launch_bam_count(const CountArgs &a, int n_cu, hipStream_t st);
+
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st);
 

@@ -1295,6 +1295,60 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// f2 (second half): `sam count` (src/sam_count.rs:44-127) — per record the filter chain and the fragment interval
+// in the reference's u32 arithmetic, then one count for every region of the record's chromosome that the interval
+// overlaps.  The reference walks a deque of the chromosome's regions sorted by start (:122-126: stop at the first
+// region that starts at or after the fragment's end, skip regions that end at or before its start); here that is a
+// binary search for the stop point and a backward walk that ends as soon as the running maximum of the region ends
+// (rpmax) says nothing further left can reach the fragment.  The deque's pop_front (:116-119) only drops regions
+// that can no longer be hit in a coordinate-sorted file, which the host checks record by record (:70-72).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bam_count_kernel(const CountArgs a)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
+		const u32 f = a.flag[r];
+		if (f & (0x4u | 0x400u | 0x100u | 0x800u)) continue;               // :46-48
+		if ((u32)a.mapq[r] < a.min_mapq) continue;                          // :49
+		const int32_t pos = a.pos[r], tid = a.tid[r];
+		u32 start = (u32)pos, end;                                          // :75
+		if (a.single_end) {
+			end = (u32)a.end_pos[r];                                        // :77
+		} else {
+			if (!(f & 0x1u) || (f & 0x8u)) continue;                        // :79-80
+			if (tid != a.mtid[r]) continue;                                 // :81
+			const int32_t mpos = a.mpos[r];
+			if (pos > mpos || (pos == mpos && !(f & 0x40u))) continue;      // :91
+			const int32_t tl = a.tlen[r];
+			const u32 ins = tl < 0 ? 0u - (u32)tl : (u32)tl;                // :93
+			if (ins < 20u) continue;                                        // :94
+			end = start + ins;                                              // :96
+		}
+		if (end - start > a.max_frag_len) continue;                         // :99
+		if (a.center) { start += (end - start) / 2u; end = start + 1u; }    // :103-107
+		if (tid < 0 || tid >= a.n_chr) continue;                            // the host has raised chr_names[tid] already
+		const int lo = a.chr_off[tid], hi = a.chr_off[tid + 1];
+		int b = lo, e = hi;                                                 // first region with rstart >= end
+		while (b < e) {
+			const int mid = (b + e) >> 1;
+			if (a.rstart[mid] >= end) e = mid; else b = mid + 1;
+		}
+		for (int i = b - 1; i >= lo; i--) {
+			if (a.rpmax[i] <= start) break;
+			if (a.rend[i] > start) atomicAdd(&a.counts[a.ridx[i]], 1u);
+		}
+	}
+}
+
+hipError_t launch_bam_count(const CountArgs &a, int n_cu, hipStream_t st)
+{
+	if (a.n <= 0) return hipSuccess;
+	const int64_t want = (a.n + 255) / 256;
+	const int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
+	bam_count_kernel<<<grid, 256, 0, st>>>(a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f4: `sam to fastq` sequence() (src/sam_to_fastq.rs:31-59) — BAM 4-bit bases -> ASCII, reverse-complemented for
 // reverse-strand records, 'N' where the quality is below min_baseq.  One thread per 16 output bytes; a workgroup
 // walks tiles of 64 rows, whose lengths and strands it keeps in LDS.

@@ -557,3 +557,70 @@ def test_sam_to_reads_errors_and_quirks(bins, tmp_path):
                  ["to", "bed", str(bam), "o"], ["to"], ["to", "fastq", "--x", str(bam), "o"]):
         both(bins, "sam", args, tmp_path)
 
+
+
+# ---- f2 (second half): sam count -----------------------------------------------------------------------------------
+def sorted_bam(path, n, seed, **kw):
+    rng = np.random.default_rng(seed)
+    flags = rng.choice(np.array([99, 147, 83, 163, 65, 129, 0, 16, 4, 1024 + 99, 256 + 99, 2048 + 99, 73, 1]), size=n)
+    tid = np.sort(rng.integers(0, 3, size=n))
+    pos = rng.integers(0, 500_000, size=n)
+    order = np.lexsort((pos, tid))
+    tid, pos = tid[order], pos[order]
+    recs = []
+    for i in range(n):
+        tl = int(rng.integers(-600, 600))
+        f = int(flags[i])
+        recs.append(dict(tid=-1 if f & 4 else int(tid[i]), mtid=int(tid[i]) if rng.random() < 0.95 else -1, flag=f, tlen=tl, pos=int(pos[i]),
+                         mpos=int(pos[i]) if rng.random() < 0.1 else int(pos[i] + tl // 2), name=f"q{i}", mapq=int(rng.integers(0, 61)),
+                         cigar=[(0, int(rng.integers(1, 80))), (2, int(rng.integers(0, 5))), (4, 3), (0, int(rng.integers(0, 40)))], seq_len=10))
+    cu.write_bam(path, [("chr1", 1_000_000), ("chr2", 900_000), ("chrM", 16_000)], recs, **kw)
+    return recs
+
+
+def test_sam_count_cli(bins, tmp_path):
+    bam = tmp_path / "s.bam"
+    sorted_bam(str(bam), 30000, seed=41)
+    rng = np.random.default_rng(42)
+    lines = [b"# comment line\n"]
+    for i in range(400):
+        c = [b"chr1", b"chr2", b"chrM", b"chrUn"][int(rng.integers(0, 4))]
+        st = int(rng.integers(0, 500_000))
+        ln = int(rng.choice([0, 1, 100, 1000, 50000]))
+        lines.append(c + b"\t%d\t%d" % (st, st + ln) + (b"\tname%d\t0\t+" % i if i % 3 == 0 else b"") + (b"  \n" if i % 5 == 0 else b"\n"))
+    bed = tmp_path / "r.bed"
+    bed.write_bytes(b"".join(lines))
+    a, *_ = both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)
+    counts = [int(x) for x in a[1].split()]
+    assert len(counts) == 400 and sum(counts) > 1000 and a[2] == b"Reading target regions from BED file...\nCounting DNA fragments...\n"
+    for extra in (["--single-end"], ["--center"], ["--min-mapq=30"], ["--max-frag-len", "200"], ["--single-end", "--center", "--min-mapq", "20", "--max-frag-len=50"],
+                  ["--max-frag-len=0"], ["--min-mapq=255"]):
+        both(bins, "sam", ["count"] + extra + [str(bam), str(bed)], tmp_path)
+    both(bins, "sam", ["count", "-", str(bed)], tmp_path, stdin=bam.read_bytes())
+    # order-dependent errors and input errors
+    recs = sorted_bam(str(bam), 3000, seed=43)
+    ok = [i for i, r in enumerate(recs) if r["flag"] == 99 and r["tid"] == 0]
+    i, j = ok[5], ok[60]                                                     # two countable chr1 records, far apart: swap them
+    assert recs[i]["pos"] < recs[j]["pos"]
+    recs[i], recs[j] = recs[j], recs[i]
+    cu.write_bam(str(bam), [("chr1", 1_000_000), ("chr2", 900_000), ("chrM", 16_000)], recs)
+    a, *_ = both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)
+    assert a[0] == 255 and a[1] == b"" and a[2].endswith(b"ERROR: Input BAM file is not coordinate sorted.\n")
+    sorted_bam(str(bam), 3000, seed=44, truncate=40000)
+    a, *_ = both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)
+    assert a[0] == 255 and a[2].endswith(b"ERROR: BAM file ended prematurely.\n")
+    sorted_bam(str(bam), 2000, seed=45)
+    bed.write_bytes(b"chr1\t10\t20\nchr1\t5\n")
+    both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)                # Invalid region in BED file
+    bed.write_bytes(b"chr1\t10\t20\n\n")
+    both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)                # an empty line is an invalid region too
+    bed.write_bytes(b"chr1\tx\t20\n")
+    a, *_ = both(bins, "sam", ["count", str(bam), str(bed)], tmp_path, same_stderr=False)
+    assert a[0] == 101
+    bed.write_bytes(b"")
+    a, *_ = both(bins, "sam", ["count", str(bam), str(bed)], tmp_path)        # no regions: nothing printed
+    assert a[0] == 0 and a[1] == b""
+    bed.write_bytes(b"chr1\t0\t1000000\n")
+    for args in (["count"], ["count", str(bam)], ["count", "--min-mapq=256", str(bam), str(bed)], ["count", "--max-frag-len=x", str(bam), str(bed)],
+                 ["count", str(bam), "missing.bed"], ["count", "missing.bam", str(bed)], ["count", "--bogus", str(bam), str(bed)]):
+        both(bins, "sam", args, tmp_path)

@@ -397,6 +397,83 @@ def test_bam_fragments_filter(ctx, oracle, n, lo, hi):
 
 
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
+# ---- f2 (second half): sam count ---------------------------------------------------------------------------------
+def count_inputs(n, n_chr, n_regions, seed, span=2_000_000):
+    """Coordinate-sorted record columns and BED-like regions (unsorted, overlapping, nested, empty, some on a chromosome
+    the BAM does not have)."""
+    rng = np.random.default_rng(seed)
+    tid = np.sort(rng.integers(0, n_chr, size=n)).astype(np.int32)
+    pos = rng.integers(0, span, size=n).astype(np.int32)
+    order = np.lexsort((pos, tid))
+    tid, pos = tid[order], pos[order]
+    flag = rng.choice(np.array([99, 147, 83, 163, 65, 129, 97, 145, 0, 16, 4, 1024 + 99, 256 + 99, 2048 + 99, 73, 1], dtype=np.uint16), size=n)
+    mapq = rng.integers(0, 61, size=n).astype(np.uint8)
+    tlen = rng.integers(-700, 700, size=n).astype(np.int32)
+    odd = np.nonzero(rng.random(n) < 0.02)[0]
+    tlen[odd] = rng.choice(np.array([0, 19, 20, -20, 5000, 5001, -2**31, 2**31 - 1], dtype=np.int64), size=len(odd)).astype(np.int32)
+    mpos = (pos.astype(np.int64) + tlen.astype(np.int64) // 2).astype(np.int32)
+    same = rng.random(n) < 0.1
+    mpos[same] = pos[same]
+    mtid = tid.copy()
+    mtid[rng.random(n) < 0.05] = -1
+    end_pos = (pos + rng.integers(0, 160, size=n)).astype(np.int32)
+    rchr = rng.integers(-1, n_chr, size=n_regions).astype(np.int32)
+    rstart = rng.integers(0, span, size=n_regions).astype(np.uint32)
+    rlen = rng.choice(np.array([0, 1, 50, 300, 2000, 100000], dtype=np.uint32), size=n_regions)
+    rend = (rstart + rlen).astype(np.uint32)
+    return dict(flag=flag, mapq=mapq, tid=tid, mtid=mtid, pos=pos, mpos=mpos, tlen=tlen, end_pos=end_pos), rchr, rstart, rend
+
+
+def grouped_regions(rchr, rstart, rend, n_chr):
+    """The C-ABI takes regions grouped by reference (any order inside a group) + their original indices."""
+    keep = np.nonzero(rchr >= 0)[0]
+    order = keep[np.argsort(rchr[keep], kind="stable")]
+    chr_off = np.zeros(n_chr + 1, dtype=np.int32)
+    np.add.at(chr_off, rchr[keep] + 1, 1)
+    return np.cumsum(chr_off).astype(np.int32), rstart[order], rend[order], order.astype(np.int32)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(min_mapq=30), dict(max_frag_len=300), dict(single_end=True), dict(center=True),
+                                dict(single_end=True, center=True, min_mapq=10, max_frag_len=100), dict(max_frag_len=0), dict(max_frag_len=2**32 - 1)])
+def test_sam_count_matches_oracle(ctx, oracle, kw):
+    n_chr = 5
+    cols, rchr, rstart, rend = count_inputs(200_000, n_chr, 3000, seed=9)
+    want, code, _ = oracle.count_batch(**cols, n_chr=n_chr, rchr=rchr, rstart=rstart, rend=rend, **kw)
+    assert code == 0 and (want.sum() > 1000 or kw.get("max_frag_len") == 0)
+    chr_off, gs, ge, gi = grouped_regions(rchr, rstart, rend, n_chr)
+    ctx.count_set_regions(chr_off, gs, ge, gi, n_regions=3000)
+    got_cols = dict(cols)
+    if not kw.get("single_end"):
+        got_cols["end_pos"] = None
+    half = 77_777                                                    # two batches: counters accumulate
+    ctx.count_add(**{k: (None if v is None else v[:half]) for k, v in got_cols.items()}, **kw)
+    ctx.count_add(**{k: (None if v is None else v[half:]) for k, v in got_cols.items()}, **kw)
+    got = ctx.count_get()
+    assert len(got) == 3000 and np.array_equal(got[gi], want[gi]) and got[rchr < 0].sum() == 0
+    ctx.count_set_regions(chr_off, gs, ge, gi, n_regions=3000)       # setting the regions again clears the counters
+    assert ctx.count_get().sum() == 0
+
+
+def test_sam_count_edge_cases(ctx, oracle):
+    # no regions at all, one chromosome without regions, a region list with one entry
+    cols, _, _, _ = count_inputs(1000, 2, 1, seed=3)
+    ctx.count_set_regions(np.array([0, 0, 0], dtype=np.int32), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    ctx.count_add(**dict(cols, end_pos=None))
+    assert len(ctx.count_get()) == 0
+    rchr, rstart, rend = np.array([1], np.int32), np.array([0], np.uint32), np.array([2_000_000], np.uint32)
+    want, code, _ = oracle.count_batch(**cols, n_chr=2, rchr=rchr, rstart=rstart, rend=rend)
+    ctx.count_set_regions(np.array([0, 0, 1], dtype=np.int32), rstart, rend)
+    ctx.count_add(**dict(cols, end_pos=None))
+    assert code == 0 and int(ctx.count_get()[0]) == int(want[0]) > 0
+    # the oracle's own order checks (the host does them in the product)
+    cols["pos"] = cols["pos"][::-1].copy()
+    _, code, where = oracle.count_batch(**cols, n_chr=2, rchr=rchr, rstart=rstart, rend=rend)
+    assert code == 1 and where > 0
+    from seqkit_amd.capi import SeqkitHipError
+    with pytest.raises(SeqkitHipError):
+        ctx.count_set_regions(np.array([0, 2, 1], dtype=np.int32), rstart, rend)
+
+
 # ---- f4: sam to fastq sequence() -----------------------------------------------------------------------------
 def bam_rows(n, stride, seed, seq4_stride=None, iupac_frac=0.1):
     """Random BAM-style rows: packed 4-bit codes (mostly 1/2/4/8, some ambiguity codes), raw phred 0..60 with a few 255,
