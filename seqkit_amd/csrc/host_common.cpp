@@ -389,6 +389,279 @@ static std::string gzip_member(const std::string &in)
 	return out;
 }
 
+// ---- BgzfStream ----------------------------------------------------------------------------------------------
+struct Inflater {                      // libdeflate's decompressor, when the library is there
+	void *(*alloc)() = nullptr;
+	void (*free_)(void *) = nullptr;
+	int (*inflate)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+	uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+	Inflater()
+	{
+		if (getenv("SEQKIT_NO_LIBDEFLATE")) return;
+		void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+		if (!h) return;
+		alloc = reinterpret_cast<void *(*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+		free_ = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+		inflate = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(h, "libdeflate_deflate_decompress"));
+		crc = reinterpret_cast<uint32_t (*)(uint32_t, const void *, size_t)>(dlsym(h, "libdeflate_crc32"));
+		if (!alloc || !free_ || !inflate || !crc) alloc = nullptr;
+	}
+};
+
+struct BgzfStream::Impl {
+	struct Block {
+		std::vector<uint8_t> comp;         // the whole BGZF block as read
+		std::vector<uint8_t> data;         // inflated
+		size_t cdata_off = 0, cdata_len = 0;
+		bool done = false, bad = false;
+	};
+	int fd;
+	bool bgzf = false;                     // decided from the first block header
+	// ---- parallel path
+	std::mutex mu;
+	std::condition_variable cv_work, cv_done, cv_room;
+	std::deque<std::shared_ptr<Block>> order;      // blocks in file order (front = next to deliver)
+	std::deque<std::shared_ptr<Block>> todo;       // blocks waiting for a worker
+	bool eof = false, stop = false, read_error = false;
+	std::vector<std::thread> workers;
+	std::thread reader;
+	std::shared_ptr<Block> cur;
+	size_t cur_off = 0;
+	size_t max_in_flight = 64;
+	// ---- plain gzip path
+	z_stream z;
+	std::vector<uint8_t> zin;
+	bool z_eof = false;
+	std::vector<uint8_t> head;             // bytes consumed while sniffing the format
+
+	static bool read_full(int fd, uint8_t *p, size_t n, size_t &got)
+	{
+		got = 0;
+		while (got < n) {
+			const ssize_t r = ::read(fd, p + got, n - got);
+			if (r < 0) { if (errno == EINTR) continue; return false; }
+			if (r == 0) break;
+			got += (size_t)r;
+		}
+		return true;
+	}
+
+	// BSIZE of a BGZF block header (18+ bytes: gzip header with FEXTRA and a 'B','C' subfield), or 0
+	static size_t bgzf_block_size(const uint8_t *h, size_t n, size_t &xlen)
+	{
+		if (n < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
+		xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+		if (12 + xlen > n) return 0;
+		for (size_t o = 12; o + 4 <= 12 + xlen;) {
+			const size_t slen = (size_t)h[o + 2] | ((size_t)h[o + 3] << 8);
+			if (h[o] == 'B' && h[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) return ((size_t)h[o + 4] | ((size_t)h[o + 5] << 8)) + 1;
+			o += 4 + slen;
+		}
+		return 0;
+	}
+
+	void reader_main()
+	{
+		std::vector<uint8_t> hdr(head);                      // first header bytes were read by the constructor
+		for (;;) {
+			size_t got = 0;
+			if (hdr.size() < 18) {
+				const size_t have = hdr.size();
+				hdr.resize(18);
+				if (!read_full(fd, hdr.data() + have, 18 - have, got)) { fail_read(); return; }
+				hdr.resize(have + got);
+			}
+			if (hdr.empty()) break;                          // clean end of file
+			size_t xlen = 0;
+			const size_t bsize = hdr.size() >= 18 ? bgzf_block_size(hdr.data(), hdr.size(), xlen) : 0;
+			auto b = std::make_shared<Block>();
+			if (bsize == 0 || bsize < 12 + xlen + 8) {
+				// a cut-off header is the end of the data; anything else that is not a BGZF block is corrupt
+				if (hdr.size() >= 18) { b->bad = true; b->done = true; push(b, false); }
+				break;
+			}
+			b->comp.resize(bsize);
+			memcpy(b->comp.data(), hdr.data(), 18);
+			if (!read_full(fd, b->comp.data() + 18, bsize - 18, got)) { fail_read(); return; }
+			if (got != bsize - 18) break;                    // file ends inside a block: the data end before it
+			b->cdata_off = 12 + xlen;
+			b->cdata_len = bsize - b->cdata_off - 8;
+			hdr.clear();
+			if (!push(b, true)) return;
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		eof = true;
+		cv_done.notify_all();
+		cv_work.notify_all();
+	}
+	void fail_read()
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		read_error = true; eof = true;
+		cv_done.notify_all();
+		cv_work.notify_all();
+	}
+	bool push(const std::shared_ptr<Block> &b, bool work)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		cv_room.wait(lk, [&] { return stop || order.size() < max_in_flight; });
+		if (stop) return false;
+		order.push_back(b);
+		if (work) { todo.push_back(b); cv_work.notify_one(); }
+		else cv_done.notify_all();
+		return true;
+	}
+	void worker_main()
+	{
+		static const Inflater ld;
+		void *dec = ld.alloc ? ld.alloc() : nullptr;
+		for (;;) {
+			std::shared_ptr<Block> b;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_work.wait(lk, [&] { return stop || !todo.empty() || eof; });
+				if (stop || (todo.empty() && eof)) { if (dec) ld.free_(dec); return; }
+				b = todo.front();
+				todo.pop_front();
+			}
+			const uint8_t *tail = b->comp.data() + b->comp.size() - 8;
+			const uint32_t want_crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+			const uint32_t isize = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
+			bool ok = isize <= (1u << 16);
+			if (ok && isize == 0) {
+				ok = want_crc == 0;                              // an empty block (the end-of-file marker): nothing to inflate
+			} else if (ok) {
+				b->data.resize(isize);
+				if (dec) {
+					size_t out_n = 0;
+					ok = ld.inflate(dec, b->comp.data() + b->cdata_off, b->cdata_len, b->data.data(), isize, &out_n) == 0 && out_n == isize;
+					if (ok) ok = ld.crc(0, b->data.data(), isize) == want_crc;
+				} else {
+					z_stream zs;
+					memset(&zs, 0, sizeof zs);
+					ok = inflateInit2(&zs, -15) == Z_OK;
+					if (ok) {
+						zs.next_in = b->comp.data() + b->cdata_off; zs.avail_in = (uInt)b->cdata_len;
+						zs.next_out = b->data.data(); zs.avail_out = isize;
+						const int rc = ::inflate(&zs, Z_FINISH);
+						ok = rc == Z_STREAM_END && zs.avail_out == 0;
+						inflateEnd(&zs);
+						if (ok) ok = (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->data.data(), isize) == want_crc;
+					}
+				}
+			}
+			std::vector<uint8_t>().swap(b->comp);
+			std::lock_guard<std::mutex> lk(mu);
+			b->bad = !ok;
+			b->done = true;
+			cv_done.notify_all();
+		}
+	}
+
+	bool failed = false;                   // corrupt data seen: what preceded it has been delivered, every later read is -1
+
+	long read_parallel(uint8_t *dst, size_t n)
+	{
+		if (failed) return -1;
+		size_t got = 0;
+		while (got < n) {
+			if (!cur || cur_off == cur->data.size()) {
+				std::unique_lock<std::mutex> lk(mu);
+				if (cur) { cur.reset(); }
+				cv_done.wait(lk, [&] { return (!order.empty() && order.front()->done) || (order.empty() && eof); });
+				if (order.empty()) { if (read_error) { failed = true; if (got == 0) return -1; } break; }
+				cur = order.front();
+				order.pop_front();
+				cur_off = 0;
+				cv_room.notify_one();
+				if (cur->bad) { cur.reset(); failed = true; return got ? (long)got : -1; }
+				continue;
+			}
+			const size_t take = std::min(n - got, cur->data.size() - cur_off);
+			memcpy(dst + got, cur->data.data() + cur_off, take);
+			cur_off += take;
+			got += take;
+		}
+		return (long)got;
+	}
+
+	long read_plain(uint8_t *dst, size_t n)
+	{
+		if (failed) return -1;
+		size_t got = 0;
+		while (got < n) {
+			if (z.avail_in == 0 && !z_eof) {
+				size_t r = 0;
+				if (!read_full(fd, zin.data(), zin.size(), r)) { failed = true; return got ? (long)got : -1; }
+				if (r == 0) z_eof = true;
+				z.next_in = zin.data();
+				z.avail_in = (uInt)r;
+			}
+			if (z.avail_in == 0 && z_eof) break;
+			z.next_out = dst + got;
+			z.avail_out = (uInt)std::min<size_t>(n - got, 1u << 30);
+			const size_t before = z.avail_out;
+			const int rc = ::inflate(&z, Z_NO_FLUSH);
+			got += before - z.avail_out;
+			if (rc == Z_STREAM_END) { inflateReset(&z); continue; }       // next gzip member
+			if (rc != Z_OK && rc != Z_BUF_ERROR) { failed = true; return got ? (long)got : -1; }
+			if (rc == Z_BUF_ERROR && z.avail_in == 0 && z_eof) break;
+		}
+		return (long)got;
+	}
+};
+
+BgzfStream::BgzfStream(int fd) : impl_(new Impl())
+{
+	Impl &m = *impl_;
+	m.fd = fd;
+	m.head.resize(18);
+	size_t got = 0;
+	Impl::read_full(fd, m.head.data(), 18, got);
+	m.head.resize(got);
+	size_t xlen = 0;
+	m.bgzf = got == 18 && Impl::bgzf_block_size(m.head.data(), 18, xlen) != 0;
+	if (m.bgzf) {
+		unsigned n = std::thread::hardware_concurrency();
+		if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
+		if (n < 1) n = 1;
+		if (n > 8) n = 8;
+		m.max_in_flight = (size_t)n * 16;
+		m.reader = std::thread([&m] { m.reader_main(); });
+		for (unsigned i = 0; i < n; i++) m.workers.emplace_back([&m] { m.worker_main(); });
+	} else {
+		memset(&m.z, 0, sizeof m.z);
+		inflateInit2(&m.z, 15 + 32);                         // gzip or zlib wrapper, detected; raw bytes fail like gzread's would not, see below
+		m.zin.resize(1 << 16);
+		memcpy(m.zin.data(), m.head.data(), m.head.size());
+		m.z.next_in = m.zin.data();
+		m.z.avail_in = (uInt)m.head.size();
+	}
+}
+
+BgzfStream::~BgzfStream()
+{
+	Impl &m = *impl_;
+	if (m.bgzf) {
+		{
+			std::lock_guard<std::mutex> lk(m.mu);
+			m.stop = true;
+			m.cv_work.notify_all(); m.cv_room.notify_all(); m.cv_done.notify_all();
+		}
+		if (m.reader.joinable()) m.reader.join();
+		for (auto &t : m.workers) if (t.joinable()) t.join();
+	} else {
+		inflateEnd(&m.z);
+	}
+	if (m.fd > 0) ::close(m.fd);
+	delete impl_;
+}
+
+long BgzfStream::read(void *dst, size_t n)
+{
+	return impl_->bgzf ? impl_->read_parallel(static_cast<uint8_t *>(dst), n) : impl_->read_plain(static_cast<uint8_t *>(dst), n);
+}
+
 void Pool::start()
 {
 	if (!threads.empty()) return;

@@ -81,6 +81,25 @@ private:
 	Impl *impl_;
 };
 
+// ---- BGZF reader ("BGZF/BAM reader, parallel block inflate") ------------------------------
+// A BAM file is a series of BGZF blocks: gzip members of at most 64 KiB whose extra field carries the compressed
+// block size, so block boundaries are known without inflating.  One thread reads raw blocks, a few threads inflate
+// them (libdeflate through dlopen when present, zlib otherwise) and verify the CRC, and read() hands the bytes out in
+// file order.  Input that is gzip but not BGZF is inflated as one zlib stream.  read() is gzread(): the number of
+// bytes delivered (< n only at the end of the data, which is also what a file cut inside a block looks like), or -1
+// when the data are corrupt.
+class BgzfStream {
+public:
+	explicit BgzfStream(int fd);                         // takes the descriptor
+	~BgzfStream();
+	BgzfStream(const BgzfStream &) = delete;
+	BgzfStream &operator=(const BgzfStream &) = delete;
+	long read(void *dst, size_t n);
+	struct Impl;
+private:
+	Impl *impl_;
+};
+
 // ---- buffered stdout -----------------------------------------------------------------------------------
 class Out {
 public:

@@ -11,6 +11,8 @@
 // series of gzip members; after the header every record is block_size:u32 + a 32-byte fixed core) and hands the core
 // columns flag / refID / next_refID / tlen to the device as SoA batches.  Order-dependent pieces stay here, as
 // SURVEY.md §8(e) lists them: the --reads=N early stop and the --on-target sweep (S2, not part of the device path).
+#include <fcntl.h>
+
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -49,13 +51,10 @@ class BamStream {
 public:
 	explicit BamStream(const std::string &path) : path_(path)
 	{
-		if (path == "-") gz_ = gzdopen(0, "rb");
-		else gz_ = gzopen(path.c_str(), "rb");
-		if (!gz_) {
-			if (path == "-") error("Failed to read BAM file from standard input.");
-			error("Cannot open BAM file '%s'", path.c_str());
-		}
-		gzbuffer(gz_, 1 << 20);
+		int fd = 0;
+		if (path != "-") fd = open(path.c_str(), O_RDONLY);
+		if (fd < 0) error("Cannot open BAM file '%s'", path.c_str());
+		bz_.reset(new host::BgzfStream(fd));
 		uint8_t h[8];
 		if (!get(h, 8) || memcmp(h, "BAM\1", 4) != 0) open_fail();
 		if (!skip(le32(h + 4))) open_fail();
@@ -71,7 +70,6 @@ public:
 			if (!get(h, 4)) open_fail();
 		}
 	}
-	~BamStream() { if (gz_) gzclose(gz_); }
 	// Record errors ("BAM file ended prematurely." / "Invalid BAM record.", src/common.rs:150-154) end the stream: next()
 	// returns false and the caller, once it has written what the records before the error produce, calls
 	// raise_deferred() — the point the record-at-a-time reference would have reached.
@@ -81,7 +79,7 @@ public:
 	{
 		if (!err_.empty()) return false;
 		uint8_t h[4];
-		const int r = gzread(gz_, h, 4);
+		const long r = bz_->read(h, 4);
 		if (r == 0) return false;
 		if (r < 0) return rd_fail("Invalid BAM record.");
 		if (r != 4) return rd_fail("BAM file ended prematurely.");
@@ -120,7 +118,7 @@ public:
 	{
 		if (!err_.empty()) return false;
 		uint8_t h[4];
-		const int r = gzread(gz_, h, 4);
+		const long r = bz_->read(h, 4);
 		if (r == 0) return false;
 		if (r < 0) return rd_fail("Invalid BAM record.");
 		if (r != 4) return rd_fail("BAM file ended prematurely.");
@@ -155,7 +153,7 @@ private:
 	{
 		size_t got = 0;
 		while (got < n) {
-			const int r = gzread(gz_, dst + got, (unsigned)(n - got));
+			const long r = bz_->read(dst + got, n - got);
 			if (r <= 0) return false;
 			got += (size_t)r;
 		}
@@ -166,7 +164,7 @@ private:
 	{
 		size_t got = 0;
 		while (got < n) {
-			const int r = gzread(gz_, dst + got, (unsigned)(n - got));
+			const long r = bz_->read(dst + got, n - got);
 			if (r < 0) return rd_fail("Invalid BAM record.");
 			if (r == 0) return rd_fail("BAM file ended prematurely.");
 			got += (size_t)r;
@@ -185,7 +183,7 @@ private:
 	}
 	std::string err_;
 	std::string path_;
-	gzFile gz_ = nullptr;
+	std::unique_ptr<host::BgzfStream> bz_;
 	std::vector<uint8_t> var_;
 };
 

@@ -200,3 +200,45 @@ def test_oracle_cli_under_asan(oracle, tmp_path, golden):
     cu.write_bam(str(bam), [("chr1", 1000)], [dict(tid=0, mtid=0, flag=99, tlen=180, pos=1, mpos=100)])
     a = subprocess.run([str(d / "sam_oracle"), "fragment", "lengths", "--max-frag-size=200", str(bam)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and (b"180" + TAB + b"1" + NL) in a.stdout, a.stderr
+
+
+def test_bgzf_stream_parallel_inflate_unit(tmp_path):
+    """host::BgzfStream: blocks inflated by several threads come out in file order; a file cut inside a block ends the
+    data before that block; a flipped byte is reported as corrupt; plain (non-BGZF) gzip still reads; libdeflate and zlib
+    paths agree."""
+    import gzip
+    import os
+    import subprocess
+    import numpy as np
+    exe = _build_cpp(tmp_path, "bgzf_stream_test")
+    rng = np.random.default_rng(5)
+    raw = bytes(rng.integers(0, 7, size=3_000_000, dtype=np.uint8)) + bytes(rng.integers(0, 256, size=200_000, dtype=np.uint8))
+    blocks = [cu.bgzf_block(raw[i:i + 60000]) for i in range(0, len(raw), 60000)] + [cu.bgzf_block(b"")]
+    f = tmp_path / "x.bgzf"
+
+    def run(env=None):
+        r = subprocess.run([str(exe), str(f)], stdout=subprocess.PIPE, timeout=120, env=dict(os.environ, **(env or {})))
+        return r.returncode, r.stdout
+
+    f.write_bytes(b"".join(blocks))
+    for env in ({}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_THREADS": "3"}):
+        assert run(env) == (0, raw)
+    whole = b"".join(blocks)
+    cut = len(b"".join(blocks[:20])) + 100                                  # inside block 20
+    f.write_bytes(whole[:cut])
+    assert run() == (0, raw[:20 * 60000])
+    f.write_bytes(whole[:len(b"".join(blocks[:20])) + 7])                   # inside a block header
+    assert run() == (0, raw[:20 * 60000])
+    bad = bytearray(whole)
+    bad[len(b"".join(blocks[:10])) + 40] ^= 0x55                            # payload of block 10
+    f.write_bytes(bytes(bad))
+    rc, out = run()
+    assert rc == 3 and out == raw[:10 * 60000]
+    rc, out = run({"SEQKIT_NO_LIBDEFLATE": "1"})
+    assert rc == 3 and out == raw[:10 * 60000]
+    f.write_bytes(gzip.compress(raw[:500_000]) + gzip.compress(raw[500_000:700_000]))    # gzip members without the BGZF field
+    assert run() == (0, raw[:700_000])
+    f.write_bytes(b"")
+    assert run() == (0, b"")
+    f.write_bytes(b"not gzip at all, just text\n" * 10)
+    assert run()[0] == 3
