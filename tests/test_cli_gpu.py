@@ -226,6 +226,41 @@ def test_demultiplex_dry_run_header_barcodes_device_census(bins, tmp_path):
         assert a[0] == b[0] == 0 and a[2] == b[2] and a[1] == b[1] and len(a[1].splitlines()) == 100, (a[2][-300:], b[2][-300:])
 
 
+def test_demultiplex_dry_run_long_and_foreign_barcodes_host_census(bins, tmp_path):
+    """Barcodes the device table cannot key — longer than 31 characters, or (from index files) with bytes outside
+    ACGTNacgtn+ — are counted on the host; the dry-run table must come out the same."""
+    n, L = 2500, 20
+    table = synth.make_sheet(8, L, dual=True, seed=31)                      # 20+1+20 = 41 characters
+    sheet = tmp_path / "sheet.tsv"
+    sheet.write_bytes(b"".join(f"S{i}\t".encode() + table[i].tobytes() + b"\n" for i in range(8)))
+    bc, _ = synth.observe_barcodes(table, n, seed=32, p_exact=0.4, p_sub=0.2, halves=2)
+    seq, qual = synth.make_reads(n, 20, seed=33)
+    headers = [f"@SIM:{i} 1:N:0".encode() + b" BC:" + bc[i].tobytes() for i in range(n)]
+    r1 = tmp_path / "r1.fq"
+    r1.write_bytes(synth.fastq_text(seq, qual, headers=headers))
+    args = ["demultiplex", "--dry-run=2400", str(sheet), str(r1)]
+    for d in ("a", "b"):
+        (tmp_path / d).mkdir()
+    a = cu.run(bins["fasta"][0], args, cwd=tmp_path / "a", env={"SEQKIT_BLOCK_RECORDS": "100"})
+    b = cu.run(bins["fasta"][1], args, cwd=tmp_path / "b")
+    assert a[0] == b[0] == 0 and a[1] == b[1] and a[2] == b[2] and len(a[1].splitlines()) == 100
+    # 8-character index reads with the odd 'R' or '.' in them: device census for the clean ones, host for the rest
+    table = synth.make_sheet(8, 8, seed=34)
+    sheet.write_bytes(b"".join(f"S{i}\t".encode() + table[i].tobytes() + b"\n" for i in range(8)))
+    rng = np.random.default_rng(35)
+    ib = synth.BASES[rng.integers(0, 4, size=(n, 8))]
+    ib[rng.random((n, 8)) < 0.03] = ord("R")
+    ib[rng.random((n, 8)) < 0.01] = ord(".")
+    ones = np.full((n, 8), ord("I"), dtype=np.uint8)
+    i1 = tmp_path / "i1.fq"
+    i1.write_bytes(synth.fastq_text(np.ascontiguousarray(ib), ones, prefix="RUN"))
+    r1.write_bytes(synth.fastq_text(seq, qual, prefix="RUN"))
+    args = ["demultiplex", f"--index1={i1}", "--dry-run=2500", str(sheet), str(r1)]
+    a = cu.run(bins["fasta"][0], args, cwd=tmp_path / "a", env={"SEQKIT_BLOCK_RECORDS": "333"})
+    b = cu.run(bins["fasta"][1], args, cwd=tmp_path / "b")
+    assert a[0] == b[0] == 0 and a[1] == b[1] and a[2] == b[2] and len(a[1].splitlines()) == 100 and b"R" in a[1]
+
+
 def stats_fixture(n, seed, n_hot=30, lower=True):
     rng = np.random.default_rng(seed)
     hot = synth.BASES[rng.integers(0, 4, size=(n_hot, 10))]
