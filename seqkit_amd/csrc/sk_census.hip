@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -42,8 +43,8 @@ struct Census {
 };
 
 constexpr int kCensusStats = 4;          // [0] distinct keys, [1] rows counted, [2] rows rejected, [3] probe overflows
-constexpr u64 kInitialSlots = 1ull << 24;   // 512 MiB: two launches' worth of all-new keys before the first rehash
-constexpr int64_t kCensusChunk = 1 << 24;   // most rows per launch; the table is grown between launches so that it is never
+constexpr u64 kInitialSlots = 1ull << 26;   // 2 GiB of the 288: one launch may then take 32 M rows (SK_CENSUS_SLOTS_LOG2 overrides; tests use it)
+constexpr int64_t kCensusChunk = 1 << 25;   // most rows per launch; the table is grown between launches so that it is never
 constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
 constexpr int kLdsSlots = 2048;
 constexpr int kLdsProbes = 4;
@@ -375,7 +376,9 @@ hipError_t census_create(Census **out, hipStream_t st)
 	Census *cs = new Census();
 	hipError_t e = hipMalloc((void **)&cs->stats, kCensusStats * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
-	if (e == hipSuccess) e = census_alloc_table(cs, kInitialSlots, st);
+	u64 init_slots = kInitialSlots;
+	if (const char *ev = getenv("SK_CENSUS_SLOTS_LOG2")) init_slots = 1ull << atoi(ev);
+	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
 	*out = cs;

@@ -622,27 +622,32 @@ def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle):
         ctx.census_add(np.zeros((4, 40), dtype=np.uint8), L=32)
 
 
-def test_census_grows_past_its_first_table(ctx, oracle):
-    """More distinct barcodes than half the initial table: the table is rehashed between launches, nothing is lost."""
-    n = 9_000_000
+def test_census_grows_past_its_first_table(oracle, monkeypatch):
+    """More distinct barcodes than half the table: it is rehashed between launches, nothing is lost.  (The first table
+    normally has 2^26 slots; a context created with SK_CENSUS_SLOTS_LOG2=16 starts small.)"""
+    import seqkit_amd
+    monkeypatch.setenv("SK_CENSUS_SLOTS_LOG2", "16")
+    n = 3_000_000
     rng = np.random.default_rng(11)
-    vals = rng.integers(0, 4 ** 15, size=n, dtype=np.int64)
-    digits = (vals[:, None] >> (2 * np.arange(15))) & 3
+    vals = rng.integers(0, 4 ** 11, size=n, dtype=np.int64)                   # ~2.1 M distinct 11-mers
+    digits = (vals[:, None] >> (2 * np.arange(11))) & 3
     bc = np.zeros((n, 16), dtype=np.uint8)
-    bc[:, :15] = np.frombuffer(b"ACGT", dtype=np.uint8)[digits]
-    ctx.census_reset()
-    slots0 = ctx.census_stats()["slots"]
-    ctx.census_add(bc, L=15)
-    st = ctx.census_stats()
-    uniq, first, counts = np.unique(vals, return_index=True, return_counts=True)
-    assert st["distinct"] == len(uniq) and st["counted"] == n and st["slots"] > slots0 and st["slots"] >= 2 * st["distinct"]
-    got, total = ctx.census_entries(min_count=2)
-    order = np.argsort(first[counts >= 2], kind="stable")
-    assert total == int((counts >= 2).sum())
-    assert [(c, f) for _, c, f in got] == [(int(c), int(f)) for c, f in zip(counts[counts >= 2][order], first[counts >= 2][order])]
-    hist = ctx.census_count_hist()
-    assert int(hist.sum()) == len(uniq) and int(hist[0]) == int((counts == 1).sum())
-    ctx.census_reset()
+    bc[:, :11] = np.frombuffer(b"ACGT", dtype=np.uint8)[digits]
+    with seqkit_amd.Context(0) as c2:
+        c2.census_reset()
+        slots0 = c2.census_stats()["slots"]
+        assert slots0 == 1 << 16
+        for lo in range(0, n, 700_000):                                       # several host batches, each several launches
+            c2.census_add(bc[lo:lo + 700_000], L=11, row_base=lo)
+        st = c2.census_stats()
+        uniq, first, counts = np.unique(vals, return_index=True, return_counts=True)
+        assert st["distinct"] == len(uniq) and st["counted"] == n and st["slots"] > slots0 and st["slots"] >= 2 * st["distinct"]
+        got, total = c2.census_entries(min_count=3)
+        order = np.argsort(first[counts >= 3], kind="stable")
+        assert total == int((counts >= 3).sum()) > 1000
+        assert [(c, f) for _, c, f in got] == [(int(c), int(f)) for c, f in zip(counts[counts >= 3][order], first[counts >= 3][order])]
+        hist = c2.census_count_hist()
+        assert int(hist.sum()) == len(uniq) and int(hist[0]) == int((counts == 1).sum())
 
 
 def test_errors_are_codes_not_crashes(ctx):

@@ -51,7 +51,7 @@ bench.gen_shard(torch, dev, n, table, seed=4000, chunk=2_000_000,
 torch.cuda.synchronize()
 print(f"arena 0 {a.data_ptr():#x}: {probe(a):.3f} ms", flush=True)
 keep = []
-for i in range(1, 5):
+for i in range(1, int(os.environ.get("ARENAS", "4"))):
     b = torch.empty(total, dtype=torch.uint8, device=dev)
     b.copy_(a)
     torch.cuda.synchronize()
