@@ -127,26 +127,55 @@ __device__ __forceinline__ void store_tail(uint8_t *p, const u32x4 &v, int valid
 // ---------------------------------------------------------------------------------------------------
 // M1 flat: mask by quality over the whole matrix as one byte stream (no row structure involved).
 // ---------------------------------------------------------------------------------------------------
+// A workgroup takes 16 KiB spans (4 x 256 chunks of 16 bytes); a thread's four loads of each input are issued before
+// the first is used, so 8 KiB per wave are in flight, and both the loads and the stores bypass the caches' retention
+// (read-once / write-once data).
 template <int MODE>
 __global__ __launch_bounds__(256) void mask_flat_kernel(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                                         uint8_t *__restrict__ out, int64_t bytes, u32 cl2)
 {
+#ifndef SK_MASK_UNROLL
+#define SK_MASK_UNROLL 4
+#endif
+	constexpr int kUnroll = SK_MASK_UNROLL;
 	const int64_t nchunk = (bytes + 15) >> 4;
-	const int64_t step = (int64_t)gridDim.x * blockDim.x;
-	for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += step) {
-		const int64_t off = c << 4;
-		u32x4 q, s, o, vq;
-		if (off + 16 <= bytes) {
-			q = *reinterpret_cast<const u32x4 *>(qual + off);
-			s = *reinterpret_cast<const u32x4 *>(seq + off);
-			mask_dword4<MODE>(q, s, cl2, o, vq);
-			*reinterpret_cast<u32x4 *>(out + off) = o;
+	const int64_t nspan = (nchunk + 256 * kUnroll - 1) / (256 * kUnroll);
+	for (int64_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+		// every wave owns 4 KiB of the span: chunks wave*256 + k*64 + lane
+		const int64_t c0 = sp * (256 * kUnroll) + (threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+		if ((sp + 1) * (256 * kUnroll) * 16 <= bytes) {                     // the whole span is inside the matrix
+			u32x4 q[kUnroll], sv[kUnroll];
+#pragma unroll
+			for (int k = 0; k < kUnroll; k++) {
+				const int64_t off = (c0 + k * 64) << 4;
+				q[k] = stream_load(qual + off);
+				sv[k] = stream_load(seq + off);
+			}
+#pragma unroll
+			for (int k = 0; k < kUnroll; k++) {
+				u32x4 o, vq;
+				mask_dword4<MODE>(q[k], sv[k], cl2, o, vq);
+				stream_store(out + ((c0 + k * 64) << 4), o);
+			}
 		} else {
-			int valid = (int)(bytes - off);
-			q = load_tail(qual + off, valid);
-			s = load_tail(seq + off, valid);
-			mask_dword4<MODE>(q, s, cl2, o, vq);
-			store_tail(out + off, o, valid);
+			for (int k = 0; k < kUnroll; k++) {
+				const int64_t c = c0 + k * 64;
+				if (c >= nchunk) break;
+				const int64_t off = c << 4;
+				u32x4 q, s, o, vq;
+				if (off + 16 <= bytes) {
+					q = *reinterpret_cast<const u32x4 *>(qual + off);
+					s = *reinterpret_cast<const u32x4 *>(seq + off);
+					mask_dword4<MODE>(q, s, cl2, o, vq);
+					*reinterpret_cast<u32x4 *>(out + off) = o;
+				} else {
+					int valid = (int)(bytes - off);
+					q = load_tail(qual + off, valid);
+					s = load_tail(seq + off, valid);
+					mask_dword4<MODE>(q, s, cl2, o, vq);
+					store_tail(out + off, o, valid);
+				}
+			}
 		}
 	}
 }
@@ -156,8 +185,11 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 {
 	if (bytes <= 0) return hipSuccess;
 	int64_t nchunk = (bytes + 15) >> 4;
-	int64_t want = (nchunk + 255) / 256;
-	int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
+	int64_t want = (nchunk + 256 * SK_MASK_UNROLL - 1) / (256 * SK_MASK_UNROLL);
+	// Fewer waves with more bytes each in flight stream better than many: measured at 16 M x 150 (450 B/read),
+	// workgroups per CU 1: 5.8-6.0, 2: 5.6, 3: 5.9-6.0, 4: 5.5, 8: 5.3 TB/s.
+	static const int wgs_per_cu = getenv("SK_MASK_WGS") ? atoi(getenv("SK_MASK_WGS")) : 3;
+	int grid = (int)(want < (int64_t)n_cu * wgs_per_cu ? want : (int64_t)n_cu * wgs_per_cu);
 	switch (qc.mode) {
 	case 0: mask_flat_kernel<0><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
 	case 1: mask_flat_kernel<1><<<grid, 256, 0, st>>>(seq, qual, out, bytes, qc.cl2); break;
@@ -506,7 +538,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(static_cast<const uint8_t *>(p)) + (p ? byte_off : 0), 0, p ? records : 0, 0x00020000);
 }
 
-template <int MODE, bool DEMUX>
+template <int MODE, bool DEMUX, int SLOTS>
 __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 	}
 	const int64_t tstep = (int64_t)gridDim.x * nwave;
 	int64_t tile_end = ntiles;                       // first tile NOT owned by this wave's run (set below)
-	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + kSlots - 1) / kSlots * kSlots;   // chunks per full tile, rounded up to the slot count
+	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;   // chunks per full tile, rounded up to the slot count
 	const int voff = lane * 16;
 
 	// descriptors of the two input streams of item (t, k); a tile past the end gets zero records
@@ -565,9 +597,9 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 	}
 	rsrc_t rq, rs;
 	in_rsrc(t, 0, rq, rs);
-	u32x4 qv[kSlots], sv[kSlots];
+	u32x4 qv[SLOTS], sv[SLOTS];
 #pragma unroll
-	for (int i = 0; i < kSlots; i++) {
+	for (int i = 0; i < SLOTS; i++) {
 		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + i * 1024, 0, kAuxStream);
 		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
 	}
@@ -604,17 +636,17 @@ __global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, con
 			asm volatile("" : "+v"(len_ld));
 
 			// ---- stream phase: 16 B per lane, 1 KiB per wave instruction, two chunks in flight ------------
-			for (int c = 0; c < nchunkp; c += kSlots) {
-				const bool last = c + kSlots >= nchunkp;
+			for (int c = 0; c < nchunkp; c += SLOTS) {
+				const bool last = c + SLOTS >= nchunkp;
 #pragma unroll
-				for (int i = 0; i < kSlots; i++) {
+				for (int i = 0; i < SLOTS; i++) {
 					const int off = (c + i) * 1024 + voff;
 					u32x4 o, vq;
 					mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
 					__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
 					if (do_trim && off < nb) *reinterpret_cast<u32x4 *>(tile + off) = vq;
-					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + kSlots * 1024, 0, kAuxStream);
-					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + kSlots * 1024, 0, kAuxStream);
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
 				}
 			}
 			rq = nq; rs = ns;
@@ -1080,15 +1112,15 @@ static const void *tile_pass2_fn(int mode)
 	}
 }
 
-template <bool DEMUX>
+template <bool DEMUX, int SLOTS>
 static const void *tile_pass_fn(int mode)
 {
 	switch (mode) {
-	case 0: return reinterpret_cast<const void *>(tile_pass_kernel<0, DEMUX>);
-	case 1: return reinterpret_cast<const void *>(tile_pass_kernel<1, DEMUX>);
-	case 2: return reinterpret_cast<const void *>(tile_pass_kernel<2, DEMUX>);
-	case 3: return reinterpret_cast<const void *>(tile_pass_kernel<3, DEMUX>);
-	default: return reinterpret_cast<const void *>(tile_pass_kernel<4, DEMUX>);
+	case 0: return reinterpret_cast<const void *>(tile_pass_kernel<0, DEMUX, SLOTS>);
+	case 1: return reinterpret_cast<const void *>(tile_pass_kernel<1, DEMUX, SLOTS>);
+	case 2: return reinterpret_cast<const void *>(tile_pass_kernel<2, DEMUX, SLOTS>);
+	case 3: return reinterpret_cast<const void *>(tile_pass_kernel<3, DEMUX, SLOTS>);
+	default: return reinterpret_cast<const void *>(tile_pass_kernel<4, DEMUX, SLOTS>);
 	}
 }
 
@@ -1142,9 +1174,14 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		if (!fuse_demux) b.bc = nullptr;
 		return plan_and_launch(fuse_demux ? tile_pass2_fn<true>(b.qc.mode) : tile_pass2_fn<false>(b.qc.mode), b, row_bytes, fuse_demux, 4, n_cu, st, 2);
 	}
-	if (fuse_demux) return plan_and_launch(tile_pass_fn<true>(b.qc.mode), b, row_bytes, true, 8, n_cu, st);
+	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 8, n_cu, st);
 	b.bc = nullptr;
-	return plan_and_launch(tile_pass_fn<false>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
+	// one mate = two read streams at most: keep four chunks per stream in flight instead of two (trim alone
+	// 3.6 -> 4.0 TB/s, mask + trim of one mate 4.9 -> 5.1 TB/s at 16 M x 150; no gain with two mates or the barcode phase)
+	int active = 0;
+	for (int mi = 0; mi < b.n_mates; mi++) active += (b.mate[mi].out_seq || b.mate[mi].lowest_k) ? 1 : 0;
+	if (active == 1) return plan_and_launch(tile_pass_fn<false, 4>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
+	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
