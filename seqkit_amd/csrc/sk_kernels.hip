@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(256) void trim_rows_global_kernel(const uint8_t *__
 
 // LDS layout + workgroup shape for a tile kernel; the grid comes from the occupancy API so that every
 // workgroup of the persistent grid is resident (a queued workgroup would run its whole share of tiles late).
-static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_bytes, bool with_tables, int max_nw, int n_cu, hipStream_t st, int images = 1)
+static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_bytes, bool with_tables, int max_nw, int n_cu, hipStream_t st, int images = 1,
+                                  int max_wg = 0)
 {
 	static const int kLdsPerCu = 160 * 1024;
 	LdsPlan lp{};
@@ -1046,19 +1047,21 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 	lp.tile_slot = kLdsPad + ((kTileRows * row_bytes + 15) & ~15) + kLdsPad;
 	// the shape search (occupancy queries, LDS opt-in) is cached per (device, kernel, LDS layout): small batches from
 	// the command-line hosts launch thousands of times with the same shape
-	struct Shape { int dev; const void *fn; int tiles_off, tile_slot, max_nw, nw, wg; };
+	struct Shape { int dev; const void *fn; int tiles_off, tile_slot, max_nw, max_wg, nw, wg; };
 	static std::mutex cache_m;
 	static std::vector<Shape> cache;
-	static const int env_nw = getenv("SK_TILE_WAVES") ? atoi(getenv("SK_TILE_WAVES")) : 0;      // tuning knobs (tools/ablate.py)
-	static const int env_wg = getenv("SK_TILE_WGS") ? atoi(getenv("SK_TILE_WGS")) : 0;
+	// tuning knobs (tools/ablate.py, tools/waves_exp.py): read per launch so that one process can compare shapes on the same buffers
+	const int env_nw = getenv("SK_TILE_WAVES") ? atoi(getenv("SK_TILE_WAVES")) : 0;
+	const int env_wg = getenv("SK_TILE_WGS") ? atoi(getenv("SK_TILE_WGS")) : 0;
+	const bool use_cache = env_nw == 0 && env_wg == 0;
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
 	int best_nw = 0, best_wg = 0, best_waves = 0;
-	{
+	if (use_cache) {
 		std::lock_guard<std::mutex> lk(cache_m);
 		for (const Shape &c : cache)
-			if (c.dev == dev && c.fn == fn && c.tiles_off == lp.tiles_off && c.tile_slot == lp.tile_slot * images && c.max_nw == max_nw) {
+			if (c.dev == dev && c.fn == fn && c.tiles_off == lp.tiles_off && c.tile_slot == lp.tile_slot * images && c.max_nw == max_nw && c.max_wg == max_wg) {
 				best_nw = c.nw; best_wg = c.wg; best_waves = c.nw * c.wg;
 				break;
 			}
@@ -1066,19 +1069,19 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 	if (best_waves == 0) {
 		e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
 		if (e != hipSuccess) return e;
-		for (int nw = max_nw; nw >= 1; nw >>= 1) {
-			if (env_nw && nw != env_nw && env_nw <= max_nw) continue;
+		for (int nw = (env_nw > 0 && env_nw <= 8) ? env_nw : max_nw; nw >= 1; nw >>= 1) {
 			const int lds = lp.tiles_off + nw * images * lp.tile_slot;
 			if (lds > kLdsPerCu) continue;
 			int wg = 0;
 			e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
 			if (e != hipSuccess) return e;
-			if (env_wg > 0 && wg > env_wg) wg = env_wg;
+			if (env_wg > 0) { if (wg > env_wg) wg = env_wg; }
+			else if (max_wg > 0 && wg > max_wg) wg = max_wg;
 			if (wg * nw > best_waves) { best_waves = wg * nw; best_nw = nw; best_wg = wg; }
 		}
-		if (best_waves > 0) {
+		if (best_waves > 0 && use_cache) {
 			std::lock_guard<std::mutex> lk(cache_m);
-			cache.push_back({dev, fn, lp.tiles_off, lp.tile_slot * images, max_nw, best_nw, best_wg});
+			cache.push_back({dev, fn, lp.tiles_off, lp.tile_slot * images, max_nw, max_wg, best_nw, best_wg});
 		}
 	}
 	if (best_waves == 0) return hipErrorInvalidValue;
@@ -1174,14 +1177,17 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		if (!fuse_demux) b.bc = nullptr;
 		return plan_and_launch(fuse_demux ? tile_pass2_fn<true>(b.qc.mode) : tile_pass2_fn<false>(b.qc.mode), b, row_bytes, fuse_demux, 4, n_cu, st, 2);
 	}
-	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 8, n_cu, st);
+	// Shape of the phase kernel: EIGHT resident waves per CU, as two workgroups of four.  More waves keep more requests
+	// in flight than HBM serves well (tools/waves_exp.py, same buffers, 62.5 M clusters: 16 waves 9.52 ms, 8 waves
+	// 9.31 ms; at 16 M clusters +5 % for the fused pass, +14 % for mask + trim of two mates, +10 % for one mate).
+	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 4, n_cu, st, 1, 2);
 	b.bc = nullptr;
 	// one mate = two read streams at most: keep four chunks per stream in flight instead of two (trim alone
 	// 3.6 -> 4.0 TB/s, mask + trim of one mate 4.9 -> 5.1 TB/s at 16 M x 150; no gain with two mates or the barcode phase)
 	int active = 0;
 	for (int mi = 0; mi < b.n_mates; mi++) active += (b.mate[mi].out_seq || b.mate[mi].lowest_k) ? 1 : 0;
-	if (active == 1) return plan_and_launch(tile_pass_fn<false, 4>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
-	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 8, n_cu, st);
+	if (active == 1) return plan_and_launch(tile_pass_fn<false, 4>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
+	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1508,7 +1514,8 @@ hipError_t launch_bam_fragments(const uint16_t *flag, const int32_t *tid, const 
 	const u32 ulo = lo > 0x80000000ll ? 0xffffffffu : (u32)lo, uhi = hi < 0 ? 0u : (u32)hi;
 	const bool empty = hi < 0 || lo > hi;
 	int64_t want = (n + 2047) / 2048;
-	int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
+	static const int wgs = getenv("SK_BAM_WGS") ? atoi(getenv("SK_BAM_WGS")) : 2;      // 1/2/3/4/8 per CU: 48 (flag+tlen) / 76 / 75 / 71 / 69 % of HBM peak
+	int grid = (int)(want < (int64_t)n_cu * wgs ? want : (int64_t)n_cu * wgs);
 	bam_fragments_kernel<<<grid, 256, 0, st>>>(flag, tid, mtid, tlen, n, empty ? 1u : ulo, empty ? 0u : uhi, keep_bits, kept);
 	return hipGetLastError();
 }
@@ -1523,7 +1530,8 @@ hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const 
 	const bool aligned = (((uintptr_t)flag | (want_hist ? ((uintptr_t)tid | (uintptr_t)mtid | (uintptr_t)tlen) : 0)) & 15u) == 0;
 	if (aligned) {
 		int64_t want = (n + 2047) / 2048;
-		int grid = (int)(want < (int64_t)n_cu * 4 ? want : (int64_t)n_cu * 4);
+		static const int wgs = getenv("SK_BAM_WGS") ? atoi(getenv("SK_BAM_WGS")) : 2;      // 1/2/3/4/8 per CU: 48 (flag+tlen) / 76 / 75 / 71 / 69 % of HBM peak
+		int grid = (int)(want < (int64_t)n_cu * wgs ? want : (int64_t)n_cu * wgs);
 		bam_flag_tlen_kernel<<<grid, 256, lds_bins * 4, st>>>(flag, tid, mtid, tlen, n, max_frag, out, want_counters, want_hist, lds_bins);
 	} else {
 		int64_t want = (n + 255) / 256;
