@@ -1496,7 +1496,8 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 	// rl = e / dpr as a multiply-high: exact while e * dpr < 2^32, and e < 64 * dpr
 	const u32 inv = (dpr > 1 && dpr < 8192u) ? (u32)(((1ull << 32) + dpr - 1) / dpr) : 0u;
 	const int64_t ntiles = (n + 63) / 64;
-	const int grid = (int)(ntiles < (int64_t)n_cu * 8 ? ntiles : (int64_t)n_cu * 8);
+	static const int wgs = getenv("SK_SEQ_WGS") ? atoi(getenv("SK_SEQ_WGS")) : 8;
+	const int grid = (int)(ntiles < (int64_t)n_cu * wgs ? ntiles : (int64_t)n_cu * wgs);
 	const u32 m4 = (u32)(min_baseq & 0xFF) * 0x01010101u;
 	if ((min_baseq & 0xFF) < 128)
 		bam_sequence_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
