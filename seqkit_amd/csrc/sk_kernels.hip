@@ -214,6 +214,16 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 // ---------------------------------------------------------------------------------------------------
 // The four running sums inside a dword come from v_dot4_u32_u8 with byte-select multipliers, so they are
 // independent of each other (no 4-deep add chain) and cost one VALU op per byte.
+//
+// Since K_j = U_j*2^11 + j with j < 2^11, the break condition U_j > 50 is K_j >= 51*2^11 — one constant for every j.
+// A dword is therefore handled whole: its four keys give Kmin and Kmax (two v_min3 / v_max3 pairs); while
+// Kmax < 51*2^11 nothing broke and Kmin is merged into the running best.  The dword in which a lane stops — a key at
+// or above the limit, or the row's last, partial dword — is only REMEMBERED (its index and the running sum before it);
+// after the loop every lane replays its own stop dword byte by byte.  That takes the per-byte compare / mask / select
+// chain and most of the scalar bookkeeping out of the loop (33 -> 21 VALU and 25 -> 11 SALU per dword step), and
+// the next dword's LDS read is issued before the current one is used.
+constexpr int kBreakKey = 51 << kKeyBits;
+
 template <bool UNIFORM_LEN>
 __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
@@ -221,33 +231,55 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	const u32 sh = (u32)end & 3u;
 	int a = end & ~3;
 	u32 hi = *reinterpret_cast<const u32 *>(tile + a);
+	a = max(a - 4, -4);                                       // rows shorter than the scan stay inside the front pad
+	u32 lo = *reinterpret_cast<const u32 *>(tile + a);
 	u32 T = 0;
 	int best = 0;
 	bool alive = active;
+	int stop_jj = -1;                                         // the dword this lane stopped in (-1: none yet)
+	u32 stop_T = 0, stop_d = 0;                               // running sum before that dword, and the dword itself
 	const int ndw = (maxlen + 3) >> 2;
+	const int step = 1 - m * (1 << kKeyBits);                 // C_j = j - j*m*2^11 = j * step
 	for (int jj = 0; jj < ndw; jj++) {
-		a = max(a - 4, -4);                                   // rows shorter than the scan stay inside the front pad
-		u32 lo = *reinterpret_cast<const u32 *>(tile + a);
-		u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);       // bytes [end-4(jj+1), end-4jj) of the image
+		const u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh); // bytes [end-4(jj+1), end-4jj) of the image
 		hi = lo;
+		a = max(a - 4, -4);
+		lo = *reinterpret_cast<const u32 *>(tile + a);        // next step's dword, in flight during this one
+		const u32 T0 = T;
 		u32 Ts[4];
 		Ts[0] = __builtin_amdgcn_udot4(d, 0x01000000u, T, false);
 		Ts[1] = __builtin_amdgcn_udot4(d, 0x01010000u, T, false);
 		Ts[2] = __builtin_amdgcn_udot4(d, 0x01010100u, T, false);
 		Ts[3] = __builtin_amdgcn_udot4(d, 0x01010101u, T, false);
 		T = Ts[3];
+		const int c0 = (4 * jj + 1) * step;                   // scalar
+		const int K0 = (int)(Ts[0] << kKeyBits) + c0;
+		const int K1 = (int)(Ts[1] << kKeyBits) + (c0 + step);
+		const int K2 = (int)(Ts[2] << kKeyBits) + (c0 + 2 * step);
+		const int K3 = (int)(Ts[3] << kKeyBits) + (c0 + 3 * step);
+		const int kmin = min(min(K0, K1), min(K2, K3));
+		const int kmax = max(max(K0, K1), max(K2, K3));
+		bool whole = kmax < kBreakKey;                        // no byte of this dword breaks
+		if (UNIFORM_LEN) whole = whole && (4 * jj + 4 <= maxlen);     // scalar: false only in the row's last, partial dword
+		else whole = whole && (4 * jj + 4 <= len);
+		const bool stops = alive && !whole;
+		stop_jj = stops ? jj : stop_jj;
+		stop_T = stops ? T0 : stop_T;
+		stop_d = stops ? d : stop_d;
+		alive = alive && whole;
+		best = alive ? min(best, kmin) : best;
+		if (__ballot(alive) == 0ull) break;
+	}
+	if (stop_jj >= 0) {                                       // replay the stop dword: src/fasta_trim_by_quality.rs:33-41 byte by byte
+		u32 t = stop_T;
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			const int j = 4 * jj + i + 1;                     // bytes consumed so far, wave-uniform
-			const int jm = j * m;                             // scalar
-			bool ok = (int)Ts[i] <= 50 + jm;
-			if (!UNIFORM_LEN) ok = ok && (j <= len);
-			else ok = ok && (j <= maxlen);                    // scalar condition: only the last dword can fail it
-			alive = alive && ok;
-			int K = (int)Ts[i] * (1 << kKeyBits) + (j - jm * (1 << kKeyBits));
-			best = alive ? min(best, K) : best;
+			const int j = 4 * stop_jj + i + 1;
+			t += (stop_d >> (8 * (3 - i))) & 0xFFu;
+			const int K = (int)(t << kKeyBits) + j * step;
+			if (j > len || K >= kBreakKey) break;
+			best = min(best, K);
 		}
-		if (__ballot(alive) == 0ull) break;
 	}
 	return len - (best & ((1 << kKeyBits) - 1));
 }
@@ -529,6 +561,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #ifndef SK_SLOTS
 #define SK_SLOTS 2
 #endif
+#ifndef SK_SLOTS1
+#define SK_SLOTS1 4
+#endif
 constexpr int kSlots = SK_SLOTS;                      // 1 KiB chunk loads in flight per wave and stream
 constexpr int kAuxStream = (SK_NT & 1) ? 2 : 0;      // nt on the read-once streams
 constexpr int kAuxStreamSt = (SK_NT & 2) ? 2 : 0;
@@ -539,7 +574,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int
 }
 
 template <int MODE, bool DEMUX, int SLOTS>
-__global__ __launch_bounds__(512, 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
+__global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction: make it an SGPR
@@ -1182,11 +1217,18 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	// 9.31 ms; at 16 M clusters +5 % for the fused pass, +14 % for mask + trim of two mates, +10 % for one mate).
 	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 4, n_cu, st, 1, 2);
 	b.bc = nullptr;
-	// one mate = two read streams at most: keep four chunks per stream in flight instead of two (trim alone
-	// 3.6 -> 4.0 TB/s, mask + trim of one mate 4.9 -> 5.1 TB/s at 16 M x 150; no gain with two mates or the barcode phase)
+	// One mate = two read streams at most: keep four chunks per stream in flight instead of two (mask + trim of one
+	// mate 4.9 -> 5.1 TB/s at 16 M x 150; no gain with two mates or the barcode phase).  Trim alone reads ONE stream and
+	// spends most of its time in the scan: there the whole next tile (ten chunks at 150 bp) is kept in flight, which the
+	// eight-wave shape has the registers for (3.6 -> 3.9 -> 4.3 TB/s with 2 / 4 / 10 slots on read-like qualities).
 	int active = 0;
-	for (int mi = 0; mi < b.n_mates; mi++) active += (b.mate[mi].out_seq || b.mate[mi].lowest_k) ? 1 : 0;
-	if (active == 1) return plan_and_launch(tile_pass_fn<false, 4>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
+	bool any_mask = false;
+	for (int mi = 0; mi < b.n_mates; mi++) {
+		active += (b.mate[mi].out_seq || b.mate[mi].lowest_k) ? 1 : 0;
+		any_mask = any_mask || b.mate[mi].out_seq;
+	}
+	if (active == 1 && !any_mask) return plan_and_launch(tile_pass_fn<false, 10>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
+	if (active == 1) return plan_and_launch(tile_pass_fn<false, SK_SLOTS1>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
 	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
 }
 
