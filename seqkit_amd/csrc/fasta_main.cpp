@@ -351,7 +351,7 @@ struct HostCensus {                                  // what the device table ca
 
 // Every barcode that can be among the `need` most frequent ones, in first-seen order.  A small census is fetched
 // whole; from a large one only the barcodes whose count reaches the power of two that still leaves `need` of them.
-static std::vector<CensusEnt> census_fetch(const HostCensus &hc, size_t need)
+static std::vector<CensusEnt> census_fetch(const HostCensus &hc, size_t need, int64_t dev_first_mul = 1)
 {
 	std::vector<CensusEnt> all;
 	sk_ctx *ctx = host::gpu();
@@ -372,7 +372,7 @@ static std::vector<CensusEnt> census_fetch(const HostCensus &hc, size_t need)
 	check(sk_census_entries(ctx, min_count, dev.data(), dev.size(), &total), "sk_census_entries");
 	if (total != expect) error("census changed while it was read (%llu != %llu).", (unsigned long long)total, (unsigned long long)expect);
 	all.reserve(dev.size() + hc.ents.size());
-	for (const sk_census_entry &e : dev) all.push_back({e.barcode, e.count, e.first_row});
+	for (const sk_census_entry &e : dev) all.push_back({e.barcode, e.count, e.first_row * dev_first_mul});
 	for (const CensusEnt &e : hc.ents) all.push_back(e);
 	std::stable_sort(all.begin(), all.end(), [](const CensusEnt &a, const CensusEnt &b) { return a.first < b.first; });
 	return all;
@@ -433,7 +433,8 @@ static int statistics(int argc, char **argv)
 				memcpy(rows.data() + nrows * kCensusStride, bc, n);
 				if (++nrows == kBatch) flush();
 			} else {
-				longs.add(std::string(bc, n), row_base + (int64_t)nrows);
+				// between the device rows before and after it: device row i is first-seen at 2i (census_fetch below)
+				longs.add(std::string(bc, n), 2 * (row_base + (int64_t)nrows) - 1);
 			}
 		}
 		if (line[0] == '@') { for (int k = 0; k < 3; k++) read(skip); }     // :30-31
@@ -446,7 +447,7 @@ static int statistics(int argc, char **argv)
 	snprintf(buf, sizeof buf, "Total sequence records: %llu\n", (unsigned long long)total_records);       // :41
 	host::out().write(buf, strlen(buf));
 	host::out().write("Most frequent sample barcodes:\n");                  // :43
-	std::vector<CensusEnt> ents = census_fetch(longs, 100);
+	std::vector<CensusEnt> ents = census_fetch(longs, 100, 2);
 	print_most_frequent(ents);
 	return 0;
 }

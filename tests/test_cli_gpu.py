@@ -302,6 +302,15 @@ def test_statistics_cli(bins, tmp_path):
     gz.write_bytes(gzip.compress(text))
     both(bins, "fasta", ["statistics", str(gz)], tmp_path)
     both(bins, "fasta", ["statistics", "-"], tmp_path, stdin=text)
+    # order among equal counts when device-keyed (<= 31 characters) and host-keyed (longer) barcodes interleave
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(160):
+        ln = 40 if i % 3 == 1 else 12
+        recs.append(b"@r%d BC:" % i + synth.BASES[rng.integers(0, 4, size=ln)].tobytes() + b"\nAC\n+\nII\n")
+    fq.write_bytes(b"".join(recs))
+    a, *_ = both(bins, "fasta", ["statistics", str(fq)], tmp_path)
+    assert a[1].count(b": 1\n") == 100
 
 
 def test_statistics_cli_errors_and_small_tables(bins, tmp_path):
