@@ -377,7 +377,10 @@ hipError_t census_create(Census **out, hipStream_t st)
 	hipError_t e = hipMalloc((void **)&cs->stats, kCensusStats * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
 	u64 init_slots = kInitialSlots;
-	if (const char *ev = getenv("SK_CENSUS_SLOTS_LOG2")) init_slots = 1ull << atoi(ev);
+	if (const char *ev = getenv("SK_CENSUS_SLOTS_LOG2")) {
+		const int lg = atoi(ev);
+		if (lg >= 10 && lg <= 32) init_slots = 1ull << lg;
+	}
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
 	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
@@ -454,6 +457,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 			const int64_t room = (int64_t)(cs->slots / 2) - (int64_t)cs->distinct;
 			const int64_t least = nr < kCensusMinChunk ? nr : kCensusMinChunk;
 			if (room >= least) nr = nr < room ? nr : room;
+			if (nr < n - o && nr >= 64) nr &= ~(int64_t)63;       // later launches start on a tile (and dword) boundary of the matrix
 			else e = census_reserve(cs, (u64)nr, n_cu, st);
 			if (e != hipSuccess) return e;
 		}
