@@ -169,6 +169,7 @@ static int trim_by_quality(int argc, char **argv)
 	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_TRIM);
 	{ host::LineReader probe(pos[0]); }                                     // :12  FileReader::new comes before the parse (error order)
 	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :13
+	host::gpu_warmup();
 	host::run_block_pipeline(pos[0], 4, [min_baseq](const char *d, size_t n, bool, host::BlockResult &res) { trim_block(d, n, min_baseq, res); });
 	return 0;
 }
@@ -272,6 +273,7 @@ static int mask_by_quality(int argc, char **argv)
 	if (!host::parse_args(argc, argv, 4, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_MASK);
 	{ host::LineReader probe(pos[0]); }                                     // :13
 	const uint8_t min_baseq = parse_min_baseq(pos[1]);                      // :14
+	host::gpu_warmup();
 	host::run_block_pipeline(pos[0], 4, [min_baseq](const char *d, size_t n, bool, host::BlockResult &res) { mask_block(d, n, min_baseq, res); });
 	return 0;
 }
@@ -403,6 +405,7 @@ static int statistics(int argc, char **argv)
 	std::vector<std::string> pos;
 	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_STATS);
 	host::LineReader fastq(pos[0]);                                         // :14
+	host::gpu_warmup();
 	check(sk_census_reset(host::gpu()), "sk_census_reset");
 	size_t kBatch = 1u << 20;
 	if (const char *e = getenv("SEQKIT_BLOCK_RECORDS")) kBatch = std::max<size_t>(1, (size_t)atoll(e));     // tests use tiny batches
@@ -714,6 +717,7 @@ static int demultiplex(int argc, char **argv)
 	for (int k = 1; k <= 2; k++)
 		if (!opts[k].value.empty()) { { host::LineReader probe(opts[k].value); } files[2 + nindex].reset(new host::RecordBlocks(opts[k].value, 4)); nindex++; }
 
+	host::gpu_warmup();
 	fputs("Reading sample sheet...\n", stderr);                             // :58
 	std::vector<Sample> samples;
 	g_samples = &samples;

@@ -783,15 +783,37 @@ std::mutex &gpu_mutex()
 	return m;
 }
 
+// The context takes a few hundred ms to create (runtime start-up, code object load).  gpu_warmup() starts that in the
+// background as soon as a command knows it will need the device, so that it overlaps opening and reading the input;
+// a failure stays silent until gpu() is actually called.
+struct GpuInit { int rc = SK_OK; sk_ctx *ctx = nullptr; std::string err; };
+static GpuInit create_ctx()
+{
+	GpuInit r;
+	int dev = 0;
+	if (const char *e = getenv("SEQKIT_GPU")) dev = atoi(e);
+	r.rc = sk_create(dev, &r.ctx);
+	if (r.rc != SK_OK) r.err = sk_last_error(nullptr);
+	return r;
+}
+static std::mutex g_warm_m;
+static std::shared_future<GpuInit> g_warm;
+
+void gpu_warmup()
+{
+	std::lock_guard<std::mutex> lk(g_warm_m);
+	if (!g_warm.valid()) g_warm = std::async(std::launch::async, create_ctx).share();
+}
+
 sk_ctx *gpu()
 {
 	static sk_ctx *ctx = nullptr;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		int dev = 0;
-		if (const char *e = getenv("SEQKIT_GPU")) dev = atoi(e);
-		const int rc = sk_create(dev, &ctx);
-		if (rc != SK_OK) error("No usable MI355X for the seqkit HIP path (%s); this build has no CPU fallback.", sk_last_error(nullptr));
+		gpu_warmup();
+		const GpuInit r = g_warm.get();
+		if (r.rc != SK_OK) error("No usable MI355X for the seqkit HIP path (%s); this build has no CPU fallback.", r.err.c_str());
+		ctx = r.ctx;
 	});
 	return ctx;
 }

@@ -113,6 +113,7 @@ Out &out();
 
 // ---- the GPU context (created on first use; no CPU fallback) -------------------------------------------
 sk_ctx *gpu();
+void gpu_warmup();                                       // start creating the context in the background (silent on failure)
 // a ctx is used by one thread at a time: worker threads take this lock around their sk_* calls
 std::mutex &gpu_mutex();
 

@@ -217,6 +217,7 @@ static int statistics(int argc, char **argv)
 	if (!host::parse_args(argc, argv, 2, opts, pos, 1) || pos.size() != 1) error("Invalid arguments.\n%s", USAGE_STATS);
 	const std::string bam_path = expand_home(pos[0]), targets_path = expand_home(opts[0].value);     // :17-18
 	const int64_t max_frag_len = 5000;                                                                 // :19
+	host::gpu_warmup();
 	BamStream bam(bam_path);
 
 	std::vector<std::vector<Region>> target_regions;                                                   // :26-54
@@ -326,6 +327,7 @@ static int fragment_lengths(int argc, char **argv)
 	if (max_frag > 200000000ull) error("--max-frag-size above 200000000 is not supported by this build.");
 	std::vector<uint64_t> hist(max_frag + 1, 0);                                                       // :27
 	uint64_t total = 0;
+	host::gpu_warmup();
 	BamStream bam(pos[0]);                                                                            // :30
 	Columns col;
 	BamCore c;
@@ -387,6 +389,7 @@ static int fragments(int argc, char **argv)                        // src/sam_fr
 	int64_t min_size, max_size;
 	if (!parse_i64(opts[0].value, min_size)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--min-size)");   // :17
 	if (!parse_i64(opts[1].value, max_size)) panic("called `Result::unwrap()` on an `Err` value: ParseIntError (--max-size)");   // :18
+	host::gpu_warmup();
 	BamStream bam(pos[0]);
 	Columns col;
 	BamCore c;
@@ -466,6 +469,7 @@ static int count(int argc, char **argv)                            // src/sam_co
 		}
 	}
 	fprintf(stderr, "Counting %s...\n", single_end ? "reads" : "DNA fragments");                                            // :34-35
+	host::gpu_warmup();
 	BamStream bam(pos[0]);                                                                                                 // :36
 	for (const std::string &nm : bam.names)                                                                                // :37-38
 		if (!host::utf8_valid(reinterpret_cast<const uint8_t *>(nm.data()), nm.size())) panic("called `Result::unwrap()` on an `Err` value: Utf8Error");
@@ -616,6 +620,7 @@ static int to_reads(int argc, char **argv)
 		out_single.gz.reset(new host::GzWriter(pos[1] + "." + ext + ".gz"));
 		host::at_exit_flush(close_sinks);
 	}
+	host::gpu_warmup();
 	BamStream bam(pos[0]);                                                                                   // :96
 	PendingReads reads_1, reads_2;
 
