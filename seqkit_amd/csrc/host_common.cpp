@@ -54,6 +54,14 @@ bool utf8_valid(const uint8_t *s, size_t n)
 {
 	size_t i = 0;
 	while (i < n) {
+		// ASCII runs, eight bytes at a time (FASTQ is all ASCII: this is the whole cost of the check in practice)
+		while (i + 8 <= n) {
+			uint64_t w;
+			memcpy(&w, s + i, 8);
+			if (w & 0x8080808080808080ull) break;
+			i += 8;
+		}
+		if (i >= n) break;
 		const uint8_t b = s[i];
 		if (b < 0x80) { i++; continue; }
 		size_t need;
