@@ -876,6 +876,43 @@ struct RawSource {
 
 }  // namespace
 
+static size_t count_newlines(const char *p, size_t n)
+{
+	size_t cnt = 0, i = 0;
+	const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full, knl = 0x0A0A0A0A0A0A0A0Aull;
+	for (; i + 8 <= n; i += 8) {
+		uint64_t w;
+		memcpy(&w, p + i, 8);
+		const uint64_t x = w ^ knl;                              // zero bytes where the input has a newline
+		const uint64_t t = ~(((x & k7f) + k7f) | x | k7f);      // 0x80 exactly in the zero bytes
+		cnt += (size_t)__builtin_popcountll(t);
+	}
+	for (; i < n; i++) cnt += p[i] == '\n';
+	return cnt;
+}
+
+// consume up to `want` lines of [p, p+n): returns the bytes consumed (ending right after a newline, or n when the
+// buffer runs out first) and subtracts the lines found from `want`
+static size_t take_lines(const char *p, size_t n, size_t &want)
+{
+	size_t i = 0;
+	const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full, knl = 0x0A0A0A0A0A0A0A0Aull;
+	while (want > 0 && i + 8 <= n) {
+		uint64_t w;
+		memcpy(&w, p + i, 8);
+		const uint64_t x = w ^ knl;
+		const uint64_t t = ~(((x & k7f) + k7f) | x | k7f);
+		const size_t c = (size_t)__builtin_popcountll(t);
+		if (c < want) { want -= c; i += 8; continue; }
+		break;                                                   // the last wanted newline is inside this word
+	}
+	while (want > 0 && i < n) {
+		if (p[i] == '\n') want--;
+		i++;
+	}
+	return i;
+}
+
 struct RecordBlocks::Impl {
 	RawSource src;
 	int lpr;
@@ -896,12 +933,10 @@ bool RecordBlocks::next(size_t nrec, std::string &blk)
 	size_t cut = std::string::npos;
 	for (;;) {
 		// count newlines in what is buffered
-		while (m.scan < m.buf.size() && m.lines < want_lines) {
-			const char *p = m.buf.data() + m.scan;
-			const char *nl = static_cast<const char *>(memchr(p, '\n', m.buf.size() - m.scan));
-			if (!nl) { m.scan = m.buf.size(); break; }
-			m.scan = (size_t)(nl - m.buf.data()) + 1;
-			m.lines++;
+		if (m.scan < m.buf.size() && m.lines < want_lines) {
+			size_t left = want_lines - m.lines;
+			m.scan += take_lines(m.buf.data() + m.scan, m.buf.size() - m.scan, left);
+			m.lines = want_lines - left;
 		}
 		if (m.lines >= want_lines) { cut = m.scan; break; }
 		if (m.eof) { cut = m.buf.size(); break; }
@@ -960,15 +995,16 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 		blk->resize(start + got);
 		size_t cut = blk->size();
 		if (!eof) {
-			// count newlines; keep whole records only
-			size_t lines = 0, last_rec_end = 0;
-			const char *p = blk->data(), *e = p + blk->size();
-			while (p < e) {
-				const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)));
-				if (!nl) break;
-				lines++;
-				p = nl + 1;
-				if (lines % (size_t)lines_per_record == 0) last_rec_end = (size_t)(p - blk->data());
+			// keep whole records only: count the block's newlines eight bytes at a time, then walk back from the end over
+			// the lines of the last, incomplete record
+			const size_t lines = count_newlines(blk->data(), blk->size());
+			size_t drop = lines % (size_t)lines_per_record;
+			size_t last_rec_end = 0;
+			if (lines > drop) {
+				const char *base = blk->data();
+				const char *nl = static_cast<const char *>(memrchr(base, '\n', blk->size()));
+				while (drop > 0) { nl = static_cast<const char *>(memrchr(base, '\n', (size_t)(nl - base))); drop--; }
+				last_rec_end = (size_t)(nl - base) + 1;
 			}
 			cut = last_rec_end;
 			if (cut == 0) {                    // a record larger than the block: grow and retry
