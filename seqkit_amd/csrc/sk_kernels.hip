@@ -1212,24 +1212,31 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		if (!fuse_demux) b.bc = nullptr;
 		return plan_and_launch(fuse_demux ? tile_pass2_fn<true>(b.qc.mode) : tile_pass2_fn<false>(b.qc.mode), b, row_bytes, fuse_demux, 4, n_cu, st, 2);
 	}
-	// Shape of the phase kernel: EIGHT resident waves per CU, as two workgroups of four.  More waves keep more requests
-	// in flight than HBM serves well (tools/waves_exp.py, same buffers, 62.5 M clusters: 16 waves 9.52 ms, 8 waves
-	// 9.31 ms; at 16 M clusters +5 % for the fused pass, +14 % for mask + trim of two mates, +10 % for one mate).
-	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 4, n_cu, st, 1, 2);
+	// Shape of the phase kernel: workgroups of four waves, and how many of them a CU holds depends on what the pass is
+	// bound by (tools/waves_exp.py, tools/small_n.py; same buffers, one process):
+	//  * two mates, streaming-bound: TWO per CU (eight resident waves).  More waves keep more requests in flight than
+	//    HBM serves well: 62.5 M clusters 9.52 ms with 16 waves, 9.31 ms with 8; at 16 M clusters +5 % for the fused
+	//    pass, +14 % for mask + trim of two mates.  Short inputs (fewer than 16 tiles per wave) take three, to shorten
+	//    the tail: 1 M clusters 176 -> 160 us;
+	//  * one mate with the mask: three (1 M reads 101 -> 89 us, no difference at 16 M);
+	//  * trim alone, bound by the scan's VALU work: four (16 M reads of full-length scans 1.19 -> 0.80 ms).
+	const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows;
+	const int wg_two_mates = ntiles < (int64_t)n_cu * 4 * 2 * 16 ? 3 : 2;
+	if (fuse_demux) return plan_and_launch(tile_pass_fn<true, kSlots>(b.qc.mode), b, row_bytes, true, 4, n_cu, st, 1, wg_two_mates);
 	b.bc = nullptr;
 	// One mate = two read streams at most: keep four chunks per stream in flight instead of two (mask + trim of one
 	// mate 4.9 -> 5.1 TB/s at 16 M x 150; no gain with two mates or the barcode phase).  Trim alone reads ONE stream and
-	// spends most of its time in the scan: there the whole next tile (ten chunks at 150 bp) is kept in flight, which the
-	// eight-wave shape has the registers for (3.6 -> 3.9 -> 4.3 TB/s with 2 / 4 / 10 slots on read-like qualities).
+	// spends most of its time in the scan: there the whole next tile (ten chunks at 150 bp) is kept in flight
+	// (3.6 -> 3.9 -> 4.3 TB/s with 2 / 4 / 10 slots on read-like qualities).
 	int active = 0;
 	bool any_mask = false;
 	for (int mi = 0; mi < b.n_mates; mi++) {
 		active += (b.mate[mi].out_seq || b.mate[mi].lowest_k) ? 1 : 0;
 		any_mask = any_mask || b.mate[mi].out_seq;
 	}
-	if (active == 1 && !any_mask) return plan_and_launch(tile_pass_fn<false, 10>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
-	if (active == 1) return plan_and_launch(tile_pass_fn<false, SK_SLOTS1>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
-	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 2);
+	if (active == 1 && !any_mask) return plan_and_launch(tile_pass_fn<false, 10>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 4);
+	if (active == 1) return plan_and_launch(tile_pass_fn<false, SK_SLOTS1>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, 3);
+	return plan_and_launch(tile_pass_fn<false, kSlots>(b.qc.mode), b, row_bytes, false, 4, n_cu, st, 1, wg_two_mates);
 }
 
 // ---------------------------------------------------------------------------------------------------
