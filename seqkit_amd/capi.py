@@ -351,6 +351,11 @@ class Context:
         self._check(self._lib.sk_count_add(self._h, *[_ptr(c) for c in cols], n, min_mapq, max_frag_len, int(single_end), int(center)),
                     "sk_count_add")
 
+    def count_add_dev(self, flag: int, mapq: int, tid: int, mtid: int, pos: int, mpos: int, tlen: int, end_pos: int, n: int,
+                      min_mapq: int = 0, max_frag_len: int = 5000, single_end: bool = False, center: bool = False) -> None:
+        self._check(self._lib.sk_count_add_dev(self._h, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos or None, n, min_mapq, max_frag_len,
+                                               int(single_end), int(center)), "sk_count_add_dev")
+
     def count_get(self) -> np.ndarray:
         out = np.zeros(max(self._n_regions, 1), dtype=np.uint32)
         self._check(self._lib.sk_count_get(self._h, _ptr(out)), "sk_count_get")

@@ -73,6 +73,24 @@ kept = torch.zeros((1,), dtype=torch.int64, device=dev)
 timeit("f2 sam fragments filter 200M records (14 B)", lambda: ctx.bam_fragments_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 0, 5000, bits.data_ptr(), kept.data_ptr()), n, 14.125, iters=3, rounds=3)
 del flag, tid, mtid, tlen, bits
 
+# sam count: 100M coordinate-sorted paired records on 24 references, 20k regions of 1 kb (31 B/record)
+n = 100_000_000
+n_chr = 24
+rng = np.random.default_rng(9)
+ctid = torch.sort(torch.randint(0, n_chr, (n,), dtype=torch.int32, device=dev, generator=g)).values.contiguous()
+cpos = torch.randint(0, 100_000_000, (n,), dtype=torch.int32, device=dev, generator=g)
+ctl = torch.randint(50, 600, (n,), dtype=torch.int32, device=dev, generator=g)
+cflag = torch.full((n,), 99, dtype=torch.int16, device=dev)
+cmapq = torch.full((n,), 60, dtype=torch.uint8, device=dev)
+cmpos = (cpos + ctl // 2).contiguous()
+rchr = np.sort(rng.integers(0, n_chr, size=20000)).astype(np.int32)
+rstart = rng.integers(0, 100_000_000, size=20000).astype(np.uint32)
+chr_off = np.searchsorted(rchr, np.arange(n_chr + 1)).astype(np.int32)
+ctx.count_set_regions(chr_off, rstart, (rstart + 1000).astype(np.uint32))
+timeit("sam count 100M records, 20k regions (31 B/record)", lambda: ctx.count_add_dev(cflag.data_ptr(), cmapq.data_ptr(), ctid.data_ptr(), ctid.data_ptr(), cpos.data_ptr(), cmpos.data_ptr(), ctl.data_ptr(), 0, n), n, 31, iters=3, rounds=3)
+print("   regions hit:", int((ctx.count_get() > 0).sum()), "of 20000; fragments counted:", int(ctx.count_get().sum()) // (3 * 3 + 2))
+del ctid, cpos, ctl, cflag, cmapq, cmpos
+
 # f4: sam to fastq sequence(), 16M records x 152-base rows (0.5 + 1 + 1 B per base, + len and flag)
 n = 16_000_000
 s4 = torch.randint(0, 256, (n, 76), dtype=torch.uint8, device=dev, generator=g)
