@@ -216,3 +216,110 @@ def test_fasta_deinterleave_and_split_into_anchors_cli(bins, tmp_path):
     for args in (["split", "into", "anchors", str(fq)], ["split", "into", "anchors", str(fq), "x"], ["split", "into", "anchors", "missing", "3"],
                  ["split", "into", "anchors", str(fq), "9223372036854775808"]):
         both(bins, "fasta", args, tmp_path, same_stderr=False)
+
+
+# ---- a third statement: the commands in a few lines of Python each, against the host binary (regular inputs only) -------
+RUST_WS = "".join(chr(c) for c in [9, 10, 11, 12, 13, 32, 0x85, 0xA0, 0x1680, *range(0x2000, 0x200B), 0x2028, 0x2029, 0x202F, 0x205F, 0x3000])
+
+
+def rust_trim_end(s: str) -> str:
+    return s.rstrip(RUST_WS)                                              # str::trim_end: Unicode White_Space only (not 0x1c..0x1f)
+
+
+def records(text: bytes):
+    """[(header, seq, plus, qual)] with line ends kept; FASTA records have plus = qual = None."""
+    lines = text.decode().splitlines(keepends=True)
+    out, i = [], 0
+    while i < len(lines):
+        if lines[i].startswith("@"):
+            out.append(tuple(lines[i:i + 4]))
+            i += 4
+        else:
+            out.append((lines[i], lines[i + 1], None, None))
+            i += 2
+    return out
+
+
+def test_text_commands_against_python_models(bins, tmp_path):
+    import re
+    text = mixed_text(800, seed=11, fasta_every=5)
+    fq = tmp_path / "m.fq"
+    fq.write_bytes(text)
+    recs = records(text)
+    run = lambda args: cu.run(bins["fasta"][0], args, cwd=tmp_path)
+
+    # fasta trim --first=3 --last=4  (src/fasta_trim.rs:24-47)
+    exp = []
+    for h, s, p, q in recs:
+        n = len(rust_trim_end(s))
+        keep = 3 + 4 < n
+        exp.append(h + (s[3:n - 4] if keep else "") + "\n")
+        if p is not None:
+            exp.append("+\n" + (q[3:n - 4] if keep else "") + "\n")
+    rc, out, _ = run(["trim", "--first=3", "--last=4", str(fq)])
+    assert rc == 0 and out.decode() == "".join(exp)
+
+    # fasta to raw  (src/fasta_to_raw.rs:14-27)
+    rc, out, _ = run(["to", "raw", str(fq)])
+    assert rc == 0 and out.decode() == "".join(s for _, s, _, _ in recs)
+
+    # fasta convert basespace  (src/fasta_convert_basespace.rs:25-45)
+    exp = []
+    for k, (h, s, p, q) in enumerate(recs, 1):
+        bc = rust_trim_end(h).split(":")[-1]
+        exp.append(f"@{k}" + (f" BC:{bc}" if bc else "") + "\n" + s + (p + q if p is not None else ""))
+    rc, out, _ = run(["convert", "basespace", str(fq)])
+    assert rc == 0 and out.decode() == "".join(exp)
+
+    # fasta simplify read ids [--discard-umi]  (src/fasta_simplify_read_ids.rs:30-60)
+    for discard in (False, True):
+        exp = []
+        for k, (h, s, p, q) in enumerate(recs, 1):
+            m = None if discard else re.search(r" UMI:[^\s]*", h)
+            exp.append(f"{h[0]}{k}" + (m.group(0) if m else "") + "\n" + s + ("+\n" + q if p is not None else ""))
+        rc, out, _ = run(["simplify", "read", "ids"] + (["--discard-umi"] if discard else []) + [str(fq)])
+        assert rc == 0 and out.decode() == "".join(exp)
+
+    # fasta split into anchors <fastq> 7 on FASTA records and on FASTQ records that are long enough (:22-44)
+    ok = [r for r in recs if len(rust_trim_end(r[1])) >= 14]
+    a_in = tmp_path / "anch.fq"
+    a_in.write_bytes("".join("".join(x for x in r if x is not None) for r in ok).encode())
+    exp = []
+    for k, (h, s, p, q) in enumerate(ok, 1):
+        n = len(rust_trim_end(s))
+        if p is not None:
+            exp.append(f"@{k}\n{s[:7]}\n+\n{q[:7]}\n@{k}\n{s[n - 7:n]}\n+\n{q[n - 7:n]}\n")
+        else:
+            exp.append(f">{k}\n{s[:7]}\n>{k}\n{s[n - 7:n]}\n")
+    rc, out, _ = run(["split", "into", "anchors", str(a_in), "7"])
+    assert rc == 0 and out.decode() == "".join(exp) and len(ok) > 300
+
+    # FASTQ only: remove base qualities, extract dual umi, interleave / deinterleave
+    fqs = [r for r in recs if r[2] is not None]
+    fqs = fqs[:len(fqs) // 2 * 2]
+    only = tmp_path / "only.fq"
+    only.write_bytes("".join("".join(r) for r in fqs).encode())
+    rc, out, _ = run(["remove", "base", "qualities", str(only)])
+    assert rc == 0 and out.decode() == "".join(">" + h[1:] + s for h, s, _, _ in fqs)
+    long_enough = [(a, b) for a, b in zip(fqs[0::2], fqs[1::2]) if len(a[1]) > 5 and len(b[1]) > 5 and len(a[3]) > 5 and len(b[3]) > 5]
+    umi_in = tmp_path / "umi.fq"
+    umi_in.write_bytes("".join("".join(a) + "".join(b) for a, b in long_enough).encode())
+    exp = []
+    for a, b in long_enough:                                               # src/fasta_extract_dual_umi.rs:57-66
+        umi = a[1][:5] + "+" + b[1][:5]
+        for h, s, _, q in (a, b):
+            exp.append(f"{rust_trim_end(h)} RX:{umi}\n{s[5:]}+\n{q[5:]}")
+    rc, out, _ = run(["extract", "dual", "umi", "--first-bases=5", str(umi_in)])
+    assert rc == 0 and out.decode() == "".join(exp) and len(long_enough) > 200
+    m1, m2 = tmp_path / "m1.fq", tmp_path / "m2.fq"
+    m1.write_bytes("".join("".join(r) for r in fqs[0::2]).encode())
+    m2.write_bytes("".join("".join(r) for r in fqs[1::2]).encode())
+    rc, out, _ = run(["interleave", str(m1), str(m2)])
+    assert rc == 0 and out == only.read_bytes()
+
+    # fasta add base qualities <fasta> 30 on the FASTA records (src/fasta_add_base_qualities.rs:19-26)
+    fas = [r for r in recs if r[2] is None]
+    fa = tmp_path / "only.fa"
+    fa.write_bytes("".join(h + s for h, s, _, _ in fas).encode())
+    rc, out, _ = run(["add", "base", "qualities", str(fa), "30"])
+    assert rc == 0 and out.decode() == "".join("@" + h[1:] + s + "+\n" + "?" * (len(s) - 1) + "\n" for h, s, _, _ in fas)
