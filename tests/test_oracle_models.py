@@ -145,3 +145,91 @@ def test_count_model(oracle, kw):
             if rchr[r] == tid and int(rstart[r]) < end and int(rend[r]) > start:
                 want[r] += 1
     assert np.array_equal(got.astype(np.int64), want) and want.sum() > 50
+
+
+# ---- the oracle COMMAND LINES against plain-Python statements of the reference's main loops (regular ASCII inputs) --------
+def _run_oracle(oracle, args, cwd):
+    import subprocess
+    r = subprocess.run([oracle.FASTA_BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_trim_and_mask_cli_models(oracle, tmp_path):
+    n = 1500
+    seq, qual = synth.make_reads(n, 60, seed=21)
+    qual = synth.add_forced_classes(qual, seed=21)
+    ln = synth.ragged_lengths(n, 60, seed=21)
+    ln[ln == 0] = 1
+    text = synth.fastq_text(seq, qual, prefix="SIM:21", lengths=ln)
+    fq = tmp_path / "t.fq"
+    fq.write_bytes(text)
+    lines = text.decode("latin-1").split("\n")
+    recs = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+    for m in (20, 2, 41):
+        # src/fasta_trim_by_quality.rs:19-48
+        out = []
+        for h, s, _, q in recs:
+            total = lowest_total = -50
+            k = lowest_k = len(q)
+            while k > 0:
+                k -= 1
+                total += ((ord(q[k]) - 33) % 256) - m
+                if total > 0:
+                    break
+                if total < lowest_total:
+                    lowest_total, lowest_k = total, k
+            out.append(h + "\n" + ("N\n+\n!\n" if lowest_k == 0 else f"{s[:lowest_k]}\n+\n{q[:lowest_k]}\n"))
+        rc, got, _ = _run_oracle(oracle, ["trim", "by", "quality", str(fq), str(m)], tmp_path)
+        assert rc == 0 and got.decode("latin-1") == "".join(out), m
+        # src/fasta_mask_by_quality.rs:20-45
+        out = [h + "\n" + "".join("N" if ((ord(b) - 33) % 256) < m else a for a, b in zip(s, q)) + "\n+\n" + q + "\n" for h, s, _, q in recs]
+        rc, got, _ = _run_oracle(oracle, ["mask", "by", "quality", str(fq), str(m)], tmp_path)
+        assert rc == 0 and got.decode("latin-1") == "".join(out), m
+
+
+def test_demultiplex_cli_model(oracle, tmp_path):
+    """Header mode, single end, sheet with a UMI column: per-sample files, warnings and the summary line from ~30 lines of Python."""
+    import gzip
+    import re
+    S, n = 12, 3000
+    table = synth.make_sheet(S, 8, seed=31)
+    table = np.concatenate([table, np.full((S, 4), ord("U"), dtype=np.uint8)], axis=1)       # 8 barcode bases + 4 UMI bases
+    table[3] = table[2]                                                                        # a duplicated barcode: ambiguous
+    bc, _ = synth.observe_barcodes(table[:, :8].copy(), n, seed=32, p_exact=0.7, p_sub=0.2)
+    rng = np.random.default_rng(33)
+    umi = synth.BASES[rng.integers(0, 4, size=(n, 4))]
+    full = np.concatenate([bc, umi], axis=1)
+    seq, qual = synth.make_reads(n, 30, seed=34)
+    headers = [f"@SIM:{i} 1:N:0  ".encode() + b" BC:" + full[i].tobytes() + (b" extra  " if i % 4 == 0 else b"") for i in range(n)]
+    (tmp_path / "r.fq").write_bytes(synth.fastq_text(seq, qual, headers=headers))
+    (tmp_path / "sheet.tsv").write_bytes(b"# name\tbarcode\n" + b"".join(f"S{i}\t".encode() + table[i].tobytes() + b"\textra\n" for i in range(S)))
+    rc, out, err = _run_oracle(oracle, ["demultiplex", "sheet.tsv", "r.fq"], tmp_path)
+    assert rc == 0 and out == b""
+    files = {f"S{i}.fq.gz": [] for i in range(S)}
+    warn, identified = [], 0
+    text = (tmp_path / "r.fq").read_bytes().decode()
+    lines = text.split("\n")
+    sheet = [table[i].tobytes().decode() for i in range(S)]
+    for i in range(0, len(lines) - 1, 4):
+        h, body = lines[i], lines[i + 1:i + 4]
+        mt = re.search(r" BC:[ACGTNacgtn+]+", h)
+        obs = mt.group(0)[4:]
+        diffs = [sum(1 for a, b in zip(obs, cand) if b not in "NU" and a != b) for cand in sheet]       # :269-277
+        low = min(diffs)
+        first = diffs.index(low)
+        last = len(diffs) - 1 - diffs[::-1].index(low)
+        if low > 1:
+            continue
+        if first != last:                                                                                # :181-189
+            warn.append(f"WARNING: Sequenced barcode {obs} was an equally good match ({low} mismatches) for samples S{first} ({sheet[first]}) and "
+                        f"S{last} ({sheet[last]}), and was therefore not assigned to any sample.\n")
+            continue
+        identified += 1
+        u = "".join(a for a, b in zip(obs, sheet[first]) if b == "U")                                    # :200-203
+        hdr = (h[:mt.start()] + h[mt.end():]).rstrip(" \t")                                              # :145, :206
+        files[f"S{first}.fq.gz"].append(hdr + (f" UMI:{u}" if u else "") + "\n" + "\n".join(body) + "\n")
+    for name, parts in files.items():
+        assert gzip.open(tmp_path / name).read().decode() == "".join(parts), name
+    want_err = ("Reading sample sheet...\nStarting demultiplexing in single end mode...\n" + "".join(warn) +
+                f"{identified} / {n} ({identified / n * 100:.1f}%) clusters carried a barcode matching one of the provided samples.\n")
+    assert err.decode() == want_err and len(warn) > 10 and identified > 1000
