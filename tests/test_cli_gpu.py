@@ -204,6 +204,30 @@ def test_demultiplex_index_files_and_dry_run(bins, tmp_path):
     assert a[1] == b[1] and len(a[1].splitlines()) == 100          # same canonical order among equal counts (first seen)
 
 
+def test_readme_pipeline_add_barcode_into_demultiplex(bins, tmp_path):
+    """The reference README's pipeline (BASELINE configs[3]): `fasta demultiplex sheet <(fasta add barcode R1 I1) <(fasta add
+    barcode R2 I1)` — both mates get the index read's bases as BC: field through pipes, then the paired demultiplex."""
+    import subprocess
+    n = 4000
+    table = synth.make_sheet(24, 8, dual=True, seed=51)
+    (tmp_path / "sheet.tsv").write_bytes(b"".join(f"P{i}\t".encode() + table[i].tobytes() + b"\n" for i in range(24)))
+    bc, _ = synth.observe_barcodes(table, n, seed=52, halves=2)
+    for m in (1, 2):
+        seq, qual = synth.make_reads(n, 50, seed=52 + m)
+        (tmp_path / f"R{m}.fq").write_bytes(synth.fastq_text(seq, qual, headers=[f"@SIM:{i} {m}:N:0:1".encode() for i in range(n)]))
+    ones = np.full((n, 17), ord("F"), dtype=np.uint8)
+    (tmp_path / "I1.fq").write_bytes(synth.fastq_text(np.ascontiguousarray(bc), ones, headers=[f"@SIM:{i} 1:N:0:1".encode() for i in range(n)]))
+    res = {}
+    for label, binary in (("hip", bins["fasta"][0]), ("orc", bins["fasta"][1])):
+        d = tmp_path / label
+        d.mkdir()
+        cmd = f'{binary} demultiplex ../sheet.tsv <({binary} add barcode ../R1.fq ../I1.fq) <({binary} add barcode ../R2.fq ../I1.fq)'
+        r = subprocess.run(["bash", "-c", cmd], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        res[label] = (r.returncode, r.stdout, r.stderr, cu.gunzip_dir(d))
+    assert res["hip"][0] == res["orc"][0] == 0 and res["hip"][1:3] == res["orc"][1:3]
+    assert res["hip"][3] == res["orc"][3] and len(res["hip"][3]) == 48 and sum(map(len, res["hip"][3].values())) > 400_000
+
+
 def test_demultiplex_dry_run_header_barcodes_device_census(bins, tmp_path):
     """Dry run in header mode: the unmatched barcodes are counted by the device census; blocks of 64 clusters make the
     table see many launches.  Counts, order and the early stop at N must match the oracle."""
