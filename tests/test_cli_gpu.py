@@ -692,3 +692,100 @@ def test_sam_count_cli(bins, tmp_path):
     for args in (["count"], ["count", str(bam)], ["count", "--min-mapq=256", str(bam), str(bed)], ["count", "--max-frag-len=x", str(bam), str(bed)],
                  ["count", str(bam), "missing.bed"], ["count", "missing.bam", str(bed)], ["count", "--bogus", str(bam), str(bed)]):
         both(bins, "sam", args, tmp_path)
+
+
+# ---- randomized differential test: odd inputs through both command lines ------------------------------------------------
+def fuzz_fastq(rng, n_records):
+    """FASTQ-like text with the things real files get wrong: ragged line ends, CRLF, blanks, non-ASCII and invalid UTF-8,
+    missing lines, wrong record markers, length mismatches, empty lines, no final newline."""
+    out = []
+    for i in range(n_records):
+        ln = int(rng.integers(0, 30))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn"), size=ln).astype(np.uint8))
+        qual = bytes(rng.integers(33, 75, size=ln, dtype=np.uint8))
+        head = b"@r%d" % i + (b" BC:" + bytes(rng.choice(list(b"ACGTN+"), size=int(rng.integers(1, 12))).astype(np.uint8)) if rng.random() < 0.8 else b"")
+        plus = b"+" + (head[1:] if rng.random() < 0.2 else b"")
+        u = rng.random()
+        if u < 0.04:
+            qual = qual[:max(0, ln - 2)]                                     # shorter qualities
+        elif u < 0.08:
+            qual += b"II"                                                    # longer qualities
+        elif u < 0.11:
+            seq = seq[:ln // 2] + "\u00e9".encode() + seq[ln // 2:]          # a two-byte character among the bases
+        elif u < 0.14:
+            qual = qual[:ln // 2] + "\u20ac".encode() + qual[ln // 2 + 3:]   # a three-byte character among the qualities
+        elif u < 0.16:
+            qual = qual + b" \t"                                             # trailing blanks
+        elif u < 0.18:
+            qual = qual + bytes([0x1F])                                      # 0x1F is not whitespace for Rust
+        eol = b"\r\n" if rng.random() < 0.1 else b"\n"
+        lines = [head + eol, seq + eol, plus + eol, qual + eol]
+        v = rng.random()
+        if v < 0.01:
+            lines[0] = b"r%d\n" % i                                          # no '@'
+        elif v < 0.02:
+            lines[2] = b"-\n"                                                # no '+'
+        elif v < 0.03:
+            del lines[int(rng.integers(0, 4))]                               # a line is missing
+        elif v < 0.035:
+            lines.insert(int(rng.integers(0, 4)), b"\n")                     # a stray empty line
+        elif v < 0.04:
+            lines[1] = seq[:3] + bytes([0xFF]) + seq[3:] + eol               # invalid UTF-8
+        out.extend(lines)
+    text = b"".join(out)
+    if rng.random() < 0.3:
+        text = text[:len(text) - int(rng.integers(1, 25))]                   # cut off at the end
+    return text
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_fuzz_trim_and_mask_cli(bins, tmp_path, seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    fq = tmp_path / "f.fq"
+    fq.write_bytes(fuzz_fastq(rng, int(rng.integers(1, 120))))
+    if seed % 3 == 0:
+        monkeypatch.setenv("SEQKIT_BLOCK_BYTES", str(int(rng.integers(40, 400))))     # many tiny blocks
+    q = str(int(rng.choice([0, 2, 20, 30, 41, 255])))
+    for cmd in ("trim", "mask"):
+        a = cu.run(bins["fasta"][0], [cmd, "by", "quality", str(fq), q], cwd=tmp_path)
+        b = cu.run(bins["fasta"][1], [cmd, "by", "quality", str(fq), q], cwd=tmp_path)
+        assert a[0] == b[0] and a[1] == b[1], (cmd, seed, a[2][-300:], b[2][-300:])
+        if a[0] != 101:
+            assert a[2] == b[2]                                              # panic texts are not byte-identical; everything else is
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_demultiplex_cli(bins, tmp_path, seed, monkeypatch):
+    rng = np.random.default_rng(2000 + seed)
+    L = int(rng.choice([4, 6, 11]))
+    S = int(rng.integers(1, 9))
+    sheet = [bytes(rng.choice(list(b"ACGTNU+"), size=L, p=[.22, .22, .22, .22, .05, .05, .02]).astype(np.uint8)) for _ in range(S)]
+    rows = [b"# sheet\n"] + [b"s%d\t" % k + bcs + (b"\textra" if k % 2 else b"") + b"\n" for k, bcs in enumerate(sheet)]
+    if rng.random() < 0.2:
+        rows.append(b"dup\t" + sheet[0] + b"\n")                             # a second sample with the same barcode
+    (tmp_path / "sheet.tsv").write_bytes(b"".join(rows))
+    recs = []
+    for i in range(int(rng.integers(1, 150))):
+        src = sheet[int(rng.integers(0, S))] if rng.random() < 0.7 else bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+        obs = bytearray(src.replace(b"U", b"A").replace(b"+", b"+"))
+        if rng.random() < 0.3:
+            obs[int(rng.integers(0, L))] = int(rng.choice(list(b"ACGTN")))
+        if rng.random() < 0.02:
+            obs = obs[:-1]                                                   # wrong length: an error for the whole run
+        ln = int(rng.integers(1, 20))
+        h = b"@c%d 1:N:0 BC:" % i + bytes(obs) + (b" tail " if rng.random() < 0.3 else b"")
+        recs.append(h + b"\n" + bytes(rng.choice(list(b"ACGT"), size=ln).astype(np.uint8)) + b"\n+\n" + bytes(rng.integers(33, 75, size=ln, dtype=np.uint8)) + b"\n")
+    if rng.random() < 0.1:
+        recs.insert(len(recs) // 2, b"@nobc 1:N:0\nAC\n+\nII\n")            # No BC:xxxx field found.
+    (tmp_path / "r.fq").write_bytes(b"".join(recs))
+    if seed % 2 == 0:
+        monkeypatch.setenv("SEQKIT_BLOCK_RECORDS", str(int(rng.integers(1, 9))))
+    res = []
+    for k, d in enumerate(("hip", "orc")):
+        (tmp_path / d).mkdir()
+        r = cu.run(bins["fasta"][k], ["demultiplex", "../sheet.tsv", "../r.fq"], cwd=tmp_path / d)
+        res.append((r, cu.gunzip_dir(tmp_path / d)))
+    (a, fa), (b, fb) = res
+    assert a[0] == b[0] and a[1] == b[1] and fa == fb, (seed, a[2][-400:], b[2][-400:])
+    if a[0] != 101:
+        assert a[2] == b[2]
