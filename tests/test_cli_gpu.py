@@ -789,3 +789,47 @@ def test_fuzz_demultiplex_cli(bins, tmp_path, seed, monkeypatch):
     assert a[0] == b[0] and a[1] == b[1] and fa == fb, (seed, a[2][-400:], b[2][-400:])
     if a[0] != 101:
         assert a[2] == b[2]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_sam_cli(bins, tmp_path, seed):
+    """Random BAM records (any flag bits, ragged reads, odd cigars, extreme TLEN), sometimes cut off, through every `sam`
+    command of this build."""
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.integers(1, 400))
+    recs = []
+    pos = 0
+    for i in range(n):
+        ln = int(rng.integers(0, 40))
+        pos += int(rng.integers(0, 50))
+        tid = int(rng.integers(-1, 3))
+        recs.append(dict(tid=tid, mtid=tid if rng.random() < 0.8 else int(rng.integers(-1, 3)), pos=pos, mpos=pos + int(rng.integers(-300, 300)),
+                         tlen=int(rng.choice([0, 19, 20, 150, -150, 4999, 5000, 5001, -2**31, 2**31 - 1])) if rng.random() < 0.5 else int(rng.integers(-800, 800)),
+                         flag=int(rng.integers(0, 4096)), mapq=int(rng.integers(0, 256)), name=f"q{int(rng.integers(0, max(1, n // 2)))}",
+                         codes=[int(c) for c in rng.integers(0, 16, size=ln)], qual=[int(q) for q in rng.integers(0, 94, size=ln)],
+                         cigar=[(int(rng.integers(0, 9)), int(rng.integers(0, 30))) for _ in range(int(rng.integers(0, 4)))]))
+    order = np.argsort([(r["tid"] if r["tid"] >= 0 else 99, r["pos"]) for r in recs], axis=0)[:, 0] if seed % 2 == 0 else np.arange(n)
+    recs = [recs[int(k)] for k in order]
+    kw = {}
+    if seed % 4 == 3:
+        kw["truncate"] = int(rng.integers(200, 200 + 40 * n))
+    bam = tmp_path / "z.bam"
+    cu.write_bam(str(bam), [("chr1", 100000), ("chr2", 100000), ("chr3", 5000)], recs, **kw)
+    bed = tmp_path / "z.bed"
+    bed.write_bytes(b"".join(b"chr%d\t%d\t%d\n" % (int(rng.integers(1, 5)), st, st + int(rng.integers(0, 3000)))
+                             for st in (int(x) for x in rng.integers(0, 20000, size=int(rng.integers(0, 60))))))
+    cmds = [["statistics", str(bam)], ["fragment", "lengths", f"--max-frag-size={int(rng.choice([0, 200, 5000]))}", str(bam)],
+            ["fragment", "lengths", f"--reads={int(rng.integers(1, 50))}", str(bam)],
+            ["fragments", f"--min-size={int(rng.choice([0, 100]))}", f"--max-size={int(rng.choice([200, 5000, 10**10]))}", str(bam)],
+            ["count", str(bam), str(bed)], ["count", "--single-end", "--center", f"--min-mapq={int(rng.integers(0, 61))}", str(bam), str(bed)],
+            ["to", "interleaved", "fastq", str(bam)], ["to", "fasta", str(bam), "pfx"]]
+    for args in cmds:
+        res = []
+        for k, d in enumerate(("hip", "orc")):
+            (tmp_path / d).mkdir(exist_ok=True)
+            r = cu.run(bins["sam"][k], args, cwd=tmp_path / d)
+            res.append((r, cu.gunzip_dir(tmp_path / d)))
+        (a, fa), (b, fb) = res
+        assert a[0] == b[0] and a[1] == b[1] and fa == fb, (seed, args, a[2][-300:], b[2][-300:])
+        if a[0] != 101:
+            assert a[2] == b[2], (seed, args)
