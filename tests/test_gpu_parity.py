@@ -397,6 +397,55 @@ def test_bam_fragments_filter(ctx, oracle, n, lo, hi):
 
 
 # ---- error behaviour of the boundary ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(160))
+def test_fuzz_fused_pass_random_shapes(ctx, oracle, seed):
+    """Random everything: rows, stride (LDS tile path and the long-row path), ragged or full lengths, one or two mates, mask
+    and/or trim, with or without barcodes, any sheet size / barcode length / mismatch budget / threshold, arbitrary bytes."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 63, 64, 65, 200, 1023, 4100]))
+    stride = int(rng.choice([1, 2, 7, 33, 64, 100, 150, 151, 255, 640, 1100]))
+    if stride > 600:
+        n = min(n, 300)
+    nm = int(rng.integers(1, 3))
+    do_mask, do_trim = [(True, True), (True, False), (False, True)][int(rng.integers(0, 3))]
+    m = int(rng.choice([0, 1, 2, 20, 30, 41, 95, 200, 223, 224, 255]))
+    arbitrary = rng.random() < 0.4
+    mates = []
+    for _ in range(nm):
+        if arbitrary:
+            seq = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+            qual = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+        else:
+            seq, qual = synth.make_reads(n, stride, seed=int(rng.integers(0, 1 << 30)))
+            qual = synth.add_forced_classes(qual, seed=seed)
+        ln = synth.ragged_lengths(n, stride, seed=seed) if rng.random() < 0.5 else None
+        mates.append((seq, qual, ln))
+    bc = table = None
+    md = 1
+    if rng.random() < 0.7:
+        S = int(rng.choice([1, 2, 16, 96, 130, 300]))
+        L = int(rng.choice([4, 8, 17, 24, 33]))
+        table = rng.choice(np.frombuffer(b"ACGTNU", dtype=np.uint8), size=(S, L), p=[.23, .23, .23, .23, .05, .03])
+        pick = table[rng.integers(0, S, size=n)].copy()
+        noise = rng.random((n, L)) < 0.08
+        pick[noise] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=int(noise.sum()))
+        bc = np.ascontiguousarray(pick)
+        md = int(rng.choice([0, 1, 1, 2, 5]))
+        ctx.set_barcodes(np.ascontiguousarray(table), md)
+    r = ctx.fused_pass(mates, m, bc=bc, want_detail=True, do_mask=do_mask, do_trim=do_trim)
+    if bc is not None:
+        e_assign, e_low, e_first, e_last, _ = oracle.demux_batch(table, bc, md)
+        assert np.array_equal(r["assign"], e_assign) and np.array_equal(r["lowest_diff"], e_low)
+        assert np.array_equal(r["first_idx"], e_first) and np.array_equal(r["last_idx"], e_last)
+    for i, (seq, qual, ln) in enumerate(mates):
+        if do_trim:
+            assert np.array_equal(r["lowest_k"][i], oracle.trim_batch(qual, ln, m)), (seed, i)
+        if do_mask:
+            exp = oracle.mask_batch(seq, qual, ln, m)
+            valid = np.ones((n, stride), dtype=bool) if ln is None else (np.arange(stride)[None, :] < ln[:, None])
+            assert np.array_equal(r["out_seq"][i][valid], exp[valid]), (seed, i)
+
+
 # ---- f2 (second half): sam count ---------------------------------------------------------------------------------
 def count_inputs(n, n_chr, n_regions, seed, span=2_000_000):
     """Coordinate-sorted record columns and BED-like regions (unsorted, overlapping, nested, empty, some on a chromosome
