@@ -182,6 +182,14 @@ int sk_count_add_dev(sk_ctx *ctx, const uint16_t *flag, const uint8_t *mapq, con
                      uint8_t min_mapq, uint32_t max_frag_len, int single_end, int center);
 int sk_count_get(sk_ctx *ctx, uint32_t *region_frags /* n_regions */);
 
+/* ---- `fasta gc content` ------------------------------------------------------------------------------------------
+ * src/fasta_gc_content.rs:41-46.  sk_gc_set_genome copies the concatenated sequences to the device once (it stays
+ * there until the next call or sk_destroy); sk_gc_count then returns, for region i = bytes [start[i], start[i]+len[i])
+ * of that buffer, gc[i] = bytes that are C, G, c or g and total[i] = bytes that are neither N nor n.  Region bounds are
+ * the caller's to check (the reference's `chr_seq.get(start..stop)`, :41).                                          */
+int sk_gc_set_genome(sk_ctx *ctx, const uint8_t *genome, int64_t genome_len);
+int sk_gc_count(sk_ctx *ctx, const int64_t *start, const int64_t *len, int64_t n_regions, uint64_t *gc, uint64_t *total);
+
 /* ---- f4: `sam to fastq` sequence() ---------------------------------------------------------------------------
  * src/sam_to_fastq.rs:31-59: the bases of BAM records as ASCII — codes 1,2,4,8 -> A,C,G,T, anything else N; records
  * with flag & 0x10 come out reverse-complemented; a base whose quality is below min_baseq (the reference passes 10,

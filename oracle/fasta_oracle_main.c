@@ -822,7 +822,102 @@ static int split_into_anchors(int argc, char **argv)
 	return 0;
 }
 
-/* src/fasta_main.rs:42-82 (every arm but `fasta gc content`, which needs rust-bio's FASTA reader) */
+static const char *USAGE_GC =
+"\nUsage:\n  fasta gc content <genome.fa> <regions.bed>\n\nDescription:\n"
+"Calculates the GC content percentage of FASTA file regions listed in the input\n"
+"BED file. Ambiguous N nucleotides are omitted from both the numerator and the\n"
+"denominator.\n";
+
+/* src/fasta_gc_content.rs:17-50.  The FASTA reader is rust-bio 0.19's (not in the tree): restated from its published
+ * behaviour — a record is a '>' line plus the lines up to the next '>' line, each trim_right()ed; id = header[1..]
+ * trimmed, up to its first space. */
+typedef struct { oc_str id, seq; } chrom_t;
+
+static int gc_content(int argc, char **argv)
+{
+	const char *pos[2]; int npos;
+	if (!oc_parse(argc, argv, 3, NULL, 0, pos, &npos, 2) || npos != 2) oc_error("Invalid arguments.\n%s", USAGE_GC);
+	fputs("Reading reference genome into memory...\n", stderr);                 /* :22 */
+	FILE *fa = fopen(pos[0], "rb");                                            /* :23 */
+	if (!fa) oc_error("Input FASTA file %s could not be read.", pos[0]);
+	chrom_t *chr = NULL; size_t nchr = 0, capchr = 0;
+	{
+		oc_str line = {0};
+		int have = 0;
+		for (;;) {                                                             /* fasta::Reader::read, one record */
+			if (!have) {
+				/* read_line's Err (invalid UTF-8) is unwrap()ed at :27: a panic, not error! */
+				oc_clear(&line);
+				int c;
+				while ((c = getc(fa)) != EOF) { uint8_t b = (uint8_t)c; oc_append(&line, &b, 1); if (c == '\n') break; }
+				if (line.n == 0) break;
+				if (!orc_utf8_valid(line.p, line.n)) oc_panic("called `Result::unwrap()` on an `Err` value: stream did not contain valid UTF-8");
+			}
+			if (line.p[0] != '>') oc_panic("called `Result::unwrap()` on an `Err` value: Expected > at record start.");
+			size_t hend = orc_trim_end_len(line.p, line.n), e = 1;
+			while (e < hend && line.p[e] != ' ') e++;
+			if (nchr == capchr) { capchr = capchr ? capchr * 2 : 64; chr = (chrom_t *)realloc(chr, capchr * sizeof *chr); }
+			size_t slot = nchr;
+			for (size_t k = 0; k < nchr; k++)                                   /* HashMap::insert: a repeated id replaces */
+				if (chr[k].id.n == e - 1 && memcmp(chr[k].id.p, line.p + 1, e - 1) == 0) { slot = k; break; }
+			if (slot == nchr) { memset(&chr[nchr], 0, sizeof(chrom_t)); oc_assign(&chr[nchr].id, line.p + 1, e - 1); nchr++; }
+			oc_clear(&chr[slot].seq);
+			oc_append(&chr[slot].seq, "", 0);
+			for (;;) {
+				oc_clear(&line);
+				int c;
+				while ((c = getc(fa)) != EOF) { uint8_t b = (uint8_t)c; oc_append(&line, &b, 1); if (c == '\n') break; }
+				if (line.n && !orc_utf8_valid(line.p, line.n)) oc_panic("called `Result::unwrap()` on an `Err` value: stream did not contain valid UTF-8");
+				if (line.n == 0 || line.p[0] == '>') break;
+				oc_append(&chr[slot].seq, line.p, orc_trim_end_len(line.p, line.n));
+			}
+			have = line.n > 0;
+			if (!have) break;
+		}
+		fclose(fa);
+	}
+	oc_reader bed = oc_reader_open(pos[1]);                                     /* :31 */
+	oc_str line = {0};
+	while (oc_read_line(&bed, &line)) {                                        /* :33 */
+		size_t off = orc_trim_start_off(line.p, line.n), end = orc_trim_end_len(line.p, line.n);
+		if (end < off) end = off;
+		size_t cs[3] = {0, 0, 0}, ce[3] = {0, 0, 0}; int ncol = 0;             /* :34 split('\t') */
+		for (size_t a = off;;) {
+			size_t b = a;
+			while (b < end && line.p[b] != '\t') b++;
+			if (ncol < 3) { cs[ncol] = a; ce[ncol] = b; }
+			ncol++;
+			if (b >= end) break;
+			a = b + 1;
+		}
+		if (ncol < 3) fprintf(stderr, "WARNING: Input BED file contains line with less than 3 columns:\n%s\n\n", (const char *)line.p);   /* :35-37 */
+		chrom_t *c = NULL;                                                     /* :39 */
+		for (size_t k = 0; k < nchr; k++)
+			if (chr[k].id.n == ce[0] - cs[0] && memcmp(chr[k].id.p, line.p + cs[0], chr[k].id.n) == 0) { c = &chr[k]; break; }
+		if (!c) continue;
+		char num[64];
+		uint64_t start, stop;
+		if (ncol < 2) oc_panic("index out of bounds: the len is 1 but the index is 1");
+		size_t l1 = ce[1] - cs[1];
+		if (l1 >= sizeof num) oc_error("Invalid region:\n%s\n", (const char *)line.p);
+		memcpy(num, line.p + cs[1], l1); num[l1] = 0;
+		if (!oc_parse_uint(num, UINT64_MAX, &start)) oc_error("Invalid region:\n%s\n", (const char *)line.p);      /* :40 */
+		if (ncol < 3) oc_panic("index out of bounds: the len is 2 but the index is 2");
+		size_t l2 = ce[2] - cs[2];
+		if (l2 >= sizeof num) oc_error("Invalid region:\n%s\n", (const char *)line.p);
+		memcpy(num, line.p + cs[2], l2); num[l2] = 0;
+		if (!oc_parse_uint(num, UINT64_MAX, &stop)) oc_error("Invalid region:\n%s\n", (const char *)line.p);       /* :41 */
+		if (start > stop || stop > c->seq.n) oc_error("Invalid region:\n%s\n", (const char *)line.p);             /* :42 */
+		uint64_t gc, total;
+		orc_gc_count(c->seq.p + start, (size_t)(stop - start), &gc, &total);   /* :44-45 */
+		float ratio = (float)gc / (float)total;                                /* :46 */
+		if (total == 0) printf("%llu\t%llu\tNaN\n", (unsigned long long)gc, (unsigned long long)total);
+		else printf("%llu\t%llu\t%.3f\n", (unsigned long long)gc, (unsigned long long)total, (double)ratio);
+	}
+	return 0;
+}
+
+/* src/fasta_main.rs:42-82 */
 int main(int argc, char **argv)
 {
 	int rc;
@@ -848,6 +943,8 @@ int main(int argc, char **argv)
 		rc = trim_fixed(argc, argv);
 	else if (argc >= 4 && !strcmp(argv[1], "mask") && !strcmp(argv[2], "by") && !strcmp(argv[3], "quality"))
 		rc = mask_by_quality(argc, argv);
+	else if (argc >= 3 && !strcmp(argv[1], "gc") && !strcmp(argv[2], "content"))
+		rc = gc_content(argc, argv);
 	else if (argc >= 3 && !strcmp(argv[1], "add") && !strcmp(argv[2], "barcode"))
 		rc = add_barcode(argc, argv);
 	else if (argc >= 4 && !strcmp(argv[1], "extract") && !strcmp(argv[2], "dual") && !strcmp(argv[3], "umi"))

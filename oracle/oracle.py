@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         _lib.orc_fragment_lengths_stop.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_uint64, vp, vp]
         _lib.orc_fragments_keep.restype = i64
         _lib.orc_fragments_keep.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
+        _lib.orc_gc_count.restype = None
+        _lib.orc_gc_count.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib.orc_count_state_init.restype = None
         _lib.orc_count_state_init.argtypes = [vp]
         _lib.orc_count_state_free.restype = None
@@ -232,3 +234,11 @@ def count_batch(flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n_chr, rchr, rs
                                  len(rstart), _p(frags), C.byref(where))
     lib().orc_count_state_free(C.byref(st))
     return frags[:len(rstart)], code, int(where.value)
+
+
+def gc_count(seq: bytes):
+    """(gc, total) of src/fasta_gc_content.rs:44-45."""
+    g, t = C.c_uint64(), C.c_uint64()
+    buf = np.frombuffer(seq, dtype=np.uint8) if len(seq) else np.zeros(1, dtype=np.uint8)
+    lib().orc_gc_count(_p(buf), len(seq), C.byref(g), C.byref(t))
+    return int(g.value), int(t.value)

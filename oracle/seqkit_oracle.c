@@ -584,3 +584,16 @@ int orc_count_batch(orc_count_state *st, const uint16_t *flag, const uint8_t *ma
 	}
 	return 0;
 }
+
+/* ---- fasta gc content: src/fasta_gc_content.rs:44-45 ---------------------------------- */
+void orc_gc_count(const uint8_t *seq, size_t n, uint64_t *gc, uint64_t *total)
+{
+	uint64_t g = 0, t = 0;
+	for (size_t i = 0; i < n; i++) {
+		uint8_t b = seq[i];
+		if (b == 'C' || b == 'G' || b == 'c' || b == 'g') g++;
+		if (b != 'N' && b != 'n') t++;
+	}
+	*gc = g;
+	*total = t;
+}

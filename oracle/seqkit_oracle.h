@@ -139,6 +139,10 @@ int orc_count_batch(orc_count_state *st, const uint16_t *flag, const uint8_t *ma
                     const int32_t *rchr, const uint32_t *rstart, const uint32_t *rend, int64_t n_regions,
                     uint32_t *region_frags, int64_t *where);
 
+/* ---- fasta gc content: src/fasta_gc_content.rs:41-46 --------------------------------- */
+/* gc = bytes that are C, G, c or g; total = bytes that are neither N nor n. */
+void orc_gc_count(const uint8_t *seq, size_t n, uint64_t *gc, uint64_t *total);
+
 /* ---- text helpers that restate Rust std behaviour used on the path -------------- */
 /* str::trim_end(): length of s after removing trailing Unicode White_Space chars
  * (U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F, 3000);

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
-    "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get",
+    "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get", "sk_gc_set_genome", "sk_gc_count",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
     "sk_timer_start", "sk_timer_stop",
 ]
@@ -94,6 +94,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_count_add": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_uint8, C.c_uint32, i32, i32]),
         "sk_count_add_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_uint8, C.c_uint32, i32, i32]),
         "sk_count_get": (i32, [vp, vp]),
+        "sk_gc_set_genome": (i32, [vp, vp, i64]),
+        "sk_gc_count": (i32, [vp, vp, vp, i64, vp, vp]),
         "sk_census_reset": (i32, [vp]),
         "sk_census_add": (i32, [vp, vp, i32, i32, i64, vp, i64]),
         "sk_census_add_dev": (i32, [vp, vp, i32, i32, i64, vp, i64]),
@@ -360,6 +362,20 @@ class Context:
         out = np.zeros(max(self._n_regions, 1), dtype=np.uint32)
         self._check(self._lib.sk_count_get(self._h, _ptr(out)), "sk_count_get")
         return out[:self._n_regions]
+
+    # ---- fasta gc content -------------------------------------------------------------------
+    def gc_set_genome(self, genome) -> None:
+        g = np.ascontiguousarray(np.frombuffer(genome, dtype=np.uint8) if isinstance(genome, (bytes, bytearray)) else genome, dtype=np.uint8)
+        self._check(self._lib.sk_gc_set_genome(self._h, _ptr(g) if g.size else None, g.size), "sk_gc_set_genome")
+
+    def gc_count(self, start, length):
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        n = len(start)
+        gc = np.zeros(max(n, 1), dtype=np.uint64)
+        total = np.zeros(max(n, 1), dtype=np.uint64)
+        self._check(self._lib.sk_gc_count(self._h, _ptr(start), _ptr(length), n, _ptr(gc), _ptr(total)), "sk_gc_count")
+        return gc[:n], total[:n]
 
     # ---- f4: sam to fastq sequence() ---------------------------------------------------------
     def bam_sequence(self, seq4, qual, length, flag, min_baseq: int = 10) -> np.ndarray:

@@ -455,6 +455,106 @@ static int statistics(int argc, char **argv)
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fasta gc content <genome.fa> <regions.bed> (src/fasta_gc_content.rs:17-50).  The genome goes to the device once; the
+// two byte counts of every region (:44-45) come back per batch of BED lines.  The FASTA reader is rust-bio 0.19's
+// (`bio::io::fasta::Reader::records`, not in the reference tree), restated from its published behaviour: a record is a
+// line starting with '>' and the following lines up to the next '>' line, each with its trailing whitespace removed; the
+// id is the header up to its first space.
+// ---------------------------------------------------------------------------------------------------------
+static const char *USAGE_GC =
+	"\nUsage:\n  fasta gc content <genome.fa> <regions.bed>\n\nDescription:\n"
+	"Calculates the GC content percentage of FASTA file regions listed in the input\n"
+	"BED file. Ambiguous N nucleotides are omitted from both the numerator and the\n"
+	"denominator.\n";
+
+static int gc_content(int argc, char **argv)
+{
+	std::vector<host::Opt> opts;
+	std::vector<std::string> pos;
+	if (!host::parse_args(argc, argv, 3, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_GC);
+	fputs("Reading reference genome into memory...\n", stderr);                         // :22
+	FILE *fa = fopen(pos[0].c_str(), "rb");                                             // :23 File::open: no gzip, no "-"
+	if (!fa) error("Input FASTA file %s could not be read.", pos[0].c_str());
+	host::gpu_warmup();
+	std::string genome;                                                                 // all sequences, back to back
+	std::unordered_map<std::string, std::pair<int64_t, int64_t>> chrs;                  // id -> (offset, length)   :25-29
+	{
+		std::string line;
+		char *buf = nullptr;
+		size_t cap = 0;
+		auto read_line = [&](std::string &l) {                                          // BufRead::read_line: appends, UTF-8 or Err
+			const ssize_t r = getline(&buf, &cap, fa);
+			if (r <= 0) return;
+			if (!host::utf8_valid(reinterpret_cast<const uint8_t *>(buf), (size_t)r)) panic("called `Result::unwrap()` on an `Err` value: stream did not contain valid UTF-8");
+			l.append(buf, (size_t)r);
+		};
+		for (;;) {
+			if (line.empty()) { read_line(line); if (line.empty()) break; }
+			if (line[0] != '>') panic("called `Result::unwrap()` on an `Err` value: Expected > at record start.");       // :27 entry.unwrap()
+			const size_t hend = host::trim_end_len(line);
+			const size_t sp = line.find(' ', 1);
+			const std::string id = line.substr(1, (sp == std::string::npos || sp > hend ? hend : sp) - 1);
+			const int64_t off = (int64_t)genome.size();
+			for (;;) {
+				line.clear();
+				read_line(line);
+				if (line.empty() || line[0] == '>') break;
+				genome.append(line.data(), host::trim_end_len(line));
+			}
+			chrs[id] = {off, (int64_t)genome.size() - off};                             // HashMap::insert: a repeated id replaces
+		}
+		free(buf);
+		fclose(fa);
+	}
+	check(sk_gc_set_genome(host::gpu(), reinterpret_cast<const uint8_t *>(genome.data()), (int64_t)genome.size()), "sk_gc_set_genome");
+
+	host::LineReader bed(pos[1]);                                                       // :31
+	std::vector<int64_t> starts, lens;
+	std::vector<uint64_t> gc, total;
+	std::string line, stop_msg;
+	int stop_code = 0;
+	auto flush = [&]() {
+		if (starts.empty()) return;
+		gc.assign(starts.size(), 0); total.assign(starts.size(), 0);
+		check(sk_gc_count(host::gpu(), starts.data(), lens.data(), (int64_t)starts.size(), gc.data(), total.data()), "sk_gc_count");
+		char out[96];
+		for (size_t i = 0; i < starts.size(); i++) {
+			const float ratio = (float)gc[i] / (float)total[i];                         // :46 `as f32`, `{:.3}`
+			if (total[i] == 0) snprintf(out, sizeof out, "%llu\t%llu\tNaN\n", (unsigned long long)gc[i], (unsigned long long)total[i]);
+			else snprintf(out, sizeof out, "%llu\t%llu\t%.3f\n", (unsigned long long)gc[i], (unsigned long long)total[i], (double)ratio);
+			host::out().write(out, strlen(out));
+		}
+		starts.clear(); lens.clear();
+	};
+	for (;;) {
+		const bool ok = bed.read_line(line);
+		if (bed.bad_utf8()) { stop_msg = "I/O error while reading from file."; stop_code = 255; break; }
+		if (!ok) break;
+		const size_t off = host::trim_start_off(line), end = host::trim_end_len(line);                       // :34 line.trim().split('\t')
+		const std::string t = end > off ? line.substr(off, end - off) : std::string();
+		std::vector<std::string> cols;
+		size_t a = 0;
+		for (;;) { const size_t b = t.find('\t', a); cols.push_back(t.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; }
+		if (cols.size() < 3) fprintf(stderr, "WARNING: Input BED file contains line with less than 3 columns:\n%s\n\n", line.c_str());   // :35-37
+		auto it = chrs.find(cols[0]);                                                   // :39
+		if (it == chrs.end()) continue;
+		if (cols.size() < 2) { stop_msg = "index out of bounds: the len is 1 but the index is 1"; stop_code = 101; break; }
+		uint64_t start, stop;
+		if (!host::parse_uint(cols[1].c_str(), UINT64_MAX, start)) { stop_msg = "Invalid region:\n" + line + "\n"; stop_code = 255; break; }       // :40
+		if (cols.size() < 3) { stop_msg = "index out of bounds: the len is 2 but the index is 2"; stop_code = 101; break; }
+		if (!host::parse_uint(cols[2].c_str(), UINT64_MAX, stop)) { stop_msg = "Invalid region:\n" + line + "\n"; stop_code = 255; break; }        // :41
+		if (start > stop || stop > (uint64_t)it->second.second) { stop_msg = "Invalid region:\n" + line + "\n"; stop_code = 255; break; }         // :42 get(start..stop)
+		starts.push_back(it->second.first + (int64_t)start);
+		lens.push_back((int64_t)(stop - start));
+		if (starts.size() >= (1u << 16)) flush();
+	}
+	flush();
+	if (stop_code == 101) panic(stop_msg.c_str());
+	if (stop_code) error("%s", stop_msg.c_str());
+	return 0;
+}
+
 // ---- one block of clusters (all input files cut at the same record count) -> per-sample text -----------------------
 struct DemuxCfg {
 	std::vector<Sample> *samples;
@@ -852,6 +952,7 @@ int main(int argc, char **argv)
 	else if (argc >= 4 && is(1, "trim") && is(2, "by") && is(3, "quality")) rc = trim_by_quality(argc, argv);
 	else if (argc >= 2 && is(1, "trim")) fasta_text_command(argc, argv, false, rc);
 	else if (argc >= 4 && is(1, "mask") && is(2, "by") && is(3, "quality")) rc = mask_by_quality(argc, argv);
+	else if (argc >= 3 && is(1, "gc") && is(2, "content")) rc = gc_content(argc, argv);
 	else if (argc >= 3 && is(1, "add") && is(2, "barcode")) rc = add_barcode(argc, argv);
 	else if (fasta_text_command(argc, argv, false, rc)) {}
 	else if (argc >= 2 && is(1, "demultiplex")) rc = demultiplex(argc, argv);

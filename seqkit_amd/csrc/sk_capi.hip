@@ -32,6 +32,9 @@ struct sk_ctx {
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
 	sk::Census *census = nullptr;
+	// `fasta gc content`: the genome, resident
+	uint8_t *d_genome = nullptr;
+	int64_t genome_len = 0;
 	// `sam count` region tables
 	int cnt_n_chr = 0;
 	int64_t cnt_n_regions = 0;
@@ -129,6 +132,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->census) sk::census_destroy(c->census);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
+	if (c->d_genome) (void)hipFree(c->d_genome);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -773,6 +777,62 @@ int sk_count_get(sk_ctx *c, uint32_t *region_frags)
 	if (int r = bind(c)) return r;
 	SK_HIP(c, hipStreamSynchronize(c->stream));
 	if (c->cnt_n_regions) SK_HIP(c, hipMemcpy(region_frags, c->d_region_frags, (size_t)c->cnt_n_regions * 4, hipMemcpyDeviceToHost));
+	return SK_OK;
+}
+
+// ---- fasta gc content -------------------------------------------------------------------------------------------
+int sk_gc_set_genome(sk_ctx *c, const uint8_t *genome, int64_t genome_len)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (genome_len < 0 || (genome_len > 0 && !genome)) return fail(c, SK_ERR_INVALID, "sk_gc_set_genome: bad arguments");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->d_genome) { SK_HIP(c, hipFree(c->d_genome)); c->d_genome = nullptr; c->genome_len = 0; }
+	hipError_t e = hipMalloc((void **)&c->d_genome, (size_t)genome_len + 32);
+	if (e != hipSuccess) { c->d_genome = nullptr; return fail(c, SK_ERR_NOMEM, "genome of %lld bytes: %s", (long long)genome_len, hipGetErrorString(e)); }
+	if (genome_len) SK_HIP(c, hipMemcpy(c->d_genome, genome, (size_t)genome_len, hipMemcpyHostToDevice));
+	c->genome_len = genome_len;
+	return SK_OK;
+}
+
+int sk_gc_count(sk_ctx *c, const int64_t *start, const int64_t *len, int64_t n_regions, uint64_t *gc, uint64_t *total)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!c->d_genome) return fail(c, SK_ERR_INVALID, "sk_gc_set_genome has not been called");
+	if (n_regions < 0 || n_regions > 0x7fffffff) return fail(c, SK_ERR_INVALID, "n_regions = %lld", (long long)n_regions);
+	if (n_regions == 0) return SK_OK;
+	if (!start || !len || !gc || !total) return fail(c, SK_ERR_INVALID, "NULL argument");
+	if (int r = bind(c)) return r;
+	// regions -> segments of at most 64 KiB, one wave each
+	const int64_t kSeg = 64 * 1024;
+	std::vector<int64_t> sstart;
+	std::vector<int32_t> slen, sreg;
+	for (int64_t i = 0; i < n_regions; i++) {
+		if (start[i] < 0 || len[i] < 0 || start[i] > c->genome_len || len[i] > c->genome_len - start[i])
+			return fail(c, SK_ERR_INVALID, "region %lld = [%lld, +%lld) leaves the genome (%lld bytes)", (long long)i, (long long)start[i], (long long)len[i], (long long)c->genome_len);
+		for (int64_t o = 0; o < len[i]; o += kSeg) {
+			sstart.push_back(start[i] + o);
+			slen.push_back((int32_t)std::min<int64_t>(kSeg, len[i] - o));
+			sreg.push_back((int32_t)i);
+		}
+	}
+	const size_t ns = sstart.size();
+	const size_t b_out = up256((size_t)n_regions * 16), b_s = up256(ns * 8 + 8), b_l = up256(ns * 4 + 4);
+	if (int r = ensure_ws(c, b_out + b_s + 2 * b_l)) return r;
+	unsigned long long *dout = (unsigned long long *)c->ws;
+	int64_t *dstart = (int64_t *)(c->ws + b_out);
+	int32_t *dlen = (int32_t *)(c->ws + b_out + b_s), *dreg = (int32_t *)(c->ws + b_out + b_s + b_l);
+	SK_HIP(c, hipMemsetAsync(dout, 0, (size_t)n_regions * 16, c->stream));
+	if (ns) {
+		SK_HIP(c, hipMemcpyAsync(dstart, sstart.data(), ns * 8, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dlen, slen.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, hipMemcpyAsync(dreg, sreg.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+		SK_HIP(c, sk::launch_gc_count(c->d_genome, dstart, dlen, dreg, (int64_t)ns, dout, c->n_cu, c->stream));
+	}
+	std::vector<uint64_t> h((size_t)n_regions * 2);
+	SK_HIP(c, hipMemcpyAsync(h.data(), dout, (size_t)n_regions * 16, hipMemcpyDeviceToHost, c->stream));
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	for (int64_t i = 0; i < n_regions; i++) { gc[i] = h[(size_t)2 * i]; total[i] = h[(size_t)2 * i + 1]; }
 	return SK_OK;
 }
 

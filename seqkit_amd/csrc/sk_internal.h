@@ -92,6 +92,9 @@ struct CountArgs {
 };
 hipError_t launch_bam_count(const CountArgs &a, int n_cu, hipStream_t st);
 
+hipError_t launch_gc_count(const uint8_t *genome, const int64_t *seg_start, const int32_t *seg_len, const int32_t *seg_region, int64_t nseg,
+                           unsigned long long *out, int n_cu, hipStream_t st);
+
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st);
 

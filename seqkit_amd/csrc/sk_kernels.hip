@@ -1441,6 +1441,80 @@ hipError_t launch_bam_count(const CountArgs &a, int n_cu, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// `fasta gc content` (src/fasta_gc_content.rs:41-46): per region of a genome held in HBM, gc = bytes that are C, G, c or
+// g and total = bytes that are neither N nor n.  The host cuts regions into segments of at most 64 KiB; one wave
+// counts one segment with 16-byte loads (aligned body, byte-wise head and tail) and adds its two sums to the region's
+// counters.  1 byte read per base: HBM-bound.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 zero_bytes(u32 x)       // 0x80 in every byte of x that is 0
+{
+	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+__device__ __forceinline__ void gc_dword(u32 w, u32 &gc, u32 &non_n)
+{
+	const u32 up = w & 0xDFDFDFDFu;          // clear bit 5: only 'c'/'C', 'g'/'G', 'n'/'N' land on the three letters tested below
+	gc += (u32)__popc(zero_bytes(up ^ 0x43434343u) | zero_bytes(up ^ 0x47474747u));
+	non_n += 4u - (u32)__popc(zero_bytes(up ^ 0x4E4E4E4Eu));
+}
+
+__device__ __forceinline__ void gc_byte(u32 b, u32 &gc, u32 &non_n)
+{
+	const u32 up = b & 0xDFu;
+	gc += (up == 0x43u || up == 0x47u) ? 1u : 0u;
+	non_n += (up != 0x4Eu) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void gc_count_kernel(const uint8_t *__restrict__ genome, const int64_t *__restrict__ seg_start,
+                                                       const int32_t *__restrict__ seg_len, const int32_t *__restrict__ seg_region, int64_t nseg,
+                                                       unsigned long long *__restrict__ out /* [2 * regions]: gc, total */)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+	for (int64_t s = wave; s < nseg; s += nwaves) {
+		const uint8_t *p = genome + seg_start[s];
+		const int n = seg_len[s];
+		u32 gc = 0, non_n = 0;
+		int head = (int)((16 - ((uintptr_t)p & 15)) & 15);
+		if (head > n) head = n;
+		if (lane < head) gc_byte(p[lane], gc, non_n);
+		const int body = (n - head) & ~15;
+		const u32x4 *v = reinterpret_cast<const u32x4 *>(p + head);
+		const int nchunk = body >> 4;
+		int i = lane;
+		for (; i + 192 < nchunk; i += 256) {                                  // four 1 KiB rows of the wave in flight
+			u32x4 w[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) w[k] = stream_load(reinterpret_cast<const uint8_t *>(v + i + 64 * k));
+#pragma unroll
+			for (int k = 0; k < 4; k++) { gc_dword(w[k][0], gc, non_n); gc_dword(w[k][1], gc, non_n); gc_dword(w[k][2], gc, non_n); gc_dword(w[k][3], gc, non_n); }
+		}
+		for (; i < nchunk; i += 64) {
+			const u32x4 w = stream_load(reinterpret_cast<const uint8_t *>(v + i));
+			gc_dword(w[0], gc, non_n); gc_dword(w[1], gc, non_n); gc_dword(w[2], gc, non_n); gc_dword(w[3], gc, non_n);
+		}
+		const int tail0 = head + body;
+		if (tail0 + lane < n) gc_byte(p[tail0 + lane], gc, non_n);
+		for (int o = 32; o > 0; o >>= 1) { gc += __shfl_xor(gc, o); non_n += __shfl_xor(non_n, o); }
+		if (lane == 0) {
+			const int r = seg_region[s];
+			if (gc) atomicAdd(&out[2 * r], (unsigned long long)gc);
+			if (non_n) atomicAdd(&out[2 * r + 1], (unsigned long long)non_n);
+		}
+	}
+}
+
+hipError_t launch_gc_count(const uint8_t *genome, const int64_t *seg_start, const int32_t *seg_len, const int32_t *seg_region, int64_t nseg,
+                           unsigned long long *out, int n_cu, hipStream_t st)
+{
+	if (nseg <= 0) return hipSuccess;
+	const int64_t want = (nseg + 3) / 4;
+	const int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
+	gc_count_kernel<<<grid, 256, 0, st>>>(genome, seg_start, seg_len, seg_region, nseg, out);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f4: `sam to fastq` sequence() (src/sam_to_fastq.rs:31-59) — BAM 4-bit bases -> ASCII, reverse-complemented for
 // reverse-strand records, 'N' where the quality is below min_baseq.  One thread per 16 output bytes; a workgroup
 // walks tiles of 64 rows, whose lengths and strands it keeps in LDS.

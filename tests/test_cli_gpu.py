@@ -833,3 +833,63 @@ def test_fuzz_sam_cli(bins, tmp_path, seed):
         assert a[0] == b[0] and a[1] == b[1] and fa == fb, (seed, args, a[2][-300:], b[2][-300:])
         if a[0] != 101:
             assert a[2] == b[2], (seed, args)
+
+
+# ---- fasta gc content -------------------------------------------------------------------------------------------------
+def test_gc_content_cli(bins, tmp_path):
+    rng = np.random.default_rng(61)
+    chroms = {}
+    fa = []
+    for name, ln in (("chr1", 250_000), ("chr2", 70_001), ("chrN", 500), ("chr1", 1200)):       # the second chr1 replaces the first
+        seq = bytes(rng.choice(list(b"ACGTNacgtn"), size=ln, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).astype(np.uint8))
+        if name == "chrN":
+            seq = b"N" * 250 + b"n" * 250
+        chroms[name] = seq
+        width = int(rng.choice([60, 61, 80]))
+        fa.append(b">" + name.encode() + b" some description\n")
+        for i in range(0, ln, width):
+            fa.append(seq[i:i + width] + (b"\r\n" if rng.random() < 0.05 else b"  \n" if rng.random() < 0.05 else b"\n"))
+    genome = tmp_path / "g.fa"
+    genome.write_bytes(b"".join(fa))
+    lines, expect = [], []
+    for _ in range(600):
+        c = ["chr1", "chr2", "chrN", "chrX"][int(rng.integers(0, 4))]
+        ln = len(chroms.get(c, b"x" * 1000))
+        a = int(rng.integers(0, ln + 1))
+        b = int(rng.integers(a, ln + 1)) if rng.random() < 0.8 else a + int(rng.integers(0, 200))
+        b = min(b, ln)
+        lines.append(f"{c}\t{a}\t{b}" + ("\tname\t0\t+" if rng.random() < 0.3 else "") + "\n")
+        if c in chroms:
+            s = chroms[c][a:b]
+            gc = sum(s.count(x) for x in (b"C", b"G", b"c", b"g"))
+            tot = len(s) - s.count(b"N") - s.count(b"n")
+            expect.append(f"{gc}\t{tot}\t" + ("NaN" if tot == 0 else f"{np.float32(gc) / np.float32(tot):.3f}") + "\n")
+    lines.insert(10, "chrX\t5\n")                                                              # too few columns, unknown chromosome: a warning only
+    bed = tmp_path / "r.bed"
+    bed.write_bytes("".join(lines).encode())
+    a, *_ = both(bins, "fasta", ["gc", "content", str(genome), str(bed)], tmp_path)
+    assert a[0] == 0 and a[1].decode() == "".join(expect) and b"WARNING: Input BED file contains line with less than 3 columns" in a[2]
+    # errors stop the run after what came before them
+    bed.write_bytes(b"chr2\t0\t100\nchr2\t10\t70002\nchr2\t0\t5\n")
+    a, *_ = both(bins, "fasta", ["gc", "content", str(genome), str(bed)], tmp_path)
+    assert a[0] == 255 and a[1].count(b"\n") == 1 and a[2].endswith(b"ERROR: Invalid region:\nchr2\t10\t70002\n\n\n")
+    bed.write_bytes(b"chr2\t7\t3\n")
+    both(bins, "fasta", ["gc", "content", str(genome), str(bed)], tmp_path)
+    bed.write_bytes(b"chr2\tx\t3\n")
+    both(bins, "fasta", ["gc", "content", str(genome), str(bed)], tmp_path)
+    bed.write_bytes(b"chr2\t3\n")
+    a, *_ = both(bins, "fasta", ["gc", "content", str(genome), str(bed)], tmp_path, same_stderr=False)     # cols[2] is out of bounds: a panic
+    assert a[0] == 101
+    bed.write_bytes(b"chr2\t0\t10\n")
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"ACGT\n>chr2\nACGT\n")
+    a, *_ = both(bins, "fasta", ["gc", "content", str(bad), str(bed)], tmp_path, same_stderr=False)        # Expected > at record start.
+    assert a[0] == 101
+    bad.write_bytes(b">chr2\nAC\xffGT\n")
+    a, *_ = both(bins, "fasta", ["gc", "content", str(bad), str(bed)], tmp_path, same_stderr=False)
+    assert a[0] == 101
+    bad.write_bytes(b"")
+    a, *_ = both(bins, "fasta", ["gc", "content", str(bad), str(bed)], tmp_path)                           # empty genome: no chromosome matches
+    assert a[0] == 0 and a[1] == b""
+    for args in (["gc", "content"], ["gc", "content", str(genome)], ["gc", "content", "missing.fa", str(bed)], ["gc", "content", str(genome), "missing.bed"]):
+        both(bins, "fasta", args, tmp_path)

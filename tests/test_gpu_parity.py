@@ -446,6 +446,26 @@ def test_fuzz_fused_pass_random_shapes(ctx, oracle, seed):
             assert np.array_equal(r["out_seq"][i][valid], exp[valid]), (seed, i)
 
 
+# ---- fasta gc content ------------------------------------------------------------------------------------------------
+def test_gc_count_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(17)
+    genome = rng.choice(np.frombuffer(b"ACGTNacgtnRYKM-*", dtype=np.uint8), size=3_000_000, p=[.2, .2, .2, .2, .04, .03, .03, .03, .03, .01] + [.005] * 6)
+    genome = np.ascontiguousarray(genome)
+    ctx.gc_set_genome(genome)
+    starts = np.concatenate([rng.integers(0, len(genome) - 200_000, size=400), [0, 0, len(genome), len(genome) - 1, 5]]).astype(np.int64)
+    lens = np.concatenate([rng.choice([0, 1, 15, 16, 17, 100, 1000, 65535, 65536, 65537, 200_000], size=400), [len(genome), 0, 0, 1, 31]]).astype(np.int64)
+    gc, total = ctx.gc_count(starts, lens)
+    raw = genome.tobytes()
+    for i in range(len(starts)):
+        assert (int(gc[i]), int(total[i])) == oracle.gc_count(raw[starts[i]:starts[i] + lens[i]]), (i, starts[i], lens[i])
+    assert ctx.gc_count(np.zeros(0, np.int64), np.zeros(0, np.int64))[0].size == 0
+    from seqkit_amd.capi import SeqkitHipError
+    with pytest.raises(SeqkitHipError):
+        ctx.gc_count(np.array([len(genome) - 5]), np.array([6]))                # leaves the genome
+    ctx.gc_set_genome(b"")                                                       # an empty genome is a genome
+    assert [int(x) for x in ctx.gc_count(np.array([0]), np.array([0]))[0]] == [0]
+
+
 # ---- f2 (second half): sam count ---------------------------------------------------------------------------------
 def count_inputs(n, n_chr, n_regions, seed, span=2_000_000):
     """Coordinate-sorted record columns and BED-like regions (unsorted, overlapping, nested, empty, some on a chromosome

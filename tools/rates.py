@@ -91,6 +91,21 @@ timeit("sam count 100M records, 20k regions (31 B/record)", lambda: ctx.count_ad
 print("   regions hit:", int((ctx.count_get() > 0).sum()), "of 20000; fragments counted:", int(ctx.count_get().sum()) // (3 * 3 + 2))
 del ctid, cpos, ctl, cflag, cmapq, cmpos
 
+# fasta gc content: a 1 GB genome, 10 000 regions of 100 kb (1 B/base); host entry point, so the region list's upload,
+# the launch and the read-back of 10 000 x 16 B are inside the time
+genome = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)[rng.integers(0, 10, size=1_000_000_000)]
+ctx.gc_set_genome(genome)
+gs = rng.integers(0, 1_000_000_000 - 100_000, size=10000).astype(np.int64)
+gl = np.full(10000, 100_000, dtype=np.int64)
+ctx.gc_count(gs, gl)
+t0 = time.perf_counter()
+for _ in range(5):
+    ctx.gc_count(gs, gl)
+dt = (time.perf_counter() - t0) / 5
+print(f"fasta gc content, 10 000 regions x 100 kb of a resident 1 GB genome: {dt * 1e3:.3f} ms  {1e9 / dt / 1e9:.1f} G bases/s = GB/s ({1e9 / dt / 8e12 * 100:.1f}% of 8 TB/s)", flush=True)
+ctx.gc_set_genome(b"")
+del genome
+
 # f4: sam to fastq sequence(), 16M records x 152-base rows (0.5 + 1 + 1 B per base, + len and flag)
 n = 16_000_000
 s4 = torch.randint(0, 256, (n, 76), dtype=torch.uint8, device=dev, generator=g)
