@@ -7,7 +7,11 @@
  *   fasta mask by quality <fastq_file> <min_baseq>      src/fasta_mask_by_quality.rs:11-47
  *   fasta add barcode <fastq_file> <barcode_file>       src/fasta_add_barcode.rs:11-45
  *   fasta demultiplex [options] <sheet> <fq1> [<fq2>]   src/fasta_demultiplex.rs:30-265
- * dispatch: src/fasta_main.rs:61-76.
+ *   fasta statistics <fastq_file>                        src/fasta_statistics.rs:12-51
+ *   fasta gc content <genome.fa> <regions.bed>           src/fasta_gc_content.rs:17-50
+ *   and the line filters: check, to raw, add / remove base qualities, simplify read ids, interleave, deinterleave,
+ *   split into anchors, trim, extract dual umi, convert basespace (each function cites its source file)
+ * dispatch: src/fasta_main.rs:42-82.
  */
 #include "cli_common.h"
 

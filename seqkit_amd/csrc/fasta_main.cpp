@@ -1,11 +1,14 @@
 // fasta — the `fasta` binary of the reference for its per-read hot path, with the per-read arithmetic done by
 // the MI355X library behind include/seqkit_hip.h.  Same command words, arguments, stdin/stdout/file surface,
-// messages and exit codes as the reference (dispatch: src/fasta_main.rs:61-76):
+// messages and exit codes as the reference (dispatch: src/fasta_main.rs:42-82):
 //
 //   fasta trim by quality <fastq_file> <min_baseq>                 src/fasta_trim_by_quality.rs:10-50
 //   fasta mask by quality <fastq_file> <min_baseq>                 src/fasta_mask_by_quality.rs:11-47
 //   fasta add barcode <fastq_file> <barcode_file>                  src/fasta_add_barcode.rs:11-45
 //   fasta demultiplex [options] <sample_sheet> <fastq_1> [<fastq_2>]   src/fasta_demultiplex.rs:30-265
+//   fasta statistics <fastq_file>                                  src/fasta_statistics.rs:12-51   (device census)
+//   fasta gc content <genome.fa> <regions.bed>                     src/fasta_gc_content.rs:17-50
+//   the host-only line filters live in fasta_text.cpp
 //
 // The host owns parsing and I/O and keeps the reference's record-at-a-time ORDER of effects: records are
 // gathered into batches (fixed-stride SoA), the batch goes through the C-ABI, and the results are emitted
