@@ -3,20 +3,27 @@
 
 Workload (BASELINE.json configs[3], the one the metric is quoted on): 2x150 bp paired clusters, 96 dual-index
 8+8 barcodes (`i7+i5`, 17 chars), <=1 mismatch, min_baseq 20.  configs[3] is 500 M clusters read-sharded over
-8 GPUs; one GPU's shard (62.5 M clusters, 57.8 GB of device-resident SoA buffers) is the per-GPU work at every
-N (weak scaling), so N=8 is exactly configs[3].  A "step" = one pass of the hot path over the rank's whole
-shard + the count reduce (RCCL all-reduce of u64[S+3] when N > 1).  A "read" is one cluster, as the reference's
-own `total_reads` counter counts them (src/fasta_demultiplex.rs:169).
+8 GPUs; one GPU's shard (62.5 M clusters, 57.8 GB of device-resident buffers) is the per-GPU work at every N
+(weak scaling), so N=8 is exactly configs[3].  A "step" = one pass of the hot path over the rank's whole shard +
+the count reduce (RCCL all-reduce of u64[S+3] through the library's own communicator when N > 1).  A "read" is one
+cluster, as the reference's own `total_reads` counter counts them (src/fasta_demultiplex.rs:169).
 
-One JSON line on stdout (rank 0).  Inputs are resident in HBM before the timed region; the kernel duration for
-the roofline object comes from HIP events recorded on the stream the kernel runs on.
+Launch: `python bench.py --gpus N` starts the N rank processes ITSELF (before torch or the GPU is touched) when it
+is not already running under a launcher; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+it is one of the ranks.  Either way: one process per GPU, rank 0 prints ONE JSON line on stdout.  Inputs are
+resident in HBM before the timed region; the kernel duration for the roofline object comes from HIP events recorded
+on the stream the kernel runs on.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,21 +40,84 @@ BYTES_PER_PAIR = 2 * (2 * L_READ) + L_BC + 2 * (L_READ + 2) + 4      # 925
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=62_500_000, help="clusters per GPU (default: configs[3] / 8)")
+    ap.add_argument("--layout", choices=["blocked", "soa"], default=os.environ.get("SK_BENCH_LAYOUT", "blocked"),
+                    help="batch layout in HBM: tile-blocked (one read range + one write range per 64-cluster tile) or row-major SoA matrices")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="clusters timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=1,
                     help="threads for the CPU baseline (the reference's loops are single-threaded, so 1 is the faithful number; "
                          "more threads split the sample into slices)")
+    ap.add_argument("--faithful-reads", type=int, default=1_000_000,
+                    help="reads of cfg 2 / cfg 3 text run through the line-at-a-time oracle CLI for cpu_baseline.faithful (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.rates (device-resident rates of the other configs)")
     ap.add_argument("--gen-chunk", type=int, default=2_000_000)
-    ap.add_argument("--arena", type=int, default=-1,
-                    help="carve every matrix of the shard from ONE allocation (made first), 4 KiB-aligned and staggered by this many bytes; "
-                         "-1 = one torch allocation per matrix")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks here.  Nothing above or inside this function imports torch or touches the
+# GPU, so no process that has initialised a GPU is ever re-executed; rank 0's stdout (the JSON line) is relayed.
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.environ.get("SK_BENCH_WORKER")                  # tests put a stub here
+    cmd = [sys.executable, worker] if worker else [sys.executable, os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    failed = None
+    deadline = time.time() + float(os.environ.get("SK_BENCH_LAUNCH_TIMEOUT", "3000"))
+    pending = set(range(n))
+    import select
+    while pending:
+        if 0 in pending:
+            rd, _, _ = select.select([procs[0].stdout], [], [], 0.2)
+            if rd:
+                chunk = os.read(procs[0].stdout.fileno(), 1 << 16)
+                out0 += chunk
+        else:
+            time.sleep(0.2)
+        for r in list(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            if r == 0:
+                out0 += procs[0].stdout.read() or b""
+            pending.discard(r)
+            if rc != 0 and failed is None:
+                failed = (r, rc)
+        if failed is not None or time.time() > deadline:
+            for r in pending:                                   # the exact children started above, nothing else
+                procs[r].kill()
+            for r in pending:
+                procs[r].wait()
+            if failed is None:
+                failed = (-1, 124)
+            break
+    if failed is not None:
+        sys.stderr.write(f"[bench] rank {failed[0]} failed with exit code {failed[1]}\n")
+        return failed[1] if 0 < failed[1] < 256 else 1
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
+    if not lines:
+        sys.stderr.write("[bench] rank 0 printed nothing\n")
+        return 1
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 def gen_shard(torch, dev, n, table_np, seed, chunk, into=None):
@@ -95,8 +165,164 @@ def gen_shard(torch, dev, n, table_np, seed, chunk, into=None):
     return seq, qual, bc
 
 
+def pack_blocked(torch, lay, seq, qual, bc, nt):
+    """SoA matrices of nt*64 rows -> (input buffer, output buffer) of the tile-blocked layout (device-side byte moves)."""
+    dev = seq[0].device
+    bin_ = torch.zeros(nt * lay.in_block, dtype=torch.uint8, device=dev)
+    v = bin_.view(nt, lay.in_block)
+    row = 64 * lay.stride
+    for i in range(lay.n_mates):
+        v[:, lay.in_qual[i]:lay.in_qual[i] + row] = qual[i].view(nt, row)
+        if lay.in_seq[i] >= 0:
+            v[:, lay.in_seq[i]:lay.in_seq[i] + row] = seq[i].view(nt, row)
+    if lay.in_bc >= 0:
+        v[:, lay.in_bc:lay.in_bc + 64 * lay.bc_stride] = bc.view(nt, 64 * lay.bc_stride)
+    bout = torch.empty(nt * lay.out_block, dtype=torch.uint8, device=dev)
+    return bin_, bout
+
+
+def unpack_blocked(torch, lay, bout, nt):
+    """The first nt tiles of a blocked output buffer as SoA tensors (copies)."""
+    v = bout[:nt * lay.out_block].view(nt, lay.out_block)
+    row = 64 * lay.stride
+    res = {"out_seq": [], "lowest_k": []}
+    for i in range(lay.n_mates):
+        if lay.out_seq[i] >= 0:
+            res["out_seq"].append(v[:, lay.out_seq[i]:lay.out_seq[i] + row].reshape(nt * 64, lay.stride))
+        if lay.out_lowest_k[i] >= 0:
+            res["lowest_k"].append(v[:, lay.out_lowest_k[i]:lay.out_lowest_k[i] + 128].contiguous().view(torch.int16).reshape(nt * 64))
+    if lay.out_assign >= 0:
+        res["assign"] = v[:, lay.out_assign:lay.out_assign + 256].contiguous().view(torch.int32).reshape(nt * 64)
+    return res
+
+
+def library_digest() -> str:
+    import seqkit_amd
+    h = hashlib.sha256()
+    with open(seqkit_amd.library_path(), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def kernel_sources_digest() -> str:
+    """Digest of the kernel sources: the PMC traffic record in profiles/ is only quoted for the kernels it was measured on."""
+    h = hashlib.sha256()
+    for name in ("sk_kernels.hip", "sk_internal.h"):
+        with open(os.path.join(REPO, "seqkit_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def secondary_rates(torch, ctx, dev):
+    """extra.rates: device-resident rates of the other BASELINE configs on this GPU, a few ms each, outside the timed
+    region.  Same workloads as tools/rates.py; `frac` is algorithmic bytes / time / 8 TB/s."""
+    from seqkit_amd import synth
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    out = []
+
+    def timeit(name, fn, units, bpu, iters=10, rounds=3):
+        for _ in range(2):
+            fn()
+        ctx.sync()
+        ts = []
+        for _ in range(rounds):
+            ctx.timer_start()
+            for _ in range(iters):
+                fn()
+            ts.append(ctx.timer_stop() / iters)
+        ms = sorted(ts)[len(ts) // 2]
+        gbs = units * bpu / ms / 1e6
+        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(units / ms / 1e6, 2), "bytes_per_unit": bpu,
+                    "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+
+    n = 16_000_000
+    q = torch.randint(35, 74, (n, 150), dtype=torch.uint8, device=dev, generator=g)
+    s = torch.randint(65, 85, (n, 150), dtype=torch.uint8, device=dev, generator=g)
+    o = torch.empty_like(s)
+    lk = torch.empty((n,), dtype=torch.int16, device=dev)
+    timeit("cfg1 shape: mask by quality 16M x 150bp", lambda: ctx.mask_by_quality_dev(s.data_ptr(), q.data_ptr(), 150, n, 20, o.data_ptr()), n, 450)
+    timeit("cfg2 worst case: trim by quality 16M x 150bp, uniform Q2-Q40 (no early break)",
+           lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
+    timeit("cfg2: trim by quality 1M x 150bp, uniform Q2-Q40", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, 1_000_000, 20, lk.data_ptr()), 1_000_000, 152)
+    mu = 36.0 - 16.0 * (torch.arange(150, device=dev, dtype=torch.float32) / 149) ** 2
+    for r0 in range(0, n, 2_000_000):
+        q[r0:r0 + 2_000_000] = ((torch.randn((2_000_000, 150), generator=g, device=dev) * 6.0 + mu).round_().clamp_(2, 40) + 33).to(torch.uint8)
+    timeit("cfg2 read-like qualities: trim by quality 16M x 150bp", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
+    del q, s, o, lk
+    n = 10_000_000
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    ctx.set_barcodes(table, 1)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
+    bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+    assign = torch.empty((n,), dtype=torch.int32, device=dev)
+    timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    ctx.set_barcodes(table, 1)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+    bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+    timeit("demultiplex only 10M x 17ch, 96 dual-index", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
+    del bc, assign
+    n = 200_000_000
+    flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
+    flag = torch.from_numpy(flag_np.view(np.int16)).to(dev).repeat(100)
+    tid = torch.from_numpy(tid_np).to(dev).repeat(100)
+    mtid = torch.from_numpy(mtid_np).to(dev).repeat(100)
+    tlen = torch.from_numpy(tlen_np).to(dev).repeat(100)
+    outb = torch.zeros((4 + 5001,), dtype=torch.int64, device=dev)
+    timeit("cfg5: sam statistics + fragment lengths 200M records",
+           lambda: ctx.bam_flag_tlen_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 5000, outb.data_ptr()), n, 14, iters=3)
+    del flag, tid, mtid, tlen
+    return out
+
+
+def faithful_cpu(n_reads):
+    """cpu_baseline.faithful: the line-at-a-time oracle CLI — same loops as the reference's commands,
+    one thread — end to end on cfg 2 / cfg 3 text, stdout to /dev/null (per-sample gzip children included for
+    demultiplex, as the reference spawns them)."""
+    from oracle import oracle as orc
+    from seqkit_amd import synth
+    orc.build()
+    d = tempfile.mkdtemp(prefix="sk_faithful_")
+    res = {}
+    try:
+        nb = min(n_reads, 100_000)
+        reps = max(1, n_reads // nb)
+        seq, qual = synth.make_reads(nb, 150, seed=2)
+        qual = synth.add_forced_classes(qual, seed=2)
+        table = synth.make_sheet(16, 8, dual=False, seed=3)
+        bc, _ = synth.observe_barcodes(table, nb, seed=3)
+        headers = [f"@SIM:3:{i} 1:N:0".encode() + b" BC:" + bc[i].tobytes() for i in range(nb)]
+        block = synth.fastq_text(seq, qual, headers=headers)
+        fq = os.path.join(d, "in.fq")
+        with open(fq, "wb") as f:
+            for _ in range(reps):
+                f.write(block)
+        sheet = os.path.join(d, "sheet.tsv")
+        with open(sheet, "wb") as f:
+            for i in range(16):
+                f.write(f"S{i:02d}\t".encode() + table[i].tobytes() + b"\n")
+        n = nb * reps
+        for key, argv in (("cfg2_trim_by_quality", ["trim", "by", "quality", fq, "20"]),
+                          ("cfg1_mask_by_quality", ["mask", "by", "quality", fq, "20"]),
+                          ("cfg3_demultiplex_16", ["demultiplex", sheet, fq])):
+            t0 = time.perf_counter()
+            r = subprocess.run([orc.FASTA_BIN] + argv, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            res[key] = {"M_reads_per_s": round(n / dt / 1e6, 3), "seconds": round(dt, 2), "reads": n, "rc": r.returncode}
+        res["what"] = ("oracle CLI (C restatement of the reference's line-at-a-time command loops, 1 thread; demultiplex with its gzip "
+                       "children), 150 bp text FASTQ -> /dev/null; not the Rust binary")
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     # stdout carries exactly ONE line (the JSON).  Everything else that writes to fd 1 — RCCL's version banner comes out
     # of C stdio at exit, torch warnings, ... — is sent to stderr; the JSON line goes to the saved descriptor at the end.
     sys.stdout.flush()
@@ -105,82 +331,76 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist
 
     import seqkit_amd
-    from seqkit_amd import shard, synth
+    from seqkit_amd import capi, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = None
-    if world > 1 or os.environ.get("SK_BENCH_FORCE_DIST"):
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        try:
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # nccl == RCCL on ROCm (xGMI links)
-            backend = "nccl"
-        except Exception as e:                              # keep the bench alive if RCCL cannot come up: counts via gloo
-            sys.stderr.write(f"[bench] RCCL init failed ({e}); falling back to gloo for the count reduce\n")
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            backend = "gloo"
-
     ctx = seqkit_amd.Context(local_rank)                    # raises if libseqkit_hip.so is missing
     table = synth.make_sheet(S_SAMPLES, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
 
+    # Ranks meet over gloo (plumbing: rendezvous, barrier, max of the elapsed times); the path's one collective —
+    # the sum of the u64[S+3] counters — runs in the library's own RCCL communicator on the ctx stream.
+    distributed = world > 1 or bool(os.environ.get("SK_BENCH_FORCE_DIST"))
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init_rank(box[0], rank, world)
+
     n = args.pairs
-    if args.arena >= 0:
-        sizes = [n * L_READ] * 4 + [n * L_BC] + [n * L_READ] * 2 + [n * 2] * 2 + [n * 4]
-        step = [(sz + args.arena + 4095) // 4096 * 4096 for sz in sizes]
-        arena = torch.empty(sum(step) + 4096, dtype=torch.uint8, device=dev)
-        offs = [sum(step[:i]) for i in range(len(step))]
-        cut = [arena[o:o + sz] for o, sz in zip(offs, sizes)]
-        seq = [cut[0].view(n, L_READ), cut[2].view(n, L_READ)]
-        qual = [cut[1].view(n, L_READ), cut[3].view(n, L_READ)]
-        bc = cut[4].view(n, L_BC)
-        out_seq = [cut[5].view(n, L_READ), cut[6].view(n, L_READ)]
-        lowest_k = [cut[7].view(torch.int16), cut[8].view(torch.int16)]
-        assign = cut[9].view(torch.int32)
-        gen_shard(torch, dev, n, table, seed=4000 + rank, chunk=args.gen_chunk, into=(seq, qual, bc))
-    else:
-        seq, qual, bc = gen_shard(torch, dev, n, table, seed=4000 + rank, chunk=args.gen_chunk)
-        out_seq = [torch.empty_like(seq[0]) for _ in range(2)]
-        lowest_k = [torch.empty((n,), dtype=torch.int16, device=dev) for _ in range(2)]     # raw u16 storage
-        assign = torch.empty((n,), dtype=torch.int32, device=dev)
+    nt = (n + 63) // 64
+    npad = nt * 64                                           # whole tiles, so that the SoA matrices repack into blocks as views
+    seq, qual, bc = gen_shard(torch, dev, npad, table, seed=4000 + rank, chunk=args.gen_chunk)
     counts = torch.zeros((S_SAMPLES + 3,), dtype=torch.int64, device=dev)
+    lay = None
+    if args.layout == "blocked":
+        lay = capi.blocked_layout(2, L_READ, L_BC, capi.SK_BLK_MASK | capi.SK_BLK_TRIM)
+        bin_, bout = pack_blocked(torch, lay, seq, qual, bc, nt)
+        ns_keep = min(max(args.cpu_sample, 0), n)
+        ns_keep = (ns_keep + 63) // 64 * 64
+        seq = [t[:ns_keep].clone() for t in seq]             # only the parity sample stays in SoA form
+        qual = [t[:ns_keep].clone() for t in qual]
+        bc = bc[:ns_keep].clone()
+        torch.cuda.empty_cache()
+    else:
+        out_seq = [torch.empty_like(seq[0]) for _ in range(2)]
+        lowest_k = [torch.empty((npad,), dtype=torch.int16, device=dev) for _ in range(2)]     # raw u16 storage
+        assign = torch.empty((npad,), dtype=torch.int32, device=dev)
+        mates = [{"seq": seq[i].data_ptr(), "qual": qual[i].data_ptr(), "len": 0,
+                  "out_seq": out_seq[i].data_ptr(), "lowest_k": lowest_k[i].data_ptr()} for i in range(2)]
     torch.cuda.synchronize()
 
     # everything below runs on the ctx's own HIP stream (torch sees it as an external stream)
     stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
-    mates = [{"seq": seq[i].data_ptr(), "qual": qual[i].data_ptr(), "len": 0,
-              "out_seq": out_seq[i].data_ptr(), "lowest_k": lowest_k[i].data_ptr()} for i in range(2)]
 
     def step(ev=None):
         with torch.cuda.stream(stream):
             counts.zero_()
             if ev is not None:
                 ev[0].record(stream)
-            ctx.fused_pass_dev(n, L_READ, MIN_BASEQ, mates, bc=bc.data_ptr(), bc_stride=L_BC,
-                               assign=assign.data_ptr(), counts=counts.data_ptr())
+            if lay is not None:
+                ctx.fused_pass_blocked_dev(lay, bin_.data_ptr(), bout.data_ptr(), n, MIN_BASEQ, counts=counts.data_ptr())
+            else:
+                ctx.fused_pass_dev(n, L_READ, MIN_BASEQ, mates, bc=bc.data_ptr(), bc_stride=L_BC,
+                                   assign=assign.data_ptr(), counts=counts.data_ptr())
             if ev is not None:
                 ev[1].record(stream)
-            if backend == "gloo":                            # host round trip (only when RCCL is unavailable)
-                h = counts.cpu()
-                shard.reduce_counts(h)
-                counts.copy_(h)
-            else:
-                shard.reduce_counts(counts)                  # the path's only cross-shard state (no-op at N=1)
+            ctx.allreduce_u64_dev(counts.data_ptr(), S_SAMPLES + 3)     # the path's only cross-shard state (nothing to do at N=1)
 
     def fence():
-        if backend is not None:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,8 +413,8 @@ def main():
         step(events[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if backend is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
@@ -209,6 +429,11 @@ def main():
     if rank == 0 and args.cpu_sample > 0:
         from oracle import oracle as orc
         ns = min(args.cpu_sample, n)
+        if lay is not None:
+            u = unpack_blocked(torch, lay, bout, (ns + 63) // 64)
+            g_assign, g_k, g_m = u["assign"][:ns], [x[:ns] for x in u["lowest_k"]], [x[:ns] for x in u["out_seq"]]
+        else:
+            g_assign, g_k, g_m = assign[:ns], [x[:ns] for x in lowest_k], [x[:ns] for x in out_seq]
         h_bc = bc[:ns].cpu().numpy()
         h_seq = [seq[i][:ns].cpu().numpy() for i in range(2)]
         h_qual = [qual[i][:ns].cpu().numpy() for i in range(2)]
@@ -232,10 +457,10 @@ def main():
         e_assign = np.concatenate([p[0] for p in parts])
         e_k = [np.concatenate([p[1][i] for p in parts]) for i in range(2)]
         e_m = [np.concatenate([p[2][i] for p in parts]) for i in range(2)]
-        ok = np.array_equal(assign[:ns].cpu().numpy(), e_assign)
+        ok = np.array_equal(g_assign.cpu().numpy(), e_assign)
         for i in range(2):
-            ok = ok and np.array_equal(lowest_k[i][:ns].cpu().numpy().view(np.uint16), e_k[i])
-            ok = ok and np.array_equal(out_seq[i][:ns].cpu().numpy(), e_m[i])
+            ok = ok and np.array_equal(g_k[i].cpu().numpy().view(np.uint16), e_k[i])
+            ok = ok and np.array_equal(g_m[i].cpu().numpy(), e_m[i])
         parity = bool(ok)
         cpu_baseline = {"value": round(ns / cpu_s / 1e6, 4), "unit": "M reads/s", "cores": nthr, "kind": "port",
                         "sample": f"first {ns} clusters of rank 0's shard, same fused work (demultiplex + 2x trim + 2x mask), "
@@ -244,20 +469,44 @@ def main():
                                   "not the Rust binary"}
         if not ok:
             raise SystemExit("PARITY FAILURE: GPU outputs differ from the oracle on the sampled clusters")
+        if args.faithful_reads > 0:
+            try:
+                cpu_baseline["faithful"] = faithful_cpu(args.faithful_reads)
+            except Exception as e:                                   # a reported baseline must not take the bench line down
+                cpu_baseline["faithful"] = {"error": str(e)}
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        if lay is not None:
+            del bin_, bout
+        else:
+            del out_seq, lowest_k, assign, mates
+        del seq, qual, bc
+        torch.cuda.empty_cache()
+        try:
+            extra = {"rates": secondary_rates(torch, ctx, dev),
+                     "note": "device-resident, outside the timed region, HIP events on the ctx stream; frac = algorithmic bytes / time / 8 TB/s"}
+        except Exception as e:
+            extra = {"error": str(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n * world / (elapsed / args.steps) / 1e6
         achieved = BYTES_PER_PAIR * n / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes (tools/profile_bench.sh) and
+        # recorded in profiles/pmc_traffic.json together with the digest of the kernel sources they were taken on; the record is
+        # quoted only when it matches this build, layout and size — otherwise traffic is null.
         traffic = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("pairs") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("pairs") == n and tj.get("layout") == args.layout and tj.get("kernel_sources_sha256_16") == kernel_sources_digest():
+                    traffic = {"value": tj.get("hbm_bytes_per_launch"), "source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this build)",
+                               "kernel_sources_sha256_16": tj.get("kernel_sources_sha256_16")}
             except Exception:
                 traffic = None
+        kernel = "sk::tile_blocked_kernel" if lay is not None else "sk::tile_pass_kernel"
         line = {
             "metric": "M reads/s demultiplex (150bp, 96 barcodes) at 1/8 GPUs; % HBM roofline",
             "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -268,19 +517,25 @@ def main():
                                    "min_baseq 20 (= BASELINE configs[3], 500M clusters read-sharded over 8 GPUs)",
                        "clusters_per_gpu": n, "read_len": L_READ, "barcodes": S_SAMPLES, "barcode_len": L_BC,
                        "min_baseq": MIN_BASEQ, "read_unit": "cluster (as the reference's total_reads counts)",
-                       "count_reduce": ("RCCL all-reduce u64[99] per step" if backend == "nccl" else "gloo all-reduce u64[99] per step") if backend else "none (1 GPU)"},
+                       "layout": args.layout,
+                       "count_reduce": (f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
+                                        if distributed else "none (1 GPU)")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "sk::tile_pass_kernel", "kernel_ms": round(kern_ms, 4),
+                         "kernel": kernel, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},
             "cpu_baseline": cpu_baseline,
             "parity_sample_ok": parity,
             "identified_frac": round(float(total_counts[S + 1]) / float(total_counts[S]), 4),
+            "library_sha256_16": library_digest(),
+            "extra": extra,
         }
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if distributed:
+        ctx.comm_destroy()
     ctx.close()
-    if backend is not None:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -35,6 +35,7 @@ extern "C" {
 #define SK_ERR_NO_DEVICE (-3)  /* no gfx950-capable device at that index                              */
 #define SK_ERR_STATE    (-4)   /* call order (e.g. demux before sk_set_barcodes)                      */
 #define SK_ERR_NOMEM    (-5)
+#define SK_ERR_COMM     (-6)   /* RCCL: library not loadable, or a collective failed                   */
 
 /* assignment codes written by the demultiplex entry points (src/fasta_demultiplex.rs:168-194) */
 #define SK_ASSIGN_NONE      (-1)   /* lowest_diff > max_diff                                   */
@@ -131,6 +132,35 @@ typedef struct {
 int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
 int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 
+/* ---- the fused pass over a TILE-BLOCKED batch -----------------------------------------------------------------
+ * Same arithmetic and the same reference lines as sk_fused_pass; only where the bytes sit differs.  A batch is cut
+ * into tiles of 64 consecutive clusters.  Everything tile t READS is one contiguous block of `in_block` bytes at
+ * in + t*in_block, everything it WRITES one block of `out_block` bytes at out + t*out_block; inside a block every
+ * array of the 64 clusters is one segment: row (r mod 64) of mate m's qualities at  in_qual[m] + (r mod 64)*stride,
+ * its bases at in_seq[m] + ..., the observed barcode at in_bc + (r mod 64)*bc_stride, the optional u16 length at
+ * in_len[m] + 2*(r mod 64); outputs likewise (out_seq[m], u16 out_lowest_k[m], i32 out_assign, and with
+ * SK_BLK_DETAIL u8 out_lowest_diff, i16 out_first_idx, i16 out_last_idx).  Offsets of absent segments are -1.
+ * Both buffers hold WHOLE blocks also for the last, partial tile ((n+63)/64 blocks; the padding rows are read and
+ * their outputs are unspecified).  Why: a device wave streams one read range and one write range per tile, and a
+ * host moves a batch with ONE copy per direction.  sk_blocked_layout_init fills the struct from the shape; the
+ * packer (host) owns the layout, so no existing file format is touched.  Served shapes: stride <= 960; with
+ * barcodes, sheets of <= 128 samples over <= 7 distinct non-wildcard bytes, L <= 31, bc_stride <= 32 — everything
+ * else takes sk_fused_pass(_dev) (SK_ERR_INVALID here).                                                          */
+#define SK_BLK_MASK   1     /* out_seq segments (mask by quality)                 */
+#define SK_BLK_TRIM   2     /* out_lowest_k segments (trim by quality)            */
+#define SK_BLK_LEN    4     /* in_len segments (ragged rows); else every row is `stride` long */
+#define SK_BLK_DETAIL 8     /* lowest_diff / first_idx / last_idx beside assign   */
+typedef struct {
+	int32_t n_mates, stride, bc_stride, flags;   /* bc_stride 0 = no barcodes (no demultiplex)                  */
+	int32_t in_block, out_block;                 /* bytes per tile of 64 clusters (multiples of 64)             */
+	int32_t in_qual[2], in_seq[2], in_len[2], in_bc;
+	int32_t out_seq[2], out_lowest_k[2], out_assign, out_lowest_diff, out_first_idx, out_last_idx;
+} sk_blocked_layout;
+int sk_blocked_layout_init(sk_blocked_layout *lay, int n_mates, int stride, int bc_stride, int flags);
+/* in/out: device buffers of ((n+63)/64) * in_block / out_block bytes, 16-byte aligned; counts as in sk_fused_args */
+int sk_fused_pass_blocked_dev(sk_ctx *ctx, const sk_blocked_layout *lay, const uint8_t *in, uint8_t *out, int64_t n,
+                              uint8_t min_baseq, uint64_t *counts);
+
 /* ---- counters: sample.total_reads[S], total_reads, identified_reads (+ ambiguous) -----------------
  * src/fasta_demultiplex.rs:108-109,169,177-178.  Layout u64[S+3]: per-sample counts, then [S] total,
  * [S+1] identified, [S+2] ambiguous.  These are the only cross-shard state of the path; a multi-GPU
@@ -138,6 +168,26 @@ int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 int sk_counts_reset(sk_ctx *ctx);
 int sk_counts_get(sk_ctx *ctx, uint64_t *counts /* host, S+3 */);
 void *sk_counts_device_ptr(sk_ctx *ctx);
+
+/* ---- (e) multi-GPU: the count reduce over RCCL / xGMI ---------------------------------------------------------
+ * Reads shard trivially (every cluster is independent); the additive counters above — and the BAM counters and
+ * histogram — are the only state that crosses shards (src/fasta_demultiplex.rs:108-109,169,177-178 are plain `+= 1`
+ * on one thread in the reference).  RCCL (librccl.so.1, loaded on first use) sums them; there is no other collective.
+ *  - one process driving several GPUs (the C++ hosts): sk_counts_allreduce(ctxs, n) sums the u64[S+3] counters of
+ *    all n ctxs in place, so that every ctx ends with the totals.  Ctxs that share a device are summed on that device
+ *    first; distinct devices then take part in one ncclAllReduce(ncclSum, ncclUint64) on their ctx streams (a
+ *    communicator per device set is created with ncclCommInitAll on first use).  Synchronous when n > 1.
+ *  - one process per GPU (bench.py, torchrun): rank 0 calls sk_comm_get_unique_id, the host hands the 128 bytes to
+ *    every rank (any side channel), every rank calls sk_comm_init_rank; afterwards sk_counts_allreduce(&ctx, 1) and
+ *    sk_allreduce_u64_dev sum across the ranks, enqueued on the ctx stream (asynchronous; sk_sync waits).          */
+#define SK_COMM_ID_BYTES 128
+int sk_comm_get_unique_id(uint8_t id[SK_COMM_ID_BYTES]);
+int sk_comm_init_rank(sk_ctx *ctx, const uint8_t id[SK_COMM_ID_BYTES], int rank, int n_ranks);
+int sk_comm_destroy(sk_ctx *ctx);
+int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx);
+/* in-place sum of a device u64 vector over the ranks of sk_comm_init_rank (BAM counters + histogram, or counters
+ * a host keeps in its own device buffer); a ctx without a communicator is its own world: nothing to do.           */
+int sk_allreduce_u64_dev(sk_ctx *ctx, uint64_t *buf, size_t count);
 
 /* ---- S1 + H1: BAM flag counters and |TLEN| histogram -----------------------------------------------
  * src/sam_statistics.rs:63-69 (counters[0]=total, [1]=aligned, [2]=duplicate) and

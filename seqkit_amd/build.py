@@ -51,7 +51,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(LIB_PATH, HIP_DEPS):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + HIP_SOURCES
+               "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + HIP_SOURCES + ["-ldl"]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         _run(cmd, CSRC)

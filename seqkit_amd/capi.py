@@ -24,7 +24,9 @@ EXPORTED_SYMBOLS = [
     "sk_malloc_device", "sk_free_device", "sk_malloc_pinned", "sk_free_pinned", "sk_copy_h2d", "sk_copy_d2h",
     "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
-    "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
+    "sk_blocked_layout_init", "sk_fused_pass_blocked_dev",
+    "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
+    "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
     "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get", "sk_gc_set_genome", "sk_gc_count",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
@@ -46,6 +48,76 @@ class _FusedArgs(C.Structure):
                 ("mate", _Mate * 2), ("bc", C.c_void_p), ("bc_stride", C.c_int), ("assign", C.c_void_p),
                 ("lowest_diff", C.c_void_p), ("first_idx", C.c_void_p), ("last_idx", C.c_void_p),
                 ("counts", C.c_void_p)]
+
+
+SK_BLK_MASK, SK_BLK_TRIM, SK_BLK_LEN, SK_BLK_DETAIL = 1, 2, 4, 8
+
+
+class BlockedLayout(C.Structure):
+    """sk_blocked_layout: where each array of a 64-cluster tile sits inside the tile's input / output block."""
+    _fields_ = [("n_mates", C.c_int32), ("stride", C.c_int32), ("bc_stride", C.c_int32), ("flags", C.c_int32),
+                ("in_block", C.c_int32), ("out_block", C.c_int32),
+                ("in_qual", C.c_int32 * 2), ("in_seq", C.c_int32 * 2), ("in_len", C.c_int32 * 2), ("in_bc", C.c_int32),
+                ("out_seq", C.c_int32 * 2), ("out_lowest_k", C.c_int32 * 2), ("out_assign", C.c_int32),
+                ("out_lowest_diff", C.c_int32), ("out_first_idx", C.c_int32), ("out_last_idx", C.c_int32)]
+
+    def ntiles(self, n: int) -> int:
+        return (n + 63) // 64
+
+    def in_bytes(self, n: int) -> int:
+        return self.ntiles(n) * self.in_block
+
+    def out_bytes(self, n: int) -> int:
+        return self.ntiles(n) * self.out_block
+
+    # ---- host-side packer / unpacker (numpy views only: bytes are moved, nothing is computed) ----------------
+    def _seg(self, buf: np.ndarray, block: int, off: int, row_bytes: int) -> np.ndarray:
+        """[ntiles, 64, row_bytes] view of one segment of every block."""
+        nt = buf.size // block
+        return np.lib.stride_tricks.as_strided(buf[off:], shape=(nt, 64, row_bytes), strides=(block, row_bytes, 1))
+
+    def pack(self, mates, bc=None) -> np.ndarray:
+        """mates: list of (seq, qual, len-or-None) uint8 [n, stride] matrices -> the input buffer (uint8, whole blocks)."""
+        n = mates[0][1].shape[0]
+        nt = self.ntiles(n)
+        buf = np.zeros(nt * self.in_block, dtype=np.uint8)
+
+        def put(off, mat, row_bytes):
+            seg = self._seg(buf, self.in_block, off, row_bytes)
+            full = n // 64
+            m2 = np.ascontiguousarray(mat).view(np.uint8).reshape(n, row_bytes)
+            if full:
+                seg[:full] = m2[:full * 64].reshape(full, 64, row_bytes)
+            if n % 64:
+                seg[full, :n % 64] = m2[full * 64:]
+        for m, (seq, qual, length) in enumerate(mates):
+            put(self.in_qual[m], qual, self.stride)
+            if self.in_seq[m] >= 0:
+                put(self.in_seq[m], seq, self.stride)
+            if self.in_len[m] >= 0:
+                put(self.in_len[m], np.asarray(length, dtype=np.uint16), 2)
+        if self.in_bc >= 0:
+            put(self.in_bc, bc, self.bc_stride)
+        return buf
+
+    def unpack(self, out: np.ndarray, n: int) -> dict:
+        def get(off, row_bytes, dtype=np.uint8):
+            seg = self._seg(out, self.out_block, off, row_bytes)
+            flat = np.ascontiguousarray(seg).reshape(-1, row_bytes)[:n]
+            return flat if dtype == np.uint8 and row_bytes != 1 else np.ascontiguousarray(flat).view(dtype).reshape(n)
+        res = {"out_seq": [], "lowest_k": []}
+        for m in range(self.n_mates):
+            if self.out_seq[m] >= 0:
+                res["out_seq"].append(get(self.out_seq[m], self.stride))
+            if self.out_lowest_k[m] >= 0:
+                res["lowest_k"].append(get(self.out_lowest_k[m], 2, np.uint16))
+        if self.out_assign >= 0:
+            res["assign"] = get(self.out_assign, 4, np.int32)
+        if self.out_lowest_diff >= 0:
+            res["lowest_diff"] = get(self.out_lowest_diff, 1, np.uint8)
+            res["first_idx"] = get(self.out_first_idx, 2, np.int16)
+            res["last_idx"] = get(self.out_last_idx, 2, np.int16)
+        return res
 
 
 _libs: dict = {}
@@ -83,7 +155,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_mask_by_quality_dev": (i32, [vp, vp, vp, i32, i64, u8, vp]),
         "sk_fused_pass": (i32, [vp, C.POINTER(_FusedArgs)]),
         "sk_fused_pass_dev": (i32, [vp, C.POINTER(_FusedArgs)]),
+        "sk_blocked_layout_init": (i32, [C.POINTER(BlockedLayout), i32, i32, i32, i32]),
+        "sk_fused_pass_blocked_dev": (i32, [vp, C.POINTER(BlockedLayout), vp, vp, i64, u8, vp]),
         "sk_counts_reset": (i32, [vp]), "sk_counts_get": (i32, [vp, vp]), "sk_counts_device_ptr": (vp, [vp]),
+        "sk_comm_get_unique_id": (i32, [vp]), "sk_comm_init_rank": (i32, [vp, vp, i32, i32]), "sk_comm_destroy": (i32, [vp]),
+        "sk_counts_allreduce": (i32, [C.POINTER(vp), i32]), "sk_allreduce_u64_dev": (i32, [vp, vp, C.c_size_t]),
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
         "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
@@ -110,6 +186,23 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn.argtypes = args
     _libs[path] = lib
     return lib
+
+
+def blocked_layout(n_mates: int, stride: int, bc_stride: int, flags: int, lib=None) -> BlockedLayout:
+    lay = BlockedLayout()
+    rc = (lib or load_library()).sk_blocked_layout_init(C.byref(lay), n_mates, stride, bc_stride, flags)
+    if rc != 0:
+        raise SeqkitHipError(f"sk_blocked_layout_init({n_mates}, {stride}, {bc_stride}, {flags}) failed ({rc})")
+    return lay
+
+
+def comm_unique_id(lib=None) -> bytes:
+    """sk_comm_get_unique_id: 128 opaque bytes rank 0 hands to every rank (ncclGetUniqueId underneath)."""
+    buf = (C.c_uint8 * 128)()
+    rc = (lib or load_library()).sk_comm_get_unique_id(buf)
+    if rc != 0:
+        raise SeqkitHipError(f"sk_comm_get_unique_id failed ({rc})")
+    return bytes(buf)
 
 
 def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
@@ -213,6 +306,25 @@ class Context:
 
     def counts_device_ptr(self) -> int:
         return int(self._lib.sk_counts_device_ptr(self._h) or 0)
+
+    # ---- (e) the count reduce over RCCL ----------------------------------------------------
+    def comm_init_rank(self, unique_id: bytes, rank: int, n_ranks: int) -> None:
+        """One process per GPU: join the communicator whose 128-byte id rank 0 made with comm_unique_id()."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.sk_comm_init_rank(self._h, buf, rank, n_ranks), "sk_comm_init_rank")
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.sk_comm_destroy(self._h), "sk_comm_destroy")
+
+    def counts_allreduce(self, others=()) -> None:
+        """Sum the u64[S+3] counters over `self` + `others` (one process, several ctxs), or — alone, after
+        comm_init_rank — over the ranks."""
+        ctxs = [self] + list(others)
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        self._check(self._lib.sk_counts_allreduce(arr, len(ctxs)), "sk_counts_allreduce")
+
+    def allreduce_u64_dev(self, buf: int, count: int) -> None:
+        self._check(self._lib.sk_allreduce_u64_dev(self._h, buf, count), "sk_allreduce_u64_dev")
 
     # ---- host entry points --------------------------------------------------------------
     def demux_assign(self, bc, want_detail: bool = True):
@@ -455,6 +567,31 @@ class Context:
         a.last_idx = last_idx or None
         a.counts = counts or None
         self._check(self._lib.sk_fused_pass_dev(self._h, C.byref(a)), "sk_fused_pass_dev")
+
+    def fused_pass_blocked_dev(self, lay: BlockedLayout, inp: int, out: int, n: int, min_baseq: int, counts: int = 0) -> None:
+        self._check(self._lib.sk_fused_pass_blocked_dev(self._h, C.byref(lay), inp, out, n, min_baseq, counts or None),
+                    "sk_fused_pass_blocked_dev")
+
+    def fused_pass_blocked(self, mates, min_baseq: int, bc=None, want_detail: bool = False, do_mask: bool = True,
+                           do_trim: bool = True) -> dict:
+        """The tile-blocked pass on host matrices: pack -> device -> sk_fused_pass_blocked_dev -> unpack (tests)."""
+        n, stride = mates[0][1].shape
+        ragged = mates[0][2] is not None
+        flags = (SK_BLK_MASK if do_mask else 0) | (SK_BLK_TRIM if do_trim else 0) | (SK_BLK_LEN if ragged else 0) | \
+                (SK_BLK_DETAIL if want_detail else 0)
+        lay = blocked_layout(len(mates), stride, 0 if bc is None else bc.shape[1], flags, self._lib)
+        hin = lay.pack(mates, bc)
+        hout = np.empty(lay.out_bytes(n), dtype=np.uint8)
+        din, dout = self.malloc_device(hin.nbytes + 16), self.malloc_device(hout.nbytes + 16)
+        try:
+            self.copy_h2d(din, hin)
+            self.fused_pass_blocked_dev(lay, din, dout, n, min_baseq)
+            self.copy_d2h(hout, dout)
+            self.sync()
+        finally:
+            self.free_device(din)
+            self.free_device(dout)
+        return lay.unpack(hout, n)
 
     def demux_assign_dev(self, bc: int, bc_stride: int, n: int, assign: int, lowest_diff: int = 0, first_idx: int = 0,
                          last_idx: int = 0, counts: int = 0) -> None:

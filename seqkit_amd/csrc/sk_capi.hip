@@ -1,12 +1,15 @@
 // sk_capi.hip — the C-ABI of include/seqkit_hip.h on top of the gfx950 kernels.
 // No CPU fallback lives here: without a GPU sk_create() fails and every other call needs a ctx.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is loaded with dlopen on first use
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,6 +35,8 @@ struct sk_ctx {
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
 	sk::Census *census = nullptr;
+	ncclComm_t comm = nullptr;         // one-process-per-GPU communicator (sk_comm_init_rank)
+	int comm_ranks = 0;
 	// `fasta gc content`: the genome, resident
 	uint8_t *d_genome = nullptr;
 	int64_t genome_len = 0;
@@ -131,6 +136,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->census) sk::census_destroy(c->census);
+	if (c->comm) (void)sk_comm_destroy(c);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->d_genome) (void)hipFree(c->d_genome);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -319,6 +325,186 @@ int sk_counts_get(sk_ctx *c, uint64_t *counts)
 
 void *sk_counts_device_ptr(sk_ctx *c) { return (c && c->have_table) ? (void *)c->d_counts : nullptr; }
 
+// ---- (e) the count reduce over RCCL ---------------------------------------------------------------------------
+// librccl is 570 MB: the command-line hosts must not pay for loading it unless they drive several GPUs, so it is
+// dlopen'ed on first use (the same SONAME torch loads, so a process that has torch in it shares its copy).
+namespace {
+struct Rccl {
+	void *h = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommInitAll) CommInitAll = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string err;
+};
+
+Rccl *rccl()
+{
+	static Rccl r;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		const char *names[] = {getenv("SK_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		for (const char *nm : names) {
+			if (!nm || !*nm) continue;
+			r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+			if (r.h) break;
+			r.err = dlerror();
+		}
+		if (!r.h) return;
+		bool ok = true;
+		auto sym = [&](const char *nm) { void *p = dlsym(r.h, nm); if (!p) { ok = false; r.err = std::string("missing symbol ") + nm; } return p; };
+		r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+		r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+		r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+		r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+		r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+		r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+		r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+		r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+		if (!ok) { dlclose(r.h); r.h = nullptr; }
+	});
+	return &r;
+}
+
+// communicators of one process over a set of devices (ncclCommInitAll), made once per device list
+struct LocalComms { std::vector<int> devs; std::vector<ncclComm_t> comms; };
+std::mutex g_local_m;
+std::vector<LocalComms> g_local;
+
+__global__ void counts_add_kernel(unsigned long long *dst, const unsigned long long *src, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] += src[i];
+}
+}  // namespace
+
+#define SK_NCCL(c, call)                                                                                  \
+	do {                                                                                                  \
+		ncclResult_t r_ = (call);                                                                         \
+		if (r_ != ncclSuccess) return fail((c), SK_ERR_COMM, "%s: %s", #call, rccl()->GetErrorString(r_)); \
+	} while (0)
+
+static int rccl_ready(sk_ctx *c)
+{
+	Rccl *r = rccl();
+	if (!r->h) return fail(c, SK_ERR_COMM, "librccl.so.1 cannot be loaded (%s): the count reduce across GPUs needs RCCL", r->err.c_str());
+	return SK_OK;
+}
+
+int sk_comm_get_unique_id(uint8_t id[SK_COMM_ID_BYTES])
+{
+	static_assert(SK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+	if (!id) return SK_ERR_INVALID;
+	if (int r = rccl_ready(nullptr)) return r;
+	ncclUniqueId u;
+	SK_NCCL(nullptr, rccl()->GetUniqueId(&u));
+	memcpy(id, u.internal, SK_COMM_ID_BYTES);
+	return SK_OK;
+}
+
+int sk_comm_init_rank(sk_ctx *c, const uint8_t id[SK_COMM_ID_BYTES], int rank, int n_ranks)
+{
+	if (!c || !id) return SK_ERR_INVALID;
+	if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, SK_ERR_INVALID, "rank %d of %d", rank, n_ranks);
+	if (c->comm) return fail(c, SK_ERR_STATE, "this ctx already has a communicator");
+	if (int r = rccl_ready(c)) return r;
+	if (int r = bind(c)) return r;
+	ncclUniqueId u;
+	memcpy(u.internal, id, SK_COMM_ID_BYTES);
+	SK_NCCL(c, rccl()->CommInitRank(&c->comm, n_ranks, u, rank));
+	c->comm_ranks = n_ranks;
+	return SK_OK;
+}
+
+int sk_comm_destroy(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!c->comm) return SK_OK;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	ncclResult_t r = rccl()->CommDestroy(c->comm);
+	c->comm = nullptr; c->comm_ranks = 0;
+	return r == ncclSuccess ? SK_OK : fail(c, SK_ERR_COMM, "ncclCommDestroy: %s", rccl()->GetErrorString(r));
+}
+
+int sk_allreduce_u64_dev(sk_ctx *c, uint64_t *buf, size_t count)
+{
+	if (!c || (count && !buf)) return SK_ERR_INVALID;
+	if (!c->comm || c->comm_ranks <= 1 || count == 0) return SK_OK;          // a world of one
+	if (int r = bind(c)) return r;
+	SK_NCCL(c, rccl()->AllReduce(buf, buf, count, ncclUint64, ncclSum, c->comm, c->stream));
+	return SK_OK;
+}
+
+int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx)
+{
+	if (!ctxs || n_ctx < 1) return SK_ERR_INVALID;
+	for (int i = 0; i < n_ctx; i++) if (!ctxs[i]) return SK_ERR_INVALID;
+	sk_ctx *c0 = ctxs[0];
+	for (int i = 0; i < n_ctx; i++) {
+		if (!ctxs[i]->have_table) return fail(c0, SK_ERR_STATE, "ctx %d: sk_set_barcodes has not been called", i);
+		if (ctxs[i]->S != c0->S) return fail(c0, SK_ERR_INVALID, "ctx %d has %d samples, ctx 0 has %d", i, ctxs[i]->S, c0->S);
+	}
+	const int nc = c0->S + 3;
+	if (n_ctx == 1) return sk_allreduce_u64_dev(c0, (uint64_t *)c0->d_counts, (size_t)nc);     // across ranks (or nothing to do)
+	for (int i = 0; i < n_ctx; i++)
+		if (ctxs[i]->comm) return fail(c0, SK_ERR_STATE, "ctx %d belongs to a one-process-per-GPU communicator: reduce it alone", i);
+
+	// 1. everything enqueued so far must have happened before another stream reads the counters
+	for (int i = 0; i < n_ctx; i++) { SK_HIP(c0, hipSetDevice(ctxs[i]->device)); SK_HIP(c0, hipStreamSynchronize(ctxs[i]->stream)); }
+	// 2. ctxs that share a device: summed on that device into the first of them (its "leader")
+	std::vector<int> leader_of(n_ctx), leaders;
+	for (int i = 0; i < n_ctx; i++) {
+		int l = -1;
+		for (int k : leaders) if (ctxs[k]->device == ctxs[i]->device) { l = k; break; }
+		if (l < 0) { leaders.push_back(i); l = i; }
+		leader_of[i] = l;
+	}
+	for (int i = 0; i < n_ctx; i++) {
+		const int l = leader_of[i];
+		if (l == i) continue;
+		SK_HIP(c0, hipSetDevice(ctxs[l]->device));
+		counts_add_kernel<<<(nc + 255) / 256, 256, 0, ctxs[l]->stream>>>(ctxs[l]->d_counts, ctxs[i]->d_counts, nc);
+		SK_HIP(c0, hipGetLastError());
+	}
+	// 3. distinct devices: one RCCL all-reduce (sum, u64) on the leaders' streams
+	if (leaders.size() > 1) {
+		if (int r = rccl_ready(c0)) return r;
+		std::vector<int> devs;
+		for (int k : leaders) devs.push_back(ctxs[k]->device);
+		std::vector<ncclComm_t> comms;
+		{
+			std::lock_guard<std::mutex> lk(g_local_m);
+			for (const LocalComms &lc : g_local) if (lc.devs == devs) { comms = lc.comms; break; }
+			if (comms.empty()) {
+				comms.resize(devs.size());
+				SK_NCCL(c0, rccl()->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+				g_local.push_back({devs, comms});
+			}
+		}
+		SK_NCCL(c0, rccl()->GroupStart());
+		for (size_t k = 0; k < leaders.size(); k++) {
+			sk_ctx *l = ctxs[leaders[k]];
+			ncclResult_t r = rccl()->AllReduce(l->d_counts, l->d_counts, (size_t)nc, ncclUint64, ncclSum, comms[k], l->stream);
+			if (r != ncclSuccess) { (void)rccl()->GroupEnd(); return fail(c0, SK_ERR_COMM, "ncclAllReduce: %s", rccl()->GetErrorString(r)); }
+		}
+		SK_NCCL(c0, rccl()->GroupEnd());
+	}
+	// 4. the totals back to the ctxs that share a leader's device
+	for (int i = 0; i < n_ctx; i++) {
+		const int l = leader_of[i];
+		if (l == i) continue;
+		SK_HIP(c0, hipSetDevice(ctxs[l]->device));
+		SK_HIP(c0, hipMemcpyAsync(ctxs[i]->d_counts, ctxs[l]->d_counts, (size_t)nc * 8, hipMemcpyDeviceToDevice, ctxs[l]->stream));
+	}
+	for (int k : leaders) { SK_HIP(c0, hipSetDevice(ctxs[k]->device)); SK_HIP(c0, hipStreamSynchronize(ctxs[k]->stream)); }
+	return SK_OK;
+}
+
 // ---- fused pass ------------------------------------------------------------------------------------
 static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
 {
@@ -453,6 +639,69 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 		}
 		SK_HIP(c, hipStreamSynchronize(c->stream));
 	}
+	return SK_OK;
+}
+
+// ---- tile-blocked batches ---------------------------------------------------------------------------------------
+int sk_blocked_layout_init(sk_blocked_layout *lay, int n_mates, int stride, int bc_stride, int flags)
+{
+	if (!lay) return SK_ERR_INVALID;
+	if (n_mates < 1 || n_mates > 2 || bc_stride < 0 || stride <= 0 || stride > 65535) return SK_ERR_INVALID;
+	if (!(flags & (SK_BLK_MASK | SK_BLK_TRIM))) return SK_ERR_INVALID;      // barcodes alone: sk_demux_assign(_dev)
+	memset(lay, 0, sizeof *lay);
+	lay->n_mates = n_mates; lay->stride = stride; lay->bc_stride = bc_stride; lay->flags = flags;
+	for (int m = 0; m < 2; m++) lay->in_qual[m] = lay->in_seq[m] = lay->in_len[m] = lay->out_seq[m] = lay->out_lowest_k[m] = -1;
+	lay->in_bc = lay->out_assign = lay->out_lowest_diff = lay->out_first_idx = lay->out_last_idx = -1;
+	int64_t in = 0, out = 0;
+	auto seg = [](int64_t &at, int64_t bytes) { int64_t o = at; at += (bytes + 63) & ~(int64_t)63; return (int32_t)o; };
+	for (int m = 0; m < n_mates; m++) {                       // streams first, in the order the kernel walks them
+		lay->in_qual[m] = seg(in, 64 * (int64_t)stride);
+		if (flags & SK_BLK_MASK) lay->in_seq[m] = seg(in, 64 * (int64_t)stride);
+	}
+	if (bc_stride > 0) lay->in_bc = seg(in, 64 * (int64_t)bc_stride);
+	if (flags & SK_BLK_LEN) for (int m = 0; m < n_mates; m++) lay->in_len[m] = seg(in, 128);
+	if (flags & SK_BLK_MASK) for (int m = 0; m < n_mates; m++) lay->out_seq[m] = seg(out, 64 * (int64_t)stride);
+	if (flags & SK_BLK_TRIM) for (int m = 0; m < n_mates; m++) lay->out_lowest_k[m] = seg(out, 128);
+	if (bc_stride > 0) {
+		lay->out_assign = seg(out, 256);
+		if (flags & SK_BLK_DETAIL) { lay->out_lowest_diff = seg(out, 64); lay->out_first_idx = seg(out, 128); lay->out_last_idx = seg(out, 128); }
+	}
+	if (in > 0x3fffffff || out > 0x3fffffff) return SK_ERR_INVALID;
+	lay->in_block = (int32_t)in; lay->out_block = (int32_t)out;
+	return SK_OK;
+}
+
+int sk_fused_pass_blocked_dev(sk_ctx *c, const sk_blocked_layout *lay, const uint8_t *in, uint8_t *out, int64_t n, uint8_t min_baseq, uint64_t *counts)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!lay) return fail(c, SK_ERR_INVALID, "layout is NULL");
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld is negative", (long long)n);
+	if (n == 0) return SK_OK;
+	sk_blocked_layout want;
+	if (sk_blocked_layout_init(&want, lay->n_mates, lay->stride, lay->bc_stride, lay->flags) != SK_OK || memcmp(&want, lay, sizeof want) != 0)
+		return fail(c, SK_ERR_INVALID, "layout was not made by sk_blocked_layout_init");
+	if (!in || !out || !aligned16(in) || !aligned16(out)) return fail(c, SK_ERR_INVALID, "in/out must be 16-byte aligned device buffers");
+	if (lay->bc_stride > 0) {
+		if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
+		if (lay->bc_stride < c->L) return fail(c, SK_ERR_INVALID, "bc_stride = %d is below the barcode length %d", lay->bc_stride, c->L);
+	}
+	if (int r = bind(c)) return r;
+	sk::BlockedArgs a;
+	memset(&a, 0, sizeof a);
+	a.in = in; a.out = out; a.n = n;
+	a.n_mates = lay->n_mates; a.stride = lay->stride; a.bc_stride = lay->bc_stride;
+	a.in_block = lay->in_block; a.out_block = lay->out_block;
+	for (int m = 0; m < 2; m++) {
+		a.in_qual[m] = lay->in_qual[m]; a.in_seq[m] = lay->in_seq[m]; a.in_len[m] = lay->in_len[m];
+		a.out_seq[m] = lay->out_seq[m]; a.out_lowest_k[m] = lay->out_lowest_k[m];
+	}
+	a.in_bc = lay->in_bc; a.out_assign = lay->out_assign; a.out_lowest_diff = lay->out_lowest_diff;
+	a.out_first_idx = lay->out_first_idx; a.out_last_idx = lay->out_last_idx;
+	a.qc = sk::make_qual_consts(min_baseq);
+	if (lay->bc_stride > 0) a.table = table_of(c);
+	a.counts = counts ? (unsigned long long *)counts : c->d_counts;
+	if (!sk::blocked_shape_ok(a)) return fail(c, SK_ERR_INVALID, "shape not served by the tile-blocked pass (stride %d, bc_stride %d, S %d): use sk_fused_pass_dev", lay->stride, lay->bc_stride, c->S);
+	SK_HIP(c, sk::launch_tile_blocked(a, c->n_cu, c->stream));
 	return SK_OK;
 }
 

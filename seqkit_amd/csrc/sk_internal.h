@@ -65,6 +65,26 @@ struct TileArgs {
 	unsigned long long *counts;     // device u64[S+3]
 };
 
+// Tile-blocked batch (include/seqkit_hip.h: sk_blocked_layout): tile t of 64 clusters reads the ONE byte range
+// in + t*in_block .. +in_block and writes out + t*out_block .. +out_block; the offsets say where each segment of the
+// tile sits inside its block (-1 = absent).  Both buffers hold whole blocks, also for the last, partial tile.
+struct BlockedArgs {
+	const uint8_t *in;
+	uint8_t *out;
+	int64_t n;
+	int n_mates, stride, bc_stride;
+	int in_block, out_block;
+	int in_qual[2], in_seq[2], in_len[2], in_bc;
+	int out_seq[2], out_lowest_k[2], out_assign, out_lowest_diff, out_first_idx, out_last_idx;
+	QualConsts qc;
+	BarcodeDev table;
+	unsigned long long *counts;     // device u64[S+3]
+};
+hipError_t launch_tile_blocked(const BlockedArgs &a, int n_cu, hipStream_t st);
+// true when the blocked kernel serves this shape (rows fit an LDS tile and the packed scan key; with barcodes: the
+// bit-sliced matcher with <= 4 groups and a tile of barcodes in two 1 KiB chunks)
+bool blocked_shape_ok(const BlockedArgs &a);
+
 // launchers (all asynchronous on `st`); return hipError_t of the launch
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st);
 hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *out, int64_t bytes,

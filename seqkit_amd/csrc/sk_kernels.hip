@@ -8,10 +8,16 @@
 //    structure needed), stores the masked bases with 16 B/lane stores, and drops the quality bytes
 //    into a wave-private LDS image of the tile.  The LDS image is the transposition point: afterwards
 //    lane r walks row r from its 3' end (dword LDS reads + v_alignbyte for the row's misalignment).
-//  * workgroup = one wavefront, so the tile hand-off needs no cross-wave barrier; up to 16 tiles are
-//    resident per CU (9.6 KiB of LDS each at 150 bp) and interleave their stream / scan phases.
-//  * barcode matching is lane-per-read against a one-hot re-coding of the sheet: matches =
-//    popcount(obs & cand) over W dwords, candidates fetched through the scalar cache (wave-uniform).
+//  * a workgroup is four wavefronts that share only the read-only matcher tables and the per-sample
+//    histogram in LDS; there is no barrier inside the tile loop (the lanes of ONE wave hand data to each
+//    other through the wave's private LDS tile).  2-4 workgroups are resident per CU depending on what
+//    the pass is bound by (launch_tile_pass), persistent over tiles.
+//  * barcode matching is lane-per-read and bit-sliced: walk the L positions, not the S candidates; the
+//    per-candidate mismatch counts are column sums kept as bit planes (demux_row_bitsliced).  Sheets
+//    the bit-sliced tables cannot hold fall back to a one-hot popcount or a byte-compare matcher.
+//  * two batch layouts: row-major SoA matrices (tile_pass_kernel) and the tile-blocked layout, where
+//    everything a 64-cluster tile reads is ONE contiguous range and everything it writes another
+//    (tile_blocked_kernel).
 //  * everything is integer/byte work bounded by HBM; there is no MFMA in this file by design.
 //
 // Reference semantics restated per function: see the citations (paths relative to the reference tree).
@@ -519,9 +525,8 @@ __device__ __forceinline__ void demux_commit(const TileArgs &a, const LdsPlan &l
 	wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
 }
 
-__device__ __forceinline__ void flush_counts(const TileArgs &a, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc)
+__device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc)
 {
-	const int S = a.table.S;
 	if (lp.use_lds_hist) {
 		if (lane == 0) {
 			if (wc.total) atomicAdd(&hist[S], wc.total);
@@ -531,12 +536,12 @@ __device__ __forceinline__ void flush_counts(const TileArgs &a, const LdsPlan &l
 		__syncthreads();
 		for (int i = threadIdx.x; i < S + 3; i += blockDim.x) {
 			u32 c = hist[i];
-			if (c) atomicAdd(&a.counts[i], (unsigned long long)c);
+			if (c) atomicAdd(&counts[i], (unsigned long long)c);
 		}
 	} else if (lane == 0) {
-		if (wc.total) atomicAdd(&a.counts[S], (unsigned long long)wc.total);
-		if (wc.ident) atomicAdd(&a.counts[S + 1], (unsigned long long)wc.ident);
-		if (wc.ambig) atomicAdd(&a.counts[S + 2], (unsigned long long)wc.ambig);
+		if (wc.total) atomicAdd(&counts[S], (unsigned long long)wc.total);
+		if (wc.ident) atomicAdd(&counts[S + 1], (unsigned long long)wc.ident);
+		if (wc.ambig) atomicAdd(&counts[S + 2], (unsigned long long)wc.ambig);
 	}
 }
 
@@ -727,7 +732,148 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 			wave_lds_fence();
 		}
 	}
-	if (DEMUX) flush_counts(a, lp, hist, lane, wc);
+	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tile_blocked_kernel — the same pass over the TILE-BLOCKED layout (BlockedArgs): everything a tile reads is one
+// contiguous range of `in` (qual / seq of each mate, the observed barcodes, optional lengths) and everything it
+// writes one contiguous range of `out`.  A wave therefore streams ONE advancing read range and ONE write range
+// instead of five and four far-apart ones, the host moves a batch with one copy per direction, and the kernel needs
+// two buffer descriptors per tile (block base + scalar segment offsets) instead of one per array.  Blocks are
+// whole also for the last tile, so nothing is clipped: rows past n are computed and land in the block's padding;
+// only the counters look at `active`.  The LDS image takes whole chunks (its slot is nchunkp KiB).
+// ---------------------------------------------------------------------------------------------------
+// Every global access is an unconditional raw-buffer instruction whose VGPR offset carries the segment offset, so
+// the hardware range check (VGPR offset + immediate against num_records = the block size) covers it; absent
+// segments get an offset past every block (kNoSeg): their loads return zeros without memory traffic, their stores
+// are dropped, and no branch sits around a VMEM instruction (exact s_waitcnt counts, as in tile_pass_kernel).
+constexpr int kNoSeg = 0x40000000;
+
+template <int MODE, bool DEMUX, int SLOTS>
+__global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs a, const LdsPlan lp)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int nwave = blockDim.x >> 6;
+	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
+	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
+	if (DEMUX) stage_tables(a.table, lp, hist);
+	WaveCounts wc = {0u, 0u, 0u};
+
+	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int stride = a.stride;
+	const u32 cl2 = a.qc.cl2;
+	const bool do_trim = a.out_lowest_k[0] >= 0, ragged = a.in_len[0] >= 0;
+	const int seg = kTileRows * stride;
+	const int nchunkp = (((seg + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;
+	const int voff = lane * 16;
+	const int64_t tstep = (int64_t)gridDim.x * nwave;
+	auto seg_off = [](int o) { return o >= 0 ? o : kNoSeg; };
+
+	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	// descriptor of a tile's input block; past the last tile: zero records (the prefetch of the item after the last)
+	auto in_block = [&](int64_t tt) { return make_rsrc(tt < ntiles ? a.in : nullptr, tt * (int64_t)a.in_block, a.in_block); };
+	rsrc_t rin = in_block(t);
+	int vq = voff + a.in_qual[0], vs = voff + seg_off(a.in_seq[0]);      // lane offsets of the item's two streams inside the block
+	u32x4 qv[SLOTS], sv[SLOTS];
+#pragma unroll
+	for (int i = 0; i < SLOTS; i++) {
+		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + i * 1024, 0, kAuxStream);
+		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + i * 1024, 0, kAuxStream);
+	}
+
+	for (; t < ntiles; t += tstep) {
+		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
+		if (DEMUX) {
+			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rin, voff + a.in_bc, 0, 0);
+			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rin, voff + a.in_bc + 1024, 0, 0);
+		}
+		const rsrc_t rout = make_rsrc(a.out, t * (int64_t)a.out_block, a.out_block);
+
+		for (int k = 0; k < a.n_mates; k++) {
+			// masked bases go through their own descriptor: it clips the item's last chunk at the segment's end
+			const int so = k ? a.out_seq[1] : a.out_seq[0];
+			const rsrc_t ro = make_rsrc(so >= 0 ? a.out : nullptr, t * (int64_t)a.out_block + so, seg);
+			// rin is still this tile's block here (it moves on in the last chunks of the tile's last mate)
+			int len_ld = (int)__builtin_amdgcn_raw_buffer_load_b16(rin, lane * 2 + seg_off(k ? a.in_len[1] : a.in_len[0]), 0, 0);
+			asm volatile("" : "+v"(len_ld));                      // materialise now (see tile_pass_kernel)
+
+			// ---- stream phase: SLOTS chunks of each stream in flight ------------------------------------------------
+			int c = 0;
+			for (; c < nchunkp - SLOTS; c += SLOTS) {
+#pragma unroll
+				for (int i = 0; i < SLOTS; i++) {
+					const int off = (c + i) * 1024;
+					u32x4 o, w;
+					mask_dword4<MODE>(qv[i], sv[i], cl2, o, w);
+					__builtin_amdgcn_raw_buffer_store_b128(o, ro, voff + off, 0, kAuxStreamSt);
+					*reinterpret_cast<u32x4 *>(tile + voff + off) = w;
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + off + SLOTS * 1024, 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + off + SLOTS * 1024, 0, kAuxStream);
+				}
+			}
+			// the item's last chunks; their slots already fetch the NEXT item — the other mate of this tile, or the
+			// first mate of the wave's next tile — so loads stay in flight across the scan and barcode phases
+			{
+				const bool last_mate = k + 1 >= a.n_mates;
+				if (last_mate) rin = in_block(t + tstep);
+				vq = voff + (last_mate ? a.in_qual[0] : a.in_qual[1]);
+				vs = voff + seg_off(last_mate ? a.in_seq[0] : a.in_seq[1]);
+#pragma unroll
+				for (int i = 0; i < SLOTS; i++) {
+					const int off = (c + i) * 1024;
+					u32x4 o, w;
+					mask_dword4<MODE>(qv[i], sv[i], cl2, o, w);
+					__builtin_amdgcn_raw_buffer_store_b128(o, ro, voff + off, 0, kAuxStreamSt);
+					*reinterpret_cast<u32x4 *>(tile + voff + off) = w;
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + i * 1024, 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + i * 1024, 0, kAuxStream);
+				}
+			}
+
+			// ---- scan phase --------------------------------------------------------------------------------------
+			if (do_trim) {
+				wave_lds_fence();
+				const bool active = lane < a.n - t * kTileRows;
+				const int len = ragged ? min(len_ld, stride) : stride;      // rows past n hold padding: keep the scan inside the image
+				int kk;
+				if (ragged) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, a.qc.min_baseq, active);
+				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, a.qc.min_baseq, active);
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, rout, lane * 2 + (k ? a.out_lowest_k[1] : a.out_lowest_k[0]), 0, 0);
+				wave_lds_fence();
+			}
+		}
+
+		// ---- barcode phase (bit-sliced matcher) --------------------------------------------------------------------
+		if (DEMUX) {
+			const int bstride = a.bc_stride;
+			*reinterpret_cast<u32x4 *>(tile + voff) = bcv0;
+			*reinterpret_cast<u32x4 *>(tile + 1024 + voff) = bcv1;
+			wave_lds_fence();
+			int best = 0x7fffffff, first = 0, last = 0;
+			const uint8_t *row = tile + lane * bstride;
+			switch (a.table.G) {   // wave-uniform
+			case 1: demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, 1, 0, a.table.L, best, first, last); break;
+			case 2: demux_row_bitsliced<2>(row, sk_smem, a.table.bs_mm_off, 2, 0, a.table.L, best, first, last); break;
+			case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
+			default: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
+			}
+			int code = kAssignNone;                                  // D3: src/fasta_demultiplex.rs:168-194
+			if (best <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, rout, lane * 4 + a.out_assign, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), rout, lane + seg_off(a.out_lowest_diff), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, rout, lane * 2 + seg_off(a.out_first_idx), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, rout, lane * 2 + seg_off(a.out_last_idx), 0, 0);
+			const bool active = lane < a.n - t * kTileRows;
+			if (active && code >= 0) atomicAdd(&hist[code], 1u);
+			wc.total += (u32)__popcll(__ballot(active));
+			wc.ident += (u32)__popcll(__ballot(active && code >= 0));
+			wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+			wave_lds_fence();
+		}
+	}
+	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -968,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void tile_pass2_kernel(const TileArgs a, co
 		wave_lds_fence();
 		demux_tile(demux_t, (item & 1) ? img1 : img0, bcv0, bcv1);
 	}
-	if (DEMUX) flush_counts(a, lp, hist, lane, wc);
+	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
 
 // the last (n*stride mod 4) bytes of a matrix, which the dword-clipped 16-byte stores of the tile pass leave out
@@ -1043,7 +1189,7 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 		demux_commit(a, lp, hist, row0 + lane, active, diff, first, last, wc);
 		wave_lds_fence();
 	}
-	flush_counts(a, lp, hist, lane, wc);
+	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
 
 // rows too long for an LDS tile: one thread per row straight from global memory (correct, not fast)
@@ -1066,20 +1212,22 @@ __global__ __launch_bounds__(256) void trim_rows_global_kernel(const uint8_t *__
 
 // LDS layout + workgroup shape for a tile kernel; the grid comes from the occupancy API so that every
 // workgroup of the persistent grid is resident (a queued workgroup would run its whole share of tiles late).
-static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_bytes, bool with_tables, int max_nw, int n_cu, hipStream_t st, int images = 1,
-                                  int max_wg = 0)
+struct LaunchShape { LdsPlan lp; int grid, block, lds; };
+
+static hipError_t plan_shape(const void *fn, const BarcodeDev &table, int64_t n, int image_bytes /* LDS image per wave */, bool with_tables, int max_nw,
+                             int n_cu, int images, int max_wg, LaunchShape &out)
 {
 	static const int kLdsPerCu = 160 * 1024;
 	LdsPlan lp{};
 	lp.table_bytes = 0;
 	if (with_tables) {
-		int tb = b.table.bs ? b.table.bs_bytes : b.table.onehot ? b.table.S * padded_w(b.table.W) * 4 : b.table.S * b.table.L;
+		int tb = table.bs ? table.bs_bytes : table.onehot ? table.S * padded_w(table.W) * 4 : table.S * table.L;
 		lp.table_bytes = (tb + 15) & ~15;
 	}
-	lp.use_lds_hist = (with_tables && b.table.S + 3 <= kMaxLdsHist) ? 1 : 0;
+	lp.use_lds_hist = (with_tables && table.S + 3 <= kMaxLdsHist) ? 1 : 0;
 	lp.hist_off = lp.table_bytes;
-	lp.tiles_off = (lp.hist_off + (lp.use_lds_hist ? (b.table.S + 3) * 4 : 0) + 15) & ~15;
-	lp.tile_slot = kLdsPad + ((kTileRows * row_bytes + 15) & ~15) + kLdsPad;
+	lp.tiles_off = (lp.hist_off + (lp.use_lds_hist ? (table.S + 3) * 4 : 0) + 15) & ~15;
+	lp.tile_slot = kLdsPad + ((image_bytes + 15) & ~15) + kLdsPad;
 	// the shape search (occupancy queries, LDS opt-in) is cached per (device, kernel, LDS layout): small batches from
 	// the command-line hosts launch thousands of times with the same shape
 	struct Shape { int dev; const void *fn; int tiles_off, tile_slot, max_nw, max_wg, nw, wg; };
@@ -1120,11 +1268,12 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 		}
 	}
 	if (best_waves == 0) return hipErrorInvalidValue;
-	const int lds = lp.tiles_off + best_nw * images * lp.tile_slot;
-	int64_t ntiles = (b.n + kTileRows - 1) / kTileRows;
+	out.lds = lp.tiles_off + best_nw * images * lp.tile_slot;
+	int64_t ntiles = (n + kTileRows - 1) / kTileRows;
 	int64_t want = (ntiles + best_nw - 1) / best_nw;
 	int64_t cap = (int64_t)n_cu * best_wg;
-	int grid = (int)(want < cap ? want : cap);
+	out.grid = (int)(want < cap ? want : cap);
+	out.block = kWave * best_nw;
 	// Optional start-up stagger of the waves (SK_STAGGER = s_sleep(127) units per phase slot).  Off by default: it
 	// moved the fused pass by -10 % .. +6 % depending on where the waves' phases happened to settle.
 	{
@@ -1133,9 +1282,63 @@ static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_byt
 		lp.stagger = env_st > 0 ? env_st : 0;
 		lp.tile_map = env_map;
 	}
+	out.lp = lp;
+	return hipSuccess;
+}
+
+static hipError_t plan_and_launch(const void *fn, const TileArgs &b, int row_bytes, bool with_tables, int max_nw, int n_cu, hipStream_t st, int images = 1,
+                                  int max_wg = 0)
+{
+	LaunchShape sh;
+	hipError_t e = plan_shape(fn, b.table, b.n, kTileRows * row_bytes, with_tables, max_nw, n_cu, images, max_wg, sh);
+	if (e != hipSuccess) return e;
 	TileArgs bb = b;
-	void *kargs[] = {(void *)&bb, (void *)&lp};
-	return hipLaunchKernel(fn, dim3(grid), dim3(kWave * best_nw), kargs, lds, st);
+	void *kargs[] = {(void *)&bb, (void *)&sh.lp};
+	return hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
+}
+
+template <bool DEMUX, int SLOTS>
+static const void *tile_blocked_fn(int mode)
+{
+	switch (mode) {
+	case 0: return reinterpret_cast<const void *>(tile_blocked_kernel<0, DEMUX, SLOTS>);
+	case 1: return reinterpret_cast<const void *>(tile_blocked_kernel<1, DEMUX, SLOTS>);
+	case 2: return reinterpret_cast<const void *>(tile_blocked_kernel<2, DEMUX, SLOTS>);
+	case 3: return reinterpret_cast<const void *>(tile_blocked_kernel<3, DEMUX, SLOTS>);
+	default: return reinterpret_cast<const void *>(tile_blocked_kernel<4, DEMUX, SLOTS>);
+	}
+}
+
+bool blocked_shape_ok(const BlockedArgs &a)
+{
+	if (a.n_mates < 1 || a.n_mates > 2 || a.stride < 1 || a.stride > kMaxTileStride) return false;
+	if (a.out_seq[0] < 0 && a.out_lowest_k[0] < 0) return false;
+	if (a.in_bc >= 0) {
+		if (!a.table.bs || a.table.G > 4 || a.table.S <= 0 || kTileRows * a.bc_stride > 2048) return false;
+	}
+	return true;
+}
+
+hipError_t launch_tile_blocked(const BlockedArgs &a, int n_cu, hipStream_t st)
+{
+	if (a.n <= 0) return hipSuccess;
+	if (!blocked_shape_ok(a)) return hipErrorInvalidValue;
+	const bool demux = a.in_bc >= 0;
+	const int slots = a.n_mates == 1 ? SK_SLOTS1 : kSlots;
+	const int nchunkp = (((kTileRows * a.stride + 1023) >> 10) + slots - 1) / slots * slots;
+	int image = nchunkp * 1024;                                       // the LDS image takes whole chunks, trim or not
+	if (demux && image < 2048) image = 2048;
+	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int max_wg = a.n_mates == 1 ? 3 : (ntiles < (int64_t)n_cu * 4 * 2 * 16 ? 3 : 2);   // as launch_tile_pass
+	const void *fn;
+	if (a.n_mates == 1) fn = demux ? tile_blocked_fn<true, SK_SLOTS1>(a.qc.mode) : tile_blocked_fn<false, SK_SLOTS1>(a.qc.mode);
+	else fn = demux ? tile_blocked_fn<true, kSlots>(a.qc.mode) : tile_blocked_fn<false, kSlots>(a.qc.mode);
+	LaunchShape sh;
+	hipError_t e = plan_shape(fn, a.table, a.n, image, demux, 4, n_cu, 1, max_wg, sh);
+	if (e != hipSuccess) return e;
+	BlockedArgs bb = a;
+	void *kargs[] = {(void *)&bb, (void *)&sh.lp};
+	return hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
 }
 
 template <bool DEMUX>

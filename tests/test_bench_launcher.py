@@ -1,0 +1,47 @@
+"""bench.py --gpus N without a launcher starts N rank processes itself (before torch / the GPU is touched), hands each
+its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, relays rank 0's JSON line and fails when any rank fails.  CPU only: the
+ranks are a stub (SK_BENCH_WORKER)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(tmp_path, n, extra_env=None, args=()):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"SK_BENCH_WORKER": os.path.join(REPO, "tests", "_bench_stub.py"), "SK_STUB_DIR": str(tmp_path)})
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), *args], env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_n_ranks_with_the_right_environment(tmp_path):
+    r = run(tmp_path, 4, args=("--steps", "2", "--warmup", "1"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 4, "stub": True}      # exactly one line: rank 0's JSON
+    recs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(4)]
+    assert [x["RANK"] for x in recs] == ["0", "1", "2", "3"] and [x["LOCAL_RANK"] for x in recs] == ["0", "1", "2", "3"]
+    assert all(x["WORLD_SIZE"] == "4" and x["MASTER_ADDR"] == "127.0.0.1" for x in recs)
+    assert len({x["MASTER_PORT"] for x in recs}) == 1 and recs[0]["MASTER_PORT"].isdigit()
+    assert all(x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for x in recs)
+    assert all(x["argv"] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] for x in recs)
+
+
+def test_launcher_fails_when_a_rank_fails_and_ends_the_others(tmp_path):
+    t0 = time.time()
+    r = run(tmp_path, 3, {"SK_STUB_FAIL_RANK": "1"})
+    assert r.returncode == 7 and "rank 1 failed" in r.stderr
+    assert r.stdout.strip() == ""
+    assert time.time() - t0 < 25          # the sleeping ranks were ended, not waited for
+
+
+def test_under_a_launcher_bench_is_one_rank(tmp_path):
+    """With WORLD_SIZE in the environment (torchrun) bench.py does not spawn: it is a rank, and a --gpus that disagrees is an error."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -342,6 +342,113 @@ def test_fused_pass_multichunk_host_staging(ctx, oracle):
     assert np.array_equal(r["out_seq"][0], oracle.mask_batch(seq, qual, None, 20))
 
 
+# ---- the same pass over the tile-blocked batch layout (sk_fused_pass_blocked_dev) ---------------------------------
+def check_blocked(ctx, oracle, mates, m, table=None, bc=None, md=1, do_mask=True, do_trim=True, detail=True):
+    n, stride = mates[0][1].shape
+    if table is not None:
+        ctx.set_barcodes(table, md)
+    r = ctx.fused_pass_blocked(mates, m, bc=bc, want_detail=detail, do_mask=do_mask, do_trim=do_trim)
+    if bc is not None:
+        e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, md)
+        assert np.array_equal(r["assign"], e_assign)
+        if detail:
+            assert np.array_equal(r["lowest_diff"], e_low)
+            assert np.array_equal(r["first_idx"], e_first) and np.array_equal(r["last_idx"], e_last)
+        assert np.array_equal(ctx.counts(), e_counts)
+    for i, (seq, qual, ln) in enumerate(mates):
+        if do_trim:
+            assert np.array_equal(r["lowest_k"][i], oracle.trim_batch(qual, ln, m)), i
+        if do_mask:
+            exp = oracle.mask_batch(seq, qual, ln, m)
+            valid = np.ones((n, stride), dtype=bool) if ln is None else (np.arange(stride)[None, :] < ln[:, None])
+            assert np.array_equal(r["out_seq"][i][valid], exp[valid]), i
+
+
+@pytest.mark.parametrize("n,L,paired,ragged", [(30011, 150, True, False), (777, 150, False, False), (5003, 101, True, True),
+                                               (64 * 300, 33, True, False), (1, 150, True, False), (63, 250, False, True),
+                                               (4097, 151, True, False), (130, 960, False, False)])
+def test_blocked_pass_cfg4_shapes(ctx, oracle, n, L, paired, ragged):
+    """cfg 4 (paired 2x150, 96 dual-index barcodes) and neighbours in the tile-blocked layout == the three oracle steps."""
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, n, seed=n, halves=2)
+    ln = synth.ragged_lengths(n, L, seed=n) if ragged else None
+    mates = []
+    for mi in range(2 if paired else 1):
+        seq, qual = synth.make_reads(n, L, seed=170 + mi)
+        mates.append((seq, synth.add_forced_classes(qual, seed=180 + mi), ln))
+    check_blocked(ctx, oracle, mates, 20, table, bc)
+    check_blocked(ctx, oracle, mates, 20, table, bc, detail=False)
+    check_blocked(ctx, oracle, mates, 30, do_mask=False)                 # trim alone, no barcodes
+    check_blocked(ctx, oracle, mates, 2, do_trim=False)                  # mask alone
+    check_blocked(ctx, oracle, mates, 41, table, bc, do_mask=False)      # demultiplex + trim
+
+
+@pytest.mark.parametrize("min_baseq", [0, 1, 20, 95, 96, 222, 223, 224, 255])
+def test_blocked_pass_all_threshold_modes(ctx, oracle, min_baseq):
+    rng = np.random.default_rng(900 + min_baseq)
+    n, stride = 2000, 150
+    mates = []
+    for _ in range(2):
+        seq = synth.BASES[rng.integers(0, 4, size=(n, stride))]
+        qual = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+        mates.append((seq, qual, None))
+    check_blocked(ctx, oracle, mates, min_baseq)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_blocked_pass_random_shapes(ctx, oracle, seed):
+    """Random rows / stride / lengths / mates / mask-trim mix / sheets the blocked pass serves / thresholds / bytes."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([1, 63, 64, 65, 200, 1023, 4100]))
+    stride = int(rng.choice([1, 2, 7, 33, 64, 100, 150, 151, 255, 640, 960]))
+    if stride > 600:
+        n = min(n, 300)
+    nm = int(rng.integers(1, 3))
+    do_mask, do_trim = [(True, True), (True, False), (False, True)][int(rng.integers(0, 3))]
+    m = int(rng.choice([0, 1, 2, 20, 30, 41, 95, 200, 223, 224, 255]))
+    ragged = rng.random() < 0.5
+    ln = synth.ragged_lengths(n, stride, seed=seed) if ragged else None
+    mates = []
+    for _ in range(nm):
+        if rng.random() < 0.4:
+            seq = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+            qual = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+        else:
+            seq, qual = synth.make_reads(n, stride, seed=int(rng.integers(0, 1 << 30)))
+            qual = synth.add_forced_classes(qual, seed=seed)
+        mates.append((seq, qual, ln))
+    bc = table = None
+    md = 1
+    if rng.random() < 0.7:
+        S = int(rng.choice([1, 2, 16, 96, 128]))
+        L = int(rng.choice([4, 8, 17, 24, 31]))
+        table = np.ascontiguousarray(rng.choice(np.frombuffer(b"ACGTNU", dtype=np.uint8), size=(S, L), p=[.23, .23, .23, .23, .05, .03]))
+        pick = table[rng.integers(0, S, size=n)].copy()
+        noise = rng.random((n, L)) < 0.08
+        pick[noise] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=int(noise.sum()))
+        bc = np.ascontiguousarray(pick)
+        md = int(rng.choice([0, 1, 1, 2, 5]))
+    check_blocked(ctx, oracle, mates, m, table, bc, md, do_mask, do_trim)
+
+
+def test_blocked_pass_rejects_what_it_does_not_serve(ctx):
+    """Shapes outside the tile-blocked pass fail loudly (SK_ERR_INVALID) instead of taking another path silently."""
+    import seqkit_amd
+    from seqkit_amd import capi
+    n = 100
+    seq, qual = synth.make_reads(n, 1100, seed=1)
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        ctx.fused_pass_blocked([(seq, qual, None)], 20)                  # rows longer than an LDS tile
+    table = np.frombuffer(b"ACGTRYKM" * 4, dtype=np.uint8).reshape(4, 8).copy()   # 8 distinct bytes: no bit-sliced tables
+    table[1] = np.frombuffer(b"WSBDHVXZ", dtype=np.uint8)
+    ctx.set_barcodes(table, 1)
+    seq, qual = synth.make_reads(n, 50, seed=1)
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        ctx.fused_pass_blocked([(seq, qual, None)], 20, bc=np.ascontiguousarray(table[np.zeros(n, dtype=int)]))
+    with pytest.raises(seqkit_amd.SeqkitHipError):
+        capi.blocked_layout(0, 150, 17, 3)
+
+
 # ---- BAM ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,max_frag", [(1, 5000), (1000, 5000), (300001, 5000), (50000, 100), (50000, 0), (20000, 20000)])
 def test_bam_flag_tlen(ctx, oracle, n, max_frag):
