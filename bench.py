@@ -365,7 +365,7 @@ def main():
     seq, qual, bc = gen_shard(torch, dev, npad, table, seed=4000 + rank, chunk=args.gen_chunk)
     counts = torch.zeros((S_SAMPLES + 3,), dtype=torch.int64, device=dev)
     lay = None
-    if args.layout == "blocked":
+    if args.layout.startswith("blocked"):
         lay = capi.blocked_layout(2, L_READ, L_BC, capi.SK_BLK_MASK | capi.SK_BLK_TRIM)
         bin_, bout = pack_blocked(torch, lay, seq, qual, bc, nt)
         ns_keep = min(max(args.cpu_sample, 0), n)

@@ -101,10 +101,10 @@ class BlockedLayout(C.Structure):
         return buf
 
     def unpack(self, out: np.ndarray, n: int) -> dict:
-        def get(off, row_bytes, dtype=np.uint8):
+        def get(off, row_bytes, dtype=None):
             seg = self._seg(out, self.out_block, off, row_bytes)
             flat = np.ascontiguousarray(seg).reshape(-1, row_bytes)[:n]
-            return flat if dtype == np.uint8 and row_bytes != 1 else np.ascontiguousarray(flat).view(dtype).reshape(n)
+            return flat if dtype is None else np.ascontiguousarray(flat).view(dtype).reshape(n)
         res = {"out_seq": [], "lowest_k": []}
         for m in range(self.n_mates):
             if self.out_seq[m] >= 0:

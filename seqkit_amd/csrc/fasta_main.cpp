@@ -71,10 +71,11 @@ static const size_t kBatchBytes = 192u << 20;      // SoA bytes per batch
 static const size_t kBatchRecords = 1u << 18;
 static const size_t kMaxRow = 65535;               // len is u16 at the C-ABI
 
-static void check(int rc, const char *what)
+static void check(sk_ctx *ctx, int rc, const char *what)
 {
-	if (rc != SK_OK) error("%s failed: %s", what, sk_last_error(host::gpu()));
+	if (rc != SK_OK) error("%s failed: %s", what, sk_last_error(ctx));
 }
+static void check(int rc, const char *what) { check(host::gpu(), rc, what); }
 
 static uint8_t parse_min_baseq(const std::string &s)
 {
@@ -83,17 +84,27 @@ static uint8_t parse_min_baseq(const std::string &s)
 	return (uint8_t)v;
 }
 
-// a batch of rows packed at a fixed stride
+// a batch of rows packed at a fixed stride, in pinned memory (what the device copies from / into by DMA)
 struct Matrix {
-	std::vector<uint8_t> data;
+	uint8_t *data = nullptr;
 	int stride = 1;
-	void pack(const std::vector<host::Line> &rows)
+	void alloc(size_t nrows, size_t row_bytes, host::PinnedArena &arena)
+	{
+		stride = (int)std::max<size_t>(row_bytes, 1);
+		data = arena.take(nrows * (size_t)stride + 16);
+	}
+	void put(size_t r, const char *p, size_t n)              // row r = p[0..n), zero padded
+	{
+		uint8_t *d = data + r * (size_t)stride;
+		memcpy(d, p, n);
+		if (n < (size_t)stride) memset(d + n, 0, (size_t)stride - n);
+	}
+	void pack(const std::vector<host::Line> &rows, host::PinnedArena &arena)
 	{
 		size_t mx = 1;
 		for (const host::Line &l : rows) mx = std::max(mx, l.n);
-		stride = (int)mx;
-		data.assign(rows.size() * mx, 0);
-		for (size_t r = 0; r < rows.size(); r++) memcpy(data.data() + r * mx, rows[r].p, rows[r].n);
+		alloc(rows.size(), mx, arena);
+		for (size_t r = 0; r < rows.size(); r++) put(r, rows[r].p, rows[r].n);
 	}
 };
 
@@ -134,14 +145,15 @@ static void trim_block(const char *data, size_t n, uint8_t min_baseq, host::Bloc
 		recs.push_back(r);
 	}
 	// T1 through the C-ABI: src/fasta_trim_by_quality.rs:28-42
-	std::vector<uint16_t> lowest_k(rows.size());
+	host::PinnedArena arena(n / 2 + 65536);
+	uint16_t *lowest_k = arena.take_n<uint16_t>(rows.size() + 1);
 	if (!rows.empty()) {
 		Matrix q;
-		q.pack(rows);
-		std::vector<uint16_t> len16(rows.size());
+		q.pack(rows, arena);
+		uint16_t *len16 = arena.take_n<uint16_t>(rows.size());
 		for (size_t i = 0; i < rows.size(); i++) len16[i] = (uint16_t)rows[i].n;
-		std::lock_guard<std::mutex> lk(host::gpu_mutex());
-		check(sk_trim_by_quality(host::gpu(), q.data.data(), len16.data(), q.stride, (int64_t)rows.size(), min_baseq, lowest_k.data()), "sk_trim_by_quality");
+		host::GpuLease g;
+		check(g.ctx(), sk_trim_by_quality(g.ctx(), q.data, len16, q.stride, (int64_t)rows.size(), min_baseq, lowest_k), "sk_trim_by_quality");
 	}
 	res.out.reserve(n + 16);
 	size_t k = 0;
@@ -238,19 +250,20 @@ static void mask_block(const char *data, size_t n, uint8_t min_baseq, host::Bloc
 		srows.push_back({cseq.back().data(), cseq.back().size()});
 		qrows.push_back({cqual.back().data(), cqual.back().size()});
 	}
+	host::PinnedArena arena(n + 65536);
 	Matrix s, q;
 	if (!srows.empty()) {
-		s.pack(srows);
-		q.pack(qrows);
-		std::vector<uint16_t> len16(srows.size());
+		s.pack(srows, arena);
+		q.pack(qrows, arena);
+		uint16_t *len16 = arena.take_n<uint16_t>(srows.size());
 		for (size_t i = 0; i < srows.size(); i++) len16[i] = (uint16_t)srows[i].n;
-		std::lock_guard<std::mutex> lk(host::gpu_mutex());
-		check(sk_mask_by_quality(host::gpu(), s.data.data(), q.data.data(), len16.data(), s.stride, (int64_t)srows.size(), min_baseq), "sk_mask_by_quality");
+		host::GpuLease g;
+		check(g.ctx(), sk_mask_by_quality(g.ctx(), s.data, q.data, len16, s.stride, (int64_t)srows.size(), min_baseq), "sk_mask_by_quality");
 	}
 	res.out.reserve(n + 16);
 	for (const MaskRec &r : recs) {
 		res.out.append(r.header.p, r.header.n);                             // :25-26
-		const char *row = reinterpret_cast<const char *>(s.data.data()) + r.row * (size_t)s.stride;
+		const char *row = reinterpret_cast<const char *>(s.data) + r.row * (size_t)s.stride;
 		if (r.ascii) {
 			res.out.append(row, r.seq.n);
 		} else {
@@ -658,14 +671,18 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 	// ---- D1+D2+D3 (and, fused, M1 + T1 of both mates) for the block through the C-ABI ------------------------------
 	const size_t nb = cl.size();
 	res.nclusters = nb;
-	std::vector<int32_t> assign(nb, SK_ASSIGN_NONE);                        // empty sheet: lowest_diff stays usize::MAX
-	std::vector<uint8_t> lowest(nb);
-	std::vector<int16_t> first(nb), last(nb);
-	std::vector<uint8_t> bc(nb * L);
-	for (size_t i = 0; i < nb; i++) memcpy(bc.data() + i * L, cl[i].barcode.data(), L);
+	size_t hint = nb * (L + 16) + 65536;
+	if (fused) hint += 3 * (blk[0].size() + blk[1].size()) / 2;
+	host::PinnedArena arena(hint);
+	int32_t *assign = arena.take_n<int32_t>(nb + 1);
+	for (size_t i = 0; i < nb; i++) assign[i] = SK_ASSIGN_NONE;             // empty sheet: lowest_diff stays usize::MAX
+	uint8_t *lowest = arena.take_n<uint8_t>(nb + 1);
+	int16_t *first = arena.take_n<int16_t>(nb + 1), *last = arena.take_n<int16_t>(nb + 1);
+	uint8_t *bc = arena.take(nb * L + 16);
+	for (size_t i = 0; i < nb; i++) memcpy(bc + i * L, cl[i].barcode.data(), L);
 	const int nm = cfg.paired_end ? 2 : 1;
 	Matrix mseq[2], mqual[2], mout[2];
-	std::vector<uint16_t> mlen[2], mlk[2];
+	uint16_t *mlen[2] = {nullptr, nullptr}, *mlk[2] = {nullptr, nullptr};
 	if (nb > 0 && fused) {
 		size_t stride = 1;
 		for (size_t i = 0; i < nb; i++) {
@@ -677,38 +694,38 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 		memset(&fa, 0, sizeof fa);
 		fa.n = (int64_t)nb; fa.n_mates = nm; fa.stride = (int)stride; fa.min_baseq = cfg.q;
 		for (int m = 0; m < nm; m++) {
-			mseq[m].data.assign(nb * stride, 0);
-			mqual[m].data.assign(nb * stride, 0);
-			mlen[m].resize(nb);
-			mlk[m].resize(nb);
+			mseq[m].alloc(nb, stride, arena);
+			mqual[m].alloc(nb, stride, arena);
+			mlen[m] = arena.take_n<uint16_t>(nb);
+			mlk[m] = arena.take_n<uint16_t>(nb);
 			for (size_t i = 0; i < nb; i++) {
 				const host::Line &sl = m ? cl[i].m2[1] : cl[i].l2, &ql = m ? cl[i].m2[3] : cl[i].l4;
 				const size_t ls = strip_nl(sl), lq = strip_nl(ql);
-				memcpy(mseq[m].data.data() + i * stride, sl.p, ls);
-				memcpy(mqual[m].data.data() + i * stride, ql.p, lq);
+				mseq[m].put(i, sl.p, ls);
+				mqual[m].put(i, ql.p, lq);
 				mlen[m][i] = (uint16_t)std::min(host::trim_end_len(ql.p, ql.n), lq);      // trim: n = qual.trim_end().len()
 			}
-			mout[m].data.resize(nb * stride);
-			mout[m].stride = (int)stride;
-			fa.mate[m].seq = mseq[m].data.data(); fa.mate[m].qual = mqual[m].data.data(); fa.mate[m].len = mlen[m].data();
-			fa.mate[m].out_seq = cfg.do_mask ? mout[m].data.data() : nullptr;
-			fa.mate[m].lowest_k = cfg.do_trim ? mlk[m].data() : nullptr;
+			mout[m].alloc(nb, stride, arena);
+			fa.mate[m].seq = mseq[m].data; fa.mate[m].qual = mqual[m].data; fa.mate[m].len = mlen[m];
+			fa.mate[m].out_seq = cfg.do_mask ? mout[m].data : nullptr;
+			fa.mate[m].lowest_k = cfg.do_trim ? mlk[m] : nullptr;
 		}
 		if (L > 0) {
-			fa.bc = bc.data(); fa.bc_stride = (int)L; fa.assign = assign.data();
-			fa.lowest_diff = lowest.data(); fa.first_idx = first.data(); fa.last_idx = last.data();
+			fa.bc = bc; fa.bc_stride = (int)L; fa.assign = assign;
+			fa.lowest_diff = lowest; fa.first_idx = first; fa.last_idx = last;
 		}
-		std::lock_guard<std::mutex> lk(host::gpu_mutex());
-		check(sk_fused_pass(host::gpu(), &fa), "sk_fused_pass");
+		host::GpuLease g;
+		check(g.ctx(), sk_fused_pass(g.ctx(), &fa), "sk_fused_pass");
 	} else if (nb > 0 && L > 0) {
-		std::lock_guard<std::mutex> lk(host::gpu_mutex());
-		check(sk_demux_assign(host::gpu(), bc.data(), (int)L, (int64_t)nb, assign.data(), lowest.data(), first.data(), last.data()), "sk_demux_assign");
+		host::GpuLease g;
+		check(g.ctx(), sk_demux_assign(g.ctx(), bc, (int)L, (int64_t)nb, assign, lowest, first, last), "sk_demux_assign");
 	}
-	// :190-194 — in a dry run the barcodes that matched no sample are counted: on the device, from the same matrix
+	// :190-194 — in a dry run the barcodes that matched no sample are counted: on the device, from the same matrix.  The
+	// census table lives in ONE context (slot 0), whichever slot assigned the block.
 	const bool dev_census = cfg.dry_run && L > 0 && L <= kCensusMaxLen;
 	if (dev_census && nb > 0) {
-		std::lock_guard<std::mutex> lk(host::gpu_mutex());
-		check(sk_census_add(host::gpu(), bc.data(), (int)L, (int)L, (int64_t)nb, assign.data(), (int64_t)base), "sk_census_add");
+		host::GpuLease g(0);
+		check(g.ctx(), sk_census_add(g.ctx(), bc, (int)L, (int)L, (int64_t)nb, assign, (int64_t)base), "sk_census_add");
 	}
 
 	// body of one written record: verbatim lines, or the lines `mask by quality` then `trim by quality` would print
@@ -720,7 +737,7 @@ static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, f
 		if (cfg.do_mask) {                                                  // src/fasta_mask_by_quality.rs:32-45
 			if (ls != lq) { res.err = "Read sequence and base qualities are of different length."; return false; }
 			if (!host::is_ascii(sl.p, sl.n) || !host::is_ascii(ql.p, ql.n)) { res.err = "Non-ASCII read lines are not supported together with --mask-by-quality."; return false; }
-			seq_p = reinterpret_cast<const char *>(mout[m].data.data()) + i * (size_t)mout[m].stride;
+			seq_p = reinterpret_cast<const char *>(mout[m].data) + i * (size_t)mout[m].stride;
 			seq_n = ls + 1;                                                 // masked bases + the newline mask prints
 		}
 		if (cfg.do_trim) {                                                  // src/fasta_trim_by_quality.rs:44-48
@@ -865,7 +882,7 @@ static int demultiplex(int argc, char **argv)
 	{
 		std::vector<uint8_t> table((size_t)S * barcode_len);
 		for (int s = 0; s < S; s++) memcpy(table.data() + (size_t)s * barcode_len, samples[s].barcode.data(), barcode_len);
-		check(sk_set_barcodes(host::gpu(), table.data(), S, (int)barcode_len, 1 /* MAX_BARCODE_DIFFERENCE :168 */), "sk_set_barcodes");
+		host::gpu_for_each([&](sk_ctx *c) { check(c, sk_set_barcodes(c, table.data(), S, (int)barcode_len, 1 /* MAX_BARCODE_DIFFERENCE :168 */), "sk_set_barcodes"); });
 	}
 
 	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single");     // :106-107
@@ -927,6 +944,21 @@ static int demultiplex(int argc, char **argv)
 		while (inflight.size() >= nthreads) drain_one();
 	}
 	while (!inflight.empty()) drain_one();
+
+	// The blocks were dealt to several contexts (SEQKIT_GPUS devices x SEQKIT_CTXS_PER_GPU): their additive counters —
+	// the reference's total_reads / identified_reads / sample.total_reads, :108-109,169,177-178 — are summed over all of
+	// them (on one device by a kernel, across devices by RCCL), and must be what the ordered hand-off counted.
+	if (S > 0 && barcode_len > 0) {
+		std::vector<sk_ctx *> all;
+		for (size_t k = 0; k < host::gpu_slots(); k++) all.push_back(host::gpu_slot(k));
+		check(all[0], sk_counts_allreduce(all.data(), (int)all.size()), "sk_counts_allreduce");
+		std::vector<uint64_t> dc((size_t)S + 3);
+		check(all[0], sk_counts_get(all[0], dc.data()), "sk_counts_get");
+		bool same = dc[(size_t)S] == total_reads && dc[(size_t)S + 1] == identified_reads;
+		for (int s = 0; s < S && same; s++) same = dc[(size_t)s] == samples[s].total_reads;
+		if (!same) { close_outputs(); error("internal: the device counters (%llu clusters, %llu identified) differ from the records handed on (%llu, %llu).",
+		                                    (unsigned long long)dc[(size_t)S], (unsigned long long)dc[(size_t)S + 1], (unsigned long long)total_reads, (unsigned long long)identified_reads); }
+	}
 
 	if (dry_run > 0) {                                                      // :251-261
 		fprintf(stderr, "Dry run completed with %llu clusters. Barcodes found:\n", (unsigned long long)total_reads);

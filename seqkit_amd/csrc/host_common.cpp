@@ -454,10 +454,10 @@ struct BgzfStream::Impl {
 		return true;
 	}
 
-	// BSIZE of a BGZF block header (18+ bytes: gzip header with FEXTRA and a 'B','C' subfield), or 0
+	// BSIZE of a BGZF block from its gzip header (12 bytes + the XLEN bytes of extra subfields, among which 'B','C'), or 0
 	static size_t bgzf_block_size(const uint8_t *h, size_t n, size_t &xlen)
 	{
-		if (n < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
+		if (n < 12 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
 		xlen = (size_t)h[10] | ((size_t)h[11] << 8);
 		if (12 + xlen > n) return 0;
 		for (size_t o = 12; o + 4 <= 12 + xlen;) {
@@ -468,30 +468,50 @@ struct BgzfStream::Impl {
 		return 0;
 	}
 
+	// Read a block's whole gzip header into hdr (on top of what it holds): the 12 fixed bytes, then — when they are a gzip
+	// header with FEXTRA — the XLEN bytes of subfields, however many precede 'BC' (RFC 1952; htslib reads such files).
+	// false = read error.  A short hdr afterwards means the file ended there.
+	static bool read_header(int fd, std::vector<uint8_t> &hdr)
+	{
+		size_t got = 0;
+		if (hdr.size() < 12) {
+			const size_t have = hdr.size();
+			hdr.resize(12);
+			if (!read_full(fd, hdr.data() + have, 12 - have, got)) return false;
+			hdr.resize(have + got);
+		}
+		if (hdr.size() < 12 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return true;
+		const size_t want = 12 + ((size_t)hdr[10] | ((size_t)hdr[11] << 8));
+		if (hdr.size() < want) {
+			const size_t have = hdr.size();
+			hdr.resize(want);
+			if (!read_full(fd, hdr.data() + have, want - have, got)) return false;
+			hdr.resize(have + got);
+		}
+		return true;
+	}
+
 	void reader_main()
 	{
-		std::vector<uint8_t> hdr(head);                      // first header bytes were read by the constructor
+		std::vector<uint8_t> hdr(head);                      // the first block's header was read by the constructor
 		for (;;) {
 			size_t got = 0;
-			if (hdr.size() < 18) {
-				const size_t have = hdr.size();
-				hdr.resize(18);
-				if (!read_full(fd, hdr.data() + have, 18 - have, got)) { fail_read(); return; }
-				hdr.resize(have + got);
-			}
+			if (!read_header(fd, hdr)) { fail_read(); return; }
 			if (hdr.empty()) break;                          // clean end of file
 			size_t xlen = 0;
-			const size_t bsize = hdr.size() >= 18 ? bgzf_block_size(hdr.data(), hdr.size(), xlen) : 0;
+			const size_t bsize = bgzf_block_size(hdr.data(), hdr.size(), xlen);
 			auto b = std::make_shared<Block>();
 			if (bsize == 0 || bsize < 12 + xlen + 8) {
 				// a cut-off header is the end of the data; anything else that is not a BGZF block is corrupt
-				if (hdr.size() >= 18) { b->bad = true; b->done = true; push(b, false); }
+				const bool cut = hdr.size() < 12 || (hdr[0] == 31 && hdr[1] == 139 && hdr[2] == 8 && (hdr[3] & 4) && hdr.size() < 12 + (((size_t)hdr[10]) | ((size_t)hdr[11] << 8)));
+				if (!cut) { b->bad = true; b->done = true; push(b, false); }
 				break;
 			}
+			const size_t hl = hdr.size();                    // == 12 + xlen
 			b->comp.resize(bsize);
-			memcpy(b->comp.data(), hdr.data(), 18);
-			if (!read_full(fd, b->comp.data() + 18, bsize - 18, got)) { fail_read(); return; }
-			if (got != bsize - 18) break;                    // file ends inside a block: the data end before it
+			memcpy(b->comp.data(), hdr.data(), hl);
+			if (!read_full(fd, b->comp.data() + hl, bsize - hl, got)) { fail_read(); return; }
+			if (got != bsize - hl) break;                    // file ends inside a block: the data end before it
 			b->cdata_off = 12 + xlen;
 			b->cdata_len = bsize - b->cdata_off - 8;
 			hdr.clear();
@@ -623,12 +643,10 @@ BgzfStream::BgzfStream(int fd) : impl_(new Impl())
 {
 	Impl &m = *impl_;
 	m.fd = fd;
-	m.head.resize(18);
-	size_t got = 0;
-	Impl::read_full(fd, m.head.data(), 18, got);
-	m.head.resize(got);
+	m.head.clear();
+	Impl::read_header(fd, m.head);
 	size_t xlen = 0;
-	m.bgzf = got == 18 && Impl::bgzf_block_size(m.head.data(), 18, xlen) != 0;
+	m.bgzf = Impl::bgzf_block_size(m.head.data(), m.head.size(), xlen) != 0;
 	if (m.bgzf) {
 		unsigned n = std::thread::hardware_concurrency();
 		if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
@@ -640,7 +658,7 @@ BgzfStream::BgzfStream(int fd) : impl_(new Impl())
 	} else {
 		memset(&m.z, 0, sizeof m.z);
 		inflateInit2(&m.z, 15 + 32);                         // gzip or zlib wrapper, detected; raw bytes fail like gzread's would not, see below
-		m.zin.resize(1 << 16);
+		m.zin.resize(std::max<size_t>(1 << 16, m.head.size()));
 		memcpy(m.zin.data(), m.head.data(), m.head.size());
 		m.z.next_in = m.zin.data();
 		m.z.avail_in = (uInt)m.head.size();
@@ -785,23 +803,35 @@ Out &out()
 }
 
 // ---- GPU ---------------------------------------------------------------------------------------------------
-std::mutex &gpu_mutex()
-{
-	static std::mutex m;
-	return m;
-}
-
-// The context takes a few hundred ms to create (runtime start-up, code object load).  gpu_warmup() starts that in the
+// The contexts take a few hundred ms to create (runtime start-up, code object load).  gpu_warmup() starts that in the
 // background as soon as a command knows it will need the device, so that it overlaps opening and reading the input;
-// a failure stays silent until gpu() is actually called.
-struct GpuInit { int rc = SK_OK; sk_ctx *ctx = nullptr; std::string err; };
-static GpuInit create_ctx()
+// a failure stays silent until a context is actually asked for.
+struct GpuInit { int rc = SK_OK; std::vector<sk_ctx *> ctxs; std::string err; };
+static GpuInit create_ctxs()
 {
 	GpuInit r;
-	int dev = 0;
-	if (const char *e = getenv("SEQKIT_GPU")) dev = atoi(e);
-	r.rc = sk_create(dev, &r.ctx);
-	if (r.rc != SK_OK) r.err = sk_last_error(nullptr);
+	std::vector<int> devs;
+	if (const char *e = getenv("SEQKIT_GPUS")) {
+		for (const char *p = e; *p;) {
+			char *end = nullptr;
+			const long d = strtol(p, &end, 10);
+			if (end == p) break;
+			devs.push_back((int)d);
+			p = (*end == ',') ? end + 1 : end;
+			if (*end && *end != ',') break;
+		}
+	}
+	if (devs.empty()) devs.push_back(getenv("SEQKIT_GPU") ? atoi(getenv("SEQKIT_GPU")) : 0);
+	int per = getenv("SEQKIT_CTXS_PER_GPU") ? atoi(getenv("SEQKIT_CTXS_PER_GPU")) : 2;
+	if (per < 1) per = 1;
+	if (per > 8) per = 8;
+	for (int k = 0; k < per && r.rc == SK_OK; k++)          // slot order d0 d1 ... d0 d1 ...: consecutive blocks go to different devices
+		for (int d : devs) {
+			sk_ctx *c = nullptr;
+			r.rc = sk_create(d, &c);
+			if (r.rc != SK_OK) { r.err = sk_last_error(nullptr); break; }
+			r.ctxs.push_back(c);
+		}
 	return r;
 }
 static std::mutex g_warm_m;
@@ -810,20 +840,122 @@ static std::shared_future<GpuInit> g_warm;
 void gpu_warmup()
 {
 	std::lock_guard<std::mutex> lk(g_warm_m);
-	if (!g_warm.valid()) g_warm = std::async(std::launch::async, create_ctx).share();
+	if (!g_warm.valid()) g_warm = std::async(std::launch::async, create_ctxs).share();
 }
 
-sk_ctx *gpu()
+namespace {
+struct GpuPool {
+	std::vector<sk_ctx *> ctxs;
+	std::vector<char> busy;
+	size_t next = 0;
+	std::mutex m;
+	std::condition_variable cv;
+};
+GpuPool &gpu_pool()
 {
-	static sk_ctx *ctx = nullptr;
+	static GpuPool p;
 	static std::once_flag once;
 	std::call_once(once, [] {
 		gpu_warmup();
 		const GpuInit r = g_warm.get();
 		if (r.rc != SK_OK) error("No usable MI355X for the seqkit HIP path (%s); this build has no CPU fallback.", r.err.c_str());
-		ctx = r.ctx;
+		p.ctxs = r.ctxs;
+		p.busy.assign(p.ctxs.size(), 0);
 	});
-	return ctx;
+	return p;
+}
+}  // namespace
+
+sk_ctx *gpu() { return gpu_pool().ctxs[0]; }
+size_t gpu_slots() { return gpu_pool().ctxs.size(); }
+sk_ctx *gpu_slot(size_t i) { return gpu_pool().ctxs[i]; }
+void gpu_for_each(const std::function<void(sk_ctx *)> &fn)
+{
+	for (sk_ctx *c : gpu_pool().ctxs) fn(c);
+}
+
+GpuLease::GpuLease()
+{
+	GpuPool &p = gpu_pool();
+	std::unique_lock<std::mutex> lk(p.m);
+	for (;;) {
+		for (size_t k = 0; k < p.ctxs.size(); k++) {
+			const size_t s = (p.next + k) % p.ctxs.size();
+			if (!p.busy[s]) {
+				p.busy[s] = 1;
+				p.next = s + 1;
+				slot_ = s;
+				ctx_ = p.ctxs[s];
+				return;
+			}
+		}
+		p.cv.wait(lk);
+	}
+}
+
+GpuLease::GpuLease(size_t slot)
+{
+	GpuPool &p = gpu_pool();
+	std::unique_lock<std::mutex> lk(p.m);
+	p.cv.wait(lk, [&] { return !p.busy[slot]; });
+	p.busy[slot] = 1;
+	slot_ = slot;
+	ctx_ = p.ctxs[slot];
+}
+
+GpuLease::~GpuLease()
+{
+	GpuPool &p = gpu_pool();
+	{
+		std::lock_guard<std::mutex> lk(p.m);
+		p.busy[slot_] = 0;
+	}
+	p.cv.notify_all();
+}
+
+// ---- pinned staging ---------------------------------------------------------------------------------------------
+struct PinnedArena::Buf { uint8_t *p = nullptr; size_t cap = 0, want = 0; };
+namespace {
+std::mutex g_arena_m;
+std::vector<PinnedArena::Buf *> g_arena_free;
+}  // namespace
+
+PinnedArena::PinnedArena(size_t hint_bytes)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_arena_m);
+		if (!g_arena_free.empty()) { buf_ = g_arena_free.back(); g_arena_free.pop_back(); }
+		else buf_ = new Buf();
+	}
+	if (hint_bytes > buf_->want) buf_->want = hint_bytes;
+	if (buf_->want > buf_->cap) {                             // the last use overflowed: grow now, while nothing points into it
+		if (buf_->p) (void)sk_free_pinned(gpu(), buf_->p);
+		buf_->p = nullptr;
+		void *q = nullptr;
+		const size_t cap = buf_->want + (buf_->want >> 2);
+		if (sk_malloc_pinned(gpu(), cap, &q) != SK_OK) error("Cannot allocate %zu bytes of pinned host memory (%s).", cap, sk_last_error(gpu()));
+		buf_->p = static_cast<uint8_t *>(q);
+		buf_->cap = cap;
+	}
+}
+
+PinnedArena::~PinnedArena()
+{
+	for (void *q : extra_) (void)sk_free_pinned(gpu(), q);
+	if (used_ > buf_->want) buf_->want = used_;
+	std::lock_guard<std::mutex> lk(g_arena_m);
+	g_arena_free.push_back(buf_);
+}
+
+uint8_t *PinnedArena::take(size_t bytes)
+{
+	const size_t at = (used_ + 63) & ~(size_t)63;
+	used_ = at + bytes;
+	if (used_ <= buf_->cap) return buf_->p + at;
+	void *q = nullptr;                                        // does not fit: its own block for this use, a bigger main buffer next time
+	if (sk_malloc_pinned(gpu(), bytes ? bytes : 1, &q) != SK_OK) error("Cannot allocate %zu bytes of pinned host memory (%s).", bytes, sk_last_error(gpu()));
+	extra_.push_back(q);
+	return static_cast<uint8_t *>(q);
 }
 
 size_t trim_end_len(const char *p, size_t n)

@@ -111,11 +111,48 @@ private:
 };
 Out &out();
 
-// ---- the GPU context (created on first use; no CPU fallback) -------------------------------------------
-sk_ctx *gpu();
-void gpu_warmup();                                       // start creating the context in the background (silent on failure)
-// a ctx is used by one thread at a time: worker threads take this lock around their sk_* calls
-std::mutex &gpu_mutex();
+// ---- the GPU contexts (created on first use; no CPU fallback) ------------------------------------------
+// SEQKIT_GPUS=0,1,... lists the devices a command spreads its blocks over (default: SEQKIT_GPU, else device 0; a
+// device may be listed more than once); every listed device gets SEQKIT_CTXS_PER_GPU contexts (default 2), each with
+// its own streams and workspace, so that the copies of one block run under the kernel of another.  A context ("slot")
+// is used by one thread at a time: a worker holds a GpuLease around its sk_* calls.  Blocks are dealt to the slots
+// round-robin; the results are handed on in input order by the callers, whichever slot computed them.
+sk_ctx *gpu();                                           // slot 0: set-up calls and single-threaded commands
+void gpu_warmup();                                       // start creating the contexts in the background (silent on failure)
+size_t gpu_slots();                                      // number of contexts
+sk_ctx *gpu_slot(size_t i);
+void gpu_for_each(const std::function<void(sk_ctx *)> &fn);      // every slot, in order (sk_set_barcodes, ...)
+class GpuLease {
+public:
+	GpuLease();                                          // the next slot in round-robin order that is free (waits for one)
+	explicit GpuLease(size_t slot);                      // that slot (waits for it): state that lives in one context (census)
+	~GpuLease();
+	GpuLease(const GpuLease &) = delete;
+	GpuLease &operator=(const GpuLease &) = delete;
+	sk_ctx *ctx() const { return ctx_; }
+private:
+	size_t slot_;
+	sk_ctx *ctx_;
+};
+
+// ---- pinned staging -----------------------------------------------------------------------------------------
+// Batch matrices are packed straight into page-locked memory (sk_malloc_pinned), so the library's H2D / D2H copies
+// are DMA transfers instead of staged ones.  A worker takes a PinnedArena for the life of one block (pack -> device
+// -> emit); arenas are recycled, and an arena only grows.
+class PinnedArena {
+public:
+	explicit PinnedArena(size_t hint_bytes = 0);         // hint: what this use will take in all (the buffer grows before use, not under it)
+	~PinnedArena();                                      // back to the pool
+	PinnedArena(const PinnedArena &) = delete;
+	PinnedArena &operator=(const PinnedArena &) = delete;
+	uint8_t *take(size_t bytes);                         // 64-byte aligned, valid until the arena is destroyed; NOT zeroed
+	template <class T> T *take_n(size_t n) { return reinterpret_cast<T *>(take(n * sizeof(T))); }
+	struct Buf;
+private:
+	Buf *buf_;
+	size_t used_ = 0;
+	std::vector<void *> extra_;                          // overflow blocks of this use (freed on release; the main buffer grows for the next use)
+};
 
 // ---- block-parallel record pipeline (the ingest half of SURVEY.md §8f f1) ------------------------------
 // The input is cut into blocks of whole records (`lines_per_record` lines each; only the last block may end in a

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -63,6 +64,7 @@ public:
 		for (uint32_t i = 0; i < n_ref; i++) {
 			if (!get(h, 4)) open_fail();
 			const uint32_t l_name = le32(h);
+			if (l_name > (1u << 20)) open_fail();               // a reference name of megabytes is a damaged header, not an allocation to attempt
 			std::string name(l_name, '\0');
 			if (l_name && !get(reinterpret_cast<uint8_t *>(&name[0]), l_name)) open_fail();
 			if (!name.empty() && name.back() == '\0') name.pop_back();
@@ -141,8 +143,15 @@ public:
 		// htslib bam_read1: a record whose variable part cannot hold its own fields is invalid
 		if (v.l_read_name < 1 || v.l_seq > 0x7fffffffu ||
 		    (uint64_t)v.n_cigar * 4 + v.l_read_name + (((uint64_t)v.l_seq + 1) >> 1) + v.l_seq > rest) return rd_fail("Invalid BAM record.");
-		body.resize(rest);
-		if (rest && !need(body.data(), rest)) return false;
+		// the record's size comes from the file: take it in steps, so that a damaged size field runs into the end of the data
+		// ("BAM file ended prematurely.") instead of into one allocation of gigabytes
+		body.clear();
+		for (uint32_t done = 0; done < rest;) {
+			const uint32_t step = std::min<uint32_t>(rest - done, 16u << 20);
+			try { body.resize((size_t)done + step); } catch (const std::bad_alloc &) { return rd_fail("Invalid BAM record."); }
+			if (!need(body.data() + done, step)) return false;
+			done += step;
+		}
 		return true;
 	}
 	std::vector<std::string> names;

@@ -20,7 +20,8 @@ struct sk_ctx {
 	int device = 0;
 	int n_cu = 256;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipStream_t stream2 = nullptr;     // second lane of the host entry points' chunk pipeline (H2D of chunk i+1 under kernel / D2H of chunk i)
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_pipe = nullptr;
 	std::string err;
 	// barcode table
 	bool have_table = false;
@@ -79,13 +80,43 @@ static int ensure_ws(sk_ctx *c, size_t bytes)
 	if (c->ws) { SK_HIP(c, hipStreamSynchronize(c->stream)); SK_HIP(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
 	size_t want = bytes + (bytes >> 2);
 	hipError_t e = hipMalloc((void **)&c->ws, want);
-	if (e != hipSuccess) { want = bytes; e = hipMalloc((void **)&c->ws, want); }
-	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "device workspace of %zu bytes: %s", want, hipGetErrorString(e));
+	if (e != hipSuccess) { (void)hipGetLastError(); want = bytes; e = hipMalloc((void **)&c->ws, want); }      // the tolerated failure must not stay as the sticky last error
+	if (e != hipSuccess) { (void)hipGetLastError(); c->ws = nullptr; return fail(c, SK_ERR_NOMEM, "device workspace of %zu bytes: %s", want, hipGetErrorString(e)); }
 	c->ws_bytes = want;
 	return SK_OK;
 }
 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// The host-pointer entry points cut a batch into chunks and run them as a two-deep software pipeline: chunk k uses
+// stream (k & 1) and half (k & 1) of the workspace, so the H2D copies of chunk k+1 run under the kernel and the D2H
+// copies of chunk k, and a half is reused only by the next chunk of the SAME stream (in order: no hazard).  Copies are
+// true DMA when the caller's buffers are pinned (sk_malloc_pinned); pageable buffers work too, staged by the runtime.
+struct ChunkPipe {
+	sk_ctx *c;
+	size_t half = 0;
+	int k = 0;
+	explicit ChunkPipe(sk_ctx *ctx) : c(ctx) {}
+	int begin(size_t bytes_per_chunk, size_t shared_tail = 0)      // shared_tail: bytes after the two halves used by every chunk (accumulators)
+	{
+		half = up256(bytes_per_chunk);
+		if (int r = ensure_ws(c, 2 * half + shared_tail)) return r;
+		SK_HIP(c, hipEventRecord(c->ev_pipe, c->stream));          // the second lane starts after whatever the ctx stream holds
+		SK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pipe, 0));
+		return SK_OK;
+	}
+	hipStream_t st() const { return (k & 1) ? c->stream2 : c->stream; }
+	uint8_t *ws() const { return c->ws + (size_t)(k & 1) * half; }
+	uint8_t *tail() const { return c->ws + 2 * half; }
+	void next() { k++; }
+	int end()
+	{
+		SK_HIP(c, hipStreamSynchronize(c->stream2));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+		return SK_OK;
+	}
+};
+static const size_t kPipeChunkBytes = 48u << 20;
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 extern "C" {
@@ -117,6 +148,8 @@ int sk_create(int device_id, sk_ctx **out)
 	c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	e = hipSetDevice(device_id);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pipe, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreate(&c->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&c->ev1);
 	if (e != hipSuccess) { int r = fail(nullptr, SK_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete c; return r; }
@@ -129,6 +162,7 @@ void sk_destroy(sk_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->d_raw) (void)hipFree(c->d_raw);
 	if (c->d_onehot) (void)hipFree(c->d_onehot);
 	if (c->d_lut) (void)hipFree(c->d_lut);
@@ -141,6 +175,8 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_genome) (void)hipFree(c->d_genome);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->ev_pipe) (void)hipEventDestroy(c->ev_pipe);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -178,7 +214,7 @@ int sk_malloc_pinned(sk_ctx *c, size_t bytes, void **out)
 	if (!c || !out) return SK_ERR_INVALID;
 	if (int r = bind(c)) return r;
 	*out = nullptr;
-	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);     // pinned for every device of the process
 	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
 	return SK_OK;
 }
@@ -581,15 +617,17 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 		if (mt.lowest_k) per_row += 2;
 	}
 	if (a->bc) per_row += (size_t)a->bc_stride + 4 + 1 + 2 + 2;
-	int64_t chunk = (int64_t)((size_t)(192u << 20) / (per_row ? per_row : 1));
+	int64_t chunk = (int64_t)(kPipeChunkBytes / (per_row ? per_row : 1));
 	chunk &= ~(int64_t)63;
 	if (chunk < 64) chunk = 64;
 	if (chunk > a->n) chunk = (a->n + 63) & ~(int64_t)63;
-	if (int r = ensure_ws(c, (size_t)chunk * per_row + 64 * 256)) return r;
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin((size_t)chunk * per_row + 64 * 256)) return r;
 
-	for (int64_t r0 = 0; r0 < a->n; r0 += chunk) {
+	for (int64_t r0 = 0; r0 < a->n; r0 += chunk, pipe.next()) {
 		const int64_t nr = (a->n - r0) < chunk ? (a->n - r0) : chunk;
-		uint8_t *p = c->ws;
+		hipStream_t st = pipe.st();
+		uint8_t *p = pipe.ws();
 		auto carve = [&](size_t bytes) { uint8_t *q = p; p += up256(bytes); return q; };
 		sk_fused_args d = *a;
 		d.n = nr; d.counts = nullptr;
@@ -599,24 +637,24 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 			dm = sk_mate{nullptr, nullptr, nullptr, nullptr, nullptr};
 			if (!mt.out_seq && !mt.lowest_k) continue;
 			uint8_t *dq = carve((size_t)nr * stride);
-			SK_HIP(c, hipMemcpyAsync(dq, mt.qual + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
+			SK_HIP(c, hipMemcpyAsync(dq, mt.qual + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, st));
 			dm.qual = dq;
 			if (mt.out_seq) {
 				uint8_t *ds = carve((size_t)nr * stride);
-				SK_HIP(c, hipMemcpyAsync(ds, mt.seq + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
+				SK_HIP(c, hipMemcpyAsync(ds, mt.seq + r0 * stride, (size_t)nr * stride, hipMemcpyHostToDevice, st));
 				dm.seq = ds;
 				dm.out_seq = carve((size_t)nr * stride);
 			}
 			if (mt.len) {
 				uint16_t *dl = (uint16_t *)carve((size_t)nr * 2);
-				SK_HIP(c, hipMemcpyAsync(dl, mt.len + r0, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+				SK_HIP(c, hipMemcpyAsync(dl, mt.len + r0, (size_t)nr * 2, hipMemcpyHostToDevice, st));
 				dm.len = dl;
 			}
 			if (mt.lowest_k) dm.lowest_k = (uint16_t *)carve((size_t)nr * 2);
 		}
 		if (a->bc) {
 			uint8_t *db = carve((size_t)nr * a->bc_stride);
-			SK_HIP(c, hipMemcpyAsync(db, a->bc + r0 * a->bc_stride, (size_t)nr * a->bc_stride, hipMemcpyHostToDevice, c->stream));
+			SK_HIP(c, hipMemcpyAsync(db, a->bc + r0 * a->bc_stride, (size_t)nr * a->bc_stride, hipMemcpyHostToDevice, st));
 			d.bc = db;
 			d.assign = (int32_t *)carve((size_t)nr * 4);
 			d.lowest_diff = a->lowest_diff ? carve((size_t)nr) : nullptr;
@@ -624,22 +662,21 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 			d.last_idx = a->last_idx ? (int16_t *)carve((size_t)nr * 2) : nullptr;
 		}
 		sk::TileArgs t = tile_args_of(c, &d);
-		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
+		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, st));
 		for (int m = 0; m < a->n_mates; m++) {
 			const sk_mate &mt = a->mate[m];
 			const sk_mate &dm = d.mate[m];
-			if (mt.out_seq) SK_HIP(c, hipMemcpyAsync(mt.out_seq + r0 * stride, dm.out_seq, (size_t)nr * stride, hipMemcpyDeviceToHost, c->stream));
-			if (mt.lowest_k) SK_HIP(c, hipMemcpyAsync(mt.lowest_k + r0, dm.lowest_k, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
+			if (mt.out_seq) SK_HIP(c, hipMemcpyAsync(mt.out_seq + r0 * stride, dm.out_seq, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
+			if (mt.lowest_k) SK_HIP(c, hipMemcpyAsync(mt.lowest_k + r0, dm.lowest_k, (size_t)nr * 2, hipMemcpyDeviceToHost, st));
 		}
 		if (a->bc) {
-			SK_HIP(c, hipMemcpyAsync(a->assign + r0, d.assign, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-			if (a->lowest_diff) SK_HIP(c, hipMemcpyAsync(a->lowest_diff + r0, d.lowest_diff, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
-			if (a->first_idx) SK_HIP(c, hipMemcpyAsync(a->first_idx + r0, d.first_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
-			if (a->last_idx) SK_HIP(c, hipMemcpyAsync(a->last_idx + r0, d.last_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, c->stream));
+			SK_HIP(c, hipMemcpyAsync(a->assign + r0, d.assign, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+			if (a->lowest_diff) SK_HIP(c, hipMemcpyAsync(a->lowest_diff + r0, d.lowest_diff, (size_t)nr, hipMemcpyDeviceToHost, st));
+			if (a->first_idx) SK_HIP(c, hipMemcpyAsync(a->first_idx + r0, d.first_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, st));
+			if (a->last_idx) SK_HIP(c, hipMemcpyAsync(a->last_idx + r0, d.last_idx, (size_t)nr * 2, hipMemcpyDeviceToHost, st));
 		}
-		SK_HIP(c, hipStreamSynchronize(c->stream));
 	}
-	return SK_OK;
+	return pipe.end();
 }
 
 // ---- tile-blocked batches ---------------------------------------------------------------------------------------
@@ -660,6 +697,7 @@ int sk_blocked_layout_init(sk_blocked_layout *lay, int n_mates, int stride, int 
 	}
 	if (bc_stride > 0) lay->in_bc = seg(in, 64 * (int64_t)bc_stride);
 	if (flags & SK_BLK_LEN) for (int m = 0; m < n_mates; m++) lay->in_len[m] = seg(in, 128);
+	if (flags & ~(SK_BLK_MASK | SK_BLK_TRIM | SK_BLK_LEN | SK_BLK_DETAIL)) return SK_ERR_INVALID;
 	if (flags & SK_BLK_MASK) for (int m = 0; m < n_mates; m++) lay->out_seq[m] = seg(out, 64 * (int64_t)stride);
 	if (flags & SK_BLK_TRIM) for (int m = 0; m < n_mates; m++) lay->out_lowest_k[m] = seg(out, 128);
 	if (bc_stride > 0) {
@@ -781,20 +819,21 @@ int sk_mask_by_quality(sk_ctx *c, uint8_t *seq, const uint8_t *qual, const uint1
 	(void)len;   // pad bytes of the output are unspecified: the whole matrix is one byte stream
 	if (int r = bind(c)) return r;
 	const int64_t total = n * (int64_t)stride;
-	int64_t chunk = (int64_t)64 << 20;
+	int64_t chunk = (int64_t)16 << 20;
 	if (chunk > total) chunk = (total + 15) & ~(int64_t)15;
-	if (int r = ensure_ws(c, (size_t)up256((size_t)chunk) * 3)) return r;
-	uint8_t *ds = c->ws, *dq = c->ws + up256((size_t)chunk), *dout = c->ws + 2 * up256((size_t)chunk);
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin((size_t)up256((size_t)chunk) * 3)) return r;
 	sk::QualConsts qc = sk::make_qual_consts(min_baseq);
-	for (int64_t o = 0; o < total; o += chunk) {
+	for (int64_t o = 0; o < total; o += chunk, pipe.next()) {
 		const int64_t nb = (total - o) < chunk ? (total - o) : chunk;
-		SK_HIP(c, hipMemcpyAsync(ds, seq + o, (size_t)nb, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dq, qual + o, (size_t)nb, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, sk::launch_mask_flat(ds, dq, dout, nb, qc, c->n_cu, c->stream));
-		SK_HIP(c, hipMemcpyAsync(seq + o, dout, (size_t)nb, hipMemcpyDeviceToHost, c->stream));
-		SK_HIP(c, hipStreamSynchronize(c->stream));
+		hipStream_t st = pipe.st();
+		uint8_t *ds = pipe.ws(), *dq = ds + up256((size_t)chunk), *dout = ds + 2 * up256((size_t)chunk);
+		SK_HIP(c, hipMemcpyAsync(ds, seq + o, (size_t)nb, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dq, qual + o, (size_t)nb, hipMemcpyHostToDevice, st));
+		SK_HIP(c, sk::launch_mask_flat(ds, dq, dout, nb, qc, c->n_cu, st));
+		SK_HIP(c, hipMemcpyAsync(seq + o, dout, (size_t)nb, hipMemcpyDeviceToHost, st));
 	}
-	return SK_OK;
+	return pipe.end();
 }
 
 // ---- BAM -------------------------------------------------------------------------------------------
@@ -821,28 +860,31 @@ int sk_bam_flag_tlen(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	if (!counters && !hist) return fail(c, SK_ERR_INVALID, "nothing to do");
 	if (int r = bind(c)) return r;
 	const size_t nout = 4 + (hist ? (size_t)max_frag + 1 : 0);
-	int64_t chunk = 8 << 20;
+	int64_t chunk = 4 << 20;
 	if (chunk > n) chunk = n;
 	const size_t cols = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4);
-	if (int r = ensure_ws(c, cols + up256(nout * 8))) return r;
-	uint8_t *p = c->ws;
-	uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
-	int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
-	int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
-	int32_t *dtlen = (int32_t *)p; p += up256((size_t)chunk * 4);
-	unsigned long long *dout = (unsigned long long *)p;
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin(cols, up256(nout * 8))) return r;
+	unsigned long long *dout = (unsigned long long *)pipe.tail();
 	SK_HIP(c, hipMemsetAsync(dout, 0, nout * 8, c->stream));
-	for (int64_t o = 0; o < n; o += chunk) {
+	SK_HIP(c, hipStreamSynchronize(c->stream));                   // both lanes add into dout
+	for (int64_t o = 0; o < n; o += chunk, pipe.next()) {
 		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
-		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
+		hipStream_t st = pipe.st();
+		uint8_t *p = pipe.ws();
+		uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
+		int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+		int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+		int32_t *dtlen = (int32_t *)p;
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, st));
 		if (hist) {
-			SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
-			SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
-			SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+			SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+			SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+			SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
 		}
-		SK_HIP(c, sk::launch_bam_flag_tlen(dflag, dtid, dmtid, dtlen, nr, max_frag, dout, counters ? 1 : 0, hist ? 1 : 0, c->n_cu, c->stream));
-		SK_HIP(c, hipStreamSynchronize(c->stream));
+		SK_HIP(c, sk::launch_bam_flag_tlen(dflag, dtid, dmtid, dtlen, nr, max_frag, dout, counters ? 1 : 0, hist ? 1 : 0, c->n_cu, st));
 	}
+	if (int r = pipe.end()) return r;
 	std::vector<uint64_t> h(nout);
 	SK_HIP(c, hipMemcpy(h.data(), dout, nout * 8, hipMemcpyDeviceToHost));
 	if (counters) for (int i = 0; i < 3; i++) counters[i] += h[i];
@@ -875,28 +917,31 @@ int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	if (n == 0) return SK_OK;
 	if (!flag || !tid || !mtid || !tlen || !keep_bits) return fail(c, SK_ERR_INVALID, "NULL column or output");
 	if (int r = bind(c)) return r;
-	int64_t chunk = 8 << 20;
+	int64_t chunk = 4 << 20;
 	if (chunk > n) chunk = (n + 7) & ~(int64_t)7;
-	const size_t need = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4) + up256((size_t)chunk / 8 + 8) + 256;
-	if (int r = ensure_ws(c, need)) return r;
-	uint8_t *p = c->ws;
-	uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
-	int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
-	int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
-	int32_t *dtlen = (int32_t *)p; p += up256((size_t)chunk * 4);
-	uint8_t *dbits = p; p += up256((size_t)chunk / 8 + 8);
-	unsigned long long *dkept = (unsigned long long *)p;
+	const size_t need = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4) + up256((size_t)chunk / 8 + 8);
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin(need, 256)) return r;
+	unsigned long long *dkept = (unsigned long long *)pipe.tail();
 	SK_HIP(c, hipMemsetAsync(dkept, 0, 8, c->stream));
-	for (int64_t o = 0; o < n; o += chunk) {      // chunk is a multiple of 8 records: byte-aligned in keep_bits
+	SK_HIP(c, hipStreamSynchronize(c->stream));                   // both lanes add into dkept
+	for (int64_t o = 0; o < n; o += chunk, pipe.next()) {         // chunk is a multiple of 8 records: byte-aligned in keep_bits
 		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
-		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, sk::launch_bam_fragments(dflag, dtid, dmtid, dtlen, nr, min_size, max_size, dbits, dkept, c->n_cu, c->stream));
-		SK_HIP(c, hipMemcpyAsync(keep_bits + o / 8, dbits, (size_t)((nr + 7) / 8), hipMemcpyDeviceToHost, c->stream));
-		SK_HIP(c, hipStreamSynchronize(c->stream));
+		hipStream_t st = pipe.st();
+		uint8_t *p = pipe.ws();
+		uint16_t *dflag = (uint16_t *)p; p += up256((size_t)chunk * 2);
+		int32_t *dtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+		int32_t *dmtid = (int32_t *)p; p += up256((size_t)chunk * 4);
+		int32_t *dtlen = (int32_t *)p; p += up256((size_t)chunk * 4);
+		uint8_t *dbits = p;
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dtid, tid + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dmtid, mtid + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dtlen, tlen + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+		SK_HIP(c, sk::launch_bam_fragments(dflag, dtid, dmtid, dtlen, nr, min_size, max_size, dbits, dkept, c->n_cu, st));
+		SK_HIP(c, hipMemcpyAsync(keep_bits + o / 8, dbits, (size_t)((nr + 7) / 8), hipMemcpyDeviceToHost, st));
 	}
+	if (int r = pipe.end()) return r;
 	uint64_t k = 0;
 	SK_HIP(c, hipMemcpy(&k, dkept, 8, hipMemcpyDeviceToHost));
 	if (kept) *kept += k;
@@ -994,28 +1039,29 @@ int sk_count_add(sk_ctx *c, const uint16_t *flag, const uint8_t *mapq, const int
 	if (int r = count_args(c, a, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n, min_mapq, max_frag_len, single_end, center)) return r;
 	if (n == 0) return SK_OK;
 	if (int r = bind(c)) return r;
-	int64_t chunk = 4 << 20;
+	int64_t chunk = 2 << 20;
 	if (chunk > n) chunk = n;
 	const size_t b2 = up256((size_t)chunk * 2), b1 = up256((size_t)chunk), b4 = up256((size_t)chunk * 4);
-	if (int r = ensure_ws(c, b2 + b1 + 6 * b4)) return r;
-	uint8_t *p = c->ws;
-	uint16_t *dflag = (uint16_t *)p; p += b2;
-	uint8_t *dmapq = p; p += b1;
-	int32_t *dcol[6];
-	for (int k = 0; k < 6; k++) { dcol[k] = (int32_t *)p; p += b4; }
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin(b2 + b1 + 6 * b4)) return r;
 	const int32_t *hcol[6] = {tid, mtid, pos, mpos, tlen, end_pos};
-	for (int64_t o = 0; o < n; o += chunk) {
+	for (int64_t o = 0; o < n; o += chunk, pipe.next()) {
 		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
-		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dmapq, mapq + o, (size_t)nr, hipMemcpyHostToDevice, c->stream));
+		hipStream_t st = pipe.st();
+		uint8_t *p = pipe.ws();
+		uint16_t *dflag = (uint16_t *)p; p += b2;
+		uint8_t *dmapq = p; p += b1;
+		int32_t *dcol[6];
+		for (int k = 0; k < 6; k++) { dcol[k] = (int32_t *)p; p += b4; }
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dmapq, mapq + o, (size_t)nr, hipMemcpyHostToDevice, st));
 		for (int k = 0; k < 6; k++)
-			if (hcol[k]) SK_HIP(c, hipMemcpyAsync(dcol[k], hcol[k] + o, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+			if (hcol[k]) SK_HIP(c, hipMemcpyAsync(dcol[k], hcol[k] + o, (size_t)nr * 4, hipMemcpyHostToDevice, st));
 		a.flag = dflag; a.mapq = dmapq; a.tid = dcol[0]; a.mtid = dcol[1]; a.pos = dcol[2]; a.mpos = dcol[3]; a.tlen = dcol[4]; a.end_pos = dcol[5];
 		a.n = nr;
-		SK_HIP(c, sk::launch_bam_count(a, c->n_cu, c->stream));
-		SK_HIP(c, hipStreamSynchronize(c->stream));
+		SK_HIP(c, sk::launch_bam_count(a, c->n_cu, st));
 	}
-	return SK_OK;
+	return pipe.end();
 }
 
 int sk_count_get(sk_ctx *c, uint32_t *region_frags)
@@ -1040,6 +1086,7 @@ int sk_gc_set_genome(sk_ctx *c, const uint8_t *genome, int64_t genome_len)
 	hipError_t e = hipMalloc((void **)&c->d_genome, (size_t)genome_len + 32);
 	if (e != hipSuccess) { c->d_genome = nullptr; return fail(c, SK_ERR_NOMEM, "genome of %lld bytes: %s", (long long)genome_len, hipGetErrorString(e)); }
 	if (genome_len) SK_HIP(c, hipMemcpy(c->d_genome, genome, (size_t)genome_len, hipMemcpyHostToDevice));
+	SK_HIP(c, hipDeviceSynchronize());     // the ctx streams are non-blocking: make the upload visible to them (as sk_set_barcodes does)
 	c->genome_len = genome_len;
 	return SK_OK;
 }
@@ -1116,24 +1163,25 @@ int sk_bam_sequence(sk_ctx *c, const uint8_t *seq4, int seq4_stride, const uint8
 	if (n == 0) return SK_OK;
 	if (int r = bind(c)) return r;
 	const size_t per_row = (size_t)seq4_stride + 2 * (size_t)stride + 4;
-	int64_t chunk = (int64_t)((128u << 20) / per_row);
+	int64_t chunk = (int64_t)(kPipeChunkBytes / per_row);
 	if (chunk < 1) chunk = 1;
 	if (chunk > n) chunk = n;
 	const size_t b_seq = up256((size_t)chunk * seq4_stride), b_q = up256((size_t)chunk * stride), b_col = up256((size_t)chunk * 2);
-	if (int r = ensure_ws(c, b_seq + 2 * b_q + 2 * b_col)) return r;
-	uint8_t *dseq = c->ws, *dq = dseq + b_seq, *dout = dq + b_q;
-	uint16_t *dlen = (uint16_t *)(dout + b_q), *dflag = (uint16_t *)(dout + b_q + b_col);
-	for (int64_t o = 0; o < n; o += chunk) {
+	ChunkPipe pipe(c);
+	if (int r = pipe.begin(b_seq + 2 * b_q + 2 * b_col)) return r;
+	for (int64_t o = 0; o < n; o += chunk, pipe.next()) {
 		const int64_t nr = (n - o) < chunk ? (n - o) : chunk;
-		SK_HIP(c, hipMemcpyAsync(dseq, seq4 + o * (int64_t)seq4_stride, (size_t)nr * seq4_stride, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dq, qual + o * (int64_t)stride, (size_t)nr * stride, hipMemcpyHostToDevice, c->stream));
-		if (len) SK_HIP(c, hipMemcpyAsync(dlen, len + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, c->stream));
-		SK_HIP(c, sk::launch_bam_sequence(dseq, seq4_stride, dq, stride, len ? dlen : nullptr, dflag, nr, min_baseq, dout, c->n_cu, c->stream));
-		SK_HIP(c, hipMemcpyAsync(out + o * (int64_t)stride, dout, (size_t)nr * stride, hipMemcpyDeviceToHost, c->stream));
-		SK_HIP(c, hipStreamSynchronize(c->stream));
+		hipStream_t st = pipe.st();
+		uint8_t *dseq = pipe.ws(), *dq = dseq + b_seq, *dout = dq + b_q;
+		uint16_t *dlen = (uint16_t *)(dout + b_q), *dflag = (uint16_t *)(dout + b_q + b_col);
+		SK_HIP(c, hipMemcpyAsync(dseq, seq4 + o * (int64_t)seq4_stride, (size_t)nr * seq4_stride, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dq, qual + o * (int64_t)stride, (size_t)nr * stride, hipMemcpyHostToDevice, st));
+		if (len) SK_HIP(c, hipMemcpyAsync(dlen, len + o, (size_t)nr * 2, hipMemcpyHostToDevice, st));
+		SK_HIP(c, hipMemcpyAsync(dflag, flag + o, (size_t)nr * 2, hipMemcpyHostToDevice, st));
+		SK_HIP(c, sk::launch_bam_sequence(dseq, seq4_stride, dq, stride, len ? dlen : nullptr, dflag, nr, min_baseq, dout, c->n_cu, st));
+		SK_HIP(c, hipMemcpyAsync(out + o * (int64_t)stride, dout, (size_t)nr * stride, hipMemcpyDeviceToHost, st));
 	}
-	return SK_OK;
+	return pipe.end();
 }
 
 // ---- f3: barcode census ----------------------------------------------------------------------------------------

@@ -768,10 +768,15 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 	const int seg = kTileRows * stride;
 	const int nchunkp = (((seg + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;
 	const int voff = lane * 16;
+	const int lim = seg - voff;                  // chunk offsets below this are inside the lane's part of a segment
 	const int64_t tstep = (int64_t)gridDim.x * nwave;
 	auto seg_off = [](int o) { return o >= 0 ? o : kNoSeg; };
+	// A segment's last chunk runs past the segment (64*stride is rarely a multiple of 1 KiB): those lanes must not
+	// touch memory — inside the block they would fetch the NEXT segment's bytes a second time (+7 % read traffic at
+	// 150 bp) — so their offset is sent out of range, where the hardware answers with zeros and no request.
+	auto at = [&](int base, int coff) { return coff < lim ? base + coff : kNoSeg; };
 
-	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	int64_t t = (int64_t)blockIdx.x * nwave + wave;             // tiles are dealt round-robin to the resident waves
 	// descriptor of a tile's input block; past the last tile: zero records (the prefetch of the item after the last)
 	auto in_block = [&](int64_t tt) { return make_rsrc(tt < ntiles ? a.in : nullptr, tt * (int64_t)a.in_block, a.in_block); };
 	rsrc_t rin = in_block(t);
@@ -779,15 +784,16 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 	u32x4 qv[SLOTS], sv[SLOTS];
 #pragma unroll
 	for (int i = 0; i < SLOTS; i++) {
-		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + i * 1024, 0, kAuxStream);
-		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + i * 1024, 0, kAuxStream);
+		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vq, i * 1024), 0, kAuxStream);
+		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vs, i * 1024), 0, kAuxStream);
 	}
+	const int bc_lim = kTileRows * a.bc_stride - voff;
 
 	for (; t < ntiles; t += tstep) {
 		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
 		if (DEMUX) {
-			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rin, voff + a.in_bc, 0, 0);
-			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rin, voff + a.in_bc + 1024, 0, 0);
+			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rin, 0 < bc_lim ? voff + a.in_bc : kNoSeg, 0, 0);
+			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rin, 1024 < bc_lim ? voff + a.in_bc + 1024 : kNoSeg, 0, 0);
 		}
 		const rsrc_t rout = make_rsrc(a.out, t * (int64_t)a.out_block, a.out_block);
 
@@ -809,8 +815,8 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 					mask_dword4<MODE>(qv[i], sv[i], cl2, o, w);
 					__builtin_amdgcn_raw_buffer_store_b128(o, ro, voff + off, 0, kAuxStreamSt);
 					*reinterpret_cast<u32x4 *>(tile + voff + off) = w;
-					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + off + SLOTS * 1024, 0, kAuxStream);
-					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + off + SLOTS * 1024, 0, kAuxStream);
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vq, off + SLOTS * 1024), 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vs, off + SLOTS * 1024), 0, kAuxStream);
 				}
 			}
 			// the item's last chunks; their slots already fetch the NEXT item — the other mate of this tile, or the
@@ -827,8 +833,8 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 					mask_dword4<MODE>(qv[i], sv[i], cl2, o, w);
 					__builtin_amdgcn_raw_buffer_store_b128(o, ro, voff + off, 0, kAuxStreamSt);
 					*reinterpret_cast<u32x4 *>(tile + voff + off) = w;
-					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vq + i * 1024, 0, kAuxStream);
-					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, vs + i * 1024, 0, kAuxStream);
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vq, i * 1024), 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, at(vs, i * 1024), 0, kAuxStream);
 				}
 			}
 
@@ -1324,15 +1330,16 @@ hipError_t launch_tile_blocked(const BlockedArgs &a, int n_cu, hipStream_t st)
 	if (a.n <= 0) return hipSuccess;
 	if (!blocked_shape_ok(a)) return hipErrorInvalidValue;
 	const bool demux = a.in_bc >= 0;
+	// chunks in flight per stream: 2 / 3 / 4 measure the same on the two-mate pass (10.56-10.64 ms), 5 is slower
 	const int slots = a.n_mates == 1 ? SK_SLOTS1 : kSlots;
+	const void *fn;
+	if (a.n_mates == 1) fn = demux ? tile_blocked_fn<true, SK_SLOTS1>(a.qc.mode) : tile_blocked_fn<false, SK_SLOTS1>(a.qc.mode);
+	else fn = demux ? tile_blocked_fn<true, kSlots>(a.qc.mode) : tile_blocked_fn<false, kSlots>(a.qc.mode);
 	const int nchunkp = (((kTileRows * a.stride + 1023) >> 10) + slots - 1) / slots * slots;
 	int image = nchunkp * 1024;                                       // the LDS image takes whole chunks, trim or not
 	if (demux && image < 2048) image = 2048;
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int max_wg = a.n_mates == 1 ? 3 : (ntiles < (int64_t)n_cu * 4 * 2 * 16 ? 3 : 2);   // as launch_tile_pass
-	const void *fn;
-	if (a.n_mates == 1) fn = demux ? tile_blocked_fn<true, SK_SLOTS1>(a.qc.mode) : tile_blocked_fn<false, SK_SLOTS1>(a.qc.mode);
-	else fn = demux ? tile_blocked_fn<true, kSlots>(a.qc.mode) : tile_blocked_fn<false, kSlots>(a.qc.mode);
 	LaunchShape sh;
 	hipError_t e = plan_shape(fn, a.table, a.n, image, demux, 4, n_cu, 1, max_wg, sh);
 	if (e != hipSuccess) return e;

@@ -154,6 +154,31 @@ def test_demultiplex_header_mode(bins, tmp_path, monkeypatch, paired, dual, bloc
     assert len(outs) == 24 * (2 if paired else 1) and sum(len(v) for v in outs.values()) > 0
 
 
+@pytest.mark.parametrize("gpus,per", [("0,0", "1"), ("0,0,0", "2"), ("0", "1")])
+def test_demultiplex_multi_device_mode(bins, tmp_path, monkeypatch, gpus, per):
+    """SEQKIT_GPUS spreads the blocks over several contexts (here: the same device listed several times — the GPU box has one),
+    each with its own streams and counters; blocks are handed on in input order and the counters are summed with
+    sk_counts_allreduce.  Same files, same stderr and stdout as the single-context run and as the oracle."""
+    monkeypatch.setenv("SEQKIT_BLOCK_RECORDS", "61")
+    monkeypatch.setenv("SEQKIT_THREADS", "6")
+    sheet, files, table, bc = demux_inputs(tmp_path, 5000, True, True, seed=11)
+    single = tmp_path / "single"
+    single.mkdir()
+    ref = cu.run(bins["fasta"][0], ["demultiplex", "--trim-by-quality=20", "--mask-by-quality=20", sheet] + files, cwd=single,
+                 env={"SEQKIT_GPUS": "0", "SEQKIT_CTXS_PER_GPU": "1"})
+    monkeypatch.setenv("SEQKIT_GPUS", gpus)
+    monkeypatch.setenv("SEQKIT_CTXS_PER_GPU", per)
+    multi = tmp_path / "multi"
+    multi.mkdir()
+    got = cu.run(bins["fasta"][0], ["demultiplex", "--trim-by-quality=20", "--mask-by-quality=20", sheet] + files, cwd=multi)
+    assert got[0] == 0 and got == ref
+    assert cu.gunzip_dir(multi) == cu.gunzip_dir(single)
+    a, b, da, _ = both(bins, "fasta", ["demultiplex", sheet] + files, tmp_path)            # and against the oracle, plain demultiplex
+    assert a[0] == 0
+    a, b, _, _ = both(bins, "fasta", ["demultiplex", "--dry-run=3000", sheet] + files, tmp_path)
+    assert a[0] == 0
+
+
 def test_demultiplex_umi_and_ambiguity_warnings(bins, tmp_path):
     sheet, files, table, bc = demux_inputs(tmp_path, 2000, True, False, seed=5, umi=True)
     # two samples one substitution apart from a third barcode -> equally good matches -> WARNING lines on stderr
