@@ -223,6 +223,7 @@ def secondary_rates(torch, ctx, dev):
     out = []
 
     def timeit(name, fn, units, bpu, iters=10, rounds=3):
+        torch.cuda.synchronize()                 # the inputs were made on torch's stream; fn runs on the ctx stream
         for _ in range(2):
             fn()
         ctx.sync()

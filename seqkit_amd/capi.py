@@ -181,6 +181,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_timer_start": (i32, [vp]), "sk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in protos.items():
+        if path != library_path() and not hasattr(lib, name):
+            continue                                    # an older build of the C-ABI loaded for A/B timing: what it has is enough
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

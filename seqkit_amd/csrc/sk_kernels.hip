@@ -29,6 +29,16 @@
 
 namespace sk {
 
+#ifndef SK_STRAGGLER_FROM
+#define SK_STRAGGLER_FROM 4
+#endif
+#ifndef SK_STRAGGLER_ROWS
+#define SK_STRAGGLER_ROWS 8
+#endif
+#ifndef SK_STRAGGLER_LEFT
+#define SK_STRAGGLER_LEFT 6
+#endif
+
 typedef uint32_t u32;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -229,59 +239,160 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 // chain and most of the scalar bookkeeping out of the loop (33 -> 21 VALU and 25 -> 11 SALU per dword step), and
 // the next dword's LDS read is issued before the current one is used.
 constexpr int kBreakKey = 51 << kKeyBits;
+constexpr int kStragglerFrom = SK_STRAGGLER_FROM;   // 8-byte steps before the hand-over is considered
+constexpr int kStragglerLeft = SK_STRAGGLER_LEFT;   // ... and at least this many steps of the longest row are left
+constexpr int kStragglerRows = SK_STRAGGLER_ROWS;   // hand over when at most this many rows are still being scanned
+
+// ---- scan / reduce inside groups of 8 lanes, on DPP (gfx9 control row_shr:n = 0x110+n; a row is 16 lanes = 2 groups) ----
+// `u` is the lane's index in its group; a lane whose source would lie outside the group takes `idle` instead.
+__device__ __forceinline__ int group8_inclusive_sum(int x, int u)
+{
+	int t;
+	t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); x += u >= 1 ? t : 0;
+	t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); x += u >= 2 ? t : 0;
+	t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); x += u >= 4 ? t : 0;
+	return x;
+}
+__device__ __forceinline__ int group8_min(int x)       // every lane of the group ends with the group's minimum (xor butterfly: 1, 2, mirror)
+{
+	x = min(x, __builtin_amdgcn_update_dpp(x, x, 0xb1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+	x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x4e, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+	x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror: the other quad of the group
+	return x;
+}
+
+// Stragglers.  The lane-per-row loop below costs the same whether 64 rows are still being scanned or one, and one read
+// of a tile that never breaks (a read of '#', say — every run has some) keeps the whole wave in it for all ceil(L/4)
+// steps.  When at most 8 rows are left they are finished by the whole wave together: row g goes to lanes 8g..8g+7, lane
+// u of the group takes the 4 bytes u-th next in scan order (32 bytes of every row per round), the running sums come from
+// a prefix sum inside the group, the first lane of a group that sees the break (or the row's end) cuts the range, and the
+// minimum key before the cut is a minimum over the group.  ~60 VALU per round for all rows, against ~21 per dword step.
+// In: the rows of `todo` (<= 8) have consumed `j0` bytes each (whole dwords, none of them stopped); T / best are the
+// per-lane running sum and best key.  Out: best of those lanes (src/fasta_trim_by_quality.rs:33-41 for the rest of the row).
+__device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsigned long long todo, int j0, int step, int lane,
+                                                       int end, int len, u32 T, int &best)
+{
+	const int g = lane >> 3, u = lane & 7;
+	// which row does this lane's group work on: the g-th set bit of todo (groups beyond the number of rows idle)
+	int row = -1;
+	{
+		unsigned long long m = todo;
+		for (int k = 0; k < 8 && m; k++) {                        // scalar loop
+			const int r = (int)__builtin_ctzll(m);
+			m &= m - 1;
+			row = g == k ? r : row;
+		}
+	}
+	const bool have = row >= 0;
+	const int src = (have ? row : lane) << 2;                     // ds_bpermute addresses lanes in bytes
+	const int end_r = __builtin_amdgcn_ds_bpermute(src, end), len_r = __builtin_amdgcn_ds_bpermute(src, len);
+	u32 T_r = (u32)__builtin_amdgcn_ds_bpermute(src, (int)T);
+	int best_r = 0x7fffffff;
+	const u32 sh = (u32)end_r & 3u;                               // (end_r - j) & 3 for every j that is a multiple of 4
+	bool going = have;
+	for (int jr = j0; __ballot(going && jr < len_r) != 0ull; jr += 32) {
+		const int e = end_r - jr - 4 * u;                          // this lane's 4 bytes: addresses [e-4, e), scanned downwards
+		const int a = max(e & ~3, 0);                              // lanes past the row's start read the front of the image: masked below
+		const u32 hi = *reinterpret_cast<const u32 *>(tile + a), lo = *reinterpret_cast<const u32 *>(tile + a - 4);
+		const u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+		const int s0 = (int)__builtin_amdgcn_udot4(d, 0x01000000u, 0u, false), s1 = (int)__builtin_amdgcn_udot4(d, 0x01010000u, 0u, false);
+		const int s2 = (int)__builtin_amdgcn_udot4(d, 0x01010100u, 0u, false), s3 = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
+		const int incl = group8_inclusive_sum(s3, u);
+		const u32 Tb = T_r + (u32)(incl - s3);                     // sum before this lane's first byte
+		const int j1 = jr + 4 * u + 1;                             // bytes consumed after this lane's first byte
+		const int c1 = j1 * step;
+		const int K0 = (int)((Tb + (u32)s0) << kKeyBits) + c1, K1 = (int)((Tb + (u32)s1) << kKeyBits) + (c1 + step);
+		const int K2 = (int)((Tb + (u32)s2) << kKeyBits) + (c1 + 2 * step), K3 = (int)((Tb + (u32)s3) << kKeyBits) + (c1 + 3 * step);
+		// the scan stops at the first byte past the row's end or whose total is positive (:36); keys from there on do not count
+		const bool ok0 = going && j1 <= len_r && K0 < kBreakKey;
+		const bool ok1 = ok0 && j1 + 1 <= len_r && K1 < kBreakKey;
+		const bool ok2 = ok1 && j1 + 2 <= len_r && K2 < kBreakKey;
+		const bool ok3 = ok2 && j1 + 3 <= len_r && K3 < kBreakKey;
+		const u32 stops = (u32)(__ballot(!ok3) >> (8 * g)) & 0xffu;           // the lanes of this group that hold a stop
+		const int f = stops ? (int)__builtin_ctz(stops) : 8;                 // the first of them
+		int k = min(min(ok0 ? K0 : 0x7fffffff, ok1 ? K1 : 0x7fffffff), min(ok2 ? K2 : 0x7fffffff, ok3 ? K3 : 0x7fffffff));
+		k = u <= f ? k : 0x7fffffff;
+		best_r = min(best_r, k);
+		going = going && stops == 0u;
+		T_r += (u32)__builtin_amdgcn_ds_bpermute((lane | 7) << 2, incl);      // the group's total of this round
+	}
+	best_r = group8_min(best_r);                                                // row g's minimum over all rounds, in every lane of group g
+	{
+		unsigned long long m = todo;
+		for (int k = 0; m; k++) {
+			const int r = (int)__builtin_ctzll(m);
+			m &= m - 1;
+			const int v = __builtin_amdgcn_readlane(best_r, 8 * k);
+			best = lane == r ? min(best, v) : best;
+		}
+	}
+}
 
 template <bool UNIFORM_LEN>
 __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
+	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
+	// minimum and one maximum, and the step's bookkeeping (who is alive, who stops, is anybody left) is paid once per
+	// eight bytes — it is about as many instructions as the arithmetic of four bytes.
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
 	int a = end & ~3;
 	u32 hi = *reinterpret_cast<const u32 *>(tile + a);
-	a = max(a - 4, -4);                                       // rows shorter than the scan stay inside the front pad
-	u32 lo = *reinterpret_cast<const u32 *>(tile + a);
 	u32 T = 0;
 	int best = 0;
 	bool alive = active;
-	int stop_jj = -1;                                         // the dword this lane stopped in (-1: none yet)
-	u32 stop_T = 0, stop_d = 0;                               // running sum before that dword, and the dword itself
-	const int ndw = (maxlen + 3) >> 2;
+	int stop_jj = -1;                                         // the 8-byte step this lane stopped in (-1: none yet)
+	u32 stop_T = 0, stop_d1 = 0, stop_d0 = 0;                 // running sum before that step, and its two dwords
+	const int nst = (maxlen + 7) >> 3;
 	const int step = 1 - m * (1 << kKeyBits);                 // C_j = j - j*m*2^11 = j * step
-	for (int jj = 0; jj < ndw; jj++) {
-		const u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh); // bytes [end-4(jj+1), end-4jj) of the image
-		hi = lo;
-		a = max(a - 4, -4);
-		lo = *reinterpret_cast<const u32 *>(tile + a);        // next step's dword, in flight during this one
+	unsigned long long strag = 0ull;                          // rows handed to trim_finish_stragglers, and the bytes they have consumed
+	int strag_j0 = 0;
+	for (int jj = 0; jj < nst; jj++) {
+		a = max(a - 8, -8);                                   // rows shorter than the scan stay inside the front pad
+		const u32 lo1 = *reinterpret_cast<const u32 *>(tile + a + 4), lo0 = *reinterpret_cast<const u32 *>(tile + a);
+		const u32 d1 = __builtin_amdgcn_alignbyte(hi, lo1, sh);   // bytes [end-8jj-4, end-8jj) of the image: scanned first
+		const u32 d0 = __builtin_amdgcn_alignbyte(lo1, lo0, sh);  // bytes [end-8jj-8, end-8jj-4)
+		hi = lo0;
 		const u32 T0 = T;
-		u32 Ts[4];
-		Ts[0] = __builtin_amdgcn_udot4(d, 0x01000000u, T, false);
-		Ts[1] = __builtin_amdgcn_udot4(d, 0x01010000u, T, false);
-		Ts[2] = __builtin_amdgcn_udot4(d, 0x01010100u, T, false);
-		Ts[3] = __builtin_amdgcn_udot4(d, 0x01010101u, T, false);
-		T = Ts[3];
-		const int c0 = (4 * jj + 1) * step;                   // scalar
-		const int K0 = (int)(Ts[0] << kKeyBits) + c0;
-		const int K1 = (int)(Ts[1] << kKeyBits) + (c0 + step);
-		const int K2 = (int)(Ts[2] << kKeyBits) + (c0 + 2 * step);
-		const int K3 = (int)(Ts[3] << kKeyBits) + (c0 + 3 * step);
-		const int kmin = min(min(K0, K1), min(K2, K3));
-		const int kmax = max(max(K0, K1), max(K2, K3));
-		bool whole = kmax < kBreakKey;                        // no byte of this dword breaks
-		if (UNIFORM_LEN) whole = whole && (4 * jj + 4 <= maxlen);     // scalar: false only in the row's last, partial dword
-		else whole = whole && (4 * jj + 4 <= len);
+		u32 Ts[8];
+		Ts[0] = __builtin_amdgcn_udot4(d1, 0x01000000u, T, false);
+		Ts[1] = __builtin_amdgcn_udot4(d1, 0x01010000u, T, false);
+		Ts[2] = __builtin_amdgcn_udot4(d1, 0x01010100u, T, false);
+		Ts[3] = __builtin_amdgcn_udot4(d1, 0x01010101u, T, false);
+		Ts[4] = __builtin_amdgcn_udot4(d0, 0x01000000u, Ts[3], false);
+		Ts[5] = __builtin_amdgcn_udot4(d0, 0x01010000u, Ts[3], false);
+		Ts[6] = __builtin_amdgcn_udot4(d0, 0x01010100u, Ts[3], false);
+		Ts[7] = __builtin_amdgcn_udot4(d0, 0x01010101u, Ts[3], false);
+		T = Ts[7];
+		const int c0 = (8 * jj + 1) * step;                   // scalar
+		int K[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) K[i] = (int)(Ts[i] << kKeyBits) + (c0 + i * step);
+		const int kmin = min(min(min(K[0], K[1]), min(K[2], K[3])), min(min(K[4], K[5]), min(K[6], K[7])));
+		const int kmax = max(max(max(K[0], K[1]), max(K[2], K[3])), max(max(K[4], K[5]), max(K[6], K[7])));
+		bool whole = kmax < kBreakKey;                        // no byte of this step breaks
+		if (UNIFORM_LEN) whole = whole && (8 * jj + 8 <= maxlen);     // scalar: false only in the row's last, partial step
+		else whole = whole && (8 * jj + 8 <= len);
 		const bool stops = alive && !whole;
 		stop_jj = stops ? jj : stop_jj;
 		stop_T = stops ? T0 : stop_T;
-		stop_d = stops ? d : stop_d;
+		stop_d1 = stops ? d1 : stop_d1;
+		stop_d0 = stops ? d0 : stop_d0;
 		alive = alive && whole;
 		best = alive ? min(best, kmin) : best;
-		if (__ballot(alive) == 0ull) break;
+		const unsigned long long left = __ballot(alive);
+		if (left == 0ull) break;
+		// few rows left and they are past where reads usually break: leave the loop, the whole wave finishes each of them
+		// (and only while enough of the row is left for the hand-over to pay: it costs about as much as a few steps)
+		if (jj >= kStragglerFrom && jj + kStragglerLeft < nst && __popcll(left) <= kStragglerRows) { strag = left; strag_j0 = 8 * (jj + 1); break; }
 	}
-	if (stop_jj >= 0) {                                       // replay the stop dword: src/fasta_trim_by_quality.rs:33-41 byte by byte
+	if (strag) trim_finish_stragglers(tile, strag, strag_j0, step, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
+	if (stop_jj >= 0) {                                       // replay the stop step: src/fasta_trim_by_quality.rs:33-41 byte by byte
 		u32 t = stop_T;
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int j = 4 * stop_jj + i + 1;
-			t += (stop_d >> (8 * (3 - i))) & 0xFFu;
+		for (int i = 0; i < 8; i++) {
+			const int j = 8 * stop_jj + i + 1;
+			t += ((i < 4 ? stop_d1 : stop_d0) >> (8 * (3 - (i & 3)))) & 0xFFu;
 			const int K = (int)(t << kKeyBits) + j * step;
 			if (j > len || K >= kBreakKey) break;
 			best = min(best, K);
@@ -581,6 +692,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int
 template <int MODE, bool DEMUX, int SLOTS>
 __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const TileArgs a, const LdsPlan lp)
 {
+	// SLOTS == 10 is the trim-alone pass (launch_tile_pass): one input stream, no bases, nothing stored but lowest_k — the
+	// seq registers, the mask arithmetic and the (dropped) stores are left out of it at compile time
+	constexpr bool kTrimOnly = SLOTS == 10;
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction: make it an SGPR
 	const int nwave = blockDim.x >> 6;
@@ -637,11 +751,11 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 	}
 	rsrc_t rq, rs;
 	in_rsrc(t, 0, rq, rs);
-	u32x4 qv[SLOTS], sv[SLOTS];
+	u32x4 qv[SLOTS], sv[kTrimOnly ? 1 : SLOTS];
 #pragma unroll
 	for (int i = 0; i < SLOTS; i++) {
 		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + i * 1024, 0, kAuxStream);
-		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
+		if (!kTrimOnly) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
 	}
 
 	for (; t < t_end; t += t_step) {
@@ -682,11 +796,16 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 				for (int i = 0; i < SLOTS; i++) {
 					const int off = (c + i) * 1024 + voff;
 					u32x4 o, vq;
-					mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
-					__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
+					if (kTrimOnly) {
+#pragma unroll
+						for (int w = 0; w < 4; w++) vq[w] = sub33(qv[i][w], (qv[i][w] & kLo7) + 0x5f5f5f5fu);
+					} else {
+						mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
+						__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
+					}
 					if (do_trim && off < nb) *reinterpret_cast<u32x4 *>(tile + off) = vq;
 					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
-					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
+					if (!kTrimOnly) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
 				}
 			}
 			rq = nq; rs = ns;
