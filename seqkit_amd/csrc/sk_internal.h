@@ -44,7 +44,26 @@ struct BarcodeDev {
 	const uint8_t *bs;
 	int bs_bytes, bs_mm_off, G;
 	int S, L, W, max_diff;
+	// neighbourhood table (sk_kernels.hip: demux_hash_kernel), or nullptr: every canonical barcode within max_diff (<= 1)
+	// of some sheet row, keyed by its bytes, with the decision (sample index or kAssignAmbiguous) as the value
+	const uint32_t *hk;        // two cuckoo tables of hk_mask+1 slots each, one after the other; a slot = hk_slot_dw dwords:
+	                           // hk_W key dwords, then the value (kHashEmpty = free slot)
+	int hk_W, hk_slot_dw, hk_mask;     // key dwords, slot pitch, slots per table - 1
+	int hk_sh, hk_fold;        // byte -> table index: ((b ^ (hk_fold ? b >> 4 : 0)) >> hk_sh) & 7
+	uint32_t hk_tab_lo, hk_tab_hi;     // the 8 sheet letters by that index (v_perm table)
+	uint32_t hk_seed;
+	uint32_t hk_keep[8];       // per key dword: 0xFF in the bytes of columns that count (inside L, not a wildcard column)
 };
+constexpr uint32_t kHashEmpty = 0x80000000u;
+constexpr int kMaxHashLen = 32;
+// The one hash both sides use (host builds the table, the kernel probes it): Jenkins one-at-a-time over the key dwords.
+__host__ __device__ inline uint32_t demux_key_hash(const uint32_t *key, int W, uint32_t seed)
+{
+	uint32_t h = seed;
+	for (int w = 0; w < W; w++) { h += key[w]; h += h << 10; h ^= h >> 6; }
+	h += h << 3; h ^= h >> 11; h += h << 15;
+	return h;
+}
 
 constexpr int kMaxBitSlicedLen = 31;     // 5 counter planes
 constexpr int kMaxBitSlicedBytes = 24 * 1024;

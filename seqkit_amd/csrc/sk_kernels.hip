@@ -1317,6 +1317,159 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// D1+D2+D3 by table lookup: demultiplex alone, when only the decision is asked for.
+// With max_diff <= 1 the barcodes that get a sample (or the ambiguity verdict) are few: every sheet row and its
+// one-substitution neighbours over the sheet's own alphabet plus "any other byte" — 96 x (17 x 5 + 1) = 8 256 keys
+// for the 96 dual-index sheet.  sk_set_barcodes enumerates them, decides each with the reference's loop
+// (src/fasta_demultiplex.rs:154-194) and puts key -> decision into an open-addressing table; a read is then ONE
+// lookup instead of S x L compares: its bytes are made canonical (a byte the sheet never uses, and every column that
+// is a wildcard in all rows, becomes 0), hashed, and probed; not found = no sample within max_diff = SK_ASSIGN_NONE.
+// Canonical bytes without a 256-entry table: the host finds a 3-bit function of a byte that separates the sheet's
+// letters ((b [^ b>>4]) >> sh) & 7; v_perm looks the letter with that index up for four bytes at once, and a byte
+// is kept iff it equals its letter.  The table is two cuckoo tables (a key sits in one of two slots: two loads, never a
+// loop), <= 4 MiB, read through L2.  Sheets this cannot serve (max_diff > 1,
+// wildcards in some rows only, more than 7 letters, detail outputs wanted) take demux_tile_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int W, bool DIRECT, bool BOTH>
+__global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int nwave = blockDim.x >> 6;
+	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
+	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
+	if (lp.use_lds_hist) for (int i = threadIdx.x; i < a.table.S + 3; i += blockDim.x) hist[i] = 0u;
+	__syncthreads();
+	WaveCounts wc = {0u, 0u, 0u};
+	const BarcodeDev &tb = a.table;
+	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int bstride = a.bc_stride;
+	const int voff = lane * 16;
+	const int64_t tstep = (int64_t)gridDim.x * nwave;
+	auto tile_rsrc = [&](int64_t t) {
+		const bool ok = t < ntiles;
+		const int64_t row0 = ok ? t * kTileRows : 0;
+		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
+		return make_rsrc(a.bc, row0 * (int64_t)bstride, (rows * bstride + 3) & ~3);
+	};
+	// the observed bytes of the lane's row as W dwords.  DIRECT (rows start on dword boundaries): straight from memory,
+	// lane r reads row r — for 8-byte rows that is one fully coalesced 8 B/lane load; otherwise the tile goes through the
+	// wave's LDS image with 16 B/lane loads and rows are read back at any alignment.  Either way the NEXT tile's loads are
+	// in flight while this one is looked up.
+	// (a big table must stay in L2: the read-once barcode stream is then loaded nontemporal — 68 -> 98 G pairs/s for the
+	// 1 MiB table of the 96 dual-index sheet; with a small table plain loads are faster, 246 against 221 G reads/s)
+	constexpr int kAux = BOTH ? 0 : kAuxStream;
+	u32 raw[W];
+	u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
+	auto fetch = [&](int64_t t) {
+		const rsrc_t rb = tile_rsrc(t);
+		if (DIRECT) {
+#pragma unroll
+			for (int w = 0; w < W; w++) raw[w] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride + 4 * w, 0, kAux);
+		} else {
+			v0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAux);
+			v1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
+		}
+	};
+	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	fetch(t);
+	for (; t < ntiles; t += tstep) {
+		const int64_t row0 = t * kTileRows;
+		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
+		const bool active = lane < rows;
+		u32 d[W];
+		if (DIRECT) {
+#pragma unroll
+			for (int w = 0; w < W; w++) d[w] = raw[w];
+			fetch(t + tstep);
+		} else {
+			*reinterpret_cast<u32x4 *>(tile + voff) = v0;
+			*reinterpret_cast<u32x4 *>(tile + 1024 + voff) = v1;
+			fetch(t + tstep);
+			wave_lds_fence();
+			const int rs = lane * bstride;
+			const u32 sh = (u32)rs & 3u;
+			const u32 *x = reinterpret_cast<const u32 *>(tile + (rs & ~3));
+			u32 lo = x[0];
+#pragma unroll
+			for (int w = 0; w < W; w++) {
+				const u32 hi = x[w + 1];
+				d[w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+				lo = hi;
+			}
+		}
+		// canonical key: a byte stays iff it is the sheet letter with its index; everything else, and the columns that do not count, become 0
+		u32 key[W];
+		u32 h = tb.hk_seed;
+#pragma unroll
+		for (int w = 0; w < W; w++) {
+			const u32 f = tb.hk_fold ? d[w] ^ ((d[w] >> 4) & 0x0f0f0f0fu) : d[w];
+			const u32 sel = (f >> tb.hk_sh) & 0x07070707u;
+			const u32 letter = __builtin_amdgcn_perm(tb.hk_tab_hi, tb.hk_tab_lo, sel);
+			const u32 df = d[w] ^ letter;                           // zero byte <=> the observed byte is a sheet letter
+			const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;     // 0x80 in every byte that differs
+			const u32 drop = (nz << 1) - (nz >> 7);                 // 0xFF in every byte that differs
+			key[w] = d[w] & ~drop & tb.hk_keep[w];
+			h += key[w]; h += h << 10; h ^= h >> 6;                 // demux_key_hash
+		}
+		h += h << 3; h ^= h >> 11; h += h << 15;
+		// Two slots, at most two loads, no loop (cuckoo).  The builder tries the first table first and moves a key to the
+		// second only when its first slot is taken, so: first slot holds the key -> done; first slot free -> the key is in
+		// neither; first slot holds another key -> look at the second slot (a minority of the lanes: less table traffic).
+		int code = kAssignNone;
+		auto probe = [&](u32 slot, bool &occupied) {
+			const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;
+			u32 sv[W + 1];
+			if (W < 4) {
+				const u32x4 q = *reinterpret_cast<const u32x4 *>(sp);
+#pragma unroll
+				for (int w = 0; w <= W; w++) sv[w] = q[w];
+			} else {
+				const u32x4 q0 = *reinterpret_cast<const u32x4 *>(sp), q1 = *reinterpret_cast<const u32x4 *>(sp + 4);
+#pragma unroll
+				for (int w = 0; w <= W && w < 8; w++) sv[w] = w < 4 ? q0[w] : q1[w - 4];
+				if (W == 8) sv[8] = sp[8];
+			}
+			occupied = sv[W] != kHashEmpty;
+			bool same = occupied;
+#pragma unroll
+			for (int w = 0; w < W; w++) same = same && sv[w] == key[w];
+			code = same ? (int)sv[W] : code;
+			return same;
+		};
+		// (BOTH — small tables that stay in the vector cache: both loads at once, no dependent second trip)
+		bool occ1 = false, occ2 = false;
+		const bool hit1 = probe(h & (u32)tb.hk_mask, occ1);
+		if (BOTH || (occ1 && !hit1)) probe((u32)tb.hk_mask + 1u + ((h >> 16) & (u32)tb.hk_mask), occ2);
+		__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
+		if (active && code >= 0) {
+			if (lp.use_lds_hist) atomicAdd(&hist[code], 1u);
+			else atomicAdd(&a.counts[code], 1ull);
+		}
+		wc.total += (u32)__popcll(__ballot(active));
+		wc.ident += (u32)__popcll(__ballot(active && code >= 0));
+		wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+		if (!DIRECT) wave_lds_fence();
+	}
+	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
+}
+
+template <bool DIRECT, bool BOTH>
+static const void *demux_hash_fn_w(int W)
+{
+	switch (W) {
+	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH>);
+	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH>);
+	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH>);
+	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH>);
+	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH>);
+	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH>);
+	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH>);
+	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH>);
+	}
+}
+
 // rows too long for an LDS tile: one thread per row straight from global memory (correct, not fast)
 __global__ __launch_bounds__(256) void trim_rows_global_kernel(const uint8_t *__restrict__ qual, const uint16_t *__restrict__ len,
                                                                int stride, int64_t n, int m, uint16_t *__restrict__ lowest_k)
@@ -1521,7 +1674,34 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	static const bool env_no_fuse = getenv("SK_NO_FUSED_DEMUX") != nullptr;
 	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 && !env_no_fuse;
 	if (b.bc && !fuse_demux) {
-		hipError_t e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
+		// only the decision is wanted and the sheet has a neighbourhood table: one lookup per read
+		static const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
+		const bool by_table = b.table.hk && !b.lowest_diff && !b.first_idx && !b.last_idx && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
+		hipError_t e;
+		if (by_table) {
+			LaunchShape sh;
+			// rows on dword boundaries that hold all key dwords: read straight from memory (lane r = row r)
+			const bool direct = (b.bc_stride & 3) == 0 && 4 * b.table.hk_W <= b.bc_stride;
+			// both cuckoo slots at once while the two tables are small enough to stay in the CU's vector cache (cfg 3: 32 KiB;
+			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
+			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
+			const void *fn = direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))
+			                        : (both ? demux_hash_fn_w<false, true>(b.table.hk_W) : demux_hash_fn_w<false, false>(b.table.hk_W));
+			e = plan_shape(fn, b.table, b.n, 2048, false, 4, n_cu, 1, 0, sh);
+			if (e == hipSuccess) {
+				// the histogram sits where the matcher tables would: plan_shape(with_tables = false) leaves no room for it
+				sh.lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
+				sh.lp.hist_off = 0;
+				const int hist_bytes = sh.lp.use_lds_hist ? ((b.table.S + 3) * 4 + 15) & ~15 : 0;
+				sh.lp.tiles_off += hist_bytes;
+				sh.lds += hist_bytes;
+				TileArgs bb = b;
+				void *kargs[] = {(void *)&bb, (void *)&sh.lp};
+				e = hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
+			}
+		} else {
+			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
+		}
 		if (e != hipSuccess) return e;
 	}
 	if (!any_mate) return hipSuccess;

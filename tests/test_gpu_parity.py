@@ -253,6 +253,66 @@ def test_counters_accumulate_and_reset(ctx, oracle):
     assert ctx.counts().sum() == 0
 
 
+# ---- demultiplex alone, decision only: the neighbourhood-table lookup (demux_hash_kernel) ---------------------------
+def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
+    """assign + counters without the detail columns: served by the lookup table when the sheet has one, by the matchers
+    otherwise — the same answers either way, and the same as with the detail columns."""
+    ctx.set_barcodes(table, max_diff)
+    assign, low, first, last = ctx.demux_assign(bc, want_detail=False)
+    e_assign, _, _, _, e_counts = oracle.demux_batch(table, bc, max_diff)
+    assert low is None and np.array_equal(assign, e_assign)
+    assert np.array_equal(ctx.counts(), e_counts)
+
+
+@pytest.mark.parametrize("no_table", [False, True])
+def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
+    if no_table:
+        monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    bc, _ = synth.observe_barcodes(table, 200_003, seed=3)
+    check_demux_decision_only(ctx, oracle, table, bc)
+    check_demux_decision_only(ctx, oracle, table, bc, max_diff=0)
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, 100_001, seed=4, halves=2)
+    check_demux_decision_only(ctx, oracle, table, bc)
+    padded = np.zeros((bc.shape[0], 24), dtype=np.uint8)          # bc_stride above the barcode length
+    padded[:, :17] = bc
+    padded[:, 17:] = 0x41
+    ctx.set_barcodes(table, 1)
+    assign, *_ = ctx.demux_assign(padded, want_detail=False)
+    assert np.array_equal(assign, oracle.demux_batch(table, bc, 1)[0])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_demux_decision_only(ctx, oracle, seed):
+    """Sheets with and without a lookup table: wildcard columns (all rows / some rows), duplicates, lower case next to upper
+    case, up to 7 letters and more, any length to 32 and above, max_diff 0 / 1 / 2, observed barcodes with foreign bytes."""
+    rng = np.random.default_rng(12000 + seed)
+    S = int(rng.choice([1, 2, 3, 16, 40, 96]))
+    L = int(rng.choice([1, 3, 4, 8, 9, 17, 24, 31, 32, 33]))
+    alphabet = [b"ACGT", b"ACGTN", b"ACGT+", b"ACGTacgt", b"ACGTRYKM", b"AC", b"ACGTN+U"][int(rng.integers(0, 7))]
+    table = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=(S, L)).astype(np.uint8)
+    kind = int(rng.integers(0, 4))
+    if kind == 1 and L >= 4:                     # UMI columns: a wildcard in every row
+        table[:, L - 3:] = ord("U")
+    elif kind == 2:                               # wildcards here and there (no table then)
+        table[rng.random((S, L)) < 0.1] = ord("N")
+    if S >= 3 and rng.random() < 0.3:
+        table[2] = table[0]                       # duplicate barcodes: always ambiguous
+    n = int(rng.choice([1, 64, 777, 5000]))
+    pick = table[rng.integers(0, S, size=n)].copy()
+    noise = rng.random((n, L)) < 0.07
+    pick[noise] = rng.choice(np.frombuffer(b"ACGTNacgtn+U\x00\xff#", dtype=np.uint8), size=int(noise.sum()))
+    bc = np.ascontiguousarray(pick)
+    table = np.ascontiguousarray(table)
+    md = int(rng.choice([0, 1, 1, 1, 2]))
+    check_demux_decision_only(ctx, oracle, table, bc, md)
+    ctx.set_barcodes(table, md)                   # and the detail form right after, on the same sheet
+    assign, low, first, last = ctx.demux_assign(bc)
+    e = oracle.demux_batch(table, bc, md)
+    assert np.array_equal(assign, e[0]) and np.array_equal(low, e[1]) and np.array_equal(first, e[2]) and np.array_equal(last, e[3])
+
+
 # ---- fused pass ---------------------------------------------------------------------------------------------
 @pytest.fixture(params=["phases", "interleaved", "blocked-tiles", "interleaved+blocked"])
 def pass_variant(request, monkeypatch):
