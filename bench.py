@@ -352,13 +352,35 @@ def main():
     # Ranks meet over gloo (plumbing: rendezvous, barrier, max of the elapsed times); the path's one collective —
     # the sum of the u64[S+3] counters — runs in the library's own RCCL communicator on the ctx stream.
     distributed = world > 1 or bool(os.environ.get("SK_BENCH_FORCE_DIST"))
+    rccl_err = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        box = [capi.comm_unique_id() if rank == 0 else None]
+        # RCCL inside the library; should a node refuse it (no usable interface for the bootstrap, say), every rank falls back to
+        # summing the counters through gloo with a host round trip, and the JSON line says so — a scaling run still gets numbers
+        rccl_err = None
+        try:
+            box = [capi.comm_unique_id() if rank == 0 else None]
+        except Exception as e:
+            box, rccl_err = [None], str(e)
         dist.broadcast_object_list(box, src=0)
-        ctx.comm_init_rank(box[0], rank, world)
+        if box[0] is not None:
+            try:
+                ctx.comm_init_rank(box[0], rank, world)
+            except Exception as e:
+                rccl_err = str(e)
+        else:
+            rccl_err = rccl_err or "rank 0 could not make a unique id"
+        flags = [None] * world
+        dist.all_gather_object(flags, rccl_err)
+        rccl_err = next((f for f in flags if f), None)
+        if rccl_err is not None:
+            sys.stderr.write(f"[bench] RCCL unavailable ({rccl_err}); the count reduce goes through gloo\n")
+            try:
+                ctx.comm_destroy()
+            except Exception:
+                pass
 
     n = args.pairs
     nt = (n + 63) // 64
@@ -398,7 +420,12 @@ def main():
                                    assign=assign.data_ptr(), counts=counts.data_ptr())
             if ev is not None:
                 ev[1].record(stream)
-            ctx.allreduce_u64_dev(counts.data_ptr(), S_SAMPLES + 3)     # the path's only cross-shard state (nothing to do at N=1)
+            if rccl_err is None:
+                ctx.allreduce_u64_dev(counts.data_ptr(), S_SAMPLES + 3)     # the path's only cross-shard state (nothing to do at N=1)
+            else:
+                h = counts.cpu()
+                dist.all_reduce(h)
+                counts.copy_(h)
 
     def fence():
         if distributed:
@@ -519,8 +546,9 @@ def main():
                        "clusters_per_gpu": n, "read_len": L_READ, "barcodes": S_SAMPLES, "barcode_len": L_BC,
                        "min_baseq": MIN_BASEQ, "read_unit": "cluster (as the reference's total_reads counts)",
                        "layout": args.layout,
-                       "count_reduce": (f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
-                                        if distributed else "none (1 GPU)")},
+                       "count_reduce": ("none (1 GPU)" if not distributed else
+                                        f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
+                                        if rccl_err is None else f"gloo all-reduce with a host round trip (RCCL unavailable: {rccl_err})")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kernel, "kernel_ms": round(kern_ms, 4),

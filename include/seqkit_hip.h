@@ -152,7 +152,7 @@ int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 #define SK_BLK_DETAIL 8     /* lowest_diff / first_idx / last_idx beside assign   */
 typedef struct {
 	int32_t n_mates, stride, bc_stride, flags;   /* bc_stride 0 = no barcodes (no demultiplex)                  */
-	int32_t in_block, out_block;                 /* bytes per tile of 64 clusters (multiples of 64)             */
+	int32_t in_block, out_block;                 /* bytes per tile of 64 clusters (multiples of 128)            */
 	int32_t in_qual[2], in_seq[2], in_len[2], in_bc;
 	int32_t out_seq[2], out_lowest_k[2], out_assign, out_lowest_diff, out_first_idx, out_last_idx;
 } sk_blocked_layout;

@@ -275,6 +275,23 @@ class Context:
     def free_device(self, p: int) -> None:
         self._check(self._lib.sk_free_device(self._h, p), "sk_free_device")
 
+    def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array in page-locked host memory (sk_malloc_pinned): the host entry points move such buffers by DMA.
+        The memory belongs to the ctx's process until free_pinned(array)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.sk_malloc_pinned(self._h, max(nbytes, 1), C.byref(p)), "sk_malloc_pinned")
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def free_pinned(self, arr: np.ndarray) -> None:
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self._lib.sk_free_pinned(self._h, p), "sk_free_pinned")
+
     def copy_h2d(self, dst: int, src: np.ndarray) -> None:
         self._check(self._lib.sk_copy_h2d(self._h, dst, src.ctypes.data, src.nbytes), "sk_copy_h2d")
 

@@ -860,6 +860,8 @@ int sk_blocked_layout_init(sk_blocked_layout *lay, int n_mates, int stride, int 
 		lay->out_assign = seg(out, 256);
 		if (flags & SK_BLK_DETAIL) { lay->out_lowest_diff = seg(out, 64); lay->out_first_idx = seg(out, 128); lay->out_last_idx = seg(out, 128); }
 	}
+	in = (in + 127) & ~(int64_t)127;                            // whole 128-byte lines: no line is shared by two tiles (two waves would fetch it)
+	out = (out + 127) & ~(int64_t)127;
 	if (in > 0x3fffffff || out > 0x3fffffff) return SK_ERR_INVALID;
 	lay->in_block = (int32_t)in; lay->out_block = (int32_t)out;
 	return SK_OK;

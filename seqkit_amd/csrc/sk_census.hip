@@ -100,17 +100,24 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 		if (k == 0) {
 			k = atomicCAS(&s->klo, 0ull, klo);
 			if (k == 0) {
+				// The slot is ours until its high word is published: everybody else who finds klo here waits for that
+				// (v == 0 below).  So the first count and the first row go in as plain stores, and the release store of
+				// the high word hands the slot over — ONE atomic for a new key instead of three (scattered atomics are what
+				// bounds a census of mostly distinct barcodes: about 20 G of them per second chip-wide).
+				// (the two stores are write-through at agent scope; the fence only makes this wave wait for their
+				// acknowledgement — an agent-scope release would write the whole L2 back for every key)
+				__hip_atomic_store(&s->count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&s->first_inv, first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				claimed++;
-				k = klo;
-				v = want;
-			} else {
-				v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return true;
 			}
+			v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			f = 0;
 		}
 		if (k == klo) {
-			if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }      // owner is between its CAS and its store: look again
+			if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }      // owner is between its CAS and its release store: look again
 			if (v == want) {
 				atomicAdd(&s->count, cnt);
 				if (f < first_inv) atomicMax(&s->first_inv, first_inv);
@@ -429,7 +436,7 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 	CensusSlot *old_tab = cs->tab;
 	const u64 old_slots = cs->slots;
 	hipError_t e = census_alloc_table(cs, slots, st);
-	if (e != hipSuccess) { cs->tab = old_tab; cs->slots = old_slots; return e; }
+	if (e != hipSuccess) { (void)hipGetLastError(); cs->tab = old_tab; cs->slots = old_slots; return e; }
 	census_rehash_kernel<<<n_cu * 8, 256, 0, st>>>(old_tab, old_slots, cs->tab, slots - 1, cs->stats);
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -443,23 +450,28 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (bc_stride > kCensusMaxStride) return hipErrorInvalidValue;
 	const int tile_slot = (64 * bc_stride + 15) & ~15;
 	const size_t lds = kLdsSlots * sizeof(LdsSlot) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
+	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
+	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
+	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) chunk = (int64_t)1 << lg; }
+	if (const char *ev = getenv("SK_CENSUS_MIN_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) min_chunk = (int64_t)1 << lg; }
+	if (min_chunk > chunk) min_chunk = chunk;
 	int64_t nr = 0;
 	for (int64_t o = 0; o < n; o += nr) {
 		// The launch must not be able to fill the table beyond one half even if every row is a new key.  When
 		// the bound on the key count says it could, fetch the exact count; then either take a smaller bite
 		// (at least kCensusMinChunk rows: launches have a fixed cost) or grow the table.
-		nr = (n - o) < kCensusChunk ? (n - o) : kCensusChunk;
+		nr = (n - o) < chunk ? (n - o) : chunk;
 		hipError_t e = hipSuccess;
 		if (2 * (cs->distinct + (u64)nr) > cs->slots) {
 			uint64_t s[4];
 			e = census_stats(cs, s, st);
 			if (e != hipSuccess) return e;
 			const int64_t room = (int64_t)(cs->slots / 2) - (int64_t)cs->distinct;
-			const int64_t least = nr < kCensusMinChunk ? nr : kCensusMinChunk;
-			if (room >= least) nr = nr < room ? nr : room;
-			if (nr < n - o && nr >= 64) nr &= ~(int64_t)63;       // later launches start on a tile (and dword) boundary of the matrix
-			else e = census_reserve(cs, (u64)nr, n_cu, st);
+			const int64_t least = nr < min_chunk ? nr : min_chunk;
+			if (room >= least) nr = nr < room ? nr : room;        // a smaller bite fits the table as it is
+			else e = census_reserve(cs, (u64)nr, n_cu, st);       // no room worth a launch: grow for the whole bite
 			if (e != hipSuccess) return e;
+			if (nr < n - o && nr >= 64) nr &= ~(int64_t)63;       // later launches start on a tile (and dword) boundary of the matrix
 		}
 		cs->distinct += (u64)nr;                              // upper bound until the next census_stats()
 		CensusArgs a;

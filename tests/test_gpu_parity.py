@@ -886,6 +886,30 @@ def test_census_grows_past_its_first_table(oracle, monkeypatch):
         assert int(hist.sum()) == len(uniq) and int(hist[0]) == int((counts == 1).sum())
 
 
+@pytest.mark.parametrize("chunk_log2,min_log2", [("15", "12"), ("17", "17"), ("13", "6")])
+def test_census_grows_between_the_launches_of_one_call(oracle, monkeypatch, chunk_log2, min_log2):
+    """One sk_census_add call that is many launches: with all-distinct barcodes and a small first table every launch has to
+    decide between a smaller bite and a bigger table — not only the last one.  The table never gets more than half full
+    (no row lost to a probe overflow, which census_stats would report as an error), whatever the launch sizes are."""
+    import seqkit_amd
+    monkeypatch.setenv("SK_CENSUS_SLOTS_LOG2", "14")
+    monkeypatch.setenv("SK_CENSUS_CHUNK_LOG2", chunk_log2)
+    monkeypatch.setenv("SK_CENSUS_MIN_CHUNK_LOG2", min_log2)
+    n = 600_000
+    vals = np.random.default_rng(21).permutation(4 ** 10)[:n].astype(np.int64)      # all distinct 10-mers
+    digits = (vals[:, None] >> (2 * np.arange(10))) & 3
+    bc = np.zeros((n, 12), dtype=np.uint8)
+    bc[:, :10] = np.frombuffer(b"ACGT", dtype=np.uint8)[digits]
+    with seqkit_amd.Context(0) as c2:
+        c2.census_reset()
+        c2.census_add(bc, L=10)
+        st = c2.census_stats()                                # raises if any row overflowed its probe budget
+        assert st["distinct"] == n and st["counted"] == n and st["slots"] >= 2 * n
+        c2.census_add(bc[:1000], L=10, row_base=n)            # all of them again: counts 2, first rows unchanged
+        got, total = c2.census_entries(min_count=2)
+        assert total == 1000 and [(c, f) for _, c, f in got] == [(2, i) for i in range(1000)]
+
+
 def test_errors_are_codes_not_crashes(ctx):
     import seqkit_amd
     with pytest.raises(seqkit_amd.SeqkitHipError):

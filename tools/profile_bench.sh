@@ -9,7 +9,7 @@ W=/tmp/skprof_$TAG
 rm -rf $W; mkdir -p $W $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py "$@" 2>/dev/null | tail -1 > $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-sample 0 "$@" > $W/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-extra "$@" > $W/trace.log 2>&1
 python3 $R/tools/summarize_prof.py $W/trace $OUT/rocprof
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
@@ -17,8 +17,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
   "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-include-regex "sk::" --output-format csv -d $W/pmc$i -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 "$@" > $W/pmc$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-include-regex "sk::" --output-format csv -d $W/pmc$i -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extra "$@" > $W/pmc$i.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $W/pmc* > $OUT/pmc_summary.txt 2>&1
 cat $OUT/pmc_summary.txt
+LAYOUT=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['layout'])")
+PAIRS=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['clusters_per_gpu'])")
+KERN=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['roofline']['kernel'])")
+python3 $R/tools/make_pmc_traffic.py $OUT/pmc_summary.txt $PAIRS $LAYOUT "$KERN" > $OUT/pmc_traffic.json
+cat $OUT/pmc_traffic.json
 cut -c1-400 $OUT/bench.json
