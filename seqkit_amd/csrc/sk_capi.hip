@@ -34,6 +34,8 @@ struct sk_ctx {
 	int bs_bytes = 0, bs_mm_off = 0, G = 0;
 	uint32_t *d_hk = nullptr;          // neighbourhood table of the sheet (demux_hash_kernel), when it has one
 	sk::BarcodeDev hk{};               // only the hk_* fields are used
+	std::vector<uint8_t> sheet;        // the sheet as given to sk_set_barcodes (the table is built from it on first use)
+	bool hk_tried = false;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
@@ -465,21 +467,30 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 			c->bs_bytes = (int)bytes; c->bs_mm_off = mm_off; c->G = G;
 		}
 	}
-	// neighbourhood table: every canonical barcode within max_diff (<= 1) of a sheet row -> the reference's decision for it
-	{
-		std::vector<uint32_t> slots;
-		sk::BarcodeDev hk{};
-		if (!getenv("SK_NO_HASH_DEMUX") && build_neighbour_table(table, S, L, max_diff, hk, slots)) {
-			SK_HIP(c, hipMalloc((void **)&c->d_hk, slots.size() * 4));
-			SK_HIP(c, hipMemcpy(c->d_hk, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
-			c->hk = hk;
-			c->hk.hk = c->d_hk;
-		}
-	}
+	// (the neighbourhood table of the sheet is built on the first decision-only demultiplex: ensure_neighbour_table)
+	c->sheet.assign(table, table + (size_t)S * L);
+	c->hk_tried = false;
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx stream is non-blocking: make the uploads visible to it
 	c->have_table = true;
+	return SK_OK;
+}
+
+// The neighbourhood table costs a few tens of ms of host work per sheet (enumerate, decide, place): it is built when a
+// call first asks for the decision alone — the command-line hosts, which always want the detail columns, never pay for it.
+static int ensure_neighbour_table(sk_ctx *c)
+{
+	if (c->hk_tried || !c->have_table) return SK_OK;
+	c->hk_tried = true;
+	std::vector<uint32_t> slots;
+	sk::BarcodeDev hk{};
+	if (getenv("SK_NO_HASH_DEMUX") || !build_neighbour_table(c->sheet.data(), c->S, c->L, c->max_diff, hk, slots)) return SK_OK;
+	SK_HIP(c, hipMalloc((void **)&c->d_hk, slots.size() * 4));
+	SK_HIP(c, hipMemcpy(c->d_hk, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+	SK_HIP(c, hipDeviceSynchronize());     // the ctx streams are non-blocking: make the upload visible to them
+	c->hk = hk;
+	c->hk.hk = c->d_hk;
 	return SK_OK;
 }
 
@@ -720,6 +731,8 @@ static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
 		if (a->bc_stride > sk::kMaxTileStride) return fail(c, SK_ERR_INVALID, "bc_stride = %d above %d", a->bc_stride, sk::kMaxTileStride);
 		if (!a->assign) return fail(c, SK_ERR_INVALID, "assign is NULL");
 		if (dev && !aligned16(a->bc)) return fail(c, SK_ERR_INVALID, "bc must be 16-byte aligned");
+		if (!a->lowest_diff && !a->first_idx && !a->last_idx && !any)
+			if (int r = ensure_neighbour_table(c)) return r;
 	} else if (!any) {
 		return fail(c, SK_ERR_INVALID, "nothing to do: no bc, no out_seq, no lowest_k");
 	}

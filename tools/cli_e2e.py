@@ -15,7 +15,7 @@ from seqkit_amd import build, synth  # noqa: E402
 
 orc.build()
 build.build_all()
-FASTA = os.path.join(build.BINDIR, "fasta")
+FASTA = os.environ.get("E2E_FASTA") or os.path.join(build.BINDIR, "fasta")     # E2E_FASTA: another build of the host, for A/B on one box
 n_block, reps = 100_000, int(sys.argv[1]) if len(sys.argv) > 1 else 20
 d = tempfile.mkdtemp(prefix="sk_e2e_")
 seq, qual = synth.make_reads(n_block, 150, seed=1)
