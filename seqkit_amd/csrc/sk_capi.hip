@@ -122,6 +122,13 @@ struct ChunkPipe {
 	}
 };
 static const size_t kPipeChunkBytes = 48u << 20;
+// chunk sizes of the host entry points; SK_HOST_CHUNK_LOG2 (read per call) shrinks every one of them to 2^k bytes / records,
+// so that tests walk many chunks, both lanes and both workspace halves with small inputs
+static size_t pipe_chunk(size_t dflt)
+{
+	if (const char *e = getenv("SK_HOST_CHUNK_LOG2")) { const int lg = atoi(e); if (lg >= 6 && lg <= 30) return (size_t)1 << lg; }
+	return dflt;
+}
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 // ---- the sheet's neighbourhood table (see demux_hash_kernel) ------------------------------------------------------
@@ -786,7 +793,7 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 		if (mt.lowest_k) per_row += 2;
 	}
 	if (a->bc) per_row += (size_t)a->bc_stride + 4 + 1 + 2 + 2;
-	int64_t chunk = (int64_t)(kPipeChunkBytes / (per_row ? per_row : 1));
+	int64_t chunk = (int64_t)(pipe_chunk(kPipeChunkBytes) / (per_row ? per_row : 1));
 	chunk &= ~(int64_t)63;
 	if (chunk < 64) chunk = 64;
 	if (chunk > a->n) chunk = (a->n + 63) & ~(int64_t)63;
@@ -990,7 +997,7 @@ int sk_mask_by_quality(sk_ctx *c, uint8_t *seq, const uint8_t *qual, const uint1
 	(void)len;   // pad bytes of the output are unspecified: the whole matrix is one byte stream
 	if (int r = bind(c)) return r;
 	const int64_t total = n * (int64_t)stride;
-	int64_t chunk = (int64_t)16 << 20;
+	int64_t chunk = (int64_t)pipe_chunk((size_t)16 << 20);
 	if (chunk > total) chunk = (total + 15) & ~(int64_t)15;
 	ChunkPipe pipe(c);
 	if (int r = pipe.begin((size_t)up256((size_t)chunk) * 3)) return r;
@@ -1031,7 +1038,7 @@ int sk_bam_flag_tlen(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	if (!counters && !hist) return fail(c, SK_ERR_INVALID, "nothing to do");
 	if (int r = bind(c)) return r;
 	const size_t nout = 4 + (hist ? (size_t)max_frag + 1 : 0);
-	int64_t chunk = 4 << 20;
+	int64_t chunk = (int64_t)pipe_chunk((size_t)4 << 20);
 	if (chunk > n) chunk = n;
 	const size_t cols = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4);
 	ChunkPipe pipe(c);
@@ -1088,7 +1095,7 @@ int sk_bam_fragments(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	if (n == 0) return SK_OK;
 	if (!flag || !tid || !mtid || !tlen || !keep_bits) return fail(c, SK_ERR_INVALID, "NULL column or output");
 	if (int r = bind(c)) return r;
-	int64_t chunk = 4 << 20;
+	int64_t chunk = (int64_t)pipe_chunk((size_t)4 << 20);
 	if (chunk > n) chunk = (n + 7) & ~(int64_t)7;
 	const size_t need = up256((size_t)chunk * 2) + 3 * up256((size_t)chunk * 4) + up256((size_t)chunk / 8 + 8);
 	ChunkPipe pipe(c);
@@ -1210,7 +1217,7 @@ int sk_count_add(sk_ctx *c, const uint16_t *flag, const uint8_t *mapq, const int
 	if (int r = count_args(c, a, flag, mapq, tid, mtid, pos, mpos, tlen, end_pos, n, min_mapq, max_frag_len, single_end, center)) return r;
 	if (n == 0) return SK_OK;
 	if (int r = bind(c)) return r;
-	int64_t chunk = 2 << 20;
+	int64_t chunk = (int64_t)pipe_chunk((size_t)2 << 20);
 	if (chunk > n) chunk = n;
 	const size_t b2 = up256((size_t)chunk * 2), b1 = up256((size_t)chunk), b4 = up256((size_t)chunk * 4);
 	ChunkPipe pipe(c);
@@ -1334,7 +1341,7 @@ int sk_bam_sequence(sk_ctx *c, const uint8_t *seq4, int seq4_stride, const uint8
 	if (n == 0) return SK_OK;
 	if (int r = bind(c)) return r;
 	const size_t per_row = (size_t)seq4_stride + 2 * (size_t)stride + 4;
-	int64_t chunk = (int64_t)(kPipeChunkBytes / per_row);
+	int64_t chunk = (int64_t)(pipe_chunk(kPipeChunkBytes) / per_row);
 	if (chunk < 1) chunk = 1;
 	if (chunk > n) chunk = n;
 	const size_t b_seq = up256((size_t)chunk * seq4_stride), b_q = up256((size_t)chunk * stride), b_col = up256((size_t)chunk * 2);
@@ -1402,7 +1409,7 @@ int sk_census_add(sk_ctx *c, const uint8_t *bc, int bc_stride, int L, int64_t n,
 	if (n == 0) return SK_OK;
 	if (int r = bind(c)) return r;
 	if (int r = census_ready(c)) return r;
-	int64_t chunk = (int64_t)((64u << 20) / (size_t)(bc_stride + 4));
+	int64_t chunk = (int64_t)(pipe_chunk((size_t)64 << 20) / (size_t)(bc_stride + 4));
 	if (chunk > n) chunk = n;
 	if (int r = ensure_ws(c, up256((size_t)chunk * bc_stride) + up256((size_t)chunk * 4))) return r;
 	uint8_t *dbc = c->ws;

@@ -910,6 +910,56 @@ def test_census_grows_between_the_launches_of_one_call(oracle, monkeypatch, chun
         assert total == 1000 and [(c, f) for _, c, f in got] == [(2, i) for i in range(1000)]
 
 
+@pytest.mark.parametrize("chunk_log2", ["12", "15"])
+def test_host_entry_points_in_many_chunks(ctx, oracle, monkeypatch, chunk_log2):
+    """Every host-pointer entry point cut into many chunks (SK_HOST_CHUNK_LOG2): the two-lane pipeline — alternating streams,
+    alternating workspace halves, accumulators shared by both lanes — gives what one chunk gives."""
+    monkeypatch.setenv("SK_HOST_CHUNK_LOG2", chunk_log2)
+    n, L = 5003, 101
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, n, seed=31, halves=2)
+    ln = synth.ragged_lengths(n, L, seed=31)
+    mates = []
+    for mi in range(2):
+        seq, qual = synth.make_reads(n, L, seed=230 + mi)
+        mates.append((seq, synth.add_forced_classes(qual, seed=240 + mi), ln))
+    ctx.set_barcodes(table, 1)
+    r = ctx.fused_pass(mates, 20, bc=bc, want_detail=True)
+    e = oracle.demux_batch(table, bc, 1)
+    assert np.array_equal(r["assign"], e[0]) and np.array_equal(r["lowest_diff"], e[1]) and np.array_equal(ctx.counts(), e[4])
+    for mi, (seq, qual, _) in enumerate(mates):
+        assert np.array_equal(r["lowest_k"][mi], oracle.trim_batch(qual, ln, 20))
+        exp = oracle.mask_batch(seq, qual, ln, 20)
+        valid = np.arange(L)[None, :] < ln[:, None]
+        assert np.array_equal(r["out_seq"][mi][valid], exp[valid])
+    assert np.array_equal(ctx.mask_by_quality(mates[0][0], mates[0][1], None, 30), oracle.mask_batch(mates[0][0], mates[0][1], None, 30))
+    assert np.array_equal(ctx.trim_by_quality(mates[1][1], ln, 2), oracle.trim_batch(mates[1][1], ln, 2))
+    assert np.array_equal(ctx.demux_assign(bc, want_detail=False)[0], e[0])
+    # BAM columns
+    flag, tid, mtid, tlen = synth.make_bam_cores(70001, seed=9)
+    counters, hist, total = ctx.bam_flag_tlen(flag, tid, mtid, tlen, 5000)
+    ec, eh, et = oracle.bam_flag_tlen(flag, tid, mtid, tlen, 5000)
+    assert np.array_equal(counters, ec) and np.array_equal(hist, eh) and total == et
+    keep, kept = ctx.bam_fragments(flag, tid, mtid, tlen, 50, 700)
+    ek = oracle.fragments_keep(flag, tid, mtid, tlen, 50, 700)
+    assert np.array_equal(keep, ek) and kept == int(ek.sum())
+    seq4, qual, lens, flags = bam_rows(3001, 152, seed=6)
+    assert_rows_equal(ctx.bam_sequence(seq4, qual, lens, flags, 10), oracle.bam_sequence_batch(seq4, qual, lens, flags, 10), lens)
+    # census
+    ctx.census_reset()
+    ctx.census_add(bc)
+    got, _ = ctx.census_entries()
+    assert got == oracle.census(bc)
+    # sam count
+    n_chr = 5
+    cols, rchr, rstart, rend = count_inputs(60_000, n_chr, 3000, seed=12)
+    want, code, _ = oracle.count_batch(**cols, n_chr=n_chr, rchr=rchr, rstart=rstart, rend=rend)
+    chr_off, gs, ge, gi = grouped_regions(rchr, rstart, rend, n_chr)
+    ctx.count_set_regions(chr_off, gs, ge, gi, n_regions=3000)
+    ctx.count_add(**dict(cols, end_pos=None))
+    assert code == 0 and np.array_equal(ctx.count_get()[gi], want[gi])
+
+
 def test_errors_are_codes_not_crashes(ctx):
     import seqkit_amd
     with pytest.raises(seqkit_amd.SeqkitHipError):
