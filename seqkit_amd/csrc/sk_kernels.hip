@@ -682,7 +682,14 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #endif
 constexpr int kSlots = SK_SLOTS;                      // 1 KiB chunk loads in flight per wave and stream
 constexpr int kAuxStream = (SK_NT & 1) ? 2 : 0;      // nt on the read-once streams
+#ifdef SK_ST_AUX
+constexpr int kAuxStreamSt = SK_ST_AUX;              // tuning: cache-policy bits of the streaming stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#else
 constexpr int kAuxStreamSt = (SK_NT & 2) ? 2 : 0;
+#endif
+#ifdef SK_LD_AUX
+#undef SK_LD_AUX_SET
+#endif
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int records)
 {

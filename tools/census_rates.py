@@ -47,3 +47,9 @@ g = torch.Generator(device=dev)
 g.manual_seed(3)
 rnd = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (rows, 16), device=dev, generator=g)].contiguous()
 run("worst case: every row a new 16-mer (16 B/row)", rnd, 16)
+# where does the time go: only exact sheet barcodes (everything is counted in the workgroups' LDS tables) and only
+# single-substitution neighbours (6.5 k distinct keys: more than an LDS table holds)
+for name, kw in (("all rows exact sheet barcodes (LDS tables only)", dict(p_exact=1.0, p_sub=0.0)), ("exact + single substitutions, no random halves", dict(p_exact=0.85, p_sub=0.15))):
+    b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
+    b = torch.from_numpy(b_np).to(dev).repeat(reps, 1).contiguous()
+    run(name, b, 17)
