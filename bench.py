@@ -46,8 +46,9 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=62_500_000, help="clusters per GPU (default: configs[3] / 8)")
-    ap.add_argument("--layout", choices=["blocked", "soa"], default=os.environ.get("SK_BENCH_LAYOUT", "blocked"),
-                    help="batch layout in HBM: tile-blocked (one read range + one write range per 64-cluster tile) or row-major SoA matrices")
+    ap.add_argument("--layout", choices=["soa", "blocked"], default=os.environ.get("SK_BENCH_LAYOUT", "soa"),
+                    help="batch layout in HBM: row-major SoA matrices (with placement tuning the faster of the two) or tile-blocked "
+                         "(one read range + one write range per 64-cluster tile)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="clusters timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=1,
                     help="threads for the CPU baseline (the reference's loops are single-threaded, so 1 is the faithful number; "
@@ -57,8 +58,9 @@ def parse(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip extra.rates (device-resident rates of the other configs)")
     ap.add_argument("--gen-chunk", type=int, default=2_000_000)
     ap.add_argument("--placements", type=int, default=3,
-                    help="blocked layout: allocate this many candidate (input, output) buffer pairs, time the pass on each before the warm-up "
-                         "and keep the fastest (where a buffer's pages lie moves the same kernel by up to 6 %%); 1 = take what comes")
+                    help="candidate device buffers per big matrix (SoA) / per buffer (blocked): allocated at start-up, the pass is timed "
+                         "while one matrix at a time is swapped for its other candidates (sk_fused_tune_placement_dev), the fastest combination "
+                         "is kept and the rest freed — where a buffer's pages lie moves the same kernel by up to 12 %%; 1 = take what comes")
     return ap.parse_args(argv)
 
 
@@ -363,23 +365,28 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # The shard lives in two buffers (tile-blocked layout), allocated before the library's context, RCCL or any temporary
-    # exists.  WHERE a buffer's pages lie moves the same kernel on the same data by up to 6 % — a property of the
-    # allocation that stays for its lifetime (tools/placement_draws.py: four pairs allocated in one process 10.49 / 10.85 /
-    # 10.89 / 10.94 ms, each reproducible to 0.1 %).  A long-lived process chooses once: --placements K pairs are
-    # allocated, the pass is timed on each BEFORE the warm-up, the fastest pair is kept and the others are freed.  The
-    # probe timings go into the JSON line.
+    # Placement tuning.  WHERE the pages of a device buffer lie moves the same kernel on the same bytes by up to 12 % on one
+    # GPU — a property of the allocations that stays for their lifetime, bimodal, and relational (how the buffers of the
+    # streams that are active together lie to each other; DESIGN.md §6, tools/soa_placement_search.py: 9.34 against 10.6 ms).
+    # A long-lived process chooses once: the shard's big buffers are allocated --placements times over, before the
+    # library's context, RCCL or any temporary exists; the input candidates get the same bytes; then, BEFORE the warm-up,
+    # sk_fused_tune_placement_dev (SoA matrices) / a probe of every input x output pair (blocked) keeps the fastest
+    # combination and the rest is freed.  What was probed and chosen goes into the JSON line (config.placement).
     n = args.pairs
     nt = (n + 63) // 64
     npad = nt * 64                                           # whole tiles
     lay = None
+    K = max(1, min(args.placements, 8))
     if args.layout == "blocked":
         lay = capi.blocked_layout(2, L_READ, L_BC, capi.SK_BLK_MASK | capi.SK_BLK_TRIM)
         cands = [(torch.empty(nt * lay.in_block, dtype=torch.uint8, device=dev), torch.empty(nt * lay.out_block, dtype=torch.uint8, device=dev))
-                 for _ in range(max(1, args.placements))]
+                 for _ in range(K)]
         bin_, bout = cands[0]
         bin_.zero_()
-        torch.cuda.synchronize()
+    else:
+        big = lambda: [[torch.empty((npad, L_READ), dtype=torch.uint8, device=dev) for _ in range(K)] for _ in range(2)]     # [mate][candidate]
+        c_seq, c_qual, c_out = big(), big(), big()
+    torch.cuda.synchronize()
     ctx = seqkit_amd.Context(local_rank)                    # raises if libseqkit_hip.so is missing
     table = synth.make_sheet(S_SAMPLES, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
@@ -458,12 +465,33 @@ def main():
         del cands
         torch.cuda.empty_cache()
     else:
-        seq, qual, bc = gen_shard(torch, dev, npad, table, seed=4000 + rank, chunk=args.gen_chunk)
-        out_seq = [torch.empty_like(seq[0]) for _ in range(2)]
+        seq, qual = [c_seq[i][0] for i in range(2)], [c_qual[i][0] for i in range(2)]
+        bc = torch.empty((npad, L_BC), dtype=torch.uint8, device=dev)
+        gen_shard(torch, dev, npad, table, seed=4000 + rank, chunk=args.gen_chunk, into=(seq, qual, bc))
+        out_seq = [c_out[i][0] for i in range(2)]
         lowest_k = [torch.empty((npad,), dtype=torch.int16, device=dev) for _ in range(2)]     # raw u16 storage
         assign = torch.empty((npad,), dtype=torch.int32, device=dev)
         mates = [{"seq": seq[i].data_ptr(), "qual": qual[i].data_ptr(), "len": 0,
                   "out_seq": out_seq[i].data_ptr(), "lowest_k": lowest_k[i].data_ptr()} for i in range(2)]
+        placement = {"candidates": K, "ms_before": None, "ms_after": None, "probes": 0}
+        if K > 1:
+            for i in range(2):
+                for k in range(1, K):
+                    c_seq[i][k].copy_(c_seq[i][0])
+                    c_qual[i][k].copy_(c_qual[i][0])
+            torch.cuda.synchronize()
+            cd = [{"seq": [t.data_ptr() for t in c_seq[i]], "qual": [t.data_ptr() for t in c_qual[i]], "out_seq": [t.data_ptr() for t in c_out[i]]}
+                  for i in range(2)]
+            mates, ms0, ms1, probes = ctx.fused_tune_placement_dev(n, L_READ, MIN_BASEQ, mates, cd, bc=bc.data_ptr(), bc_stride=L_BC,
+                                                                   assign=assign.data_ptr(), sweeps=2)
+            by_ptr = {t.data_ptr(): t for grp in (c_seq, c_qual, c_out) for per_mate in grp for t in per_mate}
+            seq = [by_ptr[mates[i]["seq"]] for i in range(2)]
+            qual = [by_ptr[mates[i]["qual"]] for i in range(2)]
+            out_seq = [by_ptr[mates[i]["out_seq"]] for i in range(2)]
+            placement.update(ms_before=round(ms0, 4), ms_after=round(ms1, 4), probes=probes)
+            del by_ptr, cd
+        del c_seq, c_qual, c_out
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
 
     # everything below runs on the ctx's own HIP stream (torch sees it as an external stream)
@@ -607,8 +635,12 @@ def main():
                        "clusters_per_gpu": n, "read_len": L_READ, "barcodes": S_SAMPLES, "barcode_len": L_BC,
                        "min_baseq": MIN_BASEQ, "read_unit": "cluster (as the reference's total_reads counts)",
                        "layout": args.layout,
-                       "placement": (dict(placement, what="candidate input and output buffers allocated at start-up; the pass timed on every (input, output) "
-                                                          "combination before the warm-up (probe_ms[i][j]); the fastest combination kept, the rest freed") if lay is not None else None),
+                       "placement": dict(placement, what=("candidate input and output buffers allocated at start-up; the pass timed on every (input, output) "
+                                                          "combination before the warm-up (probe_ms[i][j]); the fastest combination kept, the rest freed"
+                                                          if lay is not None else
+                                                          "candidate device buffers for each of the six big matrices allocated at start-up; sk_fused_tune_placement_dev "
+                                                          "times the pass while one matrix at a time is swapped for its other candidates, before the warm-up; "
+                                                          "the fastest combination kept, the rest freed")),
                        "count_reduce": ("none (1 GPU)" if not distributed else
                                         f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
                                         if rccl_err is None else f"gloo all-reduce with a host round trip (RCCL unavailable: {rccl_err})")},

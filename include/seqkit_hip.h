@@ -132,6 +132,27 @@ typedef struct {
 int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
 int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 
+/* ---- placement tuning for resident batches ---------------------------------------------------------------------------
+ * WHERE the pages of a device buffer lie moves the fused pass by up to 12 % on one and the same GPU: measured on MI355X,
+ * the same kernel on the same bytes takes 9.35 ms with one set of allocations and 10.6 ms with another, each reproducible
+ * to 0.1 % for the life of the buffers, bimodal, and decided by how the buffers of the streams that are active together
+ * relate to each other — not by their addresses' alignment, padding or order (tools/soa_placement_search.py,
+ * tools/arena_sweep.py).  A host whose batch buffers live long (a resident shard that is processed many
+ * times, a ring of staging buffers) can therefore choose once: it allocates k candidate device buffers for each big
+ * matrix of the pass, fills the input candidates with the same bytes, and this call times the pass while it swaps one
+ * matrix at a time for its other candidates (coordinate descent, `sweeps` rounds, 1 + 2 launches per probe) and leaves
+ * the fastest combination in `args`.  The losers are the caller's to free.  Counters are not touched (the probes count
+ * into a scratch vector).  ms_before / ms_after: the pass on the first candidates and on the chosen ones.            */
+#define SK_MAX_CANDIDATES 8
+typedef struct {
+	int k;                                              /* candidates per matrix, 1..SK_MAX_CANDIDATES            */
+	const uint8_t *seq[2][SK_MAX_CANDIDATES];           /* per mate; entries of an unused mate / matrix are NULL  */
+	const uint8_t *qual[2][SK_MAX_CANDIDATES];
+	uint8_t *out_seq[2][SK_MAX_CANDIDATES];
+} sk_fused_candidates;
+int sk_fused_tune_placement_dev(sk_ctx *ctx, sk_fused_args *args, const sk_fused_candidates *cands, int sweeps,
+                                float *ms_before, float *ms_after, int *n_probes);
+
 /* ---- the fused pass over a TILE-BLOCKED batch -----------------------------------------------------------------
  * Same arithmetic and the same reference lines as sk_fused_pass; only where the bytes sit differs.  A batch is cut
  * into tiles of 64 consecutive clusters.  Everything tile t READS is one contiguous block of `in_block` bytes at

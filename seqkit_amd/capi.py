@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "sk_malloc_device", "sk_free_device", "sk_malloc_pinned", "sk_free_pinned", "sk_copy_h2d", "sk_copy_d2h",
     "sk_set_barcodes", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
-    "sk_blocked_layout_init", "sk_fused_pass_blocked_dev",
+    "sk_blocked_layout_init", "sk_fused_pass_blocked_dev", "sk_fused_tune_placement_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
     "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
@@ -48,6 +48,10 @@ class _FusedArgs(C.Structure):
                 ("mate", _Mate * 2), ("bc", C.c_void_p), ("bc_stride", C.c_int), ("assign", C.c_void_p),
                 ("lowest_diff", C.c_void_p), ("first_idx", C.c_void_p), ("last_idx", C.c_void_p),
                 ("counts", C.c_void_p)]
+
+
+class _FusedCandidates(C.Structure):
+    _fields_ = [("k", C.c_int), ("seq", (C.c_void_p * 8) * 2), ("qual", (C.c_void_p * 8) * 2), ("out_seq", (C.c_void_p * 8) * 2)]
 
 
 SK_BLK_MASK, SK_BLK_TRIM, SK_BLK_LEN, SK_BLK_DETAIL = 1, 2, 4, 8
@@ -157,6 +161,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_fused_pass_dev": (i32, [vp, C.POINTER(_FusedArgs)]),
         "sk_blocked_layout_init": (i32, [C.POINTER(BlockedLayout), i32, i32, i32, i32]),
         "sk_fused_pass_blocked_dev": (i32, [vp, C.POINTER(BlockedLayout), vp, vp, i64, u8, vp]),
+        "sk_fused_tune_placement_dev": (i32, [vp, C.POINTER(_FusedArgs), C.POINTER(_FusedCandidates), i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                              C.POINTER(i32)]),
         "sk_counts_reset": (i32, [vp]), "sk_counts_get": (i32, [vp, vp]), "sk_counts_device_ptr": (vp, [vp]),
         "sk_comm_get_unique_id": (i32, [vp]), "sk_comm_init_rank": (i32, [vp, vp, i32, i32]), "sk_comm_destroy": (i32, [vp]),
         "sk_counts_allreduce": (i32, [C.POINTER(vp), i32]), "sk_allreduce_u64_dev": (i32, [vp, vp, C.c_size_t]),
@@ -611,6 +617,32 @@ class Context:
             self.free_device(din)
             self.free_device(dout)
         return lay.unpack(hout, n)
+
+    def fused_tune_placement_dev(self, n: int, stride: int, min_baseq: int, mates, cands, bc: int = 0, bc_stride: int = 0, assign: int = 0,
+                                 sweeps: int = 2):
+        """mates as in fused_pass_dev; cands: list per mate of {"seq": [ptr...], "qual": [...], "out_seq": [...]} (same k everywhere).
+        Returns (mates with the chosen pointers, ms_before, ms_after, n_probes)."""
+        a = _FusedArgs()
+        a.n, a.n_mates, a.stride, a.min_baseq = n, len(mates), stride, min_baseq
+        for i, m in enumerate(mates):
+            a.mate[i].seq = m.get("seq") or None
+            a.mate[i].qual = m.get("qual") or None
+            a.mate[i].len = m.get("len") or None
+            a.mate[i].out_seq = m.get("out_seq") or None
+            a.mate[i].lowest_k = m.get("lowest_k") or None
+        a.bc, a.bc_stride, a.assign = bc or None, bc_stride, assign or None
+        cd = _FusedCandidates()
+        cd.k = len(cands[0]["qual"])
+        for i, cm in enumerate(cands):
+            for k in range(cd.k):
+                cd.seq[i][k] = cm["seq"][k] if cm.get("seq") else None
+                cd.qual[i][k] = cm["qual"][k]
+                cd.out_seq[i][k] = cm["out_seq"][k] if cm.get("out_seq") else None
+        before, after, probes = C.c_float(), C.c_float(), C.c_int()
+        self._check(self._lib.sk_fused_tune_placement_dev(self._h, C.byref(a), C.byref(cd), sweeps, C.byref(before), C.byref(after), C.byref(probes)),
+                    "sk_fused_tune_placement_dev")
+        chosen = [dict(m, seq=a.mate[i].seq or 0, qual=a.mate[i].qual or 0, out_seq=a.mate[i].out_seq or 0) for i, m in enumerate(mates)]
+        return chosen, float(before.value), float(after.value), int(probes.value)
 
     def demux_assign_dev(self, bc: int, bc_stride: int, n: int, assign: int, lowest_diff: int = 0, first_idx: int = 0,
                          last_idx: int = 0, counts: int = 0) -> None:

@@ -855,6 +855,84 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 	return pipe.end();
 }
 
+// ---- placement tuning -------------------------------------------------------------------------------------------
+int sk_fused_tune_placement_dev(sk_ctx *c, sk_fused_args *a, const sk_fused_candidates *cd, int sweeps, float *ms_before, float *ms_after, int *n_probes)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!a || !cd) return fail(c, SK_ERR_INVALID, "args or candidates is NULL");
+	if (cd->k < 1 || cd->k > SK_MAX_CANDIDATES || sweeps < 0) return fail(c, SK_ERR_INVALID, "k = %d (1..%d), sweeps = %d", cd->k, SK_MAX_CANDIDATES, sweeps);
+	if (int r = check_fused(c, a, true)) return r;
+	if (int r = bind(c)) return r;
+	// the matrices that take part: those the pass uses and that have candidates
+	struct Slot { int mate, what; };                       // what: 0 seq, 1 qual, 2 out_seq
+	std::vector<Slot> slots;
+	for (int m = 0; m < a->n_mates; m++) {
+		const sk_mate &mt = a->mate[m];
+		if (!mt.out_seq && !mt.lowest_k) continue;
+		if (mt.out_seq && cd->seq[m][0]) slots.push_back({m, 0});
+		if (cd->qual[m][0]) slots.push_back({m, 1});
+		if (mt.out_seq && cd->out_seq[m][0]) slots.push_back({m, 2});
+	}
+	for (const Slot &sl : slots)
+		for (int k = 0; k < cd->k; k++) {
+			const void *p = sl.what == 0 ? (const void *)cd->seq[sl.mate][k] : sl.what == 1 ? (const void *)cd->qual[sl.mate][k] : (const void *)cd->out_seq[sl.mate][k];
+			if (!p || !aligned16(p)) return fail(c, SK_ERR_INVALID, "candidate %d of mate %d is NULL or not 16-byte aligned", k, sl.mate);
+		}
+	unsigned long long *scratch = nullptr;                  // the probes count here, not into the caller's counters
+	SK_HIP(c, hipMalloc((void **)&scratch, (size_t)(c->S + 3) * 8 + 8));
+	sk_fused_args t = *a;
+	t.counts = (uint64_t *)scratch;
+	std::vector<int> choice(slots.size(), 0);
+	auto apply = [&](sk_fused_args &x, const std::vector<int> &ch) {
+		for (size_t i = 0; i < slots.size(); i++) {
+			sk_mate &mt = x.mate[slots[i].mate];
+			if (slots[i].what == 0) mt.seq = cd->seq[slots[i].mate][ch[i]];
+			else if (slots[i].what == 1) mt.qual = cd->qual[slots[i].mate][ch[i]];
+			else mt.out_seq = cd->out_seq[slots[i].mate][ch[i]];
+		}
+	};
+	int probes = 0;
+	int rc = SK_OK;
+	auto time_choice = [&](const std::vector<int> &ch, float &ms) -> int {
+		apply(t, ch);
+		sk::TileArgs ta = tile_args_of(c, &t);
+		probes++;
+		hipError_t e = sk::launch_tile_pass(ta, c->n_cu, c->stream);                 // warm
+		if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
+		for (int i = 0; i < 2 && e == hipSuccess; i++) e = sk::launch_tile_pass(ta, c->n_cu, c->stream);
+		if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+		if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+		if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+		if (e != hipSuccess) return fail(c, SK_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
+		ms *= 0.5f;
+		return SK_OK;
+	};
+	float best = 0.f;
+	rc = time_choice(choice, best);
+	const float first = best;
+	for (int sw = 0; sw < sweeps && rc == SK_OK; sw++) {
+		bool moved = false;
+		for (size_t i = 0; i < slots.size() && rc == SK_OK; i++)
+			for (int k = 0; k < cd->k && rc == SK_OK; k++) {
+				if (k == choice[i]) continue;
+				std::vector<int> trial = choice;
+				trial[i] = k;
+				float ms = 0.f;
+				rc = time_choice(trial, ms);
+				if (rc == SK_OK && ms < best * 0.998f) { best = ms; choice = trial; moved = true; }
+			}
+		if (!moved) break;
+	}
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(scratch);
+	if (rc != SK_OK) return rc;
+	apply(*a, choice);
+	if (ms_before) *ms_before = first;
+	if (ms_after) *ms_after = best;
+	if (n_probes) *n_probes = probes;
+	return SK_OK;
+}
+
 // ---- tile-blocked batches ---------------------------------------------------------------------------------------
 int sk_blocked_layout_init(sk_blocked_layout *lay, int n_mates, int stride, int bc_stride, int flags)
 {
