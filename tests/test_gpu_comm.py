@@ -73,3 +73,58 @@ def test_rank_communicator_of_one(hip_lib, oracle):
         with pytest.raises(seqkit_amd.SeqkitHipError):
             c.comm_init_rank(uid, 0, 1)                   # a ctx has one communicator
         c.comm_destroy()
+
+
+def test_placement_tuning_keeps_the_bytes_and_the_counters(hip_lib, oracle):
+    """sk_fused_tune_placement_dev: K candidate device buffers per matrix; whatever combination it settles on, the pass over
+    it gives the oracle's bytes, the chosen pointers are candidates, and the ctx counters were not touched by the probes."""
+    import seqkit_amd
+    n, L, K = 20000, 150, 3
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, n, seed=91, halves=2)
+    mates_h = []
+    for mi in range(2):
+        seq, qual = synth.make_reads(n, L, seed=310 + mi)
+        mates_h.append((seq, synth.add_forced_classes(qual, seed=320 + mi)))
+    with seqkit_amd.Context(0) as c:
+        c.set_barcodes(table, 1)
+        dev = []
+
+        def dmalloc(nbytes, src=None):
+            p = c.malloc_device(nbytes + 16)
+            dev.append(p)
+            if src is not None:
+                c.copy_h2d(p, np.ascontiguousarray(src))
+            return p
+        cands = [{"seq": [dmalloc(n * L, mates_h[i][0]) for _ in range(K)], "qual": [dmalloc(n * L, mates_h[i][1]) for _ in range(K)],
+                  "out_seq": [dmalloc(n * L) for _ in range(K)]} for i in range(2)]
+        d_bc, d_assign = dmalloc(n * 17, bc), dmalloc(n * 4)
+        d_lk = [dmalloc(n * 2) for _ in range(2)]
+        mates = [{"seq": cands[i]["seq"][0], "qual": cands[i]["qual"][0], "len": 0, "out_seq": cands[i]["out_seq"][0], "lowest_k": d_lk[i]} for i in range(2)]
+        c.sync()
+        before = c.counts()
+        chosen, ms0, ms1, probes = c.fused_tune_placement_dev(n, L, 20, mates, cands, bc=d_bc, bc_stride=17, assign=d_assign, sweeps=2)
+        assert np.array_equal(c.counts(), before) and int(before.sum()) == 0
+        assert probes >= 1 + 6 * (K - 1) and ms0 > 0 and 0 < ms1 <= ms0 * 1.0001
+        for i in range(2):
+            assert chosen[i]["seq"] in cands[i]["seq"] and chosen[i]["qual"] in cands[i]["qual"] and chosen[i]["out_seq"] in cands[i]["out_seq"]
+            assert chosen[i]["lowest_k"] == d_lk[i]
+        c.fused_pass_dev(n, L, 20, chosen, bc=d_bc, bc_stride=17, assign=d_assign)
+        got_assign = np.empty(n, dtype=np.int32)
+        c.copy_d2h(got_assign, d_assign)
+        outs = [np.empty((n, L), dtype=np.uint8) for _ in range(2)]
+        lks = [np.empty(n, dtype=np.uint16) for _ in range(2)]
+        for i in range(2):
+            c.copy_d2h(outs[i], chosen[i]["out_seq"])
+            c.copy_d2h(lks[i], d_lk[i])
+        c.sync()
+        e = oracle.demux_batch(table, bc, 1)
+        assert np.array_equal(got_assign, e[0]) and np.array_equal(c.counts(), e[4])
+        for i in range(2):
+            assert np.array_equal(outs[i], oracle.mask_batch(mates_h[i][0], mates_h[i][1], None, 20))
+            assert np.array_equal(lks[i], oracle.trim_batch(mates_h[i][1], None, 20))
+        # bad arguments are codes
+        with pytest.raises(seqkit_amd.SeqkitHipError):
+            c.fused_tune_placement_dev(n, L, 20, mates, [dict(cands[0], qual=[cands[0]["qual"][0], 0, 0]), cands[1]], bc=d_bc, bc_stride=17, assign=d_assign)
+        for p in dev:
+            c.free_device(p)

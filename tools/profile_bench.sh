@@ -9,8 +9,11 @@ W=/tmp/skprof_$TAG
 rm -rf $W; mkdir -p $W $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py "$@" 2>/dev/null | tail -1 > $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-extra "$@" > $W/trace.log 2>&1
-python3 $R/tools/summarize_prof.py $W/trace $OUT/rocprof
+# the traced run keeps its own JSON line: its HIP-event kernel time and the trace's durations of its timed steps come from
+# the SAME process (placements — and with them the kernel time — differ from process to process)
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -- python3 $R/bench.py --steps 8 --warmup 2 --cpu-sample 0 --no-extra "$@" > $W/trace.log 2>$W/trace.err
+grep '^{"metric"' $W/trace.log | tail -1 > $OUT/traced_bench.json
+python3 $R/tools/summarize_prof.py $W/trace $OUT/rocprof $OUT/traced_bench.json
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
