@@ -340,6 +340,29 @@ def faithful_cpu(n_reads):
     return res
 
 
+def join_count_reduce(dist, rank, world, make_unique_id, init_rank):
+    """The ranks agree on how the counters are summed.  Rank 0 makes the communicator id (sk_comm_get_unique_id), every rank
+    gets it over the rendezvous backend and joins (sk_comm_init_rank).  Should any rank fail at either step (a node may have
+    no usable interface for RCCL's bootstrap), ALL ranks learn of it and fall back together to a gloo sum with a host round
+    trip — the JSON line then says so; a scaling run still gets numbers.  Returns None (RCCL) or the reason (gloo)."""
+    err = None
+    try:
+        box = [make_unique_id() if rank == 0 else None]
+    except Exception as e:
+        box, err = [None], str(e)
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is not None:
+        try:
+            init_rank(box[0], rank, world)
+        except Exception as e:
+            err = str(e)
+    else:
+        err = err or "rank 0 could not make a unique id"
+    flags = [None] * world
+    dist.all_gather_object(flags, err)
+    return next((f for f in flags if f), None)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -399,24 +422,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        # RCCL inside the library; should a node refuse it (no usable interface for the bootstrap, say), every rank falls back to
-        # summing the counters through gloo with a host round trip, and the JSON line says so — a scaling run still gets numbers
-        rccl_err = None
-        try:
-            box = [capi.comm_unique_id() if rank == 0 else None]
-        except Exception as e:
-            box, rccl_err = [None], str(e)
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is not None:
-            try:
-                ctx.comm_init_rank(box[0], rank, world)
-            except Exception as e:
-                rccl_err = str(e)
-        else:
-            rccl_err = rccl_err or "rank 0 could not make a unique id"
-        flags = [None] * world
-        dist.all_gather_object(flags, rccl_err)
-        rccl_err = next((f for f in flags if f), None)
+        rccl_err = join_count_reduce(dist, rank, world, capi.comm_unique_id, ctx.comm_init_rank)
         if rccl_err is not None:
             sys.stderr.write(f"[bench] RCCL unavailable ({rccl_err}); the count reduce goes through gloo\n")
             try:

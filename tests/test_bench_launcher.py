@@ -45,3 +45,27 @@ def test_under_a_launcher_bench_is_one_rank(tmp_path):
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def rank_run(tmp_path, n, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"SK_BENCH_WORKER": os.path.join(REPO, "tests", "_bench_rank_worker.py")})
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_ranks_meet_and_agree_on_the_count_reduce(tmp_path):
+    """World size 2 on CPU (gloo), started by bench.py's launcher: every rank receives rank 0's communicator id and joins; when
+    the id cannot be made, or ONE rank cannot join, ALL ranks fall back to the gloo sum together."""
+    ok = rank_run(tmp_path, 2)
+    assert ok["n_gpus"] == 2 and [x[0] for x in ok["ranks"]] == [None, None]
+    assert [x[1] for x in ok["ranks"]] == [True, True] and [x[2] for x in ok["ranks"]] == [0, 1]
+    assert [x[3] for x in ok["ranks"]] == [5, 10]                      # RCCL would have summed; the stand-in does not
+    no_uid = rank_run(tmp_path, 2, {"SK_STUB_UID_FAILS": "1"})
+    assert all(x[0] == "no interface" for x in no_uid["ranks"]) and [x[3] for x in no_uid["ranks"]] == [15, 15]
+    one_out = rank_run(tmp_path, 3, {"SK_STUB_INIT_FAILS_ON": "2"})
+    assert all(x[0] == "rank 2 cannot join" for x in one_out["ranks"]) and [x[3] for x in one_out["ranks"]] == [30, 30, 30]
