@@ -407,8 +407,19 @@ def main():
         bin_, bout = cands[0]
         bin_.zero_()
     else:
-        big = lambda: [[torch.empty((npad, L_READ), dtype=torch.uint8, device=dev) for _ in range(K)] for _ in range(2)]     # [mate][candidate]
-        c_seq, c_qual, c_out = big(), big(), big()
+        c_seq, c_qual, c_out = [[], []], [[], []], [[], []]              # [mate][candidate]
+        for k in range(K):
+            try:
+                got = [torch.empty((npad, L_READ), dtype=torch.uint8, device=dev) for _ in range(6)]
+            except torch.cuda.OutOfMemoryError:                          # less free memory than 3 x 56 GB: tune over what fits
+                if k == 0:
+                    raise
+                sys.stderr.write(f"[bench] {k} candidate allocation(s) per matrix fit the free device memory, not {K}\n")
+                K = k
+                break
+            for i in range(2):
+                c_seq[i].append(got[3 * i]); c_qual[i].append(got[3 * i + 1]); c_out[i].append(got[3 * i + 2])
+            del got
     torch.cuda.synchronize()
     ctx = seqkit_amd.Context(local_rank)                    # raises if libseqkit_hip.so is missing
     table = synth.make_sheet(S_SAMPLES, 8, dual=True, seed=4)

@@ -699,6 +699,7 @@ int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx)
 		SK_NCCL(c0, rccl()->GroupStart());
 		for (size_t k = 0; k < leaders.size(); k++) {
 			sk_ctx *l = ctxs[leaders[k]];
+			(void)hipSetDevice(l->device);                         // each rank's call with its own device current
 			ncclResult_t r = rccl()->AllReduce(l->d_counts, l->d_counts, (size_t)nc, ncclUint64, ncclSum, comms[k], l->stream);
 			if (r != ncclSuccess) { (void)rccl()->GroupEnd(); return fail(c0, SK_ERR_COMM, "ncclAllReduce: %s", rccl()->GetErrorString(r)); }
 		}
