@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: librccl is loaded with dlopen on first use
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -592,6 +593,15 @@ __global__ void counts_add_kernel(unsigned long long *dst, const unsigned long l
 }
 }  // namespace
 
+// RCCL announces itself on stdout when a communicator comes up (version banner).  stdout belongs to the host's results
+// (the reference's commands print there), so while a communicator is being made fd 1 points at stderr, and what stdio
+// buffered during that time is flushed there before fd 1 is put back.
+struct StdoutToStderr {
+	int saved = -1;
+	StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
+	~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
+};
+
 #define SK_NCCL(c, call)                                                                                  \
 	do {                                                                                                  \
 		ncclResult_t r_ = (call);                                                                         \
@@ -611,6 +621,7 @@ int sk_comm_get_unique_id(uint8_t id[SK_COMM_ID_BYTES])
 	if (!id) return SK_ERR_INVALID;
 	if (int r = rccl_ready(nullptr)) return r;
 	ncclUniqueId u;
+	StdoutToStderr quiet;
 	SK_NCCL(nullptr, rccl()->GetUniqueId(&u));
 	memcpy(id, u.internal, SK_COMM_ID_BYTES);
 	return SK_OK;
@@ -625,6 +636,7 @@ int sk_comm_init_rank(sk_ctx *c, const uint8_t id[SK_COMM_ID_BYTES], int rank, i
 	if (int r = bind(c)) return r;
 	ncclUniqueId u;
 	memcpy(u.internal, id, SK_COMM_ID_BYTES);
+	StdoutToStderr quiet;
 	SK_NCCL(c, rccl()->CommInitRank(&c->comm, n_ranks, u, rank));
 	c->comm_ranks = n_ranks;
 	return SK_OK;
@@ -692,6 +704,7 @@ int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx)
 			for (const LocalComms &lc : g_local) if (lc.devs == devs) { comms = lc.comms; break; }
 			if (comms.empty()) {
 				comms.resize(devs.size());
+				StdoutToStderr quiet;
 				SK_NCCL(c0, rccl()->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
 				g_local.push_back({devs, comms});
 			}
