@@ -375,6 +375,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SK_BENCH_SAME_DEVICE"):               # testing aid for one-GPU boxes: every rank on device 0 (RCCL refuses that: exercises the fallback)
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 

@@ -128,3 +128,26 @@ def test_placement_tuning_keeps_the_bytes_and_the_counters(hip_lib, oracle):
             c.fused_tune_placement_dev(n, L, 20, mates, [dict(cands[0], qual=[cands[0]["qual"][0], 0, 0]), cands[1]], bc=d_bc, bc_stride=17, assign=d_assign)
         for p in dev:
             c.free_device(p)
+
+
+def test_bench_two_ranks_on_one_gpu_take_the_gloo_fallback(hip_lib, oracle):
+    """The whole N > 1 flow of bench.py on a one-GPU box: its launcher starts two ranks, both are put on device 0
+    (SK_BENCH_SAME_DEVICE), RCCL refuses two ranks on one device, ALL ranks fall back to the gloo sum together, the counter
+    identities over both shards hold (asserted inside bench.py) and rank 0's line says n_gpus = 2 and which reduce ran."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SK_BENCH_SAME_DEVICE="1", SK_BENCH_LAUNCH_TIMEOUT="500")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--pairs", "2000000", "--placements", "2", "--steps", "3", "--warmup", "1",
+                        "--no-extra", "--faithful-reads", "0", "--cpu-sample", "200000"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True and d["scaling"] == "weak"
+    assert "gloo" in d["config"]["count_reduce"] or "RCCL" in d["config"]["count_reduce"]
+    assert d["value"] > 0 and d["config"]["placement"]["candidates"] == 2
