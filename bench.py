@@ -632,16 +632,17 @@ def main():
         # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes (tools/profile_bench.sh) and
         # recorded in profiles/pmc_traffic.json together with the digest of the kernel sources they were taken on; the record is
         # quoted only when it matches this build, layout and size — otherwise traffic is null.
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("pairs") == n and tj.get("layout") == args.layout and tj.get("kernel_sources_sha256_16") == kernel_sources_digest():
-                    traffic = {"value": tj.get("hbm_bytes_per_launch"), "source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this build)",
-                               "kernel_sources_sha256_16": tj.get("kernel_sources_sha256_16")}
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = {"file": "profiles/pmc_traffic.json", "how": "separate rocprofv3 --pmc passes of this build (FETCH_SIZE x 2 + WRITE_SIZE), not this run",
+                                      "kernel_sources_sha256_16": tj.get("kernel_sources_sha256_16")}
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         kernel = "sk::tile_blocked_kernel" if lay is not None else "sk::tile_pass_kernel"
         line = {
             "metric": "M reads/s demultiplex (150bp, 96 barcodes) at 1/8 GPUs; % HBM roofline",
@@ -664,7 +665,7 @@ def main():
                                         f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
                                         if rccl_err is None else f"gloo all-reduce with a host round trip (RCCL unavailable: {rccl_err})")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},
