@@ -84,31 +84,44 @@ __host__ __device__ inline u32 census_code(u32 b)
 	}
 }
 
-// add (cnt, first) for one key to the HBM table; returns false when the probe budget ran out.  The three words
-// of a slot are fetched together (one round trip); on the usual path — the key is already there — the two
-// updates that follow are fire-and-forget atomics.
-__device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+struct SlotView { u64 k, v, f; };      // klo, ~khi and ~first of a slot as loaded at some earlier time
+
+// one round trip for the three words
+__device__ __forceinline__ SlotView census_peek(const CensusSlot *s)
+{
+	SlotView sv;
+	sv.k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	sv.v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	sv.f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return sv;
+}
+
+// add (cnt, first) for one key to the HBM table, starting at slot idx whose contents were fetched before (sv);
+// returns false when the probe budget ran out.  sv may be stale: a slot's key never changes once it is published, an
+// empty or unpublished view is checked again (CAS / reload), and an old `first` only costs a superfluous atomicMax.
+// On the usual path — the key is already there — the two updates are fire-and-forget atomics.
+__device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 idx, SlotView sv, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
 	const u64 want = ~khi;
-	u64 idx = (u64)census_hash(klo, khi) & mask;
 	u32 probes = 0;
+	u64 k = sv.k, v = sv.v, f = sv.f;
 	while (probes < kMaxProbes) {
 		CensusSlot *s = tab + idx;
-		u64 k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		u64 v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		u64 f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// naming all three here leaves no load outstanding on any way out of this function, for which the code after
+		// the call would otherwise wait — together with the caller's prefetched tile
+		asm volatile("" :: "v"(k), "v"(v), "v"(f));
 		if (k == 0) {
 			k = atomicCAS(&s->klo, 0ull, klo);
 			if (k == 0) {
 				// The slot is ours until its high word is published: everybody else who finds klo here waits for that
-				// (v == 0 below).  So the first count and the first row go in as plain stores, and the release store of
-				// the high word hands the slot over — ONE atomic for a new key instead of three (scattered atomics are what
-				// bounds a census of mostly distinct barcodes: about 20 G of them per second chip-wide).
-				// (the two stores are write-through at agent scope; the fence only makes this wave wait for their
-				// acknowledgement — an agent-scope release would write the whole L2 back for every key)
+				// (v == 0 below).  So the first count and the first row go in as plain stores, and the store of the high
+				// word hands the slot over — ONE atomic for a new key instead of three.
+				// (the stores are write-through at agent scope and the wait is for their acknowledgement — an
+				// agent-scope release would write the whole L2 back for every key)
 				__hip_atomic_store(&s->count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(&s->first_inv, first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the two stores
 				__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				claimed++;
 				return true;
@@ -117,7 +130,12 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 			f = 0;
 		}
 		if (k == klo) {
-			if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }      // owner is between its CAS and its release store: look again
+			if (v == 0) {                                              // owner is between its CAS and its publishing store: look again
+				__builtin_amdgcn_s_sleep(1);
+				v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				continue;
+			}
 			if (v == want) {
 				atomicAdd(&s->count, cnt);
 				if (f < first_inv) atomicMax(&s->first_inv, first_inv);
@@ -126,8 +144,16 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 		}
 		idx = (idx + 1) & mask;
 		probes++;
+		const SlotView nx = census_peek(tab + idx);
+		k = nx.k; v = nx.v; f = nx.f;
 	}
 	return false;
+}
+
+__device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+{
+	const u64 idx = (u64)census_hash(klo, khi) & mask;
+	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
 }
 
 extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
@@ -144,7 +170,7 @@ struct CensusArgs {
 	u64 *stats;
 };
 
-constexpr int kCensusWaves = 8;           // waves per workgroup: they share the LDS table
+constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the LDS table
 constexpr int kCensusMaxStride = 64;      // 64 rows x 64 B = 4 KiB per wave tile = 4 x 16 B per lane
 
 __device__ __forceinline__ void census_wave_fence()
@@ -154,37 +180,45 @@ __device__ __forceinline__ void census_wave_fence()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct CensusTileRegs { uint4 v[4]; int32_t code; };
+constexpr int kCensusMaxSub = 4;          // 64-row tiles per wave and step
+constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step: 5 x 16 B per lane in flight
+constexpr int kCensusQueue = 128;         // flush queue entries (16 B key + 4 B row): fewer than 64 left over + one tile's 64
 
-// The 64 rows of tile t are one contiguous, 16-byte aligned byte range: 16 bytes per lane and step, as unconditional
-// raw-buffer loads whose descriptor ends at the tile's last valid dword (the hardware drops what lies beyond it, so
-// like the tile pass this may read up to 3 bytes past the end of the matrix).
-__device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t, int lane, CensusTileRegs &rg)
+struct CensusTileRegs { uint4 v[5]; int32_t code[kCensusMaxSub]; };
+
+// The R x 64 rows of step t are one contiguous, 16-byte aligned byte range: 16 bytes per lane and load, as unconditional
+// raw-buffer loads whose descriptor ends at the range's last valid dword (the hardware drops what lies beyond it, so
+// like the tile pass this may read up to 3 bytes past the end of the matrix).  What a wave has in flight is what
+// bounds this kernel when everything is counted in LDS (one 1 KiB tile per wave: 2 TB/s), hence R tiles per step.
+__device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t, int R, int lane, CensusTileRegs &rg)
 {
+	const int step_bytes = R * 64 * a.bc_stride;
 	const int64_t total = a.n * (int64_t)a.bc_stride;
-	const int64_t base = t * 64 * (int64_t)a.bc_stride;
+	const int64_t base = t * (int64_t)step_bytes;
 	const int64_t rem = total - base;
-	const int bytes = (int)(rem < 64 * (int64_t)a.bc_stride ? rem : 64 * (int64_t)a.bc_stride);
-	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.bc) + base, 0, (bytes + 3) & ~3, 0x00020000);
+	const int bytes = rem <= 0 ? 0 : (int)(rem < step_bytes ? rem : step_bytes);      // a step past the end loads nothing
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.bc) + (rem <= 0 ? 0 : base), 0, (bytes + 3) & ~3, 0x00020000);
+	// No branches around the loads — a load inside a conditional block is waited for at the end of that block, which
+	// serialises the five of them and the counting behind them; what lies beyond the step is clipped by the descriptor.
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const int off = lane * 16 + k * 1024;
-		if (k * 1024 < 64 * a.bc_stride) {          // wave-uniform
-			const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-			memcpy(&rg.v[k], &v, 16);
-		}
+	for (int k = 0; k < 5; k++) {
+		const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + k * 1024, 0, 0);
+		memcpy(&rg.v[k], &v, 16);
 	}
-	const int64_t r = t * 64 + lane;
-	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign), 0, a.assign ? (int)(a.n * 4 > 0x7ffffffc ? 0x7ffffffc : a.n * 4) : 0, 0x00020000);
-	rg.code = kAssignNone;
-	if (a.assign != nullptr) rg.code = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(r * 4), 0, 0);
+	const int64_t r0 = t * R * 64;
+	const int64_t left = a.n - r0;
+	const int rows = a.assign == nullptr || left <= 0 ? 0 : (int)(left < R * 64 ? left : R * 64);
+	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign) + (rows ? r0 : 0), 0, rows * 4, 0x00020000);
+#pragma unroll
+	for (int j = 0; j < kCensusMaxSub; j++)
+		rg.code[j] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, j < R ? (j * 64 + lane) * 4 : 0x7ffffff0, 0, 0);
 }
 
-// One row per lane, one 64-row tile per wave and step.  A wave keeps the next tile's bytes in registers while it
+// One row per lane, R 64-row tiles per wave and step.  A wave keeps the next step's bytes in registers while it
 // works on the current one (its private LDS tile), so the only workgroup barriers are the two around the loop.
 // Keys are counted in the workgroup's LDS table; a key that finds no room there within kLdsProbes slots goes
 // straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
-__global__ __launch_bounds__(kCensusWaves * 64, 2) void census_kernel(const CensusArgs a, const int tile_slot)
+template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot)
 {
 	LdsSlot *lt = reinterpret_cast<LdsSlot *>(census_smem);
 	const int tid = threadIdx.x;
@@ -198,30 +232,44 @@ __global__ __launch_bounds__(kCensusWaves * 64, 2) void census_kernel(const Cens
 	__syncthreads();
 
 	const int stride = a.bc_stride;
-	const int64_t ntiles = (a.n + 63) / 64;
+	const int step_bytes = R * 64 * stride;
+	const int64_t nsteps = (a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64);
 	const int64_t step = (int64_t)gridDim.x * nwave;
 	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
 	CensusTileRegs rg;
-	bool pend = false;
-	u64 pklo = 0, pkhi = 0, pfirst = 0;
+	uint4 *qkey = reinterpret_cast<uint4 *>(tile);                 // the flush queue reuses the wave's tile
+	u32 *qrel = reinterpret_cast<u32 *>(tile + kCensusQueue * 16);
 	int64_t t = (int64_t)blockIdx.x * nwave + wave;
-	if (t < ntiles) census_load_tile(a, t, lane, rg);
-	for (; t < ntiles; t += step) {
-		const int bytes = 64 * stride;
+	census_load_tile(a, t, R, lane, rg);
+	for (; t < nsteps; t += step) {
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
+		for (int k = 0; k < 5; k++) {
 			const int off = lane * 16 + k * 1024;
-			if (off < bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];
+			if (off < step_bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];
 		}
-		const int32_t code = rg.code;
+		// which of the step's rows are counted, worked out BEFORE the next step's loads are issued: nothing below may
+		// wait for a register that a load of this or an earlier step wrote, or it waits for the new loads as well
+		u32 take = 0xFu;
+		if (a.assign != nullptr) {
+			take = 0u;
+#pragma unroll
+			for (int j = 0; j < kCensusMaxSub; j++) take |= (rg.code[j] == kAssignNone ? 1u : 0u) << j;
+		}
 		census_wave_fence();
-		if (t + step < ntiles) census_load_tile(a, t + step, lane, rg);       // in flight while this tile is counted
-		const int64_t r = t * 64 + lane;
-		bool fresh = false;
-		u64 nklo = 0, nkhi = 0, nfirst = 0;
-		if (r < a.n && code == kAssignNone) {
+		census_load_tile(a, t + step, R, lane, rg);       // in flight while this step is counted
+		// Counting touches LDS only.  Keys the LDS table had no room for are parked in registers (one per lane and tile)
+		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
+		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
+		u64 pklo[R], pkhi[R];
+		u32 parked = 0u;
+#pragma unroll
+		for (int j = 0; j < R; j++) {
+		const int64_t r = (t * R + j) * 64 + lane;
+		pklo[j] = 0ull;
+		pkhi[j] = 0ull;
+		if (r < a.n && ((take >> j) & 1u)) {
 			// the row as dwords: aligned LDS reads funnel-shifted to the row's first byte
-			const int rs = lane * stride;
+			const int rs = (j * 64 + lane) * stride;
 			const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
 			const u32 sh = (u32)rs & 3u;
 			u32 kw[4] = {0u, 0u, 0u, 0u};
@@ -235,11 +283,11 @@ __global__ __launch_bounds__(kCensusWaves * 64, 2) void census_kernel(const Cens
 					lo = hi;
 #pragma unroll
 					for (int b = 0; b < 4; b++) {
-						const int j = 4 * q + b;
-						if (j < kMaxCensusLen) {
+						const int jj = 4 * q + b;
+						if (jj < kMaxCensusLen) {
 							const u32 c = lut[(x >> (8 * b)) & 0xFFu] & live;
 							if (c == 0u) live = 0u;                      // bytes after the first NUL are padding
-							kw[(j + 1) >> 3] |= c << (4 * ((j + 1) & 7));
+							kw[(jj + 1) >> 3] |= c << (4 * ((jj + 1) & 7));
 						}
 					}
 				}
@@ -288,23 +336,43 @@ __global__ __launch_bounds__(kCensusWaves * 64, 2) void census_kernel(const Cens
 						p++;
 					}
 				}
-				if (!done) { fresh = true; nklo = klo; nkhi = khi; nfirst = first_inv; }
+				if (!done) { pklo[j] = klo; pkhi[j] = khi; parked |= 1u << j; }
 			}
 		}
-		// Keys the LDS table had no room for wait in their lane's registers until enough lanes hold one: the HBM
-		// insert is a chain of dependent round trips, worth paying for many keys at once rather than for a few.
-		if (__any(fresh && pend)) {
-			if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
-			pend = false;
 		}
-		if (fresh) { pend = true; pklo = nklo; pkhi = nkhi; pfirst = nfirst; }
-		if (__popcll(__ballot(pend)) >= 32) {
-			if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
-			pend = false;
+		census_wave_fence();
+		// The parked keys, packed densely through the (now dead) tile so that one insert serves up to 64 of them: its
+		// dependent round trips are paid per call, not per key.  (Fetching the slots a step ahead of the insert was tried:
+		// no gain — what bounds this leg is the rate of scattered atomics, not their latency.)
+		if (__any(parked != 0u)) {
+			int qn = 0;
+#pragma unroll
+			for (int j = 0; j < R; j++) {
+				const bool has = ((parked >> j) & 1u) != 0u;
+				const u64 bal = __ballot(has);
+				if (has) {
+					const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+					qkey[pos] = make_uint4((u32)pklo[j], (u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32));
+					qrel[pos] = (u32)(j * 64 + lane);
+				}
+				qn += __popcll(bal);
+				while (qn >= 64 || (j == R - 1 && qn > 0)) {
+					census_wave_fence();
+					const int cnt = qn < 64 ? qn : 64;
+					if (lane < cnt) {
+						const uint4 kq = qkey[qn - cnt + lane];
+						const u32 rel = qrel[qn - cnt + lane];
+						const u64 klo = (u64)kq.x | ((u64)kq.y << 32), khi = (u64)kq.z | ((u64)kq.w << 32);
+						const u64 first_inv = ~(u64)(a.row_base + t * R * 64 + rel);
+						if (!census_insert(a.tab, a.mask, klo, khi, 1ull, first_inv, claimed)) overflow++;
+					}
+					qn -= cnt;
+					census_wave_fence();
+				}
+			}
 		}
 		census_wave_fence();
 	}
-	if (pend && !census_insert(a.tab, a.mask, pklo, pkhi, 1ull, pfirst, claimed)) overflow++;
 	__syncthreads();
 	// merge the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of them
 	// hold (the frequent ones) are not hit by all of them at the same moment
@@ -389,7 +457,10 @@ hipError_t census_create(Census **out, hipStream_t st)
 		if (lg >= 10 && lg <= 32) init_slots = 1ull << lg;
 	}
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
 	*out = cs;
 	return hipSuccess;
@@ -448,7 +519,11 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
                       int n_cu, hipStream_t st)
 {
 	if (bc_stride > kCensusMaxStride) return hipErrorInvalidValue;
-	const int tile_slot = (64 * bc_stride + 15) & ~15;
+	int R = kCensusStepBytes / (64 * bc_stride);
+	R = R < 1 ? 1 : (R > kCensusMaxSub ? kCensusMaxSub : R);
+	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
+	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
+	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
 	const size_t lds = kLdsSlots * sizeof(LdsSlot) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
 	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
 	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
@@ -471,7 +546,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 			if (room >= least) nr = nr < room ? nr : room;        // a smaller bite fits the table as it is
 			else e = census_reserve(cs, (u64)nr, n_cu, st);       // no room worth a launch: grow for the whole bite
 			if (e != hipSuccess) return e;
-			if (nr < n - o && nr >= 64) nr &= ~(int64_t)63;       // later launches start on a tile (and dword) boundary of the matrix
+			if (nr < n - o && nr >= 64) nr &= ~(int64_t)63;       // later launches start on a 16-byte boundary of the matrix
 		}
 		cs->distinct += (u64)nr;                              // upper bound until the next census_stats()
 		CensusArgs a;
@@ -484,10 +559,15 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.tab = cs->tab;
 		a.mask = cs->slots - 1;
 		a.stats = cs->stats;
-		const int64_t groups = (nr + 64 * kCensusWaves - 1) / (64 * kCensusWaves);
-		int grid = n_cu * (lds <= 80 * 1024 ? 2 : 1);
+		const int64_t groups = (nr + (int64_t)64 * R * kCensusWaves - 1) / ((int64_t)64 * R * kCensusWaves);
+		int grid = n_cu;
 		if (grid > groups) grid = (int)groups;
-		census_kernel<<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot);
+		switch (R) {
+		case 1: census_kernel<1><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
+		case 2: census_kernel<2><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
+		case 3: census_kernel<3><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
+		default: census_kernel<4><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
+		}
 		e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
