@@ -23,6 +23,10 @@ mu = 36.0 - 16.0 * (torch.arange(150, device=dev, dtype=torch.float32) / 149) **
 def gen(kind):
     if kind == "uniform Q2-Q40":
         return torch.randint(35, 74, (n, 150), dtype=torch.uint8, device=dev, generator=g)
+    if kind == "every row all '#' (no scan ever breaks)":
+        return torch.full((n, 150), ord("#"), dtype=torch.uint8, device=dev)
+    if kind == "uniform Q2-Q30 (drifts down: long scans)":
+        return torch.randint(35, 64, (n, 150), dtype=torch.uint8, device=dev, generator=g)
     q = torch.empty((n, 150), dtype=torch.uint8, device=dev)
     for r0 in range(0, n, 2_000_000):
         m = min(2_000_000, n - r0)
@@ -35,7 +39,7 @@ def gen(kind):
 
 
 lk = torch.empty((n,), dtype=torch.int16, device=dev)
-for kind in ("uniform Q2-Q40", "read-like", "read-like + 5% all-'#' rows"):
+for kind in ("uniform Q2-Q40", "every row all '#' (no scan ever breaks)", "uniform Q2-Q30 (drifts down: long scans)", "read-like", "read-like + 5% all-'#' rows"):
     q = gen(kind)
     exp = orc.trim_batch(q[:200_000].cpu().numpy(), None, 20)
     for name, ctx in ctxs:
@@ -50,5 +54,5 @@ for kind in ("uniform Q2-Q40", "read-like", "read-like + 5% all-'#' rows"):
                 run()
             ts.append(ctx.timer_stop() / 10)
         ms = sorted(ts)[2]
-        print(f"{kind:30s} {name:5s}: {ms:7.4f} ms  {n / ms / 1e6:6.2f} G reads/s  {152 * n / ms / 1e6 / 80:5.1f}% of 8 TB/s", flush=True)
+        print(f"{kind:42s} {name:5s}: {ms:7.4f} ms  {n / ms / 1e6:6.2f} G reads/s  {152 * n / ms / 1e6 / 80:5.1f}% of 8 TB/s", flush=True)
     del q
