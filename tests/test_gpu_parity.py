@@ -827,6 +827,29 @@ def test_census_matches_oracle(ctx, oracle, n, L, stride, n_hot, hot_frac):
     assert st["counted"] == n and st["rejected"] == 0 and sum(c for _, c, _ in got) == n
 
 
+@pytest.mark.parametrize("stride", [8, 20, 21, 26, 27, 40, 41, 64])
+def test_census_every_step_shape(ctx, oracle, stride):
+    """A wave step is 4, 3, 2 or 1 tiles of 64 rows depending on the row pitch (5 KiB per step): row counts around the
+    tile, step and workgroup boundaries of each, with and without assignment codes, ragged barcodes."""
+    L = min(stride, 31)
+    R = max(1, min(4, 5120 // (64 * stride)))
+    rng = np.random.default_rng(stride)
+    for n in (1, 63, 64, 65, 64 * R - 1, 64 * R, 64 * R + 1, 64 * R * 16 - 1, 64 * R * 16 + 1, 64 * R * 16 * 3 + 77):
+        bc = random_barcodes(n, L, stride, 5, 0.6, seed=n + stride, alphabet=b"ACGTNacgtn+")
+        short = rng.random(n) < 0.3                         # some barcodes end early: NUL padding inside L
+        cut = rng.integers(0, L, size=n)
+        for r in np.nonzero(short)[0]:
+            bc[r, cut[r]:] = 0
+        assign = np.where(rng.random(n) < 0.5, -1, rng.integers(0, 7, size=n)).astype(np.int32)
+        for asg in (None, assign):
+            ctx.census_reset()
+            ctx.census_add(bc, L=L, assign=asg)
+            got, total = ctx.census_entries()
+            want = oracle.census(bc, L=L, assign=asg)
+            assert total == len(want) and got == want, (stride, n, asg is not None)
+            assert ctx.census_stats()["counted"] == (n if asg is None else int((asg == -1).sum()))
+
+
 def test_census_only_unassigned_rows_batches_and_row_base(ctx, oracle):
     """The dry-run use (src/fasta_demultiplex.rs:190): only reads with no sample within max_diff are counted; fed in
     batches, in any order, the first-seen index is still the smallest global row."""
