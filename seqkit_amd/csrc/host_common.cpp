@@ -2,6 +2,7 @@
 #include "host_common.h"
 
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -783,6 +784,16 @@ void GzWriter::close()
 // ---- stdout ------------------------------------------------------------------------------------------------
 void Out::write(const char *p, size_t n)
 {
+	if (n >= (1u << 20)) {                                     // a block's worth: no second copy through the buffer
+		flush();
+		size_t off = 0;
+		while (off < n) {
+			const ssize_t w = ::write(1, p + off, n - off);
+			if (w <= 0) break;
+			off += (size_t)w;
+		}
+		return;
+	}
 	buf_.append(p, n);
 	if (buf_.size() >= (1u << 20)) flush();
 }
@@ -1008,7 +1019,7 @@ struct RawSource {
 
 }  // namespace
 
-static size_t count_newlines(const char *p, size_t n)
+static size_t count_newlines_swar(const char *p, size_t n)
 {
 	size_t cnt = 0, i = 0;
 	const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full, knl = 0x0A0A0A0A0A0A0A0Aull;
@@ -1023,9 +1034,32 @@ static size_t count_newlines(const char *p, size_t n)
 	return cnt;
 }
 
+// 128 bytes per iteration where the CPU has AVX2 (the cutter thread of the block pipeline looks at every input byte
+// once, here: 2.9 -> 9 GB/s)
+__attribute__((target("avx2"))) static size_t count_newlines_avx2(const char *p, size_t n)
+{
+	size_t cnt = 0, i = 0;
+	const __m256i nl = _mm256_set1_epi8('\n');
+	for (; i + 128 <= n; i += 128) {
+		const __m256i a = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i)), nl);
+		const __m256i b = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i + 32)), nl);
+		const __m256i c = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i + 64)), nl);
+		const __m256i d = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i + 96)), nl);
+		cnt += (size_t)__builtin_popcountll((uint64_t)(uint32_t)_mm256_movemask_epi8(a) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(b) << 32));
+		cnt += (size_t)__builtin_popcountll((uint64_t)(uint32_t)_mm256_movemask_epi8(c) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(d) << 32));
+	}
+	return cnt + count_newlines_swar(p + i, n - i);
+}
+
+static size_t count_newlines(const char *p, size_t n)
+{
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	return avx2 ? count_newlines_avx2(p, n) : count_newlines_swar(p, n);
+}
+
 // consume up to `want` lines of [p, p+n): returns the bytes consumed (ending right after a newline, or n when the
 // buffer runs out first) and subtracts the lines found from `want`
-static size_t take_lines(const char *p, size_t n, size_t &want)
+static size_t take_lines_swar(const char *p, size_t n, size_t &want)
 {
 	size_t i = 0;
 	const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full, knl = 0x0A0A0A0A0A0A0A0Aull;
@@ -1045,11 +1079,30 @@ static size_t take_lines(const char *p, size_t n, size_t &want)
 	return i;
 }
 
+__attribute__((target("avx2"))) static size_t take_lines_avx2(const char *p, size_t n, size_t &want)
+{
+	size_t i = 0;
+	const __m256i nl = _mm256_set1_epi8('\n');
+	while (want > 0 && i + 64 <= n) {
+		const __m256i a = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i)), nl);
+		const __m256i b = _mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i + 32)), nl);
+		const size_t c = (size_t)__builtin_popcountll((uint64_t)(uint32_t)_mm256_movemask_epi8(a) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(b) << 32));
+		if (c < want) { want -= c; i += 64; continue; }
+		break;                                                   // the last wanted newline is inside these 64 bytes
+	}
+	return i + take_lines_swar(p + i, n - i, want);
+}
+
+static size_t take_lines(const char *p, size_t n, size_t &want)
+{
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	return avx2 ? take_lines_avx2(p, n, want) : take_lines_swar(p, n, want);
+}
+
 struct RecordBlocks::Impl {
 	RawSource src;
 	int lpr;
-	std::string buf;
-	size_t scan = 0, lines = 0;
+	std::string buf;                  // bytes read beyond the last block handed out
 	bool eof = false;
 	Impl(const std::string &path, int l) : src(path), lpr(l) {}
 };
@@ -1059,30 +1112,30 @@ RecordBlocks::~RecordBlocks() { delete impl_; }
 
 bool RecordBlocks::next(size_t nrec, std::string &blk)
 {
+	// The block is put together in the caller's string: what the previous call left over, then fresh chunks until it
+	// holds the wanted lines; only the tail beyond the cut (less than one chunk) is copied, into the next call's start.
 	Impl &m = *impl_;
 	blk.clear();
+	blk.swap(m.buf);
 	const size_t want_lines = nrec * (size_t)m.lpr;
-	size_t cut = std::string::npos;
+	size_t scan = 0, lines = 0, cut;
 	for (;;) {
-		// count newlines in what is buffered
-		if (m.scan < m.buf.size() && m.lines < want_lines) {
-			size_t left = want_lines - m.lines;
-			m.scan += take_lines(m.buf.data() + m.scan, m.buf.size() - m.scan, left);
-			m.lines = want_lines - left;
+		if (scan < blk.size() && lines < want_lines) {
+			size_t left = want_lines - lines;
+			scan += take_lines(blk.data() + scan, blk.size() - scan, left);
+			lines = want_lines - left;
 		}
-		if (m.lines >= want_lines) { cut = m.scan; break; }
-		if (m.eof) { cut = m.buf.size(); break; }
-		const size_t old = m.buf.size(), chunk = 4u << 20;
-		m.buf.resize(old + chunk);
-		const size_t r = m.src.read_some(&m.buf[old], chunk);
-		m.buf.resize(old + r);
+		if (lines >= want_lines) { cut = scan; break; }
+		if (m.eof) { cut = blk.size(); break; }
+		const size_t old = blk.size(), chunk = 4u << 20;
+		blk.resize(old + chunk);
+		const size_t r = m.src.read_some(&blk[old], chunk);
+		blk.resize(old + r);
 		if (r == 0) m.eof = true;
 	}
-	if (cut == 0) return false;
-	blk.assign(m.buf, 0, cut);
-	m.buf.erase(0, cut);
-	m.scan = 0;
-	m.lines = 0;
+	if (cut == 0) { blk.clear(); return false; }
+	m.buf.assign(blk, cut, std::string::npos);
+	blk.resize(cut);
 	return true;
 }
 
@@ -1096,70 +1149,137 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 	if (nthreads > 32) nthreads = 32;
 	if (const char *e = getenv("SEQKIT_BLOCK_BYTES")) block_bytes = (size_t)atoll(e);      // tests use tiny blocks
 
-	struct Pending { std::shared_ptr<std::string> data; std::future<std::shared_ptr<BlockResult>> fut; };
+	// Three roles.  This thread reads and cuts (it looks at every input byte once, to count newlines); workers turn
+	// blocks into output; a writer thread takes the results in input order and writes them, so that reading the input and
+	// writing the output overlap.  Blocks are plain uninitialised buffers: value-initialising 8 MiB per block and copying
+	// every result through the output buffer were half of this thread's time.
+	struct Block { std::unique_ptr<char[]> p; size_t n = 0, cap = 0; };
+	struct Pending { std::shared_ptr<Block> data; std::future<std::shared_ptr<BlockResult>> fut; };
 	std::deque<Pending> inflight;
-	auto drain_one = [&]() -> bool {      // returns false when the pipeline must stop (error raised)
-		std::shared_ptr<BlockResult> r = inflight.front().fut.get();
-		inflight.pop_front();
-		out().write(r->out);
-		if (!r->err.empty()) {
-			for (auto &p : inflight) p.fut.wait();
-			if (r->err_code == 101) panic(r->err.c_str());
-			error("%s", r->err.c_str());
+	std::mutex m;
+	std::condition_variable cv_push, cv_pop;
+	bool closed = false, failed = false;
+	std::shared_ptr<BlockResult> failure;
+	std::thread writer([&]() {
+		for (;;) {
+			Pending pd;
+			{
+				std::unique_lock<std::mutex> lk(m);
+				cv_push.wait(lk, [&] { return !inflight.empty() || closed; });
+				if (inflight.empty()) return;
+				pd = std::move(inflight.front());
+				inflight.pop_front();
+			}
+			cv_pop.notify_one();
+			std::shared_ptr<BlockResult> r = pd.fut.get();
+			out().write(r->out);
+			if (!r->err.empty()) {
+				// the output of the records before the bad one is out; let the blocks in flight finish, then stop
+				std::unique_lock<std::mutex> lk(m);
+				failed = true;
+				failure = r;
+				while (!inflight.empty()) {
+					Pending q = std::move(inflight.front());
+					inflight.pop_front();
+					lk.unlock();
+					q.fut.wait();
+					lk.lock();
+				}
+				lk.unlock();
+				cv_pop.notify_all();
+				return;
+			}
 		}
-		return true;
-	};
+	});
 
 	std::string carry;
 	bool eof = false;
+	// SEQKIT_PROF=1: where this thread's time went, on stderr when the input is through
+	double t_alloc = 0, t_read = 0, t_count = 0, t_wait = 0, t_spawn = 0;
+	auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+	const bool prof = getenv("SEQKIT_PROF") != nullptr;
 	while (!eof) {
+		{
+			std::lock_guard<std::mutex> lk(m);
+			if (failed) break;
+		}
+		double t0 = now();
 		// fill one block: previous carry + fresh bytes, then cut after the last newline that completes a record
-		auto blk = std::make_shared<std::string>();
-		blk->swap(carry);
-		const size_t start = blk->size();
-		blk->resize(start + block_bytes);
+		auto blk = std::make_shared<Block>();
+		blk->cap = carry.size() + block_bytes;
+		blk->p.reset(new char[blk->cap]);
+		memcpy(blk->p.get(), carry.data(), carry.size());
+		const size_t start = carry.size();
 		size_t got = 0;
+		t_alloc += now() - t0; t0 = now();
 		while (got < block_bytes) {
-			const size_t r = src.read_some(&(*blk)[start + got], block_bytes - got);
+			const size_t r = src.read_some(blk->p.get() + start + got, block_bytes - got);
 			if (r == 0) { eof = true; break; }
 			got += r;
 		}
-		blk->resize(start + got);
-		size_t cut = blk->size();
+		blk->n = start + got;
+		carry.clear();
+		t_read += now() - t0; t0 = now();
 		if (!eof) {
-			// keep whole records only: count the block's newlines eight bytes at a time, then walk back from the end over
-			// the lines of the last, incomplete record
-			const size_t lines = count_newlines(blk->data(), blk->size());
+			// keep whole records only: count the block's newlines, then walk back from the end over the lines of the last,
+			// incomplete record
+			const char *base = blk->p.get();
+			const size_t lines = count_newlines(base, blk->n);
 			size_t drop = lines % (size_t)lines_per_record;
-			size_t last_rec_end = 0;
+			size_t cut = 0;
 			if (lines > drop) {
-				const char *base = blk->data();
-				const char *nl = static_cast<const char *>(memrchr(base, '\n', blk->size()));
+				const char *nl = static_cast<const char *>(memrchr(base, '\n', blk->n));
 				while (drop > 0) { nl = static_cast<const char *>(memrchr(base, '\n', (size_t)(nl - base))); drop--; }
-				last_rec_end = (size_t)(nl - base) + 1;
+				cut = (size_t)(nl - base) + 1;
 			}
-			cut = last_rec_end;
 			if (cut == 0) {                    // a record larger than the block: grow and retry
-				carry.swap(*blk);
+				carry.assign(base, blk->n);
 				block_bytes *= 2;
 				continue;
 			}
-			carry.assign(*blk, cut, std::string::npos);
-			blk->resize(cut);
+			carry.assign(base + cut, blk->n - cut);
+			blk->n = cut;
 		}
-		if (blk->empty() && eof) break;
+		if (blk->n == 0 && eof) break;
+		t_count += now() - t0; t0 = now();
 		const bool last = eof;
 		Pending pd;
 		pd.data = blk;
 		pd.fut = std::async(std::launch::async, [blk, last, &fn]() {
 			auto res = std::make_shared<BlockResult>();
-			fn(blk->data(), blk->size(), last, *res);
+			fn(blk->p.get(), blk->n, last, *res);
 			return res;
 		});
-		inflight.push_back(std::move(pd));
-		while (inflight.size() >= nthreads) drain_one();
+		t_spawn += now() - t0; t0 = now();
+		{
+			std::unique_lock<std::mutex> lk(m);
+			cv_pop.wait(lk, [&] { return inflight.size() < nthreads || failed; });
+			inflight.push_back(std::move(pd));         // (after a failure the writer is gone: the destructor of the future waits)
+		}
+		cv_push.notify_one();
+		t_wait += now() - t0;
 	}
-	while (!inflight.empty()) drain_one();
+	{
+		std::lock_guard<std::mutex> lk(m);
+		closed = true;
+	}
+	cv_push.notify_one();
+	writer.join();
+	if (prof) fprintf(stderr, "block pipeline, reading thread: allocate %.3f read %.3f cut %.3f hand over %.3f wait for a free worker %.3f s\n", t_alloc, t_read, t_count, t_spawn, t_wait);
+	{
+		std::unique_lock<std::mutex> lk(m);
+		while (!inflight.empty()) {                    // blocks queued after the writer stopped
+			Pending q = std::move(inflight.front());
+			inflight.pop_front();
+			lk.unlock();
+			q.fut.wait();
+			lk.lock();
+		}
+	}
+	if (failure) {
+		if (failure->err_code == 101) panic(failure->err.c_str());
+		error("%s", failure->err.c_str());
+	}
 }
 
 }  // namespace host

@@ -41,7 +41,7 @@ import resource  # noqa: E402
 def t(cmd, cwd):
     r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("E2E_STDERR") else subprocess.DEVNULL)
     dt = time.perf_counter() - t0
     r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     print(f"    cpu user {r1.ru_utime - r0.ru_utime:.1f} s sys {r1.ru_stime - r0.ru_stime:.1f} s", flush=True)
