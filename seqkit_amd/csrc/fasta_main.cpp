@@ -608,7 +608,7 @@ static void close_outputs()
 
 static inline size_t strip_nl(const host::Line &l) { return l.n - ((l.n && l.p[l.n - 1] == '\n') ? 1 : 0); }
 
-static void demux_block(const DemuxCfg &cfg, const std::string *blk /* fastq1, fastq2, index1, index2 */, uint64_t base /* clusters before this block */, DemuxOut &res)
+static void demux_block(const DemuxCfg &cfg, const host::Bytes *blk /* fastq1, fastq2, index1, index2 */, uint64_t base /* clusters before this block */, DemuxOut &res)
 {
 	std::vector<Sample> &samples = *cfg.samples;
 	const int S = (int)samples.size();
@@ -891,17 +891,26 @@ static int demultiplex(int argc, char **argv)
 	if (dry_run > 0) check(sk_census_reset(host::gpu()), "sk_census_reset");
 
 	DemuxCfg cfg{&samples, barcode_len, paired_end, nindex, do_mask, do_trim, do_mask ? mask_q : trim_q, dry_run > 0};
-	unsigned nthreads = std::thread::hardware_concurrency();
+	unsigned nthreads = host::cpu_budget();
 	if (const char *e = getenv("SEQKIT_THREADS")) nthreads = (unsigned)atoi(e);
 	if (nthreads < 1) nthreads = 1;
 	if (nthreads > 16) nthreads = 16;
 	size_t block_records = kDemuxBlockRecords;
 	if (const char *e = getenv("SEQKIT_BLOCK_RECORDS")) block_records = (size_t)atoll(e);     // tests use tiny blocks
 
-	struct Pending { std::shared_ptr<std::vector<std::string>> data; std::future<std::shared_ptr<DemuxOut>> fut; };
+	struct Pending { std::shared_ptr<std::vector<host::Bytes>> data; std::future<std::shared_ptr<DemuxOut>> fut; };
 	std::deque<Pending> inflight;
+	// SEQKIT_PROF=1: where the main thread's time went (stderr, at the end)
+	const bool prof = getenv("SEQKIT_PROF") != nullptr;
+	auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+	double t_read = 0, t_wait = 0, t_hand = 0, t_cut_wait = 0;
+	const double t_loop0 = now();
 	auto drain_one = [&]() {
+		double t0 = now();
 		std::shared_ptr<DemuxOut> r = inflight.front().fut.get();
+		t_wait += now() - t0;
+		t0 = now();
+		struct Hand { double &acc, t0; decltype(now) &clk; ~Hand() { acc += clk() - t0; } } hand{t_hand, t0, now};
 		inflight.pop_front();
 		fputs(r->warn.c_str(), stderr);
 		total_reads += r->nclusters;                                        // :169
@@ -909,8 +918,8 @@ static int demultiplex(int argc, char **argv)
 		for (int s = 0; s < S; s++) samples[s].total_reads += r->per_sample[s];
 		if (!cfg.dry_run)
 			for (int s = 0; s < S; s++) {
-				if (!r->out1[s].empty()) samples[s].out[0]->write(r->out1[s]);
-				if (paired_end && !r->out2[s].empty()) samples[s].out[1]->write(r->out2[s]);
+				if (!r->out1[s].empty()) samples[s].out[0]->write(std::move(r->out1[s]));
+				if (paired_end && !r->out2[s].empty()) samples[s].out[1]->write(std::move(r->out2[s]));
 			}
 		for (auto &e : r->extras.ents) extra_barcodes.add(e.label, e.first, e.count);
 		if (!r->err.empty()) {
@@ -921,20 +930,58 @@ static int demultiplex(int argc, char **argv)
 		}
 	};
 
+	// A reader thread cuts the input files into blocks (all files at the same record count) a few blocks ahead; this
+	// thread starts a worker per block and hands the results on in input order.
+	struct Cut { std::shared_ptr<std::vector<host::Bytes>> data; size_t want; };
+	std::deque<Cut> cuts;
+	std::mutex cm;
+	std::condition_variable cv_cut, cv_room;
+	bool cut_done = false;
+	std::thread reader([&]() {
+		uint64_t ahead = 0;
+		for (;;) {
+			size_t want = block_records;
+			if (dry_run > 0) {                                              // :248 — blocks are cut so that exactly N clusters are read
+				if (ahead >= dry_run) break;
+				want = (size_t)std::min<uint64_t>(want, dry_run - ahead);
+			}
+			auto data = std::make_shared<std::vector<host::Bytes>>(4);
+			const double tr0 = now();
+			if (!files[0]->next(want, (*data)[0])) break;                   // :117 — the loop is driven by fastq_1
+			for (int f = 1; f < 4; f++) if (files[f]) files[f]->next(want, (*data)[f]);
+			t_read += now() - tr0;
+			ahead += want;                           // a short block is the last one
+			{
+				std::unique_lock<std::mutex> lk(cm);
+				cv_room.wait(lk, [&] { return cuts.size() < 4; });
+				cuts.push_back({data, want});
+			}
+			cv_cut.notify_one();
+		}
+		{
+			std::lock_guard<std::mutex> lk(cm);
+			cut_done = true;
+		}
+		cv_cut.notify_one();
+	});
 	uint64_t submitted = 0;
 	for (;;) {
-		size_t want = block_records;
-		if (dry_run > 0) {                                                  // :248 — blocks are cut so that exactly N clusters are read
-			if (submitted >= dry_run) break;
-			want = (size_t)std::min<uint64_t>(want, dry_run - submitted);
+		Cut c;
+		{
+			const double tw0 = now();
+			std::unique_lock<std::mutex> lk(cm);
+			cv_cut.wait(lk, [&] { return !cuts.empty() || cut_done; });
+			t_cut_wait += now() - tw0;
+			if (cuts.empty()) break;
+			c = std::move(cuts.front());
+			cuts.pop_front();
 		}
-		auto data = std::make_shared<std::vector<std::string>>(4);
-		if (!files[0]->next(want, (*data)[0])) break;                       // :117 — the loop is driven by fastq_1
-		for (int f = 1; f < 4; f++) if (files[f]) files[f]->next(want, (*data)[f]);
+		cv_room.notify_one();
+		auto data = c.data;
 		Pending pd;
 		pd.data = data;
 		const uint64_t base = submitted;
-		submitted += want;                           // a short block is the last one
+		submitted += c.want;
 		pd.fut = std::async(std::launch::async, [data, base, &cfg]() {
 			auto res = std::make_shared<DemuxOut>();
 			demux_block(cfg, data->data(), base, *res);
@@ -943,7 +990,9 @@ static int demultiplex(int argc, char **argv)
 		inflight.push_back(std::move(pd));
 		while (inflight.size() >= nthreads) drain_one();
 	}
+	reader.join();
 	while (!inflight.empty()) drain_one();
+	const double t_loop1 = now();
 
 	// The blocks were dealt to several contexts (SEQKIT_GPUS devices x SEQKIT_CTXS_PER_GPU): their additive counters —
 	// the reference's total_reads / identified_reads / sample.total_reads, :108-109,169,177-178 — are summed over all of
@@ -970,6 +1019,8 @@ static int demultiplex(int argc, char **argv)
 	}
 	close_outputs();
 	host::out().flush();
+	if (prof) fprintf(stderr, "demultiplex: block loop %.3f s (reader thread: read and cut %.3f; main thread: wait for a cut block %.3f, wait for the oldest "
+	                          "result %.3f, hand it on %.3f), finishing the outputs %.3f s\n", t_loop1 - t_loop0, t_read, t_cut_wait, t_wait, t_hand, now() - t_loop1);
 	fprintf(stderr, "%llu / %llu (%s%%) clusters carried a barcode matching one of the provided samples.\n",      // :263-264
 	        (unsigned long long)identified_reads, (unsigned long long)total_reads,
 	        host::fmt_pct((double)identified_reads / (double)total_reads * 100.0).c_str());

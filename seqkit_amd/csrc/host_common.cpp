@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <immintrin.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -22,6 +23,29 @@
 #include <thread>
 
 namespace host {
+
+// hardware_concurrency() counts the machine; a container is often allowed a fraction of it (cgroup cpu.max), and sizing
+// the pools for 256 CPUs under a quota of 16 only buys throttling stalls for every thread, the reader's included.
+unsigned cpu_budget()
+{
+	static const unsigned budget = [] {
+		unsigned n = std::thread::hardware_concurrency();
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (unsigned)c < n) n = (unsigned)c; }
+		long long quota = -1, period = 0;
+		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "max 100000" or "1600000 100000"
+			char q[32];
+			if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+			fclose(f);
+		} else {
+			if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+			if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+		}
+		if (quota > 0 && period > 0) { const unsigned c = (unsigned)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+		return n < 1 ? 1u : n;
+	}();
+	return budget;
+}
 
 static void (*g_flush)() = nullptr;
 void at_exit_flush(void (*fn)()) { g_flush = fn; }
@@ -297,7 +321,7 @@ bool LineReader::read_line(std::string &line)
 // ---- GzWriter: block-parallel gzip ------------------------------------------------------------------------
 namespace {
 
-struct Job { GzWriter::Impl *w; uint64_t seq; std::string data; };
+struct Job { GzWriter::Impl *w; uint64_t seq; std::vector<std::string> parts; };      // one gzip member = the parts, concatenated
 
 struct Pool {
 	std::mutex m;
@@ -324,8 +348,11 @@ constexpr size_t kGzBlock = 512u << 10;      // uncompressed bytes per gzip memb
 
 struct GzWriter::Impl {
 	int fd = -1;
-	std::string buf;
+	std::vector<std::string> parts;    // what the next member will hold; strings handed over whole are kept as they are
+	size_t bytes = 0;                  // ... and their total size
+	bool open_tail = false;            // the last part was started by write(p, n) and takes more bytes
 	uint64_t next_submit = 0;
+	void submit();
 	// completion side (guarded by m)
 	std::mutex m;
 	std::condition_variable cv;
@@ -649,7 +676,7 @@ BgzfStream::BgzfStream(int fd) : impl_(new Impl())
 	size_t xlen = 0;
 	m.bgzf = Impl::bgzf_block_size(m.head.data(), m.head.size(), xlen) != 0;
 	if (m.bgzf) {
-		unsigned n = std::thread::hardware_concurrency();
+		unsigned n = cpu_budget();
 		if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
 		if (n < 1) n = 1;
 		if (n > 8) n = 8;
@@ -692,7 +719,7 @@ long BgzfStream::read(void *dst, size_t n)
 void Pool::start()
 {
 	if (!threads.empty()) return;
-	unsigned n = std::thread::hardware_concurrency();
+	unsigned n = cpu_budget();
 	if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
 	if (n < 1) n = 1;
 	if (n > 64) n = 64;
@@ -721,7 +748,16 @@ void Pool::run()
 			j = std::move(q.front());
 			q.pop_front();
 		}
-		std::string comp = gzip_member(j.data);
+		// the copy that makes the member's bytes contiguous happens here, on a pool thread, not in the caller
+		std::string joined;
+		if (j.parts.size() > 1) {
+			size_t total = 0;
+			for (const std::string &p : j.parts) total += p.size();
+			joined.reserve(total);
+			for (const std::string &p : j.parts) joined += p;
+		}
+		static const std::string empty;
+		std::string comp = gzip_member(j.parts.empty() ? empty : j.parts.size() == 1 ? j.parts[0] : joined);
 		j.w->completed(j.seq, std::move(comp));
 		{
 			std::unique_lock<std::mutex> lk(m);
@@ -753,26 +789,43 @@ GzWriter::~GzWriter()
 	delete impl_;
 }
 
+void GzWriter::Impl::submit()
+{
+	Job j{this, next_submit++, std::move(parts)};
+	parts.clear();
+	bytes = 0;
+	open_tail = false;
+	pool().submit(std::move(j));
+}
+
 void GzWriter::write(const char *p, size_t n)
 {
 	if (!impl_ || impl_->fd < 0) return;
-	impl_->buf.append(p, n);
-	if (impl_->buf.size() >= kGzBlock) {
-		Job j{impl_, impl_->next_submit++, std::move(impl_->buf)};
-		impl_->buf.clear();
-		impl_->buf.reserve(kGzBlock + 4096);
-		pool().submit(std::move(j));
+	if (!impl_->open_tail) {
+		impl_->parts.emplace_back();
+		impl_->parts.back().reserve(kGzBlock + 4096);
+		impl_->open_tail = true;
 	}
+	impl_->parts.back().append(p, n);
+	impl_->bytes += n;
+	if (impl_->bytes >= kGzBlock) impl_->submit();
+}
+
+// a whole string changes hands: no copy on the calling thread
+void GzWriter::write(std::string &&s)
+{
+	if (!impl_ || impl_->fd < 0 || s.empty()) return;
+	impl_->bytes += s.size();
+	impl_->parts.push_back(std::move(s));
+	impl_->open_tail = false;
+	if (impl_->bytes >= kGzBlock) impl_->submit();
 }
 
 void GzWriter::close()
 {
 	if (!impl_ || impl_->fd < 0) return;
 	// an empty file still gets one (empty) member, like `gzip -c < /dev/null`
-	if (!impl_->buf.empty() || impl_->next_submit == 0) {
-		Job j{impl_, impl_->next_submit++, std::move(impl_->buf)};
-		pool().submit(std::move(j));
-	}
+	if (impl_->bytes > 0 || impl_->next_submit == 0) impl_->submit();
 	{
 		std::unique_lock<std::mutex> lk(impl_->m);
 		impl_->cv.wait(lk, [this] { return impl_->next_write == impl_->next_submit; });
@@ -1099,10 +1152,69 @@ static size_t take_lines(const char *p, size_t n, size_t &want)
 	return avx2 ? take_lines_avx2(p, n, want) : take_lines_swar(p, n, want);
 }
 
+// ---- Bytes: recycled block buffers ----
+namespace {
+struct FreeBufs {
+	std::mutex m;
+	std::vector<std::pair<char *, size_t>> list;
+	~FreeBufs() { for (auto &e : list) free(e.first); }
+};
+FreeBufs &free_bufs()
+{
+	static FreeBufs f;
+	return f;
+}
+constexpr size_t kMaxFreeBufs = 96;
+}  // namespace
+
+Bytes::~Bytes()
+{
+	if (!p_) return;
+	FreeBufs &f = free_bufs();
+	std::lock_guard<std::mutex> lk(f.m);
+	if (f.list.size() < kMaxFreeBufs) f.list.emplace_back(p_, cap_);
+	else free(p_);
+}
+
+Bytes &Bytes::operator=(Bytes &&o) noexcept
+{
+	if (this != &o) {
+		this->~Bytes();
+		p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
+		o.p_ = nullptr; o.n_ = o.cap_ = 0;
+	}
+	return *this;
+}
+
+void Bytes::reserve(size_t cap)
+{
+	if (cap <= cap_) return;
+	if (n_ == 0) {                                           // nothing to keep: a recycled buffer that is big enough will do
+		FreeBufs &f = free_bufs();
+		std::lock_guard<std::mutex> lk(f.m);
+		size_t best = f.list.size();
+		for (size_t i = 0; i < f.list.size(); i++)
+			if (f.list[i].second >= cap && (best == f.list.size() || f.list[i].second < f.list[best].second)) best = i;
+		if (best < f.list.size()) {
+			if (p_) f.list.emplace_back(p_, cap_);             // (cannot overflow the list: one was just taken... almost)
+			p_ = f.list[best].first;
+			cap_ = f.list[best].second;
+			f.list.erase(f.list.begin() + (long)best);
+			return;
+		}
+	}
+	size_t nc = cap_ * 2 > cap ? cap_ * 2 : cap;
+	char *np = static_cast<char *>(realloc(p_, nc));
+	if (!np) error("out of memory");
+	p_ = np;
+	cap_ = nc;
+}
+
 struct RecordBlocks::Impl {
 	RawSource src;
 	int lpr;
-	std::string buf;                  // bytes read beyond the last block handed out
+	Bytes carry;                      // bytes read beyond the last block handed out
+	size_t biggest = 0;               // the largest block so far: the next one reserves that much at once
 	bool eof = false;
 	Impl(const std::string &path, int l) : src(path), lpr(l) {}
 };
@@ -1110,13 +1222,16 @@ struct RecordBlocks::Impl {
 RecordBlocks::RecordBlocks(const std::string &path, int lines_per_record) : impl_(new Impl(path, lines_per_record)) {}
 RecordBlocks::~RecordBlocks() { delete impl_; }
 
-bool RecordBlocks::next(size_t nrec, std::string &blk)
+bool RecordBlocks::next(size_t nrec, Bytes &blk)
 {
-	// The block is put together in the caller's string: what the previous call left over, then fresh chunks until it
+	// The block is put together in the caller's buffer: what the previous call left over, then fresh chunks until it
 	// holds the wanted lines; only the tail beyond the cut (less than one chunk) is copied, into the next call's start.
 	Impl &m = *impl_;
+	const size_t chunk = 4u << 20;
 	blk.clear();
-	blk.swap(m.buf);
+	blk.reserve(std::max(m.biggest, m.carry.size()) + chunk);
+	blk.append(m.carry.data(), m.carry.size());
+	m.carry.clear();
 	const size_t want_lines = nrec * (size_t)m.lpr;
 	size_t scan = 0, lines = 0, cut;
 	for (;;) {
@@ -1127,15 +1242,16 @@ bool RecordBlocks::next(size_t nrec, std::string &blk)
 		}
 		if (lines >= want_lines) { cut = scan; break; }
 		if (m.eof) { cut = blk.size(); break; }
-		const size_t old = blk.size(), chunk = 4u << 20;
-		blk.resize(old + chunk);
-		const size_t r = m.src.read_some(&blk[old], chunk);
-		blk.resize(old + r);
+		const size_t old = blk.size();
+		blk.reserve(old + chunk);
+		const size_t r = m.src.read_some(blk.data() + old, chunk);
+		blk.set_size(old + r);
 		if (r == 0) m.eof = true;
 	}
 	if (cut == 0) { blk.clear(); return false; }
-	m.buf.assign(blk, cut, std::string::npos);
-	blk.resize(cut);
+	m.carry.append(blk.data() + cut, blk.size() - cut);
+	blk.set_size(cut);
+	if (cut > m.biggest) m.biggest = cut;
 	return true;
 }
 
@@ -1143,7 +1259,7 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 {
 	RawSource src(path);
 	size_t block_bytes = 8u << 20;
-	unsigned nthreads = std::thread::hardware_concurrency();
+	unsigned nthreads = cpu_budget();
 	if (const char *e = getenv("SEQKIT_THREADS")) nthreads = (unsigned)atoi(e);
 	if (nthreads < 1) nthreads = 1;
 	if (nthreads > 32) nthreads = 32;
