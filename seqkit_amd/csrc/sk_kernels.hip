@@ -41,6 +41,7 @@ namespace sk {
 
 typedef uint32_t u32;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;   // AMDGPU constant address space
 
@@ -2127,6 +2128,98 @@ __global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__rest
 	}
 }
 
+// The same with EIGHT output bytes per thread, for rows whose pitch is a multiple of 8: the per-element bookkeeping (row
+// and column from the element index, row info, source position) is paid once per 8 bytes, and there are four memory
+// instructions per 8 bytes instead of ten — two- and one-dword loads of the qualities (three dwords cover any 8 bytes),
+// one two-dword load of the packed bases (8 bytes from the dword that holds the first code cover any 8 codes), one
+// two-dword store; with two-dword accesses a wave instruction still covers one contiguous 512 bytes on the forward
+// strand.  Source positions s0..s0+7 with s0 = 8j (forward) or len-8-8j (reverse); everything else as above.
+#ifndef SK_SEQ_UNROLL
+#define SK_SEQ_UNROLL 1                  // elements per thread and iteration: 1 / 2 / 4 -> 60.4 / 57.5 / 50.4 % of the HBM peak (tools/seq_ab.py)
+#endif
+constexpr int kSeqUnroll = SK_SEQ_UNROLL;
+template <bool SMALL_M>
+__global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
+                                                            int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
+                                                            int64_t n, u32 m4, u32 inv_upr, uint8_t *__restrict__ out)
+{
+	__shared__ u32 row_info[64];                                   // len | reverse << 16
+	const int upr = stride >> 3;                                   // 8-byte units per row
+	const int64_t ntiles = (n + 63) / 64;
+	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const int64_t row0 = t * 64;
+		const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
+		__syncthreads();
+		if ((int)threadIdx.x < rows) {
+			const int64_t r = row0 + threadIdx.x;
+			const u32 l = len ? (u32)len[r] : (u32)stride;
+			row_info[threadIdx.x] = l | (((u32)flag[r] >> 4) & 1u) << 16;
+		}
+		__syncthreads();
+		const rsrc_t rq = make_rsrc(qual, row0 * (int64_t)stride, rows * stride);
+		const rsrc_t rs = make_rsrc(seq4, row0 * (int64_t)seq4_stride, rows * seq4_stride);
+		const rsrc_t ro = make_rsrc(out, row0 * (int64_t)stride, rows * stride);
+		const u32 total = (u32)rows * (u32)upr;
+		// kSeqUnroll elements per thread and iteration, all their loads issued before the first is used
+		for (u32 e = threadIdx.x; e < total; e += blockDim.x * kSeqUnroll) {
+			u32 rlv[kSeqUnroll], w0v[kSeqUnroll];
+			int jv[kSeqUnroll], s0v[kSeqUnroll];
+			bool revv[kSeqUnroll];
+			u32x2 w12v[kSeqUnroll], ddv[kSeqUnroll];
+#pragma unroll
+			for (int u = 0; u < kSeqUnroll; u++) {
+				const u32 eu = e + (u32)u * blockDim.x;
+				const u32 ec = eu < total ? eu : total - 1;           // past the tile: recompute the last element, store nothing
+				const u32 rl = inv_upr ? __umulhi(ec, inv_upr) : ec / (u32)upr;
+				const int j = (int)(ec - rl * (u32)upr);
+				const u32 info = row_info[rl];
+				const int l = (int)(info & 0xFFFFu);
+				const bool rev = (info >> 16) != 0u;
+				int s0 = rev ? l - 8 - 8 * j : 8 * j;
+				if (s0 < -8) s0 = -8;                                  // every byte of this unit is past the read already
+				// qualities s0..s0+7 in source order: three dwords, funnel-shifted below (a dword that would start before the row
+				// is replaced by the row's first one: what it contributes lies before the read's first base)
+				const int qrow = (int)rl * stride, qd = s0 >> 2;
+				w0v[u] = __builtin_amdgcn_raw_buffer_load_b32(rq, qrow + 4 * (qd < 0 ? 0 : qd), 0, 0);
+				w12v[u] = __builtin_amdgcn_raw_buffer_load_b64(rq, qrow + 4 * (qd + 1 < 0 ? 0 : qd + 1), 0, 0);
+				// base codes s0..s0+7: the 8 bytes from the dword that holds byte a = s0 >> 1 cover bytes a..a+4
+				const int sd = (s0 >> 1) >> 2;
+				ddv[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)rl * seq4_stride + 4 * (sd < 0 ? 0 : sd), 0, 0);
+				rlv[u] = rl; jv[u] = j; s0v[u] = s0; revv[u] = rev;
+			}
+#pragma unroll
+			for (int u = 0; u < kSeqUnroll; u++) {
+				const int s0 = s0v[u];
+				const bool rev = revv[u];
+				const int qd = s0 >> 2;
+				const u32 sh = (u32)s0 & 3u;
+				const u32 w0 = w0v[u], w1 = w12v[u][0], w2 = qd + 1 < 0 ? w12v[u][0] : w12v[u][1];      // qd = -2: the third dword is the row's first
+				const u32 qa = __builtin_amdgcn_alignbyte(w1, w0, sh), qb = __builtin_amdgcn_alignbyte(w2, w1, sh);
+				const int a = s0 >> 1, sd = a >> 2;
+				const u32 d0 = ddv[u][0], d1 = sd < 0 ? ddv[u][0] : ddv[u][1];                           // sd = -1: the second dword is the row's first
+				const u32 b03 = __builtin_amdgcn_alignbyte(d1, d0, (u32)a & 3u);          // bytes a..a+3
+				const u32 b4 = __builtin_amdgcn_alignbyte(0u, d1, (u32)a & 3u) & 0xFFu;   // byte a+4
+				const u32 be = __builtin_bswap32(b03);                                    // codes 2a..2a+7, the first in the top nibble
+				const u32 n8 = (s0 & 1) ? ((be << 4) | (b4 >> 4)) : be;                   // codes s0..s0+7, likewise
+				const u32 c_first = spread_nibbles(n8 >> 16), c_last = spread_nibbles(n8 & 0xFFFFu);      // byte b = code at position +3-b of its four
+				u32 q_lo, q_hi, n_lo, n_hi;
+				if (rev) {          // output byte k = source position s0+7-k
+					q_lo = __builtin_amdgcn_perm(0u, qb, 0x00010203u); q_hi = __builtin_amdgcn_perm(0u, qa, 0x00010203u);
+					n_lo = c_last; n_hi = c_first;
+				} else {
+					q_lo = qa; q_hi = qb;
+					n_lo = __builtin_amdgcn_perm(0u, c_first, 0x00010203u); n_hi = __builtin_amdgcn_perm(0u, c_last, 0x00010203u);
+				}
+				const u32 lo_low = bytes_below<SMALL_M>(q_lo, m4), hi_low = bytes_below<SMALL_M>(q_hi, m4);
+				u32x2 o;
+				o[0] = (kN4 & lo_low) | (bases_from_codes(n_lo, rev) & ~lo_low);
+				o[1] = (kN4 & hi_low) | (bases_from_codes(n_hi, rev) & ~hi_low);
+				if (e + (u32)u * blockDim.x < total) __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)rlv[u] * stride + 8 * jv[u], 0, 0);
+			}
+		}
+	}
+}
+
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st)
 {
@@ -2138,6 +2231,16 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 	static const int wgs = getenv("SK_SEQ_WGS") ? atoi(getenv("SK_SEQ_WGS")) : 8;
 	const int grid = (int)(ntiles < (int64_t)n_cu * wgs ? ntiles : (int64_t)n_cu * wgs);
 	const u32 m4 = (u32)(min_baseq & 0xFF) * 0x01010101u;
+	static const bool wide = !getenv("SK_SEQ_DWORD");
+	if (wide && (stride & 7) == 0) {
+		const u32 upr = (u32)stride >> 3;
+		const u32 inv8 = (upr > 1 && upr < 8192u) ? (u32)(((1ull << 32) + upr - 1) / upr) : 0u;
+		if ((min_baseq & 0xFF) < 128)
+			bam_sequence8_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
+		else
+			bam_sequence8_kernel<false><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
+		return hipGetLastError();
+	}
 	if ((min_baseq & 0xFF) < 128)
 		bam_sequence_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
 	else

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""`sequence()` (sam to fastq's base decoding) of several builds of the C-ABI on the same rows in one process.
+usage: SK_LIBS=tools/ab/x.so python tools/seq_ab.py [records]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import seqkit_amd  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
+dev = torch.device("cuda", 0)
+libs = [("cur", None)] + [(os.path.basename(p)[:-3], os.path.abspath(p)) for p in os.environ.get("SK_LIBS", "").split(",") if p]
+ctxs = [(name, seqkit_amd.Context(0, lib_path=path)) for name, path in libs]
+g = torch.Generator(device=dev)
+g.manual_seed(5)
+s4 = torch.randint(0, 256, (n, 76), dtype=torch.uint8, device=dev, generator=g)
+q = torch.randint(0, 42, (n, 152), dtype=torch.uint8, device=dev, generator=g)
+ln = torch.full((n,), 150, dtype=torch.int16, device=dev)
+o = torch.empty((n, 152), dtype=torch.uint8, device=dev)
+for what in ("mixed strands", "forward only"):
+    fl = (torch.randint(0, 2, (n,), dtype=torch.int16, device=dev, generator=g) * 16) if what == "mixed strands" else torch.zeros((n,), dtype=torch.int16, device=dev)
+    ref = None
+    for name, ctx in ctxs:
+        def run():
+            ctx.bam_sequence_dev(s4.data_ptr(), 76, q.data_ptr(), 152, ln.data_ptr(), fl.data_ptr(), n, 10, o.data_ptr())
+        run(); ctx.sync()
+        got = o[:100000, :150].clone()
+        if ref is None:
+            ref = got
+        assert torch.equal(got, ref), name
+        ts = []
+        for _ in range(5):
+            ctx.timer_start()
+            for _ in range(5):
+                run()
+            ts.append(ctx.timer_stop() / 5)
+        ms = sorted(ts)[2]
+        print(f"{what:14s} {name:8s}: {ms:7.4f} ms  {n / ms / 1e6:6.2f} G records/s  {384 * n / ms / 1e6 / 80:5.1f}% of 8 TB/s", flush=True)
