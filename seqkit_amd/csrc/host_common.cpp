@@ -634,7 +634,7 @@ struct BgzfStream::Impl {
 				continue;
 			}
 			const size_t take = std::min(n - got, cur->data.size() - cur_off);
-			memcpy(dst + got, cur->data.data() + cur_off, take);
+			if (dst) memcpy(dst + got, cur->data.data() + cur_off, take);      // dst == nullptr: skip
 			cur_off += take;
 			got += take;
 		}
@@ -679,7 +679,7 @@ BgzfStream::BgzfStream(int fd) : impl_(new Impl())
 		unsigned n = cpu_budget();
 		if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
 		if (n < 1) n = 1;
-		if (n > 8) n = 8;
+		if (n > 32) n = 32;
 		m.max_in_flight = (size_t)n * 16;
 		m.reader = std::thread([&m] { m.reader_main(); });
 		for (unsigned i = 0; i < n; i++) m.workers.emplace_back([&m] { m.worker_main(); });
@@ -714,6 +714,20 @@ BgzfStream::~BgzfStream()
 long BgzfStream::read(void *dst, size_t n)
 {
 	return impl_->bgzf ? impl_->read_parallel(static_cast<uint8_t *>(dst), n) : impl_->read_plain(static_cast<uint8_t *>(dst), n);
+}
+
+long BgzfStream::skip(size_t n)
+{
+	if (impl_->bgzf) return impl_->read_parallel(nullptr, n);
+	uint8_t buf[1 << 14];                                  // a plain zlib stream has to be inflated somewhere
+	size_t got = 0;
+	while (got < n) {
+		const long r = impl_->read_plain(buf, std::min(n - got, sizeof buf));
+		if (r < 0) return got ? (long)got : -1;
+		if (r == 0) break;
+		got += (size_t)r;
+	}
+	return (long)got;
 }
 
 void Pool::start()

@@ -97,6 +97,7 @@ public:
 	BgzfStream(const BgzfStream &) = delete;
 	BgzfStream &operator=(const BgzfStream &) = delete;
 	long read(void *dst, size_t n);
+	long skip(size_t n);                                 // read() without a destination: same return values, no copy of what is skipped
 	struct Impl;
 private:
 	Impl *impl_;

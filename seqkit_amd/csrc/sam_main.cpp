@@ -80,15 +80,16 @@ public:
 	bool next(BamCore &c, bool want_end)
 	{
 		if (!err_.empty()) return false;
-		uint8_t h[4];
-		const long r = bz_->read(h, 4);
+		// block_size and the 32-byte core in one read; a short one is sorted out by the rules of the two reads it replaces
+		uint8_t hc[36];
+		const long r = bz_->read(hc, 36);
 		if (r == 0) return false;
 		if (r < 0) return rd_fail("Invalid BAM record.");
-		if (r != 4) return rd_fail("BAM file ended prematurely.");
-		const uint32_t block_size = le32(h);
+		if (r < 4) return rd_fail("BAM file ended prematurely.");
+		const uint32_t block_size = le32(hc);
 		if (block_size < 32) return rd_fail("Invalid BAM record.");
-		uint8_t core[32];
-		if (!need(core, 32)) return false;
+		if (r < 36 && !need(hc + r, (size_t)(36 - r))) return false;
+		const uint8_t *core = hc + 4;
 		c.tid = (int32_t)le32(core + 0);
 		c.pos = (int32_t)le32(core + 4);
 		const uint32_t l_read_name = core[8];
@@ -180,13 +181,14 @@ private:
 		}
 		return true;
 	}
-	bool skip(uint32_t n)
+	bool skip(uint32_t n)                                     // need() without a destination
 	{
-		uint8_t buf[1 << 14];
-		while (n) {
-			const uint32_t c = n > sizeof buf ? (uint32_t)sizeof buf : n;
-			if (!need(buf, c)) return false;
-			n -= c;
+		size_t got = 0;
+		while (got < n) {
+			const long r = bz_->skip(n - got);
+			if (r < 0) return rd_fail("Invalid BAM record.");
+			if (r == 0) return rd_fail("BAM file ended prematurely.");
+			got += (size_t)r;
 		}
 		return true;
 	}

@@ -104,3 +104,6 @@ if not ONLY or ONLY in "sam to fastq":
         print(f"{'sam to fastq (gz out)':34s} {label:7s} {dt:7.2f} s  {n_bam / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
         dt, rc = t([binary, "to", "interleaved", "fastq", bam], w)
         print(f"{'sam to interleaved fastq':34s} {label:7s} {dt:7.2f} s  {n_bam / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
+        for cmd in (["statistics", bam], ["fragment", "lengths", bam], ["fragments", bam]):
+            dt, rc = t([binary] + cmd, w)
+            print(f"{'sam ' + ' '.join(cmd[:-1]):34s} {label:7s} {dt:7.2f} s  {n_bam / dt / 1e6:6.2f} M records/s  rc={rc}", flush=True)
