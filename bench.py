@@ -328,7 +328,42 @@ def secondary_rates(torch, ctx, dev):
     timeit("cfg5: sam statistics + fragment lengths 200M records",
            lambda ch: ctx.bam_flag_tlen_dev(bcand["flag"][ch["flag"]].data_ptr(), bcand["tid"][ch["tid"]].data_ptr(), bcand["mtid"][ch["mtid"]].data_ptr(),
                                             bcand["tlen"][ch["tlen"]].data_ptr(), n, 5000, outb.data_ptr()), n, 14, iters=3, cands=bcand)
-    del flag, tid, mtid, tlen, bcand
+    bits = torch.empty(((n + 7) // 8,), dtype=torch.uint8, device=dev)
+    kept = torch.zeros((1,), dtype=torch.int64, device=dev)
+    timeit("f2: sam fragments filter 200M records", lambda: ctx.bam_fragments_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 0, 5000,
+                                                                                  bits.data_ptr(), kept.data_ptr()), n, 14.125, iters=3)
+    del flag, tid, mtid, tlen, bcand, bits, kept
+    # f4: sequence() of `sam to fastq`: 4-bit bases -> ASCII, reverse complement, q < 10 -> N
+    n = 16_000_000
+    s4 = torch.randint(0, 256, (n, 76), dtype=torch.uint8, device=dev, generator=g)
+    q = torch.randint(0, 42, (n, 152), dtype=torch.uint8, device=dev, generator=g)
+    ln = torch.full((n,), 150, dtype=torch.int16, device=dev)
+    fl = torch.randint(0, 2, (n,), dtype=torch.int16, device=dev, generator=g) * 16
+    o = torch.empty((n, 152), dtype=torch.uint8, device=dev)
+    timeit("f4: sequence() 16M x 150 bases, both strands", lambda: ctx.bam_sequence_dev(s4.data_ptr(), 76, q.data_ptr(), 152, ln.data_ptr(), fl.data_ptr(), n, 10, o.data_ptr()),
+           n, 76 + 152 + 152 + 4, iters=5)
+    del s4, q, ln, fl, o
+    # f3: barcode census (`fasta statistics`, `--dry-run`): rows/s; every launch starts from an empty table
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    ctx.set_barcodes(table, 1)
+    for name, kw in (("f3: census 32M rows, clean run (per index 97 % exact, 2.5 % one substitution, 0.5 % random)", dict(p_exact=0.97, p_sub=0.025)),
+                     ("f3: census 32M rows, noisy run (per index 85 % / 10 % / 5 %)", {})):
+        b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
+        bc = torch.from_numpy(b_np).to(dev).repeat(32, 1).contiguous()
+
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            ctx.census_reset()                   # clearing the 2 GiB table is not part of the count
+            ctx.sync()
+            ctx.timer_start()
+            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], 17, bc.shape[0], 0, 0)
+            ts.append(ctx.timer_stop())
+        ms = sorted(ts[1:])[1]
+        rows = bc.shape[0]
+        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
+                    "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4)})
+        del bc
     return out
 
 
