@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 // loop), <= 4 MiB, read through L2.  Sheets this cannot serve (max_diff > 1,
 // wildcards in some rows only, more than 7 letters, detail outputs wanted) take demux_tile_kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int W, bool DIRECT, bool BOTH>
+template <int W, bool DIRECT, bool BOTH, bool PAIR = false>
 __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -1368,33 +1368,53 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 	// (a big table must stay in L2: the read-once barcode stream is then loaded nontemporal — 68 -> 98 G pairs/s for the
 	// 1 MiB table of the 96 dual-index sheet; with a small table plain loads are faster, 246 against 221 G reads/s)
 	constexpr int kAux = BOTH ? 0 : kAuxStream;
-	u32 raw[W];
+	// PAIR (DIRECT rows, short calls): TWO tiles per wave and iteration, taken through the stages together (keys and
+	// hashes, the table loads of both, then the compares and stores).  A 10 M-read call is 19 iterations per wave, each a
+	// chain of dependent round trips (rows -> table slot -> store), and a second independent chain hides half of them:
+	// 160 -> 196 G reads/s; at 100 M reads per call it is the other way round (238 -> 222), so the launch chooses.
+	static_assert(!PAIR || DIRECT, "two tiles per iteration: rows come straight from memory");
+	constexpr int NT = PAIR ? 2 : 1;
+	u32 raw[NT][W];
 	u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
-	auto fetch = [&](int64_t t) {
+	auto fetch = [&](int64_t t, int i) {
 		const rsrc_t rb = tile_rsrc(t);
 		if (DIRECT) {
 #pragma unroll
-			for (int w = 0; w < W; w++) raw[w] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride + 4 * w, 0, kAux);
+			for (int w = 0; w < W; w++) raw[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride + 4 * w, 0, kAux);
 		} else {
 			v0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAux);
 			v1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
 		}
 	};
+	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
+		const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;
+		if (W < 4) {
+			const u32x4 q = *reinterpret_cast<const u32x4 *>(sp);
+#pragma unroll
+			for (int w = 0; w <= W; w++) sv[w] = q[w];
+		} else {
+			const u32x4 q0 = *reinterpret_cast<const u32x4 *>(sp), q1 = *reinterpret_cast<const u32x4 *>(sp + 4);
+#pragma unroll
+			for (int w = 0; w <= W && w < 8; w++) sv[w] = w < 4 ? q0[w] : q1[w - 4];
+			if (W == 8) sv[8] = sp[8];
+		}
+	};
 	int64_t t = (int64_t)blockIdx.x * nwave + wave;
-	fetch(t);
-	for (; t < ntiles; t += tstep) {
-		const int64_t row0 = t * kTileRows;
-		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
-		const bool active = lane < rows;
-		u32 d[W];
+#pragma unroll
+	for (int i = 0; i < NT; i++) fetch(t + i * tstep, i);
+	for (; t < ntiles; t += NT * tstep) {
+		u32 d[NT][W], key[NT][W], h[NT], sv1[NT][W + 1], sv2[NT][W + 1];
 		if (DIRECT) {
 #pragma unroll
-			for (int w = 0; w < W; w++) d[w] = raw[w];
-			fetch(t + tstep);
+			for (int i = 0; i < NT; i++)
+#pragma unroll
+				for (int w = 0; w < W; w++) d[i][w] = raw[i][w];
+#pragma unroll
+			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
 		} else {
 			*reinterpret_cast<u32x4 *>(tile + voff) = v0;
 			*reinterpret_cast<u32x4 *>(tile + 1024 + voff) = v1;
-			fetch(t + tstep);
+			fetch(t + tstep, 0);
 			wave_lds_fence();
 			const int rs = lane * bstride;
 			const u32 sh = (u32)rs & 3u;
@@ -1403,78 +1423,82 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 #pragma unroll
 			for (int w = 0; w < W; w++) {
 				const u32 hi = x[w + 1];
-				d[w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+				d[0][w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
 				lo = hi;
 			}
 		}
 		// canonical key: a byte stays iff it is the sheet letter with its index; everything else, and the columns that do not count, become 0
-		u32 key[W];
-		u32 h = tb.hk_seed;
 #pragma unroll
-		for (int w = 0; w < W; w++) {
-			const u32 f = tb.hk_fold ? d[w] ^ ((d[w] >> 4) & 0x0f0f0f0fu) : d[w];
-			const u32 sel = (f >> tb.hk_sh) & 0x07070707u;
-			const u32 letter = __builtin_amdgcn_perm(tb.hk_tab_hi, tb.hk_tab_lo, sel);
-			const u32 df = d[w] ^ letter;                           // zero byte <=> the observed byte is a sheet letter
-			const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;     // 0x80 in every byte that differs
-			const u32 drop = (nz << 1) - (nz >> 7);                 // 0xFF in every byte that differs
-			key[w] = d[w] & ~drop & tb.hk_keep[w];
-			h += key[w]; h += h << 10; h ^= h >> 6;                 // demux_key_hash
+		for (int i = 0; i < NT; i++) {
+			u32 hh = tb.hk_seed;
+#pragma unroll
+			for (int w = 0; w < W; w++) {
+				const u32 f = tb.hk_fold ? d[i][w] ^ ((d[i][w] >> 4) & 0x0f0f0f0fu) : d[i][w];
+				const u32 sel = (f >> tb.hk_sh) & 0x07070707u;
+				const u32 letter = __builtin_amdgcn_perm(tb.hk_tab_hi, tb.hk_tab_lo, sel);
+				const u32 df = d[i][w] ^ letter;                        // zero byte <=> the observed byte is a sheet letter
+				const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;     // 0x80 in every byte that differs
+				const u32 drop = (nz << 1) - (nz >> 7);                 // 0xFF in every byte that differs
+				key[i][w] = d[i][w] & ~drop & tb.hk_keep[w];
+				hh += key[i][w]; hh += hh << 10; hh ^= hh >> 6;         // demux_key_hash
+			}
+			hh += hh << 3; hh ^= hh >> 11; hh += hh << 15;
+			h[i] = hh;
 		}
-		h += h << 3; h ^= h >> 11; h += h << 15;
 		// Two slots, at most two loads, no loop (cuckoo).  The builder tries the first table first and moves a key to the
 		// second only when its first slot is taken, so: first slot holds the key -> done; first slot free -> the key is in
 		// neither; first slot holds another key -> look at the second slot (a minority of the lanes: less table traffic).
-		int code = kAssignNone;
-		auto probe = [&](u32 slot, bool &occupied) {
-			const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;
-			u32 sv[W + 1];
-			if (W < 4) {
-				const u32x4 q = *reinterpret_cast<const u32x4 *>(sp);
-#pragma unroll
-				for (int w = 0; w <= W; w++) sv[w] = q[w];
-			} else {
-				const u32x4 q0 = *reinterpret_cast<const u32x4 *>(sp), q1 = *reinterpret_cast<const u32x4 *>(sp + 4);
-#pragma unroll
-				for (int w = 0; w <= W && w < 8; w++) sv[w] = w < 4 ? q0[w] : q1[w - 4];
-				if (W == 8) sv[8] = sp[8];
-			}
-			occupied = sv[W] != kHashEmpty;
-			bool same = occupied;
-#pragma unroll
-			for (int w = 0; w < W; w++) same = same && sv[w] == key[w];
-			code = same ? (int)sv[W] : code;
-			return same;
-		};
 		// (BOTH — small tables that stay in the vector cache: both loads at once, no dependent second trip)
-		bool occ1 = false, occ2 = false;
-		const bool hit1 = probe(h & (u32)tb.hk_mask, occ1);
-		if (BOTH || (occ1 && !hit1)) probe((u32)tb.hk_mask + 1u + ((h >> 16) & (u32)tb.hk_mask), occ2);
-		__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
-		if (active && code >= 0) {
-			if (lp.use_lds_hist) atomicAdd(&hist[code], 1u);
-			else atomicAdd(&a.counts[code], 1ull);
+#pragma unroll
+		for (int i = 0; i < NT; i++) {
+			load_slot(h[i] & (u32)tb.hk_mask, sv1[i]);
+			if (BOTH) load_slot((u32)tb.hk_mask + 1u + ((h[i] >> 16) & (u32)tb.hk_mask), sv2[i]);
 		}
-		wc.total += (u32)__popcll(__ballot(active));
-		wc.ident += (u32)__popcll(__ballot(active && code >= 0));
-		wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+#pragma unroll
+		for (int i = 0; i < NT; i++) {
+			const int64_t ti = t + i * tstep;
+			const int64_t row0 = ti < ntiles ? ti * kTileRows : 0;
+			const int rows = ti < ntiles ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
+			const bool active = lane < rows;
+			int code = kAssignNone;
+			auto match = [&](const u32 (&sv)[W + 1], bool &occupied) {
+				occupied = sv[W] != kHashEmpty;
+				bool same = occupied;
+#pragma unroll
+				for (int w = 0; w < W; w++) same = same && sv[w] == key[i][w];
+				code = same ? (int)sv[W] : code;
+				return same;
+			};
+			bool occ1 = false, occ2 = false;
+			const bool hit1 = match(sv1[i], occ1);
+			if (BOTH) match(sv2[i], occ2);
+			else if (occ1 && !hit1) { load_slot((u32)tb.hk_mask + 1u + ((h[i] >> 16) & (u32)tb.hk_mask), sv2[i]); match(sv2[i], occ2); }
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
+			if (active && code >= 0) {
+				if (lp.use_lds_hist) atomicAdd(&hist[code], 1u);
+				else atomicAdd(&a.counts[code], 1ull);
+			}
+			wc.total += (u32)__popcll(__ballot(active));
+			wc.ident += (u32)__popcll(__ballot(active && code >= 0));
+			wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+		}
 		if (!DIRECT) wave_lds_fence();
 	}
 	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
 
-template <bool DIRECT, bool BOTH>
+template <bool DIRECT, bool BOTH, bool PAIR = false>
 static const void *demux_hash_fn_w(int W)
 {
 	switch (W) {
-	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH>);
-	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH>);
-	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH>);
-	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH>);
-	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH>);
-	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH>);
-	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH>);
-	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH>);
+	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, PAIR>);
+	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, PAIR>);
+	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, PAIR>);
+	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, PAIR>);
+	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, PAIR>);
+	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, PAIR>);
+	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, PAIR>);
+	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, PAIR>);
 	}
 }
 
@@ -1693,7 +1717,10 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			// both cuckoo slots at once while the two tables are small enough to stay in the CU's vector cache (cfg 3: 32 KiB;
 			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
 			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
-			const void *fn = direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))
+			// short calls (fewer than about 64 tiles per wave at full occupancy): two tiles per iteration
+			const bool pair = direct && (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
+			const void *fn = pair ? (both ? demux_hash_fn_w<true, true, true>(b.table.hk_W) : demux_hash_fn_w<true, false, true>(b.table.hk_W))
+			               : direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))
 			                        : (both ? demux_hash_fn_w<false, true>(b.table.hk_W) : demux_hash_fn_w<false, false>(b.table.hk_W));
 			e = plan_shape(fn, b.table, b.n, 2048, false, 4, n_cu, 1, 0, sh);
 			if (e == hipSuccess) {
