@@ -1339,6 +1339,7 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 // loop), <= 4 MiB, read through L2.  Sheets this cannot serve (max_diff > 1,
 // wildcards in some rows only, more than 7 letters, detail outputs wanted) take demux_tile_kernel.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kHashTileLds = 2048 + 64;      // LDS per tile of the lookup kernel: 64 rows of at most 32 bytes, and the dword read past a row's end
 template <int W, bool DIRECT, bool BOTH, bool PAIR = false>
 __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
 {
@@ -1368,22 +1369,21 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 	// (a big table must stay in L2: the read-once barcode stream is then loaded nontemporal — 68 -> 98 G pairs/s for the
 	// 1 MiB table of the 96 dual-index sheet; with a small table plain loads are faster, 246 against 221 G reads/s)
 	constexpr int kAux = BOTH ? 0 : kAuxStream;
-	// PAIR (DIRECT rows, short calls): TWO tiles per wave and iteration, taken through the stages together (keys and
+	// PAIR (short calls): TWO tiles per wave and iteration, taken through the stages together (keys and
 	// hashes, the table loads of both, then the compares and stores).  A 10 M-read call is 19 iterations per wave, each a
 	// chain of dependent round trips (rows -> table slot -> store), and a second independent chain hides half of them:
 	// 160 -> 196 G reads/s; at 100 M reads per call it is the other way round (238 -> 222), so the launch chooses.
-	static_assert(!PAIR || DIRECT, "two tiles per iteration: rows come straight from memory");
 	constexpr int NT = PAIR ? 2 : 1;
 	u32 raw[NT][W];
-	u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
+	u32x4 v0[NT], v1[NT];
 	auto fetch = [&](int64_t t, int i) {
 		const rsrc_t rb = tile_rsrc(t);
 		if (DIRECT) {
 #pragma unroll
 			for (int w = 0; w < W; w++) raw[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride + 4 * w, 0, kAux);
 		} else {
-			v0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAux);
-			v1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
+			v0[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAux);
+			v1[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
 		}
 	};
 	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
@@ -1412,19 +1412,26 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 #pragma unroll
 			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
 		} else {
-			*reinterpret_cast<u32x4 *>(tile + voff) = v0;
-			*reinterpret_cast<u32x4 *>(tile + 1024 + voff) = v1;
-			fetch(t + tstep, 0);
+#pragma unroll
+			for (int i = 0; i < NT; i++) {                             // tile i of the pair has its own 2 KiB + pad of the wave's LDS slot
+				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + voff) = v0[i];
+				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + 1024 + voff) = v1[i];
+			}
+#pragma unroll
+			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
 			wave_lds_fence();
 			const int rs = lane * bstride;
 			const u32 sh = (u32)rs & 3u;
-			const u32 *x = reinterpret_cast<const u32 *>(tile + (rs & ~3));
-			u32 lo = x[0];
 #pragma unroll
-			for (int w = 0; w < W; w++) {
-				const u32 hi = x[w + 1];
-				d[0][w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
-				lo = hi;
+			for (int i = 0; i < NT; i++) {
+				const u32 *x = reinterpret_cast<const u32 *>(tile + i * kHashTileLds + (rs & ~3));
+				u32 lo = x[0];
+#pragma unroll
+				for (int w = 0; w < W; w++) {
+					const u32 hi = x[w + 1];
+					d[i][w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+					lo = hi;
+				}
 			}
 		}
 		// canonical key: a byte stays iff it is the sheet letter with its index; everything else, and the columns that do not count, become 0
@@ -1718,11 +1725,12 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
 			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
 			// short calls (fewer than about 64 tiles per wave at full occupancy): two tiles per iteration
-			const bool pair = direct && (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
-			const void *fn = pair ? (both ? demux_hash_fn_w<true, true, true>(b.table.hk_W) : demux_hash_fn_w<true, false, true>(b.table.hk_W))
+			const bool pair = (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
+			const void *fn = pair ? (direct ? (both ? demux_hash_fn_w<true, true, true>(b.table.hk_W) : demux_hash_fn_w<true, false, true>(b.table.hk_W))
+			                                : (both ? demux_hash_fn_w<false, true, true>(b.table.hk_W) : demux_hash_fn_w<false, false, true>(b.table.hk_W)))
 			               : direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))
 			                        : (both ? demux_hash_fn_w<false, true>(b.table.hk_W) : demux_hash_fn_w<false, false>(b.table.hk_W));
-			e = plan_shape(fn, b.table, b.n, 2048, false, 4, n_cu, 1, 0, sh);
+			e = plan_shape(fn, b.table, b.n, pair ? 2 * kHashTileLds : 2048, false, 4, n_cu, 1, 0, sh);
 			if (e == hipSuccess) {
 				// the histogram sits where the matcher tables would: plan_shape(with_tables = false) leaves no room for it
 				sh.lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
