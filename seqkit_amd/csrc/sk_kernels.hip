@@ -692,6 +692,18 @@ constexpr int kAuxStreamSt = (SK_NT & 2) ? 2 : 0;
 #undef SK_LD_AUX_SET
 #endif
 
+// The kernel's first argument as it lies in the kernel-argument segment, behind an offset of zero that is produced by
+// an asm statement at the point of use: a load through it is a scalar load that cannot be hoisted out of the loop it
+// stands in.  For arguments that are needed once per tile and would otherwise occupy scalar registers all the time.
+template <class T>
+__device__ __forceinline__ const T __attribute__((address_space(4))) *kernel_args_now()
+{
+	u32 z;
+	asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+	return reinterpret_cast<const T __attribute__((address_space(4))) *>(
+		(const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + z);
+}
+
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t byte_off, int records)
 {
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(static_cast<const uint8_t *>(p)) + (p ? byte_off : 0), 0, p ? records : 0, 0x00020000);
@@ -711,42 +723,44 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 	if (DEMUX) stage_tables(a.table, lp, hist);
 	WaveCounts wc = {0u, 0u, 0u};
 
-	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int ntiles = (int)((a.n + kTileRows - 1) / kTileRows);      // tile indices are 32-bit here (launch_tile_pass checks): five 64-bit counters were ten scalar registers
 	const int stride = a.stride;
 	const int m = a.qc.min_baseq;
 	const u32 cl2 = a.qc.cl2;
 
-	// active mates (those with any output), as explicit scalars so that nothing is indexed at run time
-	int nam = 0;
-	MateDev am0 = a.mate[0], am1 = a.mate[1];
+	// Active mates (those with any output).  A mate's five pointers are fetched from the kernel arguments when its item
+	// starts (a scalar load indexed by k): held in registers for the whole kernel they were twenty of the SGPRs this
+	// kernel does not have.
+	int nam = 0, mate0 = 0;
 	{
 		const bool act0 = a.n_mates > 0 && (a.mate[0].out_seq || a.mate[0].lowest_k);
 		const bool act1 = a.n_mates > 1 && (a.mate[1].out_seq || a.mate[1].lowest_k);
 		if (act0 && act1) nam = 2;
 		else if (act0) nam = 1;
-		else if (act1) { nam = 1; am0 = a.mate[1]; }
+		else if (act1) { nam = 1; mate0 = 1; }
 	}
-	const int64_t tstep = (int64_t)gridDim.x * nwave;
-	int64_t tile_end = ntiles;                       // first tile NOT owned by this wave's run (set below)
+	const int tstep = (int)gridDim.x * nwave;
+	int tile_end = ntiles;                           // first tile NOT owned by this wave's run (set below)
 	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;   // chunks per full tile, rounded up to the slot count
 	const int voff = lane * 16;
 
 	// descriptors of the two input streams of item (t, k); a tile past the end gets zero records
-	auto in_rsrc = [&](int64_t t, int k, rsrc_t &rq, rsrc_t &rs) {
-		const MateDev &mt = k ? am1 : am0;
+	auto in_rsrc = [&](int t, int k, rsrc_t &rq, rsrc_t &rs) {
+		const MateDev &mt = a.mate[mate0 + k];
 		const bool ok = t < tile_end;
-		const int64_t row0 = ok ? t * kTileRows : 0;
+		const int64_t row0 = ok ? (int64_t)t * kTileRows : 0;
 		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
 		const int nb = (rows * stride + 3) & ~3;
 		rq = make_rsrc(mt.qual, row0 * (int64_t)stride, nb);
 		rs = make_rsrc(mt.out_seq ? mt.seq : nullptr, row0 * (int64_t)stride, nb);
 	};
 
-	int64_t t = (int64_t)blockIdx.x * nwave + wave, t_end = ntiles, t_step = tstep;
+	int t = (int)blockIdx.x * nwave + wave, t_end = ntiles, t_step = tstep;
 	if (lp.tile_map == 1) {
-		const int64_t per_wave = (ntiles + tstep - 1) / tstep;
-		t = t * per_wave;
-		t_end = (t + per_wave) < ntiles ? (t + per_wave) : ntiles;
+		const int per_wave = (ntiles + tstep - 1) / tstep;
+		const int64_t first = (int64_t)t * per_wave;
+		t = first < ntiles ? (int)first : ntiles;
+		t_end = (int64_t)t + per_wave < ntiles ? t + per_wave : ntiles;
 		t_step = 1;
 	}
 	tile_end = t_end;
@@ -767,27 +781,28 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 	}
 
 	for (; t < t_end; t += t_step) {
-		const int64_t row0 = t * kTileRows;
+		const int64_t row0 = (int64_t)t * kTileRows;
 		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
 		const bool active = lane < rows;
 
 		// the tile's observed barcodes are fetched now and only looked at in the barcode phase
 		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
 		if (DEMUX) {
-			const rsrc_t rb = make_rsrc(a.bc, row0 * (int64_t)a.bc_stride, (rows * a.bc_stride + 3) & ~3);
+			const TileArgs __attribute__((address_space(4))) *ka = kernel_args_now<TileArgs>();
+			const int bstride = ka->bc_stride;
+			const rsrc_t rb = make_rsrc(ka->bc, row0 * (int64_t)bstride, (rows * bstride + 3) & ~3);
 			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, 0);
 			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, 0);
 		}
 
 		for (int k = 0; k < nam; k++) {
-			const MateDev &mt = k ? am1 : am0;
+			const MateDev &mt = a.mate[mate0 + k];
 			const bool do_trim = mt.lowest_k != nullptr;
 			const int nb = rows * stride;
 			const rsrc_t ro = make_rsrc(mt.out_seq, row0 * (int64_t)stride, nb & ~3);
-			const rsrc_t rk = make_rsrc(mt.lowest_k, row0 * 2, rows * 2);
 			const rsrc_t rl = make_rsrc(do_trim ? mt.len : nullptr, row0 * 2, rows * 2);
 			// the item after this one: the other mate of this tile, or the first mate of the wave's next tile
-			const int64_t tn = (k + 1 < nam) ? t : t + t_step;
+			const int tn = (k + 1 < nam) ? t : t + t_step;
 			const int kn = (k + 1 < nam) ? k + 1 : 0;
 			rsrc_t nq, ns;
 			in_rsrc(tn, kn, nq, ns);
@@ -826,32 +841,39 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 				if (stride >= (1 << kKeyBits)) kk = trim_scan_wide(tile, lane * stride, len, stride, m, active);
 				else if (mt.len != nullptr) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, m, active);
 				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, m, active);
-				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, rk, lane * 2, 0, 0);
+				// (the descriptor of lowest_k is made here, from the pointer as it lies in the kernel arguments: four scalar
+				// registers less across the chunk loop and the scan)
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, make_rsrc(kernel_args_now<TileArgs>()->mate[mate0 + k].lowest_k, row0 * 2, rows * 2), lane * 2, 0, 0);
 				wave_lds_fence();
 			}
 		}
 
 		// ---- barcode phase (bit-sliced matcher) -----------------------------------------------------------
 		if (DEMUX) {
-			const int bstride = a.bc_stride;
+			// (what this phase needs of the kernel arguments — the matcher's shape, the four column pointers — is read from
+			// them here, once per tile, through an offset the compiler cannot see through: as loop invariants they would
+			// sit in scalar registers for the whole kernel)
+			const TileArgs __attribute__((address_space(4))) *ka = kernel_args_now<TileArgs>();
+			const int bstride = ka->bc_stride;
 			if (voff < rows * bstride) *reinterpret_cast<u32x4 *>(tile + voff) = bcv0;
 			if (1024 + voff < rows * bstride) *reinterpret_cast<u32x4 *>(tile + 1024 + voff) = bcv1;
 			wave_lds_fence();
 			int best = 0x7fffffff, first = 0, last = 0;
 			const uint8_t *row = tile + lane * bstride;
-			switch (a.table.G) {   // wave-uniform
-			case 1: demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, 1, 0, a.table.L, best, first, last); break;
-			case 2: demux_row_bitsliced<2>(row, sk_smem, a.table.bs_mm_off, 2, 0, a.table.L, best, first, last); break;
-			case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
-			default: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
+			const int mm_off = ka->table.bs_mm_off, tL = ka->table.L;
+			switch (ka->table.G) {   // wave-uniform
+			case 1: demux_row_bitsliced<1>(row, sk_smem, mm_off, 1, 0, tL, best, first, last); break;
+			case 2: demux_row_bitsliced<2>(row, sk_smem, mm_off, 2, 0, tL, best, first, last); break;
+			case 3: demux_row_bitsliced<3>(row, sk_smem, mm_off, 3, 0, tL, best, first, last); break;
+			default: demux_row_bitsliced<4>(row, sk_smem, mm_off, 4, 0, tL, best, first, last); break;
 			}
 			// D3 (src/fasta_demultiplex.rs:168-194) with descriptor-clipped stores
 			int code = kAssignNone;
-			if (best <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
-			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), make_rsrc(a.lowest_diff, row0, rows), lane, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, make_rsrc(a.first_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, make_rsrc(a.last_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
+			if (best <= ka->table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(ka->assign, row0 * 4, rows * 4), lane * 4, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), make_rsrc(ka->lowest_diff, row0, rows), lane, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, make_rsrc(ka->first_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, make_rsrc(ka->last_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
 			if (active && code >= 0) atomicAdd(&hist[code], 1u);
 			wc.total += (u32)__popcll(__ballot(active));
 			wc.ident += (u32)__popcll(__ballot(active && code >= 0));
@@ -859,7 +881,10 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 			wave_lds_fence();
 		}
 	}
-	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
+	if (DEMUX) {
+		const TileArgs __attribute__((address_space(4))) *ka = kernel_args_now<TileArgs>();
+		flush_counts(ka->table.S, ka->counts, lp, hist, lane, wc);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1686,6 +1711,7 @@ static const void *tile_pass_fn(int mode)
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
+	if ((a.n + kTileRows - 1) / kTileRows > (int64_t)1 << 30) return hipErrorInvalidValue;      // the kernels count tiles in 32 bits (2^36 rows: no device holds them)
 	TileArgs b = a;
 	bool any_mate = false;
 	for (int mi = 0; mi < b.n_mates; mi++) any_mate = any_mate || b.mate[mi].out_seq || b.mate[mi].lowest_k;
