@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 	if (DEMUX) stage_tables(a.table, lp, hist);
 	WaveCounts wc = {0u, 0u, 0u};
 
-	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int ntiles = (int)((a.n + kTileRows - 1) / kTileRows);      // 32-bit tile indices (launch_tile_blocked checks)
 	const int stride = a.stride;
 	const u32 cl2 = a.qc.cl2;
 	const bool do_trim = a.out_lowest_k[0] >= 0, ragged = a.in_len[0] >= 0;
@@ -921,16 +921,20 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 	const int nchunkp = (((seg + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;
 	const int voff = lane * 16;
 	const int lim = seg - voff;                  // chunk offsets below this are inside the lane's part of a segment
-	const int64_t tstep = (int64_t)gridDim.x * nwave;
+	const int tstep = (int)gridDim.x * nwave;
 	auto seg_off = [](int o) { return o >= 0 ? o : kNoSeg; };
 	// A segment's last chunk runs past the segment (64*stride is rarely a multiple of 1 KiB): those lanes must not
 	// touch memory — inside the block they would fetch the NEXT segment's bytes a second time (+7 % read traffic at
 	// 150 bp) — so their offset is sent out of range, where the hardware answers with zeros and no request.
 	auto at = [&](int base, int coff) { return coff < lim ? base + coff : kNoSeg; };
 
-	int64_t t = (int64_t)blockIdx.x * nwave + wave;             // tiles are dealt round-robin to the resident waves
+	int t = (int)blockIdx.x * nwave + wave;                     // tiles are dealt round-robin to the resident waves
 	// descriptor of a tile's input block; past the last tile: zero records (the prefetch of the item after the last)
-	auto in_block = [&](int64_t tt) { return make_rsrc(tt < ntiles ? a.in : nullptr, tt * (int64_t)a.in_block, a.in_block); };
+	auto in_block = [&](int tt) {
+		const BlockedArgs __attribute__((address_space(4))) *ka = kernel_args_now<BlockedArgs>();
+		const int bytes = ka->in_block;
+		return make_rsrc(tt < ntiles ? ka->in : nullptr, tt * (int64_t)bytes, bytes);
+	};
 	rsrc_t rin = in_block(t);
 	int vq = voff + a.in_qual[0], vs = voff + seg_off(a.in_seq[0]);      // lane offsets of the item's two streams inside the block
 	u32x4 qv[SLOTS], sv[SLOTS];
@@ -944,17 +948,21 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 	for (; t < ntiles; t += tstep) {
 		u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
 		if (DEMUX) {
-			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rin, 0 < bc_lim ? voff + a.in_bc : kNoSeg, 0, 0);
-			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rin, 1024 < bc_lim ? voff + a.in_bc + 1024 : kNoSeg, 0, 0);
+			const int in_bc = kernel_args_now<BlockedArgs>()->in_bc;      // once per tile: read where it is used (as tile_pass_kernel does)
+			bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rin, 0 < bc_lim ? voff + in_bc : kNoSeg, 0, 0);
+			bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rin, 1024 < bc_lim ? voff + in_bc + 1024 : kNoSeg, 0, 0);
 		}
-		const rsrc_t rout = make_rsrc(a.out, t * (int64_t)a.out_block, a.out_block);
+		const BlockedArgs __attribute__((address_space(4))) *kt = kernel_args_now<BlockedArgs>();
+		uint8_t *const out_base = kt->out;
+		const int out_block = kt->out_block;
+		const rsrc_t rout = make_rsrc(out_base, t * (int64_t)out_block, out_block);
 
 		for (int k = 0; k < a.n_mates; k++) {
 			// masked bases go through their own descriptor: it clips the item's last chunk at the segment's end
-			const int so = k ? a.out_seq[1] : a.out_seq[0];
-			const rsrc_t ro = make_rsrc(so >= 0 ? a.out : nullptr, t * (int64_t)a.out_block + so, seg);
+			const int so = a.out_seq[k];
+			const rsrc_t ro = make_rsrc(so >= 0 ? out_base : nullptr, t * (int64_t)out_block + so, seg);
 			// rin is still this tile's block here (it moves on in the last chunks of the tile's last mate)
-			int len_ld = (int)__builtin_amdgcn_raw_buffer_load_b16(rin, lane * 2 + seg_off(k ? a.in_len[1] : a.in_len[0]), 0, 0);
+			int len_ld = (int)__builtin_amdgcn_raw_buffer_load_b16(rin, lane * 2 + seg_off(a.in_len[k]), 0, 0);
 			asm volatile("" : "+v"(len_ld));                      // materialise now (see tile_pass_kernel)
 
 			// ---- stream phase: SLOTS chunks of each stream in flight ------------------------------------------------
@@ -976,8 +984,8 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 			{
 				const bool last_mate = k + 1 >= a.n_mates;
 				if (last_mate) rin = in_block(t + tstep);
-				vq = voff + (last_mate ? a.in_qual[0] : a.in_qual[1]);
-				vs = voff + seg_off(last_mate ? a.in_seq[0] : a.in_seq[1]);
+				vq = voff + (a.in_qual[last_mate ? 0 : 1]);
+				vs = voff + seg_off(a.in_seq[last_mate ? 0 : 1]);
 #pragma unroll
 				for (int i = 0; i < SLOTS; i++) {
 					const int off = (c + i) * 1024;
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 				int kk;
 				if (ragged) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, a.qc.min_baseq, active);
 				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, a.qc.min_baseq, active);
-				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, rout, lane * 2 + (k ? a.out_lowest_k[1] : a.out_lowest_k[0]), 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, rout, lane * 2 + (a.out_lowest_k[k]), 0, 0);
 				wave_lds_fence();
 			}
 		}
@@ -1019,10 +1027,11 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 			}
 			int code = kAssignNone;                                  // D3: src/fasta_demultiplex.rs:168-194
 			if (best <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
-			__builtin_amdgcn_raw_buffer_store_b32((u32)code, rout, lane * 4 + a.out_assign, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), rout, lane + seg_off(a.out_lowest_diff), 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, rout, lane * 2 + seg_off(a.out_first_idx), 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, rout, lane * 2 + seg_off(a.out_last_idx), 0, 0);
+			const BlockedArgs __attribute__((address_space(4))) *ka = kernel_args_now<BlockedArgs>();
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, rout, lane * 4 + ka->out_assign, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), rout, lane + seg_off(ka->out_lowest_diff), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, rout, lane * 2 + seg_off(ka->out_first_idx), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, rout, lane * 2 + seg_off(ka->out_last_idx), 0, 0);
 			const bool active = lane < a.n - t * kTileRows;
 			if (active && code >= 0) atomicAdd(&hist[code], 1u);
 			wc.total += (u32)__popcll(__ballot(active));
@@ -1665,6 +1674,7 @@ hipError_t launch_tile_blocked(const BlockedArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
 	if (!blocked_shape_ok(a)) return hipErrorInvalidValue;
+	if ((a.n + kTileRows - 1) / kTileRows > (int64_t)1 << 30) return hipErrorInvalidValue;      // tiles are counted in 32 bits
 	const bool demux = a.in_bc >= 0;
 	// chunks in flight per stream: 2 / 3 / 4 measure the same on the two-mate pass (10.56-10.64 ms), 5 is slower
 	const int slots = a.n_mates == 1 ? SK_SLOTS1 : kSlots;
