@@ -587,8 +587,6 @@ struct LdsPlan {
 	int tiles_off;       // first wave's tile slot (includes the front pad)
 	int tile_slot;       // bytes per wave: front pad + 64*row_bytes rounded to 16 + back pad
 	int use_lds_hist;
-	int stagger;         // start-up stagger of the waves, in s_sleep(127) units per phase slot (0 = none)
-	int tile_map;        // 0: tiles dealt round-robin to the waves; 1: each wave owns one contiguous run of tiles
 };
 
 // copy the matcher tables into the workgroup's LDS and clear its histogram (all threads; ends with a barrier)
@@ -740,14 +738,13 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 		else if (act1) { nam = 1; mate0 = 1; }
 	}
 	const int tstep = (int)gridDim.x * nwave;
-	int tile_end = ntiles;                           // first tile NOT owned by this wave's run (set below)
 	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + SLOTS - 1) / SLOTS * SLOTS;   // chunks per full tile, rounded up to the slot count
 	const int voff = lane * 16;
 
 	// descriptors of the two input streams of item (t, k); a tile past the end gets zero records
 	auto in_rsrc = [&](int t, int k, rsrc_t &rq, rsrc_t &rs) {
 		const MateDev &mt = a.mate[mate0 + k];
-		const bool ok = t < tile_end;
+		const bool ok = t < ntiles;
 		const int64_t row0 = ok ? (int64_t)t * kTileRows : 0;
 		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
 		const int nb = (rows * stride + 3) & ~3;
@@ -755,22 +752,7 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 		rs = make_rsrc(mt.out_seq ? mt.seq : nullptr, row0 * (int64_t)stride, nb);
 	};
 
-	int t = (int)blockIdx.x * nwave + wave, t_end = ntiles, t_step = tstep;
-	if (lp.tile_map == 1) {
-		const int per_wave = (ntiles + tstep - 1) / tstep;
-		const int64_t first = (int64_t)t * per_wave;
-		t = first < ntiles ? (int)first : ntiles;
-		t_end = (int64_t)t + per_wave < ntiles ? t + per_wave : ntiles;
-		t_step = 1;
-	}
-	tile_end = t_end;
-	// Waves that start together run their stream / scan phases in lockstep, which leaves HBM idle during every
-	// scan.  Spread the start of the 16 waves of a CU over one item period (16 phase slots); the offsets persist
-	// because every wave has the same period.
-	if (lp.stagger > 0) {
-		const int slot = (wave * 2 + (int)(blockIdx.x & 1) + (int)((blockIdx.x >> 1) & 7) * 5) & 15;
-		for (int i = 0; i < slot * lp.stagger; i++) __builtin_amdgcn_s_sleep(127);
-	}
+	int t = (int)blockIdx.x * nwave + wave;                 // tiles are dealt round-robin to the resident waves
 	rsrc_t rq, rs;
 	in_rsrc(t, 0, rq, rs);
 	u32x4 qv[SLOTS], sv[kTrimOnly ? 1 : SLOTS];
@@ -780,7 +762,7 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 		if (!kTrimOnly) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
 	}
 
-	for (; t < t_end; t += t_step) {
+	for (; t < ntiles; t += tstep) {
 		const int64_t row0 = (int64_t)t * kTileRows;
 		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
 		const bool active = lane < rows;
@@ -802,7 +784,7 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 			const rsrc_t ro = make_rsrc(mt.out_seq, row0 * (int64_t)stride, nb & ~3);
 			const rsrc_t rl = make_rsrc(do_trim ? mt.len : nullptr, row0 * 2, rows * 2);
 			// the item after this one: the other mate of this tile, or the first mate of the wave's next tile
-			const int tn = (k + 1 < nam) ? t : t + t_step;
+			const int tn = (k + 1 < nam) ? t : t + tstep;
 			const int kn = (k + 1 < nam) ? k + 1 : 0;
 			rsrc_t nq, ns;
 			in_rsrc(tn, kn, nq, ns);
@@ -1039,247 +1021,6 @@ __global__ __launch_bounds__(256, 4) void tile_blocked_kernel(const BlockedArgs 
 			wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
 			wave_lds_fence();
 		}
-	}
-	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// tile_pass2_kernel — the same pass with NO compute-only phase: the trim scan of item i-1 is cut into dword steps
-// and interleaved with the chunk stream of item i (two LDS images per wave: one being filled, one being scanned).
-// Why: waves that alternate a memory-only stream phase and a compute-only scan phase pull each other into lockstep
-// (a wave that is behind streams while the others scan, gets their bandwidth and catches up), and a CU whose waves all
-// scan at once leaves HBM idle.  A wave whose instruction stream is the same mix all the time has no phase to lock.
-// Costs: 2 x 64 x stride bytes of LDS per wave (8 resident waves per CU at 150 bp, 4 chunk slots in flight each).
-// ---------------------------------------------------------------------------------------------------
-struct ScanState {
-	const uint8_t *img;     // LDS image under scan
-	int a, len, best, jj;
-	u32 sh, hi, T;
-	bool alive;
-};
-
-__device__ __forceinline__ void scan_begin(ScanState &s, const uint8_t *img, int row_start, int len, bool active)
-{
-	const int end = row_start + len;
-	s.img = img; s.len = len; s.best = 0; s.jj = 0; s.T = 0; s.alive = active;
-	s.sh = (u32)end & 3u;
-	s.a = end & ~3;
-	s.hi = *reinterpret_cast<const u32 *>(img + s.a);
-}
-
-template <bool UNIFORM_LEN>
-__device__ __forceinline__ void scan_steps(ScanState &s, int nsteps, int ndw, int maxlen, int m)
-{
-	for (int it = 0; it < nsteps && s.jj < ndw; it++, s.jj++) {
-		if (__ballot(s.alive) == 0ull) { s.jj = ndw; break; }
-		s.a = max(s.a - 4, -4);
-		const u32 lo = *reinterpret_cast<const u32 *>(s.img + s.a);
-		const u32 d = __builtin_amdgcn_alignbyte(s.hi, lo, s.sh);
-		s.hi = lo;
-		u32 Ts[4];
-		Ts[0] = __builtin_amdgcn_udot4(d, 0x01000000u, s.T, false);
-		Ts[1] = __builtin_amdgcn_udot4(d, 0x01010000u, s.T, false);
-		Ts[2] = __builtin_amdgcn_udot4(d, 0x01010100u, s.T, false);
-		Ts[3] = __builtin_amdgcn_udot4(d, 0x01010101u, s.T, false);
-		s.T = Ts[3];
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const int j = 4 * s.jj + i + 1;
-			const int jm = j * m;
-			bool ok = (int)Ts[i] <= 50 + jm;
-			if (!UNIFORM_LEN) ok = ok && (j <= s.len);
-			else ok = ok && (j <= maxlen);
-			s.alive = s.alive && ok;
-			const int K = (int)Ts[i] * (1 << kKeyBits) + (j - jm * (1 << kKeyBits));
-			s.best = s.alive ? min(s.best, K) : s.best;
-		}
-	}
-}
-
-constexpr int kSlots2 = 4;
-
-template <int MODE, bool DEMUX>
-__global__ __launch_bounds__(256, 2) void tile_pass2_kernel(const TileArgs a, const LdsPlan lp)
-{
-	const int lane = threadIdx.x & (kWave - 1);
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int nwave = blockDim.x >> 6;
-	uint8_t *img0 = sk_smem + lp.tiles_off + wave * 2 * lp.tile_slot + kLdsPad;
-	uint8_t *img1 = img0 + lp.tile_slot;
-	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
-	if (DEMUX) stage_tables(a.table, lp, hist);
-	WaveCounts wc = {0u, 0u, 0u};
-
-	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
-	const int stride = a.stride;
-	const int m = a.qc.min_baseq;
-	const u32 cl2 = a.qc.cl2;
-	int nam = 0;
-	MateDev am0 = a.mate[0], am1 = a.mate[1];
-	{
-		const bool act0 = a.n_mates > 0 && (a.mate[0].out_seq || a.mate[0].lowest_k);
-		const bool act1 = a.n_mates > 1 && (a.mate[1].out_seq || a.mate[1].lowest_k);
-		if (act0 && act1) nam = 2;
-		else if (act0) nam = 1;
-		else if (act1) { nam = 1; am0 = a.mate[1]; }
-	}
-	const int64_t tstep = (int64_t)gridDim.x * nwave;
-	int64_t tile_end = ntiles;                       // first tile NOT owned by this wave's run (set below)
-	const int nchunkp = (((kTileRows * stride + 1023) >> 10) + kSlots2 - 1) / kSlots2 * kSlots2;
-	const int ngroups = nchunkp / kSlots2;
-	const int ndw = (stride + 3) >> 2;
-	const int steps_per_group = (ndw + ngroups - 1) / ngroups;
-	const int voff = lane * 16;
-
-	auto in_rsrc = [&](int64_t t, int k, rsrc_t &rq, rsrc_t &rs) {
-		const MateDev &mt = k ? am1 : am0;
-		const bool ok = t < tile_end;
-		const int64_t row0 = ok ? t * kTileRows : 0;
-		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
-		const int nb = (rows * stride + 3) & ~3;
-		rq = make_rsrc(mt.qual, row0 * (int64_t)stride, nb);
-		rs = make_rsrc(mt.out_seq ? mt.seq : nullptr, row0 * (int64_t)stride, nb);
-	};
-	// the barcode phase of one tile (bit-sliced matcher); `stage` is a free LDS image of this wave
-	auto demux_tile = [&](int64_t t, uint8_t *stage, const u32x4 &bcv0, const u32x4 &bcv1) {
-		const int64_t row0 = t * kTileRows;
-		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
-		const bool active = lane < rows;
-		const int bstride = a.bc_stride;
-		if (voff < rows * bstride) *reinterpret_cast<u32x4 *>(stage + voff) = bcv0;
-		if (1024 + voff < rows * bstride) *reinterpret_cast<u32x4 *>(stage + 1024 + voff) = bcv1;
-		wave_lds_fence();
-		int best = 0x7fffffff, first = 0, last = 0;
-		const uint8_t *row = stage + lane * bstride;
-		switch (a.table.G) {   // wave-uniform
-		case 1: demux_row_bitsliced<1>(row, sk_smem, a.table.bs_mm_off, 1, 0, a.table.L, best, first, last); break;
-		case 2: demux_row_bitsliced<2>(row, sk_smem, a.table.bs_mm_off, 2, 0, a.table.L, best, first, last); break;
-		case 3: demux_row_bitsliced<3>(row, sk_smem, a.table.bs_mm_off, 3, 0, a.table.L, best, first, last); break;
-		default: demux_row_bitsliced<4>(row, sk_smem, a.table.bs_mm_off, 4, 0, a.table.L, best, first, last); break;
-		}
-		int code = kAssignNone;
-		if (best <= a.table.max_diff) code = (first == last) ? first : kAssignAmbiguous;
-		__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
-		__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(best > 255 ? 255 : best), make_rsrc(a.lowest_diff, row0, rows), lane, 0, 0);
-		__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first, make_rsrc(a.first_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
-		__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last, make_rsrc(a.last_idx, row0 * 2, rows * 2), lane * 2, 0, 0);
-		if (active && code >= 0) atomicAdd(&hist[code], 1u);
-		wc.total += (u32)__popcll(__ballot(active));
-		wc.ident += (u32)__popcll(__ballot(active && code >= 0));
-		wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
-		wave_lds_fence();
-	};
-
-	int64_t t = (int64_t)blockIdx.x * nwave + wave, t_end = ntiles, t_step = tstep;
-	if (lp.tile_map == 1) {
-		const int64_t per_wave = (ntiles + tstep - 1) / tstep;
-		t = t * per_wave;
-		t_end = (t + per_wave) < ntiles ? (t + per_wave) : ntiles;
-		t_step = 1;
-	}
-	tile_end = t_end;
-	rsrc_t rq, rs;
-	in_rsrc(t, 0, rq, rs);
-	u32x4 qv[kSlots2], sv[kSlots2];
-#pragma unroll
-	for (int i = 0; i < kSlots2; i++) {
-		qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + i * 1024, 0, kAuxStream);
-		sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * 1024, 0, kAuxStream);
-	}
-
-	// pending scan (item i-1) and its output
-	ScanState sc;
-	sc.img = img0; sc.a = 0; sc.len = 0; sc.best = 0; sc.jj = ndw; sc.sh = 0; sc.hi = 0; sc.T = 0; sc.alive = false;
-	bool sc_valid = false, sc_ragged = false;
-	rsrc_t sc_rk = make_rsrc(nullptr, 0, 0);
-	int64_t demux_t = -1;                      // tile whose barcode phase is due once the pending scan is done
-	int item = 0;
-
-	for (; t < t_end; t += t_step) {
-		const int64_t row0 = t * kTileRows;
-		const int rows = (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows);
-		const bool active = lane < rows;
-
-		for (int k = 0; k < nam; k++, item++) {
-			const MateDev &mt = k ? am1 : am0;
-			const bool do_trim = mt.lowest_k != nullptr;
-			const int nb = rows * stride;
-			uint8_t *cur_img = (item & 1) ? img1 : img0;
-			const rsrc_t ro = make_rsrc(mt.out_seq, row0 * (int64_t)stride, nb & ~3);
-			const rsrc_t rl = make_rsrc(do_trim ? mt.len : nullptr, row0 * 2, rows * 2);
-			const int64_t tn = (k + 1 < nam) ? t : t + t_step;
-			const int kn = (k + 1 < nam) ? k + 1 : 0;
-			rsrc_t nq, ns;
-			in_rsrc(tn, kn, nq, ns);
-			// barcodes of the tile whose demux is due at the end of this item
-			u32x4 bcv0 = {0u, 0u, 0u, 0u}, bcv1 = bcv0;
-			if (DEMUX && demux_t >= 0) {
-				const int64_t r0 = demux_t * kTileRows;
-				const int rr = (int)((a.n - r0) < kTileRows ? (a.n - r0) : kTileRows);
-				const rsrc_t rb = make_rsrc(a.bc, r0 * (int64_t)a.bc_stride, (rr * a.bc_stride + 3) & ~3);
-				bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, 0);
-				bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, 0);
-			}
-			int len_ld = (int)__builtin_amdgcn_raw_buffer_load_b16(rl, lane * 2, 0, 0);
-			asm volatile("" : "+v"(len_ld));
-
-			// ---- stream item i, scan item i-1, interleaved ------------------------------------------------
-			for (int c = 0; c < nchunkp; c += kSlots2) {
-				const bool last = c + kSlots2 >= nchunkp;
-#pragma unroll
-				for (int i = 0; i < kSlots2; i++) {
-					const int off = (c + i) * 1024 + voff;
-					u32x4 o, vq;
-					mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
-					__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
-					if (do_trim && off < nb) *reinterpret_cast<u32x4 *>(cur_img + off) = vq;
-					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + kSlots2 * 1024, 0, kAuxStream);
-					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + kSlots2 * 1024, 0, kAuxStream);
-				}
-				if (sc_valid) {
-					if (sc_ragged) scan_steps<false>(sc, steps_per_group, ndw, stride, m);
-					else scan_steps<true>(sc, steps_per_group, ndw, stride, m);
-				}
-			}
-			rq = nq; rs = ns;
-
-			// ---- retire the pending scan, run the barcode phase that waited for its LDS image -------------------
-			if (sc_valid) {
-				const int kk = sc.len - (sc.best & ((1 << kKeyBits) - 1));
-				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, sc_rk, lane * 2, 0, 0);
-				sc_valid = false;
-			}
-			if (DEMUX && demux_t >= 0) {
-				demux_tile(demux_t, (item & 1) ? img0 : img1, bcv0, bcv1);      // the image the retired scan was reading
-				demux_t = -1;
-			}
-			// ---- this item's scan starts now and runs during the next item's stream -----------------------------
-			if (do_trim) {
-				wave_lds_fence();
-				const int len = (mt.len != nullptr) ? len_ld : stride;
-				scan_begin(sc, cur_img, lane * stride, len, active);
-				sc_valid = true;
-				sc_ragged = mt.len != nullptr;
-				sc_rk = make_rsrc(mt.lowest_k, row0 * 2, rows * 2);
-			}
-			if (DEMUX && k == nam - 1) demux_t = t;
-		}
-	}
-	// ---- drain: the last scan and the last tile's barcodes --------------------------------------------------
-	if (sc_valid) {
-		if (sc_ragged) scan_steps<false>(sc, ndw, ndw, stride, m);
-		else scan_steps<true>(sc, ndw, ndw, stride, m);
-		const int kk = sc.len - (sc.best & ((1 << kKeyBits) - 1));
-		__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, sc_rk, lane * 2, 0, 0);
-	}
-	if (DEMUX && demux_t >= 0) {
-		const int64_t r0 = demux_t * kTileRows;
-		const int rr = (int)((a.n - r0) < kTileRows ? (a.n - r0) : kTileRows);
-		const rsrc_t rb = make_rsrc(a.bc, r0 * (int64_t)a.bc_stride, (rr * a.bc_stride + 3) & ~3);
-		const u32x4 bcv0 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, 0);
-		const u32x4 bcv1 = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, 0);
-		wave_lds_fence();
-		demux_tile(demux_t, (item & 1) ? img1 : img0, bcv0, bcv1);
 	}
 	if (DEMUX) flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
 }
@@ -1625,14 +1366,6 @@ static hipError_t plan_shape(const void *fn, const BarcodeDev &table, int64_t n,
 	int64_t cap = (int64_t)n_cu * best_wg;
 	out.grid = (int)(want < cap ? want : cap);
 	out.block = kWave * best_nw;
-	// Optional start-up stagger of the waves (SK_STAGGER = s_sleep(127) units per phase slot).  Off by default: it
-	// moved the fused pass by -10 % .. +6 % depending on where the waves' phases happened to settle.
-	{
-		static const int env_st = getenv("SK_STAGGER") ? atoi(getenv("SK_STAGGER")) : 0;
-		const int env_map = getenv("SK_TILE_MAP") ? atoi(getenv("SK_TILE_MAP")) : 0;
-		lp.stagger = env_st > 0 ? env_st : 0;
-		lp.tile_map = env_map;
-	}
 	out.lp = lp;
 	return hipSuccess;
 }
@@ -1692,18 +1425,6 @@ hipError_t launch_tile_blocked(const BlockedArgs &a, int n_cu, hipStream_t st)
 	BlockedArgs bb = a;
 	void *kargs[] = {(void *)&bb, (void *)&sh.lp};
 	return hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
-}
-
-template <bool DEMUX>
-static const void *tile_pass2_fn(int mode)
-{
-	switch (mode) {
-	case 0: return reinterpret_cast<const void *>(tile_pass2_kernel<0, DEMUX>);
-	case 1: return reinterpret_cast<const void *>(tile_pass2_kernel<1, DEMUX>);
-	case 2: return reinterpret_cast<const void *>(tile_pass2_kernel<2, DEMUX>);
-	case 3: return reinterpret_cast<const void *>(tile_pass2_kernel<3, DEMUX>);
-	default: return reinterpret_cast<const void *>(tile_pass2_kernel<4, DEMUX>);
-	}
 }
 
 template <bool DEMUX, int SLOTS>
@@ -1791,15 +1512,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	if (total & 3)
 		for (int mi = 0; mi < b.n_mates; mi++)
 			if (b.mate[mi].out_seq) mask_tail_kernel<<<1, 4, 0, st>>>(b.mate[mi].seq, b.mate[mi].qual, b.mate[mi].out_seq, total, b.qc.min_baseq);
-	// pass2 (scan interleaved with the stream, two LDS images per wave) when 8 waves of it fit a CU and rows fit the
-	// packed scan key; everything else takes the phase kernel
-	const int env_pass2 = getenv("SK_PASS2") ? atoi(getenv("SK_PASS2")) : 0;      // read per launch: tests switch it
-	if (fuse_demux && b.bc_stride > row_bytes) row_bytes = b.bc_stride;
-	const bool any_trim = row_bytes > 0 && (b.mate[0].lowest_k || (b.n_mates > 1 && b.mate[1].lowest_k));
-	if (env_pass2 && any_trim && b.stride < (1 << kKeyBits) && 16 * (kLdsPad * 2 + ((kTileRows * row_bytes + 15) & ~15)) + 4096 <= 160 * 1024) {
-		if (!fuse_demux) b.bc = nullptr;
-		return plan_and_launch(fuse_demux ? tile_pass2_fn<true>(b.qc.mode) : tile_pass2_fn<false>(b.qc.mode), b, row_bytes, fuse_demux, 4, n_cu, st, 2);
-	}
+	if (fuse_demux && b.bc_stride > row_bytes) row_bytes = b.bc_stride;      // the barcode phase puts the tile's barcodes into the wave's LDS slot
 	// Shape of the phase kernel: workgroups of four waves, and how many of them a CU holds depends on what the pass is
 	// bound by (tools/waves_exp.py, tools/small_n.py; same buffers, one process):
 	//  * two mates, streaming-bound: TWO per CU (eight resident waves).  More waves keep more requests in flight than

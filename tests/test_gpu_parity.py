@@ -314,17 +314,7 @@ def test_fuzz_demux_decision_only(ctx, oracle, seed):
 
 
 # ---- fused pass ---------------------------------------------------------------------------------------------
-@pytest.fixture(params=["phases", "interleaved", "blocked-tiles", "interleaved+blocked"])
-def pass_variant(request, monkeypatch):
-    """The two tile-pass kernels (stream/scan phases vs scan interleaved with the stream) and both tile-to-wave maps."""
-    if "interleaved" in request.param:
-        monkeypatch.setenv("SK_PASS2", "1")
-    if "blocked" in request.param:
-        monkeypatch.setenv("SK_TILE_MAP", "1")
-    return request.param
-
-
-def test_tile_pass_variants(ctx, oracle, pass_variant):
+def test_tile_pass_shapes(ctx, oracle):
     for n, L, paired in ((30011, 150, True), (777, 150, False), (5003, 101, True), (64 * 300 + 1, 33, True)):
         table = synth.make_sheet(96, 8, dual=True, seed=4)
         bc, _ = synth.observe_barcodes(table, n, seed=n, halves=2)

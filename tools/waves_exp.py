@@ -51,14 +51,14 @@ def probe(run):
     return sorted(ts)[1]
 
 
-shapes = [("0", "0", "0"), ("0", "8", "2"), ("0", "8", "1"), ("0", "4", "2"), ("0", "4", "3"), ("0", "2", "4"), ("1", "0", "0"), ("0", "0", "0")]
+shapes = [("0", "0"), ("8", "2"), ("8", "1"), ("4", "2"), ("4", "3"), ("2", "4"), ("0", "0")]
 if os.environ.get("WAVES_SHAPES"):
     shapes = [tuple(x.split(":")) for x in os.environ["WAVES_SHAPES"].split(",")]
 for name, (nbytes, run) in CASES.items():
     if not any(tok in name for tok in ONLY.split(",")):
         continue
     for rnd in range(2):
-        for p2, nw, wg in shapes:
-            os.environ["SK_PASS2"], os.environ["SK_TILE_WAVES"], os.environ["SK_TILE_WGS"] = p2, nw, wg
+        for nw, wg in shapes:
+            os.environ["SK_TILE_WAVES"], os.environ["SK_TILE_WGS"] = nw, wg
             ms = probe(run)
-            print(f"{name:32s} round {rnd} pass2={p2} waves/WG={nw} WGs/CU={wg}: {ms:7.3f} ms  {nbytes * n / ms / 1e6 / 80:.1f}% of 8 TB/s", flush=True)
+            print(f"{name:32s} round {rnd} waves/WG={nw} WGs/CU={wg}: {ms:7.3f} ms  {nbytes * n / ms / 1e6 / 80:.1f}% of 8 TB/s", flush=True)
