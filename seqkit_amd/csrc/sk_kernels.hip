@@ -686,9 +686,6 @@ constexpr int kAuxStreamSt = SK_ST_AUX;              // tuning: cache-policy bit
 #else
 constexpr int kAuxStreamSt = (SK_NT & 2) ? 2 : 0;
 #endif
-#ifdef SK_LD_AUX
-#undef SK_LD_AUX_SET
-#endif
 
 // The kernel's first argument as it lies in the kernel-argument segment, behind an offset of zero that is produced by
 // an asm statement at the point of use: a load through it is a scalar load that cannot be hoisted out of the loop it
