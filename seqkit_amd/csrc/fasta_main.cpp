@@ -303,24 +303,30 @@ static int add_barcode(int argc, char **argv)
 	std::vector<std::string> pos;
 	if (!host::parse_args(argc, argv, 3, opts, pos, 2) || pos.size() != 2) error("Invalid arguments.\n%s", USAGE_ADDBC);
 	host::LineReader fq(pos[0]), bf(pos[1]);
-	std::string header, barcode, line;
-	auto rd = [](host::LineReader &r, std::string &s) {
-		const bool ok = r.read_line(s);
+	// lines are looked at where the readers hold them (next_line): only the barcode, which outlives its record when the
+	// barcode file runs out, is copied
+	std::string barcode;
+	auto nx = [](host::LineReader &r, const char *&p, size_t &n) {
+		const bool ok = r.next_line(p, n);
 		if (r.bad_utf8()) error("I/O error while reading from file.");
 		return ok;
 	};
+	const char *p;
+	size_t n;
 	for (;;) {
-		rd(bf, header);                                                     // :20
-		if (!header.empty() && header[0] == '@') { rd(bf, barcode); rd(bf, line); rd(bf, line); }   // :21-24
-		else if (!header.empty() && header[0] == '>') { rd(bf, barcode); }  // :25-27  (exhausted file: `barcode` keeps its value)
-		if (!rd(fq, header)) break;                                         // :29-31
-		host::out().write(header.data(), host::trim_end_len(header));       // :33
+		const bool hb = nx(bf, p, n);                                       // :20
+		const char b0 = hb ? p[0] : '\0';
+		if (b0 == '@') { if (nx(bf, p, n)) barcode.assign(p, n); else barcode.clear(); nx(bf, p, n); nx(bf, p, n); }   // :21-24
+		else if (b0 == '>') { if (nx(bf, p, n)) barcode.assign(p, n); else barcode.clear(); }   // :25-27  (exhausted file: `barcode` keeps its value)
+		if (!nx(fq, p, n)) break;                                           // :29-31
+		const char h0 = p[0];
+		host::out().write(p, host::trim_end_len(p, n));                     // :33
 		host::out().write(" BC:", 4);
 		host::out().write(barcode.data(), host::trim_end_len(barcode));
 		host::out().write("\n", 1);
-		if (header[0] == '@') { for (int k = 0; k < 3; k++) { rd(fq, line); host::out().write(line); } }   // :35-38
-		else if (header[0] == '>') { rd(fq, line); host::out().write(line); }                             // :39-40
-		else error("Invalid FASTQ line:\n%s", header.c_str());              // :41-43
+		if (h0 == '@') { for (int k = 0; k < 3; k++) if (nx(fq, p, n)) host::out().write(p, n); }   // :35-38
+		else if (h0 == '>') { if (nx(fq, p, n)) host::out().write(p, n); }                         // :39-40
+		else error("Invalid FASTQ line:\n%s", std::string(p, n).c_str());        // :41-43 (the view still holds the header: nothing was read after it)
 	}
 	return 0;
 }

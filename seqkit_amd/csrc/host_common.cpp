@@ -75,9 +75,20 @@ void panic(const char *what)
 }
 
 // ---- UTF-8 / whitespace --------------------------------------------------------------------------------
-bool utf8_valid(const uint8_t *s, size_t n)
+// length of the all-ASCII prefix, 32 bytes at a time where the CPU has AVX2 (FASTQ is all ASCII: this is the whole cost
+// of the UTF-8 check in practice)
+__attribute__((target("avx2"))) static size_t ascii_prefix_avx2(const uint8_t *s, size_t n)
 {
 	size_t i = 0;
+	for (; i + 32 <= n; i += 32)
+		if (_mm256_movemask_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i))) != 0) break;
+	return i;
+}
+
+bool utf8_valid(const uint8_t *s, size_t n)
+{
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	size_t i = avx2 ? ascii_prefix_avx2(s, n) : 0;
 	while (i < n) {
 		// ASCII runs, eight bytes at a time (FASTQ is all ASCII: this is the whole cost of the check in practice)
 		while (i + 8 <= n) {
@@ -316,6 +327,41 @@ bool LineReader::read_line(std::string &line)
 		return false;
 	}
 	return !line.empty();
+}
+
+bool LineReader::next_line(const char *&p, size_t &n)
+{
+	p = nullptr;
+	n = 0;
+	if (bad_) return false;
+	size_t scanned = 0;                                       // bytes of [pos_, end_) already known to hold no newline
+	for (;;) {
+		const uint8_t *b = buf_.data() + pos_;
+		const uint8_t *nl = end_ - pos_ > scanned ? static_cast<const uint8_t *>(memchr(b + scanned, '\n', end_ - pos_ - scanned)) : nullptr;
+		if (nl) { n = (size_t)(nl - b) + 1; break; }
+		scanned = end_ - pos_;
+		if (eof_) { n = scanned; break; }                     // the last line has no newline
+		// the line continues past what is buffered: move its start to the front and read on (a line longer than the
+		// buffer makes the buffer grow)
+		if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, scanned); pos_ = 0; end_ = scanned; }
+		if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+		ssize_t r;
+		if (gz_) r = gzread(gz_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+		else do { r = read(fd_, buf_.data() + end_, buf_.size() - end_); } while (r < 0 && errno == EINTR);
+		if (r < 0) error("I/O error while reading from file.");
+		if (r == 0) eof_ = true;
+		end_ += (size_t)r;
+	}
+	if (n == 0) return false;
+	p = reinterpret_cast<const char *>(buf_.data() + pos_);
+	pos_ += n;
+	if (!utf8_valid(reinterpret_cast<const uint8_t *>(p), n)) {
+		bad_ = true;
+		p = nullptr;
+		n = 0;
+		return false;
+	}
+	return true;
 }
 
 // ---- GzWriter: block-parallel gzip ------------------------------------------------------------------------

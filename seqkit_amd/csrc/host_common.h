@@ -54,6 +54,9 @@ public:
 	// read_line: clears `line`, reads through '\n' (kept); false at EOF.  Invalid UTF-8 sets bad_utf8() and
 	// returns false: the caller finishes the records read so far, then reports the I/O error like the reference.
 	bool read_line(std::string &line);
+	// The same line without the copy: [p, p + n) lies in the reader's buffer and stays valid until the next call on this
+	// reader.  Same rules as read_line (false at EOF or on invalid UTF-8, which sets bad_utf8()).
+	bool next_line(const char *&p, size_t &n);
 	bool bad_utf8() const { return bad_; }
 private:
 	bool fill();
