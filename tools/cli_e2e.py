@@ -61,6 +61,26 @@ for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("m
         print(f"{name:34s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
 
 
+# the reference README's pipeline (BASELINE configs[3]): both mates through `add barcode`, joined by `demultiplex`
+if not ONLY or ONLY in "pipeline":
+    plain = [f"@SIM:1:{i} 1:N:0".encode() for i in range(n_block)]
+    r1 = os.path.join(d, "R1.fq")
+    r2 = os.path.join(d, "R2.fq")
+    i1 = os.path.join(d, "I1.fq")
+    seq2, qual2 = synth.make_reads(n_block, 150, seed=2)
+    b1 = synth.fastq_text(seq, qual, headers=plain)
+    b2 = synth.fastq_text(seq2, qual2, headers=plain)
+    bi = b"".join(plain[i] + b"\n" + bc[i].tobytes() + b"\n+\n" + b"I" * bc.shape[1] + b"\n" for i in range(n_block))
+    for path, blk in ((r1, b1), (r2, b2), (i1, bi)):
+        with open(path, "wb") as f:
+            for _ in range(reps):
+                f.write(blk)
+    for label, binary in (("hip", FASTA),) if os.environ.get("E2E_NO_ORACLE") else (("hip", FASTA), ("oracle", orc.FASTA_BIN)):
+        w = os.path.join(d, label + "pipe")
+        os.makedirs(w, exist_ok=True)
+        dt, rc = t(["bash", "-c", f"{binary} demultiplex {sheet} <({binary} add barcode {r1} {i1}) <({binary} add barcode {r2} {i1})"], w)
+        print(f"{'add barcode x2 | demultiplex (pairs)':34s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M pairs/s  rc={rc}", flush=True)
+
 # f4: sam to fastq on a BAM of paired 150 bp reads
 if not ONLY or ONLY in "sam to fastq":
     import struct
