@@ -744,6 +744,23 @@ def test_bam_sequence_matches_oracle(ctx, oracle, n, stride, seq4_stride):
     assert np.array_equal(got, oracle.bam_sequence_batch(seq4, qual, None, flag, 10))
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_bam_sequence(ctx, oracle, seed):
+    """Random row pitches (multiples of 8 take the eight-bytes-per-thread kernel, the others the dword kernel), packed-row
+    pitches with and without slack, row counts around the 64-row tile, any threshold, ragged lengths on both strands."""
+    rng = np.random.default_rng(7000 + seed)
+    stride = int(rng.choice([4, 8, 12, 16, 20, 24, 40, 56, 100, 104, 152, 248, 252, 256, 1000, 1024]))
+    seq4_stride = (stride // 2 + 3) // 4 * 4 + int(rng.choice([0, 0, 4, 8]))
+    n = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 500, 3001]))
+    seq4, qual, ln, flag = bam_rows(n, stride, seed=seed, seq4_stride=seq4_stride, iupac_frac=float(rng.choice([0.0, 0.1, 0.5])))
+    m = int(rng.choice([0, 1, 10, 31, 60, 127, 128, 200, 255]))
+    got = ctx.bam_sequence(seq4, qual, ln, flag, m)
+    assert_rows_equal(got, oracle.bam_sequence_batch(seq4, qual, ln, flag, m), ln)
+    if seed % 4 == 0:
+        got = ctx.bam_sequence(seq4, qual, None, flag, m)
+        assert np.array_equal(got, oracle.bam_sequence_batch(seq4, qual, None, flag, m))
+
+
 def test_bam_sequence_every_length_and_strand(ctx, oracle):
     """Every length 0..40 on both strands: the reverse path's funnel shifts and its partial last dword."""
     stride = 40
