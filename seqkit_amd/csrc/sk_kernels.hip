@@ -1479,7 +1479,9 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
 			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
 			// short calls (fewer than about 64 tiles per wave at full occupancy): two tiles per iteration
-			const bool pair = (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
+			// (SK_DEMUX_PAIR=0 / 1 forces the choice: the tests run both kernels on the same small inputs)
+			const char *env_pair = getenv("SK_DEMUX_PAIR");
+			const bool pair = env_pair ? atoi(env_pair) != 0 : (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
 			const void *fn = pair ? (direct ? (both ? demux_hash_fn_w<true, true, true>(b.table.hk_W) : demux_hash_fn_w<true, false, true>(b.table.hk_W))
 			                                : (both ? demux_hash_fn_w<false, true, true>(b.table.hk_W) : demux_hash_fn_w<false, false, true>(b.table.hk_W)))
 			               : direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))

@@ -264,10 +264,12 @@ def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     assert np.array_equal(ctx.counts(), e_counts)
 
 
-@pytest.mark.parametrize("no_table", [False, True])
+@pytest.mark.parametrize("no_table", [False, True, "one tile per iteration"])
 def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
-    if no_table:
+    if no_table is True:
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
+    elif no_table:
+        monkeypatch.setenv("SK_DEMUX_PAIR", "0")          # the lookup kernel as calls of tens of millions of reads run it
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     bc, _ = synth.observe_barcodes(table, 200_003, seed=3)
     check_demux_decision_only(ctx, oracle, table, bc)
@@ -284,9 +286,12 @@ def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_fuzz_demux_decision_only(ctx, oracle, seed):
+def test_fuzz_demux_decision_only(ctx, oracle, seed, monkeypatch):
     """Sheets with and without a lookup table: wildcard columns (all rows / some rows), duplicates, lower case next to upper
-    case, up to 7 letters and more, any length to 32 and above, max_diff 0 / 1 / 2, observed barcodes with foreign bytes."""
+    case, up to 7 letters and more, any length to 32 and above, max_diff 0 / 1 / 2, observed barcodes with foreign bytes;
+    the lookup kernel with two tiles per iteration (what a call of this size takes) and with one (odd seeds)."""
+    if seed % 2:
+        monkeypatch.setenv("SK_DEMUX_PAIR", "0")
     rng = np.random.default_rng(12000 + seed)
     S = int(rng.choice([1, 2, 3, 16, 40, 96]))
     L = int(rng.choice([1, 3, 4, 8, 9, 17, 24, 31, 32, 33]))
