@@ -1695,38 +1695,103 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 // (rpmax) says nothing further left can reach the fragment.  The deque's pop_front (:116-119) only drops regions
 // that can no longer be hit in a coordinate-sorted file, which the host checks record by record (:70-72).
 // ---------------------------------------------------------------------------------------------------
+// Four CONSECUTIVE records per thread and iteration.  Their columns arrive as one wide load each (16 bytes of a 4-byte
+// column, 8 of the flags, 4 of the mapping qualities) instead of four narrow ones — the record-per-thread kernel spent
+// its time issuing 28 small loads per four records — and their binary searches run in lockstep, four independent loads
+// in flight where one search is a chain of about fifteen dependent ones.  VEC = the columns are 16-byte aligned.
+constexpr int kCountIlp = 4;
+template <bool VEC>
 __global__ __launch_bounds__(256) void bam_count_kernel(const CountArgs a)
 {
-	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
-		const u32 f = a.flag[r];
-		if (f & (0x4u | 0x400u | 0x100u | 0x800u)) continue;               // :46-48
-		if ((u32)a.mapq[r] < a.min_mapq) continue;                          // :49
-		const int32_t pos = a.pos[r], tid = a.tid[r];
-		u32 start = (u32)pos, end;                                          // :75
-		if (a.single_end) {
-			end = (u32)a.end_pos[r];                                        // :77
+	const int64_t ngroups = (a.n + kCountIlp - 1) / kCountIlp;
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r0 = g * kCountIlp;
+		const bool whole = r0 + kCountIlp <= a.n;
+		u32 fl[kCountIlp], mq[kCountIlp];
+		int32_t posv[kCountIlp], tidv[kCountIlp], mtidv[kCountIlp], mposv[kCountIlp], tlenv[kCountIlp], endv[kCountIlp];
+		if (VEC && whole) {
+			const u32x2 f2 = *reinterpret_cast<const u32x2 *>(a.flag + r0);
+			const u32 m4 = *reinterpret_cast<const u32 *>(a.mapq + r0);
+			const u32x4 p4 = *reinterpret_cast<const u32x4 *>(a.pos + r0), t4 = *reinterpret_cast<const u32x4 *>(a.tid + r0);
+			u32x4 e4 = {0u, 0u, 0u, 0u}, mt4 = e4, mp4 = e4, tl4 = e4;
+			if (a.single_end) e4 = *reinterpret_cast<const u32x4 *>(a.end_pos + r0);
+			else {
+				mt4 = *reinterpret_cast<const u32x4 *>(a.mtid + r0);
+				mp4 = *reinterpret_cast<const u32x4 *>(a.mpos + r0);
+				tl4 = *reinterpret_cast<const u32x4 *>(a.tlen + r0);
+			}
+#pragma unroll
+			for (int u = 0; u < kCountIlp; u++) {
+				fl[u] = (f2[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+				mq[u] = (m4 >> (8 * u)) & 0xffu;
+				posv[u] = (int32_t)p4[u]; tidv[u] = (int32_t)t4[u];
+				mtidv[u] = (int32_t)mt4[u]; mposv[u] = (int32_t)mp4[u]; tlenv[u] = (int32_t)tl4[u]; endv[u] = (int32_t)e4[u];
+			}
 		} else {
-			if (!(f & 0x1u) || (f & 0x8u)) continue;                        // :79-80
-			if (tid != a.mtid[r]) continue;                                 // :81
-			const int32_t mpos = a.mpos[r];
-			if (pos > mpos || (pos == mpos && !(f & 0x40u))) continue;      // :91
-			const int32_t tl = a.tlen[r];
-			const u32 ins = tl < 0 ? 0u - (u32)tl : (u32)tl;                // :93
-			if (ins < 20u) continue;                                        // :94
-			end = start + ins;                                              // :96
+#pragma unroll
+			for (int u = 0; u < kCountIlp; u++) {
+				const int64_t rc = r0 + u < a.n ? r0 + u : r0;                     // past the end: the group's first record again, dropped below
+				fl[u] = a.flag[rc]; mq[u] = a.mapq[rc]; posv[u] = a.pos[rc]; tidv[u] = a.tid[rc];
+				endv[u] = a.single_end ? a.end_pos[rc] : 0;
+				mtidv[u] = a.single_end ? 0 : a.mtid[rc]; mposv[u] = a.single_end ? 0 : a.mpos[rc]; tlenv[u] = a.single_end ? 0 : a.tlen[rc];
+			}
 		}
-		if (end - start > a.max_frag_len) continue;                         // :99
-		if (a.center) { start += (end - start) / 2u; end = start + 1u; }    // :103-107
-		if (tid < 0 || tid >= a.n_chr) continue;                            // the host has raised chr_names[tid] already
-		const int lo = a.chr_off[tid], hi = a.chr_off[tid + 1];
-		int b = lo, e = hi;                                                 // first region with rstart >= end
-		while (b < e) {
-			const int mid = (b + e) >> 1;
-			if (a.rstart[mid] >= end) e = mid; else b = mid + 1;
+		u32 start[kCountIlp], end[kCountIlp];
+		int lo[kCountIlp], b[kCountIlp], e[kCountIlp];
+#pragma unroll
+		for (int u = 0; u < kCountIlp; u++) {
+			const u32 f = fl[u];
+			bool ok = r0 + u < a.n;
+			ok = ok && !(f & (0x4u | 0x400u | 0x100u | 0x800u));                // :46-48
+			ok = ok && mq[u] >= a.min_mapq;                                     // :49
+			const int32_t pos = posv[u], tid = tidv[u];
+			u32 st = (u32)pos, en;                                              // :75
+			if (a.single_end) {
+				en = (u32)endv[u];                                              // :77
+			} else {
+				ok = ok && (f & 0x1u) && !(f & 0x8u);                           // :79-80
+				ok = ok && tid == mtidv[u];                                     // :81
+				const int32_t mpos = mposv[u];
+				ok = ok && !(pos > mpos || (pos == mpos && !(f & 0x40u)));      // :91
+				const int32_t tl = tlenv[u];
+				const u32 ins = tl < 0 ? 0u - (u32)tl : (u32)tl;                // :93
+				ok = ok && ins >= 20u;                                          // :94
+				en = st + ins;                                                  // :96
+			}
+			ok = ok && en - st <= a.max_frag_len;                               // :99
+			if (a.center) { st += (en - st) / 2u; en = st + 1u; }               // :103-107
+			ok = ok && tid >= 0 && tid < a.n_chr;                               // the host has raised chr_names[tid] already
+			const int tc = ok ? tid : 0;
+			lo[u] = a.chr_off[tc];
+			b[u] = lo[u];
+			e[u] = ok ? a.chr_off[tc + 1] : lo[u];                              // a dropped record searches an empty range
+			start[u] = st;
+			end[u] = en;
 		}
-		for (int i = b - 1; i >= lo; i--) {
-			if (a.rpmax[i] <= start) break;
-			if (a.rend[i] > start) atomicAdd(&a.counts[a.ridx[i]], 1u);
+		// first region with rstart >= end, for the four at once
+		for (;;) {
+			bool any = false;
+			u32 v[kCountIlp];
+			int mid[kCountIlp];
+#pragma unroll
+			for (int u = 0; u < kCountIlp; u++) {
+				mid[u] = (b[u] + e[u]) >> 1;
+				const bool go = b[u] < e[u];
+				any = any || go;
+				v[u] = go ? a.rstart[mid[u]] : 0u;
+			}
+			if (!any) break;
+#pragma unroll
+			for (int u = 0; u < kCountIlp; u++) {
+				if (b[u] < e[u]) { if (v[u] >= end[u]) e[u] = mid[u]; else b[u] = mid[u] + 1; }
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < kCountIlp; u++) {
+			for (int i = b[u] - 1; i >= lo[u]; i--) {
+				if (a.rpmax[i] <= start[u]) break;
+				if (a.rend[i] > start[u]) atomicAdd(&a.counts[a.ridx[i]], 1u);
+			}
 		}
 	}
 }
@@ -1734,9 +1799,12 @@ __global__ __launch_bounds__(256) void bam_count_kernel(const CountArgs a)
 hipError_t launch_bam_count(const CountArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
-	const int64_t want = (a.n + 255) / 256;
+	const int64_t want = (a.n + 256 * kCountIlp - 1) / (256 * kCountIlp);
 	const int grid = (int)(want < (int64_t)n_cu * 8 ? want : (int64_t)n_cu * 8);
-	bam_count_kernel<<<grid, 256, 0, st>>>(a);
+	uintptr_t bits = (uintptr_t)a.flag | (uintptr_t)a.mapq | (uintptr_t)a.pos | (uintptr_t)a.tid;
+	bits |= a.single_end ? (uintptr_t)a.end_pos : ((uintptr_t)a.mtid | (uintptr_t)a.mpos | (uintptr_t)a.tlen);
+	if ((bits & 15u) == 0) bam_count_kernel<true><<<grid, 256, 0, st>>>(a);
+	else bam_count_kernel<false><<<grid, 256, 0, st>>>(a);
 	return hipGetLastError();
 }
 
