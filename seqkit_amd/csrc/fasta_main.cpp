@@ -443,11 +443,17 @@ static int statistics(int argc, char **argv)
 		nrows = 0;
 	};
 	uint64_t total_records = 0;
-	std::string line, skip;
+	std::string line;
 	auto read = [&](std::string &l) {                                      // FileReader::read_line (src/common.rs:106-112)
 		const bool ok = fastq.read_line(l);
 		if (fastq.bad_utf8()) error("I/O error while reading from file.");
 		return ok;
+	};
+	auto skip_line = [&]() {                                                // the same read, the line left where the reader holds it
+		const char *p;
+		size_t n;
+		fastq.next_line(p, n);
+		if (fastq.bad_utf8()) error("I/O error while reading from file.");
 	};
 	while (read(line)) {                                                    // :22
 		size_t st = 0, en = 0;
@@ -462,8 +468,8 @@ static int statistics(int argc, char **argv)
 				longs.add(std::string(bc, n), 2 * (row_base + (int64_t)nrows) - 1);
 			}
 		}
-		if (line[0] == '@') { for (int k = 0; k < 3; k++) read(skip); }     // :30-31
-		else if (line[0] == '>') read(skip);                                // :32-33
+		if (line[0] == '@') { for (int k = 0; k < 3; k++) skip_line(); }    // :30-31
+		else if (line[0] == '>') skip_line();                               // :32-33
 		else error("Invalid FASTQ header:\n%s", line.c_str());              // :34-36
 		total_records += 1;                                                 // :38
 	}
