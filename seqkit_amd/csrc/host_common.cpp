@@ -4,6 +4,8 @@
 #include <dlfcn.h>
 #include <immintrin.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sched.h>
 #include <unistd.h>
 
@@ -1329,7 +1331,7 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 	// blocks into output; a writer thread takes the results in input order and writes them, so that reading the input and
 	// writing the output overlap.  Blocks are plain uninitialised buffers: value-initialising 8 MiB per block and copying
 	// every result through the output buffer were half of this thread's time.
-	struct Block { std::unique_ptr<char[]> p; size_t n = 0, cap = 0; };
+	struct Block { std::unique_ptr<char[]> p; const char *d = nullptr; size_t n = 0, cap = 0; };      // d: the bytes (p's, or a piece of the mapped file)
 	struct Pending { std::shared_ptr<Block> data; std::future<std::shared_ptr<BlockResult>> fut; };
 	std::deque<Pending> inflight;
 	std::mutex m;
@@ -1368,17 +1370,77 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 		}
 	});
 
-	std::string carry;
-	bool eof = false;
 	// SEQKIT_PROF=1: where this thread's time went, on stderr when the input is through
 	double t_alloc = 0, t_read = 0, t_count = 0, t_wait = 0, t_spawn = 0;
 	auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
 	const bool prof = getenv("SEQKIT_PROF") != nullptr;
-	while (!eof) {
+	auto stopped = [&] { std::lock_guard<std::mutex> lk(m); return failed; };
+	auto hand_over = [&](const std::shared_ptr<Block> &blk, bool last) {
+		double t0 = now();
+		Pending pd;
+		pd.data = blk;
+		pd.fut = std::async(std::launch::async, [blk, last, &fn]() {
+			auto res = std::make_shared<BlockResult>();
+			fn(blk->d, blk->n, last, *res);
+			return res;
+		});
+		t_spawn += now() - t0; t0 = now();
 		{
-			std::lock_guard<std::mutex> lk(m);
-			if (failed) break;
+			std::unique_lock<std::mutex> lk(m);
+			cv_pop.wait(lk, [&] { return inflight.size() < nthreads || failed; });
+			inflight.push_back(std::move(pd));         // (after a failure the writer is gone: the destructor of the future waits)
 		}
+		cv_push.notify_one();
+		t_wait += now() - t0;
+	};
+	// where a block of whole records ends: count its newlines, then walk back from the end over the lines of the last,
+	// incomplete record (0: not even one whole record in it)
+	auto whole_records = [&](const char *base, size_t n) -> size_t {
+		const size_t lines = count_newlines(base, n);
+		size_t drop = lines % (size_t)lines_per_record;
+		if (lines <= drop) return 0;
+		const char *nl = static_cast<const char *>(memrchr(base, '\n', n));
+		while (drop > 0) { nl = static_cast<const char *>(memrchr(base, '\n', (size_t)(nl - base))); drop--; }
+		return (size_t)(nl - base) + 1;
+	};
+
+	// A regular file is mapped: the blocks are pieces of the mapping, nothing is copied on this thread (read(2) was half
+	// of its time), and the workers take the page faults of their own blocks.  Pipes and gzip streams are read.
+	struct Mapping { const char *p = nullptr; size_t n = 0; ~Mapping() { if (p) munmap(const_cast<char *>(p), n); } } map;
+	if (!src.gz && src.fd > 0 && !getenv("SEQKIT_NO_MMAP")) {
+		struct stat st;
+		if (fstat(src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+			void *a = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, src.fd, 0);
+			if (a != MAP_FAILED) {
+				map.p = static_cast<const char *>(a);
+				map.n = (size_t)st.st_size;
+				(void)madvise(a, map.n, MADV_SEQUENTIAL);
+			}
+		}
+	}
+	if (map.p) {
+		size_t off = 0;
+		while (off < map.n && !stopped()) {
+			double t0 = now();
+			const size_t want = std::min(block_bytes, map.n - off);
+			const bool last = off + want == map.n;
+			size_t cut = want;
+			if (!last) {
+				cut = whole_records(map.p + off, want);
+				if (cut == 0) { block_bytes *= 2; continue; }       // a record larger than the block: look further
+			}
+			t_count += now() - t0;
+			auto blk = std::make_shared<Block>();
+			blk->d = map.p + off;
+			blk->n = cut;
+			hand_over(blk, last);
+			off += cut;
+		}
+	}
+	std::string carry;
+	bool eof = map.p != nullptr;
+	while (!eof) {
+		if (stopped()) break;
 		double t0 = now();
 		// fill one block: previous carry + fresh bytes, then cut after the last newline that completes a record
 		auto blk = std::make_shared<Block>();
@@ -1397,17 +1459,8 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 		carry.clear();
 		t_read += now() - t0; t0 = now();
 		if (!eof) {
-			// keep whole records only: count the block's newlines, then walk back from the end over the lines of the last,
-			// incomplete record
 			const char *base = blk->p.get();
-			const size_t lines = count_newlines(base, blk->n);
-			size_t drop = lines % (size_t)lines_per_record;
-			size_t cut = 0;
-			if (lines > drop) {
-				const char *nl = static_cast<const char *>(memrchr(base, '\n', blk->n));
-				while (drop > 0) { nl = static_cast<const char *>(memrchr(base, '\n', (size_t)(nl - base))); drop--; }
-				cut = (size_t)(nl - base) + 1;
-			}
+			const size_t cut = whole_records(base, blk->n);      // keep whole records only
 			if (cut == 0) {                    // a record larger than the block: grow and retry
 				carry.assign(base, blk->n);
 				block_bytes *= 2;
@@ -1417,23 +1470,9 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 			blk->n = cut;
 		}
 		if (blk->n == 0 && eof) break;
-		t_count += now() - t0; t0 = now();
-		const bool last = eof;
-		Pending pd;
-		pd.data = blk;
-		pd.fut = std::async(std::launch::async, [blk, last, &fn]() {
-			auto res = std::make_shared<BlockResult>();
-			fn(blk->p.get(), blk->n, last, *res);
-			return res;
-		});
-		t_spawn += now() - t0; t0 = now();
-		{
-			std::unique_lock<std::mutex> lk(m);
-			cv_pop.wait(lk, [&] { return inflight.size() < nthreads || failed; });
-			inflight.push_back(std::move(pd));         // (after a failure the writer is gone: the destructor of the future waits)
-		}
-		cv_push.notify_one();
-		t_wait += now() - t0;
+		t_count += now() - t0;
+		blk->d = blk->p.get();
+		hand_over(blk, eof);
 	}
 	{
 		std::lock_guard<std::mutex> lk(m);
