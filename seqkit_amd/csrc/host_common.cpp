@@ -1229,27 +1229,39 @@ FreeBufs &free_bufs()
 constexpr size_t kMaxFreeBufs = 96;
 }  // namespace
 
+void Bytes::borrow(const char *p, size_t n)
+{
+	this->~Bytes();
+	p_ = const_cast<char *>(p);
+	n_ = n;
+	cap_ = 0;                                                // nothing may be appended to a view
+	owned_ = false;
+}
+
 Bytes::~Bytes()
 {
-	if (!p_) return;
+	if (!p_ || !owned_) { p_ = nullptr; n_ = cap_ = 0; owned_ = true; return; }
 	FreeBufs &f = free_bufs();
 	std::lock_guard<std::mutex> lk(f.m);
 	if (f.list.size() < kMaxFreeBufs) f.list.emplace_back(p_, cap_);
 	else free(p_);
+	p_ = nullptr;
+	n_ = cap_ = 0;
 }
 
 Bytes &Bytes::operator=(Bytes &&o) noexcept
 {
 	if (this != &o) {
 		this->~Bytes();
-		p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
-		o.p_ = nullptr; o.n_ = o.cap_ = 0;
+		p_ = o.p_; n_ = o.n_; cap_ = o.cap_; owned_ = o.owned_;
+		o.p_ = nullptr; o.n_ = o.cap_ = 0; o.owned_ = true;
 	}
 	return *this;
 }
 
 void Bytes::reserve(size_t cap)
 {
+	if (!owned_) { p_ = nullptr; n_ = cap_ = 0; owned_ = true; }      // a view cannot grow: start an own buffer (callers clear() first)
 	if (cap <= cap_) return;
 	if (n_ == 0) {                                           // nothing to keep: a recycled buffer that is big enough will do
 		FreeBufs &f = free_bufs();
@@ -1278,7 +1290,17 @@ struct RecordBlocks::Impl {
 	Bytes carry;                      // bytes read beyond the last block handed out
 	size_t biggest = 0;               // the largest block so far: the next one reserves that much at once
 	bool eof = false;
-	Impl(const std::string &path, int l) : src(path), lpr(l) {}
+	const char *map = nullptr;        // a regular file is mapped: blocks are views of the mapping, nothing is copied
+	size_t map_n = 0, map_off = 0;
+	Impl(const std::string &path, int l) : src(path), lpr(l)
+	{
+		struct stat st;
+		if (!src.gz && src.fd > 0 && !getenv("SEQKIT_NO_MMAP") && fstat(src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+			void *a = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, src.fd, 0);
+			if (a != MAP_FAILED) { map = static_cast<const char *>(a); map_n = (size_t)st.st_size; (void)madvise(a, map_n, MADV_SEQUENTIAL); }
+		}
+	}
+	~Impl() { if (map) munmap(const_cast<char *>(map), map_n); }
 };
 
 RecordBlocks::RecordBlocks(const std::string &path, int lines_per_record) : impl_(new Impl(path, lines_per_record)) {}
@@ -1289,6 +1311,15 @@ bool RecordBlocks::next(size_t nrec, Bytes &blk)
 	// The block is put together in the caller's buffer: what the previous call left over, then fresh chunks until it
 	// holds the wanted lines; only the tail beyond the cut (less than one chunk) is copied, into the next call's start.
 	Impl &m = *impl_;
+	if (m.map) {
+		blk.clear();
+		if (m.map_off == m.map_n) return false;
+		size_t left = nrec * (size_t)m.lpr;
+		const size_t cut = take_lines(m.map + m.map_off, m.map_n - m.map_off, left);      // the wanted lines, or everything that is left
+		blk.borrow(m.map + m.map_off, cut);
+		m.map_off += cut;
+		return cut > 0;
+	}
 	const size_t chunk = 4u << 20;
 	blk.clear();
 	blk.reserve(std::max(m.biggest, m.carry.size()) + chunk);

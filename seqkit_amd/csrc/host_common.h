@@ -177,7 +177,7 @@ class Bytes {
 public:
 	Bytes() = default;
 	~Bytes();
-	Bytes(Bytes &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+	Bytes(Bytes &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), owned_(o.owned_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.owned_ = true; }
 	Bytes &operator=(Bytes &&o) noexcept;
 	Bytes(const Bytes &) = delete;
 	Bytes &operator=(const Bytes &) = delete;
@@ -189,9 +189,11 @@ public:
 	void reserve(size_t cap);                            // keeps the contents; takes a recycled buffer when this one is empty
 	void set_size(size_t n) { n_ = n; }                  // n <= capacity: the bytes up to n are the caller's business
 	void append(const char *p, size_t n) { reserve(n_ + n); memcpy(p_ + n_, p, n); n_ += n; }
+	void borrow(const char *p, size_t n);                // a view of bytes that somebody else keeps alive (a mapped file): read-only
 private:
 	char *p_ = nullptr;
 	size_t n_ = 0, cap_ = 0;
+	bool owned_ = true;
 };
 
 // A file read as blocks of whole records (`lines_per_record` lines each): next() returns up to `nrec` records; the last
