@@ -55,7 +55,7 @@ with open(bam, "wb") as f:
 n = millions * 1_000_000
 print(f"{n} BAM records, {os.path.getsize(bam) / 1e6:.0f} MB, written in {time.perf_counter() - t0:.1f} s", flush=True)
 for label, binary in (("hip", SAM),) if os.environ.get("E2E_NO_ORACLE") else (("hip", SAM), ("oracle", orc.SAM_BIN)):
-    for cmd in (["statistics", bam], ["fragment", "lengths", bam], ["fragments", bam]):
+    for cmd in (["statistics", bam], ["fragment", "lengths", bam], ["fragments", bam], ["to", "interleaved", "fastq", bam]):
         if label == "oracle" and cmd[0] != "statistics":
             continue
         t0 = time.perf_counter()
