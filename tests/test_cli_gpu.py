@@ -770,6 +770,8 @@ def test_fuzz_trim_and_mask_cli(bins, tmp_path, seed, monkeypatch):
     fq.write_bytes(fuzz_fastq(rng, int(rng.integers(1, 120))))
     if seed % 3 == 0:
         monkeypatch.setenv("SEQKIT_BLOCK_BYTES", str(int(rng.integers(40, 400))))     # many tiny blocks
+    if seed % 2:
+        monkeypatch.setenv("SEQKIT_NO_MMAP", "1")                                     # the input is read, not mapped
     q = str(int(rng.choice([0, 2, 20, 30, 41, 255])))
     for cmd in ("trim", "mask"):
         a = cu.run(bins["fasta"][0], [cmd, "by", "quality", str(fq), q], cwd=tmp_path)
@@ -805,6 +807,8 @@ def test_fuzz_demultiplex_cli(bins, tmp_path, seed, monkeypatch):
     (tmp_path / "r.fq").write_bytes(b"".join(recs))
     if seed % 2 == 0:
         monkeypatch.setenv("SEQKIT_BLOCK_RECORDS", str(int(rng.integers(1, 9))))
+    if seed % 4 < 2:
+        monkeypatch.setenv("SEQKIT_NO_MMAP", "1")                                     # the inputs are read, not mapped
     res = []
     for k, d in enumerate(("hip", "orc")):
         (tmp_path / d).mkdir()
