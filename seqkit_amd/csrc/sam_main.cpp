@@ -686,10 +686,23 @@ static int to_reads(int argc, char **argv)
 			if (format == OutFmt::FASTQ) {                                                                   // :107-112
 				read_seq.push_back('|');
 				const uint8_t *q = rawq.data() + r.offq;
+				// qualities below 95 (all real ones) are one ASCII byte each: add 33 to the whole row at once; a row with a
+				// larger value takes the byte-by-byte form of char::from(u8)
+				const size_t at = read_seq.size();
+				read_seq.resize(at + r.l_seq);
+				uint8_t high = 0;
 				for (uint32_t k = 0; k < r.l_seq; k++) {
 					const uint8_t ch = (uint8_t)(33 + q[k]);                                                 // u8 arithmetic wraps (release build)
-					if (ch < 0x80) read_seq.push_back((char)ch);
-					else { read_seq.push_back((char)(0xC0 | (ch >> 6))); read_seq.push_back((char)(0x80 | (ch & 0x3F))); }   // char::from(u8) as UTF-8
+					read_seq[at + k] = (char)ch;
+					high |= ch;
+				}
+				if (high & 0x80) {
+					read_seq.resize(at);
+					for (uint32_t k = 0; k < r.l_seq; k++) {
+						const uint8_t ch = (uint8_t)(33 + q[k]);
+						if (ch < 0x80) read_seq.push_back((char)ch);
+						else { read_seq.push_back((char)(0xC0 | (ch >> 6))); read_seq.push_back((char)(0x80 | (ch & 0x3F))); }   // char::from(u8) as UTF-8
+					}
 				}
 			}
 			if (!(r.flag & 0x1)) {                                                                           // :114-115
