@@ -120,15 +120,15 @@ public:
 	bool next_full(BamCore &c, Var &v, std::vector<uint8_t> &body)
 	{
 		if (!err_.empty()) return false;
-		uint8_t h[4];
-		const long r = bz_->read(h, 4);
+		uint8_t hc[36];                                          // block_size and the core in one read, as in next()
+		const long r = bz_->read(hc, 36);
 		if (r == 0) return false;
 		if (r < 0) return rd_fail("Invalid BAM record.");
-		if (r != 4) return rd_fail("BAM file ended prematurely.");
-		const uint32_t block_size = le32(h);
+		if (r < 4) return rd_fail("BAM file ended prematurely.");
+		const uint32_t block_size = le32(hc);
 		if (block_size < 32) return rd_fail("Invalid BAM record.");
-		uint8_t core[32];
-		if (!need(core, 32)) return false;
+		if (r < 36 && !need(hc + r, (size_t)(36 - r))) return false;
+		const uint8_t *core = hc + 4;
 		c.tid = (int32_t)le32(core + 0);
 		c.pos = (int32_t)le32(core + 4);
 		v.l_read_name = core[8];
