@@ -1695,10 +1695,38 @@ __global__ __launch_bounds__(256) void bam_fragments_kernel(const uint16_t *__re
 // (rpmax) says nothing further left can reach the fragment.  The deque's pop_front (:116-119) only drops regions
 // that can no longer be hit in a coordinate-sorted file, which the host checks record by record (:70-72).
 // ---------------------------------------------------------------------------------------------------
+// first index i of [b, e) with rstart[i] >= key, or e
+__device__ __forceinline__ int region_lower_bound(const uint32_t *rstart, int b, int e, u32 key)
+{
+	while (b < e) {
+		const int mid = (b + e) >> 1;
+		if (rstart[mid] >= key) e = mid; else b = mid + 1;
+	}
+	return b;
+}
+
+// the same over [lo, hi), starting from a guess p in [lo, hi]: doubling steps away from p until the answer is bracketed,
+// then a binary search inside the bracket — two probes when the answer is p or p + 1
+__device__ __forceinline__ int region_gallop(const uint32_t *rstart, int lo, int hi, int p, u32 key)
+{
+	// (three doublings at most — the answer within eight regions of the guess —, then the rest of that side is searched
+	// as a whole: records in no particular order cost a few probes more than a plain search, not twice as many)
+	if (p < hi && rstart[p] < key) {                           // to the right of p: everything before l is below the key
+		int l = p + 1, h = p + 1, step = 1;
+		while (h < hi && step <= 4 && rstart[h] < key) { l = h + 1; h += step; step <<= 1; }
+		if (step > 4 && h < hi && rstart[h] < key) { l = h + 1; h = hi; }
+		return region_lower_bound(rstart, l, h < hi ? h : hi, key);
+	}
+	int h = p, l = p - 1, step = 1;                            // p or to its left: rstart[h] >= key (or h == hi)
+	while (l >= lo && step <= 4 && rstart[l] >= key) { h = l; l -= step; step <<= 1; }
+	if (step > 4 && l >= lo && rstart[l] >= key) { h = l; l = lo - 1; }
+	return region_lower_bound(rstart, l + 1 > lo ? l + 1 : lo, h, key);
+}
+
 // Four CONSECUTIVE records per thread and iteration.  Their columns arrive as one wide load each (16 bytes of a 4-byte
 // column, 8 of the flags, 4 of the mapping qualities) instead of four narrow ones — the record-per-thread kernel spent
-// its time issuing 28 small loads per four records — and their binary searches run in lockstep, four independent loads
-// in flight where one search is a chain of about fifteen dependent ones.  VEC = the columns are 16-byte aligned.
+// its time issuing 28 small loads per four records — and only the first of the four is searched for from scratch (see
+// below).  VEC = the columns are 16-byte aligned.
 constexpr int kCountIlp = 4;
 template <bool VEC>
 __global__ __launch_bounds__(256) void bam_count_kernel(const CountArgs a)
@@ -1768,23 +1796,18 @@ __global__ __launch_bounds__(256) void bam_count_kernel(const CountArgs a)
 			start[u] = st;
 			end[u] = en;
 		}
-		// first region with rstart >= end, for the four at once
-		for (;;) {
-			bool any = false;
-			u32 v[kCountIlp];
-			int mid[kCountIlp];
+		// First region with rstart >= end.  The lane's first record is searched for in its chromosome's whole range; the
+		// next ones start from their predecessor's answer and gallop: the host demands a coordinate-sorted file, where
+		// consecutive records land on the same region or the next — two probes instead of fifteen (144 against 103 G
+		// records/s with four plain searches in lockstep; on records in no order, which only a caller of the C-ABI can
+		// hand in, 48 against 82: the answers are the same either way).
+		int hi_prev = -1;
 #pragma unroll
-			for (int u = 0; u < kCountIlp; u++) {
-				mid[u] = (b[u] + e[u]) >> 1;
-				const bool go = b[u] < e[u];
-				any = any || go;
-				v[u] = go ? a.rstart[mid[u]] : 0u;
-			}
-			if (!any) break;
-#pragma unroll
-			for (int u = 0; u < kCountIlp; u++) {
-				if (b[u] < e[u]) { if (v[u] >= end[u]) e[u] = mid[u]; else b[u] = mid[u] + 1; }
-			}
+		for (int u = 0; u < kCountIlp; u++) {
+			const int hi = e[u];
+			if (u > 0 && lo[u] == lo[u - 1] && hi == hi_prev && hi > lo[u]) b[u] = region_gallop(a.rstart, lo[u], hi, b[u - 1], end[u]);
+			else b[u] = region_lower_bound(a.rstart, lo[u], hi, end[u]);
+			hi_prev = hi;
 		}
 #pragma unroll
 		for (int u = 0; u < kCountIlp; u++) {

@@ -77,8 +77,10 @@ del flag, tid, mtid, tlen, bits
 n = 100_000_000
 n_chr = 24
 rng = np.random.default_rng(9)
-ctid = torch.sort(torch.randint(0, n_chr, (n,), dtype=torch.int32, device=dev, generator=g)).values.contiguous()
-cpos = torch.randint(0, 100_000_000, (n,), dtype=torch.int32, device=dev, generator=g)
+ckey = torch.sort((torch.randint(0, n_chr, (n,), dtype=torch.int64, device=dev, generator=g) << 32) | torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)).values
+ctid = (ckey >> 32).to(torch.int32).contiguous()          # sorted by (reference, position), as the host demands of its input
+cpos = (ckey & 0xffffffff).to(torch.int32).contiguous()
+del ckey
 ctl = torch.randint(50, 600, (n,), dtype=torch.int32, device=dev, generator=g)
 cflag = torch.full((n,), 99, dtype=torch.int16, device=dev)
 cmapq = torch.full((n,), 60, dtype=torch.uint8, device=dev)
