@@ -661,11 +661,14 @@ static int to_reads(int argc, char **argv)
 			rawq.insert(rawq.end(), qual, qual + v.l_seq);
 			recs.push_back(std::move(r));
 			max_len = std::max(max_len, v.l_seq);
-			if ((recs.size() + 1) * (size_t)(((max_len + 3) & ~3u) + 4) * 3 > kBatchBytes) break;
+			if ((recs.size() + 1) * (size_t)(((max_len + 7) & ~7u) + 4) * 3 > kBatchBytes) break;
 		}
 		const size_t n = recs.size();
 		if (n == 0) continue;
-		const size_t stride = std::max<size_t>(4, (max_len + 3) & ~(size_t)3), stride4 = std::max<size_t>(4, (stride / 2 + 3) & ~(size_t)3);
+		// row pitch: a multiple of 8, so that sequence() runs as its eight-bytes-per-thread kernel whatever the read length
+		// (reads within 4 bases of the C-ABI's 65 532 keep the multiple of 4)
+		const size_t stride8 = std::max<size_t>(8, (max_len + 7) & ~(size_t)7);
+		const size_t stride = stride8 <= 65532 ? stride8 : std::max<size_t>(4, (max_len + 3) & ~(size_t)3), stride4 = std::max<size_t>(4, (stride / 2 + 3) & ~(size_t)3);
 		m4.assign(n * stride4, 0); mq.assign(n * stride, 0); mout.resize(n * stride);
 		lens.resize(n); flags.resize(n);
 		for (size_t i = 0; i < n; i++) {
