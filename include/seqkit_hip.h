@@ -242,7 +242,9 @@ int sk_bam_fragments_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, 
  * chain (:46-50, :78-94), the fragment interval in the reference's u32 arithmetic (:75,97-107) and adds 1 to every
  * region of the record's reference that the interval overlaps (:122-126).  Columns: flag, mapq, refID, next_refID,
  * pos, next_pos, tlen of the BAM core and, for single_end only, cigar end_pos (NULL otherwise).  What depends on
- * record order — the "not coordinate sorted" error (:70-72) and chr_names[tid] (:55) — is the caller's.            */
+ * record order — the "not coordinate sorted" error (:70-72) and chr_names[tid] (:55) — is the caller's.  The counts
+ * do not depend on the order of the records; the speed does: the region search of a record starts from its
+ * predecessor's answer, which is two probes in a coordinate-sorted batch and more than a plain search otherwise.      */
 int sk_count_set_regions(sk_ctx *ctx, int n_chr, const int32_t *chr_off, const uint32_t *rstart, const uint32_t *rend,
                          const int32_t *ridx /* NULL = 0,1,2,... */, int64_t n_entries, int64_t n_regions);
 int sk_count_add(sk_ctx *ctx, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mtid,
