@@ -267,6 +267,25 @@ bool parse_args(int argc, char **argv, int first, std::vector<Opt> &opts, std::v
 	return true;
 }
 
+// Is the file behind fd BGZF (a gzip header whose extra field has the 'BC' subfield)?  Looked at with pread: the
+// descriptor's position stays where it is, and what is not a seekable file is simply not BGZF here.  The outputs of
+// this build's GzWriter are, and so is what bgzip writes: such inputs are inflated by BgzfStream's threads instead of
+// one zlib stream.
+static bool fd_is_bgzf(int fd)
+{
+	uint8_t h[1024];
+	const ssize_t r = pread(fd, h, sizeof h, 0);
+	if (r < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+	const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+	if (12 + xlen > (size_t)r) return false;
+	for (size_t o = 12; o + 4 <= 12 + xlen;) {
+		const size_t slen = (size_t)h[o + 2] | ((size_t)h[o + 3] << 8);
+		if (h[o] == 'B' && h[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) return true;
+		o += 4 + slen;
+	}
+	return false;
+}
+
 // ---- LineReader ------------------------------------------------------------------------------------------
 LineReader::LineReader(const std::string &path)
 {
@@ -277,9 +296,14 @@ LineReader::LineReader(const std::string &path)
 		fd_ = open(path.c_str(), O_RDONLY);
 		if (fd_ < 0) error("Cannot open file %s for reading.", path.c_str());
 		if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
-			gz_ = gzdopen(fd_, "rb");                 // inflates every member of the file, like `gunzip -c`
-			if (!gz_) error("Cannot start gunzip process.");
-			gzbuffer(gz_, 1 << 18);
+			if (fd_is_bgzf(fd_)) {
+				bz_ = new BgzfStream(fd_);                // takes the descriptor
+				fd_ = -1;
+			} else {
+				gz_ = gzdopen(fd_, "rb");             // inflates every member of the file, like `gunzip -c`
+				if (!gz_) error("Cannot start gunzip process.");
+				gzbuffer(gz_, 1 << 18);
+			}
 		}
 	}
 	buf_.resize(1 << 18);
@@ -287,19 +311,24 @@ LineReader::LineReader(const std::string &path)
 
 LineReader::~LineReader()
 {
+	delete bz_;
 	if (gz_) gzclose(gz_);
 	else if (fd_ > 0) close(fd_);
+}
+
+long LineReader::read_more(uint8_t *dst, size_t n)
+{
+	if (bz_) return bz_->read(dst, n);
+	if (gz_) return gzread(gz_, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+	ssize_t r;
+	do { r = read(fd_, dst, n); } while (r < 0 && errno == EINTR);
+	return (long)r;
 }
 
 bool LineReader::fill()
 {
 	if (eof_) return false;
-	ssize_t r;
-	if (gz_) {
-		r = gzread(gz_, buf_.data(), (unsigned)buf_.size());
-	} else {
-		do { r = read(fd_, buf_.data(), buf_.size()); } while (r < 0 && errno == EINTR);
-	}
+	const long r = read_more(buf_.data(), buf_.size());
 	if (r < 0) error("I/O error while reading from file.");
 	pos_ = 0;
 	end_ = (size_t)r;
@@ -347,9 +376,7 @@ bool LineReader::next_line(const char *&p, size_t &n)
 		// buffer makes the buffer grow)
 		if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, scanned); pos_ = 0; end_ = scanned; }
 		if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
-		ssize_t r;
-		if (gz_) r = gzread(gz_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
-		else do { r = read(fd_, buf_.data() + end_, buf_.size() - end_); } while (r < 0 && errno == EINTR);
+		const long r = read_more(buf_.data() + end_, buf_.size() - end_);
 		if (r < 0) error("I/O error while reading from file.");
 		if (r == 0) eof_ = true;
 		end_ += (size_t)r;
@@ -431,8 +458,9 @@ struct GzWriter::Impl {
 struct Deflater {
 	void *(*alloc)(int) = nullptr;
 	void (*free_)(void *) = nullptr;
-	size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+	size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;      // raw deflate
 	size_t (*bound)(void *, size_t) = nullptr;
+	uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
 	Deflater()
 	{
 		if (getenv("SEQKIT_NO_LIBDEFLATE")) return;
@@ -440,36 +468,63 @@ struct Deflater {
 		if (!h) return;
 		alloc = reinterpret_cast<void *(*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
 		free_ = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_compressor"));
-		compress = reinterpret_cast<size_t (*)(void *, const void *, size_t, void *, size_t)>(dlsym(h, "libdeflate_gzip_compress"));
-		bound = reinterpret_cast<size_t (*)(void *, size_t)>(dlsym(h, "libdeflate_gzip_compress_bound"));
-		if (!alloc || !free_ || !compress || !bound) alloc = nullptr;
+		compress = reinterpret_cast<size_t (*)(void *, const void *, size_t, void *, size_t)>(dlsym(h, "libdeflate_deflate_compress"));
+		bound = reinterpret_cast<size_t (*)(void *, size_t)>(dlsym(h, "libdeflate_deflate_compress_bound"));
+		crc = reinterpret_cast<uint32_t (*)(uint32_t, const void *, size_t)>(dlsym(h, "libdeflate_crc32"));
+		if (!alloc || !free_ || !compress || !bound || !crc) alloc = nullptr;
 	}
 };
 
-static std::string gzip_member(const std::string &in)
+// The output of one job as BGZF blocks (SAMv1 §4.1: gzip members of at most 64 KiB whose extra field 'BC' carries the
+// block size).  Any gzip reader takes them as the members they are; a reader that knows BGZF — htslib's bgzip, this
+// build's own BgzfStream behind every *.gz input — finds the block boundaries without inflating and inflates the
+// blocks in parallel.
+constexpr size_t kBgzfInput = 0xff00;                       // input bytes per block, as htslib cuts them: the block stays under 64 KiB whatever the data
+static const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+static void bgzf_append_block(std::string &out, const char *in, size_t n)
 {
 	static const Deflater ld;
+	const size_t at = out.size();
+	out.resize(at + 18 + n + 1024 + 8);                       // header, deflate at its worst (stored blocks), trailer
+	uint8_t *blk = reinterpret_cast<uint8_t *>(&out[at]);
+	size_t clen = 0;
+	uint32_t crc = 0;
 	if (ld.alloc) {
 		thread_local void *comp = ld.alloc(6);
 		if (comp) {
-			std::string out;
-			out.resize(ld.bound(comp, in.size()));
-			const size_t n = ld.compress(comp, in.data(), in.size(), &out[0], out.size());
-			if (n > 0) { out.resize(n); return out; }
+			clen = ld.compress(comp, in, n, blk + 18, n + 1024);
+			crc = ld.crc(0, in, n);
 		}
 	}
-	z_stream z;
-	memset(&z, 0, sizeof z);
-	deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
+	if (clen == 0) {
+		z_stream z;
+		memset(&z, 0, sizeof z);
+		deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+		z.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(in));
+		z.avail_in = (uInt)n;
+		z.next_out = blk + 18;
+		z.avail_out = (uInt)(n + 1024);
+		deflate(&z, Z_FINISH);
+		clen = (n + 1024) - z.avail_out;
+		deflateEnd(&z);
+		crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(in), (uInt)n);
+	}
+	const size_t bsize = 18 + clen + 8;                         // < 65536: kBgzfInput leaves room for incompressible data
+	static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+	memcpy(blk, head, 16);
+	blk[16] = (uint8_t)((bsize - 1) & 0xff);
+	blk[17] = (uint8_t)((bsize - 1) >> 8);
+	uint8_t *t = blk + 18 + clen;
+	for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
+	out.resize(at + bsize);
+}
+
+static std::string gzip_member(const std::string &in)
+{
 	std::string out;
-	out.resize(deflateBound(&z, in.size()) + 32);
-	z.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(in.data()));
-	z.avail_in = (uInt)in.size();
-	z.next_out = reinterpret_cast<Bytef *>(&out[0]);
-	z.avail_out = (uInt)out.size();
-	deflate(&z, Z_FINISH);
-	out.resize(out.size() - z.avail_out);
-	deflateEnd(&z);
+	out.reserve(in.size() / 3 + 64);
+	for (size_t o = 0; o < in.size(); o += kBgzfInput) bgzf_append_block(out, in.data() + o, std::min(kBgzfInput, in.size() - o));
 	return out;
 }
 
@@ -886,11 +941,17 @@ void GzWriter::write(std::string &&s)
 void GzWriter::close()
 {
 	if (!impl_ || impl_->fd < 0) return;
-	// an empty file still gets one (empty) member, like `gzip -c < /dev/null`
-	if (impl_->bytes > 0 || impl_->next_submit == 0) impl_->submit();
+	if (impl_->bytes > 0) impl_->submit();
 	{
 		std::unique_lock<std::mutex> lk(impl_->m);
 		impl_->cv.wait(lk, [this] { return impl_->next_write == impl_->next_submit; });
+	}
+	// BGZF's end-of-file marker: an empty block (also what an empty file consists of: one empty member, like
+	// `gzip -c < /dev/null`)
+	for (size_t off = 0; off < sizeof kBgzfEof;) {
+		const ssize_t w = ::write(impl_->fd, kBgzfEof + off, sizeof kBgzfEof - off);
+		if (w <= 0) break;
+		off += (size_t)w;
 	}
 	::close(impl_->fd);
 	impl_->fd = -1;
@@ -1109,6 +1170,7 @@ namespace {
 // raw byte source with the FileReader path rules (src/common.rs:88-103)
 struct RawSource {
 	gzFile gz = nullptr;
+	std::unique_ptr<BgzfStream> bz;                           // a *.gz input that is BGZF: inflated block-parallel
 	int fd = -1;
 	explicit RawSource(const std::string &path)
 	{
@@ -1116,17 +1178,24 @@ struct RawSource {
 		fd = open(path.c_str(), O_RDONLY);
 		if (fd < 0) error("Cannot open file %s for reading.", path.c_str());
 		if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+			if (fd_is_bgzf(fd)) {
+				bz.reset(new BgzfStream(fd));             // takes the descriptor
+				fd = -1;
+				return;
+			}
 			gz = gzdopen(fd, "rb");
 			if (!gz) error("Cannot start gunzip process.");
 			gzbuffer(gz, 1 << 20);
 		}
 	}
 	~RawSource() { if (gz) gzclose(gz); else if (fd > 0) close(fd); }
+	bool compressed() const { return gz != nullptr || bz != nullptr; }
 	size_t read_some(char *dst, size_t n)
 	{
-		ssize_t r;
-		if (gz) r = gzread(gz, dst, (unsigned)std::min<size_t>(n, 1u << 30));
-		else do { r = read(fd, dst, n); } while (r < 0 && errno == EINTR);
+		long r;
+		if (bz) r = bz->read(dst, n);
+		else if (gz) r = gzread(gz, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+		else do { r = (long)read(fd, dst, n); } while (r < 0 && errno == EINTR);
 		if (r < 0) error("I/O error while reading from file.");
 		return (size_t)r;
 	}
@@ -1295,7 +1364,7 @@ struct RecordBlocks::Impl {
 	Impl(const std::string &path, int l) : src(path), lpr(l)
 	{
 		struct stat st;
-		if (!src.gz && src.fd > 0 && !getenv("SEQKIT_NO_MMAP") && fstat(src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+		if (!src.compressed() && src.fd > 0 && !getenv("SEQKIT_NO_MMAP") && fstat(src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
 			void *a = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, src.fd, 0);
 			if (a != MAP_FAILED) { map = static_cast<const char *>(a); map_n = (size_t)st.st_size; (void)madvise(a, map_n, MADV_SEQUENTIAL); }
 		}
@@ -1438,7 +1507,7 @@ void run_block_pipeline(const std::string &path, int lines_per_record, const Blo
 	// A regular file is mapped: the blocks are pieces of the mapping, nothing is copied on this thread (read(2) was half
 	// of its time), and the workers take the page faults of their own blocks.  Pipes and gzip streams are read.
 	struct Mapping { const char *p = nullptr; size_t n = 0; ~Mapping() { if (p) munmap(const_cast<char *>(p), n); } } map;
-	if (!src.gz && src.fd > 0 && !getenv("SEQKIT_NO_MMAP")) {
+	if (!src.compressed() && src.fd > 0 && !getenv("SEQKIT_NO_MMAP")) {
 		struct stat st;
 		if (fstat(src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
 			void *a = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, src.fd, 0);

@@ -45,6 +45,7 @@ struct Opt { const char *name; bool takes_value; bool present; std::string value
 bool parse_args(int argc, char **argv, int first, std::vector<Opt> &opts, std::vector<std::string> &pos, size_t max_pos);
 
 // ---- line reader -----------------------------------------------------------------------------------------
+class BgzfStream;
 class LineReader {
 public:
 	explicit LineReader(const std::string &path);        // exits with the reference's message when it cannot open
@@ -60,7 +61,9 @@ public:
 	bool bad_utf8() const { return bad_; }
 private:
 	bool fill();
+	long read_more(uint8_t *dst, size_t n);              // from whichever source this reader has; < 0: read error
 	gzFile gz_ = nullptr;
+	BgzfStream *bz_ = nullptr;                           // a *.gz input that is BGZF: inflated block-parallel
 	int fd_ = -1;
 	std::vector<uint8_t> buf_;
 	size_t pos_ = 0, end_ = 0;

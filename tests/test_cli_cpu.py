@@ -1,7 +1,9 @@
 """CPU: the C++ `fasta` host against the oracle CLI for the parts that need no GPU (argument grammar, exit codes,
 `fasta add barcode`, stream plumbing).  Anything arithmetic is GPU-only and lives in test_cli_gpu.py."""
 import gzip
+import zlib
 
+import numpy as np
 import pytest
 
 from tests import cli_util as cu
@@ -34,6 +36,44 @@ def test_add_barcode_fastq_fasta_and_stale_barcode(bins, tmp_path):
     fa.write_bytes(b">s1\nACGT\n>s2\nTT\n")
     ia.write_bytes(b">b1\nAAAA\n>b2\nCCCC\n")
     same(bins, ["add", "barcode", str(fa), str(ia)], tmp_path)
+
+
+def bgzf_bytes(data, block=5000):
+    """`data` as BGZF (SAMv1 section 4.1), written from the specification: blocks of `block` input bytes and the EOF block."""
+    import struct
+    out = b""
+    for o in list(range(0, len(data), block)) + [None]:
+        piece = b"" if o is None else data[o:o + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(piece) + c.flush()
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(piece), len(piece))
+    return out
+
+
+def test_gz_inputs_plain_gzip_and_bgzf(bins, tmp_path):
+    """A *.gz input is inflated whether it is one gzip stream, several members, or BGZF (which the block-parallel reader
+    takes): the same output as for the text, in both line readers' commands."""
+    rng = np.random.default_rng(11)
+    recs = b"".join(b"@r%d some text\n" % i + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 200))).astype(np.uint8)) + b"\n+\n" + b"I" * 3 + b"\n"
+                    for i in range(4000))
+    idx = b"".join(b"@r%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=8).astype(np.uint8)) + b"\n+\nIIIIIIII\n" for i in range(4000))
+    (tmp_path / "r.fq").write_bytes(recs)
+    (tmp_path / "i.fq").write_bytes(idx)
+    ref = cu.run(bins[0], ["add", "barcode", "r.fq", "i.fq"], cwd=tmp_path)
+    assert ref[0] == 0 and ref[1].count(b" BC:") == 4000
+    with gzip.open(tmp_path / "r1.fq.gz", "wb") as f:
+        f.write(recs)
+    (tmp_path / "r2.fq.gz").write_bytes(gzip.compress(recs[:100000]) + gzip.compress(recs[100000:]))      # two members
+    (tmp_path / "r3.fq.gz").write_bytes(bgzf_bytes(recs))
+    (tmp_path / "i3.fq.gz").write_bytes(bgzf_bytes(idx, block=777))
+    for r, i in (("r1.fq.gz", "i.fq"), ("r2.fq.gz", "i.fq"), ("r3.fq.gz", "i.fq"), ("r3.fq.gz", "i3.fq.gz"), ("r.fq", "i3.fq.gz")):
+        got = cu.run(bins[0], ["add", "barcode", r, i], cwd=tmp_path)
+        assert got[0] == 0 and got[1] == ref[1], (r, i)
+    # a BGZF file cut off inside a block ends there, like a gzip stream that `gunzip -c` could not finish
+    whole = bgzf_bytes(recs)
+    (tmp_path / "cut.fq.gz").write_bytes(whole[:len(whole) // 2])
+    got = cu.run(bins[0], ["add", "barcode", "cut.fq.gz", "i.fq"], cwd=tmp_path)
+    assert ref[1].startswith(got[1][:got[1].rfind(b"\n@") + 1]) and 0 < len(got[1]) < len(ref[1])
 
 
 def test_add_barcode_stdin_gz_and_invalid_line(bins, tmp_path):
@@ -114,6 +154,21 @@ def test_block_parallel_gzip_writer(hip_lib, tmp_path):
         subprocess.run([str(exe), str(d), str(nf), str(total)], check=True, timeout=120, env=env)
         for i in range(nf):
             got = gzip.open(d / f"f{i}.gz", "rb").read()
+            # the file is BGZF (SAMv1 section 4.1): every member carries its own size in a 'BC' extra field, holds at most
+            # 64 KiB and inflates on its own; the last one is the empty end-of-file block
+            raw = (d / f"f{i}.gz").read_bytes()
+            o, parts = 0, []
+            while o < len(raw):
+                assert raw[o:o + 4] == b"\x1f\x8b\x08\x04" and raw[o + 10:o + 16] == b"\x06\x00BC\x02\x00", (i, o)
+                bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+                assert 28 <= bsize <= 65536 and o + bsize <= len(raw)
+                piece = zlib.decompress(raw[o + 18:o + bsize - 8], -15)
+                assert zlib.crc32(piece) == int.from_bytes(raw[o + bsize - 8:o + bsize - 4], "little")
+                assert len(piece) == int.from_bytes(raw[o + bsize - 4:o + bsize], "little") <= 65536
+                parts.append(piece)
+                o += bsize
+            assert parts and parts[-1] == b"" and raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+            assert b"".join(parts) == got
             exp = bytes((ord("A") + (k * (i + 3)) % 23) for k in range(total)) if total <= 200_000 else None
             assert len(got) == total
             if exp is not None:

@@ -61,6 +61,39 @@ for name, args in (("trim by quality", ["trim", "by", "quality", fq, "20"]), ("m
         print(f"{name:34s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
 
 
+# compressed inputs: one gzip stream (inflated by one zlib stream, as `gunzip -c` would) against BGZF (what this build's
+# GzWriter and bgzip write: inflated block-parallel)
+if ONLY and ONLY in "gz inputs":
+    import gzip
+    import struct
+    import zlib
+
+    def bgzf(data):
+        out = []
+        for o in list(range(0, len(data), 0xff00)) + [None]:
+            piece = b"" if o is None else data[o:o + 0xff00]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            comp = c.compress(piece) + c.flush()
+            out.append(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(piece), len(piece)))
+        return b"".join(out)
+
+    gz1 = os.path.join(d, "plain.fq.gz")
+    gz2 = os.path.join(d, "bgzf.fq.gz")
+    one = gzip.compress(block, 1)
+    with open(gz1, "wb") as f:                       # `reps` members: any gzip reader goes through them one after the other
+        for _ in range(reps):
+            f.write(one)
+    blk = bgzf(block)[:-28]
+    with open(gz2, "wb") as f:
+        for _ in range(reps):
+            f.write(blk)
+        f.write(bgzf(b""))
+    for label, path in (("gzip members", gz1), ("BGZF", gz2)):
+        w = os.path.join(d, "gzin")
+        os.makedirs(w, exist_ok=True)
+        dt, rc = t([FASTA, "trim", "by", "quality", path, "20"], w)
+        print(f"{'trim by quality, input ' + label:40s} {dt:7.2f} s  {n / dt / 1e6:6.2f} M reads/s  rc={rc}", flush=True)
+
 # the reference README's pipeline (BASELINE configs[3]): both mates through `add barcode`, joined by `demultiplex`
 if not ONLY or ONLY in "pipeline":
     plain = [f"@SIM:1:{i} 1:N:0".encode() for i in range(n_block)]
