@@ -38,6 +38,9 @@ struct sk_ctx {
 	std::vector<uint8_t> sheet;        // the sheet as given to sk_set_barcodes (the table is built from it on first use)
 	bool hk_tried = false;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
+	unsigned long long *d_count_rep = nullptr; // BarcodeDev::count_rep
+	int count_rep_pitch = 0;
+	size_t count_rep_set = 0;                  // u64 words of one set
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
@@ -317,6 +320,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_bs) (void)hipFree(c->d_bs);
 	if (c->d_hk) (void)hipFree(c->d_hk);
 	if (c->d_counts) (void)hipFree(c->d_counts);
+	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->census) sk::census_destroy(c->census);
 	if (c->comm) (void)sk_comm_destroy(c);
@@ -407,6 +411,7 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	c->hk = sk::BarcodeDev{};
 	c->bs_bytes = c->bs_mm_off = c->G = 0;
 	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
+	if (c->d_count_rep) { SK_HIP(c, hipFree(c->d_count_rep)); c->d_count_rep = nullptr; }
 	c->have_table = false;
 	c->S = S; c->L = L; c->max_diff = max_diff;
 	c->W = (L + 3) / 4;
@@ -480,6 +485,14 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	c->hk_tried = false;
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
+	if (S + 3 <= sk::kMaxLdsHist) {
+		// two sets: the chunk pipeline of the host entry points has launches of its two lanes in flight together, and a
+		// set serves one launch (the kernel and the fold behind it) at a time
+		c->count_rep_pitch = (S + 3 + 31) & ~31;                 // whole 256-byte pieces: no line is shared by two copies
+		c->count_rep_set = (size_t)sk::kCountReplicas * c->count_rep_pitch;
+		SK_HIP(c, hipMalloc((void **)&c->d_count_rep, 2 * c->count_rep_set * 8));
+		SK_HIP(c, hipMemset(c->d_count_rep, 0, 2 * c->count_rep_set * 8));
+	}
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx stream is non-blocking: make the uploads visible to it
 	c->have_table = true;
 	return SK_OK;
@@ -511,6 +524,7 @@ static sk::BarcodeDev table_of(const sk_ctx *c)
 	t.hk = c->hk.hk; t.hk_W = c->hk.hk_W; t.hk_slot_dw = c->hk.hk_slot_dw; t.hk_mask = c->hk.hk_mask;
 	t.hk_sh = c->hk.hk_sh; t.hk_fold = c->hk.hk_fold; t.hk_tab_lo = c->hk.hk_tab_lo; t.hk_tab_hi = c->hk.hk_tab_hi;
 	t.hk_seed = c->hk.hk_seed;
+	t.count_rep = c->d_count_rep; t.count_rep_pitch = c->count_rep_pitch;
 	for (int w = 0; w < 8; w++) t.hk_keep[w] = c->hk.hk_keep[w];
 	return t;
 }
@@ -852,6 +866,7 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 			d.last_idx = a->last_idx ? (int16_t *)carve((size_t)nr * 2) : nullptr;
 		}
 		sk::TileArgs t = tile_args_of(c, &d);
+		if (t.table.count_rep && (pipe.k & 1)) t.table.count_rep += c->count_rep_set;     // the second lane's set of counter copies
 		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, st));
 		for (int m = 0; m < a->n_mates; m++) {
 			const sk_mate &mt = a->mate[m];

@@ -53,7 +53,12 @@ struct BarcodeDev {
 	uint32_t hk_tab_lo, hk_tab_hi;     // the 8 sheet letters by that index (v_perm table)
 	uint32_t hk_seed;
 	uint32_t hk_keep[8];       // per key dword: 0xFF in the bytes of columns that count (inside L, not a wildcard column)
+	// spread counters (sk_kernels.hip: flush_counts_spread), or nullptr: kCountReplicas rows of count_rep_pitch u64, all zero
+	// between launches
+	unsigned long long *count_rep;
+	int count_rep_pitch;
 };
+constexpr int kCountReplicas = 16;
 constexpr uint32_t kHashEmpty = 0x80000000u;
 constexpr int kMaxHashLen = 32;
 // The one hash both sides use (host builds the table, the kernel probes it): Jenkins one-at-a-time over the key dwords.

@@ -655,6 +655,36 @@ __device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, 
 	}
 }
 
+// The counters of a demultiplex-alone launch.  Such a call can be a few tens of microseconds, and thousands of workgroups
+// each adding S + 3 numbers to the SAME S + 3 addresses took longer than the lookups (16 single-index, 1 M reads: 34 us
+// with, 8 us without; 10 M: 51 / 37 — about 10 ns per addition to an address that others add to).
+// So a workgroup adds to one of kCountReplicas copies of the counters (different lines), and a one-workgroup kernel behind
+// the launch (counts_fold_kernel) moves the copies into the counters and leaves them zero for the next launch.
+// (Folding inside the kernel — the last workgroup found by tickets — was tried: a ticket is an atomic WITH return, and
+// 2 048 of them cost 6 us at 10 M reads but 90 us at 100 M; an agent-scope release fence per workgroup cost 65 us.)
+__device__ __forceinline__ void flush_counts_spread(const BarcodeDev &tb, unsigned long long *counts, const LdsPlan &lp, u32 *hist, int lane,
+                                                    const WaveCounts &wc)
+{
+	const bool spread = tb.count_rep != nullptr && lp.use_lds_hist;
+	flush_counts(tb.S, spread ? tb.count_rep + (size_t)(blockIdx.x & (kCountReplicas - 1)) * tb.count_rep_pitch : counts, lp, hist, lane, wc);
+}
+__global__ __launch_bounds__(256) void counts_fold_kernel(unsigned long long *__restrict__ rep, int pitch, int nc, unsigned long long *__restrict__ counts)
+{
+	for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+		unsigned long long sum = 0;
+#pragma unroll
+		for (int r = 0; r < kCountReplicas; r++) { sum += rep[(size_t)r * pitch + i]; rep[(size_t)r * pitch + i] = 0; }
+		if (sum) atomicAdd(&counts[i], sum);
+	}
+}
+// what launch_tile_pass puts behind a demultiplex-alone kernel: the same condition as flush_counts_spread's
+static hipError_t launch_counts_fold(const TileArgs &b, hipStream_t st)
+{
+	if (b.table.count_rep == nullptr || b.table.S + 3 > kMaxLdsHist) return hipSuccess;
+	counts_fold_kernel<<<1, 256, 0, st>>>(b.table.count_rep, b.table.count_rep_pitch, b.table.S + 3, b.counts);
+	return hipGetLastError();
+}
+
 // One (tile, mate) item is streamed as 1 KiB chunks.  The loads of two chunks are always in flight per wave
 // (register slots R0/R1), INCLUDING across the scan and barcode phases: the last two issue slots of an item
 // already fetch the first two chunks of the wave's next item, so HBM requests keep flowing while the wave
@@ -1094,7 +1124,7 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 		demux_commit(a, lp, hist, row0 + lane, active, diff, first, last, wc);
 		wave_lds_fence();
 	}
-	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
+	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1111,8 +1141,28 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 // loop), <= 4 MiB, read through L2.  Sheets this cannot serve (max_diff > 1,
 // wildcards in some rows only, more than 7 letters, detail outputs wanted) take demux_tile_kernel.
 // ---------------------------------------------------------------------------------------------------
+// N = 1..4 consecutive dwords from a 16-byte aligned address, one load of exactly that width
+template <int N>
+__device__ __forceinline__ void load_dwords(const u32 *p, u32 *out)
+{
+	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+	typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
+	if (N == 1) {
+		out[0] = p[0];
+	} else if (N == 2) {
+		const u32x2_t v = *reinterpret_cast<const u32x2_t *>(p);
+		out[0] = v[0]; out[1] = v[1];
+	} else if (N == 3) {
+		const u32x3_t v = *reinterpret_cast<const u32x3_t *>(p);
+		out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+	} else {
+		const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+		out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+	}
+}
+
 constexpr int kHashTileLds = 2048 + 64;      // LDS per tile of the lookup kernel: 64 rows of at most 32 bytes, and the dword read past a row's end
-template <int W, bool DIRECT, bool BOTH, bool PAIR = false>
+template <int W, bool DIRECT, bool BOTH, int NT = 1>
 __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -1141,11 +1191,10 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 	// (a big table must stay in L2: the read-once barcode stream is then loaded nontemporal — 68 -> 98 G pairs/s for the
 	// 1 MiB table of the 96 dual-index sheet; with a small table plain loads are faster, 246 against 221 G reads/s)
 	constexpr int kAux = BOTH ? 0 : kAuxStream;
-	// PAIR (short calls): TWO tiles per wave and iteration, taken through the stages together (keys and
-	// hashes, the table loads of both, then the compares and stores).  A 10 M-read call is 19 iterations per wave, each a
-	// chain of dependent round trips (rows -> table slot -> store), and a second independent chain hides half of them:
-	// 160 -> 196 G reads/s; at 100 M reads per call it is the other way round (238 -> 222), so the launch chooses.
-	constexpr int NT = PAIR ? 2 : 1;
+	// NT = 4: four tiles per wave and iteration, taken through the stages together (keys and hashes, the table loads of
+	// all, then the compares and stores).  An iteration is a chain of dependent round trips (rows -> table slot in L2 ->
+	// second slot for some -> store); with the big table of a dual-index sheet four independent chains per wave hide more of
+	// them than twice the waves do.  The launch chooses.
 	u32 raw[NT][W];
 	u32x4 v0[NT], v1[NT];
 	auto fetch = [&](int64_t t, int i) {
@@ -1158,18 +1207,14 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 			v1[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
 		}
 	};
+	// a slot's W + 1 dwords with loads of exactly that width: a wider load leaves result registers that nothing reads, the
+	// register allocator hands them to the next address computation, and the hardware then has to wait for the load before
+	// that computation may write them — the two slot loads of a read went out one after the other (168 against 240 G reads/s)
 	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
-		const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;
-		if (W < 4) {
-			const u32x4 q = *reinterpret_cast<const u32x4 *>(sp);
-#pragma unroll
-			for (int w = 0; w <= W; w++) sv[w] = q[w];
-		} else {
-			const u32x4 q0 = *reinterpret_cast<const u32x4 *>(sp), q1 = *reinterpret_cast<const u32x4 *>(sp + 4);
-#pragma unroll
-			for (int w = 0; w <= W && w < 8; w++) sv[w] = w < 4 ? q0[w] : q1[w - 4];
-			if (W == 8) sv[8] = sp[8];
-		}
+		const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;          // 16-byte aligned: the pitch is 4, 8 or 16 dwords
+		load_dwords<(W + 1 < 4 ? W + 1 : 4)>(sp, &sv[0]);
+		if (W + 1 > 4) load_dwords<(W + 1 < 8 ? W + 1 - 4 : 4)>(sp + 4, &sv[4]);
+		if (W + 1 > 8) load_dwords<1>(sp + 8, &sv[W + 1 > 8 ? 8 : 0]);
 	};
 	int64_t t = (int64_t)blockIdx.x * nwave + wave;
 #pragma unroll
@@ -1185,7 +1230,7 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
 		} else {
 #pragma unroll
-			for (int i = 0; i < NT; i++) {                             // tile i of the pair has its own 2 KiB + pad of the wave's LDS slot
+			for (int i = 0; i < NT; i++) {                             // each tile of the iteration has its own 2 KiB + pad of the wave's LDS slot
 				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + voff) = v0[i];
 				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + 1024 + voff) = v1[i];
 			}
@@ -1263,21 +1308,21 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 		}
 		if (!DIRECT) wave_lds_fence();
 	}
-	flush_counts(a.table.S, a.counts, lp, hist, lane, wc);
+	flush_counts_spread(tb, a.counts, lp, hist, lane, wc);
 }
 
-template <bool DIRECT, bool BOTH, bool PAIR = false>
+template <bool DIRECT, bool BOTH, int NT = 1>
 static const void *demux_hash_fn_w(int W)
 {
 	switch (W) {
-	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, PAIR>);
-	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, PAIR>);
-	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, PAIR>);
-	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, PAIR>);
-	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, PAIR>);
-	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, PAIR>);
-	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, PAIR>);
-	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, PAIR>);
+	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, NT>);
+	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, NT>);
+	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, NT>);
+	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, NT>);
+	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, NT>);
+	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, NT>);
+	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, NT>);
+	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, NT>);
 	}
 }
 
@@ -1473,20 +1518,34 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		hipError_t e;
 		if (by_table) {
 			LaunchShape sh;
-			// rows on dword boundaries that hold all key dwords: read straight from memory (lane r = row r)
-			const bool direct = (b.bc_stride & 3) == 0 && 4 * b.table.hk_W <= b.bc_stride;
+			// rows on dword boundaries whose key is one or two dwords: read straight from memory (lane r = row r, one 8 B/lane
+			// load for 8-byte rows).  Longer keys go through the LDS image even when the rows are aligned: five dword loads at
+			// a 24-byte stride walk the same lines five times (96 dual-index padded to 24 B: 67 G pairs/s direct, 95 through LDS)
+			// (SK_DEMUX_DIRECT=0 and SK_DEMUX_TILES=1 / 4 force the choices: tools/demux_ab.py, and the tests run every
+			// kernel on the same small inputs)
+			const char *env_direct = getenv("SK_DEMUX_DIRECT");
+			const bool direct = (b.bc_stride & 3) == 0 && b.table.hk_W <= 2 && 4 * b.table.hk_W <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
 			// both cuckoo slots at once while the two tables are small enough to stay in the CU's vector cache (cfg 3: 32 KiB;
 			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
 			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
-			// short calls (fewer than about 64 tiles per wave at full occupancy): two tiles per iteration
-			// (SK_DEMUX_PAIR=0 / 1 forces the choice: the tests run both kernels on the same small inputs)
-			const char *env_pair = getenv("SK_DEMUX_PAIR");
-			const bool pair = env_pair ? atoi(env_pair) != 0 : (b.n + kTileRows - 1) / kTileRows < (int64_t)n_cu * 32 * 64;
-			const void *fn = pair ? (direct ? (both ? demux_hash_fn_w<true, true, true>(b.table.hk_W) : demux_hash_fn_w<true, false, true>(b.table.hk_W))
-			                                : (both ? demux_hash_fn_w<false, true, true>(b.table.hk_W) : demux_hash_fn_w<false, false, true>(b.table.hk_W)))
-			               : direct ? (both ? demux_hash_fn_w<true, true>(b.table.hk_W) : demux_hash_fn_w<true, false>(b.table.hk_W))
-			                        : (both ? demux_hash_fn_w<false, true>(b.table.hk_W) : demux_hash_fn_w<false, false>(b.table.hk_W));
-			e = plan_shape(fn, b.table, b.n, pair ? 2 * kHashTileLds : 2048, false, 4, n_cu, 1, 0, sh);
+			// tiles per wave iteration: four for a big table read through LDS images once the call is a few million reads
+			// (96 dual-index: 93 -> 101 G pairs/s at 10 M, 101 -> 111 at 100 M; at 1 M 72 -> 67), one otherwise (16 single-index at
+			// 10 M: 256 / 246 / 196 G reads/s with 1 / 2 / 4)
+			const char *env_nt = getenv("SK_DEMUX_TILES");
+			const int nt = env_nt ? (atoi(env_nt) == 4 ? 4 : 1) : (!direct && !both && (b.n + kTileRows - 1) / kTileRows >= (int64_t)n_cu * 32 * 4) ? 4 : 1;
+			const int W = b.table.hk_W;
+			const void *fn = nullptr;
+			switch ((nt == 4 ? 4 : 0) + (direct ? 2 : 0) + (both ? 1 : 0)) {
+			case 0: fn = demux_hash_fn_w<false, false, 1>(W); break;
+			case 1: fn = demux_hash_fn_w<false, true, 1>(W); break;
+			case 2: fn = demux_hash_fn_w<true, false, 1>(W); break;
+			case 3: fn = demux_hash_fn_w<true, true, 1>(W); break;
+			case 4: fn = demux_hash_fn_w<false, false, 4>(W); break;
+			case 5: fn = demux_hash_fn_w<false, true, 4>(W); break;
+			case 6: fn = demux_hash_fn_w<true, false, 4>(W); break;
+			default: fn = demux_hash_fn_w<true, true, 4>(W); break;
+			}
+			e = plan_shape(fn, b.table, b.n, nt > 1 ? nt * kHashTileLds : 2048, false, 4, n_cu, 1, 0, sh);
 			if (e == hipSuccess) {
 				// the histogram sits where the matcher tables would: plan_shape(with_tables = false) leaves no room for it
 				sh.lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
@@ -1501,6 +1560,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		}
+		if (e == hipSuccess) e = launch_counts_fold(b, st);
 		if (e != hipSuccess) return e;
 	}
 	if (!any_mate) return hipSuccess;

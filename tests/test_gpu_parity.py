@@ -264,12 +264,12 @@ def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     assert np.array_equal(ctx.counts(), e_counts)
 
 
-@pytest.mark.parametrize("no_table", [False, True, "one tile per iteration"])
+@pytest.mark.parametrize("no_table", [False, True, "1 tile per iteration", "4 tiles per iteration"])
 def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
     if no_table is True:
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
     elif no_table:
-        monkeypatch.setenv("SK_DEMUX_PAIR", "0")          # the lookup kernel as calls of tens of millions of reads run it
+        monkeypatch.setenv("SK_DEMUX_TILES", no_table[0])          # the lookup kernel as calls of other sizes run it
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     bc, _ = synth.observe_barcodes(table, 200_003, seed=3)
     check_demux_decision_only(ctx, oracle, table, bc)
@@ -285,13 +285,42 @@ def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
     assert np.array_equal(assign, oracle.demux_batch(table, bc, 1)[0])
 
 
+@pytest.mark.parametrize("chunk_log2", [None, 17])
+@pytest.mark.parametrize("want_detail", [False, True])
+def test_demux_counters_across_launches(ctx, oracle, monkeypatch, want_detail, chunk_log2):
+    """The counters of demultiplex alone go through per-launch copies and tickets that the last workgroup of a launch leaves
+    zero: one sheet, many launches of every grid size (one workgroup, fewer workgroups than copies, a full grid), counters
+    accumulated over all of them and compared once per launch; with small chunks a call is many launches on the two lanes of
+    the host pipeline, in flight together, each lane with its own set of copies."""
+    if chunk_log2:
+        monkeypatch.setenv("SK_HOST_CHUNK_LOG2", str(chunk_log2))
+    for S, dual in ((16, False), (96, True)):
+        table = synth.make_sheet(S, 8, dual=dual, seed=11)
+        bc, _ = synth.observe_barcodes(table, 700_001, seed=12, halves=2 if dual else 1)
+        ctx.set_barcodes(table, 1)
+        e_assign, _, _, _, e_counts = oracle.demux_batch(table, bc, 1)
+
+        def counts_of(a):          # the oracle's counters of a prefix, from its per-row decisions: per sample, total, identified, ambiguous
+            return np.concatenate([np.bincount(a[a >= 0], minlength=S), [a.size, (a >= 0).sum(), (a == -2).sum()]]).astype(np.uint64)
+        assert np.array_equal(counts_of(e_assign), e_counts.astype(np.uint64))
+        expect = np.zeros(S + 3, dtype=np.uint64)
+        for n in (1, 63, 64, 65, 1000, 256 * 9, 256 * 17 + 5, 100_000, 700_001, 64 * 4 * 15, 3, 300_000):
+            assign, *_ = ctx.demux_assign(bc[:n], want_detail=want_detail)
+            assert np.array_equal(assign, e_assign[:n])
+            expect += counts_of(e_assign[:n])
+            assert np.array_equal(ctx.counts().astype(np.uint64), expect), (S, n)
+        ctx.counts_reset()
+        assign, *_ = ctx.demux_assign(bc[:5000], want_detail=want_detail)
+        assert np.array_equal(ctx.counts().astype(np.uint64), counts_of(e_assign[:5000]))
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_demux_decision_only(ctx, oracle, seed, monkeypatch):
     """Sheets with and without a lookup table: wildcard columns (all rows / some rows), duplicates, lower case next to upper
     case, up to 7 letters and more, any length to 32 and above, max_diff 0 / 1 / 2, observed barcodes with foreign bytes;
-    the lookup kernel with two tiles per iteration (what a call of this size takes) and with one (odd seeds)."""
-    if seed % 2:
-        monkeypatch.setenv("SK_DEMUX_PAIR", "0")
+    the lookup kernel with the tiles per iteration that a call of this size takes, and with 1 / 4 (seeds 1, 2 of every three)."""
+    if seed % 3:
+        monkeypatch.setenv("SK_DEMUX_TILES", "1" if seed % 3 == 1 else "4")
     rng = np.random.default_rng(12000 + seed)
     S = int(rng.choice([1, 2, 3, 16, 40, 96]))
     L = int(rng.choice([1, 3, 4, 8, 9, 17, 24, 31, 32, 33]))
