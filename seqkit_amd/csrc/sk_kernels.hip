@@ -1162,8 +1162,8 @@ __device__ __forceinline__ void load_dwords(const u32 *p, u32 *out)
 }
 
 constexpr int kHashTileLds = 2048 + 64;      // LDS per tile of the lookup kernel: 64 rows of at most 32 bytes, and the dword read past a row's end
-template <int W, bool DIRECT, bool BOTH, int NT = 1>
-__global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
+template <int W, bool DIRECT, bool BOTH, int NT = 1, bool LDSTAB = false>
+__global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
 {
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1171,6 +1171,12 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
 	if (lp.use_lds_hist) for (int i = threadIdx.x; i < a.table.S + 3; i += blockDim.x) hist[i] = 0u;
+	// LDSTAB: the whole table (both cuckoo halves, lp.table_bytes <= 64 KiB) sits in the workgroup's LDS, right before the
+	// tile images; sixteen waves share one copy
+	const int ltab_off = lp.tiles_off - lp.table_bytes;
+	if (LDSTAB)
+		for (int i = threadIdx.x; i < (lp.table_bytes >> 4); i += blockDim.x)
+			*reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = reinterpret_cast<const u32x4 *>(a.table.hk)[i];
 	__syncthreads();
 	WaveCounts wc = {0u, 0u, 0u};
 	const BarcodeDev &tb = a.table;
@@ -1211,9 +1217,13 @@ __global__ __launch_bounds__(256) void demux_hash_kernel(const TileArgs a, const
 	// register allocator hands them to the next address computation, and the hardware then has to wait for the load before
 	// that computation may write them — the two slot loads of a read went out one after the other (168 against 240 G reads/s)
 	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
+		if (LDSTAB) {                                                  // W <= 2 here: one LDS read of W + 1 dwords
+			load_dwords<(W + 1 < 4 ? W + 1 : 4)>(reinterpret_cast<const u32 *>(sk_smem + ltab_off + (int)slot * tb.hk_slot_dw * 4), &sv[0]);
+			return;
+		}
 		const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;          // 16-byte aligned: the pitch is 4, 8 or 16 dwords
 		load_dwords<(W + 1 < 4 ? W + 1 : 4)>(sp, &sv[0]);
-		if (W + 1 > 4) load_dwords<(W + 1 < 8 ? W + 1 - 4 : 4)>(sp + 4, &sv[4]);
+		if (W + 1 > 4) load_dwords<(W + 1 < 8 ? W + 1 - 4 : 4)>(sp + 4, &sv[W + 1 > 4 ? 4 : 0]);
 		if (W + 1 > 8) load_dwords<1>(sp + 8, &sv[W + 1 > 8 ? 8 : 0]);
 	};
 	int64_t t = (int64_t)blockIdx.x * nwave + wave;
@@ -1534,6 +1544,44 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			const char *env_nt = getenv("SK_DEMUX_TILES");
 			const int nt = env_nt ? (atoi(env_nt) == 4 ? 4 : 1) : (!direct && !both && (b.n + kTileRows - 1) / kTileRows >= (int64_t)n_cu * 32 * 4) ? 4 : 1;
 			const int W = b.table.hk_W;
+			// a small table read straight from aligned short rows: the table in LDS, one copy per workgroup of sixteen waves.
+			// Two gathers of 64 different lines per tile are what the vector cache spends its tag lookups on; from LDS they are
+			// two reads.  (SK_DEMUX_LDSTAB=0 keeps the table in the vector cache: tools/demux_ab.py, tests)
+			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
+			const int table_bytes = (int)((size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4);
+			if (direct && both && nt == 1 && (!env_ldstab || atoi(env_ldstab) != 0)) {
+				const void *fl = W == 1 ? reinterpret_cast<const void *>(demux_hash_kernel<1, true, true, 1, true>)
+				                        : reinterpret_cast<const void *>(demux_hash_kernel<2, true, true, 1, true>);
+				LdsPlan lp{};
+				lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
+				lp.hist_off = 0;
+				lp.table_bytes = table_bytes;
+				lp.tiles_off = (lp.use_lds_hist ? ((b.table.S + 3) * 4 + 15) & ~15 : 0) + table_bytes;
+				lp.tile_slot = 2 * kLdsPad;                                // rows come straight from memory: no image
+				const int lds = lp.tiles_off + 16 * lp.tile_slot;
+				struct Occ { int dev; const void *fn; int lds, wg; };
+				static std::mutex occ_m;
+				static std::vector<Occ> occ;
+				int dev = 0, wg = 0;
+				e = hipGetDevice(&dev);
+				if (e != hipSuccess) return e;
+				{
+					std::lock_guard<std::mutex> lk(occ_m);
+					for (const Occ &o : occ) if (o.dev == dev && o.fn == fl && o.lds == lds) wg = o.wg;
+				}
+				if (wg == 0) {
+					e = hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+					if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fl, 1024, (size_t)lds);
+					if (e != hipSuccess) return e;
+					if (wg < 1) return hipErrorInvalidValue;
+					std::lock_guard<std::mutex> lk(occ_m);
+					occ.push_back({dev, fl, lds, wg});
+				}
+				const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows, want = (ntiles + 15) / 16, cap = (int64_t)n_cu * wg;
+				TileArgs bb = b;
+				void *kargs[] = {(void *)&bb, (void *)&lp};
+				e = hipLaunchKernel(fl, dim3((unsigned)(want < cap ? want : cap)), dim3(1024), kargs, lds, st);
+			} else {
 			const void *fn = nullptr;
 			switch ((nt == 4 ? 4 : 0) + (direct ? 2 : 0) + (both ? 1 : 0)) {
 			case 0: fn = demux_hash_fn_w<false, false, 1>(W); break;
@@ -1556,6 +1604,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 				TileArgs bb = b;
 				void *kargs[] = {(void *)&bb, (void *)&sh.lp};
 				e = hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
+			}
 			}
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);

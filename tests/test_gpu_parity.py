@@ -264,12 +264,12 @@ def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     assert np.array_equal(ctx.counts(), e_counts)
 
 
-@pytest.mark.parametrize("no_table", [False, True, "1 tile per iteration", "4 tiles per iteration"])
+@pytest.mark.parametrize("no_table", [False, True, "1 tile per iteration", "4 tiles per iteration", "0: table not in LDS"])
 def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
     if no_table is True:
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
     elif no_table:
-        monkeypatch.setenv("SK_DEMUX_TILES", no_table[0])          # the lookup kernel as calls of other sizes run it
+        monkeypatch.setenv("SK_DEMUX_LDSTAB" if "LDS" in no_table else "SK_DEMUX_TILES", no_table[0])          # the lookup kernel's other forms
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     bc, _ = synth.observe_barcodes(table, 200_003, seed=3)
     check_demux_decision_only(ctx, oracle, table, bc)
@@ -321,6 +321,8 @@ def test_fuzz_demux_decision_only(ctx, oracle, seed, monkeypatch):
     the lookup kernel with the tiles per iteration that a call of this size takes, and with 1 / 4 (seeds 1, 2 of every three)."""
     if seed % 3:
         monkeypatch.setenv("SK_DEMUX_TILES", "1" if seed % 3 == 1 else "4")
+    if seed % 4 == 1:
+        monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")          # small tables from the vector cache instead of LDS
     rng = np.random.default_rng(12000 + seed)
     S = int(rng.choice([1, 2, 3, 16, 40, 96]))
     L = int(rng.choice([1, 3, 4, 8, 9, 17, 24, 31, 32, 33]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Demultiplex alone (decision only: assignment codes + counters) of several builds on the same barcode matrix in one
-process, and of the lookup kernel's 1 / 4 tiles per wave iteration (DEMUX_TILES=1,4, or 1:0 for tiles:direct; SK_DEMUX_TILES is read per launch).
+process, and of the lookup kernel's 1 / 4 tiles per wave iteration (DEMUX_TILES=1,4, or 1:0 for tiles:direct, 1:1:0 for tiles:direct:table in LDS; SK_DEMUX_TILES is read per launch).
 usage: [SK_LIBS=tools/ab/x.so] [DEMUX_TILES=1,4] [DEMUX_N=10000000,100000000] python tools/demux_ab.py"""
 import os
 import sys
@@ -36,6 +36,8 @@ for what, S, dual, L, bpu in (("16 single-index", 16, False, 8, 12), ("96 dual-i
                 os.environ["SK_DEMUX_TILES"] = nt.split(":")[0]
                 if ":" in nt:
                     os.environ["SK_DEMUX_DIRECT"] = nt.split(":")[1]
+                if nt.count(":") > 1:
+                    os.environ["SK_DEMUX_LDSTAB"] = nt.split(":")[2]
             ctx.set_barcodes(table, 1)
             def run():
                 ctx.demux_assign_dev(bc.data_ptr(), L + pad, n, assign.data_ptr())
