@@ -310,6 +310,10 @@ def secondary_rates(torch, ctx, dev):
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     assign = torch.empty((n,), dtype=torch.int32, device=dev)
     timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+    bc_l = bc.repeat(10, 1).contiguous()          # the same sheet on a call ten times as long: what the lookup does once the launch is out of the way
+    assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
+    timeit("cfg3 sheet, 100M x 8bp in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 8, 10 * n, assign_l.data_ptr()), 10 * n, 12)
+    del bc_l, assign_l
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
