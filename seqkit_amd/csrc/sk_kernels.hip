@@ -1217,11 +1217,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_hash_kernel(const T
 	// register allocator hands them to the next address computation, and the hardware then has to wait for the load before
 	// that computation may write them — the two slot loads of a read went out one after the other (168 against 240 G reads/s)
 	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
-		if (LDSTAB) {                                                  // W <= 2 here: one LDS read of W + 1 dwords
-			load_dwords<(W + 1 < 4 ? W + 1 : 4)>(reinterpret_cast<const u32 *>(sk_smem + ltab_off + (int)slot * tb.hk_slot_dw * 4), &sv[0]);
-			return;
-		}
-		const u32 *sp = tb.hk + (size_t)slot * tb.hk_slot_dw;          // 16-byte aligned: the pitch is 4, 8 or 16 dwords
+		const u32 *sp = LDSTAB ? reinterpret_cast<const u32 *>(sk_smem + ltab_off) + (int)slot * tb.hk_slot_dw      // LDS reads of the same widths
+		                       : tb.hk + (size_t)slot * tb.hk_slot_dw;  // 16-byte aligned either way: the pitch is 4, 8 or 16 dwords
 		load_dwords<(W + 1 < 4 ? W + 1 : 4)>(sp, &sv[0]);
 		if (W + 1 > 4) load_dwords<(W + 1 < 8 ? W + 1 - 4 : 4)>(sp + 4, &sv[W + 1 > 4 ? 4 : 0]);
 		if (W + 1 > 8) load_dwords<1>(sp + 8, &sv[W + 1 > 8 ? 8 : 0]);
@@ -1321,18 +1318,18 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_hash_kernel(const T
 	flush_counts_spread(tb, a.counts, lp, hist, lane, wc);
 }
 
-template <bool DIRECT, bool BOTH, int NT = 1>
+template <bool DIRECT, bool BOTH, int NT = 1, bool LDSTAB = false>
 static const void *demux_hash_fn_w(int W)
 {
 	switch (W) {
-	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, NT>);
-	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, NT>);
-	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, NT>);
-	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, NT>);
-	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, NT>);
-	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, NT>);
-	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, NT>);
-	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, NT>);
+	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, NT, LDSTAB>);
+	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, NT, LDSTAB>);
+	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, NT, LDSTAB>);
+	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, NT, LDSTAB>);
+	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, NT, LDSTAB>);
+	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, NT, LDSTAB>);
+	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, NT, LDSTAB>);
+	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, NT, LDSTAB>);
 	}
 }
 
@@ -1544,20 +1541,21 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			const char *env_nt = getenv("SK_DEMUX_TILES");
 			const int nt = env_nt ? (atoi(env_nt) == 4 ? 4 : 1) : (!direct && !both && (b.n + kTileRows - 1) / kTileRows >= (int64_t)n_cu * 32 * 4) ? 4 : 1;
 			const int W = b.table.hk_W;
-			// a small table read straight from aligned short rows: the table in LDS, one copy per workgroup of sixteen waves.
+			// a small table: in LDS, one copy per workgroup of sixteen waves (beside their tile images when rows go through those).
 			// Two gathers of 64 different lines per tile are what the vector cache spends its tag lookups on; from LDS they are
 			// two reads.  (SK_DEMUX_LDSTAB=0 keeps the table in the vector cache: tools/demux_ab.py, tests)
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
 			const int table_bytes = (int)((size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4);
-			if (direct && both && nt == 1 && (!env_ldstab || atoi(env_ldstab) != 0)) {
-				const void *fl = W == 1 ? reinterpret_cast<const void *>(demux_hash_kernel<1, true, true, 1, true>)
-				                        : reinterpret_cast<const void *>(demux_hash_kernel<2, true, true, 1, true>);
+			if (both && nt == 1 && (!env_ldstab || atoi(env_ldstab) != 0)) {
+				const void *fl = !direct ? demux_hash_fn_w<false, true, 1, true>(W)
+				                 : W == 1 ? reinterpret_cast<const void *>(demux_hash_kernel<1, true, true, 1, true>)
+				                          : reinterpret_cast<const void *>(demux_hash_kernel<2, true, true, 1, true>);
 				LdsPlan lp{};
 				lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
 				lp.hist_off = 0;
 				lp.table_bytes = table_bytes;
 				lp.tiles_off = (lp.use_lds_hist ? ((b.table.S + 3) * 4 + 15) & ~15 : 0) + table_bytes;
-				lp.tile_slot = 2 * kLdsPad;                                // rows come straight from memory: no image
+				lp.tile_slot = kLdsPad + (direct ? 0 : 2048) + kLdsPad;    // rows straight from memory need no image
 				const int lds = lp.tiles_off + 16 * lp.tile_slot;
 				struct Occ { int dev; const void *fn; int lds, wg; };
 				static std::mutex occ_m;
