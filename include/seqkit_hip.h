@@ -81,6 +81,21 @@ int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n
                         int32_t *assign, uint8_t *lowest_diff, int16_t *first_idx, int16_t *last_idx,
                         uint64_t *counts /* device u64[S+3], NULL = ctx counters */);
 
+/* Which rows the detail columns (lowest_diff / first_idx / last_idx) are defined for.  The reference looks at them in one
+ * place only, the ambiguity warning (src/fasta_demultiplex.rs:184-188), i.e. for reads with lowest_diff <= max_diff; the
+ * branch of a read that matched nothing (:190-194) never does.
+ *   SK_DETAIL_FULL    (default) every row, as the loop :154-166 leaves them.
+ *   SK_DETAIL_MATCHED rows with assign != SK_ASSIGN_NONE; the detail of SK_ASSIGN_NONE rows is unspecified (255 / -1 /
+ *                     -1 when the lookup table answers).  A demultiplex-alone call with max_diff <= 1 is then ONE table
+ *                     lookup per read — the sheet's rows and their one-substitution neighbours, decided on the host with
+ *                     the same loop — instead of S x L compares, for sheets of <= 128 samples, <= 20 columns, <= 7
+ *                     letters; other sheets run the matchers and fill every row.  The decision-only form (all three
+ *                     pointers NULL) takes the table under either mode.
+ * Applies to sk_demux_assign(_dev) and sk_fused_pass(_dev) of this ctx from the next call on.                        */
+#define SK_DETAIL_FULL    0
+#define SK_DETAIL_MATCHED 1
+int sk_set_detail_mode(sk_ctx *ctx, int mode);
+
 /* ---- T1: 3' running-sum quality trim --------------------------------------------------------------
  * src/fasta_trim_by_quality.rs:28-42.  qual rows are the quality line after trim_end(); writes
  * lowest_k[r] in [0, len[r]] (0 means the reference emits "N\n+\n!\n", :44-45).                      */

@@ -6,7 +6,7 @@ C-ABI used by the tests and bench.py; it holds no arithmetic of its own and has 
 fallback: loading fails loudly when the HIP library is missing.
 """
 from .capi import (Context, SeqkitHipError, library_path, load_library, SK_ASSIGN_AMBIGUOUS,  # noqa: F401
-                   SK_ASSIGN_NONE, EXPORTED_SYMBOLS, BlockedLayout, blocked_layout)
+                   SK_ASSIGN_NONE, SK_DETAIL_FULL, SK_DETAIL_MATCHED, EXPORTED_SYMBOLS, BlockedLayout, blocked_layout)
 
 __all__ = ["Context", "SeqkitHipError", "library_path", "load_library", "SK_ASSIGN_NONE",
-           "SK_ASSIGN_AMBIGUOUS", "EXPORTED_SYMBOLS", "BlockedLayout", "blocked_layout"]
+           "SK_ASSIGN_AMBIGUOUS", "SK_DETAIL_FULL", "SK_DETAIL_MATCHED", "EXPORTED_SYMBOLS", "BlockedLayout", "blocked_layout"]

@@ -17,8 +17,8 @@ LIBDIR = os.path.join(ROOT, "lib")
 BINDIR = os.path.join(ROOT, "bin")
 LIB_PATH = os.path.join(LIBDIR, "libseqkit_hip.so")
 
-HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_capi.hip"]
-HIP_DEPS = HIP_SOURCES + ["sk_internal.h", os.path.join(REPO, "include", "seqkit_hip.h")]
+HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_capi.hip", "sk_lut.cpp"]
+HIP_DEPS = HIP_SOURCES + ["sk_internal.h", "sk_lut.h", os.path.join(REPO, "include", "seqkit_hip.h")]
 
 
 def _hipcc() -> str:

@@ -894,7 +894,12 @@ static int demultiplex(int argc, char **argv)
 	{
 		std::vector<uint8_t> table((size_t)S * barcode_len);
 		for (int s = 0; s < S; s++) memcpy(table.data() + (size_t)s * barcode_len, samples[s].barcode.data(), barcode_len);
-		host::gpu_for_each([&](sk_ctx *c) { check(c, sk_set_barcodes(c, table.data(), S, (int)barcode_len, 1 /* MAX_BARCODE_DIFFERENCE :168 */), "sk_set_barcodes"); });
+		// best / equally_fine / lowest_diff are read for reads that matched something (the warning, :184-188) and never for
+		// the others (:190-194): SK_DETAIL_MATCHED, which lets the plain command take the sheet's lookup table
+		host::gpu_for_each([&](sk_ctx *c) {
+			check(c, sk_set_barcodes(c, table.data(), S, (int)barcode_len, 1 /* MAX_BARCODE_DIFFERENCE :168 */), "sk_set_barcodes");
+			check(c, sk_set_detail_mode(c, SK_DETAIL_MATCHED), "sk_set_detail_mode");
+		});
 	}
 
 	fprintf(stderr, "Starting demultiplexing in %s end mode...\n", paired_end ? "paired" : "single");     // :106-107

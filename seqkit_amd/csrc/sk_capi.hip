@@ -33,10 +33,11 @@ struct sk_ctx {
 	uint8_t *d_lut = nullptr;
 	uint8_t *d_bs = nullptr;
 	int bs_bytes = 0, bs_mm_off = 0, G = 0;
-	uint32_t *d_hk = nullptr;          // neighbourhood table of the sheet (demux_hash_kernel), when it has one
-	sk::BarcodeDev hk{};               // only the hk_* fields are used
+	uint8_t *d_nbr = nullptr;          // neighbourhood table of the sheet (sk_lut.h, demux_lut_kernel), when it has one: slots, then the ambiguity pairs
+	sk::LutDev nbr{};
 	std::vector<uint8_t> sheet;        // the sheet as given to sk_set_barcodes (the table is built from it on first use)
-	bool hk_tried = false;
+	bool nbr_tried = false;
+	int detail_mode = SK_DETAIL_FULL;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
 	unsigned long long *d_count_rep = nullptr; // BarcodeDev::count_rep
 	int count_rep_pitch = 0;
@@ -135,141 +136,6 @@ static size_t pipe_chunk(size_t dflt)
 }
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// ---- the sheet's neighbourhood table (see demux_hash_kernel) ------------------------------------------------------
-// false = this sheet has none (the bit-sliced / one-hot / byte matchers serve it).
-static bool build_neighbour_table(const uint8_t *table, int S, int L, int max_diff, sk::BarcodeDev &hk, std::vector<uint32_t> &slots)
-{
-	if (S <= 0 || L <= 0 || L > sk::kMaxHashLen || max_diff > 1) return false;
-	// the sheet's letters (bytes that are not a wildcard); 0 must be free to stand for "a byte the sheet never uses"
-	bool is_letter[256] = {false};
-	std::vector<uint8_t> letters;
-	std::vector<char> wild((size_t)L, 0);
-	for (int k = 0; k < L; k++) {
-		int nw = 0;
-		for (int s = 0; s < S; s++) {
-			const uint8_t b = table[(size_t)s * L + k];
-			if (b == 'N' || b == 'U') { nw++; continue; }              // wildcards: src/fasta_demultiplex.rs:273
-			if (!is_letter[b]) { is_letter[b] = true; letters.push_back(b); }
-		}
-		if (nw != 0 && nw != S) return false;                         // a wildcard in some rows only: the key would depend on the row
-		wild[(size_t)k] = nw == S;
-	}
-	if (letters.size() > 7 || is_letter[0]) return false;
-	// a 3-bit function of a byte that separates the letters
-	int sh = -1, fold = 0;
-	for (int f = 0; f < 2 && sh < 0; f++)
-		for (int t = 0; t <= 5 && sh < 0; t++) {
-			bool used[8] = {false}, ok = true;
-			for (uint8_t b : letters) {
-				const int i = (((f ? b ^ (b >> 4) : b)) >> t) & 7;
-				if (used[i]) { ok = false; break; }
-				used[i] = true;
-			}
-			if (ok) { sh = t; fold = f; }
-		}
-	if (sh < 0) return false;
-	auto index_of = [&](uint8_t b) { return (((fold ? b ^ (b >> 4) : b)) >> sh) & 7; };
-	uint8_t tab[8];
-	for (int i = 0; i < 8; i++) {                                     // unused entries: a byte that does NOT have index i, so nothing compares equal to it
-		uint8_t b = 1;
-		while (index_of(b) == i || is_letter[b]) b++;
-		tab[i] = b;
-	}
-	for (uint8_t b : letters) tab[index_of(b)] = b;
-	const int W = (L + 3) / 4;
-	// enumerate: each row, and each row with one counting column replaced by another letter or by 0 ("any other byte")
-	std::vector<uint8_t> alts(letters);
-	alts.push_back(0);
-	auto canon_row = [&](int s) {
-		std::string k((size_t)W * 4, '\0');
-		for (int i = 0; i < L; i++) if (!wild[(size_t)i]) k[(size_t)i] = (char)table[(size_t)s * L + i];
-		return k;
-	};
-	std::vector<std::string> keys;
-	{
-		std::unordered_set<std::string> seen;
-		for (int s = 0; s < S; s++) {
-			std::string k = canon_row(s);
-			if (seen.insert(k).second) keys.push_back(k);
-			if (max_diff < 1) continue;
-			for (int i = 0; i < L; i++) {
-				if (wild[(size_t)i]) continue;
-				const char own = k[(size_t)i];
-				for (uint8_t alt : alts) {
-					if ((char)alt == own) continue;
-					k[(size_t)i] = (char)alt;
-					if (seen.insert(k).second) keys.push_back(k);
-				}
-				k[(size_t)i] = own;
-			}
-		}
-	}
-	if (keys.size() > (1u << 18)) return false;
-	// decide every key with the reference's loop: src/fasta_demultiplex.rs:154-166 (first / last argmin), :168-194
-	std::vector<int32_t> decision(keys.size());
-	for (size_t q = 0; q < keys.size(); q++) {
-		int lowest = 0x7fffffff, first = 0, last = 0;
-		for (int s = 0; s < S; s++) {
-			int d = 0;
-			for (int i = 0; i < L; i++) {
-				const uint8_t cb = table[(size_t)s * L + i];
-				if (cb == 'N' || cb == 'U') continue;
-				d += ((uint8_t)keys[q][(size_t)i] != cb) ? 1 : 0;
-			}
-			if (d < lowest) { lowest = d; first = s; last = s; }
-			else if (d == lowest) last = s;
-		}
-		decision[q] = lowest <= max_diff ? (first == last ? first : sk::kAssignAmbiguous) : sk::kAssignNone;
-	}
-	// cuckoo hashing: two tables of nslots slots, a key lives in slot (h & mask) of the first or slot (h >> 16) & mask of the
-	// second, so a lookup is exactly two loads and never a loop.  Together the tables are at most a third full, which makes
-	// the insertion walk short; a seed whose walk does not end is dropped for the next.
-	size_t nslots = 64;
-	while (nslots * 2 < 3 * keys.size()) nslots <<= 1;
-	if (nslots > 65536) return false;                             // (h >> 16) has 16 bits
-	const int slot_dw = W < 4 ? 4 : (W < 8 ? 8 : 16);
-	std::vector<uint32_t> kw((size_t)W);
-	std::vector<int> where;                                       // slot -> key index or -1, tables one after the other
-	uint32_t best_seed = 0;
-	bool placed = false;
-	for (uint32_t seed = 1; seed <= 64 && !placed; seed++) {
-		const uint32_t sd = seed * 0x9E3779B9u;
-		where.assign(2 * nslots, -1);
-		placed = true;
-		for (size_t q = 0; q < keys.size() && placed; q++) {
-			int cur = (int)q, side = 0, kicks = 0;
-			for (;;) {
-				memcpy(kw.data(), keys[(size_t)cur].data(), (size_t)W * 4);
-				const uint32_t h = sk::demux_key_hash(kw.data(), W, sd);
-				const size_t at = side == 0 ? (h & (nslots - 1)) : nslots + ((h >> 16) & (nslots - 1));
-				std::swap(cur, where[at]);
-				if (cur < 0) break;
-				side ^= 1;                                          // the evicted key goes to its slot in the other table
-				if (++kicks > 500) { placed = false; break; }
-			}
-		}
-		if (placed) best_seed = sd;
-	}
-	if (!placed) return false;
-	slots.assign(2 * nslots * (size_t)slot_dw, 0u);
-	for (size_t i = 0; i < 2 * nslots; i++) {
-		uint32_t *sp = &slots[i * (size_t)slot_dw];
-		if (where[i] < 0 || decision[(size_t)where[i]] == sk::kAssignNone) { sp[W] = sk::kHashEmpty; continue; }   // (an enumerated key always has a decision)
-		memcpy(sp, keys[(size_t)where[i]].data(), (size_t)W * 4);
-		sp[W] = (uint32_t)decision[(size_t)where[i]];
-	}
-	hk.hk_W = W; hk.hk_slot_dw = slot_dw; hk.hk_mask = (int)(nslots - 1);
-	hk.hk_sh = sh; hk.hk_fold = fold; hk.hk_seed = best_seed;
-	hk.hk_tab_lo = (uint32_t)tab[0] | ((uint32_t)tab[1] << 8) | ((uint32_t)tab[2] << 16) | ((uint32_t)tab[3] << 24);
-	hk.hk_tab_hi = (uint32_t)tab[4] | ((uint32_t)tab[5] << 8) | ((uint32_t)tab[6] << 16) | ((uint32_t)tab[7] << 24);
-	for (int w = 0; w < 8; w++) {
-		uint32_t keep = 0;
-		for (int b = 0; b < 4; b++) { const int i = 4 * w + b; if (i < L && !wild[(size_t)i]) keep |= 0xFFu << (8 * b); }
-		hk.hk_keep[w] = keep;
-	}
-	return true;
-}
-
 extern "C" {
 
 int sk_version(void) { return 0x000100; }
@@ -318,7 +184,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_onehot) (void)hipFree(c->d_onehot);
 	if (c->d_lut) (void)hipFree(c->d_lut);
 	if (c->d_bs) (void)hipFree(c->d_bs);
-	if (c->d_hk) (void)hipFree(c->d_hk);
+	if (c->d_nbr) (void)hipFree(c->d_nbr);
 	if (c->d_counts) (void)hipFree(c->d_counts);
 	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
@@ -407,8 +273,8 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	if (c->d_onehot) { SK_HIP(c, hipFree(c->d_onehot)); c->d_onehot = nullptr; }
 	if (c->d_lut) { SK_HIP(c, hipFree(c->d_lut)); c->d_lut = nullptr; }
 	if (c->d_bs) { SK_HIP(c, hipFree(c->d_bs)); c->d_bs = nullptr; }
-	if (c->d_hk) { SK_HIP(c, hipFree(c->d_hk)); c->d_hk = nullptr; }
-	c->hk = sk::BarcodeDev{};
+	if (c->d_nbr) { SK_HIP(c, hipFree(c->d_nbr)); c->d_nbr = nullptr; }
+	c->nbr = sk::LutDev{};
 	c->bs_bytes = c->bs_mm_off = c->G = 0;
 	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
 	if (c->d_count_rep) { SK_HIP(c, hipFree(c->d_count_rep)); c->d_count_rep = nullptr; }
@@ -480,9 +346,9 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 			c->bs_bytes = (int)bytes; c->bs_mm_off = mm_off; c->G = G;
 		}
 	}
-	// (the neighbourhood table of the sheet is built on the first decision-only demultiplex: ensure_neighbour_table)
+	// (the neighbourhood table of the sheet is built on the first demultiplex-alone call it can serve: ensure_neighbour_table)
 	c->sheet.assign(table, table + (size_t)S * L);
-	c->hk_tried = false;
+	c->nbr_tried = false;
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
 	if (S + 3 <= sk::kMaxLdsHist) {
@@ -498,20 +364,23 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	return SK_OK;
 }
 
-// The neighbourhood table costs a few tens of ms of host work per sheet (enumerate, decide, place): it is built when a
-// call first asks for the decision alone — the command-line hosts, which always want the detail columns, never pay for it.
+// The neighbourhood table costs some host work per sheet (enumerate, decide, place): it is built when a call first
+// asks for the decision alone or for the detail columns of matched rows only — a caller that always wants every row's
+// detail (SK_DETAIL_FULL) never pays for it.  The caller has bound the ctx's device.
 static int ensure_neighbour_table(sk_ctx *c)
 {
-	if (c->hk_tried || !c->have_table) return SK_OK;
-	c->hk_tried = true;
-	std::vector<uint32_t> slots;
-	sk::BarcodeDev hk{};
-	if (getenv("SK_NO_HASH_DEMUX") || !build_neighbour_table(c->sheet.data(), c->S, c->L, c->max_diff, hk, slots)) return SK_OK;
-	SK_HIP(c, hipMalloc((void **)&c->d_hk, slots.size() * 4));
-	SK_HIP(c, hipMemcpy(c->d_hk, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+	if (c->nbr_tried || !c->have_table) return SK_OK;
+	c->nbr_tried = true;
+	sk::LutHost h;
+	if (getenv("SK_NO_HASH_DEMUX") || !sk::lut_build(c->sheet.data(), c->S, c->L, c->max_diff, h)) return SK_OK;
+	const size_t slot_bytes = h.slots.size() * 4, amb_bytes = h.amb.size() * 2;
+	SK_HIP(c, hipMalloc((void **)&c->d_nbr, slot_bytes + amb_bytes + 16));
+	SK_HIP(c, hipMemcpy(c->d_nbr, h.slots.data(), slot_bytes, hipMemcpyHostToDevice));
+	if (amb_bytes) SK_HIP(c, hipMemcpy(c->d_nbr + slot_bytes, h.amb.data(), amb_bytes, hipMemcpyHostToDevice));
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx streams are non-blocking: make the upload visible to them
-	c->hk = hk;
-	c->hk.hk = c->d_hk;
+	c->nbr = h.dev;
+	c->nbr.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);
+	c->nbr.amb = reinterpret_cast<const int16_t *>(c->d_nbr + slot_bytes);
 	return SK_OK;
 }
 
@@ -521,12 +390,17 @@ static sk::BarcodeDev table_of(const sk_ctx *c)
 	t.raw = c->d_raw; t.onehot = c->d_onehot; t.lut = c->d_lut;
 	t.bs = c->d_bs; t.bs_bytes = c->bs_bytes; t.bs_mm_off = c->bs_mm_off; t.G = c->G;
 	t.S = c->S; t.L = c->L; t.W = c->W; t.max_diff = c->max_diff;
-	t.hk = c->hk.hk; t.hk_W = c->hk.hk_W; t.hk_slot_dw = c->hk.hk_slot_dw; t.hk_mask = c->hk.hk_mask;
-	t.hk_sh = c->hk.hk_sh; t.hk_fold = c->hk.hk_fold; t.hk_tab_lo = c->hk.hk_tab_lo; t.hk_tab_hi = c->hk.hk_tab_hi;
-	t.hk_seed = c->hk.hk_seed;
+	t.nbr = c->nbr;
 	t.count_rep = c->d_count_rep; t.count_rep_pitch = c->count_rep_pitch;
-	for (int w = 0; w < 8; w++) t.hk_keep[w] = c->hk.hk_keep[w];
 	return t;
+}
+
+int sk_set_detail_mode(sk_ctx *c, int mode)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (mode != SK_DETAIL_FULL && mode != SK_DETAIL_MATCHED) return fail(c, SK_ERR_INVALID, "detail mode %d is neither SK_DETAIL_FULL nor SK_DETAIL_MATCHED", mode);
+	c->detail_mode = mode;
+	return SK_OK;
 }
 
 int sk_counts_reset(sk_ctx *c)
@@ -766,12 +640,21 @@ static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
 		if (a->bc_stride > sk::kMaxTileStride) return fail(c, SK_ERR_INVALID, "bc_stride = %d above %d", a->bc_stride, sk::kMaxTileStride);
 		if (!a->assign) return fail(c, SK_ERR_INVALID, "assign is NULL");
 		if (dev && !aligned16(a->bc)) return fail(c, SK_ERR_INVALID, "bc must be 16-byte aligned");
-		if (!a->lowest_diff && !a->first_idx && !a->last_idx && !any)
-			if (int r = ensure_neighbour_table(c)) return r;
 	} else if (!any) {
 		return fail(c, SK_ERR_INVALID, "nothing to do: no bc, no out_seq, no lowest_k");
 	}
 	return SK_OK;
+}
+
+// demultiplex alone, with the decision only or the detail columns of matched rows only: the neighbourhood table's case.
+// Called with the ctx's device bound (the table is uploaded to the current device).
+static int prepare_demux(sk_ctx *c, const sk_fused_args *a)
+{
+	if (!a->bc) return SK_OK;
+	for (int m = 0; m < a->n_mates; m++) if (a->mate[m].out_seq || a->mate[m].lowest_k) return SK_OK;
+	const bool want_detail = a->lowest_diff || a->first_idx || a->last_idx;
+	if (want_detail && c->detail_mode != SK_DETAIL_MATCHED) return SK_OK;
+	return ensure_neighbour_table(c);
 }
 
 static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
@@ -787,6 +670,7 @@ static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
 	t.bc = a->bc; t.bc_stride = a->bc_stride;
 	if (a->bc) t.table = table_of(c);
 	t.assign = a->assign; t.lowest_diff = a->lowest_diff; t.first_idx = a->first_idx; t.last_idx = a->last_idx;
+	t.detail_matched = c->detail_mode == SK_DETAIL_MATCHED ? 1 : 0;
 	t.counts = a->counts ? (unsigned long long *)a->counts : c->d_counts;
 	return t;
 }
@@ -794,9 +678,10 @@ static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
 int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
 {
 	if (!c) return SK_ERR_INVALID;
+	if (int r = bind(c)) return r;          // first: what follows may upload the sheet's table to the current device
 	if (int r = check_fused(c, a, true)) return r;
-	if (int r = bind(c)) return r;
 	if (a->n == 0) return SK_OK;
+	if (int r = prepare_demux(c, a)) return r;
 	sk::TileArgs t = tile_args_of(c, a);
 	SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
 	return SK_OK;
@@ -806,9 +691,10 @@ int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
 int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 {
 	if (!c) return SK_ERR_INVALID;
-	if (int r = check_fused(c, a, false)) return r;
 	if (int r = bind(c)) return r;
+	if (int r = check_fused(c, a, false)) return r;
 	if (a->n == 0) return SK_OK;
+	if (int r = prepare_demux(c, a)) return r;
 	const int64_t stride = a->stride;
 	// bytes of workspace per row
 	size_t per_row = 0;
@@ -890,8 +776,9 @@ int sk_fused_tune_placement_dev(sk_ctx *c, sk_fused_args *a, const sk_fused_cand
 	if (!c) return SK_ERR_INVALID;
 	if (!a || !cd) return fail(c, SK_ERR_INVALID, "args or candidates is NULL");
 	if (cd->k < 1 || cd->k > SK_MAX_CANDIDATES || sweeps < 0) return fail(c, SK_ERR_INVALID, "k = %d (1..%d), sweeps = %d", cd->k, SK_MAX_CANDIDATES, sweeps);
-	if (int r = check_fused(c, a, true)) return r;
 	if (int r = bind(c)) return r;
+	if (int r = check_fused(c, a, true)) return r;
+	if (int r = prepare_demux(c, a)) return r;
 	// the matrices that take part: those the pass uses and that have candidates
 	struct Slot { int mate, what; };                       // what: 0 seq, 1 qual, 2 out_seq
 	std::vector<Slot> slots;

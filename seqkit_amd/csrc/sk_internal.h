@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sk_lut.h"
+
 namespace sk {
 
 constexpr int kWave = 64;             // gfx950 wavefront; one read tile = 64 reads = one wave
@@ -44,32 +46,14 @@ struct BarcodeDev {
 	const uint8_t *bs;
 	int bs_bytes, bs_mm_off, G;
 	int S, L, W, max_diff;
-	// neighbourhood table (sk_kernels.hip: demux_hash_kernel), or nullptr: every canonical barcode within max_diff (<= 1)
-	// of some sheet row, keyed by its bytes, with the decision (sample index or kAssignAmbiguous) as the value
-	const uint32_t *hk;        // two cuckoo tables of hk_mask+1 slots each, one after the other; a slot = hk_slot_dw dwords:
-	                           // hk_W key dwords, then the value (kHashEmpty = free slot)
-	int hk_W, hk_slot_dw, hk_mask;     // key dwords, slot pitch, slots per table - 1
-	int hk_sh, hk_fold;        // byte -> table index: ((b ^ (hk_fold ? b >> 4 : 0)) >> hk_sh) & 7
-	uint32_t hk_tab_lo, hk_tab_hi;     // the 8 sheet letters by that index (v_perm table)
-	uint32_t hk_seed;
-	uint32_t hk_keep[8];       // per key dword: 0xFF in the bytes of columns that count (inside L, not a wildcard column)
+	// neighbourhood table (sk_lut.h; sk_kernels.hip: demux_lut_kernel); nbr.tab == nullptr: the sheet has none
+	LutDev nbr;
 	// spread counters (sk_kernels.hip: flush_counts_spread), or nullptr: kCountReplicas rows of count_rep_pitch u64, all zero
 	// between launches
 	unsigned long long *count_rep;
 	int count_rep_pitch;
 };
 constexpr int kCountReplicas = 16;
-constexpr uint32_t kHashEmpty = 0x80000000u;
-constexpr int kMaxHashLen = 32;
-// The one hash both sides use (host builds the table, the kernel probes it): Jenkins one-at-a-time over the key dwords.
-__host__ __device__ inline uint32_t demux_key_hash(const uint32_t *key, int W, uint32_t seed)
-{
-	uint32_t h = seed;
-	for (int w = 0; w < W; w++) { h += key[w]; h += h << 10; h ^= h >> 6; }
-	h += h << 3; h ^= h >> 11; h += h << 15;
-	return h;
-}
-
 constexpr int kMaxBitSlicedLen = 31;     // 5 counter planes
 constexpr int kMaxBitSlicedBytes = 24 * 1024;
 
@@ -86,6 +70,7 @@ struct TileArgs {
 	uint8_t *lowest_diff;
 	int16_t *first_idx;
 	int16_t *last_idx;
+	int detail_matched;             // SK_DETAIL_MATCHED: the detail columns of SK_ASSIGN_NONE rows are unspecified
 	unsigned long long *counts;     // device u64[S+3]
 };
 

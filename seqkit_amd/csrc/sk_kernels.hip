@@ -1128,208 +1128,175 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// D1+D2+D3 by table lookup: demultiplex alone, when only the decision is asked for.
-// With max_diff <= 1 the barcodes that get a sample (or the ambiguity verdict) are few: every sheet row and its
-// one-substitution neighbours over the sheet's own alphabet plus "any other byte" — 96 x (17 x 5 + 1) = 8 256 keys
-// for the 96 dual-index sheet.  sk_set_barcodes enumerates them, decides each with the reference's loop
-// (src/fasta_demultiplex.rs:154-194) and puts key -> decision into an open-addressing table; a read is then ONE
-// lookup instead of S x L compares: its bytes are made canonical (a byte the sheet never uses, and every column that
-// is a wildcard in all rows, becomes 0), hashed, and probed; not found = no sample within max_diff = SK_ASSIGN_NONE.
-// Canonical bytes without a 256-entry table: the host finds a 3-bit function of a byte that separates the sheet's
-// letters ((b [^ b>>4]) >> sh) & 7; v_perm looks the letter with that index up for four bytes at once, and a byte
-// is kept iff it equals its letter.  The table is two cuckoo tables (a key sits in one of two slots: two loads, never a
-// loop), <= 4 MiB, read through L2.  Sheets this cannot serve (max_diff > 1,
-// wildcards in some rows only, more than 7 letters, detail outputs wanted) take demux_tile_kernel.
+// D1+D2+D3 by table lookup (sk_lut.h): demultiplex alone.  With max_diff <= 1 the barcodes that get a sample or the
+// ambiguity verdict are the sheet rows and their one-substitution neighbours — 96 x (16 x 4 + 1) = 6 240 keys for the 96
+// dual-index sheet.  The host decides each with the reference's loop (src/fasta_demultiplex.rs:154-194) and stores
+// lowest_diff / first / last with it; a read is: its bytes classified (v_perm letter table, packed-byte compare),
+// packed to two words, mixed, and looked up in two slots.  An 8-byte entry holds the quotient of the key instead of the
+// key, which is what makes the dual-index table 128 KiB — it lives in the workgroup's LDS (sixteen waves share one copy),
+// so the two probes of a read are two ds_read_b64 instead of two trips to L2.  Not found = nothing within max_diff =
+// SK_ASSIGN_NONE (its detail columns then say 255 / -1 / -1: SK_DETAIL_MATCHED of include/seqkit_hip.h).
+//   W1, W2 : key dwords — the row's first W1 dwords and, with a separator, W2 == W1 dwords from the byte after it
+//   DIRECT : rows start on dword boundaries, W1 <= 2, no separator: lane r loads row r straight from memory (8 B/lane
+//            coalesced for 8 bp); otherwise a tile goes through the wave's LDS image with 16 B/lane loads and the segments
+//            are read back at any alignment
+//   LDSTAB : the table fits beside the images (<= 128 KiB); else it is read through the vector cache
+//   DETAIL : lowest_diff / first_idx / last_idx are written too
+// Two tiles per wave are always in flight (register slots), so that a CU of sixteen waves has ~34 KiB on the way.  There
+// is no branch around a VMEM instruction in the loop: the waits for the register slots are counted, not drained.
 // ---------------------------------------------------------------------------------------------------
-// N = 1..4 consecutive dwords from a 16-byte aligned address, one load of exactly that width
-template <int N>
-__device__ __forceinline__ void load_dwords(const u32 *p, u32 *out)
+template <int W1, int W2, bool DIRECT, bool LDSTAB, bool DETAIL>
+__global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const TileArgs a, const LdsPlan lp)
 {
 	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
-	typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
-	if (N == 1) {
-		out[0] = p[0];
-	} else if (N == 2) {
-		const u32x2_t v = *reinterpret_cast<const u32x2_t *>(p);
-		out[0] = v[0]; out[1] = v[1];
-	} else if (N == 3) {
-		const u32x3_t v = *reinterpret_cast<const u32x3_t *>(p);
-		out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
-	} else {
-		const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
-		out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
-	}
-}
-
-constexpr int kHashTileLds = 2048 + 64;      // LDS per tile of the lookup kernel: 64 rows of at most 32 bytes, and the dword read past a row's end
-template <int W, bool DIRECT, bool BOTH, int NT = 1, bool LDSTAB = false>
-__global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_hash_kernel(const TileArgs a, const LdsPlan lp)
-{
+	constexpr int W = W1 + W2;
+	static_assert(W >= 1 && W <= 5 && (W2 == 0 || W2 == W1) && !(DIRECT && (W2 > 0 || W1 > 2)), "shape");
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int nwave = blockDim.x >> 6;
 	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
-	if (lp.use_lds_hist) for (int i = threadIdx.x; i < a.table.S + 3; i += blockDim.x) hist[i] = 0u;
-	// LDSTAB: the whole table (both cuckoo halves, lp.table_bytes <= 64 KiB) sits in the workgroup's LDS, right before the
-	// tile images; sixteen waves share one copy
-	const int ltab_off = lp.tiles_off - lp.table_bytes;
-	if (LDSTAB)
-		for (int i = threadIdx.x; i < (lp.table_bytes >> 4); i += blockDim.x)
-			*reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = reinterpret_cast<const u32x4 *>(a.table.hk)[i];
-	__syncthreads();
-	WaveCounts wc = {0u, 0u, 0u};
-	const BarcodeDev &tb = a.table;
+	const LutDev &t = a.table.nbr;
+	const int S = a.table.S;
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int bstride = a.bc_stride;
 	const int voff = lane * 16;
-	const int64_t tstep = (int64_t)gridDim.x * nwave;
-	auto tile_rsrc = [&](int64_t t) {
-		const bool ok = t < ntiles;
-		const int64_t row0 = ok ? t * kTileRows : 0;
-		const int rows = ok ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
-		return make_rsrc(a.bc, row0 * (int64_t)bstride, (rows * bstride + 3) & ~3);
-	};
-	// the observed bytes of the lane's row as W dwords.  DIRECT (rows start on dword boundaries): straight from memory,
-	// lane r reads row r — for 8-byte rows that is one fully coalesced 8 B/lane load; otherwise the tile goes through the
-	// wave's LDS image with 16 B/lane loads and rows are read back at any alignment.  Either way the NEXT tile's loads are
-	// in flight while this one is looked up.
-	// (a big table must stay in L2: the read-once barcode stream is then loaded nontemporal — 68 -> 98 G pairs/s for the
-	// 1 MiB table of the 96 dual-index sheet; with a small table plain loads are faster, 246 against 221 G reads/s)
-	constexpr int kAux = BOTH ? 0 : kAuxStream;
-	// NT = 4: four tiles per wave and iteration, taken through the stages together (keys and hashes, the table loads of
-	// all, then the compares and stores).  An iteration is a chain of dependent round trips (rows -> table slot in L2 ->
-	// second slot for some -> store); with the big table of a dual-index sheet four independent chains per wave hide more of
-	// them than twice the waves do.  The launch chooses.
-	u32 raw[NT][W];
-	u32x4 v0[NT], v1[NT];
-	auto fetch = [&](int64_t t, int i) {
-		const rsrc_t rb = tile_rsrc(t);
+	const int img = (kTileRows * bstride + 15) & ~15;
+	const u32 mask = (u32)t.mask;
+	u32 raw[2][W];
+	u32x4 v0[2], v1[2];
+	// tiles are counted in 32 bits (launch_tile_pass checks); a tile past the last clips to nothing (zero-record descriptors)
+	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kTileRows);
+	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kTileRows : (ti == nt32 - 1 ? last_rows : 0); };
+	auto fetch = [&](int ti, int s) {
+		const int rows = rows_of(ti);
+		const rsrc_t rb = make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kTileRows * bstride), (rows * bstride + 3) & ~3);
 		if (DIRECT) {
-#pragma unroll
-			for (int w = 0; w < W; w++) raw[i][w] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride + 4 * w, 0, kAux);
+			if (W == 2) {
+				const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, lane * bstride, 0, 0);
+				raw[s][0] = v[0]; raw[s][W - 1] = v[1];
+			} else {
+				raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride, 0, 0);
+			}
 		} else {
-			v0[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAux);
-			v1[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAux);
+			v0[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAuxStream);
+			v1[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAuxStream);
 		}
 	};
-	// a slot's W + 1 dwords with loads of exactly that width: a wider load leaves result registers that nothing reads, the
-	// register allocator hands them to the next address computation, and the hardware then has to wait for the load before
-	// that computation may write them — the two slot loads of a read went out one after the other (168 against 240 G reads/s)
-	auto load_slot = [&](u32 slot, u32 (&sv)[W + 1]) {
-		const u32 *sp = LDSTAB ? reinterpret_cast<const u32 *>(sk_smem + ltab_off) + (int)slot * tb.hk_slot_dw      // LDS reads of the same widths
-		                       : tb.hk + (size_t)slot * tb.hk_slot_dw;  // 16-byte aligned either way: the pitch is 4, 8 or 16 dwords
-		load_dwords<(W + 1 < 4 ? W + 1 : 4)>(sp, &sv[0]);
-		if (W + 1 > 4) load_dwords<(W + 1 < 8 ? W + 1 - 4 : 4)>(sp + 4, &sv[W + 1 > 4 ? 4 : 0]);
-		if (W + 1 > 8) load_dwords<1>(sp + 8, &sv[W + 1 > 8 ? 8 : 0]);
+	const int tstep = (int)gridDim.x * nwave;
+	int tb = (int)blockIdx.x * nwave + wave;
+	fetch(tb, 0);
+	fetch(tb + tstep, 1);
+	// the table and the histogram while the first tiles are on their way
+	if (lp.use_lds_hist) for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
+	const int ltab_off = lp.tiles_off - lp.table_bytes;                  // LDSTAB: the table sits right before the tile images
+	if (LDSTAB)
+		for (int i = threadIdx.x; i < (lp.table_bytes >> 4); i += blockDim.x)
+			*reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = reinterpret_cast<const u32x4 *>(t.tab)[i];
+	__syncthreads();
+	auto entry = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
+		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)slot * 2);
 	};
-	int64_t t = (int64_t)blockIdx.x * nwave + wave;
+	// where the lane's row lies in the image does not depend on the tile
+	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;
+	const u32 *x1 = reinterpret_cast<const u32 *>(tile + (rs & ~3)), *x2 = reinterpret_cast<const u32 *>(tile + (rs2 & ~3));
+	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
+	u32 n_total = 0, n_ident = 0, n_ambig = 0;
+	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
-	for (int i = 0; i < NT; i++) fetch(t + i * tstep, i);
-	for (; t < ntiles; t += NT * tstep) {
-		u32 d[NT][W], key[NT][W], h[NT], sv1[NT][W + 1], sv2[NT][W + 1];
-		if (DIRECT) {
+		for (int s = 0; s < 2; s++) {
+			const int ti = tb + s * tstep;
+			const int rows = rows_of(ti);
+			const int64_t ro = (int64_t)(rows ? ti : 0) * kTileRows;
+			const bool active = lane < rows;
+			u32 d[W];
+			u32 sepbad = 0u;
+			if (DIRECT) {
 #pragma unroll
-			for (int i = 0; i < NT; i++)
+				for (int w = 0; w < W; w++) d[w] = raw[s][w];
+				fetch(ti + 2 * tstep, s);
+			} else {
+				if (voff < img) *reinterpret_cast<u32x4 *>(tile + voff) = v0[s];           // the image is as long as the tile's rows, not 2 KiB
+				if (1024 + voff < img) *reinterpret_cast<u32x4 *>(tile + 1024 + voff) = v1[s];
+				fetch(ti + 2 * tstep, s);
+				wave_lds_fence();
+				u32 lo = x1[0];
 #pragma unroll
-				for (int w = 0; w < W; w++) d[i][w] = raw[i][w];
-#pragma unroll
-			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
-		} else {
-#pragma unroll
-			for (int i = 0; i < NT; i++) {                             // each tile of the iteration has its own 2 KiB + pad of the wave's LDS slot
-				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + voff) = v0[i];
-				*reinterpret_cast<u32x4 *>(tile + i * kHashTileLds + 1024 + voff) = v1[i];
-			}
-#pragma unroll
-			for (int i = 0; i < NT; i++) fetch(t + (NT + i) * tstep, i);
-			wave_lds_fence();
-			const int rs = lane * bstride;
-			const u32 sh = (u32)rs & 3u;
-#pragma unroll
-			for (int i = 0; i < NT; i++) {
-				const u32 *x = reinterpret_cast<const u32 *>(tile + i * kHashTileLds + (rs & ~3));
-				u32 lo = x[0];
-#pragma unroll
-				for (int w = 0; w < W; w++) {
-					const u32 hi = x[w + 1];
-					d[i][w] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+				for (int w = 0; w < W1; w++) {
+					const u32 hi = x1[w + 1];
+					d[w] = __builtin_amdgcn_alignbyte(hi, lo, sh1);
 					lo = hi;
 				}
-			}
-		}
-		// canonical key: a byte stays iff it is the sheet letter with its index; everything else, and the columns that do not count, become 0
+				if (W2 > 0) {
+					lo = x2[0];
 #pragma unroll
-		for (int i = 0; i < NT; i++) {
-			u32 hh = tb.hk_seed;
+					for (int w = 0; w < W2; w++) {
+						const u32 hi = x2[w + 1];
+						d[W1 + w] = __builtin_amdgcn_alignbyte(hi, lo, sh2);
+						lo = hi;
+					}
+					sepbad = (u32)tile[rs + t.sep_off] != t.sep_val ? 1u : 0u;
+				}
+			}
+			// classes: the index of the sheet letter a byte equals, `other` for every byte the sheet never uses
+			u32 c[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
 			for (int w = 0; w < W; w++) {
-				const u32 f = tb.hk_fold ? d[i][w] ^ ((d[i][w] >> 4) & 0x0f0f0f0fu) : d[i][w];
-				const u32 sel = (f >> tb.hk_sh) & 0x07070707u;
-				const u32 letter = __builtin_amdgcn_perm(tb.hk_tab_hi, tb.hk_tab_lo, sel);
-				const u32 df = d[i][w] ^ letter;                        // zero byte <=> the observed byte is a sheet letter
-				const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;     // 0x80 in every byte that differs
-				const u32 drop = (nz << 1) - (nz >> 7);                 // 0xFF in every byte that differs
-				key[i][w] = d[i][w] & ~drop & tb.hk_keep[w];
-				hh += key[i][w]; hh += hh << 10; hh ^= hh >> 6;         // demux_key_hash
+				const u32 sel = (d[w] >> t.sh) & 0x07070707u;
+				const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
+				const u32 df = d[w] ^ letter;                              // zero byte <=> the observed byte is that letter
+				const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;        // 0x80 in every byte that is not
+				const u32 m = nz - (nz >> 7);                              // 0x7f there
+				c[w] = (m & t.other) | (~m & sel);
 			}
-			hh += hh << 3; hh ^= hh >> 11; hh += hh << 15;
-			h[i] = hh;
-		}
-		// Two slots, at most two loads, no loop (cuckoo).  The builder tries the first table first and moves a key to the
-		// second only when its first slot is taken, so: first slot holds the key -> done; first slot free -> the key is in
-		// neither; first slot holds another key -> look at the second slot (a minority of the lanes: less table traffic).
-		// (BOTH — small tables that stay in the vector cache: both loads at once, no dependent second trip)
-#pragma unroll
-		for (int i = 0; i < NT; i++) {
-			load_slot(h[i] & (u32)tb.hk_mask, sv1[i]);
-			if (BOTH) load_slot((u32)tb.hk_mask + 1u + ((h[i] >> 16) & (u32)tb.hk_mask), sv2[i]);
-		}
-#pragma unroll
-		for (int i = 0; i < NT; i++) {
-			const int64_t ti = t + i * tstep;
-			const int64_t row0 = ti < ntiles ? ti * kTileRows : 0;
-			const int rows = ti < ntiles ? (int)((a.n - row0) < kTileRows ? (a.n - row0) : kTileRows) : 0;
-			const bool active = lane < rows;
-			int code = kAssignNone;
-			auto match = [&](const u32 (&sv)[W + 1], bool &occupied) {
-				occupied = sv[W] != kHashEmpty;
-				bool same = occupied;
-#pragma unroll
-				for (int w = 0; w < W; w++) same = same && sv[w] == key[i][w];
-				code = same ? (int)sv[W] : code;
-				return same;
-			};
-			bool occ1 = false, occ2 = false;
-			const bool hit1 = match(sv1[i], occ1);
-			if (BOTH) match(sv2[i], occ2);
-			else if (occ1 && !hit1) { load_slot((u32)tb.hk_mask + 1u + ((h[i] >> 16) & (u32)tb.hk_mask), sv2[i]); match(sv2[i], occ2); }
-			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, row0 * 4, rows * 4), lane * 4, 0, 0);
-			if (active && code >= 0) {
-				if (lp.use_lds_hist) atomicAdd(&hist[code], 1u);
-				else atomicAdd(&a.counts[code], 1ull);
+			u32 A, B;
+			lut_pack(c, A, B);
+			A &= t.keepA; B &= t.keepB;
+			const u32 x = lut_mix(A, B, t.seed);
+			const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);     // table 2 takes the next nb bits
+			const u32x2_t e1 = entry(x & mask);
+			const u32x2_t e2 = entry(mask + 1u + (y & mask));
+			const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
+			const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
+			const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
+			const int tot = (int)(w0 >> 31) + (int)sepbad;
+			const bool found = (m1 == 0u || m2 == 0u) && tot <= t.max_diff;
+			const int idx = (int)((w1 >> 24) & 0x7fu);
+			const bool amb = (int)w1 < 0;
+			const int code = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
+			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, ro * 4, rows * 4), lane * 4, 0, 0);
+			if (DETAIL) {
+				int first = idx, last = idx;
+				if (found && amb) { first = t.amb[2 * idx]; last = t.amb[2 * idx + 1]; }
+				__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(found ? tot : 255), make_rsrc(a.lowest_diff, ro, rows), lane, 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? first : -1), make_rsrc(a.first_idx, ro * 2, rows * 2), lane * 2, 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? last : -1), make_rsrc(a.last_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 			}
-			wc.total += (u32)__popcll(__ballot(active));
-			wc.ident += (u32)__popcll(__ballot(active && code >= 0));
-			wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
+			if (active && code >= 0) atomicAdd(&hist[code], 1u);           // S <= 128: the histogram is always in LDS
+			n_total += (u32)rows;
+			n_ident += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code >= 0));
+			n_ambig += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code == kAssignAmbiguous));
+			if (!DIRECT) wave_lds_fence();
 		}
-		if (!DIRECT) wave_lds_fence();
 	}
-	flush_counts_spread(tb, a.counts, lp, hist, lane, wc);
+	const WaveCounts wc = {n_total, n_ident, n_ambig};
+	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
-template <bool DIRECT, bool BOTH, int NT = 1, bool LDSTAB = false>
-static const void *demux_hash_fn_w(int W)
+template <bool LDSTAB, bool DETAIL>
+static const void *demux_lut_fn(int W1, int W2, bool direct)
 {
-	switch (W) {
-	case 1: return reinterpret_cast<const void *>(demux_hash_kernel<1, DIRECT, BOTH, NT, LDSTAB>);
-	case 2: return reinterpret_cast<const void *>(demux_hash_kernel<2, DIRECT, BOTH, NT, LDSTAB>);
-	case 3: return reinterpret_cast<const void *>(demux_hash_kernel<3, DIRECT, BOTH, NT, LDSTAB>);
-	case 4: return reinterpret_cast<const void *>(demux_hash_kernel<4, DIRECT, BOTH, NT, LDSTAB>);
-	case 5: return reinterpret_cast<const void *>(demux_hash_kernel<5, DIRECT, BOTH, NT, LDSTAB>);
-	case 6: return reinterpret_cast<const void *>(demux_hash_kernel<6, DIRECT, BOTH, NT, LDSTAB>);
-	case 7: return reinterpret_cast<const void *>(demux_hash_kernel<7, DIRECT, BOTH, NT, LDSTAB>);
-	default: return reinterpret_cast<const void *>(demux_hash_kernel<8, DIRECT, BOTH, NT, LDSTAB>);
+	if (direct) return W1 == 1 ? reinterpret_cast<const void *>(demux_lut_kernel<1, 0, true, LDSTAB, DETAIL>)
+	                           : reinterpret_cast<const void *>(demux_lut_kernel<2, 0, true, LDSTAB, DETAIL>);
+	if (W2 > 0) return W1 == 1 ? reinterpret_cast<const void *>(demux_lut_kernel<1, 1, false, LDSTAB, DETAIL>)
+	                           : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, LDSTAB, DETAIL>);
+	switch (W1) {
+	case 1: return reinterpret_cast<const void *>(demux_lut_kernel<1, 0, false, LDSTAB, DETAIL>);
+	case 2: return reinterpret_cast<const void *>(demux_lut_kernel<2, 0, false, LDSTAB, DETAIL>);
+	case 3: return reinterpret_cast<const void *>(demux_lut_kernel<3, 0, false, LDSTAB, DETAIL>);
+	case 4: return reinterpret_cast<const void *>(demux_lut_kernel<4, 0, false, LDSTAB, DETAIL>);
+	default: return reinterpret_cast<const void *>(demux_lut_kernel<5, 0, false, LDSTAB, DETAIL>);
 	}
 }
 
@@ -1519,95 +1486,63 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	static const bool env_no_fuse = getenv("SK_NO_FUSED_DEMUX") != nullptr;
 	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 && !env_no_fuse;
 	if (b.bc && !fuse_demux) {
-		// only the decision is wanted and the sheet has a neighbourhood table: one lookup per read
-		static const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
-		const bool by_table = b.table.hk && !b.lowest_diff && !b.first_idx && !b.last_idx && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
+		// the sheet has a neighbourhood table and the call wants the decision alone, or the detail columns of matched rows
+		// only (TileArgs::detail_matched): one lookup per read
+		const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
+		const bool want_detail = b.lowest_diff || b.first_idx || b.last_idx;
+		const bool by_table = b.table.nbr.tab && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
 		hipError_t e;
+		TileArgs bb = b;
 		if (by_table) {
-			LaunchShape sh;
+			const LutDev &t = b.table.nbr;
 			// rows on dword boundaries whose key is one or two dwords: read straight from memory (lane r = row r, one 8 B/lane
 			// load for 8-byte rows).  Longer keys go through the LDS image even when the rows are aligned: five dword loads at
-			// a 24-byte stride walk the same lines five times (96 dual-index padded to 24 B: 67 G pairs/s direct, 95 through LDS)
-			// (SK_DEMUX_DIRECT=0 and SK_DEMUX_TILES=1 / 4 force the choices: tools/demux_ab.py, and the tests run every
-			// kernel on the same small inputs)
+			// a 24-byte stride walk the same lines five times.  (SK_DEMUX_DIRECT=0 / SK_DEMUX_LDSTAB=0 force the other forms:
+			// the tests run every kernel on the same inputs)
 			const char *env_direct = getenv("SK_DEMUX_DIRECT");
-			const bool direct = (b.bc_stride & 3) == 0 && b.table.hk_W <= 2 && 4 * b.table.hk_W <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
-			// both cuckoo slots at once while the two tables are small enough to stay in the CU's vector cache (cfg 3: 32 KiB;
-			// 246 against 223 G reads/s), one after the other above that (96 dual-index, 1 MiB: 98 against 68 G pairs/s)
-			const bool both = (size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4 <= (64u << 10);
-			// tiles per wave iteration: four for a big table read through LDS images once the call is a few million reads
-			// (96 dual-index: 93 -> 101 G pairs/s at 10 M, 101 -> 111 at 100 M; at 1 M 72 -> 67), one otherwise (16 single-index at
-			// 10 M: 256 / 246 / 196 G reads/s with 1 / 2 / 4)
-			const char *env_nt = getenv("SK_DEMUX_TILES");
-			const int nt = env_nt ? (atoi(env_nt) == 4 ? 4 : 1) : (!direct && !both && (b.n + kTileRows - 1) / kTileRows >= (int64_t)n_cu * 32 * 4) ? 4 : 1;
-			const int W = b.table.hk_W;
-			// a small table: in LDS, one copy per workgroup of sixteen waves (beside their tile images when rows go through those).
-			// Two gathers of 64 different lines per tile are what the vector cache spends its tag lookups on; from LDS they are
-			// two reads.  (SK_DEMUX_LDSTAB=0 keeps the table in the vector cache: tools/demux_ab.py, tests)
+			const bool direct = (b.bc_stride & 3) == 0 && t.W2 == 0 && t.W1 <= 2 && 4 * t.W1 <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
-			const int table_bytes = (int)((size_t)(b.table.hk_mask + 1) * 2 * b.table.hk_slot_dw * 4);
-			if (both && nt == 1 && (!env_ldstab || atoi(env_ldstab) != 0)) {
-				const void *fl = !direct ? demux_hash_fn_w<false, true, 1, true>(W)
-				                 : W == 1 ? reinterpret_cast<const void *>(demux_hash_kernel<1, true, true, 1, true>)
-				                          : reinterpret_cast<const void *>(demux_hash_kernel<2, true, true, 1, true>);
-				LdsPlan lp{};
-				lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
-				lp.hist_off = 0;
-				lp.table_bytes = table_bytes;
-				lp.tiles_off = (lp.use_lds_hist ? ((b.table.S + 3) * 4 + 15) & ~15 : 0) + table_bytes;
-				lp.tile_slot = kLdsPad + (direct ? 0 : 2048) + kLdsPad;    // rows straight from memory need no image
-				const int lds = lp.tiles_off + 16 * lp.tile_slot;
-				struct Occ { int dev; const void *fn; int lds, wg; };
-				static std::mutex occ_m;
-				static std::vector<Occ> occ;
-				int dev = 0, wg = 0;
-				e = hipGetDevice(&dev);
+			const int table_bytes = (t.mask + 1) * 2 * 8;
+			const bool ldstab = table_bytes <= (128 << 10) && (!env_ldstab || atoi(env_ldstab) != 0);
+			const void *fn = ldstab ? (want_detail ? demux_lut_fn<true, true>(t.W1, t.W2, direct) : demux_lut_fn<true, false>(t.W1, t.W2, direct))
+			                        : (want_detail ? demux_lut_fn<false, true>(t.W1, t.W2, direct) : demux_lut_fn<false, false>(t.W1, t.W2, direct));
+			LdsPlan lp{};
+			lp.use_lds_hist = 1;                                      // S <= 128
+			lp.hist_off = 0;
+			lp.table_bytes = ldstab ? table_bytes : 0;
+			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
+			lp.tile_slot = kLdsPad + (direct ? 0 : (kTileRows * b.bc_stride + 15) & ~15) + kLdsPad;    // rows straight from memory need no image
+			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy; fewer when long rows leave no room for their images
+			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
+			const int lds = lp.tiles_off + nw * lp.tile_slot;
+			struct Occ { int dev; const void *fn; int lds, wg; };
+			static std::mutex occ_m;
+			static std::vector<Occ> occ;
+			int dev = 0, wg = 0;
+			e = hipGetDevice(&dev);
+			if (e != hipSuccess) return e;
+			{
+				std::lock_guard<std::mutex> lk(occ_m);
+				for (const Occ &o : occ) if (o.dev == dev && o.fn == fn && o.lds == lds) wg = o.wg;
+			}
+			if (wg == 0) {
+				e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+				if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fn, kWave * nw, (size_t)lds);
 				if (e != hipSuccess) return e;
-				{
-					std::lock_guard<std::mutex> lk(occ_m);
-					for (const Occ &o : occ) if (o.dev == dev && o.fn == fl && o.lds == lds) wg = o.wg;
-				}
-				if (wg == 0) {
-					e = hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-					if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg, fl, 1024, (size_t)lds);
-					if (e != hipSuccess) return e;
-					if (wg < 1) return hipErrorInvalidValue;
-					std::lock_guard<std::mutex> lk(occ_m);
-					occ.push_back({dev, fl, lds, wg});
-				}
-				const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows, want = (ntiles + 15) / 16, cap = (int64_t)n_cu * wg;
-				TileArgs bb = b;
-				void *kargs[] = {(void *)&bb, (void *)&lp};
-				e = hipLaunchKernel(fl, dim3((unsigned)(want < cap ? want : cap)), dim3(1024), kargs, lds, st);
-			} else {
-			const void *fn = nullptr;
-			switch ((nt == 4 ? 4 : 0) + (direct ? 2 : 0) + (both ? 1 : 0)) {
-			case 0: fn = demux_hash_fn_w<false, false, 1>(W); break;
-			case 1: fn = demux_hash_fn_w<false, true, 1>(W); break;
-			case 2: fn = demux_hash_fn_w<true, false, 1>(W); break;
-			case 3: fn = demux_hash_fn_w<true, true, 1>(W); break;
-			case 4: fn = demux_hash_fn_w<false, false, 4>(W); break;
-			case 5: fn = demux_hash_fn_w<false, true, 4>(W); break;
-			case 6: fn = demux_hash_fn_w<true, false, 4>(W); break;
-			default: fn = demux_hash_fn_w<true, true, 4>(W); break;
+				if (wg < 1) return hipErrorInvalidValue;
+				std::lock_guard<std::mutex> lk(occ_m);
+				occ.push_back({dev, fn, lds, wg});
 			}
-			e = plan_shape(fn, b.table, b.n, nt > 1 ? nt * kHashTileLds : 2048, false, 4, n_cu, 1, 0, sh);
-			if (e == hipSuccess) {
-				// the histogram sits where the matcher tables would: plan_shape(with_tables = false) leaves no room for it
-				sh.lp.use_lds_hist = b.table.S + 3 <= kMaxLdsHist ? 1 : 0;
-				sh.lp.hist_off = 0;
-				const int hist_bytes = sh.lp.use_lds_hist ? ((b.table.S + 3) * 4 + 15) & ~15 : 0;
-				sh.lp.tiles_off += hist_bytes;
-				sh.lds += hist_bytes;
-				TileArgs bb = b;
-				void *kargs[] = {(void *)&bb, (void *)&sh.lp};
-				e = hipLaunchKernel(fn, dim3(sh.grid), dim3(sh.block), kargs, sh.lds, st);
-			}
-			}
+			const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
+			const int64_t grid = want < cap ? want : cap;
+			// a few hundred workgroups add to the counters directly; thousands go through the spread copies and the fold
+			if (grid <= 512) bb.table.count_rep = nullptr;
+			void *kargs[] = {(void *)&bb, (void *)&lp};
+			e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kWave * nw), kargs, lds, st);
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		}
-		if (e == hipSuccess) e = launch_counts_fold(b, st);
+		if (e == hipSuccess) e = launch_counts_fold(bb, st);
 		if (e != hipSuccess) return e;
 	}
 	if (!any_mate) return hipSuccess;

@@ -1,0 +1,85 @@
+// sk_lut.h — the sheet's neighbourhood table: D1 + D2 + D3 (src/fasta_demultiplex.rs:154-194, :269-277) as ONE lookup.
+//
+// With max_diff <= 1 the observed barcodes that get a sample (or the ambiguity verdict) are few: every sheet row and
+// its one-substitution neighbours.  The host enumerates them, decides each with the reference's loop and stores
+//     key -> (lowest_diff, first argmin, last argmin)
+// in a table small enough for a workgroup's LDS; a read is then: classify its bytes, pack, hash, two probes.
+//
+// Key.  Every byte of a counting column (not a wildcard in the sheet, not the separator) becomes a 3-bit class: the
+// index of the sheet letter it equals, or `other` (an index no letter has) for any byte the sheet never uses.  The
+// classes of up to 20 columns are packed into two words without a carry or a multiply (lut_pack).  Columns that are a
+// wildcard in EVERY row (UMI columns), the separator and the bytes past L are masked out (keepA / keepB).
+// A separator is a column that holds the same letter in every row, a letter no other column uses ('+' of `i7+i5`):
+// a mismatch there adds one to the distance of EVERY row, so it is compared on its own and not part of the key — the
+// argmin set does not depend on it, and the table is a quarter smaller.  The two segments beside it are read on their
+// own (W1 + W2 dwords, W1 == W2): the key has no hole, 8 + 8 columns are four dwords of classes instead of five.
+//
+// Table.  Two-choice cuckoo, one 8-byte entry per slot, two tables of 2^nb slots.  (A, B) -> (X, B) with
+// X = mix(A ^ f(B) ^ seed) is a bijection (f any function, mix invertible), so an entry does not hold the key: the
+// slot index is nb bits of X, the entry keeps the other 32 - nb bits of X and B — equality of those IS equality of the
+// key (quotienting).  Table 1 is indexed by the low nb bits of X, table 2 by the next nb bits (X rotated right by nb).
+//     w0 = B (31 bits, bit 7 of every byte is never set) | lowest_diff << 31
+//     w1 = tag (32 - nb bits of X) | idx << 24 | ambiguous << 31
+// idx = the sample (first == last), or for an ambiguous key the index of its (first, last) pair in a side list.
+// A free slot has w0 = kLutFree (bit 7 set: equals no key).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define SK_HD __host__ __device__
+#else
+#define SK_HD
+#endif
+
+namespace sk {
+
+constexpr int kLutMaxLen = 20;           // columns the packing holds
+constexpr int kLutMaxSamples = 128;      // idx is 7 bits
+constexpr int kLutMinBits = 8;           // tag + idx + flag must fit 32 bits
+constexpr uint32_t kLutFree = 0x00000080u;
+
+struct LutDev {
+	const uint32_t *tab;       // 2 tables x (mask + 1) slots x 2 dwords, or nullptr: the sheet has no table
+	const int16_t *amb;        // (first, last) pairs of the ambiguous keys
+	int W1, W2;                // key dwords: the row's first W1 dwords, and (with a separator) W2 dwords from the byte after it
+	int nb, mask;              // slot bits, slots per table - 1
+	uint32_t seed, tag_mask;   // tag_mask = (1 << (32 - nb)) - 1
+	int sh;                    // byte -> letter index: (b >> sh) & 7
+	uint32_t tab_lo, tab_hi;   // the letters by index (v_perm table); an unused index holds a byte with another index
+	uint32_t other;            // the class of "a byte the sheet never uses", in every byte
+	uint32_t keepA, keepB;     // class bits of the counting columns in the packed words
+	int sep_off;               // separator: its byte offset in the row (-1 = none; then W2 == 0) ...
+	uint32_t sep_val;          // ... and its letter
+	int max_diff;              // 0 or 1
+};
+
+// classes of 4 consecutive columns (one per byte, 3 bits each) x 5 dwords -> two words; no two fields overlap
+SK_HD inline void lut_pack(const uint32_t (&c)[5], uint32_t &A, uint32_t &B)
+{
+	A = c[0] | (c[1] << 3) | ((c[4] & 0x03030303u) << 6);
+	B = c[2] | (c[3] << 3) | ((c[4] & 0x04040404u) << 4);
+}
+
+SK_HD inline uint32_t lut_mix(uint32_t A, uint32_t B, uint32_t seed)
+{
+	uint32_t t = B + (B << 10);
+	t ^= t >> 6;
+	uint32_t x = A ^ t ^ seed;
+	x ^= x >> 15;                       // every step is invertible: (A, B) -> (x, B) is a bijection
+	x += x << 10; x ^= x >> 6;
+	x += x << 3; x ^= x >> 11;
+	return x;
+}
+
+// Host side: what sk_set_barcodes' sheet becomes.  false = this sheet has no table (the matchers serve it).
+struct LutHost {
+	LutDev dev{};                        // tab / amb are null here
+	std::vector<uint32_t> slots;         // the two tables
+	std::vector<int16_t> amb;            // pairs
+	size_t n_keys = 0;
+};
+bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out);
+
+}  // namespace sk

@@ -1,0 +1,134 @@
+// CPU check of the neighbourhood table (seqkit_amd/csrc/sk_lut.{h,cpp}): build tables for many sheets and look every
+// observed barcode up with the arithmetic the kernel uses (classify, pack, mix, two probes, separator), against the
+// reference's loop written out plainly (src/fasta_demultiplex.rs:154-194, :269-277).  No GPU; the lookup below is a test
+// model of demux_lut_kernel, not a product path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../seqkit_amd/csrc/sk_lut.h"
+
+using sk::LutDev;
+using sk::LutHost;
+
+static uint32_t perm_lookup(uint32_t hi, uint32_t lo, uint32_t sel)       // v_perm_b32 with selectors 0..7
+{
+	uint32_t out = 0;
+	for (int j = 0; j < 4; j++) {
+		const uint32_t s = (sel >> (8 * j)) & 0xff;
+		const uint32_t byte = s < 4 ? (lo >> (8 * s)) & 0xff : (hi >> (8 * (s - 4))) & 0xff;
+		out |= byte << (8 * j);
+	}
+	return out;
+}
+
+struct Result { int assign, diff, first, last; };
+
+static Result lookup(const LutHost &h, const uint8_t *obs, int L)
+{
+	const LutDev &t = h.dev;
+	uint32_t d[5] = {0, 0, 0, 0, 0}, c[5] = {0, 0, 0, 0, 0};
+	uint8_t padded[32];
+	memset(padded, 0xEE, sizeof padded);                                   // bytes past L are garbage to the kernel too
+	memcpy(padded, obs, (size_t)L);
+	for (int w = 0; w < t.W1; w++) memcpy(&d[w], padded + 4 * w, 4);
+	for (int w = 0; w < t.W2; w++) memcpy(&d[t.W1 + w], padded + t.sep_off + 1 + 4 * w, 4);
+	const uint32_t sepbad = (t.sep_off >= 0 && padded[t.sep_off] != t.sep_val) ? 1u : 0u;
+	for (int w = 0; w < t.W1 + t.W2; w++) {
+		const uint32_t sel = (d[w] >> t.sh) & 0x07070707u;
+		const uint32_t letter = perm_lookup(t.tab_hi, t.tab_lo, sel);
+		const uint32_t df = d[w] ^ letter;
+		const uint32_t nz = (((df & 0x7f7f7f7fu) + 0x7f7f7f7fu) | df) & 0x80808080u;
+		const uint32_t m = nz - (nz >> 7);
+		c[w] = (m & t.other) | (~m & sel);
+	}
+	uint32_t A, B;
+	sk::lut_pack(c, A, B);
+	A &= t.keepA; B &= t.keepB;
+	const uint32_t x = sk::lut_mix(A, B, t.seed);
+	const uint32_t y = t.nb ? (x >> t.nb) | (x << (32 - t.nb)) : x;
+	const uint32_t *e1 = &h.slots[2 * (size_t)(x & (uint32_t)t.mask)];
+	const uint32_t *e2 = &h.slots[2 * ((size_t)t.mask + 1 + (y & (uint32_t)t.mask))];
+	auto hit = [&](const uint32_t *e, uint32_t tag) { return (((e[0] ^ B) & 0x7fffffffu) | ((e[1] ^ tag) & t.tag_mask)) == 0; };
+	const bool h1 = hit(e1, x >> t.nb), h2 = hit(e2, y >> t.nb);
+	if (h1 && h2) { fprintf(stderr, "key in both tables\n"); exit(1); }
+	Result r = {-1, 255, -1, -1};
+	if (!h1 && !h2) return r;
+	const uint32_t *e = h1 ? e1 : e2;
+	const int tot = (int)(e[0] >> 31) + (int)sepbad;
+	if (tot > t.max_diff) return r;
+	const int idx = (int)((e[1] >> 24) & 0x7f);
+	r.diff = tot;
+	if (e[1] >> 31) { r.assign = -2; r.first = h.amb[2 * (size_t)idx]; r.last = h.amb[2 * (size_t)idx + 1]; }
+	else { r.assign = idx; r.first = r.last = idx; }
+	return r;
+}
+
+static Result reference(const std::vector<uint8_t> &sheet, int S, int L, int max_diff, const uint8_t *obs)
+{
+	int lowest = 0x7fffffff, first = 0, last = 0;
+	for (int s = 0; s < S; s++) {
+		int d = 0;
+		for (int k = 0; k < L; k++) {
+			const uint8_t cb = sheet[(size_t)s * L + k];
+			if (cb == 'N' || cb == 'U') continue;
+			d += obs[k] != cb;
+		}
+		if (d < lowest) { lowest = d; first = s; last = s; }
+		else if (d == lowest) last = s;
+	}
+	Result r = {-1, lowest, first, last};
+	if (lowest <= max_diff) r.assign = first == last ? first : -2;
+	return r;
+}
+
+int main(int argc, char **argv)
+{
+	const int rounds = argc > 1 ? atoi(argv[1]) : 300;
+	std::mt19937_64 rng(12345);
+	auto pick = [&](int n) { return (int)(rng() % (uint64_t)n); };
+	const char *alphabets[] = {"ACGT", "ACGTN", "ACGT+", "ACGTacg", "AC", "ACGTN+U", "ACGT-_", "ACGTRYK"};
+	int built = 0, refused = 0;
+	size_t checked = 0;
+	for (int it = 0; it < rounds; it++) {
+		const int Ss[] = {1, 2, 3, 16, 40, 96, 128};
+		const int Ls[] = {1, 3, 4, 8, 9, 12, 17, 20};
+		const int S = Ss[pick(7)], L = Ls[pick(8)];
+		const std::string al = alphabets[pick(8)];
+		std::vector<uint8_t> sheet((size_t)S * L);
+		for (auto &b : sheet) b = (uint8_t)al[(size_t)pick((int)al.size())];
+		const int kind = pick(5);
+		if (kind == 1 && L >= 4) for (int s = 0; s < S; s++) for (int k = L - 3; k < L; k++) sheet[(size_t)s * L + k] = 'U';
+		if (kind == 2) for (auto &b : sheet) if (pick(10) == 0) b = 'N';
+		if (kind >= 3 && L >= 3) { const int c = pick(L); for (int s = 0; s < S; s++) sheet[(size_t)s * L + c] = '+'; }      // a separator (when '+' is nowhere else)
+		if (S >= 3 && pick(3) == 0) memcpy(&sheet[2 * (size_t)L], &sheet[0], (size_t)L);                                       // duplicate rows
+		const int max_diff = pick(4) == 0 ? 0 : 1;
+		LutHost h;
+		if (!sk::lut_build(sheet.data(), S, L, max_diff, h)) { refused++; continue; }
+		built++;
+		const char noise[] = "ACGTNacgtn+U\x00\xff#-_";
+		for (int r = 0; r < 3000; r++) {
+			uint8_t obs[32];
+			if (pick(10) == 0) for (int k = 0; k < L; k++) obs[k] = (uint8_t)noise[pick((int)sizeof noise - 1)];
+			else {
+				memcpy(obs, &sheet[(size_t)pick(S) * L], (size_t)L);
+				const int nsub = pick(4);
+				for (int j = 0; j < nsub; j++) obs[pick(L)] = (uint8_t)noise[pick((int)sizeof noise - 1)];
+			}
+			const Result got = lookup(h, obs, L), want = reference(sheet, S, L, max_diff, obs);
+			checked++;
+			const bool same = got.assign == want.assign && (want.assign == -1 || (got.diff == want.diff && got.first == want.first && got.last == want.last));
+			if (!same) {
+				fprintf(stderr, "MISMATCH it=%d S=%d L=%d max_diff=%d: got (%d,%d,%d,%d) want (%d,%d,%d,%d)\n", it, S, L, max_diff,
+				        got.assign, got.diff, got.first, got.last, want.assign, want.diff, want.first, want.last);
+				return 1;
+			}
+		}
+	}
+	// the two sheets of the benchmark: sizes (informative)
+	printf("ok: %d tables built, %d sheets refused, %zu lookups\n", built, refused, checked);
+	return 0;
+}

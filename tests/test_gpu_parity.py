@@ -253,7 +253,7 @@ def test_counters_accumulate_and_reset(ctx, oracle):
     assert ctx.counts().sum() == 0
 
 
-# ---- demultiplex alone, decision only: the neighbourhood-table lookup (demux_hash_kernel) ---------------------------
+# ---- demultiplex alone through the neighbourhood table (demux_lut_kernel): decision only, or detail of matched rows ----
 def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     """assign + counters without the detail columns: served by the lookup table when the sheet has one, by the matchers
     otherwise — the same answers either way, and the same as with the detail columns."""
@@ -264,25 +264,83 @@ def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     assert np.array_equal(ctx.counts(), e_counts)
 
 
-@pytest.mark.parametrize("no_table", [False, True, "1 tile per iteration", "4 tiles per iteration", "0: table not in LDS"])
-def test_demux_decision_only_cfg3_cfg4(ctx, oracle, monkeypatch, no_table):
-    if no_table is True:
+def check_demux_matched(ctx, oracle, table, bc, max_diff=1):
+    """SK_DETAIL_MATCHED: assign and counters of every row, lowest_diff / first / last of the rows that matched something
+    (the only rows the reference reads them for: src/fasta_demultiplex.rs:184-188)."""
+    import seqkit_amd
+    ctx.set_barcodes(table, max_diff)
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+    try:
+        assign, low, first, last = ctx.demux_assign(bc)
+    finally:
+        ctx.set_detail_mode(seqkit_amd.SK_DETAIL_FULL)
+    e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, max_diff)
+    assert np.array_equal(assign, e_assign)
+    m = e_assign != -1
+    assert np.array_equal(low[m], e_low[m]) and np.array_equal(first[m], e_first[m]) and np.array_equal(last[m], e_last[m])
+    assert np.array_equal(ctx.counts(), e_counts)
+    return int(m.sum())
+
+
+@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache"])
+def lut_form(request, monkeypatch):
+    """The forms of the lookup kernel (and the matchers, without a table) on the same inputs."""
+    if request.param == "no table":
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
-    elif no_table:
-        monkeypatch.setenv("SK_DEMUX_LDSTAB" if "LDS" in no_table else "SK_DEMUX_TILES", no_table[0])          # the lookup kernel's other forms
+    elif request.param == "rows through the LDS image":
+        monkeypatch.setenv("SK_DEMUX_DIRECT", "0")
+    elif request.param == "table in the vector cache":
+        monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")
+    return request.param
+
+
+def test_demux_by_table_cfg3_cfg4(ctx, oracle, lut_form):
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     bc, _ = synth.observe_barcodes(table, 200_003, seed=3)
+    bc[::13, 5] = ord("N")
+    bc[::17, 2] = ord("+")
     check_demux_decision_only(ctx, oracle, table, bc)
     check_demux_decision_only(ctx, oracle, table, bc, max_diff=0)
+    assert check_demux_matched(ctx, oracle, table, bc) > 100_000
+    check_demux_matched(ctx, oracle, table, bc, max_diff=0)
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     bc, _ = synth.observe_barcodes(table, 100_001, seed=4, halves=2)
+    bc[::19, 8] = ord("A")                                          # a broken separator costs one mismatch for every sample
+    bc[::23, 8] = ord("-")
+    bc[::29, 3] = ord("+")
     check_demux_decision_only(ctx, oracle, table, bc)
-    padded = np.zeros((bc.shape[0], 24), dtype=np.uint8)          # bc_stride above the barcode length
-    padded[:, :17] = bc
-    padded[:, 17:] = 0x41
-    ctx.set_barcodes(table, 1)
-    assign, *_ = ctx.demux_assign(padded, want_detail=False)
-    assert np.array_equal(assign, oracle.demux_batch(table, bc, 1)[0])
+    check_demux_decision_only(ctx, oracle, table, bc, max_diff=0)
+    assert check_demux_matched(ctx, oracle, table, bc) > 50_000
+    check_demux_matched(ctx, oracle, table, bc, max_diff=0)
+    for stride in (20, 24, 32):                                     # bc_stride above the barcode length
+        padded = np.full((bc.shape[0], stride), 0x41, dtype=np.uint8)
+        padded[:, :17] = bc
+        ctx.set_barcodes(table, 1)
+        assign, *_ = ctx.demux_assign(padded, want_detail=False)
+        assert np.array_equal(assign, oracle.demux_batch(table, bc, 1)[0])
+
+
+def test_demux_by_table_ambiguity_duplicates_umi(ctx, oracle, lut_form):
+    """Ambiguous keys keep their (first, last) pair in the side list; duplicates are always ambiguous; UMI columns do not count."""
+    table = np.array([list(b"ACGTACGTAAAA"), list(b"ACGTACGAAAAT"), list(b"TTCTTTTTUUUU"), list(b"GGGGGGGGUUUU"),
+                      list(b"CCCCCCCCCCCC"), list(b"CCCCCCCCCCCC")], dtype=np.uint8)
+    table[:, 8:] = np.frombuffer(b"UUUU", dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    src = table[rng.integers(0, 6, size=50000)].copy()
+    alphabet = np.frombuffer(b"ACGTNU+acgt", dtype=np.uint8)
+    for _ in range(2):
+        hit = rng.random(src.shape[0]) < 0.5
+        pos = rng.integers(0, 12, size=src.shape[0])
+        src[hit, pos[hit]] = alphabet[rng.integers(0, alphabet.size, size=int(hit.sum()))]
+    check_demux_decision_only(ctx, oracle, table, src)
+    check_demux_matched(ctx, oracle, table, src)
+    e = oracle.demux_batch(table, src, 1)
+    assert (e[0] == -2).sum() > 1000
+    table = np.array([list(b"AAAAAAAA"), list(b"AAAAAATT"), list(b"AAAAAATA"), list(b"TTTTTTTT")], dtype=np.uint8)      # Appendix A's ambiguity, and a chain of neighbours
+    src = table[rng.integers(0, 4, size=20000)].copy()
+    hit = rng.random(20000) < 0.7
+    src[hit, rng.integers(0, 8, size=20000)[hit]] = synth.BASES[rng.integers(0, 4, size=int(hit.sum()))]
+    check_demux_matched(ctx, oracle, table, src)
 
 
 @pytest.mark.parametrize("chunk_log2", [None, 17])
@@ -314,38 +372,54 @@ def test_demux_counters_across_launches(ctx, oracle, monkeypatch, want_detail, c
         assert np.array_equal(ctx.counts().astype(np.uint64), counts_of(e_assign[:5000]))
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_fuzz_demux_decision_only(ctx, oracle, seed, monkeypatch):
-    """Sheets with and without a lookup table: wildcard columns (all rows / some rows), duplicates, lower case next to upper
-    case, up to 7 letters and more, any length to 32 and above, max_diff 0 / 1 / 2, observed barcodes with foreign bytes;
-    the lookup kernel with the tiles per iteration that a call of this size takes, and with 1 / 4 (seeds 1, 2 of every three)."""
-    if seed % 3:
-        monkeypatch.setenv("SK_DEMUX_TILES", "1" if seed % 3 == 1 else "4")
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
+    """Sheets with and without a lookup table: wildcard columns (all rows / some rows), a separator, duplicates, lower case
+    next to upper case, up to 7 letters and more, any length to 20 and above, more than 128 samples, max_diff 0 / 1 / 2,
+    observed barcodes with foreign bytes, padded rows; every form of the lookup kernel; decision only, matched detail, and
+    the full detail right after on the same sheet."""
     if seed % 4 == 1:
-        monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")          # small tables from the vector cache instead of LDS
+        monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")          # the table from the vector cache instead of LDS
+    if seed % 4 == 2:
+        monkeypatch.setenv("SK_DEMUX_DIRECT", "0")          # aligned short rows through the LDS image too
     rng = np.random.default_rng(12000 + seed)
-    S = int(rng.choice([1, 2, 3, 16, 40, 96]))
-    L = int(rng.choice([1, 3, 4, 8, 9, 17, 24, 31, 32, 33]))
-    alphabet = [b"ACGT", b"ACGTN", b"ACGT+", b"ACGTacgt", b"ACGTRYKM", b"AC", b"ACGTN+U"][int(rng.integers(0, 7))]
+    S = int(rng.choice([1, 2, 3, 16, 40, 96, 128, 150]))
+    L = int(rng.choice([1, 3, 4, 8, 9, 12, 16, 17, 20, 21, 24, 33]))
+    alphabet = [b"ACGT", b"ACGTN", b"ACGT+", b"ACGTacgt", b"ACGTRYKM", b"AC", b"ACGTN+U", b"ACGT-_x"][int(rng.integers(0, 8))]
     table = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=(S, L)).astype(np.uint8)
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 1 and L >= 4:                     # UMI columns: a wildcard in every row
         table[:, L - 3:] = ord("U")
     elif kind == 2:                               # wildcards here and there (no table then)
         table[rng.random((S, L)) < 0.1] = ord("N")
+    elif kind >= 3 and L >= 3:                    # a separator column
+        table[:, int(rng.integers(0, L))] = ord("+") if kind == 3 else ord("A")
     if S >= 3 and rng.random() < 0.3:
         table[2] = table[0]                       # duplicate barcodes: always ambiguous
-    n = int(rng.choice([1, 64, 777, 5000]))
+    n = int(rng.choice([1, 64, 777, 5000, 70001]))
     pick = table[rng.integers(0, S, size=n)].copy()
-    noise = rng.random((n, L)) < 0.07
+    noise = rng.random((n, L)) < 0.05
     pick[noise] = rng.choice(np.frombuffer(b"ACGTNacgtn+U\x00\xff#", dtype=np.uint8), size=int(noise.sum()))
-    bc = np.ascontiguousarray(pick)
+    stride = L + int(rng.choice([0, 0, 1, 3, 7])) if L <= 24 else L
+    bc = np.full((n, stride), 0x43, dtype=np.uint8)
+    bc[:, :L] = pick
     table = np.ascontiguousarray(table)
     md = int(rng.choice([0, 1, 1, 1, 2]))
-    check_demux_decision_only(ctx, oracle, table, bc, md)
-    ctx.set_barcodes(table, md)                   # and the detail form right after, on the same sheet
-    assign, low, first, last = ctx.demux_assign(bc)
-    e = oracle.demux_batch(table, bc, md)
+    e = oracle.demux_batch(table, np.ascontiguousarray(pick), md)
+    ctx.set_barcodes(table, md)
+    assign, low, *_ = ctx.demux_assign(bc, want_detail=False)
+    assert low is None and np.array_equal(assign, e[0]) and np.array_equal(ctx.counts(), e[4])
+    import seqkit_amd
+    ctx.counts_reset()
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+    try:
+        assign, low, first, last = ctx.demux_assign(bc)
+    finally:
+        ctx.set_detail_mode(seqkit_amd.SK_DETAIL_FULL)
+    m = e[0] != -1
+    assert np.array_equal(assign, e[0]) and np.array_equal(ctx.counts(), e[4])
+    assert np.array_equal(low[m], e[1][m]) and np.array_equal(first[m], e[2][m]) and np.array_equal(last[m], e[3][m])
+    assign, low, first, last = ctx.demux_assign(bc)           # and the full detail (the matchers) on the same sheet
     assert np.array_equal(assign, e[0]) and np.array_equal(low, e[1]) and np.array_equal(first, e[2]) and np.array_equal(last, e[3])
 
 
