@@ -203,6 +203,8 @@ int sk_fused_pass_blocked_dev(sk_ctx *ctx, const sk_blocked_layout *lay, const u
  * host sums them with one all-reduce (sk_counts_device_ptr gives the device buffer to reduce).       */
 int sk_counts_reset(sk_ctx *ctx);
 int sk_counts_get(sk_ctx *ctx, uint64_t *counts /* host, S+3 */);
+/* The ctx's device u64[S+3].  It holds what was enqueued on the ctx BEFORE this call (once the ctx stream has got there):
+ * ask again after later demultiplex calls, do not keep the pointer across them.                              */
 void *sk_counts_device_ptr(sk_ctx *ctx);
 
 /* ---- (e) multi-GPU: the count reduce over RCCL / xGMI ---------------------------------------------------------

@@ -39,6 +39,8 @@ struct sk_ctx {
 	bool nbr_tried = false;
 	int detail_mode = SK_DETAIL_FULL;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
+	unsigned long long *d_counts_wide = nullptr;   // TileArgs::counts_wide: 16 x (S+3) lines; folded into d_counts by fold_counts()
+	bool wide_dirty = false;
 	unsigned long long *d_count_rep = nullptr; // BarcodeDev::count_rep
 	int count_rep_pitch = 0;
 	size_t count_rep_set = 0;                  // u64 words of one set
@@ -186,6 +188,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_bs) (void)hipFree(c->d_bs);
 	if (c->d_nbr) (void)hipFree(c->d_nbr);
 	if (c->d_counts) (void)hipFree(c->d_counts);
+	if (c->d_counts_wide) (void)hipFree(c->d_counts_wide);
 	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->census) sk::census_destroy(c->census);
@@ -277,6 +280,8 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	c->nbr = sk::LutDev{};
 	c->bs_bytes = c->bs_mm_off = c->G = 0;
 	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
+	if (c->d_counts_wide) { SK_HIP(c, hipFree(c->d_counts_wide)); c->d_counts_wide = nullptr; }
+	c->wide_dirty = false;
 	if (c->d_count_rep) { SK_HIP(c, hipFree(c->d_count_rep)); c->d_count_rep = nullptr; }
 	c->have_table = false;
 	c->S = S; c->L = L; c->max_diff = max_diff;
@@ -351,6 +356,11 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	c->nbr_tried = false;
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
+	if (S <= sk::kLutMaxSamples) {
+		const size_t wide_bytes = (((size_t)sk::kCountReplicas * (S + 3)) << sk::kCountWideShift) * 8;
+		SK_HIP(c, hipMalloc((void **)&c->d_counts_wide, wide_bytes));
+		SK_HIP(c, hipMemset(c->d_counts_wide, 0, wide_bytes));
+	}
 	if (S + 3 <= sk::kMaxLdsHist) {
 		// two sets: the chunk pipeline of the host entry points has launches of its two lanes in flight together, and a
 		// set serves one launch (the kernel and the fold behind it) at a time
@@ -395,6 +405,16 @@ static sk::BarcodeDev table_of(const sk_ctx *c)
 	return t;
 }
 
+// The lookup kernel adds the ctx's counters into one line each (d_counts_wide); everything that reads or hands out
+// d_counts first moves them over, on the ctx stream (the device is bound, and the second lane has been waited for).
+static int fold_counts(sk_ctx *c)
+{
+	if (!c->wide_dirty) return SK_OK;
+	SK_HIP(c, sk::launch_counts_fold_wide(c->d_counts_wide, c->S + 3, c->d_counts, c->stream));
+	c->wide_dirty = false;
+	return SK_OK;
+}
+
 int sk_set_detail_mode(sk_ctx *c, int mode)
 {
 	if (!c) return SK_ERR_INVALID;
@@ -408,6 +428,7 @@ int sk_counts_reset(sk_ctx *c)
 	if (!c) return SK_ERR_INVALID;
 	if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
 	if (int r = bind(c)) return r;
+	if (int r = fold_counts(c)) return r;
 	SK_HIP(c, hipMemsetAsync(c->d_counts, 0, (size_t)(c->S + 3) * 8, c->stream));
 	return SK_OK;
 }
@@ -417,12 +438,18 @@ int sk_counts_get(sk_ctx *c, uint64_t *counts)
 	if (!c || !counts) return SK_ERR_INVALID;
 	if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
 	if (int r = bind(c)) return r;
+	if (int r = fold_counts(c)) return r;
 	SK_HIP(c, hipMemcpyAsync(counts, c->d_counts, (size_t)(c->S + 3) * 8, hipMemcpyDeviceToHost, c->stream));
 	SK_HIP(c, hipStreamSynchronize(c->stream));
 	return SK_OK;
 }
 
-void *sk_counts_device_ptr(sk_ctx *c) { return (c && c->have_table) ? (void *)c->d_counts : nullptr; }
+void *sk_counts_device_ptr(sk_ctx *c)
+{
+	if (!c || !c->have_table) return nullptr;
+	if (bind(c) != SK_OK || fold_counts(c) != SK_OK) return nullptr;      // what was enqueued before this call is in the vector once the stream gets there
+	return (void *)c->d_counts;
+}
 
 // ---- (e) the count reduce over RCCL ---------------------------------------------------------------------------
 // librccl is 570 MB: the command-line hosts must not pay for loading it unless they drive several GPUs, so it is
@@ -560,6 +587,10 @@ int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx)
 		if (ctxs[i]->S != c0->S) return fail(c0, SK_ERR_INVALID, "ctx %d has %d samples, ctx 0 has %d", i, ctxs[i]->S, c0->S);
 	}
 	const int nc = c0->S + 3;
+	for (int i = 0; i < n_ctx; i++) {
+		if (int r = bind(ctxs[i])) return r;
+		if (int r = fold_counts(ctxs[i])) return r;
+	}
 	if (n_ctx == 1) return sk_allreduce_u64_dev(c0, (uint64_t *)c0->d_counts, (size_t)nc);     // across ranks (or nothing to do)
 	for (int i = 0; i < n_ctx; i++)
 		if (ctxs[i]->comm) return fail(c0, SK_ERR_STATE, "ctx %d belongs to a one-process-per-GPU communicator: reduce it alone", i);
@@ -672,6 +703,7 @@ static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
 	t.assign = a->assign; t.lowest_diff = a->lowest_diff; t.first_idx = a->first_idx; t.last_idx = a->last_idx;
 	t.detail_matched = c->detail_mode == SK_DETAIL_MATCHED ? 1 : 0;
 	t.counts = a->counts ? (unsigned long long *)a->counts : c->d_counts;
+	t.counts_wide = a->counts ? nullptr : c->d_counts_wide;
 	return t;
 }
 
@@ -683,6 +715,7 @@ int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
 	if (a->n == 0) return SK_OK;
 	if (int r = prepare_demux(c, a)) return r;
 	sk::TileArgs t = tile_args_of(c, a);
+	if (t.bc && t.counts_wide) c->wide_dirty = true;
 	SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
 	return SK_OK;
 }
@@ -753,6 +786,7 @@ int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 		}
 		sk::TileArgs t = tile_args_of(c, &d);
 		if (t.table.count_rep && (pipe.k & 1)) t.table.count_rep += c->count_rep_set;     // the second lane's set of counter copies
+		if (t.bc && t.counts_wide) c->wide_dirty = true;
 		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, st));
 		for (int m = 0; m < a->n_mates; m++) {
 			const sk_mate &mt = a->mate[m];

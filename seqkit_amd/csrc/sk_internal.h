@@ -72,7 +72,12 @@ struct TileArgs {
 	int16_t *last_idx;
 	int detail_matched;             // SK_DETAIL_MATCHED: the detail columns of SK_ASSIGN_NONE rows are unspecified
 	unsigned long long *counts;     // device u64[S+3]
+	unsigned long long *counts_wide;    // or nullptr: kCountReplicas copies of the ctx's counters with one 128-byte line each (counter i of
+	                                    // copy r at [(r * (S+3) + i) << kCountWideShift]); the lookup kernel adds there instead of to `counts`,
+	                                    // the ctx folds before anything reads
 };
+constexpr int kCountWideShift = 4;
+hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, unsigned long long *counts, hipStream_t st);
 
 // Tile-blocked batch (include/seqkit_hip.h: sk_blocked_layout): tile t of 64 clusters reads the ONE byte range
 // in + t*in_block .. +in_block and writes out + t*out_block .. +out_block; the offsets say where each segment of the

@@ -635,7 +635,8 @@ __device__ __forceinline__ void demux_commit(const TileArgs &a, const LdsPlan &l
 	wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
 }
 
-__device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc)
+// shift: counter i lives at counts[i << shift] (4: one 128-byte line per counter, TileArgs::counts_shift)
+__device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc, int shift = 0)
 {
 	if (lp.use_lds_hist) {
 		if (lane == 0) {
@@ -646,12 +647,12 @@ __device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, 
 		__syncthreads();
 		for (int i = threadIdx.x; i < S + 3; i += blockDim.x) {
 			u32 c = hist[i];
-			if (c) atomicAdd(&counts[i], (unsigned long long)c);
+			if (c) atomicAdd(&counts[(size_t)i << shift], (unsigned long long)c);
 		}
 	} else if (lane == 0) {
-		if (wc.total) atomicAdd(&counts[S], (unsigned long long)wc.total);
-		if (wc.ident) atomicAdd(&counts[S + 1], (unsigned long long)wc.ident);
-		if (wc.ambig) atomicAdd(&counts[S + 2], (unsigned long long)wc.ambig);
+		if (wc.total) atomicAdd(&counts[(size_t)S << shift], (unsigned long long)wc.total);
+		if (wc.ident) atomicAdd(&counts[(size_t)(S + 1) << shift], (unsigned long long)wc.ident);
+		if (wc.ambig) atomicAdd(&counts[(size_t)(S + 2) << shift], (unsigned long long)wc.ambig);
 	}
 }
 
@@ -667,6 +668,25 @@ __device__ __forceinline__ void flush_counts_spread(const BarcodeDev &tb, unsign
 {
 	const bool spread = tb.count_rep != nullptr && lp.use_lds_hist;
 	flush_counts(tb.S, spread ? tb.count_rep + (size_t)(blockIdx.x & (kCountReplicas - 1)) * tb.count_rep_pitch : counts, lp, hist, lane, wc);
+}
+// the ctx's wide counters (one line each) into its u64[S+3], leaving them zero (sk_capi.hip folds before anything reads)
+__global__ __launch_bounds__(256) void counts_fold_wide_kernel(unsigned long long *__restrict__ wide, int nc, unsigned long long *__restrict__ counts)
+{
+	for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+		unsigned long long sum = 0;
+#pragma unroll
+		for (int r = 0; r < kCountReplicas; r++) {
+			unsigned long long *p = wide + (((size_t)r * nc + i) << kCountWideShift);
+			const unsigned long long v = *p;
+			if (v) { sum += v; *p = 0; }
+		}
+		if (sum) counts[i] += sum;
+	}
+}
+hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, unsigned long long *counts, hipStream_t st)
+{
+	counts_fold_wide_kernel<<<1, 256, 0, st>>>(wide, nc, counts);
+	return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void counts_fold_kernel(unsigned long long *__restrict__ rep, int pitch, int nc, unsigned long long *__restrict__ counts)
 {
@@ -1190,9 +1210,24 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	// the table and the histogram while the first tiles are on their way
 	if (lp.use_lds_hist) for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
 	const int ltab_off = lp.tiles_off - lp.table_bytes;                  // LDSTAB: the table sits right before the tile images
-	if (LDSTAB)
-		for (int i = threadIdx.x; i < (lp.table_bytes >> 4); i += blockDim.x)
-			*reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = reinterpret_cast<const u32x4 *>(t.tab)[i];
+	if (LDSTAB) {
+		// eight loads per thread on their way before the first is written: the 128 KiB of a dual-index table are one round trip
+		// to L2 per workgroup, not eight
+		const int n16 = lp.table_bytes >> 4;
+		for (int i0 = threadIdx.x; i0 < n16; i0 += 8 * (int)blockDim.x) {
+			u32x4 tv[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const int i = i0 + j * (int)blockDim.x;
+				if (i < n16) tv[j] = reinterpret_cast<const u32x4 *>(t.tab)[i];
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const int i = i0 + j * (int)blockDim.x;
+				if (i < n16) *reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = tv[j];
+			}
+		}
+	}
 	__syncthreads();
 	auto entry = [&](u32 slot) {
 		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
@@ -1281,7 +1316,11 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		}
 	}
 	const WaveCounts wc = {n_total, n_ident, n_ambig};
-	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
+	// a few hundred workgroups end together, and an addition to an address that others add to takes about 10 ns: 512 x 19
+	// of them into two lines were 4.5 of cfg 3's 31 us at 10 M reads.  When the counters are the ctx's they go to one of
+	// sixteen copies with a line per counter (folded before anything reads them), else to the caller's vector as it is
+	if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
+	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
 template <bool LDSTAB, bool DETAIL>
@@ -1536,12 +1575,13 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;
 			// a few hundred workgroups add to the counters directly; thousands go through the spread copies and the fold
-			if (grid <= 512) bb.table.count_rep = nullptr;
+			if (grid <= 512 || bb.counts_wide) bb.table.count_rep = nullptr;
 			void *kargs[] = {(void *)&bb, (void *)&lp};
 			e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kWave * nw), kargs, lds, st);
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		}
+		if (by_table && bb.counts_wide) return e;                       // nothing to fold behind the launch
 		if (e == hipSuccess) e = launch_counts_fold(bb, st);
 		if (e != hipSuccess) return e;
 	}

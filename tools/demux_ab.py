@@ -15,7 +15,7 @@ from seqkit_amd import synth  # noqa: E402
 dev = torch.device("cuda", 0)
 libs = [("cur", None)] + [(os.path.basename(p)[:-3], os.path.abspath(p)) for p in os.environ.get("SK_LIBS", "").split(",") if p]
 forms = [f for f in os.environ.get("DEMUX_FORMS", "default").split(";") if f]
-KNOBS = ("SK_DEMUX_LDSTAB", "SK_DEMUX_DIRECT", "SK_NO_HASH_DEMUX")
+KNOBS = ("SK_DEMUX_LDSTAB", "SK_DEMUX_DIRECT", "SK_NO_HASH_DEMUX", "SK_DEMUX_SPREAD", "SK_EXP_NOFLUSH")
 pad = int(os.environ.get("DEMUX_PAD", "0"))          # bytes added to every row: 17 -> 24 puts the dual-index rows on dword boundaries, 8 -> 9 takes them off
 sizes = [int(x) for x in os.environ.get("DEMUX_N", "10000000,100000000").split(",")]
 details = [False, True] if os.environ.get("DEMUX_DETAIL") else [False]
@@ -24,7 +24,7 @@ for what, S, dual, L, bpu in (("16 single-index", 16, False, 8, 12), ("96 dual-i
     table = synth.make_sheet(S, 8, dual=dual, seed=3 if not dual else 4)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3 if not dual else 4, halves=2 if dual else 1)
     for n in sizes:
-        bc = torch.from_numpy(bc_np).to(dev).repeat(n // 1_000_000, 1)
+        bc = torch.from_numpy(bc_np).to(dev).repeat(max(1, n // 1_000_000), 1)[:n]
         if pad:
             bc = torch.nn.functional.pad(bc, (0, pad), value=0x41)
         bc = bc.contiguous()
@@ -52,7 +52,7 @@ for what, S, dual, L, bpu in (("16 single-index", 16, False, 8, 12), ("96 dual-i
                         else:
                             ctx.demux_assign_dev(bc.data_ptr(), L + pad, n, assign.data_ptr())
                     run(); ctx.sync()
-                    got = assign[:200000].clone()
+                    got = assign[:min(n, 200000)].clone()
                     if ref is None:
                         ref = got
                     assert torch.equal(got, ref), (name, form)
