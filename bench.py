@@ -61,6 +61,7 @@ def parse(argv=None):
                     help="candidate device buffers per big matrix (SoA) / per buffer (blocked): allocated at start-up, the pass is timed "
                          "while one matrix at a time is swapped for its other candidates (sk_fused_tune_placement_dev), the fastest combination "
                          "is kept and the rest freed — where a buffer's pages lie moves the same kernel by up to 12 %%; 1 = take what comes")
+    ap.add_argument("--test-worker", default=None, help=argparse.SUPPRESS)     # tests/test_bench_launcher.py: the script the launcher starts as a rank
     return ap.parse_args(argv)
 
 
@@ -68,15 +69,44 @@ def parse(argv=None):
 # N > 1 without a launcher: start the ranks here.  Nothing above or inside this function imports torch or touches the
 # GPU, so no process that has initialised a GPU is ever re-executed; rank 0's stdout (the JSON line) is relayed.
 # ---------------------------------------------------------------------------------------------------------------------
+EXIT_PORT_TAKEN = 98                                            # a rank's exit code when the rendezvous port was taken: the launcher draws another
+
+
 def launch_ranks(args) -> int:
     n = args.gpus
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    worker = os.environ.get("SK_BENCH_WORKER")                  # tests put a stub here
-    cmd = [sys.executable, worker] if worker else [sys.executable, os.path.abspath(__file__)]
-    cmd += sys.argv[1:]
+    worker = args.test_worker                                   # test-only flag, never read from the environment
+    argv, skip = [], False
+    for a in sys.argv[1:]:                                      # the ranks get the command line without the test flag
+        if skip:
+            skip = False
+        elif a == "--test-worker":
+            skip = True
+        elif not a.startswith("--test-worker="):
+            argv.append(a)
+    cmd = ([sys.executable, worker] if worker else [sys.executable, os.path.abspath(__file__)]) + argv
+    for attempt in range(3):
+        # the port is free now; another process may take it before rank 0 listens — rank 0 then exits with EXIT_PORT_TAKEN
+        # and all ranks are started again on a new port (fresh processes: nothing that touched a GPU is re-executed)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        rc, out0 = run_ranks(cmd, n, port)
+        if rc != EXIT_PORT_TAKEN:
+            break
+        sys.stderr.write(f"[bench] port {port} was taken before rank 0 could listen; starting the ranks again\n")
+    if rc != 0:
+        return rc
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
+    if not lines:
+        sys.stderr.write("[bench] rank 0 printed nothing\n")
+        return 1
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def run_ranks(cmd, n, port):
     procs = []
     for r in range(n):
         env = dict(os.environ)
@@ -114,15 +144,11 @@ def launch_ranks(args) -> int:
                 failed = (-1, 124)
             break
     if failed is not None:
+        if failed[1] == EXIT_PORT_TAKEN:
+            return EXIT_PORT_TAKEN, b""
         sys.stderr.write(f"[bench] rank {failed[0]} failed with exit code {failed[1]}\n")
-        return failed[1] if 0 < failed[1] < 256 else 1
-    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
-    if not lines:
-        sys.stderr.write("[bench] rank 0 printed nothing\n")
-        return 1
-    sys.stdout.write(lines[-1] + "\n")
-    sys.stdout.flush()
-    return 0
+        return (failed[1] if 0 < failed[1] < 256 else 1), b""
+    return 0, out0
 
 
 def gen_shard(torch, dev, n, table_np, seed, chunk, into=None, sink=None):
@@ -226,18 +252,16 @@ def library_digest() -> str:
 
 
 def kernel_sources_digest() -> str:
-    """Digest of the kernel sources: the PMC traffic record in profiles/ is only quoted for the kernels it was measured on."""
-    h = hashlib.sha256()
-    for name in ("sk_kernels.hip", "sk_internal.h"):
-        with open(os.path.join(REPO, "seqkit_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    """Digest of everything libseqkit_hip.so is built from — kernels, launch code, the ABI layer, headers and the compiler
+    flags: the PMC traffic record in profiles/ is only quoted for the build it was measured on."""
+    from seqkit_amd import build
+    return build.library_inputs_digest()
 
 
 def secondary_rates(torch, ctx, dev):
     """extra.rates: device-resident rates of the other BASELINE configs on this GPU, a few ms each, outside the timed
     region.  Same workloads as tools/rates.py; `frac` is algorithmic bytes / time / 8 TB/s."""
-    from seqkit_amd import synth
+    from seqkit_amd import capi, synth
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     out = []
@@ -310,6 +334,14 @@ def secondary_rates(torch, ctx, dev):
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     assign = torch.empty((n,), dtype=torch.int32, device=dev)
     timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+    # what `fasta demultiplex` asks for: the decision plus lowest_diff / first / last of the reads that matched something
+    low = torch.empty((n,), dtype=torch.uint8, device=dev)
+    first = torch.empty((n,), dtype=torch.int16, device=dev)
+    last = torch.empty((n,), dtype=torch.int16, device=dev)
+    ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
+    timeit("cfg3 with the detail columns of matched reads (SK_DETAIL_MATCHED, as the fasta demultiplex host calls it), 10M x 8bp",
+           lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr()), n, 17)
+    ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()          # the same sheet on a call ten times as long: what the lookup does once the launch is out of the way
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
     timeit("cfg3 sheet, 100M x 8bp in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 8, 10 * n, assign_l.data_ptr()), 10 * n, 12)
@@ -319,7 +351,11 @@ def secondary_rates(torch, ctx, dev):
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     timeit("demultiplex only 10M x 17ch, 96 dual-index", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
-    del bc, assign
+    ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
+    timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch",
+           lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr()), n, 26)
+    ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+    del bc, assign, low, first, last
     n = 200_000_000
     flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
     flag = torch.from_numpy(flag_np.view(np.int16)).to(dev).repeat(100)
@@ -413,27 +449,95 @@ def faithful_cpu(n_reads):
     return res
 
 
-def join_count_reduce(dist, rank, world, make_unique_id, init_rank):
-    """The ranks agree on how the counters are summed.  Rank 0 makes the communicator id (sk_comm_get_unique_id), every rank
-    gets it over the rendezvous backend and joins (sk_comm_init_rank).  Should any rank fail at either step (a node may have
-    no usable interface for RCCL's bootstrap), ALL ranks learn of it and fall back together to a gloo sum with a host round
-    trip — the JSON line then says so; a scaling run still gets numbers.  Returns None (RCCL) or the reason (gloo)."""
+def join_count_reduce(dist, rank, world, make_unique_id, init_rank, ready=None, timeout_s=None):
+    """The ranks agree on how the counters are summed.  sk_comm_init_rank blocks until EVERY rank has called it, so nobody
+    calls it before all ranks have said they can: (1) every rank makes its rank-local check (`ready`: librccl loadable, device
+    bindable) and the answers are gathered; (2) rank 0 makes the communicator id (sk_comm_get_unique_id) and every rank gets
+    it over the rendezvous backend; (3) all join.  Should any rank fail at (1) or (2), ALL ranks learn of it BEFORE the
+    bootstrap and fall back together to a gloo sum with a host round trip — the JSON line then says so; a scaling run still
+    gets numbers.  A join that RAISES on some rank is reported to all the same way afterwards.  A rank whose join does not
+    return within `timeout_s` (the others may be gone) cannot be recovered in-process: it exits non-zero, and the launcher
+    ends the other ranks.  Returns None (RCCL) or the reason (gloo)."""
     err = None
-    try:
-        box = [make_unique_id() if rank == 0 else None]
-    except Exception as e:
-        box, err = [None], str(e)
-    dist.broadcast_object_list(box, src=0)
-    if box[0] is not None:
+    if ready is not None:
         try:
-            init_rank(box[0], rank, world)
+            ready()
         except Exception as e:
-            err = str(e)
-    else:
-        err = err or "rank 0 could not make a unique id"
+            err = f"rank {rank}: {e}"
     flags = [None] * world
     dist.all_gather_object(flags, err)
+    err = next((f for f in flags if f), None)
+    box = [None]
+    if err is None and rank == 0:
+        try:
+            box = [make_unique_id()]
+        except Exception as e:
+            box = [("error", str(e))]
+    dist.broadcast_object_list(box, src=0)
+    if err is None and isinstance(box[0], tuple):
+        err = box[0][1]
+    if err is not None:
+        return err
+    import threading
+    done = {}
+
+    def join():
+        try:
+            init_rank(box[0], rank, world)
+            done["ok"] = True
+        except Exception as e:
+            done["err"] = str(e)
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(timeout_s if timeout_s is not None else float(os.environ.get("SK_BENCH_RCCL_TIMEOUT", "300")))
+    if not done:
+        # still inside the bootstrap: the ranks it waits for are gone or stuck, and the call cannot be taken back in-process
+        sys.stderr.write(f"[bench] rank {rank}: joining the RCCL communicator did not return; this rank exits and the launcher ends the others\n")
+        sys.stderr.flush()
+        os._exit(3)
+    # every rank that gets here came OUT of the join (a rank that did not has exited, which ends the run): they tell each other
+    # how it went, and one failure (RCCL refusing the device set, say) sends all of them to the gloo sum together
+    flags = [None] * world
+    dist.all_gather_object(flags, done.get("err"))
     return next((f for f in flags if f), None)
+
+
+def require_backend(rccl_err):
+    """SK_BENCH_REQUIRE_RCCL=1: a run whose count reduce would go through gloo is an error (every rank holds the same rccl_err,
+    so all of them leave together)."""
+    if rccl_err is not None and os.environ.get("SK_BENCH_REQUIRE_RCCL") == "1":
+        raise SystemExit(f"SK_BENCH_REQUIRE_RCCL=1 and the count reduce would go through gloo ({rccl_err})")
+
+
+def reduce_report(distributed, rccl_err, rank_kernel_ms, rank_reduce_us):
+    """The keys of the JSON line that say where a step of an N > 1 run went: which backend summed the counters, what the sum
+    cost per step on the ctx stream (mean and slowest rank), and the spread of the ranks' own kernel times."""
+    return {"count_reduce_backend": "none" if not distributed else ("rccl" if rccl_err is None else "gloo"),
+            "allreduce_us": None if not distributed else round(sum(rank_reduce_us) / len(rank_reduce_us), 2),
+            "allreduce_us_max": None if not distributed else round(max(rank_reduce_us), 2),
+            "kernel_ms_ranks": {"min": round(min(rank_kernel_ms), 4), "max": round(max(rank_kernel_ms), 4)}}
+
+
+def device_identity(index):
+    """gpu_unique_id and the partition modes of the device the rank runs on, from rocm-smi (a separate process; nothing here
+    touches the GPU): what two boxes whose fused pass streams differently could differ in."""
+    out = {"gpu_unique_id": None, "memory_partition": None, "compute_partition": None}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showuniqueid", "--showmemorypartition", "--showcomputepartition", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30)
+        j = json.loads(r.stdout.decode() or "{}")
+        card = next(iter(j.values())) if j else {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "unique" in kl:
+                out["gpu_unique_id"] = v
+            elif "memory partition" in kl:
+                out["memory_partition"] = v
+            elif "compute partition" in kl:
+                out["compute_partition"] = v
+    except Exception as e:
+        out["error"] = str(e)[:200]
+    return out
 
 
 def main():
@@ -507,12 +611,20 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        rccl_err = join_count_reduce(dist, rank, world, capi.comm_unique_id, ctx.comm_init_rank)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:
+            if "address already in use" in str(e).lower() or "EADDRINUSE" in str(e):
+                sys.stderr.write(f"[bench] rank {rank}: rendezvous port {os.environ['MASTER_PORT']} is taken\n")
+                sys.stderr.flush()
+                os._exit(EXIT_PORT_TAKEN)
+            raise
+        rccl_err = join_count_reduce(dist, rank, world, capi.comm_unique_id, ctx.comm_init_rank, ready=ctx.comm_ready)
         if rccl_err is not None:
             sys.stderr.write(f"[bench] RCCL unavailable ({rccl_err}); the count reduce goes through gloo\n")
+            require_backend(rccl_err)
             try:
-                ctx.comm_destroy()
+                ctx.comm_destroy()                                # a communicator some ranks did get
             except Exception:
                 pass
 
@@ -607,6 +719,8 @@ def main():
                 h = counts.cpu()
                 dist.all_reduce(h)
                 counts.copy_(h)
+            if ev is not None:
+                ev[2].record(stream)
 
     def fence():
         if distributed:
@@ -616,7 +730,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
@@ -626,7 +740,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+    kern_ms = sum(e[0].elapsed_time(e[1]) for e in events) / max(args.steps, 1)
+    # the count reduce of a step on the ctx stream (RCCL: the collective itself, the kernel's end to the reduce's end; gloo:
+    # the host round trip), and every rank's own kernel time: what a reader of an N > 1 line needs to see where a step went
+    reduce_us = sum(e[1].elapsed_time(e[2]) for e in events) / max(args.steps, 1) * 1e3
+    rank_kernel_ms = [kern_ms]
+    rank_reduce_us = [reduce_us]
+    if distributed:
+        both = [None] * world
+        dist.all_gather_object(both, (kern_ms, reduce_us))
+        rank_kernel_ms, rank_reduce_us = [b[0] for b in both], [b[1] for b in both]
 
     # ---- size-independent checks on the full shard + bit-exact parity on a sample (oracle = checker only) -----
     total_counts = counts.cpu().numpy().astype(np.uint64)
@@ -711,10 +834,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("pairs") == n and tj.get("layout") == args.layout and tj.get("kernel_sources_sha256_16") == kernel_sources_digest():
+                if tj.get("pairs") == n and tj.get("layout") == args.layout and tj.get("library_inputs_sha256_16") == kernel_sources_digest():
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = {"file": "profiles/pmc_traffic.json", "how": "separate rocprofv3 --pmc passes of this build (FETCH_SIZE x 2 + WRITE_SIZE), not this run",
-                                      "kernel_sources_sha256_16": tj.get("kernel_sources_sha256_16")}
+                                      "library_inputs_sha256_16": tj.get("library_inputs_sha256_16")}
             except Exception:
                 traffic = traffic_source = None
         kernel = "sk::tile_blocked_kernel" if lay is not None else "sk::tile_pass_kernel"
@@ -743,10 +866,12 @@ def main():
                          "kernel": kernel, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},
+            **reduce_report(distributed, rccl_err, rank_kernel_ms, rank_reduce_us),
+            "device": device_identity(local_rank),
             "cpu_baseline": cpu_baseline,
             "parity_sample_ok": parity,
             "identified_frac": round(float(total_counts[S + 1]) / float(total_counts[S]), 4),
-            "library_sha256_16": library_digest(),
+            "library_sha256_16": library_digest(), "library_inputs_sha256_16": kernel_sources_digest(),
             "extra": extra,
         }
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

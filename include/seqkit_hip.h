@@ -219,6 +219,9 @@ void *sk_counts_device_ptr(sk_ctx *ctx);
  *    every rank (any side channel), every rank calls sk_comm_init_rank; afterwards sk_counts_allreduce(&ctx, 1) and
  *    sk_allreduce_u64_dev sum across the ranks, enqueued on the ctx stream (asynchronous; sk_sync waits).          */
 #define SK_COMM_ID_BYTES 128
+/* rank-local, talks to nobody: SK_OK when this ctx could join a communicator (librccl loadable, device bindable).
+ * sk_comm_init_rank blocks until every rank has called it, so hosts exchange these answers first and only then join. */
+int sk_comm_ready(sk_ctx *ctx);
 int sk_comm_get_unique_id(uint8_t id[SK_COMM_ID_BYTES]);
 int sk_comm_init_rank(sk_ctx *ctx, const uint8_t id[SK_COMM_ID_BYTES], int rank, int n_ranks);
 int sk_comm_destroy(sk_ctx *ctx);

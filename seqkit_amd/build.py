@@ -19,6 +19,21 @@ LIB_PATH = os.path.join(LIBDIR, "libseqkit_hip.so")
 
 HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_capi.hip", "sk_lut.cpp"]
 HIP_DEPS = HIP_SOURCES + ["sk_internal.h", "sk_lut.h", os.path.join(REPO, "include", "seqkit_hip.h")]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def library_inputs_digest() -> str:
+    """Digest of everything the library is built from: every source and header of HIP_DEPS and the compiler flags.  (The
+    built file itself is not reproducible bit for bit — hipcc's object and symbol order vary from run to run — so records
+    that must name "this build" name its inputs.)"""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(HIP_FLAGS).encode())
+    for d in HIP_DEPS:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def _hipcc() -> str:
@@ -50,8 +65,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> seqkit_amd/lib/libseqkit_hip.so (cross-compiles without a GPU)."""
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(LIB_PATH, HIP_DEPS):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + HIP_SOURCES + ["-ldl"]
+        cmd = [_hipcc()] + HIP_FLAGS + ["-o", LIB_PATH] + HIP_SOURCES + ["-ldl"]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         _run(cmd, CSRC)

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_blocked_layout_init", "sk_fused_pass_blocked_dev", "sk_fused_tune_placement_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
-    "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
+    "sk_comm_ready", "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
     "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get", "sk_gc_set_genome", "sk_gc_count",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
@@ -165,7 +165,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_fused_tune_placement_dev": (i32, [vp, C.POINTER(_FusedArgs), C.POINTER(_FusedCandidates), i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                               C.POINTER(i32)]),
         "sk_counts_reset": (i32, [vp]), "sk_counts_get": (i32, [vp, vp]), "sk_counts_device_ptr": (vp, [vp]),
-        "sk_comm_get_unique_id": (i32, [vp]), "sk_comm_init_rank": (i32, [vp, vp, i32, i32]), "sk_comm_destroy": (i32, [vp]),
+        "sk_comm_ready": (i32, [vp]), "sk_comm_get_unique_id": (i32, [vp]), "sk_comm_init_rank": (i32, [vp, vp, i32, i32]), "sk_comm_destroy": (i32, [vp]),
         "sk_counts_allreduce": (i32, [C.POINTER(vp), i32]), "sk_allreduce_u64_dev": (i32, [vp, vp, C.c_size_t]),
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
@@ -342,6 +342,10 @@ class Context:
         """One process per GPU: join the communicator whose 128-byte id rank 0 made with comm_unique_id()."""
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._lib.sk_comm_init_rank(self._h, buf, rank, n_ranks), "sk_comm_init_rank")
+
+    def comm_ready(self) -> None:
+        """Rank-local: raises unless this ctx could join an RCCL communicator (library loadable, device bindable)."""
+        self._check(self._lib.sk_comm_ready(self._h), "sk_comm_ready")
 
     def comm_destroy(self) -> None:
         self._check(self._lib.sk_comm_destroy(self._h), "sk_comm_destroy")

@@ -530,6 +530,15 @@ static int rccl_ready(sk_ctx *c)
 	return SK_OK;
 }
 
+// A rank-local check that needs no other rank: can this ctx take part in an RCCL communicator at all (library loadable,
+// device bindable)?  Hosts gather the answers of all ranks BEFORE any of them enters the blocking bootstrap.
+int sk_comm_ready(sk_ctx *c)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (int r = rccl_ready(c)) return r;
+	return bind(c);
+}
+
 int sk_comm_get_unique_id(uint8_t id[SK_COMM_ID_BYTES])
 {
 	static_assert(SK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from a tools/pmc_summary.py listing: HBM bytes per launch of the headline kernel, stamped with the
-digest of the kernel sources it was measured on (bench.py quotes the record only while that digest, the layout and the size match).
+digest of everything the library was built from (sources, headers, flags; bench.py quotes the record only while that, the layout and the size match).
 usage: make_pmc_traffic.py <pmc_summary.txt> <clusters> <layout> <kernel name prefix>"""
 import json
 import os
@@ -28,5 +28,5 @@ print(json.dumps({
     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "algorithmic_bytes_per_launch": bench.BYTES_PER_PAIR * pairs,
     "ratio_to_algorithmic": round((rd + wr) / (bench.BYTES_PER_PAIR * pairs), 4),
-    "kernel_sources_sha256_16": bench.kernel_sources_digest(),
+    "library_inputs_sha256_16": bench.kernel_sources_digest(),      # every source and header of the library + the compiler flags
     "source": "tools/profile_bench.sh -> tools/pmc_summary.py -> tools/make_pmc_traffic.py"}, indent=1))
