@@ -17,6 +17,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <algorithm>
+#include <atomic>
 #include <deque>
 #include <future>
 #include <memory>
@@ -549,11 +550,36 @@ struct Inflater {                      // libdeflate's decompressor, when the li
 
 struct BgzfStream::Impl {
 	struct Block {
-		std::vector<uint8_t> comp;         // the whole BGZF block as read
+		std::vector<uint8_t> comp;         // the whole BGZF block as read ...
+		const uint8_t *src = nullptr;      // ... or where it lies in the mapped file (comp stays empty)
+		size_t src_len = 0;
 		std::vector<uint8_t> data;         // inflated
 		size_t cdata_off = 0, cdata_len = 0;
 		bool done = false, bad = false;
+		// the block walked as BAM records from its first byte, by the worker that inflated it (bam_records)
+		std::vector<BamRec> recs;
+		size_t recs_end = 0;               // offset behind the last record that lies wholly inside the block
 	};
+	// The records that lie wholly inside p[start, len): their cores to `out`; returns the offset behind the last of them.
+	// Stops at a record that does not fit, and at a block_size that no record can have (the caller's slow path reports it).
+	static size_t walk_records(const uint8_t *p, size_t len, size_t start, std::vector<BamRec> &out)
+	{
+		auto le32 = [](const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+		size_t o = start;
+		while (o + 36 <= len) {
+			const uint32_t block_size = le32(p + o);
+			if (block_size < 32 || (size_t)block_size > len - o - 4) break;
+			const uint8_t *c = p + o + 4;
+			BamRec r;
+			r.tid = (int32_t)le32(c); r.pos = (int32_t)le32(c + 4);
+			r.l_read_name = c[8]; r.mapq = c[9];
+			r.flag = (uint16_t)(c[14] | (c[15] << 8));
+			r.mtid = (int32_t)le32(c + 20); r.mpos = (int32_t)le32(c + 24); r.tlen = (int32_t)le32(c + 28);
+			out.push_back(r);
+			o += 4 + (size_t)block_size;
+		}
+		return o;
+	}
 	int fd;
 	bool bgzf = false;                     // decided from the first block header
 	// ---- parallel path
@@ -653,6 +679,39 @@ struct BgzfStream::Impl {
 		cv_done.notify_all();
 		cv_work.notify_all();
 	}
+	// A regular file is mapped instead of read: the one reader thread then only walks the block headers (18 bytes per 64 KiB),
+	// and the compressed bytes are touched for the first time by the worker that inflates them — copying them out of the page
+	// cache on one thread was what a 256-core host's `sam statistics` waited for (3.6 GB: 0.7 s of its 1.2 s).
+	const uint8_t *map = nullptr;
+	size_t map_len = 0;
+	void reader_main_mapped()
+	{
+		size_t o = 0;
+		while (o < map_len) {
+			size_t xlen = 0;
+			const size_t left = map_len - o;
+			const size_t bsize = bgzf_block_size(map + o, left < 12 + 65535 ? left : 12 + 65535, xlen);
+			auto b = std::make_shared<Block>();
+			if (bsize == 0 || bsize < 12 + xlen + 8) {
+				// a cut-off header is the end of the data; anything else that is not a BGZF block is corrupt
+				const uint8_t *h = map + o;
+				const bool cut = left < 12 || (h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && left < 12 + (((size_t)h[10]) | ((size_t)h[11] << 8)));
+				if (!cut) { b->bad = true; b->done = true; push(b, false); }
+				break;
+			}
+			if (bsize > left) break;                         // file ends inside a block: the data end before it
+			b->src = map + o;
+			b->src_len = bsize;
+			b->cdata_off = 12 + xlen;
+			b->cdata_len = bsize - b->cdata_off - 8;
+			o += bsize;
+			if (!push(b, true)) return;
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		eof = true;
+		cv_done.notify_all();
+		cv_work.notify_all();
+	}
 	void fail_read()
 	{
 		std::lock_guard<std::mutex> lk(mu);
@@ -683,7 +742,9 @@ struct BgzfStream::Impl {
 				b = todo.front();
 				todo.pop_front();
 			}
-			const uint8_t *tail = b->comp.data() + b->comp.size() - 8;
+			const uint8_t *blk = b->src ? b->src : b->comp.data();
+			const size_t blk_len = b->src ? b->src_len : b->comp.size();
+			const uint8_t *tail = blk + blk_len - 8;
 			const uint32_t want_crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
 			const uint32_t isize = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
 			bool ok = isize <= (1u << 16);
@@ -693,14 +754,14 @@ struct BgzfStream::Impl {
 				b->data.resize(isize);
 				if (dec) {
 					size_t out_n = 0;
-					ok = ld.inflate(dec, b->comp.data() + b->cdata_off, b->cdata_len, b->data.data(), isize, &out_n) == 0 && out_n == isize;
+					ok = ld.inflate(dec, blk + b->cdata_off, b->cdata_len, b->data.data(), isize, &out_n) == 0 && out_n == isize;
 					if (ok) ok = ld.crc(0, b->data.data(), isize) == want_crc;
 				} else {
 					z_stream zs;
 					memset(&zs, 0, sizeof zs);
 					ok = inflateInit2(&zs, -15) == Z_OK;
 					if (ok) {
-						zs.next_in = b->comp.data() + b->cdata_off; zs.avail_in = (uInt)b->cdata_len;
+						zs.next_in = const_cast<uint8_t *>(blk) + b->cdata_off; zs.avail_in = (uInt)b->cdata_len;
 						zs.next_out = b->data.data(); zs.avail_out = isize;
 						const int rc = ::inflate(&zs, Z_FINISH);
 						ok = rc == Z_STREAM_END && zs.avail_out == 0;
@@ -710,6 +771,10 @@ struct BgzfStream::Impl {
 				}
 			}
 			std::vector<uint8_t>().swap(b->comp);
+			if (ok && want_records && b->data.size() >= 36) {      // while the block is in this core's cache
+				b->recs.reserve(b->data.size() / 128);
+				b->recs_end = walk_records(b->data.data(), b->data.size(), 0, b->recs);
+			}
 			std::lock_guard<std::mutex> lk(mu);
 			b->bad = !ok;
 			b->done = true;
@@ -718,6 +783,35 @@ struct BgzfStream::Impl {
 	}
 
 	bool failed = false;                   // corrupt data seen: what preceded it has been delivered, every later read is -1
+	std::atomic<bool> want_records{false}; // a BAM reader is attached: workers walk every block from its first byte
+
+	// make `cur` the block that holds the stream's position; false at the end of the data or at a corrupt block (nothing consumed)
+	bool have_block()
+	{
+		while (!cur || cur_off == cur->data.size()) {
+			std::unique_lock<std::mutex> lk(mu);
+			cv_done.wait(lk, [&] { return (!order.empty() && order.front()->done) || (order.empty() && eof); });
+			if (order.empty() || order.front()->bad) return false;
+			cur = order.front();
+			order.pop_front();
+			cur_off = 0;
+			cv_room.notify_one();
+		}
+		return true;
+	}
+	long bam_records(std::vector<BamRec> &out)
+	{
+		if (failed || !bgzf) return 0;
+		if (!have_block()) return 0;                         // the end, or corrupt data: read() says which
+		const size_t before = out.size();
+		if (cur_off == 0 && cur->recs_end > 0) {                 // walked by the thread that inflated it
+			out.insert(out.end(), cur->recs.begin(), cur->recs.end());
+			cur_off = cur->recs_end;
+		} else {
+			cur_off = walk_records(cur->data.data(), cur->data.size(), cur_off, out);
+		}
+		return (long)(out.size() - before);
+	}
 
 	long read_parallel(uint8_t *dst, size_t n)
 	{
@@ -770,21 +864,33 @@ struct BgzfStream::Impl {
 	}
 };
 
-BgzfStream::BgzfStream(int fd) : impl_(new Impl())
+BgzfStream::BgzfStream(int fd, bool bam) : impl_(new Impl())
 {
 	Impl &m = *impl_;
 	m.fd = fd;
+	m.want_records = bam;
 	m.head.clear();
-	Impl::read_header(fd, m.head);
 	size_t xlen = 0;
-	m.bgzf = Impl::bgzf_block_size(m.head.data(), m.head.size(), xlen) != 0;
+	struct stat st;
+	if (!getenv("SEQKIT_NO_MMAP") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 28) {
+		void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (mp != MAP_FAILED) {
+			const uint8_t *h = static_cast<const uint8_t *>(mp);
+			const size_t hl = (size_t)st.st_size < 12 + 65535 ? (size_t)st.st_size : 12 + 65535;
+			if (Impl::bgzf_block_size(h, hl, xlen) != 0) { m.map = h; m.map_len = (size_t)st.st_size; (void)madvise(mp, m.map_len, MADV_SEQUENTIAL); }
+			else munmap(mp, (size_t)st.st_size);             // gzip that is not BGZF, or no gzip at all: the descriptor is still at its start
+		}
+	}
+	if (!m.map) Impl::read_header(fd, m.head);
+	m.bgzf = m.map || Impl::bgzf_block_size(m.head.data(), m.head.size(), xlen) != 0;
 	if (m.bgzf) {
 		unsigned n = cpu_budget();
 		if (const char *e = getenv("SEQKIT_THREADS")) n = (unsigned)atoi(e);
 		if (n < 1) n = 1;
-		if (n > 32) n = 32;
+		if (n > 64) n = 64;
 		m.max_in_flight = (size_t)n * 16;
-		m.reader = std::thread([&m] { m.reader_main(); });
+		if (m.map) m.reader = std::thread([&m] { m.reader_main_mapped(); });
+		else m.reader = std::thread([&m] { m.reader_main(); });
 		for (unsigned i = 0; i < n; i++) m.workers.emplace_back([&m] { m.worker_main(); });
 	} else {
 		memset(&m.z, 0, sizeof m.z);
@@ -810,6 +916,7 @@ BgzfStream::~BgzfStream()
 	} else {
 		inflateEnd(&m.z);
 	}
+	if (m.map) munmap(const_cast<uint8_t *>(m.map), m.map_len);
 	if (m.fd > 0) ::close(m.fd);
 	delete impl_;
 }
@@ -817,6 +924,11 @@ BgzfStream::~BgzfStream()
 long BgzfStream::read(void *dst, size_t n)
 {
 	return impl_->bgzf ? impl_->read_parallel(static_cast<uint8_t *>(dst), n) : impl_->read_plain(static_cast<uint8_t *>(dst), n);
+}
+
+long BgzfStream::bam_records(std::vector<BamRec> &out)
+{
+	return impl_->bam_records(out);
 }
 
 long BgzfStream::skip(size_t n)

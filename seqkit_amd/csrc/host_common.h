@@ -98,12 +98,21 @@ private:
 // when the data are corrupt.
 class BgzfStream {
 public:
-	explicit BgzfStream(int fd);                         // takes the descriptor
+	explicit BgzfStream(int fd, bool bam = false);       // takes the descriptor; bam: the blocks are walked as BAM records while they are inflated (bam_records)
 	~BgzfStream();
 	BgzfStream(const BgzfStream &) = delete;
 	BgzfStream &operator=(const BgzfStream &) = delete;
 	long read(void *dst, size_t n);
 	long skip(size_t n);                                 // read() without a destination: same return values, no copy of what is skipped
+	// BAM records without a call per record (src/common.rs:121-157 reads them one by one through htslib).  The fixed core
+	// of every record that lies wholly inside the current inflated block — from the stream's position on — is appended to
+	// `out` and the position moves behind the last of them; 0 = the record at the position does not (it straddles a block,
+	// the data end, or its block_size is invalid: read()/skip() deal with that one record and say which).  The walk of a
+	// block that BEGINS with a record (htslib flushes a block rather than split a record, so in files it wrote every block
+	// does) has been done by the worker thread that inflated it, while the block was in that core's cache; other blocks are
+	// walked here.
+	struct BamRec { int32_t tid, pos, mtid, mpos, tlen; uint16_t flag; uint8_t mapq, l_read_name; };
+	long bam_records(std::vector<BamRec> &out);
 	struct Impl;
 private:
 	Impl *impl_;

@@ -55,7 +55,7 @@ public:
 		int fd = 0;
 		if (path != "-") fd = open(path.c_str(), O_RDONLY);
 		if (fd < 0) error("Cannot open BAM file '%s'", path.c_str());
-		bz_.reset(new host::BgzfStream(fd));
+		bz_.reset(new host::BgzfStream(fd, true));
 		uint8_t h[8];
 		if (!get(h, 8) || memcmp(h, "BAM\1", 4) != 0) open_fail();
 		if (!skip(le32(h + 4))) open_fail();
@@ -114,6 +114,30 @@ public:
 			c.end_pos = (int32_t)e;
 		}
 		return skip(rest);
+	}
+	// The next records, one call for many: every record that lies wholly inside the current inflated block (walked by the
+	// thread that inflated it, host::BgzfStream::bam_records), or — a record that straddles blocks, the end of the data, an
+	// invalid record, or want_end — one record by next().  false as next(): the stream has ended or failed.
+	bool next_chunk(std::vector<BamCore> &out, bool want_end)
+	{
+		out.clear();
+		if (!err_.empty()) return false;
+		if (!want_end) {
+			recs_.clear();
+			if (bz_->bam_records(recs_) > 0) {
+				out.resize(recs_.size());
+				for (size_t i = 0; i < recs_.size(); i++) {
+					const host::BgzfStream::BamRec &r = recs_[i];
+					BamCore &c = out[i];
+					c.tid = r.tid; c.pos = r.pos; c.flag = r.flag; c.mtid = r.mtid; c.mpos = r.mpos; c.tlen = r.tlen; c.end_pos = r.pos; c.mapq = r.mapq;
+				}
+				return true;
+			}
+		}
+		BamCore c;
+		if (!next(c, want_end)) return false;
+		out.push_back(c);
+		return true;
 	}
 	// next record with its variable part (qname, cigar, packed bases, qualities, aux) in `body`
 	struct Var { uint32_t l_read_name, n_cigar, l_seq; };
@@ -196,6 +220,7 @@ private:
 	std::string path_;
 	std::unique_ptr<host::BgzfStream> bz_;
 	std::vector<uint8_t> var_;
+	std::vector<host::BgzfStream::BamRec> recs_;
 };
 
 static const size_t kBatch = 4u << 20;
@@ -262,11 +287,12 @@ static int statistics(int argc, char **argv)
 	uint64_t counters[3] = {0, 0, 0};
 	uint64_t total_fragments = 0, on_target_fragments = 0;
 	Columns col;
-	BamCore c;
+	std::vector<BamCore> chunk;
 	bool more = true;
 	while (more) {
 		col.clear();
-		while (col.flag.size() < kBatch && (more = bam.next(c, on_target))) col.push(c, on_target);
+		while (col.flag.size() < kBatch && (more = bam.next_chunk(chunk, on_target)))
+			for (const BamCore &c : chunk) col.push(c, on_target);
 		const int64_t n = (int64_t)col.flag.size();
 		if (n == 0) break;
 		// S1 on the device: src/sam_statistics.rs:63-69
@@ -341,11 +367,12 @@ static int fragment_lengths(int argc, char **argv)
 	host::gpu_warmup();
 	BamStream bam(pos[0]);                                                                            // :30
 	Columns col;
-	BamCore c;
+	std::vector<BamCore> chunk;
 	bool more = true, stopped = false;
 	while (more && !stopped) {
 		col.clear();
-		while (col.flag.size() < kBatch && (more = bam.next(c, false))) col.push(c, false);
+		while (col.flag.size() < kBatch && (more = bam.next_chunk(chunk, false)))
+			for (const BamCore &c : chunk) col.push(c, false);
 		const int64_t n = (int64_t)col.flag.size();
 		if (n == 0) break;
 		// H1 on the device: src/sam_fragment_lengths.rs:29-43
@@ -403,13 +430,14 @@ static int fragments(int argc, char **argv)                        // src/sam_fr
 	host::gpu_warmup();
 	BamStream bam(pos[0]);
 	Columns col;
-	BamCore c;
+	std::vector<BamCore> chunk;
 	bool more = true;
 	std::vector<uint8_t> bits;
 	char buf[128];
 	while (more) {
 		col.clear();
-		while (col.flag.size() < kBatch && (more = bam.next(c, false))) col.push(c, true);
+		while (col.flag.size() < kBatch && (more = bam.next_chunk(chunk, false)))
+			for (const BamCore &c : chunk) col.push(c, true);
 		const int64_t n = (int64_t)col.flag.size();
 		if (n == 0) break;
 		bits.assign((size_t)(n + 7) / 8, 0);
@@ -503,25 +531,27 @@ static int count(int argc, char **argv)                            // src/sam_co
 	int64_t prev_pos = 0;
 	Columns col;
 	std::vector<uint8_t> mapq;
-	BamCore c;
+	std::vector<BamCore> chunk;
 	bool more = true;
 	const char *stop = nullptr;                      // an order-dependent error met while reading: raised after the records before it
 	int stop_code = 255;
 	while (more && !stop) {
 		col.clear(); mapq.clear();
-		while (col.flag.size() < kBatch && (more = bam.next(c, single_end))) {
-			// :46-49 and the order checks :52-73 stay here: they depend on the records before
-			if (!((c.flag & 0x4) || (c.flag & 0x400) || (c.flag & 0x100) || (c.flag & 0x800) || c.mapq < min_mapq)) {
-				if (c.tid != prev_chr) {
-					prev_chr = c.tid;
-					if (c.tid < 0 || (size_t)c.tid >= bam.names.size()) { stop = "index out of bounds: chr_names[tid]"; stop_code = 101; break; }
-				} else if ((int64_t)c.pos < prev_pos) {
-					stop = "Input BAM file is not coordinate sorted."; break;                                              // :70-72
+		while (col.flag.size() < kBatch && !stop && (more = bam.next_chunk(chunk, single_end))) {
+			for (const BamCore &c : chunk) {
+				// :46-49 and the order checks :52-73 stay here: they depend on the records before
+				if (!((c.flag & 0x4) || (c.flag & 0x400) || (c.flag & 0x100) || (c.flag & 0x800) || c.mapq < min_mapq)) {
+					if (c.tid != prev_chr) {
+						prev_chr = c.tid;
+						if (c.tid < 0 || (size_t)c.tid >= bam.names.size()) { stop = "index out of bounds: chr_names[tid]"; stop_code = 101; break; }
+					} else if ((int64_t)c.pos < prev_pos) {
+						stop = "Input BAM file is not coordinate sorted."; break;                                              // :70-72
+					}
+					prev_pos = c.pos;
 				}
-				prev_pos = c.pos;
+				col.push(c, true);
+				mapq.push_back(c.mapq);
 			}
-			col.push(c, true);
-			mapq.push_back(c.mapq);
 		}
 		const int64_t n = (int64_t)col.flag.size();
 		if (n == 0) continue;

@@ -335,26 +335,29 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
 	// minimum and one maximum, and the step's bookkeeping (who is alive, who stops, is anybody left) is paid once per
 	// eight bytes — it is about as many instructions as the arithmetic of four bytes.
+	// The loop is what a pass over long scans is bound by (VALU busy 70 % of the time, rocprofv3: profiles/), so it keeps
+	// nothing it can get back later: a lane that stops only remembers in which step — its running sum simply stays what it
+	// was before that step, and the step's two dwords are read again after the loop.
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
 	int a = end & ~3;
 	u32 hi = *reinterpret_cast<const u32 *>(tile + a);
 	u32 T = 0;
 	int best = 0;
-	bool alive = active;
-	int stop_jj = -1;                                         // the 8-byte step this lane stopped in (-1: none yet)
-	u32 stop_T = 0, stop_d1 = 0, stop_d0 = 0;                 // running sum before that step, and its two dwords
+	int whole_steps = active ? 0 : -1;                        // steps this lane got through whole: the index of the step it stops in (idle lanes: never alive)
 	const int nst = (maxlen + 7) >> 3;
 	const int step = 1 - m * (1 << kKeyBits);                 // C_j = j - j*m*2^11 = j * step
 	unsigned long long strag = 0ull;                          // rows handed to trim_finish_stragglers, and the bytes they have consumed
 	int strag_j0 = 0;
+	auto min3 = [](int x, int y, int z) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
+	auto max3 = [](int x, int y, int z) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
 	for (int jj = 0; jj < nst; jj++) {
-		a = max(a - 8, -8);                                   // rows shorter than the scan stay inside the front pad
+		a -= 8;
+		if (!UNIFORM_LEN) a = max(a, -8);                     // rows shorter than the scan stay inside the front pad (full rows end 2 bytes into it)
 		const u32 lo1 = *reinterpret_cast<const u32 *>(tile + a + 4), lo0 = *reinterpret_cast<const u32 *>(tile + a);
 		const u32 d1 = __builtin_amdgcn_alignbyte(hi, lo1, sh);   // bytes [end-8jj-4, end-8jj) of the image: scanned first
 		const u32 d0 = __builtin_amdgcn_alignbyte(lo1, lo0, sh);  // bytes [end-8jj-8, end-8jj-4)
 		hi = lo0;
-		const u32 T0 = T;
 		u32 Ts[8];
 		Ts[0] = __builtin_amdgcn_udot4(d1, 0x01000000u, T, false);
 		Ts[1] = __builtin_amdgcn_udot4(d1, 0x01010000u, T, false);
@@ -364,32 +367,34 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 		Ts[5] = __builtin_amdgcn_udot4(d0, 0x01010000u, Ts[3], false);
 		Ts[6] = __builtin_amdgcn_udot4(d0, 0x01010100u, Ts[3], false);
 		Ts[7] = __builtin_amdgcn_udot4(d0, 0x01010101u, Ts[3], false);
-		T = Ts[7];
 		const int c0 = (8 * jj + 1) * step;                   // scalar
 		int K[8];
 #pragma unroll
 		for (int i = 0; i < 8; i++) K[i] = (int)(Ts[i] << kKeyBits) + (c0 + i * step);
-		const int kmin = min(min(min(K[0], K[1]), min(K[2], K[3])), min(min(K[4], K[5]), min(K[6], K[7])));
-		const int kmax = max(max(max(K[0], K[1]), max(K[2], K[3])), max(max(K[4], K[5]), max(K[6], K[7])));
-		bool whole = kmax < kBreakKey;                        // no byte of this step breaks
-		if (UNIFORM_LEN) whole = whole && (8 * jj + 8 <= maxlen);     // scalar: false only in the row's last, partial step
-		else whole = whole && (8 * jj + 8 <= len);
-		const bool stops = alive && !whole;
-		stop_jj = stops ? jj : stop_jj;
-		stop_T = stops ? T0 : stop_T;
-		stop_d1 = stops ? d1 : stop_d1;
-		stop_d0 = stops ? d0 : stop_d0;
-		alive = alive && whole;
-		best = alive ? min(best, kmin) : best;
-		const unsigned long long left = __ballot(alive);
+		const int kmax = max3(max3(K[0], K[1], K[2]), max3(K[3], K[4], K[5]), max(K[6], K[7]));
+		const int kmin = min3(min3(K[0], K[1], K[2]), min3(K[3], K[4], K[5]), min3(K[6], K[7], best));
+		// alive = got through every step so far whole, carried as the COUNT of whole steps (a register): the masks of a step are
+		// then ballots of fresh compares, their AND is scalar work, and the three updates take the mask as it is
+		unsigned long long left = __builtin_amdgcn_ballot_w64(kmax < kBreakKey) & __builtin_amdgcn_ballot_w64(whole_steps == jj);      // no byte of this step breaks
+		if (UNIFORM_LEN) left = (8 * jj + 8 <= maxlen) ? left : 0ull;     // scalar: false only in the row's last, partial step
+		else left &= __builtin_amdgcn_ballot_w64(8 * jj + 8 <= len);
+		asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(whole_steps) : "s"(left) : "vcc");
+		asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(T) : "v"(Ts[7]), "s"(left));        // a stopped lane keeps the sum from before its stop step
+		asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(best) : "v"(kmin), "s"(left));
 		if (left == 0ull) break;
 		// few rows left and they are past where reads usually break: leave the loop, the whole wave finishes each of them
 		// (and only while enough of the row is left for the hand-over to pay: it costs about as much as a few steps)
-		if (jj >= kStragglerFrom && jj + kStragglerLeft < nst && __popcll(left) <= kStragglerRows) { strag = left; strag_j0 = 8 * (jj + 1); break; }
+		if (jj >= kStragglerFrom && jj + kStragglerLeft < nst && (int)__builtin_popcountll(left) <= kStragglerRows) { strag = left; strag_j0 = 8 * (jj + 1); break; }
 	}
+	const int stop_jj = (active && whole_steps < nst && !((strag >> (threadIdx.x & (kWave - 1))) & 1ull)) ? whole_steps : -1;      // stopped in a step (not: scanned to the end, or handed over)
 	if (strag) trim_finish_stragglers(tile, strag, strag_j0, step, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
 	if (stop_jj >= 0) {                                       // replay the stop step: src/fasta_trim_by_quality.rs:33-41 byte by byte
-		u32 t = stop_T;
+		int qa = (end & ~3) - 8 * (stop_jj + 1);
+		if (!UNIFORM_LEN) qa = max(qa, -8);
+		const uint8_t *q = tile + qa;
+		const u32 h2 = *reinterpret_cast<const u32 *>(q + 8), l1 = *reinterpret_cast<const u32 *>(q + 4), l0 = *reinterpret_cast<const u32 *>(q);
+		const u32 stop_d1 = __builtin_amdgcn_alignbyte(h2, l1, sh), stop_d0 = __builtin_amdgcn_alignbyte(l1, l0, sh);
+		u32 t = T;
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			const int j = 8 * stop_jj + i + 1;

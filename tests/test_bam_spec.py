@@ -131,3 +131,84 @@ def test_bgzf_stream_walks_blocks_with_other_extra_subfields(hip_lib, tmp_path):
     first_len = struct.unpack_from("<H", data, 12 + 7 + 4)[0] + 1          # BSIZE of block 0 (behind the 7-byte XY subfield)
     cut.write_bytes(data[:first_len + 15])                               # block 1 cut inside its extra field
     assert run(cut) == (0, blocks[0])
+
+
+def test_bam_records_by_block_equal_the_record_by_record_walk(hip_lib, tmp_path):
+    """host::BgzfStream::bam_records (ASan + UBSan build): the cores of the records that lie wholly inside a block, walked by
+    the thread that inflated it when the block begins with a record, with read()/skip() for the records it leaves — against the
+    same stream read record by record, and against the spec decoder: blocks that end on record boundaries (what htslib
+    writes), blocks cut anywhere (records and even the 36-byte heads straddle), a record larger than a block, an invalid
+    block_size in the middle, a file cut inside a record, a corrupt block; one worker thread and several."""
+    from tests.test_cli_cpu import _build_cpp
+    exe = _build_cpp(tmp_path, "bgzf_stream_test")
+    rng = np.random.default_rng(21)
+    recs = []
+    for i in range(6000):
+        l_seq = int(rng.choice([0, 1, 36, 151, 400]))
+        recs.append({"tid": int(rng.integers(-1, 3)), "pos": int(rng.integers(0, 1 << 28)), "flag": int(rng.integers(0, 4096)), "mtid": int(rng.integers(-1, 3)),
+                     "mpos": int(rng.integers(0, 1 << 28)), "tlen": int(rng.integers(-6000, 6000)), "name": "r%d" % i * int(rng.integers(1, 4)),
+                     "mapq": int(rng.integers(0, 61)), "seq_len": l_seq})
+    recs[3000]["seq_len"] = 70_000                                     # larger than a BGZF block
+    hdr = b"BAM\1" + struct.pack("<i", 4) + b"@HD\n" + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1 << 28)
+
+    def rec_bytes(r):
+        name = r["name"].encode() + b"\0"
+        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r["mapq"], 4680, 1, r["flag"], r["seq_len"], r["mtid"], r["mpos"], r["tlen"])
+        body += name + struct.pack("<I", (r["seq_len"] << 4)) + bytes((r["seq_len"] + 1) // 2) + bytes([30] * r["seq_len"])
+        return struct.pack("<i", len(body)) + body
+    rb = [rec_bytes(r) for r in recs]
+    expect = [f'{r["tid"]} {r["pos"]} {r["flag"]} {r["mtid"]} {r["mpos"]} {r["tlen"]} {r["mapq"]} {len(r["name"]) + 1}' for r in recs]
+
+    def aligned_blocks(chunks):                                            # htslib's bgzf_flush_try: a block is flushed rather than a record split
+        out, cur = [], b""
+        for c in chunks:
+            if cur and len(cur) + len(c) > 0xff00:
+                out.append(cur); cur = b""
+            cur += c
+            while len(cur) > 0xff00:                                       # a record larger than a block does get split
+                out.append(cur[:0xff00]); cur = cur[0xff00:]
+        if cur:
+            out.append(cur)
+        return out
+
+    def run(path, *mode, env=None):
+        r = subprocess.run([str(exe), str(path), "records", str(len(hdr)), *mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env=dict(os.environ, **(env or {})))
+        return r.returncode, r.stdout.decode().splitlines(), r.stderr.decode()
+
+    f = tmp_path / "r.bam"
+    # 1. blocks on record boundaries: (nearly) every record comes through bam_records
+    f.write_bytes(cu.bgzf_block(hdr) + b"".join(cu.bgzf_block(b) for b in aligned_blocks(rb)) + cu.bgzf_block(b""))
+    for env in ({}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_NO_MMAP": "1"}):
+        rc, lines, err = run(f, env=env)
+        assert rc == 0 and lines == expect + ["end: clean after 6000 records"], err
+        assert int(err.split(",")[1].split()[0]) >= 5990, err              # all but the giant record and its neighbours
+    assert run(f, "slow")[1] == lines
+    # 2. blocks cut anywhere, also inside the header block: the same records
+    raw = hdr + b"".join(rb)
+    for cut in (60000, 4093, 65280):
+        f.write_bytes(b"".join(cu.bgzf_block(raw[i:i + cut]) for i in range(0, len(raw), cut)) + cu.bgzf_block(b""))
+        rc, lines, err = run(f)
+        assert rc == 0 and lines == expect + ["end: clean after 6000 records"], (cut, err)
+    # 3. an invalid block_size in the middle of a block: the records before it, then the error — both ways alike
+    bad = list(rb)
+    bad[2500] = struct.pack("<i", 31) + bad[2500][4:]
+    f.write_bytes(cu.bgzf_block(hdr) + b"".join(cu.bgzf_block(b) for b in aligned_blocks(bad)) + cu.bgzf_block(b""))
+    rc, lines, _ = run(f)
+    assert rc == 5 and lines == expect[:2500] + ["end: invalid record after 2500 records"]
+    assert run(f, "slow")[:2] == (rc, lines)
+    # 4. the file cut inside a record
+    recs[1000]["seq_len"] = 151
+    whole = cu.bgzf_block(hdr) + b"".join(cu.bgzf_block(b) for b in aligned_blocks(rb[:1000] + [rec_bytes(recs[1000])[:50]]))
+    f.write_bytes(whole)
+    rc, lines, _ = run(f)
+    assert rc == 4 and lines == expect[:1000] + ["end: premature after 1000 records"]
+    assert run(f, "slow")[:2] == (rc, lines)
+    # 5. a corrupt block: what precedes it is delivered, then the stream says so
+    blocks = [cu.bgzf_block(hdr)] + [cu.bgzf_block(b) for b in aligned_blocks(rb)]
+    k = 5
+    broken = bytearray(blocks[k]); broken[30] ^= 0x5a
+    f.write_bytes(b"".join(blocks[:k]) + bytes(broken) + b"".join(blocks[k + 1:]))
+    rc, lines, _ = run(f)
+    rc2, lines2, _ = run(f, "slow")
+    assert rc == 3 and (rc2, lines2) == (rc, lines) and lines[-1].startswith("end: invalid after") and lines[:-1] == expect[:len(lines) - 1]

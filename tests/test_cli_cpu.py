@@ -276,7 +276,7 @@ def test_bgzf_stream_parallel_inflate_unit(tmp_path):
         return r.returncode, r.stdout
 
     f.write_bytes(b"".join(blocks))
-    for env in ({}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_THREADS": "3"}):
+    for env in ({}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_THREADS": "3"}, {"SEQKIT_NO_MMAP": "1"}):      # mapped file / read through the descriptor
         assert run(env) == (0, raw)
     whole = b"".join(blocks)
     cut = len(b"".join(blocks[:20])) + 100                                  # inside block 20
@@ -289,8 +289,9 @@ def test_bgzf_stream_parallel_inflate_unit(tmp_path):
     f.write_bytes(bytes(bad))
     rc, out = run()
     assert rc == 3 and out == raw[:10 * 60000]
-    rc, out = run({"SEQKIT_NO_LIBDEFLATE": "1"})
-    assert rc == 3 and out == raw[:10 * 60000]
+    for env in ({"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_NO_MMAP": "1"}):
+        rc, out = run(env)
+        assert rc == 3 and out == raw[:10 * 60000]
     f.write_bytes(gzip.compress(raw[:500_000]) + gzip.compress(raw[500_000:700_000]))    # gzip members without the BGZF field
     assert run() == (0, raw[:700_000])
     f.write_bytes(b"")

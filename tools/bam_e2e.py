@@ -32,6 +32,7 @@ def bgzf(data, level=1):
 
 
 unit = bytearray()
+ends = []                                # where records end inside the unit
 for i in range(50_000):
     tl = int(rng.lognormal(np.log(170), 0.35))
     for mate in (0, 1):
@@ -42,8 +43,19 @@ for i in range(50_000):
         flag = 1 | 2 | (64 | 32 if mate == 0 else 128 | 16)
         body = struct.pack("<iiBBHHHiiii", 0, i, len(name), 60, 4680, 1, flag, 150, 0, i + (tl if mate == 0 else -tl), tl if mate == 0 else -tl) + name + struct.pack("<I", 150 << 4) + packed + q
         unit += struct.pack("<i", len(body)) + body
+        ends.append(len(unit))
 unit = bytes(unit)
-blocks = [bgzf(unit[o:o + 60000]) for o in range(0, len(unit), 60000)]       # the unit as whole BGZF blocks (records may straddle them)
+if os.environ.get("BAM_STRADDLE"):
+    blocks = [bgzf(unit[o:o + 60000]) for o in range(0, len(unit), 60000)]   # blocks cut anywhere: records (and their heads) straddle them
+else:
+    # what htslib writes (bgzf_flush_try): a block is flushed rather than a record split, so every block begins with a record
+    blocks, lo, prev = [], 0, 0
+    for e in ends:
+        if e - lo > 0xff00:
+            blocks.append(bgzf(unit[lo:prev]))
+            lo = prev
+        prev = e
+    blocks.append(bgzf(unit[lo:]))
 t0 = time.perf_counter()
 with open(bam, "wb") as f:
     text = b"@HD\tVN:1.6\n"
@@ -62,5 +74,8 @@ for label, binary in (("hip", SAM),) if os.environ.get("E2E_NO_ORACLE") else (("
         r = subprocess.run([binary] + cmd, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("E2E_STDERR") else subprocess.DEVNULL)
         dt = time.perf_counter() - t0
         print(f"{'sam ' + ' '.join(cmd[:-1]):26s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:7.2f} M records/s  rc={r.returncode}", flush=True)
-os.remove(bam)
+if os.environ.get("BAM_KEEP"):
+    os.replace(bam, os.environ["BAM_KEEP"])          # for tools/bam_scale.sh
+else:
+    os.remove(bam)
 os.rmdir(d)
