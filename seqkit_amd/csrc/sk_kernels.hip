@@ -2035,72 +2035,20 @@ __device__ __forceinline__ u32 spread_nibbles(u32 h)
 	return (x | (x << 4)) & 0x0F0F0F0Fu;
 }
 
-// Both strands run the same instructions.  Output bytes 4j..4j+3 of a row come from source positions s0..s0+3 with
-// s0 = 4j read forwards (stored order, :47-57) or s0 = len-4-4j read backwards (reverse complement, :36-46).  The four
-// quality bytes and the four base codes starting at s0 are fetched as aligned dwords through per-tile buffer
-// descriptors and funnel-shifted into place, and a byte permute whose selector depends on the strand puts them in
-// output order.  Where s0 < 0 (the last, partial dword of a reverse row) or s0 + 3 >= len, the bytes that fall outside
-// the read land in output positions >= len, which are unspecified; a dword that would start before the row is replaced
-// by the row's first one (the offset register must not go negative: the hardware range check adds the instruction's
-// immediate to it without wrapping), and what lies past the tile reads as 0.
-// (A 16-bytes-per-thread variant was measured and dropped: fewer VALU per byte, but its 16-byte lane pitch quarters
-// the coalescing of the dword loads and stores — 1.98 ms against 1.8 ms for 16 M x 150 bases.)
-template <bool SMALL_M>
-__global__ __launch_bounds__(256) void bam_sequence_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
-                                                           int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
-                                                           int64_t n, u32 m4, u32 inv_dpr, uint8_t *__restrict__ out)
-{
-	__shared__ u32 row_info[64];                                   // len | reverse << 16
-	const int dpr = stride >> 2;
-	const int64_t ntiles = (n + 63) / 64;
-	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-		const int64_t row0 = t * 64;
-		const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
-		__syncthreads();
-		if ((int)threadIdx.x < rows) {
-			const int64_t r = row0 + threadIdx.x;
-			const u32 l = len ? (u32)len[r] : (u32)stride;
-			row_info[threadIdx.x] = l | (((u32)flag[r] >> 4) & 1u) << 16;
-		}
-		__syncthreads();
-		const rsrc_t rq = make_rsrc(qual, row0 * (int64_t)stride, rows * stride);
-		const rsrc_t rs = make_rsrc(seq4, row0 * (int64_t)seq4_stride, rows * seq4_stride);
-		const rsrc_t ro = make_rsrc(out, row0 * (int64_t)stride, rows * stride);
-		const u32 total = (u32)rows * (u32)dpr;
-		for (u32 e = threadIdx.x; e < total; e += blockDim.x) {
-			const u32 rl = inv_dpr ? __umulhi(e, inv_dpr) : e / (u32)dpr;
-			const int j = (int)(e - rl * (u32)dpr);
-			const u32 info = row_info[rl];
-			const int l = (int)(info & 0xFFFFu);
-			const bool rev = (info >> 16) != 0u;
-			int s0 = rev ? l - 4 - 4 * j : 4 * j;
-			if (s0 < -4) s0 = -4;                                  // every byte of this dword is past the read already
-			// qualities s0..s0+3, then output order
-			const int qrow = (int)rl * stride, qd = s0 >> 2;
-			const u32 q0 = __builtin_amdgcn_raw_buffer_load_b32(rq, qrow + 4 * (qd < 0 ? 0 : qd), 0, 0);
-			const u32 q1 = __builtin_amdgcn_raw_buffer_load_b32(rq, qrow + 4 * (qd + 1), 0, 0);
-			const u32 q = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(q1, q0, (u32)s0 & 3u), rev ? 0x00010203u : 0x03020100u);
-			// base codes s0..s0+3: bytes a, a+1, a+2 of the packed row as one big-endian number hold codes 2a..2a+5
-			const int a = s0 >> 1;
-			const int srow = (int)rl * seq4_stride, sd = a >> 2;
-			const u32 d0 = __builtin_amdgcn_raw_buffer_load_b32(rs, srow + 4 * (sd < 0 ? 0 : sd), 0, 0);
-			const u32 d1 = __builtin_amdgcn_raw_buffer_load_b32(rs, srow + 4 * (sd + 1), 0, 0);
-			const u32 w = __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, (u32)a & 3u)) >> 8;
-			const u32 back = spread_nibbles((w >> (8 - 4 * (s0 & 1))) & 0xFFFFu);       // byte b = code at position s0+3-b
-			const u32 nib = __builtin_amdgcn_perm(0u, back, rev ? 0x03020100u : 0x00010203u);
-			const u32 bases = bases_from_codes(nib, rev);
-			const u32 low = bytes_below<SMALL_M>(q, m4);
-			__builtin_amdgcn_raw_buffer_store_b32((kN4 & low) | (bases & ~low), ro, (int)rl * stride + 4 * j, 0, 0);
-		}
-	}
-}
-
-// The same with EIGHT output bytes per thread, for rows whose pitch is a multiple of 8: the per-element bookkeeping (row
-// and column from the element index, row info, source position) is paid once per 8 bytes, and there are four memory
-// instructions per 8 bytes instead of ten — two- and one-dword loads of the qualities (three dwords cover any 8 bytes),
-// one two-dword load of the packed bases (8 bytes from the dword that holds the first code cover any 8 codes), one
-// two-dword store; with two-dword accesses a wave instruction still covers one contiguous 512 bytes on the forward
-// strand.  Source positions s0..s0+7 with s0 = 8j (forward) or len-8-8j (reverse); everything else as above.
+// Both strands run the same instructions.  EIGHT output bytes per thread: output bytes 8j..8j+7 of a row come from source
+// positions s0..s0+7 with s0 = 8j read forwards (stored order, :47-57) or s0 = len-8-8j read backwards (reverse
+// complement, :36-46).  The qualities and the base codes from s0 on are fetched as aligned dwords through per-tile buffer
+// descriptors — two- and one-dword loads of the qualities (three dwords cover any 8 bytes), one two-dword load of the
+// packed bases (8 bytes from the dword that holds the first code cover any 8 codes) — and funnel-shifted into place; a
+// byte permute whose selector depends on the strand puts them in output order; one two-dword store.  Where s0 < 0 (the
+// last, partial unit of a reverse row) or s0 + 7 >= len, the bytes that fall outside the read land in output positions
+// >= len, which are unspecified; a dword that would start before the row is replaced by the row's first one (the offset
+// register must not go negative: the hardware range check adds the instruction's immediate to it without wrapping), and
+// what lies past the tile reads as 0.  A row pitch that is an odd multiple of 4 has a last unit of four bytes: the same
+// instructions, and only its first dword is stored (the second would be the next row's first).
+// (Four bytes per thread was the first form: ten memory instructions per 8 bytes instead of four, 52-57 % of the HBM peak
+// against 60-66 %.  Sixteen bytes per thread was measured and dropped: fewer VALU per byte, but its 16-byte lane pitch
+// quarters the coalescing of the loads and stores.)
 #ifndef SK_SEQ_UNROLL
 #define SK_SEQ_UNROLL 1                  // elements per thread and iteration: 1 / 2 / 4 -> 60.4 / 57.5 / 50.4 % of the HBM peak (tools/seq_ab.py)
 #endif
@@ -2111,7 +2059,8 @@ __global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__res
                                                             int64_t n, u32 m4, u32 inv_upr, uint8_t *__restrict__ out)
 {
 	__shared__ u32 row_info[64];                                   // len | reverse << 16
-	const int upr = stride >> 3;                                   // 8-byte units per row
+	const int upr = (stride + 7) >> 3;                             // 8-byte units per row; the last one is half a unit when stride % 8 == 4
+	const bool half_tail = (stride & 7) != 0;
 	const int64_t ntiles = (n + 63) / 64;
 	for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
 		const int64_t row0 = t * 64;
@@ -2181,7 +2130,10 @@ __global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__res
 				u32x2 o;
 				o[0] = (kN4 & lo_low) | (bases_from_codes(n_lo, rev) & ~lo_low);
 				o[1] = (kN4 & hi_low) | (bases_from_codes(n_hi, rev) & ~hi_low);
-				if (e + (u32)u * blockDim.x < total) __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)rlv[u] * stride + 8 * jv[u], 0, 0);
+				if (e + (u32)u * blockDim.x < total) {
+					if (half_tail && jv[u] == upr - 1) __builtin_amdgcn_raw_buffer_store_b32(o[0], ro, (int)rlv[u] * stride + 8 * jv[u], 0, 0);
+					else __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)rlv[u] * stride + 8 * jv[u], 0, 0);
+				}
 			}
 		}
 	}
@@ -2191,27 +2143,17 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st)
 {
 	if (n <= 0) return hipSuccess;
-	const u32 dpr = (u32)stride >> 2;
-	// rl = e / dpr as a multiply-high: exact while e * dpr < 2^32, and e < 64 * dpr
-	const u32 inv = (dpr > 1 && dpr < 8192u) ? (u32)(((1ull << 32) + dpr - 1) / dpr) : 0u;
 	const int64_t ntiles = (n + 63) / 64;
 	static const int wgs = getenv("SK_SEQ_WGS") ? atoi(getenv("SK_SEQ_WGS")) : 8;
 	const int grid = (int)(ntiles < (int64_t)n_cu * wgs ? ntiles : (int64_t)n_cu * wgs);
 	const u32 m4 = (u32)(min_baseq & 0xFF) * 0x01010101u;
-	static const bool wide = !getenv("SK_SEQ_DWORD");
-	if (wide && (stride & 7) == 0) {
-		const u32 upr = (u32)stride >> 3;
-		const u32 inv8 = (upr > 1 && upr < 8192u) ? (u32)(((1ull << 32) + upr - 1) / upr) : 0u;
-		if ((min_baseq & 0xFF) < 128)
-			bam_sequence8_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
-		else
-			bam_sequence8_kernel<false><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
-		return hipGetLastError();
-	}
+	// rl = e / upr as a multiply-high: exact while e * upr < 2^32, and e < 64 * upr
+	const u32 upr = ((u32)stride + 7u) >> 3;
+	const u32 inv8 = (upr > 1 && upr < 8192u) ? (u32)(((1ull << 32) + upr - 1) / upr) : 0u;
 	if ((min_baseq & 0xFF) < 128)
-		bam_sequence_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
+		bam_sequence8_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
 	else
-		bam_sequence_kernel<false><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv, out);
+		bam_sequence8_kernel<false><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
 	return hipGetLastError();
 }
 

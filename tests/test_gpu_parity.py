@@ -856,7 +856,7 @@ def test_bam_sequence_matches_oracle(ctx, oracle, n, stride, seq4_stride):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_bam_sequence(ctx, oracle, seed):
-    """Random row pitches (multiples of 8 take the eight-bytes-per-thread kernel, the others the dword kernel), packed-row
+    """Random row pitches (multiples of 8, and odd multiples of 4 whose last unit is clipped to its first dword), packed-row
     pitches with and without slack, row counts around the 64-row tile, any threshold, ragged lengths on both strands."""
     rng = np.random.default_rng(7000 + seed)
     stride = int(rng.choice([4, 8, 12, 16, 20, 24, 40, 56, 100, 104, 152, 248, 252, 256, 1000, 1024]))
