@@ -50,12 +50,14 @@ constexpr int kLdsSlots = 2048;
 constexpr int kLdsProbes = 4;
 constexpr u32 kMaxProbes = 1u << 16;
 
-struct LdsSlot {             // 32 bytes
-	u64 klo;
-	u64 khi_inv;
-	u64 first_inv;
-	u32 count;
-	u32 pad;
+// The workgroup's front table, one array per field: slot i of a u64 array lies in bank pair i mod 32, so the 64 probes of a
+// wave spread over all banks.  (As 32-byte records every slot began in one of 8 bank groups: SQ_LDS_BANK_CONFLICT was
+// 1.5 x SQ_ACTIVE_INST_LDS, profiles/r02_census_pmc_summary.txt.)
+struct LdsTable {
+	u64 klo[kLdsSlots];
+	u64 khi_inv[kLdsSlots];
+	u64 first_inv[kLdsSlots];
+	u32 count[kLdsSlots];
 };
 
 // 32-bit mix of the four key words; the HBM table uses the low bits, the LDS table the high bits
@@ -84,32 +86,34 @@ __host__ __device__ inline u32 census_code(u32 b)
 	}
 }
 
-struct SlotView { u64 k, v, f; };      // klo, ~khi and ~first of a slot as loaded at some earlier time
+struct SlotView { u64 k, v; };          // klo and ~khi of a slot as loaded at some earlier time
 
-// one round trip for the three words
+// one 16-byte load for the two key words (agent scope, like the atomic loads it replaces: sc1).  What bounds the HBM leg
+// is the number of scattered memory operations (about 60 G/s chip-wide), not their bytes: a probe is this one load (three
+// 8-byte loads before: every row a new key 7.2 -> 10 G rows/s), and the slot's first row is read only when the key matched.
 __device__ __forceinline__ SlotView census_peek(const CensusSlot *s)
 {
+	typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+	u32x4_t w;
+	asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w) : "v"(s) : "memory");
+	__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the compiler does not know of the load above
+	asm volatile("" : "+v"(w));
 	SlotView sv;
-	sv.k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	sv.v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	sv.f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	sv.k = (u64)w[0] | ((u64)w[1] << 32);
+	sv.v = (u64)w[2] | ((u64)w[3] << 32);
 	return sv;
 }
 
 // add (cnt, first) for one key to the HBM table, starting at slot idx whose contents were fetched before (sv);
-// returns false when the probe budget ran out.  sv may be stale: a slot's key never changes once it is published, an
-// empty or unpublished view is checked again (CAS / reload), and an old `first` only costs a superfluous atomicMax.
-// On the usual path — the key is already there — the two updates are fire-and-forget atomics.
+// returns false when the probe budget ran out.  sv may be stale: a slot's key never changes once it is published, and an
+// empty or unpublished view is checked again (CAS / reload).
 __device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 idx, SlotView sv, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
 	const u64 want = ~khi;
 	u32 probes = 0;
-	u64 k = sv.k, v = sv.v, f = sv.f;
+	u64 k = sv.k, v = sv.v;
 	while (probes < kMaxProbes) {
 		CensusSlot *s = tab + idx;
-		// naming all three here leaves no load outstanding on any way out of this function, for which the code after
-		// the call would otherwise wait — together with the caller's prefetched tile
-		asm volatile("" :: "v"(k), "v"(v), "v"(f));
 		if (k == 0) {
 			k = atomicCAS(&s->klo, 0ull, klo);
 			if (k == 0) {
@@ -127,25 +131,25 @@ __device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 
 				return true;
 			}
 			v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			f = 0;
 		}
 		if (k == klo) {
 			if (v == 0) {                                              // owner is between its CAS and its publishing store: look again
 				__builtin_amdgcn_s_sleep(1);
 				v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				continue;
 			}
 			if (v == want) {
 				atomicAdd(&s->count, cnt);
-				if (f < first_inv) atomicMax(&s->first_inv, first_inv);
+				// (an unconditional atomicMax was measured: one more operation on an address every workgroup adds to — the
+				// duplicate-heavy shapes lost 8 %; the first row is read, on a hit only, and folded in when it is earlier)
+				if (__hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < first_inv) atomicMax(&s->first_inv, first_inv);
 				return true;
 			}
 		}
 		idx = (idx + 1) & mask;
 		probes++;
 		const SlotView nx = census_peek(tab + idx);
-		k = nx.k; v = nx.v; f = nx.f;
+		k = nx.k; v = nx.v;
 	}
 	return false;
 }
@@ -220,14 +224,14 @@ __device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t,
 // straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
 template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot)
 {
-	LdsSlot *lt = reinterpret_cast<LdsSlot *>(census_smem);
+	LdsTable *lt = reinterpret_cast<LdsTable *>(census_smem);
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int nwave = blockDim.x >> 6;
-	uint8_t *lut = census_smem + kLdsSlots * sizeof(LdsSlot);
+	uint8_t *lut = census_smem + sizeof(LdsTable);
 	uint8_t *tile = lut + 256 + (size_t)wave * tile_slot;
-	for (int i = tid; i < kLdsSlots * (int)(sizeof(LdsSlot) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
 	if (tid < 256) lut[tid] = (uint8_t)census_code((u32)tid);
 	__syncthreads();
 
@@ -311,25 +315,24 @@ template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_
 				u32 idx = (census_hash(klo, khi) >> 16) & (kLdsSlots - 1);
 				bool done = false;
 				for (int p = 0; p < kLdsProbes && !done;) {
-					LdsSlot *s = lt + idx;
-					u64 k = __hip_atomic_load(&s->klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					u64 v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					u64 f = __hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					u64 f = __hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					if (k == 0) {
-						k = atomicCAS(&s->klo, 0ull, klo);
+						k = atomicCAS(&lt->klo[idx], 0ull, klo);
 						if (k == 0) {
-							__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							__hip_atomic_store(&lt->khi_inv[idx], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 							k = klo;
 							v = want;
 						} else {
-							v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						}
 						f = 0;
 					}
 					if (k == klo && v == 0) continue;                    // claimed, high word not published yet: look again
 					if (k == klo && v == want) {
-						atomicAdd(&s->count, 1u);
-						if (f < first_inv) atomicMax(&s->first_inv, first_inv);
+						atomicAdd(&lt->count[idx], 1u);
+						if (f < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
 						done = true;
 					} else {
 						idx = (idx + 1) & (kLdsSlots - 1);
@@ -378,8 +381,9 @@ template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_
 	// hold (the frequent ones) are not hit by all of them at the same moment
 	for (int i0 = tid; i0 < kLdsSlots; i0 += blockDim.x) {
 		const int i = (i0 + (int)blockIdx.x * 67) & (kLdsSlots - 1);
-		const LdsSlot s = lt[i];
-		if (s.klo != 0 && !census_insert(a.tab, a.mask, s.klo, ~s.khi_inv, (u64)s.count, s.first_inv, claimed)) overflow += s.count;
+		const u64 sk = lt->klo[i];
+		const u32 sc = lt->count[i];
+		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 	}
 	// one atomic per wave and statistic
 	for (int o = 32; o > 0; o >>= 1) {
@@ -524,7 +528,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
 	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
-	const size_t lds = kLdsSlots * sizeof(LdsSlot) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
+	const size_t lds = sizeof(LdsTable) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
 	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
 	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
 	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) chunk = (int64_t)1 << lg; }
