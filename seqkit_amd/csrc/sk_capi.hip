@@ -231,20 +231,32 @@ int sk_free_device(sk_ctx *c, void *p)
 	if (p) SK_HIP(c, hipFree(p));
 	return SK_OK;
 }
+// Pinned memory belongs to the process, not to a ctx (hipHostMallocPortable: page-locked for every device): these two
+// touch no ctx state on the way — no device is bound, nothing is written to the ctx — so the hosts' worker threads may
+// call them on a ctx that another thread is running a pass on.  Only a failure is noted in the ctx, under a lock.
+static std::mutex g_pinned_err_m;
 int sk_malloc_pinned(sk_ctx *c, size_t bytes, void **out)
 {
 	if (!c || !out) return SK_ERR_INVALID;
-	if (int r = bind(c)) return r;
 	*out = nullptr;
-	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);     // pinned for every device of the process
-	if (e != hipSuccess) return fail(c, SK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		std::lock_guard<std::mutex> lk(g_pinned_err_m);
+		return fail(c, SK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+	}
 	return SK_OK;
 }
 int sk_free_pinned(sk_ctx *c, void *p)
 {
 	if (!c) return SK_ERR_INVALID;
-	if (int r = bind(c)) return r;
-	if (p) SK_HIP(c, hipHostFree(p));
+	if (!p) return SK_OK;
+	hipError_t e = hipHostFree(p);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		std::lock_guard<std::mutex> lk(g_pinned_err_m);
+		return fail(c, SK_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
+	}
 	return SK_OK;
 }
 int sk_copy_h2d(sk_ctx *c, void *dst, const void *src, size_t bytes)
@@ -511,7 +523,12 @@ __global__ void counts_add_kernel(unsigned long long *dst, const unsigned long l
 // RCCL announces itself on stdout when a communicator comes up (version banner).  stdout belongs to the host's results
 // (the reference's commands print there), so while a communicator is being made fd 1 points at stderr, and what stdio
 // buffered during that time is flushed there before fd 1 is put back.
+// fd 1 is process-wide state: one redirection at a time (two callers could otherwise put each other's descriptor back),
+// and only the calls that make a communicator take it — a host thread that prints a result at that very moment would see
+// it on stderr, which is why the command-line hosts make their communicators before their workers start.
+static std::mutex g_stdout_m;
 struct StdoutToStderr {
+	std::lock_guard<std::mutex> lk{g_stdout_m};
 	int saved = -1;
 	StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
 	~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
@@ -627,8 +644,10 @@ int sk_counts_allreduce(sk_ctx **ctxs, int n_ctx)
 		std::vector<int> devs;
 		for (int k : leaders) devs.push_back(ctxs[k]->device);
 		std::vector<ncclComm_t> comms;
+		// the communicators of a device set are shared by every caller that reduces over it: the lock is held from their
+		// lookup to the end of the grouped call, so two threads never interleave their operations on one ncclComm
+		std::lock_guard<std::mutex> lk(g_local_m);
 		{
-			std::lock_guard<std::mutex> lk(g_local_m);
 			for (const LocalComms &lc : g_local) if (lc.devs == devs) { comms = lc.comms; break; }
 			if (comms.empty()) {
 				comms.resize(devs.size());

@@ -151,3 +151,57 @@ def test_bench_two_ranks_on_one_gpu_take_the_gloo_fallback(hip_lib, oracle):
     assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True and d["scaling"] == "weak"
     assert "gloo" in d["config"]["count_reduce"] or "RCCL" in d["config"]["count_reduce"]
     assert d["value"] > 0 and d["config"]["placement"]["candidates"] == 2
+
+
+def _device_count():
+    lib = capi.load_library()
+    return int(lib.sk_device_count())
+
+
+needs_two = pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X in one process (the builder's GPU boxes have one; a node with more runs it)")
+
+
+@needs_two
+def test_demultiplex_by_table_on_a_second_device_while_the_first_is_current(hip_lib, oracle):
+    """The sheet's lookup table is uploaded on first use: that upload must land on the ctx's device even though the calling
+    thread's current device is another (round 2's advisor: ensure_neighbour_table ran before the ctx was bound)."""
+    import seqkit_amd
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, 50_000, seed=9, halves=2)
+    with seqkit_amd.Context(0) as c0, seqkit_amd.Context(1) as c1:
+        c0.set_barcodes(table, 1)
+        c0.demux_assign(bc, want_detail=False)              # leaves device 0 current on this thread
+        c1.set_barcodes(table, 1)
+        assign, *_ = c1.demux_assign(bc, want_detail=False)
+        e = oracle.demux_batch(table, bc, 1)
+        assert np.array_equal(assign, e[0]) and np.array_equal(c1.counts(), e[4])
+        c1.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+        assign, low, first, last = c1.demux_assign(bc)
+        m = e[0] != -1
+        assert np.array_equal(assign, e[0]) and np.array_equal(low[m], e[1][m]) and np.array_equal(first[m], e[2][m]) and np.array_equal(last[m], e[3][m])
+
+
+@needs_two
+def test_counts_allreduce_between_two_devices(hip_lib, oracle):
+    """sk_counts_allreduce over ctxs on DISTINCT devices: ncclCommInitAll over the device list and one grouped ncclAllReduce
+    on the ctx streams (the leg a one-GPU box cannot run), with a second ctx on each device summed on that device first."""
+    import seqkit_amd
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    n = 40_000
+    bc, _ = synth.observe_barcodes(table, n, seed=78, halves=2)
+    ctxs = [seqkit_amd.Context(d) for d in (0, 1, 0, 1)]
+    cuts = [0, 9000, 21000, 21000, n]
+    try:
+        for c, lo, hi in zip(ctxs, cuts[:-1], cuts[1:]):
+            c.set_barcodes(table, 1)
+            if hi > lo:
+                c.demux_assign(np.ascontiguousarray(bc[lo:hi]), want_detail=False)
+        ctxs[0].counts_allreduce(ctxs[1:])
+        expect = oracle.demux_batch(table, bc, 1)[4]
+        for c in ctxs:
+            assert np.array_equal(c.counts(), expect)
+        ctxs[0].counts_allreduce(ctxs[1:])                  # again on the cached communicators: every ctx now holds 4 x the totals
+        assert np.array_equal(ctxs[3].counts(), 4 * expect)
+    finally:
+        for c in ctxs:
+            c.close()
