@@ -76,8 +76,8 @@ def build_hosts(force: bool = False) -> list[str]:
     """The C++ `fasta` / `sam` hosts above the C-ABI (seqkit_amd/bin/)."""
     os.makedirs(BINDIR, exist_ok=True)
     out = []
-    for name, srcs, libs in (("fasta", ["host_common.cpp", "fasta_main.cpp", "fasta_text.cpp"], ["-lz", "-ldl"]),
-                             ("sam", ["host_common.cpp", "sam_main.cpp"], ["-lz", "-ldl"])):
+    for name, srcs, libs in (("fasta", ["host_common.cpp", "host_inflate.cpp", "fasta_main.cpp", "fasta_text.cpp"], ["-lz", "-ldl"]),
+                             ("sam", ["host_common.cpp", "host_inflate.cpp", "sam_main.cpp"], ["-lz", "-ldl"])):
         if not all(os.path.exists(os.path.join(CSRC, s)) for s in srcs):
             continue
         target = os.path.join(BINDIR, name)

@@ -118,6 +118,12 @@ private:
 	Impl *impl_;
 };
 
+// Raw DEFLATE of one whole buffer into one whole buffer (a BGZF block) and zlib's CRC-32, both several times faster than
+// zlib's streaming inflate() / crc32() (host_inflate.cpp).  inflate_raw: false = the decoder gave up (irregular code,
+// bad distance, sizes that do not match) and the caller asks zlib, whose verdict stands; out_len is the exact output size.
+bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
+uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len, uint32_t (*tail_crc)(uint32_t, const uint8_t *, size_t));
+
 // ---- buffered stdout -----------------------------------------------------------------------------------
 class Out {
 public:

@@ -143,7 +143,7 @@ def test_block_parallel_gzip_writer(hip_lib, tmp_path):
     exe = tmp_path / "gz_writer_test"
     csrc = build.CSRC
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(build.REPO, "include"), "-I", csrc, "-o", str(exe),
-                    os.path.join(build.REPO, "tests", "cpp", "gz_writer_test.cpp"), os.path.join(csrc, "host_common.cpp"),
+                    os.path.join(build.REPO, "tests", "cpp", "gz_writer_test.cpp"), os.path.join(csrc, "host_common.cpp"), os.path.join(csrc, "host_inflate.cpp"),
                     "-L", build.LIBDIR, "-lseqkit_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lz", "-ldl"], check=True)
     for nf, total in ((5, 3_000_000), (2, 0), (40, 100_000)):
         d = tmp_path / f"o{nf}_{total}"
@@ -186,7 +186,7 @@ def _build_cpp(tmp_path, name, extra=()):
     exe = tmp_path / name
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                     "-I", os.path.join(build.REPO, "include"), "-I", build.CSRC, "-o", str(exe),
-                    os.path.join(build.REPO, "tests", "cpp", name + ".cpp"), os.path.join(build.CSRC, "host_common.cpp"),
+                    os.path.join(build.REPO, "tests", "cpp", name + ".cpp"), os.path.join(build.CSRC, "host_common.cpp"), os.path.join(build.CSRC, "host_inflate.cpp"),
                     "-L", build.LIBDIR, "-lseqkit_hip", f"-Wl,-rpath,{build.LIBDIR}", "-lz", "-ldl", *extra], check=True)
     return exe
 
@@ -276,7 +276,8 @@ def test_bgzf_stream_parallel_inflate_unit(tmp_path):
         return r.returncode, r.stdout
 
     f.write_bytes(b"".join(blocks))
-    for env in ({}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_THREADS": "3"}, {"SEQKIT_NO_MMAP": "1"}):      # mapped file / read through the descriptor
+    for env in ({}, {"SEQKIT_NO_LIBDEFLATE": "1"}, {"SEQKIT_THREADS": "1"}, {"SEQKIT_THREADS": "3"}, {"SEQKIT_NO_MMAP": "1"},      # mapped file / read through the descriptor
+                {"SEQKIT_NO_LIBDEFLATE": "1", "SEQKIT_ZLIB_INFLATE": "1"}):                                                         # this build's decoder and CRC / zlib's
         assert run(env) == (0, raw)
     whole = b"".join(blocks)
     cut = len(b"".join(blocks[:20])) + 100                                  # inside block 20
@@ -298,3 +299,18 @@ def test_bgzf_stream_parallel_inflate_unit(tmp_path):
     assert run() == (0, b"")
     f.write_bytes(b"not gzip at all, just text\n" * 10)
     assert run()[0] == 3
+
+
+def test_own_inflate_and_crc_against_zlib_under_asan(tmp_path):
+    """host::inflate_raw / host::crc32_fast (what every BGZF block goes through when libdeflate is not there): thousands of
+    zlib streams of every level and strategy decode to the same bytes, damaged streams never crash and are never accepted
+    unless zlib accepts them with the same output, CRCs of random ranges equal zlib's.  tests/cpp/inflate_test.cpp."""
+    import os
+    import subprocess
+    from seqkit_amd import build
+    exe = tmp_path / "inflate_test"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I", build.CSRC, "-I", os.path.join(build.REPO, "include"), "-o", str(exe),
+                    os.path.join(build.REPO, "tests", "cpp", "inflate_test.cpp"), os.path.join(build.CSRC, "host_inflate.cpp"), "-lz"], check=True)
+    out = subprocess.run([str(exe), "800"], stdout=subprocess.PIPE, check=True, env={"ASAN_OPTIONS": "detect_leaks=0"}).stdout.decode()
+    assert out.startswith("ok: 800 streams"), out

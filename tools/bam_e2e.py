@@ -75,7 +75,8 @@ for label, binary in (("hip", SAM),) if os.environ.get("E2E_NO_ORACLE") else (("
         dt = time.perf_counter() - t0
         print(f"{'sam ' + ' '.join(cmd[:-1]):26s} {label:7s} {dt:7.2f} s  {n / dt / 1e6:7.2f} M records/s  rc={r.returncode}", flush=True)
 if os.environ.get("BAM_KEEP"):
-    os.replace(bam, os.environ["BAM_KEEP"])          # for tools/bam_scale.sh
+    import shutil
+    shutil.move(bam, os.environ["BAM_KEEP"])         # for tools/bam_scale.sh
 else:
     os.remove(bam)
 os.rmdir(d)
