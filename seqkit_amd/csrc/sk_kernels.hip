@@ -1328,6 +1328,123 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
+// The same lookup for rows of exactly 8 bytes on an 8-byte pitch (cfg 3), TWO rows per lane: a tile is 128 rows, a lane loads
+// its two rows with one 16-byte load (1 KiB per wave instruction instead of 512 B) and stores their two codes with one 8-byte
+// store; the per-tile scalar work (descriptors, clipping, counters) is paid once per 128 rows.  Everything per row is as above.
+template <bool LDSTAB, bool DETAIL>
+__global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const TileArgs a, const LdsPlan lp)
+{
+	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+	constexpr int kRows = 2 * kTileRows;
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int nwave = blockDim.x >> 6;
+	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
+	const LutDev &t = a.table.nbr;
+	const int S = a.table.S;
+	const int64_t ntiles = (a.n + kRows - 1) / kRows;
+	const u32 mask = (u32)t.mask;
+	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kRows);
+	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kRows : (ti == nt32 - 1 ? last_rows : 0); };
+	u32x4 raw[2];
+	auto fetch = [&](int ti, int s) {
+		const int rows = rows_of(ti);
+		raw[s] = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kRows * 8), rows * 8), lane * 16, 0, 0);
+	};
+	const int tstep = (int)gridDim.x * nwave;
+	int tb = (int)blockIdx.x * nwave + wave;
+	fetch(tb, 0);
+	fetch(tb + tstep, 1);
+	for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
+	const int ltab_off = lp.tiles_off - lp.table_bytes;
+	if (LDSTAB) {
+		const int n16 = lp.table_bytes >> 4;
+		for (int i0 = threadIdx.x; i0 < n16; i0 += 8 * (int)blockDim.x) {
+			u32x4 tv[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const int i = i0 + j * (int)blockDim.x;
+				if (i < n16) tv[j] = reinterpret_cast<const u32x4 *>(t.tab)[i];
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const int i = i0 + j * (int)blockDim.x;
+				if (i < n16) *reinterpret_cast<u32x4 *>(sk_smem + ltab_off + i * 16) = tv[j];
+			}
+		}
+	}
+	__syncthreads();
+	auto entry = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
+		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)slot * 2);
+	};
+	u32 n_total = 0, n_ident = 0, n_ambig = 0;
+	for (; tb < nt32; tb += 2 * tstep) {
+#pragma unroll
+		for (int s = 0; s < 2; s++) {
+			const int ti = tb + s * tstep;
+			const int rows = rows_of(ti);
+			const int64_t ro = (int64_t)(rows ? ti : 0) * kRows;
+			const u32x4 d = raw[s];
+			fetch(ti + 2 * tstep, s);
+			int code[2], tot[2], first[2], last[2];
+			bool found[2];
+#pragma unroll
+			for (int r = 0; r < 2; r++) {
+				u32 c[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+				for (int w = 0; w < 2; w++) {
+					const u32 dw = d[2 * r + w];
+					const u32 sel = (dw >> t.sh) & 0x07070707u;
+					const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
+					const u32 df = dw ^ letter;
+					const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;
+					const u32 m = nz - (nz >> 7);
+					c[w] = (m & t.other) | (~m & sel);
+				}
+				u32 A, B;
+				lut_pack(c, A, B);
+				A &= t.keepA; B &= t.keepB;
+				const u32 x = lut_mix(A, B, t.seed);
+				const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);
+				const u32x2_t e1 = entry(x & mask);
+				const u32x2_t e2 = entry(mask + 1u + (y & mask));
+				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
+				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
+				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
+				tot[r] = (int)(w0 >> 31);
+				found[r] = (m1 == 0u || m2 == 0u) && tot[r] <= t.max_diff;
+				const int idx = (int)((w1 >> 24) & 0x7fu);
+				const bool amb = (int)w1 < 0;
+				code[r] = found[r] ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
+				first[r] = last[r] = idx;
+				if (DETAIL && found[r] && amb) { first[r] = t.amb[2 * idx]; last[r] = t.amb[2 * idx + 1]; }
+				const bool active = 2 * lane + r < rows;
+				if (active && code[r] >= 0) atomicAdd(&hist[code[r]], 1u);
+				n_ident += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code[r] >= 0));
+				n_ambig += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code[r] == kAssignAmbiguous));
+			}
+			n_total += (u32)rows;
+			u32x2_t cv;
+			cv[0] = (u32)code[0]; cv[1] = (u32)code[1];
+			__builtin_amdgcn_raw_buffer_store_b64(cv, make_rsrc(a.assign, ro * 4, rows * 4), lane * 8, 0, 0);
+			if (DETAIL) {
+				// narrow stores per row: a descriptor clips whole elements, and a two-row element at an odd row count would lose its first row
+				const rsrc_t rd = make_rsrc(a.lowest_diff, ro, rows), rf = make_rsrc(a.first_idx, ro * 2, rows * 2), rl = make_rsrc(a.last_idx, ro * 2, rows * 2);
+#pragma unroll
+				for (int r = 0; r < 2; r++) {
+					__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(found[r] ? tot[r] : 255), rd, lane * 2 + r, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found[r] ? first[r] : -1), rf, lane * 4 + 2 * r, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found[r] ? last[r] : -1), rl, lane * 4 + 2 * r, 0, 0);
+				}
+			}
+		}
+	}
+	const WaveCounts wc = {n_total, n_ident, n_ambig};
+	if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
+	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
+}
+
 template <bool LDSTAB, bool DETAIL>
 static const void *demux_lut_fn(int W1, int W2, bool direct)
 {
@@ -1548,8 +1665,15 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
 			const int table_bytes = (t.mask + 1) * 2 * 8;
 			const bool ldstab = table_bytes <= (128 << 10) && (!env_ldstab || atoi(env_ldstab) != 0);
-			const void *fn = ldstab ? (want_detail ? demux_lut_fn<true, true>(t.W1, t.W2, direct) : demux_lut_fn<true, false>(t.W1, t.W2, direct))
-			                        : (want_detail ? demux_lut_fn<false, true>(t.W1, t.W2, direct) : demux_lut_fn<false, false>(t.W1, t.W2, direct));
+			// rows of exactly 8 key bytes on an 8-byte pitch: two rows per lane when the detail columns are written too (17 B/read:
+			// 10 M reads 249 -> 290 G reads/s; the decision alone is faster with one row per lane at 10 M, 364 against 333, and
+			// the same at 100 M).  SK_DEMUX_ROWS2=0 / 1 force the choice (tools/demux_ab.py, tests).
+			const char *env_rows2 = getenv("SK_DEMUX_ROWS2");
+			const bool rows2 = direct && t.W1 == 2 && b.bc_stride == 8 && (env_rows2 ? atoi(env_rows2) != 0 : want_detail);
+			const void *fn = rows2 ? (ldstab ? (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false>))
+			                                 : (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<false, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<false, false>)))
+			                 : ldstab ? (want_detail ? demux_lut_fn<true, true>(t.W1, t.W2, direct) : demux_lut_fn<true, false>(t.W1, t.W2, direct))
+			                          : (want_detail ? demux_lut_fn<false, true>(t.W1, t.W2, direct) : demux_lut_fn<false, false>(t.W1, t.W2, direct));
 			LdsPlan lp{};
 			lp.use_lds_hist = 1;                                      // S <= 128
 			lp.hist_off = 0;
@@ -1577,7 +1701,8 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 				std::lock_guard<std::mutex> lk(occ_m);
 				occ.push_back({dev, fn, lds, wg});
 			}
-			const int64_t ntiles = (b.n + kTileRows - 1) / kTileRows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
+			const int tile_rows = rows2 ? 2 * kTileRows : kTileRows;
+			const int64_t ntiles = (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;
 			// a few hundred workgroups add to the counters directly; thousands go through the spread copies and the fold
 			if (grid <= 512 || bb.counts_wide) bb.table.count_rep = nullptr;

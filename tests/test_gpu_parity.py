@@ -282,11 +282,15 @@ def check_demux_matched(ctx, oracle, table, bc, max_diff=1):
     return int(m.sum())
 
 
-@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache"])
+@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache", "two rows per lane", "one row per lane"])
 def lut_form(request, monkeypatch):
     """The forms of the lookup kernel (and the matchers, without a table) on the same inputs."""
     if request.param == "no table":
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
+    elif request.param == "two rows per lane":
+        monkeypatch.setenv("SK_DEMUX_ROWS2", "1")
+    elif request.param == "one row per lane":
+        monkeypatch.setenv("SK_DEMUX_ROWS2", "0")
     elif request.param == "rows through the LDS image":
         monkeypatch.setenv("SK_DEMUX_DIRECT", "0")
     elif request.param == "table in the vector cache":
@@ -382,6 +386,8 @@ def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
         monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")          # the table from the vector cache instead of LDS
     if seed % 4 == 2:
         monkeypatch.setenv("SK_DEMUX_DIRECT", "0")          # aligned short rows through the LDS image too
+    if seed % 4 == 3:
+        monkeypatch.setenv("SK_DEMUX_ROWS2", "1")           # 8-byte rows two per lane also for the decision alone
     rng = np.random.default_rng(12000 + seed)
     S = int(rng.choice([1, 2, 3, 16, 40, 96, 128, 150]))
     L = int(rng.choice([1, 3, 4, 8, 9, 12, 16, 17, 20, 21, 24, 33]))

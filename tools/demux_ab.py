@@ -15,7 +15,7 @@ from seqkit_amd import synth  # noqa: E402
 dev = torch.device("cuda", 0)
 libs = [("cur", None)] + [(os.path.basename(p)[:-3], os.path.abspath(p)) for p in os.environ.get("SK_LIBS", "").split(",") if p]
 forms = [f for f in os.environ.get("DEMUX_FORMS", "default").split(";") if f]
-KNOBS = ("SK_DEMUX_LDSTAB", "SK_DEMUX_DIRECT", "SK_NO_HASH_DEMUX", "SK_DEMUX_SPREAD", "SK_EXP_NOFLUSH")
+KNOBS = ("SK_DEMUX_LDSTAB", "SK_DEMUX_DIRECT", "SK_NO_HASH_DEMUX", "SK_DEMUX_ROWS2")
 pad = int(os.environ.get("DEMUX_PAD", "0"))          # bytes added to every row: 17 -> 24 puts the dual-index rows on dword boundaries, 8 -> 9 takes them off
 sizes = [int(x) for x in os.environ.get("DEMUX_N", "10000000,100000000").split(",")]
 details = [False, True] if os.environ.get("DEMUX_DETAIL") else [False]
