@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Demultiplex alone on one sheet, a few launches: the thing to put under rocprofv3 (tools/profile_cmd.sh).
+usage: python tools/demux_one.py [dual|cfg3] [rows] [detail]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import seqkit_amd  # noqa: E402
+from seqkit_amd import synth  # noqa: E402
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "dual"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+detail = len(sys.argv) > 3
+dev = torch.device("cuda", 0)
+ctx = seqkit_amd.Context(0)
+if kind == "dual":
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+else:
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
+L = table.shape[1]
+ctx.set_barcodes(table, 1)
+if detail:
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+bc = torch.from_numpy(bc_np).to(dev).repeat(max(1, n // 1_000_000), 1)[:n].contiguous()
+assign = torch.empty((n,), dtype=torch.int32, device=dev)
+low = torch.empty((n,), dtype=torch.uint8, device=dev)
+first = torch.empty((n,), dtype=torch.int16, device=dev)
+last = torch.empty((n,), dtype=torch.int16, device=dev)
+torch.cuda.synchronize()
+
+
+def run():
+    if detail:
+        ctx.demux_assign_dev(bc.data_ptr(), L, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr())
+    else:
+        ctx.demux_assign_dev(bc.data_ptr(), L, n, assign.data_ptr())
+
+
+for _ in range(3):
+    run()
+ctx.sync()
+ctx.timer_start()
+for _ in range(10):
+    run()
+ms = ctx.timer_stop() / 10
+b = L + 4 + (5 if detail else 0)
+print(f"{kind} n={n} detail={detail}: {ms:.4f} ms  {n / ms / 1e6:.1f} G rows/s  {n * b / ms / 1e6 / 80:.1f}% of 8 TB/s")

@@ -56,7 +56,36 @@ def cfg3():
     assert np.array_equal(assign.cpu().numpy(), e_assign)
     counts = ctx.counts()
     assert np.array_equal(counts, e_counts) and int(counts[:16].sum()) == int(counts[17]) and int(counts[16]) == n
-    print(f"cfg3 ok: 10 M x 8 bp, 16 barcodes == oracle; identified {int(counts[17])}, ambiguous {int(counts[18])}", flush=True)
+    # what `fasta demultiplex` asks for: the same lookup with lowest_diff / first / last of the reads that matched something
+    e_assign, e_low, e_first, e_last, _ = oracle.demux_batch(table, bc, 1)
+    low = torch.empty((n,), dtype=torch.uint8, device=dev)
+    first = torch.empty((n,), dtype=torch.int16, device=dev)
+    last = torch.empty((n,), dtype=torch.int16, device=dev)
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+    ctx.demux_assign_dev(d.data_ptr(), 8, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr())
+    ctx.sync()
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_FULL)
+    m = e_assign != -1
+    assert np.array_equal(assign.cpu().numpy(), e_assign)
+    assert np.array_equal(low.cpu().numpy()[m], e_low[m]) and np.array_equal(first.cpu().numpy()[m], e_first[m]) and np.array_equal(last.cpu().numpy()[m], e_last[m])
+    assert np.array_equal(ctx.counts(), 2 * e_counts)
+    print(f"cfg3 ok: 10 M x 8 bp, 16 barcodes == oracle (decision; decision + detail of the {int(m.sum())} matched reads); "
+          f"identified {int(counts[17])}, ambiguous {int(counts[18])}", flush=True)
+    # the metric's own sheet, demultiplex alone: 10 M x 17 ch, 96 dual-index
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, n, seed=4, halves=2)
+    bc[::1009, 8] = ord("-")                                    # a broken separator now and then
+    ctx.set_barcodes(table, 1)
+    d = to_dev(bc)
+    e_assign, e_low, e_first, e_last, e_counts = oracle.demux_batch(table, bc, 1)
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_MATCHED)
+    ctx.demux_assign_dev(d.data_ptr(), 17, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr())
+    ctx.sync()
+    ctx.set_detail_mode(seqkit_amd.SK_DETAIL_FULL)
+    m = e_assign != -1
+    assert np.array_equal(assign.cpu().numpy(), e_assign) and np.array_equal(ctx.counts(), e_counts)
+    assert np.array_equal(low.cpu().numpy()[m], e_low[m]) and np.array_equal(first.cpu().numpy()[m], e_first[m]) and np.array_equal(last.cpu().numpy()[m], e_last[m])
+    print(f"96 dual-index ok: 10 M x 17 ch == oracle (decision + detail of the {int(m.sum())} matched pairs)", flush=True)
 
 
 def cfg4():

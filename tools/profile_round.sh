@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in ONE session on the GPU box: bench line + kernel trace + PMC passes of the headline,
+# the N = 2 same-device line, the CLI's kernel trace, PMC of the lookup kernel and of trim alone, the rates of every tool, the
+# GPU test run.  usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
+set -u
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+bash tools/profile_bench.sh $TAG > $OUT/profile_bench.log 2>&1
+SK_BENCH_SAME_DEVICE=1 python3 bench.py --gpus 2 --pairs 4000000 --steps 5 --warmup 2 --cpu-sample 0 --no-extra --placements 1 > $OUT/two_ranks_same_device.json 2> $OUT/two_ranks.err
+bash tools/profile_cli_demux.sh $TAG 2000000 > $OUT/cli_demux.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_lut_dual "demux_lut" tools/demux_one.py dual 10000000 > $OUT/lut_dual_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_lut_cfg3 "demux_lut" tools/demux_one.py cfg3 10000000 > $OUT/lut_cfg3_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_trim_uniform "tile_pass_kernel" tools/trim_one.py uniform 16000000 > $OUT/trim_uniform_pmc.log 2>&1
+{
+  echo "== tools/rates.py"; python3 tools/rates.py 2>&1 | grep -v amdgpu.ids
+  echo "== tools/demux_ab.py (DEMUX_DETAIL=1, forms default / table in the vector cache / no table)"
+  DEMUX_DETAIL=1 DEMUX_FORMS="default;SK_DEMUX_LDSTAB=0;SK_NO_HASH_DEMUX=1" DEMUX_N=1000000,10000000,100000000 python3 tools/demux_ab.py 2>&1 | grep -v amdgpu.ids
+  echo "== tools/trim_exp.py"; python3 tools/trim_exp.py 16000000 2>&1 | grep -v amdgpu.ids
+  echo "== tools/census_rates.py"; python3 tools/census_rates.py 2>&1 | grep -v amdgpu.ids
+  echo "== tools/seq_ab.py (pitch 152, 148)"; python3 tools/seq_ab.py 2>&1 | grep -v amdgpu.ids; SEQ_STRIDE=148 python3 tools/seq_ab.py 2>&1 | grep -v amdgpu.ids
+} > $OUT/rates.txt 2>&1
+{ echo "== tools/bam_scale.sh 20"; bash tools/bam_scale.sh 20 2>&1; echo "== tools/bam_paths.sh 20"; bash tools/bam_paths.sh 20 2>&1; } > $OUT/bam_host.txt 2>&1
+python3 -m pytest tests -q -m gpu 2>&1 | tail -15 > $OUT/gpu_tests.txt
+ls -la $OUT
