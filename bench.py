@@ -523,8 +523,11 @@ def device_identity(index):
     touches the GPU): what two boxes whose fused pass streams differently could differ in."""
     out = {"gpu_unique_id": None, "memory_partition": None, "compute_partition": None}
     try:
+        # rocm-smi is a script (`#!/usr/bin/env python3`: two exec hops).  Under `rocprofv3 --pmc` the profiler's preloaded library
+        # would initialise the GPU in that child before the hops: it gets an environment without the preload.
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
         r = subprocess.run(["rocm-smi", "-d", str(index), "--showuniqueid", "--showmemorypartition", "--showcomputepartition", "--json"],
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30)
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30, env=env)
         j = json.loads(r.stdout.decode() or "{}")
         card = next(iter(j.values())) if j else {}
         for k, v in card.items():
@@ -556,6 +559,7 @@ def main():
         local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = device_identity(local_rank) if rank == 0 else None      # a child process: started before this one touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -867,7 +871,7 @@ def main():
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},
             **reduce_report(distributed, rccl_err, rank_kernel_ms, rank_reduce_us),
-            "device": device_identity(local_rank),
+            "device": device,
             "cpu_baseline": cpu_baseline,
             "parity_sample_ok": parity,
             "identified_frac": round(float(total_counts[S + 1]) / float(total_counts[S]), 4),
