@@ -33,7 +33,31 @@ struct CensusSlot {          // 32 bytes, one HBM sector pair
 	u64 first_inv;           // ~(lowest row index seen): atomicMax keeps the first occurrence
 };
 
+// The partition path (large launches): keys the front tables had no room for are written out, sorted by the region of
+// the HBM table their slot lies in, and combined per region in LDS before they touch the table (census_add below).
+constexpr int kSpillBucketsLog2 = 10;
+constexpr int kSpillBuckets = 1 << kSpillBucketsLog2;
+constexpr int kSpillMaxLen = 24;         // 24 characters = 96 bits; the key's fourth dword is then the marker alone
+
+struct CensusSpill {
+	uint4 *key = nullptr;        // [grid][cap] as the workgroups of the front kernel wrote them: a record is the key's first
+	                             // three dwords (barcodes of at most kSpillMaxLen characters) and the row index within the launch
+	uint4 *skey = nullptr;       // the same records, bucket after bucket
+	u32 *hist = nullptr;         // [grid][kSpillBuckets]: records per workgroup and bucket
+	u32 *offs = nullptr;         // [grid][kSpillBuckets]: where the workgroup's records begin within the bucket
+	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket
+	u32 *bstart = nullptr;       // [kSpillBuckets + 1]
+	u32 *wg_count = nullptr;     // [grid]
+	u32 cap = 0;                 // records per workgroup region
+	u32 bucket_shift = 0;        // bucket = (hash & mask) >> bucket_shift
+	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not partitioned
+	u32 grid = 0;                // workgroups of the front kernel
+};
+
 struct Census {
+	CensusSpill sp;
+	size_t sp_records = 0;       // capacity of key / skey
+	int sp_grid = 0;             // capacity of hist / wg_count in workgroups
 	CensusSlot *tab = nullptr;
 	u64 slots = 0;           // power of two
 	u64 *stats = nullptr;    // device u64[kCensusStats]
@@ -73,18 +97,63 @@ __device__ __forceinline__ u32 census_hash(u64 klo, u64 khi)
 	return h;
 }
 
-// byte -> 4-bit code; 0 for NUL (end of barcode), 15 for a byte outside the alphabet.  The kernel reads this
-// from a 256-byte table in LDS.
-__host__ __device__ inline u32 census_code(u32 b)
+// Four characters of a dword -> their 4-bit codes, each in the low nibble of its byte; `diff` gets a non-zero byte where
+// the character is outside the alphabet "ACGTNacgtn+" (NUL, the end of a barcode, is code 0 and not outside).
+//   lower-case letters are folded onto upper case (bit 5 cleared where bit 6 is set: 0x20 itself and '+' stay as they are),
+//   bits 0..2 of y ^ (y >> 5) tell NUL + C A N G T apart (0 2 1 3 4 5 6: found by search), the byte that class stands
+//   for comes from an eight-byte table (v_perm_b32) and must equal the folded byte, and the case is the code's bit 3.
+constexpr u32 kClassLo = 0x412B4300u;      // classes 0..3: NUL C + A
+constexpr u32 kClassHi = 0xFF54474Eu;      // classes 4..7: N G T (none)
+__device__ __forceinline__ u32 census_classify(u32 x, u32 &diff)
 {
-	switch (b) {
-	case 0: return 0;
-	case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; case 'N': return 5;
-	case 'a': return 6; case 'c': return 7; case 'g': return 8; case 't': return 9; case 'n': return 10;
-	case '+': return 11;
-	default: return 15;
-	}
+	const u32 lower = x & (x >> 1) & 0x20202020u;
+	const u32 y = x ^ lower;
+	const u32 sel = (y ^ (y >> 5)) & 0x07070707u;
+	diff = y ^ __builtin_amdgcn_perm(kClassHi, kClassLo, sel);
+	return sel | (lower >> 2);
 }
+// The key of the row that begins at byte rs of the wave's tile, NW = ceil(L / 4) dwords of it: aligned LDS reads (all
+// issued before the first is used) funnel-shifted to the row's first byte, four characters per dword classified with
+// packed-byte arithmetic.  kms[q] masks the characters of dword q that lie before L (wave-uniform).  EXACT_NUL = false is the
+// common case — no row of the wave has a NUL before L, which the caller finds out from the returned word (bit 7 of a byte
+// clear: a code was 0); with EXACT_NUL the bytes from the first NUL on are masked away, whatever they are.
+// character 4q + b is nibble (q & 1) of byte b of word q / 2; the marker (a key is never 0) sits where character 31 would,
+// and that word is the key's FIRST so that barcodes of at most 24 characters are three dwords + a constant.
+template <int NW, bool EXACT_NUL> __device__ __forceinline__ u32 census_row_key(const uint8_t *tile, int rs, const u32 (&kms)[NW], u64 &klo, u64 &khi, u32 &badacc)
+{
+	const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
+	const u32 sh = (u32)rs & 3u;
+	u32 raw[NW + 1];
+#pragma unroll
+	for (int q = 0; q <= NW; q++) raw[q] = t32[q];
+	u32 c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	u32 nzacc = 0xFFFFFFFFu, alive = 0xFFFFFFFFu;
+	badacc = 0u;
+#pragma unroll
+	for (int q = 0; q < NW; q++) {
+		const u32 x = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh);
+		const u32 km = kms[q];
+		u32 d;
+		const u32 cc = census_classify(x, d);
+		if (!EXACT_NUL) {
+			badacc |= d & km;
+			c[q] = cc & km;
+			nzacc &= (c[q] + 0x7f7f7f7fu) | ~km;              // bit 7 of a byte: its code is not 0, or it lies beyond L
+		} else {
+			const u32 zf = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & 0x80808080u & km;      // bit 7 of the bytes that are NUL
+			const u32 m = (zf != 0u ? (1u << (__builtin_ctz(zf) & 31)) - 1u : 0xFFFFFFFFu) & alive & km;
+			badacc |= d & m;
+			c[q] = cc & m;
+			if (zf != 0u) alive = 0u;
+		}
+	}
+	const u32 kw0 = c[0] | (c[1] << 4), kw1 = c[2] | (c[3] << 4), kw2 = c[4] | (c[5] << 4), kw3 = c[6] | (c[7] << 4) | 0xF0000000u;
+	klo = (u64)kw3 | ((u64)kw0 << 32);
+	khi = (u64)kw1 | ((u64)kw2 << 32);
+	return nzacc;
+}
+
+static const char kCensusAlphabet[17] = "\0C+ANGT??c?angt?";      // by code
 
 struct SlotView { u64 k, v; };          // klo and ~khi of a slot as loaded at some earlier time
 
@@ -122,10 +191,13 @@ __device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 
 				// word hands the slot over — ONE atomic for a new key instead of three.
 				// (the stores are write-through at agent scope and the wait is for their acknowledgement — an
 				// agent-scope release would write the whole L2 back for every key)
-				__hip_atomic_store(&s->count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(&s->first_inv, first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				{	// count and first row are the slot's second half: ONE 16-byte store (scattered stores, like atomics, cost per operation)
+					typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+					const u32x4_t w = {(u32)cnt, (u32)(cnt >> 32), (u32)first_inv, (u32)(first_inv >> 32)};
+					asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&s->count), "v"(w) : "memory");
+				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the two stores
+				__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the store
 				__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				claimed++;
 				return true;
@@ -160,6 +232,36 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
 }
 
+// count (cnt, first) for one key in the workgroup's LDS table; false when the key found no room within kLdsProbes slots
+__device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv)
+{
+	const u64 want = ~khi;
+	u32 idx = at & (kLdsSlots - 1);
+	for (int p = 0; p < kLdsProbes;) {
+		u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (k == 0) {
+			k = atomicCAS(&lt->klo[idx], 0ull, klo);
+			if (k == 0) {
+				__hip_atomic_store(&lt->khi_inv[idx], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				k = klo;
+			}
+		}
+		if (k == klo) {                                      // (one 8-byte load per probe; the high word only where the low one matched)
+			const u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (v == 0) continue;                            // claimed, high word not published yet: look again
+			if (v == want) {
+				atomicAdd(&lt->count[idx], cnt);
+				// rows come in roughly ascending order, so the first row rarely moves: look before the (serialising) atomic
+				if (__hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
+				return true;
+			}
+		}
+		idx = (idx + 1) & (kLdsSlots - 1);
+		p++;
+	}
+	return false;
+}
+
 extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
 
 struct CensusArgs {
@@ -172,6 +274,7 @@ struct CensusArgs {
 	CensusSlot *tab;
 	u64 mask;
 	u64 *stats;
+	CensusSpill sp;
 };
 
 constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the LDS table
@@ -222,21 +325,31 @@ __device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t,
 // works on the current one (its private LDS tile), so the only workgroup barriers are the two around the loop.
 // Keys are counted in the workgroup's LDS table; a key that finds no room there within kLdsProbes slots goes
 // straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
-template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot)
+// SPILL: such keys are not inserted but appended to the workgroup's region of the spill arrays (unconditional, clipped
+// stores: nothing waits for them), counted per bucket; census_scatter_kernel / census_combine_kernel take them from there.
+template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot)
 {
 	LdsTable *lt = reinterpret_cast<LdsTable *>(census_smem);
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int nwave = blockDim.x >> 6;
-	uint8_t *lut = census_smem + sizeof(LdsTable);
-	uint8_t *tile = lut + 256 + (size_t)wave * tile_slot;
+	uint8_t *tile = census_smem + sizeof(LdsTable) + (size_t)wave * tile_slot;
+	u32 *lh = reinterpret_cast<u32 *>(census_smem + sizeof(LdsTable) + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
 	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
-	if (tid < 256) lut[tid] = (uint8_t)census_code((u32)tid);
+	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
 	__syncthreads();
+	__amdgpu_buffer_rsrc_t sp_key;
+	if (SPILL) sp_key = __builtin_amdgcn_make_buffer_rsrc(a.sp.key + (size_t)blockIdx.x * a.sp.cap, 0, (int)(a.sp.cap * 16u), 0x00020000);
 
 	const int stride = a.bc_stride;
 	const int step_bytes = R * 64 * stride;
+	u32 kms[NW];                                                       // the characters of a row's dword q that lie before L
+#pragma unroll
+	for (int q = 0; q < NW; q++) {
+		const int keep = a.L - 4 * q;
+		kms[q] = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
+	}
 	const int64_t nsteps = (a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64);
 	const int64_t step = (int64_t)gridDim.x * nwave;
 	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
@@ -265,89 +378,56 @@ template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_
 		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
 		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
 		u64 pklo[R], pkhi[R];
+		u32 ph[R];
 		u32 parked = 0u;
 #pragma unroll
 		for (int j = 0; j < R; j++) {
-		const int64_t r = (t * R + j) * 64 + lane;
-		pklo[j] = 0ull;
-		pkhi[j] = 0ull;
-		if (r < a.n && ((take >> j) & 1u)) {
-			// the row as dwords: aligned LDS reads funnel-shifted to the row's first byte
-			const int rs = (j * 64 + lane) * stride;
-			const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
-			const u32 sh = (u32)rs & 3u;
-			u32 kw[4] = {0u, 0u, 0u, 0u};
-			u32 live = 0xFu;
-			u32 lo = t32[0];
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				if (4 * q < a.L) {                                   // wave-uniform
-					const u32 hi = t32[q + 1];
-					const u32 x = __builtin_amdgcn_alignbyte(hi, lo, sh);
-					lo = hi;
-#pragma unroll
-					for (int b = 0; b < 4; b++) {
-						const int jj = 4 * q + b;
-						if (jj < kMaxCensusLen) {
-							const u32 c = lut[(x >> (8 * b)) & 0xFFu] & live;
-							if (c == 0u) live = 0u;                      // bytes after the first NUL are padding
-							kw[(jj + 1) >> 3] |= c << (4 * ((jj + 1) & 7));
-						}
-					}
+			u32 bad;
+			const u32 nz = census_row_key<NW, false>(tile, (j * 64 + lane) * stride, kms, pklo[j], pkhi[j], bad);
+			// A NUL before L ends the barcode and what follows it is padding: only then (any row of the wave's tile) the
+			// keys are worked out again, exactly.
+			if (__any((nz & 0x80808080u) != 0x80808080u)) (void)census_row_key<NW, true>(tile, (j * 64 + lane) * stride, kms, pklo[j], pkhi[j], bad);
+			const int64_t r = (t * R + j) * 64 + lane;
+			ph[j] = 0u;
+			if (r < a.n && ((take >> j) & 1u)) {
+				if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
+				else {
+					counted++;
+					const u64 first_inv = ~(u64)(a.row_base + r);
+					const u32 h = census_hash(pklo[j], pkhi[j]);
+					if (!lds_count(lt, h >> 16, pklo[j], pkhi[j], 1u, first_inv)) { ph[j] = h; parked |= 1u << j; }
 				}
 			}
-			// characters L.. of the last dword are not part of the barcode: clear them, then add the marker nibble
-			u32 any15 = 0u;
-#pragma unroll
-			for (int w = 0; w < 4; w++) {
-				const int keep = a.L + 1 - 8 * w;                      // nibbles of this word that hold characters (wave-uniform)
-				kw[w] &= keep >= 8 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (4 * keep)) - 1u));
-				any15 |= kw[w] & (kw[w] >> 1) & (kw[w] >> 2) & (kw[w] >> 3) & 0x11111111u;
-			}
-			kw[0] |= 0xFu;
-			const u64 klo = (u64)kw[0] | ((u64)kw[1] << 32), khi = (u64)kw[2] | ((u64)kw[3] << 32);
-			const bool bad = any15 != 0u;                                // some nibble is 15: a byte outside the alphabet
-			if (bad) rejected++;
-			else {
-				counted++;
-				const u64 first_inv = ~(u64)(a.row_base + r);
-				const u64 want = ~khi;
-				u32 idx = (census_hash(klo, khi) >> 16) & (kLdsSlots - 1);
-				bool done = false;
-				for (int p = 0; p < kLdsProbes && !done;) {
-					u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					u64 f = __hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					if (k == 0) {
-						k = atomicCAS(&lt->klo[idx], 0ull, klo);
-						if (k == 0) {
-							__hip_atomic_store(&lt->khi_inv[idx], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							k = klo;
-							v = want;
-						} else {
-							v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						}
-						f = 0;
-					}
-					if (k == klo && v == 0) continue;                    // claimed, high word not published yet: look again
-					if (k == klo && v == want) {
-						atomicAdd(&lt->count[idx], 1u);
-						if (f < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
-						done = true;
-					} else {
-						idx = (idx + 1) & (kLdsSlots - 1);
-						p++;
-					}
-				}
-				if (!done) { pklo[j] = klo; pkhi[j] = khi; parked |= 1u << j; }
-			}
-		}
 		}
 		census_wave_fence();
 		// The parked keys, packed densely through the (now dead) tile so that one insert serves up to 64 of them: its
 		// dependent round trips are paid per call, not per key.  (Fetching the slots a step ahead of the insert was tried:
 		// no gain — what bounds this leg is the rate of scattered atomics, not their latency.)
-		if (__any(parked != 0u)) {
+		if (SPILL) {
+			if (__any(parked != 0u)) {                                     // (stores inside a branch are fine: nothing waits for them)
+			u32 pos[R], tot = 0u;
+#pragma unroll
+			for (int j = 0; j < R; j++) {
+				const u64 bal = __ballot(((parked >> j) & 1u) != 0u);
+				pos[j] = tot + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+				tot += (u32)__popcll(bal);
+			}
+			u32 base = 0u;
+			if (tot != 0u) {                                               // LDS only: no memory operation inside a branch
+				if (lane == 0) base = atomicAdd(&lh[kSpillBuckets], tot);
+				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			}
+#pragma unroll
+			for (int j = 0; j < R; j++) {
+				const bool has = ((parked >> j) & 1u) != 0u;
+				const u32 at = has ? base + pos[j] : 0x07ffffffu;          // beyond the region: dropped by the descriptor
+				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), (u32)((t * R + j) * 64 + lane)};
+				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
+				if (has) atomicAdd(&lh[(u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift)], 1u);
+			}
+			}
+		} else if (__any(parked != 0u)) {
 			int qn = 0;
 #pragma unroll
 			for (int j = 0; j < R; j++) {
@@ -377,6 +457,10 @@ template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_
 		census_wave_fence();
 	}
 	__syncthreads();
+	if (SPILL) {
+		for (int i = tid; i < kSpillBuckets; i += blockDim.x) a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + i] = lh[i];
+		if (tid == 0) a.sp.wg_count[blockIdx.x] = lh[kSpillBuckets];
+	}
 	// merge the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of them
 	// hold (the frequent ones) are not hit by all of them at the same moment
 	for (int i0 = tid; i0 < kLdsSlots; i0 += blockDim.x) {
@@ -396,6 +480,196 @@ template <int R> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_
 		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
 		if (counted) atomicAdd(&a.stats[1], (u64)counted);
 		if (rejected) atomicAdd(&a.stats[2], (u64)rejected);
+		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
+	}
+}
+
+// ---- the partition path -------------------------------------------------------------------------------------------
+// hist[g][b] -> offs[g][b], the offset of workgroup g's records within bucket b, and btot[b], the bucket's size.  A
+// workgroup takes 64 buckets; its 16 waves split the rows g among them (every load is one contiguous 256-byte piece of a
+// row, and none depends on another).
+constexpr int kScanBuckets = 64;
+__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, int grid)
+{
+	__shared__ u32 part[16][kScanBuckets];
+	const int lb = threadIdx.x & (kScanBuckets - 1), grp = threadIdx.x / kScanBuckets;
+	const int b = blockIdx.x * kScanBuckets + lb;
+	const int per = (grid + 15) / 16;
+	const int g0 = grp * per, g1 = min(grid, g0 + per);
+	u32 sum = 0u;
+	for (int g = g0; g < g1; g++) sum += hist[(size_t)g * kSpillBuckets + b];
+	part[grp][lb] = sum;
+	__syncthreads();
+	u32 run = 0u;
+	for (int q = 0; q < grp; q++) run += part[q][lb];
+	if (grp == 15) btot[b] = run + sum;
+	for (int g = g0; g < g1; g++) {
+		const u32 v = hist[(size_t)g * kSpillBuckets + b];
+		offs[(size_t)g * kSpillBuckets + b] = run;
+		run += v;
+	}
+}
+
+// how many records the front kernel's workgroups wrote (every thread of the workgroup gets the sum)
+__device__ __forceinline__ u32 census_spill_total(const CensusSpill &sp, u32 *red)
+{
+	u32 v = 0u;
+	for (u32 g = threadIdx.x; g < sp.grid; g += blockDim.x) v += sp.wg_count[g];
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	u32 tot = 0u;
+	for (u32 w = 0; w < (blockDim.x + 63) / 64; w++) tot += red[w];
+	__syncthreads();
+	return tot;
+}
+
+// workgroup g moves its records to their buckets (every workgroup scans the 1024 bucket sizes for itself; the first one
+// leaves the bucket starts behind for census_combine_kernel).  A scattered 16-byte store per record is what the chip does
+// 30-60 G of per second, so a chunk of 8 192 records is first sorted by bucket in LDS: neighbouring lanes then write
+// neighbouring records of a bucket (8 on average: a 128-byte line).
+constexpr int kScatterChunk = 8192;
+constexpr int kScatterPer = kScatterChunk / 1024;
+constexpr size_t kScatterLds = (size_t)kScatterChunk * 16 + 4 * kSpillBuckets * sizeof(u32);
+__global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u64 mask)
+{
+	uint4 *stage = reinterpret_cast<uint4 *>(census_smem);
+	u32 *gofs = reinterpret_cast<u32 *>(stage + kScatterChunk);      // where the workgroup's next record of a bucket goes
+	u32 *lcnt = gofs + kSpillBuckets;                                // records per bucket in this chunk
+	u32 *loff = lcnt + kSpillBuckets;                                // where they begin in the sorted chunk (+ one scratch copy)
+	u32 *sc = loff + kSpillBuckets;
+	const int g = blockIdx.x;
+	const int b = threadIdx.x;
+	if (census_spill_total(sp, sc) > sp.direct_above) return;          // census_direct_kernel takes them
+	auto exclusive = [&](u32 mine) -> u32 {                          // over the 1024 threads; sc[kSpillBuckets - 1] = the total afterwards
+		sc[b] = mine;
+		__syncthreads();
+		for (int o = 1; o < kSpillBuckets; o <<= 1) {
+			const u32 add = b >= o ? sc[b - o] : 0u;
+			__syncthreads();
+			sc[b] += add;
+			__syncthreads();
+		}
+		return sc[b] - mine;
+	};
+	{
+		const u32 mine = sp.btot[b];
+		const u32 start = exclusive(mine);
+		gofs[b] = start + sp.offs[(size_t)g * kSpillBuckets + b];
+		if (g == 0) {
+			sp.bstart[b] = start;
+			if (b == kSpillBuckets - 1) sp.bstart[kSpillBuckets] = start + mine;
+		}
+	}
+	const u32 cnt = sp.wg_count[g];
+	const uint4 *key = sp.key + (size_t)g * sp.cap;
+	for (u32 c0 = 0; c0 < cnt; c0 += kScatterChunk) {
+		const u32 nc = min((u32)kScatterChunk, cnt - c0);
+		__syncthreads();
+		lcnt[b] = 0u;
+		__syncthreads();
+		uint4 rec[kScatterPer];
+		u32 bk[kScatterPer], rank[kScatterPer];
+#pragma unroll
+		for (int q = 0; q < kScatterPer; q++) {
+			const u32 i = (u32)q * 1024u + (u32)b;
+			if (i < nc) rec[q] = key[c0 + i];
+		}
+#pragma unroll
+		for (int q = 0; q < kScatterPer; q++) {
+			const u32 i = (u32)q * 1024u + (u32)b;
+			if (i < nc) {
+				const u32 h = census_hash(0xF0000000ull | ((u64)rec[q].x << 32), (u64)rec[q].y | ((u64)rec[q].z << 32));
+				bk[q] = (u32)(((u64)h & mask) >> sp.bucket_shift);
+				rank[q] = atomicAdd(&lcnt[bk[q]], 1u);
+			}
+		}
+		__syncthreads();
+		const u32 mine = lcnt[b];
+		const u32 start = exclusive(mine);
+		loff[b] = start;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < kScatterPer; q++) {
+			const u32 i = (u32)q * 1024u + (u32)b;
+			if (i < nc) stage[loff[bk[q]] + rank[q]] = rec[q];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < kScatterPer; q++) {
+			const u32 i = (u32)q * 1024u + (u32)b;
+			if (i < nc) {
+				const uint4 r = stage[i];
+				const u32 h = census_hash(0xF0000000ull | ((u64)r.x << 32), (u64)r.y | ((u64)r.z << 32));
+				const u32 bb = (u32)(((u64)h & mask) >> sp.bucket_shift);
+				sp.skey[gofs[bb] + (i - loff[bb])] = r;
+			}
+		}
+		__syncthreads();
+		gofs[b] += mine;
+	}
+}
+
+// workgroup b combines bucket b in an LDS table and inserts every distinct key once.  All its keys hash into ONE region of
+// the HBM table (1/1024 of it), so what the inserts touch stays in this XCD's L2 while the workgroup runs.
+constexpr int kCombineThreads = 512;
+__global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const CensusArgs a)
+{
+	__shared__ LdsTable lt_s;
+	__shared__ u32 red[kCombineThreads / 64];
+	LdsTable *lt = &lt_s;
+	const int tid = threadIdx.x;
+	if (census_spill_total(a.sp, red) > a.sp.direct_above) return;
+	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+	__syncthreads();
+	u32 claimed = 0, overflow = 0;
+	const u32 lo = a.sp.bstart[blockIdx.x], hi = a.sp.bstart[blockIdx.x + 1];
+	for (u32 i = lo + tid; i < hi; i += blockDim.x) {
+		const uint4 k = a.sp.skey[i];
+		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
+		const u64 first_inv = ~(u64)(a.row_base + k.w);
+		const u32 h = census_hash(klo, khi);
+		if (!lds_count(lt, h, klo, khi, 1u, first_inv)) {      // the hash's LOW bits: its high bits are the bucket's, the same for every key here
+			const u64 idx = (u64)h & a.mask;
+			if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, 1ull, first_inv, claimed)) overflow++;
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < kLdsSlots; i += blockDim.x) {
+		const u64 sk = lt->klo[i];
+		const u32 sc = lt->count[i];
+		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		claimed += __shfl_xor(claimed, o);
+		overflow += __shfl_xor(overflow, o);
+	}
+	if ((tid & 63) == 0) {
+		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
+		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
+	}
+}
+
+// When most rows of a launch were spilled there is little to combine (the keys hardly repeat): workgroup g inserts the
+// records of its region as they lie.
+__global__ __launch_bounds__(1024) void census_direct_kernel(const CensusArgs a)
+{
+	__shared__ u32 red[16];
+	if (census_spill_total(a.sp, red) <= a.sp.direct_above) return;
+	const u32 cnt = a.sp.wg_count[blockIdx.x];
+	const uint4 *key = a.sp.key + (size_t)blockIdx.x * a.sp.cap;
+	u32 claimed = 0, overflow = 0;
+	for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+		const uint4 k = key[i];
+		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
+		if (!census_insert(a.tab, a.mask, klo, khi, 1ull, ~(u64)(a.row_base + k.w), claimed)) overflow++;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		claimed += __shfl_xor(claimed, o);
+		overflow += __shfl_xor(overflow, o);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
 		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
 	}
 }
@@ -440,7 +714,26 @@ __global__ __launch_bounds__(256) void census_compact_kernel(const CensusSlot *t
 	}
 }
 
+// the instantiations: R tiles per step x dwords per row (2, 5, 8: barcodes of at most 8, 20, 31 characters) x spill
+constexpr int kCensusVariants = 4 * 3 * 2;
+static const void *census_variant(int v)
+{
+	static const void *const tab[kCensusVariants] = {
+		(const void *)census_kernel<1, 2, false>, (const void *)census_kernel<1, 2, true>, (const void *)census_kernel<1, 5, false>, (const void *)census_kernel<1, 5, true>,
+		(const void *)census_kernel<1, 8, false>, (const void *)census_kernel<1, 8, true>,
+		(const void *)census_kernel<2, 2, false>, (const void *)census_kernel<2, 2, true>, (const void *)census_kernel<2, 5, false>, (const void *)census_kernel<2, 5, true>,
+		(const void *)census_kernel<2, 8, false>, (const void *)census_kernel<2, 8, true>,
+		(const void *)census_kernel<3, 2, false>, (const void *)census_kernel<3, 2, true>, (const void *)census_kernel<3, 5, false>, (const void *)census_kernel<3, 5, true>,
+		(const void *)census_kernel<3, 8, false>, (const void *)census_kernel<3, 8, true>,
+		(const void *)census_kernel<4, 2, false>, (const void *)census_kernel<4, 2, true>, (const void *)census_kernel<4, 5, false>, (const void *)census_kernel<4, 5, true>,
+		(const void *)census_kernel<4, 8, false>, (const void *)census_kernel<4, 8, true>,
+	};
+	return tab[v];
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
+
+static void census_spill_free(Census *cs);
 
 static hipError_t census_alloc_table(Census *cs, u64 slots, hipStream_t st)
 {
@@ -461,10 +754,9 @@ hipError_t census_create(Census **out, hipStream_t st)
 		if (lg >= 10 && lg <= 32) init_slots = 1ull << lg;
 	}
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	for (int v = 0; v < kCensusVariants; v++)
+		if (e == hipSuccess) e = hipFuncSetAttribute(census_variant(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLds);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
 	*out = cs;
 	return hipSuccess;
@@ -476,6 +768,7 @@ void census_destroy(Census *cs)
 	if (cs->tab) (void)hipFree(cs->tab);
 	if (cs->stats) (void)hipFree(cs->stats);
 	if (cs->scratch) (void)hipFree(cs->scratch);
+	census_spill_free(cs);
 	delete cs;
 }
 
@@ -519,6 +812,38 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 	return e;
 }
 
+static void census_spill_free(Census *cs)
+{
+	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count};
+	for (void *q : ptrs) if (q) (void)hipFree(q);
+	cs->sp = CensusSpill();
+	cs->sp_records = 0;
+	cs->sp_grid = 0;
+}
+
+// room for `grid` workgroup regions of `cap` records each (32 B per record: as spilled and as sorted)
+static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
+{
+	const size_t records = (size_t)grid * cap;
+	if (records <= cs->sp_records && grid <= cs->sp_grid) return hipSuccess;
+	const size_t want_records = std::max(records, cs->sp_records);
+	const int want_grid = std::max(grid, cs->sp_grid);
+	census_spill_free(cs);
+	hipError_t e = hipMalloc((void **)&cs->sp.key, want_records * sizeof(uint4));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.skey, want_records * sizeof(uint4));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.hist, (size_t)want_grid * kSpillBuckets * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.offs, (size_t)want_grid * kSpillBuckets * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.btot, kSpillBuckets * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.bstart, (kSpillBuckets + 1) * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_count, (size_t)want_grid * sizeof(u32));
+	if (e != hipSuccess) { (void)hipGetLastError(); census_spill_free(cs); return e; }
+	cs->sp_records = want_records;
+	cs->sp_grid = want_grid;
+	return hipSuccess;
+}
+
+constexpr int64_t kSpillMinRows = 1 << 21;      // smaller launches insert directly: the partition path is three more kernels
+
 hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
                       int n_cu, hipStream_t st)
 {
@@ -528,7 +853,13 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
 	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
-	const size_t lds = sizeof(LdsTable) + 256 + (size_t)kCensusWaves * tile_slot + 64;      // + slack: a row is read as 9 dwords
+	const size_t lds = sizeof(LdsTable) + (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32);      // + slack: a row is read as 9 dwords; the spill counters
+	int wgs_per_cu = 1;
+	if (const char *ev = getenv("SK_CENSUS_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= 4) wgs_per_cu = v; }      // experiments
+	int direct_pct = 50;                                    // SK_CENSUS_SPILL_MAX_PCT: more spilled rows than this share of a launch are inserted directly
+	if (const char *ev = getenv("SK_CENSUS_SPILL_MAX_PCT")) { const int v = atoi(ev); if (v >= 0 && v <= 100) direct_pct = v; }
+	int spill_mode = -1;                                    // SK_CENSUS_SPILL=0/1: never / always (tests, experiments)
+	if (const char *ev = getenv("SK_CENSUS_SPILL")) spill_mode = atoi(ev) != 0;
 	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
 	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
 	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) chunk = (int64_t)1 << lg; }
@@ -564,13 +895,34 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.mask = cs->slots - 1;
 		a.stats = cs->stats;
 		const int64_t groups = (nr + (int64_t)64 * R * kCensusWaves - 1) / ((int64_t)64 * R * kCensusWaves);
-		int grid = n_cu;
+		int grid = n_cu * wgs_per_cu;
 		if (grid > groups) grid = (int)groups;
-		switch (R) {
-		case 1: census_kernel<1><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
-		case 2: census_kernel<2><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
-		case 3: census_kernel<3><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
-		default: census_kernel<4><<<grid, kCensusWaves * 64, lds, st>>>(a, tile_slot); break;
+		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= kSpillMinRows : spill_mode != 0);
+		a.sp = CensusSpill();
+		if (spill) {
+			const int64_t nsteps = (nr + (int64_t)64 * R - 1) / ((int64_t)64 * R);
+			const int64_t per_wave = (nsteps + (int64_t)grid * kCensusWaves - 1) / ((int64_t)grid * kCensusWaves);
+			const int64_t cap = per_wave * kCensusWaves * R * 64;
+			e = cap < (1 << 26) ? census_spill_reserve(cs, grid, (u32)cap) : hipErrorInvalidValue;
+			if (e != hipSuccess) { (void)hipGetLastError(); spill = false; }      // no room for the records: insert directly
+			else {
+				a.sp = cs->sp;
+				a.sp.cap = (u32)cap;
+				a.sp.grid = (u32)grid;
+				a.sp.direct_above = (u32)((uint64_t)nr * (uint64_t)direct_pct / 100);
+				int lg = 0;
+				while ((1ull << lg) < cs->slots) lg++;
+				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
+			}
+		}
+		const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
+		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
+		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot);
+		if (spill) {
+			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, grid);
+			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
+			census_combine_kernel<<<kSpillBuckets, kCombineThreads, 0, st>>>(a);
+			census_direct_kernel<<<grid, 1024, 0, st>>>(a);
 		}
 		e = hipGetLastError();
 		if (e != hipSuccess) return e;
@@ -626,16 +978,17 @@ hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint
 	std::vector<u64> order(got);
 	for (u64 i = 0; i < got; i++) order[i] = i;
 	std::sort(order.begin(), order.end(), [&](u64 x, u64 y) { return raw[x * 4 + 3] > raw[y * 4 + 3]; });   // first_inv descending = first ascending
-	static const char kAlphabet[] = "\0ACGTNacgtn+????";
 	for (u64 i = 0; i < got; i++) {
 		const u64 *r = &raw[order[i] * 4];
 		const u64 klo = r[0], khi = ~r[1];
+		const u32 kw[4] = {(u32)(klo >> 32), (u32)khi, (u32)(khi >> 32), (u32)klo};
 		CensusEntry &en = out[i];
 		memset(en.barcode, 0, sizeof en.barcode);
 		for (int j = 0; j < 31; j++) {
-			const u32 c = (u32)((j < 15 ? klo >> (4 * (j + 1)) : khi >> (4 * (j - 15))) & 15u);
+			const int q = j >> 2, b = j & 3;
+			const u32 c = (kw[q >> 1] >> (8 * b + 4 * (q & 1))) & 15u;
 			if (c == 0) break;
-			en.barcode[j] = kAlphabet[c];
+			en.barcode[j] = kCensusAlphabet[c];
 		}
 		en.count = r[2];
 		en.first_row = (int64_t)~r[3];

@@ -83,7 +83,7 @@ int main()
 	CK(hipMalloc(&d_sum, 8));
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	for (int lg = 16; lg <= 26; lg += 5) {
+	for (int lg : {13, 16, 18, 21, 26}) {
 		const u64 slots = 1ull << lg;
 		u64 *tab;
 		CK(hipMalloc(&tab, slots * 32 * 8));
