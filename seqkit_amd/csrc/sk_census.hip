@@ -48,6 +48,7 @@ struct CensusSpill {
 	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket
 	u32 *bstart = nullptr;       // [kSpillBuckets + 1]
 	u32 *wg_count = nullptr;     // [grid]
+	u32 *work = nullptr;         // census_combine_kernel's item counter (zeroed by census_scan_kernel)
 	u32 cap = 0;                 // records per workgroup region
 	u32 bucket_shift = 0;        // bucket = (hash & mask) >> bucket_shift
 	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not partitioned
@@ -71,7 +72,7 @@ constexpr u64 kInitialSlots = 1ull << 26;   // 2 GiB of the 288: one launch may 
 constexpr int64_t kCensusChunk = 1 << 25;   // most rows per launch; the table is grown between launches so that it is never
 constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
 constexpr int kLdsSlots = 2048;
-constexpr int kLdsProbes = 4;
+constexpr int kLdsProbes = 3;
 constexpr u32 kMaxProbes = 1u << 16;
 
 // The workgroup's front table, one array per field: slot i of a u64 array lies in bank pair i mod 32, so the 64 probes of a
@@ -237,6 +238,16 @@ __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi
 {
 	const u64 want = ~khi;
 	u32 idx = at & (kLdsSlots - 1);
+	{	// the common case, without the loop's bookkeeping: the key sits in its home slot (three loads in flight together)
+		const u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const u64 f = __hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (k == klo && v == want) {
+			atomicAdd(&lt->count[idx], cnt);
+			if (f < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
+			return true;
+		}
+	}
 	for (int p = 0; p < kLdsProbes;) {
 		u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (k == 0) {
@@ -489,8 +500,9 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 // workgroup takes 64 buckets; its 16 waves split the rows g among them (every load is one contiguous 256-byte piece of a
 // row, and none depends on another).
 constexpr int kScanBuckets = 64;
-__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, int grid)
+__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, u32 *__restrict__ work, int grid)
 {
+	if (blockIdx.x == 0 && threadIdx.x == 0) *work = 0u;
 	__shared__ u32 part[16][kScanBuckets];
 	const int lb = threadIdx.x & (kScanBuckets - 1), grp = threadIdx.x / kScanBuckets;
 	const int b = blockIdx.x * kScanBuckets + lb;
@@ -610,35 +622,68 @@ __global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u6
 	}
 }
 
-// workgroup b combines bucket b in an LDS table and inserts every distinct key once.  All its keys hash into ONE region of
-// the HBM table (1/1024 of it), so what the inserts touch stays in this XCD's L2 while the workgroup runs.
+// Combine the buckets in LDS tables and insert every distinct key once.  All keys of a bucket hash into ONE region of the
+// HBM table (1/1024 of it).  A work item is at most kCombineChunk records of one bucket — a bucket that holds a frequent
+// key (one that some front table had no room for) is split among workgroups, since what they add is additive — and the
+// workgroups take items from a counter until none is left.
 constexpr int kCombineThreads = 512;
+constexpr int kCombineChunk = 8192;
 __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const CensusArgs a)
 {
 	__shared__ LdsTable lt_s;
+	__shared__ u32 cpre[kSpillBuckets + 1];                            // items before bucket b
 	__shared__ u32 red[kCombineThreads / 64];
+	__shared__ u32 item_s;
 	LdsTable *lt = &lt_s;
 	const int tid = threadIdx.x;
 	if (census_spill_total(a.sp, red) > a.sp.direct_above) return;
-	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
-	__syncthreads();
-	u32 claimed = 0, overflow = 0;
-	const u32 lo = a.sp.bstart[blockIdx.x], hi = a.sp.bstart[blockIdx.x + 1];
-	for (u32 i = lo + tid; i < hi; i += blockDim.x) {
-		const uint4 k = a.sp.skey[i];
-		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-		const u64 first_inv = ~(u64)(a.row_base + k.w);
-		const u32 h = census_hash(klo, khi);
-		if (!lds_count(lt, h, klo, khi, 1u, first_inv)) {      // the hash's LOW bits: its high bits are the bucket's, the same for every key here
-			const u64 idx = (u64)h & a.mask;
-			if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, 1ull, first_inv, claimed)) overflow++;
+	{	// items per bucket, scanned (two buckets per thread)
+		const u32 c0 = (a.sp.bstart[2 * tid + 1] - a.sp.bstart[2 * tid] + kCombineChunk - 1) / kCombineChunk;
+		const u32 c1 = (a.sp.bstart[2 * tid + 2] - a.sp.bstart[2 * tid + 1] + kCombineChunk - 1) / kCombineChunk;
+		u32 *sc = reinterpret_cast<u32 *>(lt);
+		sc[tid] = c0 + c1;
+		__syncthreads();
+		for (int o = 1; o < kCombineThreads; o <<= 1) {
+			const u32 add = tid >= o ? sc[tid - o] : 0u;
+			__syncthreads();
+			sc[tid] += add;
+			__syncthreads();
 		}
+		const u32 before = sc[tid] - (c0 + c1);
+		cpre[2 * tid] = before;
+		cpre[2 * tid + 1] = before + c0;
+		if (tid == kCombineThreads - 1) cpre[kSpillBuckets] = before + c0 + c1;
+		__syncthreads();
 	}
-	__syncthreads();
-	for (int i = tid; i < kLdsSlots; i += blockDim.x) {
-		const u64 sk = lt->klo[i];
-		const u32 sc = lt->count[i];
-		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
+	const u32 items = cpre[kSpillBuckets];
+	u32 claimed = 0, overflow = 0;
+	for (;;) {
+		__syncthreads();
+		if (tid == 0) item_s = atomicAdd(a.sp.work, 1u);
+		for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+		__syncthreads();
+		const u32 item = item_s;
+		if (item >= items) break;
+		int b = 0;                                                     // the last bucket with cpre[b] <= item
+		for (int o = kSpillBuckets / 2; o > 0; o >>= 1) if (cpre[b + o] <= item) b += o;
+		const u32 lo = a.sp.bstart[b] + (item - cpre[b]) * kCombineChunk;
+		const u32 hi = min(a.sp.bstart[b + 1], lo + kCombineChunk);
+		for (u32 i = lo + tid; i < hi; i += blockDim.x) {
+			const uint4 k = a.sp.skey[i];
+			const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
+			const u64 first_inv = ~(u64)(a.row_base + k.w);
+			const u32 h = census_hash(klo, khi);
+			if (!lds_count(lt, h, klo, khi, 1u, first_inv)) {      // the hash's LOW bits: its high bits are the bucket's, the same for every key here
+				const u64 idx = (u64)h & a.mask;
+				if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, 1ull, first_inv, claimed)) overflow++;
+			}
+		}
+		__syncthreads();
+		for (int i = tid; i < kLdsSlots; i += blockDim.x) {
+			const u64 sk = lt->klo[i];
+			const u32 sc = lt->count[i];
+			if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
+		}
 	}
 	for (int o = 32; o > 0; o >>= 1) {
 		claimed += __shfl_xor(claimed, o);
@@ -814,7 +859,7 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 
 static void census_spill_free(Census *cs)
 {
-	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count};
+	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count, cs->sp.work};
 	for (void *q : ptrs) if (q) (void)hipFree(q);
 	cs->sp = CensusSpill();
 	cs->sp_records = 0;
@@ -836,6 +881,7 @@ static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.btot, kSpillBuckets * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.bstart, (kSpillBuckets + 1) * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_count, (size_t)want_grid * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.work, sizeof(u32));
 	if (e != hipSuccess) { (void)hipGetLastError(); census_spill_free(cs); return e; }
 	cs->sp_records = want_records;
 	cs->sp_grid = want_grid;
@@ -919,9 +965,9 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
 		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot);
 		if (spill) {
-			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, grid);
+			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid);
 			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
-			census_combine_kernel<<<kSpillBuckets, kCombineThreads, 0, st>>>(a);
+			census_combine_kernel<<<2 * n_cu, kCombineThreads, 0, st>>>(a);
 			census_direct_kernel<<<grid, 1024, 0, st>>>(a);
 		}
 		e = hipGetLastError();

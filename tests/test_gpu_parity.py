@@ -918,7 +918,21 @@ def random_barcodes(n, L, stride, n_hot, hot_frac, seed, alphabet=b"ACGTN"):
     return m
 
 
-def test_census_small_known(ctx, oracle):
+@pytest.fixture(params=["direct", "partition", "spilled_direct"])
+def census_path(request, monkeypatch):
+    """The three ways a launch can take (sk_census.hip, census_add): keys the front tables have no room for are inserted by
+    the front kernel itself (small launches), or written out and then partitioned + combined per table region, or — when
+    most rows were written out — inserted as they lie.  Large launches choose between the last two by themselves; the
+    environment forces each here so that the small cases below walk all of them."""
+    if request.param == "direct":
+        monkeypatch.setenv("SK_CENSUS_SPILL", "0")
+    else:
+        monkeypatch.setenv("SK_CENSUS_SPILL", "1")
+        monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "100" if request.param == "partition" else "0")
+    return request.param
+
+
+def test_census_small_known(ctx, oracle, census_path):
     bc = census_rows([b"ACGT", b"ACG", b"ACGT", b"", b"TTTTTTTT", b"ACG", b"acgtn+AC", b"ACGT"], 8)
     ctx.census_reset()
     ctx.census_add(bc)
@@ -939,7 +953,7 @@ def test_census_small_known(ctx, oracle):
 
 @pytest.mark.parametrize("n,L,stride,n_hot,hot_frac", [(1, 8, 8, 1, 0.0), (255, 17, 17, 4, 0.5), (70000, 17, 24, 96, 0.9),
                                                        (300000, 8, 8, 96, 0.5), (200000, 31, 32, 10, 0.2), (100000, 6, 16, 3, 0.0)])
-def test_census_matches_oracle(ctx, oracle, n, L, stride, n_hot, hot_frac):
+def test_census_matches_oracle(ctx, oracle, census_path, n, L, stride, n_hot, hot_frac):
     bc = random_barcodes(n, L, stride, n_hot, hot_frac, seed=n + L, alphabet=b"ACGTNacgtn+")
     ctx.census_reset()
     ctx.census_add(bc, L=L)
@@ -951,7 +965,7 @@ def test_census_matches_oracle(ctx, oracle, n, L, stride, n_hot, hot_frac):
 
 
 @pytest.mark.parametrize("stride", [8, 20, 21, 26, 27, 40, 41, 64])
-def test_census_every_step_shape(ctx, oracle, stride):
+def test_census_every_step_shape(ctx, oracle, census_path, stride):
     """A wave step is 4, 3, 2 or 1 tiles of 64 rows depending on the row pitch (5 KiB per step): row counts around the
     tile, step and workgroup boundaries of each, with and without assignment codes, ragged barcodes."""
     L = min(stride, 31)
@@ -973,7 +987,7 @@ def test_census_every_step_shape(ctx, oracle, stride):
             assert ctx.census_stats()["counted"] == (n if asg is None else int((asg == -1).sum()))
 
 
-def test_census_only_unassigned_rows_batches_and_row_base(ctx, oracle):
+def test_census_only_unassigned_rows_batches_and_row_base(ctx, oracle, census_path):
     """The dry-run use (src/fasta_demultiplex.rs:190): only reads with no sample within max_diff are counted; fed in
     batches, in any order, the first-seen index is still the smallest global row."""
     n = 50000
@@ -992,7 +1006,7 @@ def test_census_only_unassigned_rows_batches_and_row_base(ctx, oracle):
     assert ctx.census_stats()["counted"] == int((assign == -1).sum())
 
 
-def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle):
+def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle, census_path):
     bc = census_rows([b"ACGT", b"AC-T", b"ACGU", b"ACGT", b"AC\0XX"], 5)       # bytes after the first NUL are padding
     ctx.census_reset()
     ctx.census_add(bc, L=5)
@@ -1002,6 +1016,36 @@ def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle):
     from seqkit_amd.capi import SeqkitHipError
     with pytest.raises(SeqkitHipError):
         ctx.census_add(np.zeros((4, 40), dtype=np.uint8), L=32)
+
+
+@pytest.mark.parametrize("shape", ["noisy", "one_hot_key", "mostly_new"])
+def test_census_large_launch(ctx, oracle, shape):
+    """Launches of 2 M rows and more take the partition path by themselves: a noisy dual-index run (keys repeat: partitioned
+    and combined), a run where ONE barcode is a third of all rows yet cannot be in any front table (its bucket is split among
+    workgroups) and a run of mostly new keys (more than half the rows are written out: inserted as they lie)."""
+    n = 2_300_000
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    if shape == "noisy":
+        bc, _ = synth.observe_barcodes(table, n, seed=12, halves=2)
+    else:
+        rng = np.random.default_rng(5)
+        alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+        bc = np.zeros((n, 17), dtype=np.uint8)
+        bc[:, :17] = alpha[rng.integers(0, 4, size=(n, 17))]                   # new keys throughout ...
+        if shape == "one_hot_key":
+            few = alpha[rng.integers(0, 4, size=(5000, 17))]                   # ... or 5 000 keys: more than a front table holds,
+            bc[:, :17] = few[rng.integers(0, 5000, size=n)]
+            bc[rng.random(n) < 0.33] = np.frombuffer(b"GATTACAG+CATCATCA", dtype=np.uint8)      # and one that is everywhere — but first seen
+            bc[:300000, :17] = few[rng.integers(0, 5000, size=300000)]         # only after the front tables have filled up
+    ctx.census_reset()
+    ctx.census_add(bc, L=17)
+    got, total = ctx.census_entries(min_count=2 if shape == "mostly_new" else 1)
+    want = oracle.census(bc, L=17)
+    if shape == "mostly_new":
+        want = [w for w in want if w[1] >= 2]
+    assert total == len(want) and got == want
+    st = ctx.census_stats()
+    assert st["counted"] == n and st["rejected"] == 0
 
 
 def test_census_grows_past_its_first_table(oracle, monkeypatch):
