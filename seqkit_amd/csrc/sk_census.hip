@@ -888,7 +888,7 @@ static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
 	return hipSuccess;
 }
 
-constexpr int64_t kSpillMinRows = 1 << 21;      // smaller launches insert directly: the partition path is three more kernels
+constexpr int64_t kSpillMinRows = 12 << 20;     // smaller launches insert directly: the partition path is four more kernels and pays from about 8 M rows (measured, tools/census_rates.py)
 
 hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
                       int n_cu, hipStream_t st)
@@ -904,6 +904,8 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= 4) wgs_per_cu = v; }      // experiments
 	int direct_pct = 50;                                    // SK_CENSUS_SPILL_MAX_PCT: more spilled rows than this share of a launch are inserted directly
 	if (const char *ev = getenv("SK_CENSUS_SPILL_MAX_PCT")) { const int v = atoi(ev); if (v >= 0 && v <= 100) direct_pct = v; }
+	int64_t spill_min_rows = kSpillMinRows;                 // SK_CENSUS_SPILL_MIN_ROWS_LOG2: tests lower it
+	if (const char *ev = getenv("SK_CENSUS_SPILL_MIN_ROWS_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) spill_min_rows = (int64_t)1 << lg; }
 	int spill_mode = -1;                                    // SK_CENSUS_SPILL=0/1: never / always (tests, experiments)
 	if (const char *ev = getenv("SK_CENSUS_SPILL")) spill_mode = atoi(ev) != 0;
 	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
@@ -943,7 +945,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		const int64_t groups = (nr + (int64_t)64 * R * kCensusWaves - 1) / ((int64_t)64 * R * kCensusWaves);
 		int grid = n_cu * wgs_per_cu;
 		if (grid > groups) grid = (int)groups;
-		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= kSpillMinRows : spill_mode != 0);
+		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
 		a.sp = CensusSpill();
 		if (spill) {
 			const int64_t nsteps = (nr + (int64_t)64 * R - 1) / ((int64_t)64 * R);

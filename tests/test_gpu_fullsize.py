@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5", "cfg4"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5", "census", "cfg4"])
 def test_baseline_config_at_full_size(hip_lib, oracle, cfg):
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fullsize_check.py"), cfg], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=900, cwd=REPO)

@@ -1019,10 +1019,11 @@ def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle, census_path
 
 
 @pytest.mark.parametrize("shape", ["noisy", "one_hot_key", "mostly_new"])
-def test_census_large_launch(ctx, oracle, shape):
-    """Launches of 2 M rows and more take the partition path by themselves: a noisy dual-index run (keys repeat: partitioned
+def test_census_large_launch(ctx, oracle, monkeypatch, shape):
+    """Large launches (12 M rows and more; 2 M here) take the partition path by themselves: a noisy dual-index run (keys repeat: partitioned
     and combined), a run where ONE barcode is a third of all rows yet cannot be in any front table (its bucket is split among
     workgroups) and a run of mostly new keys (more than half the rows are written out: inserted as they lie)."""
+    monkeypatch.setenv("SK_CENSUS_SPILL_MIN_ROWS_LOG2", "21")
     n = 2_300_000
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     if shape == "noisy":

@@ -3,7 +3,8 @@
 the oracle finishes in seconds (cfg 2, cfg 3, cfg 5 by construction), and through size-independent properties where it does not
 (cfg 4's per-GPU shard of 62.5 M clusters: tiling independence, idempotence of the mask, counter identities, an exact
 oracle comparison of a sample).  Run by tests/test_gpu_fullsize.py in its own process (torch must load its HIP runtime first).
-usage: python tools/fullsize_check.py [cfg2] [cfg3] [cfg4] [cfg5]"""
+The barcode census (row f3) rides along at a launch size that takes its partition path by itself.
+usage: python tools/fullsize_check.py [cfg2] [cfg3] [cfg4] [cfg5] [census]"""
 import os
 import sys
 import time
@@ -19,7 +20,7 @@ from seqkit_amd import synth  # noqa: E402
 
 dev = torch.device("cuda", 0)
 ctx = seqkit_amd.Context(0)
-which = set(sys.argv[1:]) or {"cfg2", "cfg3", "cfg4", "cfg5"}
+which = set(sys.argv[1:]) or {"cfg2", "cfg3", "cfg4", "cfg5", "census"}
 
 
 def to_dev(a):
@@ -188,8 +189,42 @@ def cfg5():
           flush=True)
 
 
+def census():
+    """f3 at 32 M rows in one launch (large launches write the keys their front tables have no room for out, partition and
+    combine them): 32 repeats of a 1 M-row noisy dual-index unit, so every count is 32 x the oracle's for the unit and every
+    first row is the unit's; then 16 M rows of which more than half are new keys (those are inserted as they lie)."""
+    unit, reps = 1_000_000, 32
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc, _ = synth.observe_barcodes(table, unit, seed=4, halves=2)
+    d = to_dev(bc).repeat(reps, 1).contiguous()
+    ctx.census_reset()
+    ctx.census_add_dev(d.data_ptr(), 17, 17, unit * reps, 0, 0)
+    want = oracle.census(bc, L=17)
+    got, total = ctx.census_entries()
+    st = ctx.census_stats()
+    assert total == len(want) and got == [(b, c * reps, f) for b, c, f in want] and st["counted"] == unit * reps and st["rejected"] == 0
+    n2 = 16_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    codes = torch.randint(0, 4, (n2, 12), device=dev, generator=g, dtype=torch.int64)      # 16.7 M possible 12-mers: most rows new, many twice
+    rnd = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[codes].contiguous()
+    ctx.census_reset()
+    ctx.census_add_dev(rnd.data_ptr(), 12, 12, n2, 0, 0)
+    vals = (codes << (2 * torch.arange(12, device=dev))).sum(dim=1)
+    uniq, counts = torch.unique(vals, return_counts=True)
+    st = ctx.census_stats()
+    assert st["distinct"] == int(uniq.numel()) and st["counted"] == n2
+    hist = ctx.census_count_hist()
+    for b in range(6):
+        assert int(hist[b]) == int(((counts >= (1 << b)) & (counts < (2 << b))).sum()), b
+    top, _ = ctx.census_entries(min_count=int(counts.max()))
+    assert len(top) == int((counts == counts.max()).sum()) and all(c == int(counts.max()) for _, c, _ in top)
+    print(f"census ok: 32 M noisy rows == 32 x oracle(unit) ({len(want)} barcodes); 16 M random 12-mers: {int(uniq.numel())} distinct, count histogram and top entries as torch.unique has them",
+          flush=True)
+
+
 t0 = time.time()
-for name, fn in (("cfg2", cfg2), ("cfg3", cfg3), ("cfg5", cfg5), ("cfg4", cfg4)):
+for name, fn in (("cfg2", cfg2), ("cfg3", cfg3), ("cfg5", cfg5), ("census", census), ("cfg4", cfg4)):
     if name in which:
         fn()
         torch.cuda.empty_cache()
