@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in ONE session on the GPU box: bench line + kernel trace + PMC passes of the headline,
 # the N = 2 same-device line, the CLI's kernel trace, PMC of the lookup kernel and of trim alone, the rates of every tool, the
-# GPU test run.  usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
+# census kernels' trace and PMC, the GPU test run.  usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
 set -u
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,6 +14,8 @@ bash tools/profile_cli_demux.sh $TAG 2000000 > $OUT/cli_demux.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_lut_dual "demux_lut" tools/demux_one.py dual 10000000 > $OUT/lut_dual_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_lut_cfg3 "demux_lut" tools/demux_one.py cfg3 10000000 > $OUT/lut_cfg3_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_trim_uniform "tile_pass_kernel" tools/trim_one.py uniform 16000000 > $OUT/trim_uniform_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_census_noisy "census_" tools/census_one.py noisy 32000000 3 > $OUT/census_noisy_pmc.log 2>&1
+bash tools/census_trace.sh ${TAG}_census > $OUT/census_trace.log 2>&1
 {
   echo "== tools/rates.py"; python3 tools/rates.py 2>&1 | grep -v amdgpu.ids
   echo "== tools/demux_ab.py (DEMUX_DETAIL=1, forms default / table in the vector cache / no table)"
