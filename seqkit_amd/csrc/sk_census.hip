@@ -480,19 +480,26 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		const u32 sc = lt->count[i];
 		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 	}
-	// one atomic per wave and statistic
+	// one atomic per WORKGROUP and statistic: the waves of a launch end together, and 4 096 additions to one address are
+	// served one after the other (34 us of an 84 us launch of 1 M rows when every wave sent its own)
 	for (int o = 32; o > 0; o >>= 1) {
 		claimed += __shfl_xor(claimed, o);
 		counted += __shfl_xor(counted, o);
 		rejected += __shfl_xor(rejected, o);
 		overflow += __shfl_xor(overflow, o);
 	}
+	__syncthreads();                                                   // the LDS table is dead: its first words take the sums
+	u32 *wg_stats = reinterpret_cast<u32 *>(lt);
+	if (tid < kCensusStats) wg_stats[tid] = 0u;
+	__syncthreads();
 	if (lane == 0) {
-		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
-		if (counted) atomicAdd(&a.stats[1], (u64)counted);
-		if (rejected) atomicAdd(&a.stats[2], (u64)rejected);
-		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
+		if (claimed) atomicAdd(&wg_stats[0], claimed);
+		if (counted) atomicAdd(&wg_stats[1], counted);
+		if (rejected) atomicAdd(&wg_stats[2], rejected);
+		if (overflow) atomicAdd(&wg_stats[3], overflow);
 	}
+	__syncthreads();
+	if (tid < kCensusStats && wg_stats[tid] != 0u) atomicAdd(&a.stats[tid], (u64)wg_stats[tid]);
 }
 
 // ---- the partition path -------------------------------------------------------------------------------------------
@@ -622,6 +629,26 @@ __global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u6
 	}
 }
 
+// claimed / overflow of a workgroup's threads -> stats[0] / stats[3], one atomic per workgroup and statistic (red: two words
+// of LDS; every thread of the workgroup calls this)
+__device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 overflow, u32 *red)
+{
+	for (int o = 32; o > 0; o >>= 1) {
+		claimed += __shfl_xor(claimed, o);
+		overflow += __shfl_xor(overflow, o);
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) red[threadIdx.x] = 0u;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) {
+		if (claimed) atomicAdd(&red[0], claimed);
+		if (overflow) atomicAdd(&red[1], overflow);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && red[0] != 0u) atomicAdd(&stats[0], (u64)red[0]);
+	if (threadIdx.x == 1 && red[1] != 0u) atomicAdd(&stats[3], (u64)red[1]);
+}
+
 // Combine the buckets in LDS tables and insert every distinct key once.  All keys of a bucket hash into ONE region of the
 // HBM table (1/1024 of it).  A work item is at most kCombineChunk records of one bucket — a bucket that holds a frequent
 // key (one that some front table had no room for) is split among workgroups, since what they add is additive — and the
@@ -685,14 +712,7 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 			if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 		}
 	}
-	for (int o = 32; o > 0; o >>= 1) {
-		claimed += __shfl_xor(claimed, o);
-		overflow += __shfl_xor(overflow, o);
-	}
-	if ((tid & 63) == 0) {
-		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
-		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
-	}
+	census_add_stats(a.stats, claimed, overflow, red);
 }
 
 // When most rows of a launch were spilled there is little to combine (the keys hardly repeat): workgroup g inserts the
@@ -709,14 +729,7 @@ __global__ __launch_bounds__(1024) void census_direct_kernel(const CensusArgs a)
 		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
 		if (!census_insert(a.tab, a.mask, klo, khi, 1ull, ~(u64)(a.row_base + k.w), claimed)) overflow++;
 	}
-	for (int o = 32; o > 0; o >>= 1) {
-		claimed += __shfl_xor(claimed, o);
-		overflow += __shfl_xor(overflow, o);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		if (claimed) atomicAdd(&a.stats[0], (u64)claimed);
-		if (overflow) atomicAdd(&a.stats[3], (u64)overflow);
-	}
+	census_add_stats(a.stats, claimed, overflow, red);
 }
 
 // grow: re-insert every slot of the old table into the new one
