@@ -660,7 +660,8 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 	__shared__ LdsTable lt_s;
 	__shared__ u32 cpre[kSpillBuckets + 1];                            // items before bucket b
 	__shared__ u32 red[kCombineThreads / 64];
-	__shared__ u32 item_s;
+	__shared__ u32 item_s, nlist;
+	__shared__ uint16_t list[kLdsSlots];
 	LdsTable *lt = &lt_s;
 	const int tid = threadIdx.x;
 	if (census_spill_total(a.sp, red) > a.sp.direct_above) return;
@@ -706,10 +707,17 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 			}
 		}
 		__syncthreads();
-		for (int i = tid; i < kLdsSlots; i += blockDim.x) {
-			const u64 sk = lt->klo[i];
+		// the occupied slots first go to a list: an insert is three dependent round trips to HBM, and a wave that walks
+		// the table pays them in every one of its four rounds in which any of its lanes finds a key (24 us per item)
+		if (tid == 0) nlist = 0u;
+		__syncthreads();
+		for (int i = tid; i < kLdsSlots; i += blockDim.x)
+			if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
+		__syncthreads();
+		for (u32 j = tid; j < nlist; j += blockDim.x) {
+			const int i = list[j];
 			const u32 sc = lt->count[i];
-			if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
+			if (!census_insert(a.tab, a.mask, lt->klo[i], ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 		}
 	}
 	census_add_stats(a.stats, claimed, overflow, red);
