@@ -529,6 +529,36 @@ __global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict
 	}
 }
 
+// exclusive prefix sum of one value per thread over the workgroup (at most 16 waves): shuffles inside a wave, the wave sums
+// through LDS (ws: 17 words) — three barriers where the textbook loop over LDS has two per doubling
+__device__ __forceinline__ u32 census_block_exclusive(u32 mine, u32 *ws, u32 *total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+	u32 v = mine;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 t = __shfl_up(v, o);
+		if (lane >= o) v += t;
+	}
+	__syncthreads();                                                   // ws may still be read from an earlier call
+	if (lane == 63) ws[wave] = v;
+	__syncthreads();
+	if (wave == 0) {
+		const u32 w = lane < nw ? ws[lane] : 0u;
+		u32 x = w;
+#pragma unroll
+		for (int o = 1; o < 16; o <<= 1) {
+			const u32 t = __shfl_up(x, o);
+			if (lane >= o) x += t;
+		}
+		if (lane < nw) ws[lane] = x - w;
+		if (lane == nw - 1) ws[16] = x;
+	}
+	__syncthreads();
+	if (total) *total = ws[16];
+	return v - mine + ws[wave];
+}
+
 // how many records the front kernel's workgroups wrote (every thread of the workgroup gets the sum)
 __device__ __forceinline__ u32 census_spill_total(const CensusSpill &sp, u32 *red)
 {
@@ -560,17 +590,7 @@ __global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u6
 	const int g = blockIdx.x;
 	const int b = threadIdx.x;
 	if (census_spill_total(sp, sc) > sp.direct_above) return;          // census_direct_kernel takes them
-	auto exclusive = [&](u32 mine) -> u32 {                          // over the 1024 threads; sc[kSpillBuckets - 1] = the total afterwards
-		sc[b] = mine;
-		__syncthreads();
-		for (int o = 1; o < kSpillBuckets; o <<= 1) {
-			const u32 add = b >= o ? sc[b - o] : 0u;
-			__syncthreads();
-			sc[b] += add;
-			__syncthreads();
-		}
-		return sc[b] - mine;
-	};
+	auto exclusive = [&](u32 mine) -> u32 { return census_block_exclusive(mine, sc, nullptr); };
 	{
 		const u32 mine = sp.btot[b];
 		const u32 start = exclusive(mine);
@@ -668,16 +688,7 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 	{	// items per bucket, scanned (two buckets per thread)
 		const u32 c0 = (a.sp.bstart[2 * tid + 1] - a.sp.bstart[2 * tid] + kCombineChunk - 1) / kCombineChunk;
 		const u32 c1 = (a.sp.bstart[2 * tid + 2] - a.sp.bstart[2 * tid + 1] + kCombineChunk - 1) / kCombineChunk;
-		u32 *sc = reinterpret_cast<u32 *>(lt);
-		sc[tid] = c0 + c1;
-		__syncthreads();
-		for (int o = 1; o < kCombineThreads; o <<= 1) {
-			const u32 add = tid >= o ? sc[tid - o] : 0u;
-			__syncthreads();
-			sc[tid] += add;
-			__syncthreads();
-		}
-		const u32 before = sc[tid] - (c0 + c1);
+		const u32 before = census_block_exclusive(c0 + c1, reinterpret_cast<u32 *>(lt), nullptr);
 		cpre[2 * tid] = before;
 		cpre[2 * tid + 1] = before + c0;
 		if (tid == kCombineThreads - 1) cpre[kSpillBuckets] = before + c0 + c1;
