@@ -920,7 +920,8 @@ static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
 	return hipSuccess;
 }
 
-constexpr int64_t kSpillMinRows = 12 << 20;     // smaller launches insert directly: the partition path is four more kernels and pays from about 8 M rows (measured, tools/census_rates.py)
+constexpr int64_t kSpillMinRows = 1 << 23;      // smaller launches insert directly: the partition path is four more kernels; measured (tools/census_rates.py, noisy run,
+                                                // insert-in-place / partition): 4 M rows 0.168 / 0.176 ms, 8 M 0.279 / 0.228, 16 M 0.523 / 0.317, 32 M 0.96 / 0.52
 
 hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
                       int n_cu, hipStream_t st)

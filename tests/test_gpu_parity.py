@@ -1020,7 +1020,7 @@ def test_census_rejects_foreign_bytes_and_bad_arguments(ctx, oracle, census_path
 
 @pytest.mark.parametrize("shape", ["noisy", "one_hot_key", "mostly_new"])
 def test_census_large_launch(ctx, oracle, monkeypatch, shape):
-    """Large launches (12 M rows and more; 2 M here) take the partition path by themselves: a noisy dual-index run (keys repeat: partitioned
+    """Large launches (8 M rows and more; 2 M here) take the partition path by themselves: a noisy dual-index run (keys repeat: partitioned
     and combined), a run where ONE barcode is a third of all rows yet cannot be in any front table (its bucket is split among
     workgroups) and a run of mostly new keys (more than half the rows are written out: inserted as they lie)."""
     monkeypatch.setenv("SK_CENSUS_SPILL_MIN_ROWS_LOG2", "21")
