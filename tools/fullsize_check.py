@@ -203,6 +203,20 @@ def census():
     got, total = ctx.census_entries()
     st = ctx.census_stats()
     assert total == len(want) and got == [(b, c * reps, f) for b, c, f in want] and st["counted"] == unit * reps and st["rejected"] == 0
+    # the dry-run shape at a row pitch of 24 (three tiles per wave step): only the rows demultiplexing left unassigned
+    ctx.set_barcodes(table, 1)
+    unit_assign = oracle.demux_batch(table, bc, 1)[0]
+    wide = np.zeros((unit, 24), dtype=np.uint8)
+    wide[:, :17] = bc
+    wide[:, 17:] = np.frombuffer(b"#", dtype=np.uint8)                         # what lies beyond L is not looked at
+    dw = to_dev(wide).repeat(reps, 1).contiguous()
+    da = to_dev(unit_assign.astype(np.int32)).repeat(reps).contiguous()
+    ctx.census_reset()
+    ctx.census_add_dev(dw.data_ptr(), 24, 17, unit * reps, da.data_ptr(), 1000)
+    want = oracle.census(bc, L=17, assign=unit_assign)
+    got, total = ctx.census_entries()
+    assert total == len(want) and got == [(b, c * reps, f + 1000) for b, c, f in want] and ctx.census_stats()["counted"] == reps * int((unit_assign == -1).sum())
+    del dw, da
     n2 = 16_000_000
     g = torch.Generator(device=dev)
     g.manual_seed(7)
@@ -219,7 +233,7 @@ def census():
         assert int(hist[b]) == int(((counts >= (1 << b)) & (counts < (2 << b))).sum()), b
     top, _ = ctx.census_entries(min_count=int(counts.max()))
     assert len(top) == int((counts == counts.max()).sum()) and all(c == int(counts.max()) for _, c, _ in top)
-    print(f"census ok: 32 M noisy rows == 32 x oracle(unit) ({len(want)} barcodes); 16 M random 12-mers: {int(uniq.numel())} distinct, count histogram and top entries as torch.unique has them",
+    print(f"census ok: 32 M noisy rows == 32 x oracle(unit), every row and (pitch 24, row_base 1000) the unassigned ones ({len(want)} barcodes); 16 M random 12-mers: {int(uniq.numel())} distinct, count histogram and top entries as torch.unique has them",
           flush=True)
 
 
