@@ -1049,6 +1049,54 @@ def test_census_large_launch(ctx, oracle, monkeypatch, shape):
     assert st["counted"] == n and st["rejected"] == 0
 
 
+@pytest.mark.parametrize("L,stride", [(4, 4), (7, 9), (17, 17), (24, 24), (31, 32)])
+def test_census_every_byte_value_at_every_position(ctx, oracle, census_path, L, stride):
+    """The key is built four characters at a time with packed-byte arithmetic (sk_census.hip, census_classify): every byte
+    value at every position of the barcode (so at every byte of a dword, at every alignment of the row in the tile) — counted
+    iff it is one of "ACGTNacgtn+", a NUL ends the barcode, anything else rejects the row."""
+    rng = np.random.default_rng(L)
+    alpha = np.frombuffer(b"ACGTNacgtn+", dtype=np.uint8)
+    rows = []
+    for pos in range(L):
+        base = alpha[rng.integers(0, len(alpha), size=(256, L))]
+        base[:, pos] = np.arange(256, dtype=np.uint8)
+        rows.append(base)
+    bc = np.zeros((256 * L, stride), dtype=np.uint8)
+    bc[:, :L] = np.concatenate(rows)
+    bc[:, L:] = 0x7F                                        # what lies beyond L is never looked at
+    ok = np.isin(np.arange(256, dtype=np.uint8), np.concatenate([alpha, np.zeros(1, np.uint8)]))
+    valid = np.tile(ok, L)                                  # the rows the device counts (the hosts count the others themselves)
+    ctx.census_reset()
+    ctx.census_add(bc, L=L)
+    got, total = ctx.census_entries()
+    want = oracle.census(bc, L=L, assign=np.where(valid, -1, 0).astype(np.int32))
+    st = ctx.census_stats()
+    assert total == len(want) and got == want
+    assert st["rejected"] == L * (256 - len(alpha) - 1) and st["counted"] == L * (len(alpha) + 1)
+
+
+def test_census_anything_after_the_first_nul_is_padding(ctx, oracle, census_path):
+    """A NUL at every position, followed by bytes of every kind (other NULs, bytes outside the alphabet, letters): the barcode
+    is what precedes the first NUL, whatever follows (src/fasta_demultiplex.rs:190 counts the header's barcode string; the
+    matrix rows are NUL-padded by the packer, but the C-ABI does not ask for clean padding)."""
+    L, stride, n = 23, 27, 6000
+    rng = np.random.default_rng(9)
+    alpha = np.frombuffer(b"ACGTNacgtn+", dtype=np.uint8)
+    bc = np.zeros((n, stride), dtype=np.uint8)
+    bc[:, :L] = alpha[rng.integers(0, len(alpha), size=(n, L))]
+    cut = rng.integers(0, L, size=n)
+    for r in range(n):
+        bc[r, cut[r]] = 0
+        bc[r, cut[r] + 1:] = rng.integers(0, 256, size=stride - cut[r] - 1)
+    bc[::7, :L] = alpha[rng.integers(0, len(alpha), size=(len(bc[::7]), L))]      # and rows without a NUL among them
+    ctx.census_reset()
+    ctx.census_add(bc, L=L)
+    got, total = ctx.census_entries()
+    want = oracle.census(bc, L=L)
+    assert total == len(want) and got == want
+    assert ctx.census_stats()["rejected"] == 0 and ctx.census_stats()["counted"] == n
+
+
 def test_census_grows_past_its_first_table(oracle, monkeypatch):
     """More distinct barcodes than half the table: it is rehashed between launches, nothing is lost.  (The first table
     normally has 2^26 slots; a context created with SK_CENSUS_SLOTS_LOG2=16 starts small.)"""
