@@ -1097,6 +1097,51 @@ def test_census_anything_after_the_first_nul_is_padding(ctx, oracle, census_path
     assert ctx.census_stats()["rejected"] == 0 and ctx.census_stats()["counted"] == n
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_census(ctx, oracle, monkeypatch, seed):
+    """Random shapes through a random path: length, pitch, row count, alphabet, share and number of frequent barcodes, early
+    NULs, bytes outside the alphabet, assignment codes, batches with row_base — every distinct barcode, its count and its
+    first row against the oracle's map."""
+    rng = np.random.default_rng(1000 + seed)
+    path = ("direct", "partition", "spilled_direct")[seed % 3]
+    monkeypatch.setenv("SK_CENSUS_SPILL", "0" if path == "direct" else "1")
+    monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "0" if path == "spilled_direct" else "100")
+    L = int(rng.integers(1, 32))
+    stride = int(rng.integers(L, min(64, L + 9) + 1))
+    n = int(rng.integers(1, 250_000))
+    alpha = np.frombuffer((b"ACGT", b"ACGTN", b"ACGTNacgtn+")[int(rng.integers(0, 3))], dtype=np.uint8)
+    n_hot = int(rng.integers(1, 3000))
+    bc = random_barcodes(n, L, stride, n_hot, float(rng.random()), seed=seed, alphabet=alpha.tobytes())
+    bc[:, L:] = rng.integers(0, 256, size=(n, stride - L), dtype=np.uint8)      # never looked at
+    short = rng.random(n) < rng.random() * 0.5
+    cut = rng.integers(0, L, size=n)
+    for r in np.nonzero(short)[0]:
+        bc[r, cut[r]:L] = 0
+    foreign = rng.random(n) < 0.01
+    pos = rng.integers(0, L, size=n)
+    bc[foreign, pos[foreign]] = rng.choice(np.frombuffer(b"-_.UXxz0 \x7f\xff\x01", dtype=np.uint8), size=int(foreign.sum()))
+    # the rows the device counts: no byte outside the alphabet before the first NUL (within L)
+    inside = np.isin(bc[:, :L], np.concatenate([alpha if len(alpha) == 11 else np.frombuffer(b"ACGTNacgtn+", np.uint8), np.zeros(1, np.uint8)]))
+    nul = bc[:, :L] == 0
+    before_nul = np.cumsum(nul, axis=1) == 0
+    valid = ~((~inside) & before_nul).any(axis=1)
+    assign = None
+    if rng.random() < 0.5:
+        assign = np.where(rng.random(n) < 0.6, -1, rng.integers(0, 5, size=n)).astype(np.int32)
+    counted = valid if assign is None else valid & (assign == -1)
+    base = int(rng.integers(0, 1 << 40))
+    ctx.census_reset()
+    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
+    for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        ctx.census_add(bc[lo:hi], L=L, assign=None if assign is None else assign[lo:hi], row_base=base + lo)
+    got, total = ctx.census_entries()
+    want = oracle.census(bc, L=L, assign=np.where(counted, -1, 0).astype(np.int32))
+    assert total == len(want) and got == [(b, c, f + base) for b, c, f in want], (seed, path, L, stride, n)
+    st = ctx.census_stats()
+    assert st["counted"] == int(counted.sum())
+    assert st["rejected"] == int(((~valid) if assign is None else (~valid) & (assign == -1)).sum())
+
+
 def test_census_grows_past_its_first_table(oracle, monkeypatch):
     """More distinct barcodes than half the table: it is rehashed between launches, nothing is lost.  (The first table
     normally has 2^26 slots; a context created with SK_CENSUS_SLOTS_LOG2=16 starts small.)"""
