@@ -329,75 +329,151 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	}
 }
 
+// The scan loop of trim_scan_packed (see there).  v_cmpx: exec &= no key of the step is at or above the limit; the best key
+// is moved on to be relative to the next step; the tail is the hand-over test (few rows left, past where reads usually break).
+// The wait at the end is for the loads the loop issued last: the compiler does not know of them and would hand their
+// registers to something else while they are still on their way.
+#define SK_SCAN_ASM_PROLOGUE \
+	"s_mov_b64 %[sv], exec\n\t" \
+	"ds_read2_b32 v[126:127], %[q] offset0:2 offset1:3\n\t" \
+	"ds_read_b32 %[hi], %[q] offset:16\n\t" \
+	"s_mov_b32 s88, 0x01000000\n\t" \
+	"s_mov_b32 s89, 0x01010000\n\t" \
+	"s_mov_b32 s90, 0x01010100\n\t" \
+	"s_mov_b32 s91, 0x01010101\n\t" \
+	"s_mov_b32 s92, %[step]\n\t" \
+	"s_lshl_b32 s93, %[step], 1\n\t" \
+	"s_add_i32 s94, s93, %[step]\n\t" \
+	"s_lshl_b32 s95, %[step], 2\n\t" \
+	"s_add_i32 s96, s95, %[step]\n\t" \
+	"s_add_i32 s97, s95, s93\n\t" \
+	"s_add_i32 s98, s97, %[step]\n\t" \
+	"s_lshl_b32 s99, %[step], 3\n\t" \
+	"s_mov_b32 %[lim], %[brk]\n\t" \
+	"s_mov_b32 %[jj], 0\n\t" \
+	"s_mov_b64 %[strag], 0\n"
+#define SK_SCAN_ASM_STEP \
+	"s_waitcnt lgkmcnt(0)\n\t" \
+	"v_alignbyte_b32 %[d1], %[hi], v127, %[sh]\n\t" \
+	"v_alignbyte_b32 %[d0], v127, v126, %[sh]\n\t" \
+	"v_mov_b32 %[hi], v126\n\t" \
+	"ds_read2_b32 v[126:127], %[q] offset1:1\n\t" \
+	"v_dot4_u32_u8 %[k0], %[d1], s88, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k1], %[d1], s89, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k2], %[d1], s90, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k3], %[d1], s91, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k4], %[d0], s88, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[k5], %[d0], s89, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[k6], %[d0], s90, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[T], %[d0], s91, %[k3]\n\t" \
+	"v_lshl_add_u32 %[k0], %[k0], 11, s92\n\t" \
+	"v_lshl_add_u32 %[k1], %[k1], 11, s93\n\t" \
+	"v_lshl_add_u32 %[k2], %[k2], 11, s94\n\t" \
+	"v_lshl_add_u32 %[k3], %[k3], 11, s95\n\t" \
+	"v_lshl_add_u32 %[k4], %[k4], 11, s96\n\t" \
+	"v_lshl_add_u32 %[k5], %[k5], 11, s97\n\t" \
+	"v_lshl_add_u32 %[k6], %[k6], 11, s98\n\t" \
+	"v_lshl_add_u32 %[k7], %[T], 11, s99\n\t" \
+	"v_max3_i32 %[d1], %[k0], %[k1], %[k2]\n\t" \
+	"v_max3_i32 %[d0], %[k3], %[k4], %[k5]\n\t" \
+	"v_max_i32 %[kx], %[k6], %[k7]\n\t" \
+	"v_max3_i32 %[d1], %[d1], %[d0], %[kx]\n\t" \
+	"v_cmpx_gt_i32_e32 vcc, %[lim], %[d1]\n\t" \
+	"s_cbranch_execz 2f\n\t" \
+	"v_min3_i32 %[k0], %[k0], %[k1], %[k2]\n\t" \
+	"v_min3_i32 %[k3], %[k3], %[k4], %[k5]\n\t" \
+	"v_min3_i32 %[k6], %[k6], %[k7], %[best]\n\t" \
+	"v_min3_i32 %[best], %[k0], %[k3], %[k6]\n\t" \
+	"v_subrev_u32_e32 %[best], s99, %[best]\n\t" \
+	"v_add_u32_e32 %[q], -8, %[q]\n\t" \
+	"s_sub_i32 %[lim], %[lim], s99\n\t" \
+	"s_add_i32 %[jj], %[jj], 1\n\t" \
+	"s_cmp_ge_i32 %[jj], %[nfull]\n\t" \
+	"s_cbranch_scc1 2f\n\t" \
+	"s_sub_i32 %[tmp], %[jj], %[from1]\n\t" \
+	"s_cmp_ge_u32 %[tmp], %[span]\n\t" \
+	"s_cbranch_scc1 1b\n\t" \
+	"s_bcnt1_i32_b64 %[tmp], exec\n\t" \
+	"s_cmp_gt_i32 %[tmp], %[rows]\n\t" \
+	"s_cbranch_scc1 1b\n\t" \
+	"s_mov_b64 %[strag], exec\n" \
+	"2:\n\t" \
+	"s_mov_b64 exec, %[sv]\n\t" \
+	"s_waitcnt lgkmcnt(0)\n\t"
+#define SK_SCAN_ASM_OPERANDS \
+	: [T] "+v"(T), [best] "+v"(best), [q] "+v"(q), [hi] "=&v"(hi), [d1] "=&v"(d1), [d0] "=&v"(d0), [k0] "=&v"(k0), [k1] "=&v"(k1), \
+	[k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [k5] "=&v"(k5), [k6] "=&v"(k6), [k7] "=&v"(k7), [kx] "=&v"(kx), \
+	[lim] "=&s"(lim), [jj] "=&s"(jj), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [strag] "=&s"(strag) \
+	: [sh] "v"(sh), [mf] "v"(my_full), [step] "s"(__builtin_amdgcn_readfirstlane(step)), [nfull] "s"(__builtin_amdgcn_readfirstlane(nfull)), [span] "s"(__builtin_amdgcn_readfirstlane((int)strag_span)), [brk] "n"(kBreakKey), \
+	[from1] "n"(kStragglerFrom + 1), [rows] "n"(kStragglerRows) \
+	: "memory", "vcc", "scc", "v126", "v127", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+
 template <bool UNIFORM_LEN>
 __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
 	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
-	// minimum and one maximum, and the step's bookkeeping (who is alive, who stops, is anybody left) is paid once per
-	// eight bytes — it is about as many instructions as the arithmetic of four bytes.
-	// The loop is what a pass over long scans is bound by (VALU busy 70 % of the time, rocprofv3: profiles/), so it keeps
-	// nothing it can get back later: a lane that stops only remembers in which step — its running sum simply stays what it
-	// was before that step, and the step's two dwords are read again after the loop.
+	// minimum and one maximum, and the step's bookkeeping is paid once per eight bytes.
+	// The loop is what a pass over long scans is bound by — by the instructions it issues, vector AND scalar (DESIGN.md
+	// A.4) — so it is written as a plain divergent loop: a lane whose step holds a break (or whose row has no whole step
+	// left) LEAVES it, and the hardware's execution mask does what selects and ballots did before (a lane that is out
+	// writes nothing: its sum, its best key and its count of whole steps stay what they were, without a v_cndmask each;
+	// "is anybody left" is the loop's own exec test).  The step a lane stopped in is replayed byte by byte after the loop.
+	// Keys are built with the SAME eight constants in every step — K' = K - 8 jj step, relative to the step — the running
+	// best is kept relative as well (one subtraction per step moves it on) and the break limit is a scalar that moves with
+	// it.  |K'| < 2^30 for rows of up to 960 bytes (T < 2^18 shifted by 11, 8 jj |step| < 2^29).
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
-	int a = end & ~3;
-	u32 hi = *reinterpret_cast<const u32 *>(tile + a);
-	u32 T = 0;
-	int best = 0;
-	int whole_steps = active ? 0 : -1;                        // steps this lane got through whole: the index of the step it stops in (idle lanes: never alive)
-	const int nst = (maxlen + 7) >> 3;
 	const int step = 1 - m * (1 << kKeyBits);                 // C_j = j - j*m*2^11 = j * step
-	unsigned long long strag = 0ull;                          // rows handed to trim_finish_stragglers, and the bytes they have consumed
-	int strag_j0 = 0;
-	auto min3 = [](int x, int y, int z) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
-	auto max3 = [](int x, int y, int z) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
-	for (int jj = 0; jj < nst; jj++) {
-		a -= 8;
-		if (!UNIFORM_LEN) a = max(a, -8);                     // rows shorter than the scan stay inside the front pad (full rows end 2 bytes into it)
-		const u32 lo1 = *reinterpret_cast<const u32 *>(tile + a + 4), lo0 = *reinterpret_cast<const u32 *>(tile + a);
-		const u32 d1 = __builtin_amdgcn_alignbyte(hi, lo1, sh);   // bytes [end-8jj-4, end-8jj) of the image: scanned first
-		const u32 d0 = __builtin_amdgcn_alignbyte(lo1, lo0, sh);  // bytes [end-8jj-8, end-8jj-4)
-		hi = lo0;
-		u32 Ts[8];
-		Ts[0] = __builtin_amdgcn_udot4(d1, 0x01000000u, T, false);
-		Ts[1] = __builtin_amdgcn_udot4(d1, 0x01010000u, T, false);
-		Ts[2] = __builtin_amdgcn_udot4(d1, 0x01010100u, T, false);
-		Ts[3] = __builtin_amdgcn_udot4(d1, 0x01010101u, T, false);
-		Ts[4] = __builtin_amdgcn_udot4(d0, 0x01000000u, Ts[3], false);
-		Ts[5] = __builtin_amdgcn_udot4(d0, 0x01010000u, Ts[3], false);
-		Ts[6] = __builtin_amdgcn_udot4(d0, 0x01010100u, Ts[3], false);
-		Ts[7] = __builtin_amdgcn_udot4(d0, 0x01010101u, Ts[3], false);
-		const int c0 = (8 * jj + 1) * step;                   // scalar
-		int K[8];
-#pragma unroll
-		for (int i = 0; i < 8; i++) K[i] = (int)(Ts[i] << kKeyBits) + (c0 + i * step);
-		const int kmax = max3(max3(K[0], K[1], K[2]), max3(K[3], K[4], K[5]), max(K[6], K[7]));
-		const int kmin = min3(min3(K[0], K[1], K[2]), min3(K[3], K[4], K[5]), min3(K[6], K[7], best));
-		// alive = got through every step so far whole, carried as the COUNT of whole steps (a register): the masks of a step are
-		// then ballots of fresh compares, their AND is scalar work, and the three updates take the mask as it is
-		unsigned long long left = __builtin_amdgcn_ballot_w64(kmax < kBreakKey) & __builtin_amdgcn_ballot_w64(whole_steps == jj);      // no byte of this step breaks
-		if (UNIFORM_LEN) left = (8 * jj + 8 <= maxlen) ? left : 0ull;     // scalar: false only in the row's last, partial step
-		else left &= __builtin_amdgcn_ballot_w64(8 * jj + 8 <= len);
-		asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(whole_steps) : "s"(left) : "vcc");
-		asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(T) : "v"(Ts[7]), "s"(left));        // a stopped lane keeps the sum from before its stop step
-		asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(best) : "v"(kmin), "s"(left));
-		if (left == 0ull) break;
-		// few rows left and they are past where reads usually break: leave the loop, the whole wave finishes each of them
-		// (and only while enough of the row is left for the hand-over to pay: it costs about as much as a few steps)
-		if (jj >= kStragglerFrom && jj + kStragglerLeft < nst && (int)__builtin_popcountll(left) <= kStragglerRows) { strag = left; strag_j0 = 8 * (jj + 1); break; }
+	const int step8 = 8 * step;
+	const int nfull = maxlen >> 3;                            // whole steps of the longest row (wave-uniform)
+	const int nst = (maxlen + 7) >> 3;
+	u32 T = 0;
+	int best = 0;                                             // relative to the step the lane is in
+	// Every lane runs the loop, rows past the end of the last tile too (their image is whatever the tile before left
+	// there and their result is clipped by the store).  No address is clamped: a lane only reads one step past the last one
+	// it executes, i.e. at most 11 bytes before its row — the previous row of the image, or the pad in front of it
+	// (kLdsPad) for row 0.
+	//
+	// The loop is written out in gfx950 assembly: what the compiler made of the same loop in C++ was 33 vector and 22
+	// scalar instructions per step (the structurizer's mask bookkeeping, a 64-bit register move for the prefetched pair,
+	// a per-lane step counter); this is 30 and 7 (10 inside the hand-over window).  v_cmpx narrows exec to the lanes the
+	// step did not stop, s_cbranch_execz is "nobody left", the lane's count of whole steps is read off its LDS pointer
+	// afterwards (only survivors move it on), and the next step's two dwords are loaded into the registers the
+	// v_alignbyte pair has just consumed.  v126/v127 are that pair (ds_read2_b32 needs a register pair and an asm operand
+	// cannot name its halves); s[88:99] hold the four byte-select multipliers and the eight key constants.
+	(void)active;
+	const int my_full = len >> 3;
+	// hand-over window as one unsigned compare: kStragglerFrom <= jj < nst - kStragglerLeft for the step jj just completed
+	const u32 strag_span = nst - kStragglerLeft > kStragglerFrom ? (u32)(nst - kStragglerLeft - kStragglerFrom) : 0u;
+	const u32 q0 = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)(tile + (end & ~3) - 16);
+	u32 q = q0;
+	unsigned long long strag = 0ull;                          // rows handed to trim_finish_stragglers
+	if (nfull > 0) {
+		u32 hi, d1, d0, k0, k1, k2, k3, k4, k5, k6, k7, kx;
+		int lim, jj, tmp;
+		unsigned long long sv;
+		if (UNIFORM_LEN)
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP SK_SCAN_ASM_OPERANDS);
+		else                                                  // a row leaves at its last, partial step (or its end): replayed
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP SK_SCAN_ASM_OPERANDS);
 	}
-	const int stop_jj = (active && whole_steps < nst && !((strag >> (threadIdx.x & (kWave - 1))) & 1ull)) ? whole_steps : -1;      // stopped in a step (not: scanned to the end, or handed over)
-	if (strag) trim_finish_stragglers(tile, strag, strag_j0, step, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
-	if (stop_jj >= 0) {                                       // replay the stop step: src/fasta_trim_by_quality.rs:33-41 byte by byte
-		int qa = (end & ~3) - 8 * (stop_jj + 1);
-		if (!UNIFORM_LEN) qa = max(qa, -8);
-		const uint8_t *q = tile + qa;
+	const int ws = (int)(q0 - q) >> 3;                        // whole steps this lane got through: only survivors of a step move q on
+	const bool handed = (strag >> (threadIdx.x & (kWave - 1))) & 1ull;
+	best += ws * step8;                                       // the true key again
+	if (strag) {
+		const int strag_j0 = 8 * __builtin_amdgcn_readlane(ws, (int)__builtin_ctzll(strag));
+		trim_finish_stragglers(tile, strag, strag_j0, step, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
+	}
+	if (!handed) {                                            // replay the step the lane stopped in: src/fasta_trim_by_quality.rs:33-41 byte by byte
+		const uint8_t *q = tile + ((end & ~3) - 8 * (ws + 1));
 		const u32 h2 = *reinterpret_cast<const u32 *>(q + 8), l1 = *reinterpret_cast<const u32 *>(q + 4), l0 = *reinterpret_cast<const u32 *>(q);
 		const u32 stop_d1 = __builtin_amdgcn_alignbyte(h2, l1, sh), stop_d0 = __builtin_amdgcn_alignbyte(l1, l0, sh);
 		u32 t = T;
+		// a lane that stopped at a break has the stop step's eight bytes in its sum already
+		if (ws < (UNIFORM_LEN ? nfull : my_full)) t -= __builtin_amdgcn_udot4(stop_d1, 0x01010101u, __builtin_amdgcn_udot4(stop_d0, 0x01010101u, 0u, false), false);
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
-			const int j = 8 * stop_jj + i + 1;
+			const int j = 8 * ws + i + 1;
 			t += ((i < 4 ? stop_d1 : stop_d0) >> (8 * (3 - (i & 3)))) & 0xFFu;
 			const int K = (int)(t << kKeyBits) + j * step;
 			if (j > len || K >= kBreakKey) break;
