@@ -30,7 +30,7 @@
 namespace sk {
 
 #ifndef SK_STRAGGLER_FROM
-#define SK_STRAGGLER_FROM 4
+#define SK_STRAGGLER_FROM 6
 #endif
 #ifndef SK_STRAGGLER_ROWS
 #define SK_STRAGGLER_ROWS 8
@@ -270,6 +270,7 @@ __device__ __forceinline__ int group8_min(int x)       // every lane of the grou
 // minimum key before the cut is a minimum over the group.  ~60 VALU per round for all rows, against ~21 per dword step.
 // In: the rows of `todo` (<= 8) have consumed `j0` bytes each (whole dwords, none of them stopped); T / best are the
 // per-lane running sum and best key.  Out: best of those lanes (src/fasta_trim_by_quality.rs:33-41 for the rest of the row).
+template <bool RAW = false>
 __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsigned long long todo, int j0, int step, int lane,
                                                        int end, int len, u32 T, int &best)
 {
@@ -295,7 +296,8 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 		const int e = end_r - jr - 4 * u;                          // this lane's 4 bytes: addresses [e-4, e), scanned downwards
 		const int a = max(e & ~3, 0);                              // lanes past the row's start read the front of the image: masked below
 		const u32 hi = *reinterpret_cast<const u32 *>(tile + a), lo = *reinterpret_cast<const u32 *>(tile + a - 4);
-		const u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+		u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+		if (RAW) d = sub33(d, (d & kLo7) + 0x5f5f5f5fu);             // the image holds raw quality bytes
 		const int s0 = (int)__builtin_amdgcn_udot4(d, 0x01000000u, 0u, false), s1 = (int)__builtin_amdgcn_udot4(d, 0x01010000u, 0u, false);
 		const int s2 = (int)__builtin_amdgcn_udot4(d, 0x01010100u, 0u, false), s3 = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
 		const int incl = group8_inclusive_sum(s3, u);
@@ -341,6 +343,7 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"s_mov_b32 s89, 0x01010000\n\t" \
 	"s_mov_b32 s90, 0x01010100\n\t" \
 	"s_mov_b32 s91, 0x01010101\n\t" \
+	"s_mov_b32 s87, 0x21212121\n\t" \
 	"s_mov_b32 s92, %[step]\n\t" \
 	"s_lshl_b32 s93, %[step], 1\n\t" \
 	"s_add_i32 s94, s93, %[step]\n\t" \
@@ -352,7 +355,7 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"s_mov_b32 %[lim], %[brk]\n\t" \
 	"s_mov_b32 %[jj], 0\n\t" \
 	"s_mov_b64 %[strag], 0\n"
-#define SK_SCAN_ASM_STEP \
+#define SK_SCAN_ASM_STEP_A \
 	"s_waitcnt lgkmcnt(0)\n\t" \
 	"v_alignbyte_b32 %[d1], %[hi], v127, %[sh]\n\t" \
 	"v_alignbyte_b32 %[d0], v127, v126, %[sh]\n\t" \
@@ -373,7 +376,11 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"v_lshl_add_u32 %[k4], %[k4], 11, s96\n\t" \
 	"v_lshl_add_u32 %[k5], %[k5], 11, s97\n\t" \
 	"v_lshl_add_u32 %[k6], %[k6], 11, s98\n\t" \
-	"v_lshl_add_u32 %[k7], %[T], 11, s99\n\t" \
+	"v_lshl_add_u32 %[k7], %[T], 11, s99\n\t"
+#define SK_SCAN_ASM_RAWCHECK \
+	"v_sad_u8 %[A], %[d1], s87, %[A]\n\t" \
+	"v_sad_u8 %[A], %[d0], s87, %[A]\n\t"
+#define SK_SCAN_ASM_STEP_B \
 	"v_max3_i32 %[d1], %[k0], %[k1], %[k2]\n\t" \
 	"v_max3_i32 %[d0], %[k3], %[k4], %[k5]\n\t" \
 	"v_max_i32 %[kx], %[k6], %[k7]\n\t" \
@@ -401,14 +408,18 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"s_mov_b64 exec, %[sv]\n\t" \
 	"s_waitcnt lgkmcnt(0)\n\t"
 #define SK_SCAN_ASM_OPERANDS \
-	: [T] "+v"(T), [best] "+v"(best), [q] "+v"(q), [hi] "=&v"(hi), [d1] "=&v"(d1), [d0] "=&v"(d0), [k0] "=&v"(k0), [k1] "=&v"(k1), \
+	: [T] "+v"(T), [best] "+v"(best), [q] "+v"(q), [A] "+v"(A), [hi] "=&v"(hi), [d1] "=&v"(d1), [d0] "=&v"(d0), [k0] "=&v"(k0), [k1] "=&v"(k1), \
 	[k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [k5] "=&v"(k5), [k6] "=&v"(k6), [k7] "=&v"(k7), [kx] "=&v"(kx), \
 	[lim] "=&s"(lim), [jj] "=&s"(jj), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [strag] "=&s"(strag) \
 	: [sh] "v"(sh), [mf] "v"(my_full), [step] "s"(__builtin_amdgcn_readfirstlane(step)), [nfull] "s"(__builtin_amdgcn_readfirstlane(nfull)), [span] "s"(__builtin_amdgcn_readfirstlane((int)strag_span)), [brk] "n"(kBreakKey), \
 	[from1] "n"(kStragglerFrom + 1), [rows] "n"(kStragglerRows) \
-	: "memory", "vcc", "scc", "v126", "v127", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+	: "memory", "vcc", "scc", "v126", "v127", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
-template <bool UNIFORM_LEN>
+// RAW: the image holds the quality bytes as they came from memory, not v = (q - 33) mod 256 (the trim-alone pass: its
+// stream phase then has no arithmetic at all).  While no byte of a row is below 33, v = q - 33 and the keys are the same
+// with m + 33 in the place of m; whether that held is checked on the way — sum |q - 33| against sum q - 33 j, two v_sad_u8
+// per step — and a row that fails (a byte below '!': nothing a sequencer writes) is scanned again byte by byte.
+template <bool UNIFORM_LEN, bool RAW = false>
 __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
 	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
@@ -423,11 +434,13 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	// it.  |K'| < 2^30 for rows of up to 960 bytes (T < 2^18 shifted by 11, 8 jj |step| < 2^29).
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
-	const int step = 1 - m * (1 << kKeyBits);                 // C_j = j - j*m*2^11 = j * step
+	const int step_true = 1 - m * (1 << kKeyBits);            // C_j = j - j*m*2^11 = j * step
+	const int step = RAW ? step_true - 33 * (1 << kKeyBits) : step_true;     // the loop's: on raw bytes m + 33 stands for m (|K'| < 2^31 still)
 	const int step8 = 8 * step;
 	const int nfull = maxlen >> 3;                            // whole steps of the longest row (wave-uniform)
 	const int nst = (maxlen + 7) >> 3;
 	u32 T = 0;
+	u32 A = 0;                                                // RAW: sum of |q - 33| over the bytes T covers
 	int best = 0;                                             // relative to the step the lane is in
 	// Every lane runs the loop, rows past the end of the last tile too (their image is whatever the tile before left
 	// there and their result is clipped by the store).  No address is clamped: a lane only reads one step past the last one
@@ -452,38 +465,64 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 		u32 hi, d1, d0, k0, k1, k2, k3, k4, k5, k6, k7, kx;
 		int lim, jj, tmp;
 		unsigned long long sv;
-		if (UNIFORM_LEN)
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP SK_SCAN_ASM_OPERANDS);
-		else                                                  // a row leaves at its last, partial step (or its end): replayed
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP SK_SCAN_ASM_OPERANDS);
+		// (the four forms differ in two places: a ragged row leaves at its last, partial step — or its end —, which is
+		// replayed; raw bytes are checked)
+		if (UNIFORM_LEN && !RAW)
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+		else if (UNIFORM_LEN)
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_RAWCHECK SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+		else if (!RAW)
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+		else
+			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_RAWCHECK SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
 	}
 	const int ws = (int)(q0 - q) >> 3;                        // whole steps this lane got through: only survivors of a step move q on
 	const bool handed = (strag >> (threadIdx.x & (kWave - 1))) & 1ull;
+	const bool broke = !handed && ws < (UNIFORM_LEN ? nfull : my_full);     // stopped at a break: the stop step's eight bytes are in its sum already
+	bool wrapped = false;
+	if (RAW) {                                                // from sums of q to sums of v, if the row allows it
+		const u32 off = 33u * 8u * (u32)(ws + (broke ? 1 : 0));
+		wrapped = A != T - off;
+		T -= off;
+	}
 	best += ws * step8;                                       // the true key again
 	if (strag) {
 		const int strag_j0 = 8 * __builtin_amdgcn_readlane(ws, (int)__builtin_ctzll(strag));
-		trim_finish_stragglers(tile, strag, strag_j0, step, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
+		trim_finish_stragglers<RAW>(tile, strag, strag_j0, step_true, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
 	}
 	if (!handed) {                                            // replay the step the lane stopped in: src/fasta_trim_by_quality.rs:33-41 byte by byte
-		const uint8_t *q = tile + ((end & ~3) - 8 * (ws + 1));
-		const u32 h2 = *reinterpret_cast<const u32 *>(q + 8), l1 = *reinterpret_cast<const u32 *>(q + 4), l0 = *reinterpret_cast<const u32 *>(q);
-		const u32 stop_d1 = __builtin_amdgcn_alignbyte(h2, l1, sh), stop_d0 = __builtin_amdgcn_alignbyte(l1, l0, sh);
+		const uint8_t *qp = tile + ((end & ~3) - 8 * (ws + 1));
+		const u32 h2 = *reinterpret_cast<const u32 *>(qp + 8), l1 = *reinterpret_cast<const u32 *>(qp + 4), l0 = *reinterpret_cast<const u32 *>(qp);
+		u32 stop_d1 = __builtin_amdgcn_alignbyte(h2, l1, sh), stop_d0 = __builtin_amdgcn_alignbyte(l1, l0, sh);
+		if (RAW) { stop_d1 = sub33(stop_d1, (stop_d1 & kLo7) + 0x5f5f5f5fu); stop_d0 = sub33(stop_d0, (stop_d0 & kLo7) + 0x5f5f5f5fu); }
 		u32 t = T;
-		// a lane that stopped at a break has the stop step's eight bytes in its sum already
-		if (ws < (UNIFORM_LEN ? nfull : my_full)) t -= __builtin_amdgcn_udot4(stop_d1, 0x01010101u, __builtin_amdgcn_udot4(stop_d0, 0x01010101u, 0u, false), false);
+		if (broke) t -= __builtin_amdgcn_udot4(stop_d1, 0x01010101u, __builtin_amdgcn_udot4(stop_d0, 0x01010101u, 0u, false), false);
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			const int j = 8 * ws + i + 1;
 			t += ((i < 4 ? stop_d1 : stop_d0) >> (8 * (3 - (i & 3)))) & 0xFFu;
-			const int K = (int)(t << kKeyBits) + j * step;
+			const int K = (int)(t << kKeyBits) + j * step_true;
 			if (j > len || K >= kBreakKey) break;
 			best = min(best, K);
 		}
 	}
-	return len - (best & ((1 << kKeyBits) - 1));
+	int low_j = best & ((1 << kKeyBits) - 1);
+	if (RAW && __builtin_amdgcn_ballot_w64(wrapped) != 0ull) {
+		if (wrapped) {                                        // src/fasta_trim_by_quality.rs:28-42 as it stands, on this row alone
+			int total = 0, low = 0;
+			low_j = 0;
+			for (int j = 1; j <= len; j++) {
+				total += (int)((tile[end - j] - 33u) & 0xFFu) - m;
+				if (total > 50) break;
+				if (total < low) { low = total; low_j = j; }
+			}
+		}
+	}
+	return len - low_j;
 }
 
 // same scan with separate (lowest_U, lowest_j); for rows longer than 2047 bytes
+template <bool RAW = false>
 __device__ __forceinline__ int trim_scan_wide(const uint8_t *tile, int row_start, int len, int maxlen, int m, bool active)
 {
 	const int end = row_start + len;
@@ -497,6 +536,7 @@ __device__ __forceinline__ int trim_scan_wide(const uint8_t *tile, int row_start
 		a = max(a - 4, -4);
 		u32 lo = *reinterpret_cast<const u32 *>(tile + a);
 		u32 d = __builtin_amdgcn_alignbyte(hi, lo, sh);
+		if (RAW) d = sub33(d, (d & kLo7) + 0x5f5f5f5fu);
 		hi = lo;
 #pragma unroll
 		for (int i = 3; i >= 0; i--) {
@@ -923,22 +963,41 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 			asm volatile("" : "+v"(len_ld));
 
 			// ---- stream phase: 16 B per lane, 1 KiB per wave instruction, two chunks in flight ------------
+			if (kTrimOnly) {
+				// Trim alone moves bytes from memory to the image and does nothing else with them, so the phase is written
+				// without per-chunk decisions: only the tile's last group of chunks can reach past the image — there a lane
+				// beyond it writes to the 16 bytes of pad behind the image instead of being masked off (one v_min against a
+				// compare, an exec save, a branch and a restore) — and the group that fetches the NEXT item is its own copy
+				// of the loop instead of five selects per chunk.  (Rows past the end of the last tile get the zeros the
+				// descriptor returns; nothing reads them but lanes whose result is clipped.)
+				const int image16 = (kTileRows * stride + 15) & ~15;
+				int c = 0;
+				for (; c + SLOTS < nchunkp; c += SLOTS) {
+#pragma unroll
+					for (int i = 0; i < SLOTS; i++) {
+						const int off = (c + i) * 1024 + voff;
+						*reinterpret_cast<u32x4 *>(tile + off) = qv[i];
+						qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, off + SLOTS * 1024, 0, kAuxStream);
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < SLOTS; i++) {
+					const int off = (c + i) * 1024 + voff;
+					*reinterpret_cast<u32x4 *>(tile + min(off, image16)) = qv[i];
+					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(nq, voff + i * 1024, 0, kAuxStream);
+				}
+			} else
 			for (int c = 0; c < nchunkp; c += SLOTS) {
 				const bool last = c + SLOTS >= nchunkp;
 #pragma unroll
 				for (int i = 0; i < SLOTS; i++) {
 					const int off = (c + i) * 1024 + voff;
 					u32x4 o, vq;
-					if (kTrimOnly) {
-#pragma unroll
-						for (int w = 0; w < 4; w++) vq[w] = sub33(qv[i][w], (qv[i][w] & kLo7) + 0x5f5f5f5fu);
-					} else {
-						mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
-						__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
-					}
+					mask_dword4<MODE>(qv[i], sv[i], cl2, o, vq);
+					__builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, kAuxStreamSt);
 					if (do_trim && off < nb) *reinterpret_cast<u32x4 *>(tile + off) = vq;
 					qv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? nq : rq, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
-					if (!kTrimOnly) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
+					sv[i] = __builtin_amdgcn_raw_buffer_load_b128(last ? ns : rs, last ? voff + i * 1024 : off + SLOTS * 1024, 0, kAuxStream);
 				}
 			}
 			rq = nq; rs = ns;
@@ -948,9 +1007,9 @@ __global__ __launch_bounds__(256, SLOTS > 4 ? 2 : 4) void tile_pass_kernel(const
 				wave_lds_fence();
 				const int len = (mt.len != nullptr) ? len_ld : stride;
 				int kk;
-				if (stride >= (1 << kKeyBits)) kk = trim_scan_wide(tile, lane * stride, len, stride, m, active);
-				else if (mt.len != nullptr) kk = trim_scan_packed<false>(tile, lane * stride, len, stride, m, active);
-				else kk = trim_scan_packed<true>(tile, lane * stride, len, stride, m, active);
+				if (stride >= (1 << kKeyBits)) kk = trim_scan_wide<kTrimOnly>(tile, lane * stride, len, stride, m, active);
+				else if (mt.len != nullptr) kk = trim_scan_packed<false, kTrimOnly>(tile, lane * stride, len, stride, m, active);
+				else kk = trim_scan_packed<true, kTrimOnly>(tile, lane * stride, len, stride, m, active);
 				// (the descriptor of lowest_k is made here, from the pointer as it lies in the kernel arguments: four scalar
 				// registers less across the chunk loop and the scan)
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)kk, make_rsrc(kernel_args_now<TileArgs>()->mate[mate0 + k].lowest_k, row0 * 2, rows * 2), lane * 2, 0, 0);
