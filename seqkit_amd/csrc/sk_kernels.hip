@@ -331,56 +331,68 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	}
 }
 
-// The scan loop of trim_scan_packed (see there).  v_cmpx: exec &= no key of the step is at or above the limit; the best key
-// is moved on to be relative to the next step; the tail is the hand-over test (few rows left, past where reads usually break).
-// The wait at the end is for the loads the loop issued last: the compiler does not know of them and would hand their
-// registers to something else while they are still on their way.
+// The scan loop of trim_scan_packed (see there), two 8-byte steps per iteration.  v_cmpx: exec &= no key of the step is at
+// or above the limit.  The two steps use the two register pairs in turn — the dword a step's upper v_alignbyte needs is
+// the lower one of the pair the step before consumed, so nothing is moved — and their sixteen key constants are relative
+// to the iteration's first byte: the best key and the limit move on once per iteration.  The tail is the hand-over test
+// (few rows left, past where reads usually break).  The wait at the end is for the loads the loop issued last: the
+// compiler does not know of them and would hand their registers to something else while they are still on their way.
+// Registers by name: v[126:127] / v[124:125] the two pairs (ds_read2_b32 needs a pair and an asm operand cannot name its
+// halves); s[80:83] the byte-select multipliers, s79 = 0x21212121, s[84:99] the key constants 1 .. 16 times `step`.
 #define SK_SCAN_ASM_PROLOGUE \
 	"s_mov_b64 %[sv], exec\n\t" \
 	"ds_read2_b32 v[126:127], %[q] offset0:2 offset1:3\n\t" \
-	"ds_read_b32 %[hi], %[q] offset:16\n\t" \
-	"s_mov_b32 s88, 0x01000000\n\t" \
-	"s_mov_b32 s89, 0x01010000\n\t" \
-	"s_mov_b32 s90, 0x01010100\n\t" \
-	"s_mov_b32 s91, 0x01010101\n\t" \
-	"s_mov_b32 s87, 0x21212121\n\t" \
-	"s_mov_b32 s92, %[step]\n\t" \
-	"s_lshl_b32 s93, %[step], 1\n\t" \
+	"ds_read_b32 v124, %[q] offset:16\n\t" \
+	"s_mov_b32 s80, 0x01000000\n\t" \
+	"s_mov_b32 s81, 0x01010000\n\t" \
+	"s_mov_b32 s82, 0x01010100\n\t" \
+	"s_mov_b32 s83, 0x01010101\n\t" \
+	"s_mov_b32 s79, 0x21212121\n\t" \
+	"s_mov_b32 s84, %[step]\n\t" \
+	"s_add_i32 s85, s84, %[step]\n\t" \
+	"s_add_i32 s86, s85, %[step]\n\t" \
+	"s_add_i32 s87, s86, %[step]\n\t" \
+	"s_add_i32 s88, s87, %[step]\n\t" \
+	"s_add_i32 s89, s88, %[step]\n\t" \
+	"s_add_i32 s90, s89, %[step]\n\t" \
+	"s_add_i32 s91, s90, %[step]\n\t" \
+	"s_add_i32 s92, s91, %[step]\n\t" \
+	"s_add_i32 s93, s92, %[step]\n\t" \
 	"s_add_i32 s94, s93, %[step]\n\t" \
-	"s_lshl_b32 s95, %[step], 2\n\t" \
+	"s_add_i32 s95, s94, %[step]\n\t" \
 	"s_add_i32 s96, s95, %[step]\n\t" \
-	"s_add_i32 s97, s95, s93\n\t" \
+	"s_add_i32 s97, s96, %[step]\n\t" \
 	"s_add_i32 s98, s97, %[step]\n\t" \
-	"s_lshl_b32 s99, %[step], 3\n\t" \
+	"s_add_i32 s99, s98, %[step]\n\t" \
 	"s_mov_b32 %[lim], %[brk]\n\t" \
 	"s_mov_b32 %[jj], 0\n\t" \
-	"s_mov_b64 %[strag], 0\n"
-#define SK_SCAN_ASM_STEP_A \
+	"s_mov_b32 %[jj1], 1\n\t" \
+	"s_mov_b64 %[strag], 0\n" \
+	"1:\n\t"
+// one step: HI / L1 / L0 the three dwords it scans (descending addresses), PAIR where the next step's two are loaded,
+// C1 .. C8 its key constants; RAWCHECK = SK_SCAN_ASM_RAWCHECK or nothing
+#define SK_SCAN_ASM_STEP(HI, L1, L0, PAIR, C1, C2, C3, C4, C5, C6, C7, C8, RAWCHECK) \
 	"s_waitcnt lgkmcnt(0)\n\t" \
-	"v_alignbyte_b32 %[d1], %[hi], v127, %[sh]\n\t" \
-	"v_alignbyte_b32 %[d0], v127, v126, %[sh]\n\t" \
-	"v_mov_b32 %[hi], v126\n\t" \
-	"ds_read2_b32 v[126:127], %[q] offset1:1\n\t" \
-	"v_dot4_u32_u8 %[k0], %[d1], s88, %[T]\n\t" \
-	"v_dot4_u32_u8 %[k1], %[d1], s89, %[T]\n\t" \
-	"v_dot4_u32_u8 %[k2], %[d1], s90, %[T]\n\t" \
-	"v_dot4_u32_u8 %[k3], %[d1], s91, %[T]\n\t" \
-	"v_dot4_u32_u8 %[k4], %[d0], s88, %[k3]\n\t" \
-	"v_dot4_u32_u8 %[k5], %[d0], s89, %[k3]\n\t" \
-	"v_dot4_u32_u8 %[k6], %[d0], s90, %[k3]\n\t" \
-	"v_dot4_u32_u8 %[T], %[d0], s91, %[k3]\n\t" \
-	"v_lshl_add_u32 %[k0], %[k0], 11, s92\n\t" \
-	"v_lshl_add_u32 %[k1], %[k1], 11, s93\n\t" \
-	"v_lshl_add_u32 %[k2], %[k2], 11, s94\n\t" \
-	"v_lshl_add_u32 %[k3], %[k3], 11, s95\n\t" \
-	"v_lshl_add_u32 %[k4], %[k4], 11, s96\n\t" \
-	"v_lshl_add_u32 %[k5], %[k5], 11, s97\n\t" \
-	"v_lshl_add_u32 %[k6], %[k6], 11, s98\n\t" \
-	"v_lshl_add_u32 %[k7], %[T], 11, s99\n\t"
-#define SK_SCAN_ASM_RAWCHECK \
-	"v_sad_u8 %[A], %[d1], s87, %[A]\n\t" \
-	"v_sad_u8 %[A], %[d0], s87, %[A]\n\t"
-#define SK_SCAN_ASM_STEP_B \
+	"v_alignbyte_b32 %[d1], " HI ", " L1 ", %[sh]\n\t" \
+	"v_alignbyte_b32 %[d0], " L1 ", " L0 ", %[sh]\n\t" \
+	"ds_read2_b32 " PAIR ", %[q] offset1:1\n\t" \
+	"v_dot4_u32_u8 %[k0], %[d1], s80, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k1], %[d1], s81, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k2], %[d1], s82, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k3], %[d1], s83, %[T]\n\t" \
+	"v_dot4_u32_u8 %[k4], %[d0], s80, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[k5], %[d0], s81, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[k6], %[d0], s82, %[k3]\n\t" \
+	"v_dot4_u32_u8 %[T], %[d0], s83, %[k3]\n\t" \
+	"v_lshl_add_u32 %[k0], %[k0], 11, " C1 "\n\t" \
+	"v_lshl_add_u32 %[k1], %[k1], 11, " C2 "\n\t" \
+	"v_lshl_add_u32 %[k2], %[k2], 11, " C3 "\n\t" \
+	"v_lshl_add_u32 %[k3], %[k3], 11, " C4 "\n\t" \
+	"v_lshl_add_u32 %[k4], %[k4], 11, " C5 "\n\t" \
+	"v_lshl_add_u32 %[k5], %[k5], 11, " C6 "\n\t" \
+	"v_lshl_add_u32 %[k6], %[k6], 11, " C7 "\n\t" \
+	"v_lshl_add_u32 %[k7], %[T], 11, " C8 "\n\t" \
+	RAWCHECK \
 	"v_max3_i32 %[d1], %[k0], %[k1], %[k2]\n\t" \
 	"v_max3_i32 %[d0], %[k3], %[k4], %[k5]\n\t" \
 	"v_max_i32 %[kx], %[k6], %[k7]\n\t" \
@@ -391,10 +403,25 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"v_min3_i32 %[k3], %[k3], %[k4], %[k5]\n\t" \
 	"v_min3_i32 %[k6], %[k6], %[k7], %[best]\n\t" \
 	"v_min3_i32 %[best], %[k0], %[k3], %[k6]\n\t" \
+	"v_add_u32_e32 %[q], -8, %[q]\n\t"
+#define SK_SCAN_ASM_RAWCHECK \
+	"v_sad_u8 %[A], %[d1], s79, %[A]\n\t" \
+	"v_sad_u8 %[A], %[d0], s79, %[A]\n\t"
+#define SK_SCAN_ASM_STEP_A(RAWCHECK) SK_SCAN_ASM_STEP("v124", "v127", "v126", "v[124:125]", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", RAWCHECK)
+#define SK_SCAN_ASM_STEP_B(RAWCHECK) SK_SCAN_ASM_STEP("v126", "v125", "v124", "v[126:127]", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", RAWCHECK)
+// a ragged row leaves at its last, partial step (or its end): that step is replayed
+#define SK_SCAN_ASM_RAGGED_TOP(JJ) \
+	"v_cmpx_lt_i32_e32 vcc, " JJ ", %[mf]\n\t" \
+	"s_cbranch_execz 2f\n\t"
+// rows of one length: an odd number of whole steps ends after a first half
+#define SK_SCAN_ASM_UNIFORM_MID \
+	"s_cmp_ge_i32 %[jj1], %[nfull]\n\t" \
+	"s_cbranch_scc1 2f\n\t"
+#define SK_SCAN_ASM_TAIL \
 	"v_subrev_u32_e32 %[best], s99, %[best]\n\t" \
-	"v_add_u32_e32 %[q], -8, %[q]\n\t" \
 	"s_sub_i32 %[lim], %[lim], s99\n\t" \
-	"s_add_i32 %[jj], %[jj], 1\n\t" \
+	"s_add_i32 %[jj], %[jj], 2\n\t" \
+	"s_add_i32 %[jj1], %[jj1], 2\n\t" \
 	"s_cmp_ge_i32 %[jj], %[nfull]\n\t" \
 	"s_cbranch_scc1 2f\n\t" \
 	"s_sub_i32 %[tmp], %[jj], %[from1]\n\t" \
@@ -408,12 +435,13 @@ __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsi
 	"s_mov_b64 exec, %[sv]\n\t" \
 	"s_waitcnt lgkmcnt(0)\n\t"
 #define SK_SCAN_ASM_OPERANDS \
-	: [T] "+v"(T), [best] "+v"(best), [q] "+v"(q), [A] "+v"(A), [hi] "=&v"(hi), [d1] "=&v"(d1), [d0] "=&v"(d0), [k0] "=&v"(k0), [k1] "=&v"(k1), \
+	: [T] "+v"(T), [best] "+v"(best), [q] "+v"(q), [A] "+v"(A), [d1] "=&v"(d1), [d0] "=&v"(d0), [k0] "=&v"(k0), [k1] "=&v"(k1), \
 	[k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [k5] "=&v"(k5), [k6] "=&v"(k6), [k7] "=&v"(k7), [kx] "=&v"(kx), \
-	[lim] "=&s"(lim), [jj] "=&s"(jj), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [strag] "=&s"(strag) \
-	: [sh] "v"(sh), [mf] "v"(my_full), [step] "s"(__builtin_amdgcn_readfirstlane(step)), [nfull] "s"(__builtin_amdgcn_readfirstlane(nfull)), [span] "s"(__builtin_amdgcn_readfirstlane((int)strag_span)), [brk] "n"(kBreakKey), \
-	[from1] "n"(kStragglerFrom + 1), [rows] "n"(kStragglerRows) \
-	: "memory", "vcc", "scc", "v126", "v127", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+	[lim] "=&s"(lim), [jj] "=&s"(jj), [jj1] "=&s"(jj1), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [strag] "=&s"(strag) \
+	: [sh] "v"(sh), [mf] "v"(my_full), [step] "s"(__builtin_amdgcn_readfirstlane(step)), [nfull] "s"(__builtin_amdgcn_readfirstlane(nfull)), \
+	[span] "s"(__builtin_amdgcn_readfirstlane((int)strag_span)), [brk] "n"(kBreakKey), [from1] "n"(kStragglerFrom + 1), [rows] "n"(kStragglerRows) \
+	: "memory", "vcc", "scc", "v124", "v125", "v126", "v127", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", \
+	"s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
 // RAW: the image holds the quality bytes as they came from memory, not v = (q - 33) mod 256 (the trim-alone pass: its
 // stream phase then has no arithmetic at all).  While no byte of a row is below 33, v = q - 33 and the keys are the same
@@ -425,13 +453,13 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
 	// minimum and one maximum, and the step's bookkeeping is paid once per eight bytes.
 	// The loop is what a pass over long scans is bound by — by the instructions it issues, vector AND scalar (DESIGN.md
-	// A.4) — so it is written as a plain divergent loop: a lane whose step holds a break (or whose row has no whole step
-	// left) LEAVES it, and the hardware's execution mask does what selects and ballots did before (a lane that is out
-	// writes nothing: its sum, its best key and its count of whole steps stay what they were, without a v_cndmask each;
-	// "is anybody left" is the loop's own exec test).  The step a lane stopped in is replayed byte by byte after the loop.
-	// Keys are built with the SAME eight constants in every step — K' = K - 8 jj step, relative to the step — the running
-	// best is kept relative as well (one subtraction per step moves it on) and the break limit is a scalar that moves with
-	// it.  |K'| < 2^30 for rows of up to 960 bytes (T < 2^18 shifted by 11, 8 jj |step| < 2^29).
+	// A.4) — so it is a plain divergent loop: a lane whose step holds a break (or whose row has no whole step left) LEAVES
+	// it, and the hardware's execution mask does what selects and ballots did before (a lane that is out writes nothing:
+	// its sum and its best key stay what they were; "is anybody left" is the loop's own exec test).  The step a lane
+	// stopped in is replayed byte by byte after the loop.
+	// Keys are built with the SAME constants in every iteration — K' = K minus the key offset of the iteration's first byte
+	// — the running best is kept relative as well (one subtraction per iteration moves it on) and the break limit is a
+	// scalar that moves with it.  |K'| < 2^31 for rows of up to 960 bytes.
 	const int end = row_start + len;
 	const u32 sh = (u32)end & 3u;
 	const int step_true = 1 - m * (1 << kKeyBits);            // C_j = j - j*m*2^11 = j * step
@@ -447,13 +475,12 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	// it executes, i.e. at most 11 bytes before its row — the previous row of the image, or the pad in front of it
 	// (kLdsPad) for row 0.
 	//
-	// The loop is written out in gfx950 assembly: what the compiler made of the same loop in C++ was 33 vector and 22
-	// scalar instructions per step (the structurizer's mask bookkeeping, a 64-bit register move for the prefetched pair,
-	// a per-lane step counter); this is 30 and 7 (10 inside the hand-over window).  v_cmpx narrows exec to the lanes the
-	// step did not stop, s_cbranch_execz is "nobody left", the lane's count of whole steps is read off its LDS pointer
-	// afterwards (only survivors move it on), and the next step's two dwords are loaded into the registers the
-	// v_alignbyte pair has just consumed.  v126/v127 are that pair (ds_read2_b32 needs a register pair and an asm operand
-	// cannot name its halves); s[88:99] hold the four byte-select multipliers and the eight key constants.
+	// The loop is written out in gfx950 assembly (SK_SCAN_ASM_* above): what the compiler made of the same loop in C++ was
+	// 33 vector and 22 scalar instructions per step (the structurizer's mask bookkeeping, a 64-bit register move for the
+	// prefetched pair, a per-lane step counter); this is 30.5 and 5 (8 inside the hand-over window), two more vector ones
+	// on raw bytes.  v_cmpx narrows exec to the lanes the step did not stop, s_cbranch_execz is "nobody left", the lane's
+	// count of whole steps is read off its LDS pointer afterwards (only survivors move it on), and the next step's two
+	// dwords are loaded into the registers the v_alignbyte pair has just consumed.
 	(void)active;
 	const int my_full = len >> 3;
 	// hand-over window as one unsigned compare: kStragglerFrom <= jj < nst - kStragglerLeft for the step jj just completed
@@ -462,19 +489,18 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	u32 q = q0;
 	unsigned long long strag = 0ull;                          // rows handed to trim_finish_stragglers
 	if (nfull > 0) {
-		u32 hi, d1, d0, k0, k1, k2, k3, k4, k5, k6, k7, kx;
-		int lim, jj, tmp;
+		u32 d1, d0, k0, k1, k2, k3, k4, k5, k6, k7, kx;
+		int lim, jj, jj1, tmp;
 		unsigned long long sv;
-		// (the four forms differ in two places: a ragged row leaves at its last, partial step — or its end —, which is
-		// replayed; raw bytes are checked)
+		// (the four forms differ in two places: a ragged row leaves at the top of a step; raw bytes are checked)
 		if (UNIFORM_LEN && !RAW)
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+			asm volatile(SK_SCAN_ASM_PROLOGUE SK_SCAN_ASM_STEP_A("") SK_SCAN_ASM_UNIFORM_MID SK_SCAN_ASM_STEP_B("") SK_SCAN_ASM_TAIL SK_SCAN_ASM_OPERANDS);
 		else if (UNIFORM_LEN)
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_RAWCHECK SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+			asm volatile(SK_SCAN_ASM_PROLOGUE SK_SCAN_ASM_STEP_A(SK_SCAN_ASM_RAWCHECK) SK_SCAN_ASM_UNIFORM_MID SK_SCAN_ASM_STEP_B(SK_SCAN_ASM_RAWCHECK) SK_SCAN_ASM_TAIL SK_SCAN_ASM_OPERANDS);
 		else if (!RAW)
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+			asm volatile(SK_SCAN_ASM_PROLOGUE SK_SCAN_ASM_RAGGED_TOP("%[jj]") SK_SCAN_ASM_STEP_A("") SK_SCAN_ASM_RAGGED_TOP("%[jj1]") SK_SCAN_ASM_STEP_B("") SK_SCAN_ASM_TAIL SK_SCAN_ASM_OPERANDS);
 		else
-			asm volatile(SK_SCAN_ASM_PROLOGUE "1:\n\t" "v_cmpx_lt_i32_e32 vcc, %[jj], %[mf]\n\t" "s_cbranch_execz 2f\n\t" SK_SCAN_ASM_STEP_A SK_SCAN_ASM_RAWCHECK SK_SCAN_ASM_STEP_B SK_SCAN_ASM_OPERANDS);
+			asm volatile(SK_SCAN_ASM_PROLOGUE SK_SCAN_ASM_RAGGED_TOP("%[jj]") SK_SCAN_ASM_STEP_A(SK_SCAN_ASM_RAWCHECK) SK_SCAN_ASM_RAGGED_TOP("%[jj1]") SK_SCAN_ASM_STEP_B(SK_SCAN_ASM_RAWCHECK) SK_SCAN_ASM_TAIL SK_SCAN_ASM_OPERANDS);
 	}
 	const int ws = (int)(q0 - q) >> 3;                        // whole steps this lane got through: only survivors of a step move q on
 	const bool handed = (strag >> (threadIdx.x & (kWave - 1))) & 1ull;
@@ -485,7 +511,7 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 		wrapped = A != T - off;
 		T -= off;
 	}
-	best += ws * step8;                                       // the true key again
+	best += (ws & ~1) * step8;                                // the true key again: it was relative to the iteration's first byte
 	if (strag) {
 		const int strag_j0 = 8 * __builtin_amdgcn_readlane(ws, (int)__builtin_ctzll(strag));
 		trim_finish_stragglers<RAW>(tile, strag, strag_j0, step_true, (int)(threadIdx.x & (kWave - 1)), end, len, T, best);
