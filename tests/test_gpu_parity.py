@@ -88,6 +88,44 @@ def test_trim_low_entropy_ties(ctx, oracle):
     assert np.array_equal(ctx.trim_by_quality(qual, None, 20), oracle.trim_batch(qual, None, 20))
 
 
+@pytest.mark.parametrize("stride", [8, 9, 15, 16, 17, 24, 31, 40, 150, 250])
+def test_trim_long_scans_every_step_count(ctx, oracle, stride):
+    """Scans that never break, over rows of an even and an odd number of whole 8-byte steps (the scan loop takes two steps
+    per iteration), alone in a tile and among rows that break early (hand-over of the last rows to the whole wave)."""
+    rng = np.random.default_rng(stride)
+    n = 64 * 5 + 7
+    qual = np.full((n, stride), ord("#"), dtype=np.uint8)
+    early = rng.random(n) < 0.9
+    early[:64] = False                                   # a whole tile of rows that go to the end
+    early[64:128] = True                                 # one of rows that all break early
+    qual[early] = (rng.integers(25, 41, size=(int(early.sum()), stride)) + 33).astype(np.uint8)
+    for ln in (None, synth.ragged_lengths(n, stride, seed=stride)):
+        for m in (20, 2):
+            assert np.array_equal(ctx.trim_by_quality(qual, ln, m), oracle.trim_batch(qual, ln, m)), (stride, m, ln is None)
+
+
+@pytest.mark.parametrize("stride", [150, 37, 251])
+def test_trim_alone_bytes_below_33(ctx, oracle, stride):
+    """Trim alone scans the raw bytes (m + 33 for m) and checks on the way that no byte of the row was below '!': one such
+    byte at every position of a row — in a whole step, in the step the row stops in, in the row's partial last step, in
+    the part the whole wave finishes — in rows that break early and rows that never do; such rows take the byte-wise path."""
+    rng = np.random.default_rng(stride + 1)
+    rows_ = []
+    for base in ("#", "read"):
+        for pos in range(stride):
+            q = (np.full(stride, ord("#"), dtype=np.uint8) if base == "#"
+                 else (np.clip(rng.normal(30, 6, size=stride).round(), 2, 40) + 33).astype(np.uint8))
+            q[pos] = rng.integers(0, 33)
+            rows_.append(q)
+    qual = np.stack(rows_)
+    rng.shuffle(qual, axis=0)
+    clean = np.full((64 * 3, stride), ord("#"), dtype=np.uint8)          # tiles without such a byte around them
+    qual = np.concatenate([clean[:64], qual, clean[64:]])
+    for ln in (None, synth.ragged_lengths(len(qual), stride, seed=stride)):
+        for m in (20, 0, 255):
+            assert np.array_equal(ctx.trim_by_quality(qual, ln, m), oracle.trim_batch(qual, ln, m)), (stride, m, ln is None)
+
+
 def test_trim_empty_batch(ctx):
     assert ctx.trim_by_quality(np.zeros((0, 150), dtype=np.uint8), None, 20).shape == (0,)
 
