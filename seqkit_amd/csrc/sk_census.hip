@@ -233,8 +233,10 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
 }
 
-// count (cnt, first) for one key in the workgroup's LDS table; false when the key found no room within kLdsProbes slots
-__device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv)
+// count (cnt, first) for one key in the workgroup's LDS table; returns the key's slot — plus kLdsClaimed when this call put
+// the key there — or -1 when it found no room within kLdsProbes slots
+constexpr int kLdsClaimed = 1 << 16;
+__device__ __forceinline__ int lds_count_at(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv)
 {
 	const u64 want = ~khi;
 	u32 idx = at & (kLdsSlots - 1);
@@ -245,9 +247,10 @@ __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi
 		if (k == klo && v == want) {
 			atomicAdd(&lt->count[idx], cnt);
 			if (f < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
-			return true;
+			return (int)idx;
 		}
 	}
+	int claimed = 0;
 	for (int p = 0; p < kLdsProbes;) {
 		u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (k == 0) {
@@ -255,6 +258,7 @@ __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi
 			if (k == 0) {
 				__hip_atomic_store(&lt->khi_inv[idx], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				k = klo;
+				claimed = kLdsClaimed;
 			}
 		}
 		if (k == klo) {                                      // (one 8-byte load per probe; the high word only where the low one matched)
@@ -264,13 +268,81 @@ __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi
 				atomicAdd(&lt->count[idx], cnt);
 				// rows come in roughly ascending order, so the first row rarely moves: look before the (serialising) atomic
 				if (__hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
-				return true;
+				return (int)idx | claimed;
 			}
 		}
 		idx = (idx + 1) & (kLdsSlots - 1);
 		p++;
 	}
-	return false;
+	return -1;
+}
+__device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv) { return lds_count_at(lt, at, klo, khi, cnt, first_inv) >= 0; }
+
+// ---- the alias table: rows whose BYTES were seen before are counted without building their key --------------------------
+// Building a row's key — classify every character, pack, hash, probe the front table — is ~125 of the front kernel's vector
+// instructions per row, and the kernel is bound by the instructions it issues.  Most rows of a run repeat a few thousand
+// byte strings (the sheet's barcodes and their neighbours), so the workgroup keeps a second, smaller LDS table keyed by the
+// row's L raw bytes (masked dwords as they lie in the tile) whose entries name the front table's slot of that string's key:
+// a row that hits it is one hash of its dwords, one entry read, a compare and the LDS atomic.  An entry is written once — by
+// a lane that has just taken the long way with exactly these bytes, so whatever the long way checks (alphabet, an early NUL
+// and what follows it) holds for every row that matches the entry byte for byte — claimed with a CAS on its slot word,
+// published by the store of that word after the bytes; a reader that overlaps the writer sees zeros or the finished entry.
+// Two candidate places per string; a string that finds both taken keeps going the long way.
+constexpr u32 kAliasBusy = 0xFFFFFFFFu;
+constexpr int kAliasMaxEntries = 2048;
+template <int NW> struct AliasShape { static constexpr int EW = NW <= 2 ? 4 : (NW <= 5 ? 6 : 0); };      // dwords per entry (the last is the slot word); 0: no table for keys that long
+
+// (need_last, wave-uniform: some row's L bytes reach into dword NW of its span — not so for L = 17, whose 17 bytes lie in five
+// dwords wherever they begin, and every LDS read of this 17-byte-pitch walk is a conflicted one)
+template <int NW> __device__ __forceinline__ void census_row_raw(const uint8_t *tile, int rs, const u32 (&kms)[NW], u32 (&xs)[NW], bool need_last = true)
+{
+	const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
+	const u32 sh = (u32)rs & 3u;
+	u32 raw[NW + 1];
+#pragma unroll
+	for (int q = 0; q < NW; q++) raw[q] = t32[q];
+	raw[NW] = 0u;
+	if (need_last) raw[NW] = t32[NW];
+#pragma unroll
+	for (int q = 0; q < NW; q++) xs[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh) & kms[q];
+}
+template <int NW> __device__ __forceinline__ u32 alias_hash(const u32 (&xs)[NW])
+{
+	u32 h = xs[0];
+#pragma unroll
+	for (int q = 1; q < NW; q++) h ^= __builtin_rotateleft32(xs[q], (7 * q + 4) & 31);
+	h *= 0x9E3779B1u;
+	return h ^ (h >> 15);
+}
+// an entry's words, and the front table's slot they name for these bytes (or -1)
+template <int NW> __device__ __forceinline__ void alias_load(const u32 *e, u32 (&w)[AliasShape<NW>::EW])
+{
+	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+	for (int i = 0; i < AliasShape<NW>::EW / 2; i++) { const u32x2_t v = *reinterpret_cast<const u32x2_t *>(e + 2 * i); w[2 * i] = v[0]; w[2 * i + 1] = v[1]; }
+}
+template <int NW> __device__ __forceinline__ int alias_match(const u32 (&w)[AliasShape<NW>::EW], const u32 (&xs)[NW])
+{
+	u32 df = 0u;
+#pragma unroll
+	for (int q = 0; q < NW; q++) df |= w[q] ^ xs[q];
+	const u32 slot1 = w[AliasShape<NW>::EW - 1];                    // slot + 1; 0 = empty, kAliasBusy = being written
+	return (df == 0u && slot1 - 1u < (u32)kLdsSlots) ? (int)(slot1 - 1u) : -1;
+}
+template <int NW> __device__ __forceinline__ void alias_install(u32 *alias, u32 amask, u32 h, const u32 (&xs)[NW], int slot)
+{
+	constexpr int EW = AliasShape<NW>::EW;
+	u32 *e = alias + (h & amask) * EW;
+	u32 old = atomicCAS(&e[EW - 1], 0u, kAliasBusy);
+	if (old != 0u) {
+		e = alias + ((h >> 16) & amask) * EW;
+		old = atomicCAS(&e[EW - 1], 0u, kAliasBusy);
+	}
+	if (old == 0u) {
+#pragma unroll
+		for (int q = 0; q < NW; q++) e[q] = xs[q];
+		__hip_atomic_store(&e[EW - 1], (u32)slot + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
 }
 
 extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
@@ -338,7 +410,7 @@ __device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t,
 // straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
 // SPILL: such keys are not inserted but appended to the workgroup's region of the spill arrays (unconditional, clipped
 // stores: nothing waits for them), counted per bucket; census_scatter_kernel / census_combine_kernel take them from there.
-template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot)
+template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot, const int alias_entries)
 {
 	LdsTable *lt = reinterpret_cast<LdsTable *>(census_smem);
 	const int tid = threadIdx.x;
@@ -347,6 +419,13 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	const int nwave = blockDim.x >> 6;
 	uint8_t *tile = census_smem + sizeof(LdsTable) + (size_t)wave * tile_slot;
 	u32 *lh = reinterpret_cast<u32 *>(census_smem + sizeof(LdsTable) + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
+	// the wave's queue of rows that take the long way (a byte each: a step has at most 256 rows), then the alias table
+	constexpr int EW = AliasShape<NW>::EW;
+	uint8_t *queue = reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + wave * (kCensusMaxSub * 64);
+	u32 *alias = reinterpret_cast<u32 *>(reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + nwave * (kCensusMaxSub * 64));
+	const bool use_alias = EW > 0 && alias_entries > 0;
+	const u32 amask = (u32)alias_entries - 1u;
+	if (EW > 0) for (int i = tid; i < alias_entries * EW; i += blockDim.x) alias[i] = 0u;
 	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
 	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
 	__syncthreads();
@@ -361,6 +440,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		const int keep = a.L - 4 * q;
 		kms[q] = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
 	}
+	const bool need_last = ((a.L + 2) >> 2) >= NW;                 // a row that begins at byte 3 of a dword reaches dword (L + 2) / 4 of its span
 	const int64_t nsteps = (a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64);
 	const int64_t step = (int64_t)gridDim.x * nwave;
 	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
@@ -389,24 +469,78 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
 		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
 		u64 pklo[R], pkhi[R];
-		u32 ph[R];
+		u32 ph[R], prid[R];
 		u32 parked = 0u;
+		// ---- rows whose bytes the alias table knows are counted where it says; the others queue up for the long way -----
+		u32 qn = (u32)(R * 64);                                        // without the table every row of the step takes it
+		if constexpr (EW > 0) if (use_alias) {
+			qn = 0u;
+			// all of the step's row reads first, then all of its table reads, then the counting: three LDS round trips per
+			// step instead of three per 64 rows
+			u32 xs[R][NW], hs[R], ew[R][EW];
+#pragma unroll
+			for (int j = 0; j < R; j++) {
+				census_row_raw<NW>(tile, (j * 64 + lane) * stride, kms, xs[j], need_last);
+				hs[j] = alias_hash<NW>(xs[j]);
+			}
+#pragma unroll
+			for (int j = 0; j < R; j++) alias_load<NW>(alias + (hs[j] & amask) * EW, ew[j]);
+#pragma unroll
+			for (int j = 0; j < R; j++) {
+				const int64_t r = (t * R + j) * 64 + lane;
+				const bool want = r < a.n && ((take >> j) & 1u);
+				int slot = alias_match<NW>(ew[j], xs[j]);
+				if (want && slot < 0) {                                        // the string's other place
+					u32 w2[EW];
+					alias_load<NW>(alias + ((hs[j] >> 16) & amask) * EW, w2);
+					slot = alias_match<NW>(w2, xs[j]);
+				}
+				if (want && slot >= 0) {
+					const u64 first_inv = ~(u64)(a.row_base + r);
+					atomicAdd(&lt->count[slot], 1u);
+					if (__hip_atomic_load(&lt->first_inv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first_inv) atomicMax(&lt->first_inv[slot], first_inv);
+					counted++;
+				}
+				const bool miss = want && slot < 0;
+				const u64 bal = __ballot(miss);
+				if (miss) queue[qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (uint8_t)(j * 64 + lane);
+				qn += (u32)__popcll(bal);
+			}
+			census_wave_fence();
+		}
+		// ---- the long way, 64 queued rows at a time ------------------------------------------------------------------------
 #pragma unroll
 		for (int j = 0; j < R; j++) {
-			u32 bad;
-			const u32 nz = census_row_key<NW, false>(tile, (j * 64 + lane) * stride, kms, pklo[j], pkhi[j], bad);
-			// A NUL before L ends the barcode and what follows it is padding: only then (any row of the wave's tile) the
-			// keys are worked out again, exactly.
-			if (__any((nz & 0x80808080u) != 0x80808080u)) (void)census_row_key<NW, true>(tile, (j * 64 + lane) * stride, kms, pklo[j], pkhi[j], bad);
-			const int64_t r = (t * R + j) * 64 + lane;
 			ph[j] = 0u;
-			if (r < a.n && ((take >> j) & 1u)) {
-				if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
-				else {
-					counted++;
-					const u64 first_inv = ~(u64)(a.row_base + r);
-					const u32 h = census_hash(pklo[j], pkhi[j]);
-					if (!lds_count(lt, h >> 16, pklo[j], pkhi[j], 1u, first_inv)) { ph[j] = h; parked |= 1u << j; }
+			prid[j] = 0u;
+			pklo[j] = pkhi[j] = 0ull;
+			if ((u32)(j * 64) < qn) {
+				const u32 qi = (u32)(j * 64 + lane);
+				const bool have = qi < qn;
+				const u32 rid = use_alias ? (have ? (u32)queue[qi] : 0u) : qi;
+				prid[j] = rid;
+				u32 bad;
+				const u32 nz = census_row_key<NW, false>(tile, (int)rid * stride, kms, pklo[j], pkhi[j], bad);
+				// A NUL before L ends the barcode and what follows it is padding: only then (any row of the wave's tile) the
+				// keys are worked out again, exactly.
+				if (__any((nz & 0x80808080u) != 0x80808080u)) (void)census_row_key<NW, true>(tile, (int)rid * stride, kms, pklo[j], pkhi[j], bad);
+				const int64_t r = t * R * 64 + rid;
+				if (have && (use_alias || (r < a.n && ((take >> j) & 1u)))) {
+					if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
+					else {
+						counted++;
+						const u64 first_inv = ~(u64)(a.row_base + r);
+						const u32 h = census_hash(pklo[j], pkhi[j]);
+						const int slot = lds_count_at(lt, h >> 16, pklo[j], pkhi[j], 1u, first_inv);
+						if (slot < 0) { ph[j] = h; parked |= 1u << j; }
+						else if constexpr (EW > 0) if (use_alias && !(slot & kLdsClaimed)) {
+							// (a key's second occurrence earns the entry: one in ten rows of a noisy run is a string never seen
+							// again, and an entry is written once)
+							u32 xs[NW];
+							census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
+							alias_install<NW>(alias, amask, alias_hash<NW>(xs), xs, slot);
+						}
+					}
 				}
 			}
 		}
@@ -433,7 +567,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				const bool has = ((parked >> j) & 1u) != 0u;
 				const u32 at = has ? base + pos[j] : 0x07ffffffu;          // beyond the region: dropped by the descriptor
 				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), (u32)((t * R + j) * 64 + lane)};
+				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), (u32)(t * R * 64) + prid[j]};
 				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
 				if (has) atomicAdd(&lh[(u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift)], 1u);
 			}
@@ -447,7 +581,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				if (has) {
 					const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
 					qkey[pos] = make_uint4((u32)pklo[j], (u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32));
-					qrel[pos] = (u32)(j * 64 + lane);
+					qrel[pos] = prid[j];
 				}
 				qn += __popcll(bal);
 				while (qn >= 64 || (j == R - 1 && qn > 0)) {
@@ -932,7 +1066,19 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
 	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
-	const size_t lds = sizeof(LdsTable) + (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32);      // + slack: a row is read as 9 dwords; the spill counters
+	size_t lds = sizeof(LdsTable) + (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32)      // + slack: a row is read as 9 dwords; the spill counters
+	             + (size_t)kCensusWaves * kCensusMaxSub * 64;          // the waves' queues of rows that take the long way
+	// the alias table takes what is left of the CU's LDS (SK_CENSUS_ALIAS=0: none — tests run both forms)
+	const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
+	const int alias_ew = nw_class == 0 ? 4 : (nw_class == 1 ? 6 : 0);
+	int alias_entries = 0;
+	if (alias_ew > 0) {
+		alias_entries = kAliasMaxEntries;
+		while (alias_entries >= 256 && lds + (size_t)alias_entries * alias_ew * 4 > 160 * 1024) alias_entries >>= 1;
+		if (alias_entries < 256) alias_entries = 0;
+		if (const char *ev = getenv("SK_CENSUS_ALIAS")) { if (atoi(ev) == 0) alias_entries = 0; }
+	}
+	lds += (size_t)alias_entries * alias_ew * 4;
 	int wgs_per_cu = 1;
 	if (const char *ev = getenv("SK_CENSUS_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= 4) wgs_per_cu = v; }      // experiments
 	int direct_pct = 50;                                    // SK_CENSUS_SPILL_MAX_PCT: more spilled rows than this share of a launch are inserted directly
@@ -996,9 +1142,8 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
 			}
 		}
-		const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
-		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
-		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot);
+		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
+		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, alias_entries);
 		if (spill) {
 			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid);
 			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);

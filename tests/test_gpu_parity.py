@@ -956,17 +956,20 @@ def random_barcodes(n, L, stride, n_hot, hot_frac, seed, alphabet=b"ACGTN"):
     return m
 
 
-@pytest.fixture(params=["direct", "partition", "spilled_direct"])
+@pytest.fixture(params=["direct", "partition", "spilled_direct", "direct_no_alias", "partition_no_alias"])
 def census_path(request, monkeypatch):
     """The three ways a launch can take (sk_census.hip, census_add): keys the front tables have no room for are inserted by
     the front kernel itself (small launches), or written out and then partitioned + combined per table region, or — when
     most rows were written out — inserted as they lie.  Large launches choose between the last two by themselves; the
-    environment forces each here so that the small cases below walk all of them."""
-    if request.param == "direct":
+    environment forces each here so that the small cases below walk all of them.  In front of all three, rows whose bytes the
+    workgroup's alias table knows are counted without building their key; `_no_alias` runs without that table."""
+    if request.param.endswith("_no_alias"):
+        monkeypatch.setenv("SK_CENSUS_ALIAS", "0")
+    if request.param.startswith("direct"):
         monkeypatch.setenv("SK_CENSUS_SPILL", "0")
     else:
         monkeypatch.setenv("SK_CENSUS_SPILL", "1")
-        monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "100" if request.param == "partition" else "0")
+        monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "100" if request.param.startswith("partition") else "0")
     return request.param
 
 
@@ -1144,6 +1147,8 @@ def test_fuzz_census(ctx, oracle, monkeypatch, seed):
     path = ("direct", "partition", "spilled_direct")[seed % 3]
     monkeypatch.setenv("SK_CENSUS_SPILL", "0" if path == "direct" else "1")
     monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "0" if path == "spilled_direct" else "100")
+    if seed % 4 == 3:
+        monkeypatch.setenv("SK_CENSUS_ALIAS", "0")           # without the alias table in front of the path
     L = int(rng.integers(1, 32))
     stride = int(rng.integers(L, min(64, L + 9) + 1))
     n = int(rng.integers(1, 250_000))
