@@ -374,34 +374,43 @@ constexpr int kCensusMaxSub = 4;          // 64-row tiles per wave and step
 constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step: 5 x 16 B per lane in flight
 constexpr int kCensusQueue = 128;         // flush queue entries (16 B key + 4 B row): fewer than 64 left over + one tile's 64
 
-struct CensusTileRegs { uint4 v[5]; int32_t code[kCensusMaxSub]; };
+struct CensusTileRegs { uint4 v[5]; int32_t code[kCensusMaxSub] = {0, 0, 0, 0}; };
 
 // The R x 64 rows of step t are one contiguous, 16-byte aligned byte range: 16 bytes per lane and load, as unconditional
-// raw-buffer loads whose descriptor ends at the range's last valid dword (the hardware drops what lies beyond it, so
-// like the tile pass this may read up to 3 bytes past the end of the matrix).  What a wave has in flight is what
-// bounds this kernel when everything is counted in LDS (one 1 KiB tile per wave: 2 TB/s), hence R tiles per step.
-__device__ __forceinline__ void census_load_tile(const CensusArgs &a, int64_t t, int R, int lane, CensusTileRegs &rg)
+// raw-buffer loads.  ONE descriptor serves the launch's whole matrix (census_add keeps a launch below 2 GiB) and ends at the
+// matrix's last valid dword: what lies beyond it — the tail of the last step, every step past it — the hardware drops (so
+// like the tile pass this may read up to 3 bytes past the end of the matrix); a step's place travels in the offset.  (A
+// descriptor per step was ~60 scalar instructions of 64-bit arithmetic per step.)  What a wave has in flight is what bounds
+// this kernel when everything is counted in LDS (one 1 KiB tile per wave: 2 TB/s), hence R tiles per step.
+struct CensusStreams { __amdgpu_buffer_rsrc_t bc, assign; };
+__device__ __forceinline__ CensusStreams census_streams(const CensusArgs &a)
 {
-	const int step_bytes = R * 64 * a.bc_stride;
-	const int64_t total = a.n * (int64_t)a.bc_stride;
-	const int64_t base = t * (int64_t)step_bytes;
-	const int64_t rem = total - base;
-	const int bytes = rem <= 0 ? 0 : (int)(rem < step_bytes ? rem : step_bytes);      // a step past the end loads nothing
-	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.bc) + (rem <= 0 ? 0 : base), 0, (bytes + 3) & ~3, 0x00020000);
+	CensusStreams cs;
+	const u32 total = (u32)(a.n * (int64_t)a.bc_stride);
+	cs.bc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.bc), 0, (int)((total + 3u) & ~3u), 0x00020000);
+	cs.assign = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign), 0, a.assign ? (int)(a.n * 4) : 0, 0x00020000);
+	return cs;
+}
+// offk[k]: where the lane's k-th 16 bytes lie within a step, or 2^31 — past every launch — when that is behind the step's end
+// (those bytes are the next step's)
+__device__ __forceinline__ void census_load_tile(const CensusStreams &cs, bool has_assign, int t, int step_bytes, const u32 (&offk)[5], int R, int lane, CensusTileRegs &rg)
+{
 	// No branches around the loads — a load inside a conditional block is waited for at the end of that block, which
-	// serialises the five of them and the counting behind them; what lies beyond the step is clipped by the descriptor.
+	// serialises the five of them and the counting behind them; what lies beyond the matrix is clipped by the descriptor.
+	// (the assignment codes, when there are any, are asked for BEFORE the tile: the one conditional block with loads in it
+	// then lies in front of the unconditional ones, and the wait for the tile counts the same loads on both paths)
+	if (has_assign) {
+		const int r0 = (t * R * 64 + lane) * 4;
+#pragma unroll
+		for (int j = 0; j < kCensusMaxSub; j++)
+			rg.code[j] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(cs.assign, j < R ? r0 + j * 256 : 0x7ffffff0, 0, 0);
+	}
+	const u32 base = (u32)t * (u32)step_bytes;
 #pragma unroll
 	for (int k = 0; k < 5; k++) {
-		const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + k * 1024, 0, 0);
+		const auto v = __builtin_amdgcn_raw_buffer_load_b128(cs.bc, (int)(base + offk[k]), 0, 0);
 		memcpy(&rg.v[k], &v, 16);
 	}
-	const int64_t r0 = t * R * 64;
-	const int64_t left = a.n - r0;
-	const int rows = a.assign == nullptr || left <= 0 ? 0 : (int)(left < R * 64 ? left : R * 64);
-	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign) + (rows ? r0 : 0), 0, rows * 4, 0x00020000);
-#pragma unroll
-	for (int j = 0; j < kCensusMaxSub; j++)
-		rg.code[j] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, j < R ? (j * 64 + lane) * 4 : 0x7ffffff0, 0, 0);
 }
 
 // One row per lane, R 64-row tiles per wave and step.  A wave keeps the next step's bytes in registers while it
@@ -441,14 +450,19 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		kms[q] = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
 	}
 	const bool need_last = ((a.L + 2) >> 2) >= NW;                 // a row that begins at byte 3 of a dword reaches dword (L + 2) / 4 of its span
-	const int64_t nsteps = (a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64);
-	const int64_t step = (int64_t)gridDim.x * nwave;
+	const int nsteps = (int)((a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64));      // (a launch is fewer than 2^31 bytes: census_add)
+	const int step = (int)gridDim.x * nwave;
+	const int n32 = (int)a.n;
+	const CensusStreams streams = census_streams(a);
+	u32 offk[5];
+#pragma unroll
+	for (int k = 0; k < 5; k++) offk[k] = lane * 16 + k * 1024 < step_bytes ? (u32)(lane * 16 + k * 1024) : 0x80000000u;
 	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
 	CensusTileRegs rg;
 	uint4 *qkey = reinterpret_cast<uint4 *>(tile);                 // the flush queue reuses the wave's tile
 	u32 *qrel = reinterpret_cast<u32 *>(tile + kCensusQueue * 16);
-	int64_t t = (int64_t)blockIdx.x * nwave + wave;
-	census_load_tile(a, t, R, lane, rg);
+	int t = (int)blockIdx.x * nwave + wave;
+	census_load_tile(streams, a.assign != nullptr, t, step_bytes, offk, R, lane, rg);
 	for (; t < nsteps; t += step) {
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
@@ -464,7 +478,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			for (int j = 0; j < kCensusMaxSub; j++) take |= (rg.code[j] == kAssignNone ? 1u : 0u) << j;
 		}
 		census_wave_fence();
-		census_load_tile(a, t + step, R, lane, rg);       // in flight while this step is counted
+		census_load_tile(streams, a.assign != nullptr, t + step, step_bytes, offk, R, lane, rg);       // in flight while this step is counted
 		// Counting touches LDS only.  Keys the LDS table had no room for are parked in registers (one per lane and tile)
 		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
 		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
@@ -487,8 +501,8 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			for (int j = 0; j < R; j++) alias_load<NW>(alias + (hs[j] & amask) * EW, ew[j]);
 #pragma unroll
 			for (int j = 0; j < R; j++) {
-				const int64_t r = (t * R + j) * 64 + lane;
-				const bool want = r < a.n && ((take >> j) & 1u);
+				const int r = (t * R + j) * 64 + lane;
+				const bool want = r < n32 && ((take >> j) & 1u);
 				int slot = alias_match<NW>(ew[j], xs[j]);
 				if (want && slot < 0) {                                        // the string's other place
 					u32 w2[EW];
@@ -513,7 +527,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		for (int j = 0; j < R; j++) {
 			ph[j] = 0u;
 			prid[j] = 0u;
-			pklo[j] = pkhi[j] = 0ull;
+			pklo[j] = pkhi[j] = 0ull;                                 // (only read where `parked` says so: these cost nothing)
 			if ((u32)(j * 64) < qn) {
 				const u32 qi = (u32)(j * 64 + lane);
 				const bool have = qi < qn;
@@ -524,8 +538,8 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				// A NUL before L ends the barcode and what follows it is padding: only then (any row of the wave's tile) the
 				// keys are worked out again, exactly.
 				if (__any((nz & 0x80808080u) != 0x80808080u)) (void)census_row_key<NW, true>(tile, (int)rid * stride, kms, pklo[j], pkhi[j], bad);
-				const int64_t r = t * R * 64 + rid;
-				if (have && (use_alias || (r < a.n && ((take >> j) & 1u)))) {
+				const int r = t * R * 64 + (int)rid;
+				if (have && (use_alias || (r < n32 && ((take >> j) & 1u)))) {
 					if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
 					else {
 						counted++;
@@ -1091,6 +1105,10 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
 	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) chunk = (int64_t)1 << lg; }
 	if (const char *ev = getenv("SK_CENSUS_MIN_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) min_chunk = (int64_t)1 << lg; }
+	{	// a launch's matrix stays below 2 GiB: the front kernel addresses it through one descriptor with 32-bit offsets
+		const int64_t max_rows = ((((int64_t)1 << 31) - (1 << 24)) / bc_stride) & ~(int64_t)63;
+		if (chunk > max_rows) chunk = max_rows;
+	}
 	if (min_chunk > chunk) min_chunk = chunk;
 	int64_t nr = 0;
 	for (int64_t o = 0; o < n; o += nr) {
