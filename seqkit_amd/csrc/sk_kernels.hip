@@ -229,16 +229,14 @@ hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *ou
 // Packing K_j = U_j*2^11 + j turns "strictly smaller U, earliest j" into one signed min; K_0 = 0 is the
 // initial state (lowest_total = -50, lowest_k = n).  |U| <= 255*2047 keeps K inside int32.
 // ---------------------------------------------------------------------------------------------------
-// The four running sums inside a dword come from v_dot4_u32_u8 with byte-select multipliers, so they are
-// independent of each other (no 4-deep add chain) and cost one VALU op per byte.
+// The running sums inside a dword come from v_dot4_u32_u8 with byte-select multipliers, so they are independent of each
+// other (no add chain) and cost one VALU op per byte.
 //
 // Since K_j = U_j*2^11 + j with j < 2^11, the break condition U_j > 50 is K_j >= 51*2^11 — one constant for every j.
-// A dword is therefore handled whole: its four keys give Kmin and Kmax (two v_min3 / v_max3 pairs); while
-// Kmax < 51*2^11 nothing broke and Kmin is merged into the running best.  The dword in which a lane stops — a key at
-// or above the limit, or the row's last, partial dword — is only REMEMBERED (its index and the running sum before it);
-// after the loop every lane replays its own stop dword byte by byte.  That takes the per-byte compare / mask / select
-// chain and most of the scalar bookkeeping out of the loop (33 -> 21 VALU and 25 -> 11 SALU per dword step), and
-// the next dword's LDS read is issued before the current one is used.
+// An 8-byte step is therefore handled whole: its eight keys give Kmin and Kmax (v_min3 / v_max3 trees); while
+// Kmax < 51*2^11 nothing broke and Kmin is merged into the running best.  The step in which a lane stops — a key at or
+// above the limit, or the row's last, partial step — is left to a replay after the loop, byte by byte; the loop itself
+// (trim_scan_packed, SK_SCAN_ASM_*) has no per-byte compare / mask / select chain.
 constexpr int kBreakKey = 51 << kKeyBits;
 constexpr int kStragglerFrom = SK_STRAGGLER_FROM;   // 8-byte steps before the hand-over is considered
 constexpr int kStragglerLeft = SK_STRAGGLER_LEFT;   // ... and at least this many steps of the longest row are left
@@ -263,12 +261,12 @@ __device__ __forceinline__ int group8_min(int x)       // every lane of the grou
 }
 
 // Stragglers.  The lane-per-row loop below costs the same whether 64 rows are still being scanned or one, and one read
-// of a tile that never breaks (a read of '#', say — every run has some) keeps the whole wave in it for all ceil(L/4)
+// of a tile that never breaks (a read of '#', say — every run has some) keeps the whole wave in it for all ceil(L/8)
 // steps.  When at most 8 rows are left they are finished by the whole wave together: row g goes to lanes 8g..8g+7, lane
 // u of the group takes the 4 bytes u-th next in scan order (32 bytes of every row per round), the running sums come from
 // a prefix sum inside the group, the first lane of a group that sees the break (or the row's end) cuts the range, and the
-// minimum key before the cut is a minimum over the group.  ~60 VALU per round for all rows, against ~21 per dword step.
-// In: the rows of `todo` (<= 8) have consumed `j0` bytes each (whole dwords, none of them stopped); T / best are the
+// minimum key before the cut is a minimum over the group.  ~60 VALU per round for all rows, against ~30 per 8-byte step.
+// In: the rows of `todo` (<= 8) have consumed `j0` bytes each (whole steps, none of them stopped); T / best are the
 // per-lane running sum and best key.  Out: best of those lanes (src/fasta_trim_by_quality.rs:33-41 for the rest of the row).
 template <bool RAW = false>
 __device__ __forceinline__ void trim_finish_stragglers(const uint8_t *tile, unsigned long long todo, int j0, int step, int lane,
@@ -452,8 +450,8 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 {
 	// EIGHT bytes per step: the two dwords come from one LDS instruction (ds_read2_b32), their eight keys give one
 	// minimum and one maximum, and the step's bookkeeping is paid once per eight bytes.
-	// The loop is what a pass over long scans is bound by — by the instructions it issues, vector AND scalar (DESIGN.md
-	// A.4) — so it is a plain divergent loop: a lane whose step holds a break (or whose row has no whole step left) LEAVES
+	// The loop is what a pass over long scans is bound by — by the instructions it issues, vector AND scalar
+	// (EXPERIMENTS.md A.4, A.5) — so it is a plain divergent loop: a lane whose step holds a break (or whose row has no whole step left) LEAVES
 	// it, and the hardware's execution mask does what selects and ballots did before (a lane that is out writes nothing:
 	// its sum and its best key stay what they were; "is anybody left" is the loop's own exec test).  The step a lane
 	// stopped in is replayed byte by byte after the loop.
@@ -482,6 +480,7 @@ __device__ __forceinline__ int trim_scan_packed(const uint8_t *tile, int row_sta
 	// count of whole steps is read off its LDS pointer afterwards (only survivors move it on), and the next step's two
 	// dwords are loaded into the registers the v_alignbyte pair has just consumed.
 	(void)active;
+	static_assert(kLdsPad >= 16, "the scan reads up to 16 bytes in front of the tile image");
 	const int my_full = len >> 3;
 	// hand-over window as one unsigned compare: kStragglerFrom <= jj < nst - kStragglerLeft for the step jj just completed
 	const u32 strag_span = nst - kStragglerLeft > kStragglerFrom ? (u32)(nst - kStragglerLeft - kStragglerFrom) : 0u;
