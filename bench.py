@@ -326,7 +326,41 @@ def secondary_rates(torch, ctx, dev):
     for r0 in range(0, n, 2_000_000):
         q[r0:r0 + 2_000_000] = ((torch.randn((2_000_000, 150), generator=g, device=dev) * 6.0 + mu).round_().clamp_(2, 40) + 33).to(torch.uint8)
     timeit("cfg2 read-like qualities: trim by quality 16M x 150bp", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
-    del q, s, o, lk
+    # The fused pass in the forms BASELINE.md §3 names beside the paired headline: single-end 150 bp with an 8 bp barcode out of
+    # 16 (the fused form of configs[2], 308 B read + 156 B written = 464 B/read), the same with ragged rows (a u16 length
+    # column, +2 B), and the paired dual-index pass with the detail columns of matched rows (lowest_diff u8, first / last i16: +5 B).
+    table = synth.make_sheet(16, 8, dual=False, seed=3)
+    ctx.set_barcodes(table, 1)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
+    bc1 = torch.from_numpy(bc_np).to(dev).repeat(16, 1).contiguous()
+    assign = torch.empty((n,), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((16 + 3,), dtype=torch.int64, device=dev)
+    mate = {"seq": s.data_ptr(), "qual": q.data_ptr(), "len": 0, "out_seq": o.data_ptr(), "lowest_k": lk.data_ptr()}
+    timeit("fused single-end: demultiplex + trim + mask, 16M x 150bp + 8bp, 16 barcodes",
+           lambda: ctx.fused_pass_dev(n, 150, 20, [mate], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 464)
+    ln = torch.randint(100, 151, (n,), dtype=torch.int16, device=dev, generator=g)
+    mate_r = dict(mate, len=ln.data_ptr())
+    timeit("fused single-end, ragged rows (u16 lengths 100-150): 16M x <=150bp + 8bp, 16 barcodes",
+           lambda: ctx.fused_pass_dev(n, 150, 20, [mate_r], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 466)
+    del bc1, ln
+    table = synth.make_sheet(96, 8, dual=True, seed=4)
+    ctx.set_barcodes(table, 1)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+    bc2 = torch.from_numpy(bc_np).to(dev).repeat(16, 1).contiguous()
+    s2, q2 = s.flip(0).contiguous(), q.flip(0).contiguous()
+    o2 = torch.empty_like(o)
+    lk2 = torch.empty_like(lk)
+    low = torch.empty((n,), dtype=torch.uint8, device=dev)
+    first = torch.empty((n,), dtype=torch.int16, device=dev)
+    last = torch.empty((n,), dtype=torch.int16, device=dev)
+    cnt2 = torch.zeros((96 + 3,), dtype=torch.int64, device=dev)
+    mates2 = [mate, {"seq": s2.data_ptr(), "qual": q2.data_ptr(), "len": 0, "out_seq": o2.data_ptr(), "lowest_k": lk2.data_ptr()}]
+    ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
+    timeit("fused paired with the detail columns of matched clusters (SK_DETAIL_MATCHED): 16M x 2x150bp, 96 dual-index",
+           lambda: ctx.fused_pass_dev(n, 150, 20, mates2, bc=bc2.data_ptr(), bc_stride=17, assign=assign.data_ptr(), lowest_diff=low.data_ptr(),
+                                      first_idx=first.data_ptr(), last_idx=last.data_ptr(), counts=cnt2.data_ptr()), n, 930)
+    ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+    del q, s, o, lk, s2, q2, o2, lk2, bc2, low, first, last, assign, cnt, cnt2
     n = 10_000_000
     table = synth.make_sheet(16, 8, dual=False, seed=3)
     ctx.set_barcodes(table, 1)
@@ -404,6 +438,22 @@ def secondary_rates(torch, ctx, dev):
         out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
                     "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4)})
         del bc
+    # the floor of the census: every row a key never seen before (random 16-mers: 32 M distinct keys enter the HBM table)
+    rows = 32_000_000
+    bc = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (rows, 16), device=dev, generator=g)].contiguous()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        ctx.census_reset()
+        ctx.sync()
+        ctx.timer_start()
+        ctx.census_add_dev(bc.data_ptr(), 16, 16, rows, 0, 0)
+        ts.append(ctx.timer_stop())
+    ms = sorted(ts[1:])[0]
+    out.append({"config": "f3: census 32M rows, every row a new key (random 16-mers)", "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2),
+                "bytes_per_unit": 16, "GBps": round(rows * 16 / ms / 1e6, 1), "frac": round(rows * 16 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "distinct": int(ctx.census_stats()["distinct"])})
+    del bc
     return out
 
 
@@ -845,6 +895,10 @@ def main():
             except Exception:
                 traffic = traffic_source = None
         kernel = "sk::tile_blocked_kernel" if lay is not None else "sk::tile_pass_kernel"
+        # the same pass on the buffers as they were allocated, before any placement was chosen (config.placement: ms_before of
+        # the SoA tuner, probe_ms[0][0] of the blocked probe); null when only one candidate was allocated — frac is then as placed
+        ms_placed = placement.get("ms_before") if lay is None else (placement["probe_ms"][0][0] if placement.get("probe_ms") else None)
+        frac_as_placed = round(BYTES_PER_PAIR * n / (ms_placed * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_placed else None
         line = {
             "metric": "M reads/s demultiplex (150bp, 96 barcodes) at 1/8 GPUs; % HBM roofline",
             "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -866,7 +920,8 @@ def main():
                                         f"RCCL ncclAllReduce(sum, u64[{S + 3}]) per step on the ctx stream, {world} rank(s), communicator inside libseqkit_hip.so"
                                         if rccl_err is None else f"gloo all-reduce with a host round trip (RCCL unavailable: {rccl_err})")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_as_placed": frac_as_placed,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},

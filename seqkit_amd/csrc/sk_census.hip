@@ -48,12 +48,21 @@ struct CensusSpill {
 	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket
 	u32 *bstart = nullptr;       // [kSpillBuckets + 1]
 	u32 *wg_count = nullptr;     // [grid]
+	u32 *wg_stats = nullptr;     // [grid][kCensusStats]: the front kernel's statistics per workgroup (summed by census_scan_kernel)
 	u32 *work = nullptr;         // census_combine_kernel's item counter (zeroed by census_scan_kernel)
 	u32 cap = 0;                 // records per workgroup region
 	u32 bucket_shift = 0;        // bucket = (hash & mask) >> bucket_shift
 	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not partitioned
 	u32 grid = 0;                // workgroups of the front kernel
+	u32 merge_copies = 0;        // != 0: the front kernel's tables leave their workgroup as records, not as inserts
 };
+
+// A record's fourth dword: the row index within the launch (a launch is at most 2^25 rows: kCensusChunk) and how many rows
+// the record stands for — digit d = 1..31 at level v = 0..3, d << (5 v) rows: a row the front tables had no room for is
+// (d, v) = (1, 0); a front-table key counted c times leaves the workgroup as the non-zero base-32 digits of c.
+constexpr int kRecRowBits = 25;
+__device__ __forceinline__ u32 census_rec_row(u32 w) { return w & ((1u << kRecRowBits) - 1u); }
+__device__ __forceinline__ u32 census_rec_count(u32 w) { return (((w >> 27) & 31u) + 1u) << (5u * ((w >> kRecRowBits) & 3u)); }
 
 struct Census {
 	CensusSpill sp;
@@ -347,6 +356,17 @@ template <int NW> __device__ __forceinline__ void alias_install(u32 *alias, u32 
 
 extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
 
+// -DSK_CENSUS_STAMPS (diagnostic builds only, tools/census_stamps.sh): every wave of the front kernel adds up the shader
+// cycles (s_memtime) it spent in each phase of its steps; sk_debug_census_stamps() reads the sums back.  No stamp executes in
+// the product build.
+#ifdef SK_CENSUS_STAMPS
+constexpr int kStampSlots = 16;
+__device__ u64 g_census_stamps[8192 * kStampSlots];
+#define SK_STAMP(i) do { const u64 now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
+
 struct CensusArgs {
 	const uint8_t *bc;
 	int bc_stride;
@@ -437,7 +457,18 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	if (EW > 0) for (int i = tid; i < alias_entries * EW; i += blockDim.x) alias[i] = 0u;
 	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
 	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
+	// The workgroup's steps are dealt to its waves as they come free (an LDS counter): the waves of a SIMD do not advance at
+	// the same rate, and with a fixed deal the workgroup waited 9-16 % of its lifetime at the barrier behind the loop for its
+	// slowest wave (profiles/r04_census_stamps.txt).  Step c of workgroup b is tile-step ((c / nwave) * grid + b) * nwave +
+	// c % nwave — the same set of steps as the fixed deal, so what the chip reads at any moment is still one advancing window.
+	u32 *step_ctr = lh + kSpillBuckets + 1;
+	if (tid == 0) *step_ctr = (u32)nwave;                              // the first nwave steps are the waves' own
+#ifdef SK_CENSUS_STAMPS
+	u64 st_acc[kStampSlots] = {};
+	u64 st_last = __builtin_amdgcn_s_memtime();
+#endif
 	__syncthreads();
+	SK_STAMP(0);                                                       // tables cleared
 	__amdgpu_buffer_rsrc_t sp_key;
 	if (SPILL) sp_key = __builtin_amdgcn_make_buffer_rsrc(a.sp.key + (size_t)blockIdx.x * a.sp.cap, 0, (int)(a.sp.cap * 16u), 0x00020000);
 
@@ -451,8 +482,9 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	}
 	const bool need_last = ((a.L + 2) >> 2) >= NW;                 // a row that begins at byte 3 of a dword reaches dword (L + 2) / 4 of its span
 	const int nsteps = (int)((a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64));      // (a launch is fewer than 2^31 bytes: census_add)
-	const int step = (int)gridDim.x * nwave;
 	const int n32 = (int)a.n;
+	const int nwave_lg = 31 - __builtin_clz((u32)nwave);              // (the launch is kCensusWaves = 16 waves: a power of two)
+	auto step_of = [&](u32 c) -> int { return (int)((((c >> nwave_lg) * gridDim.x + blockIdx.x) << nwave_lg) + (c & ((u32)nwave - 1u))); };
 	const CensusStreams streams = census_streams(a);
 	u32 offk[5];
 #pragma unroll
@@ -463,12 +495,15 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	u32 *qrel = reinterpret_cast<u32 *>(tile + kCensusQueue * 16);
 	int t = (int)blockIdx.x * nwave + wave;
 	census_load_tile(streams, a.assign != nullptr, t, step_bytes, offk, R, lane, rg);
-	for (; t < nsteps; t += step) {
+	while (t < nsteps) {
+		u32 next_c = 0u;                                               // asked for before the tile is written: the answer is there when the fence is
+		if (lane == 0) next_c = atomicAdd(step_ctr, 1u);
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
 			const int off = lane * 16 + k * 1024;
 			if (off < step_bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];
 		}
+		SK_STAMP(1);                                                   // the step's loads waited for, tile written
 		// which of the step's rows are counted, worked out BEFORE the next step's loads are issued: nothing below may
 		// wait for a register that a load of this or an earlier step wrote, or it waits for the new loads as well
 		u32 take = 0xFu;
@@ -478,7 +513,13 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			for (int j = 0; j < kCensusMaxSub; j++) take |= (rg.code[j] == kAssignNone ? 1u : 0u) << j;
 		}
 		census_wave_fence();
-		census_load_tile(streams, a.assign != nullptr, t + step, step_bytes, offk, R, lane, rg);       // in flight while this step is counted
+#ifdef SK_CENSUS_STATIC_STEPS                                              // (A/B builds: the fixed deal)
+		const int tn = t + (int)gridDim.x * nwave;
+#else
+		const int tn = step_of((u32)__builtin_amdgcn_readfirstlane((int)next_c));
+#endif
+		census_load_tile(streams, a.assign != nullptr, tn, step_bytes, offk, R, lane, rg);       // in flight while this step is counted
+		SK_STAMP(2);                                                   // fence, next step's loads issued
 		// Counting touches LDS only.  Keys the LDS table had no room for are parked in registers (one per lane and tile)
 		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
 		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
@@ -522,6 +563,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			}
 			census_wave_fence();
 		}
+		SK_STAMP(3);                                                   // rows the alias table knows
 		// ---- the long way, 64 queued rows at a time ------------------------------------------------------------------------
 #pragma unroll
 		for (int j = 0; j < R; j++) {
@@ -559,6 +601,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			}
 		}
 		census_wave_fence();
+		SK_STAMP(4);                                                   // the long way
 		// The parked keys, packed densely through the (now dead) tile so that one insert serves up to 64 of them: its
 		// dependent round trips are paid per call, not per key.  (Fetching the slots a step ahead of the insert was tried:
 		// no gain — what bounds this leg is the rate of scattered atomics, not their latency.)
@@ -614,20 +657,73 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			}
 		}
 		census_wave_fence();
+		SK_STAMP(5);                                                   // parked keys: spill records / inserts
+		t = tn;
 	}
+	SK_STAMP(6);                                                       // (loop exit)
 	__syncthreads();
+	SK_STAMP(7);                                                       // waiting for the workgroup's other waves
+	bool all_records = false;
 	if (SPILL) {
+		// The table of a noisy run is full of keys this workgroup saw a few times — and 255 other workgroups hold the same
+		// keys: inserting them from here was half a million CAS / adds at the end of the launch with nothing to hide behind,
+		// and the sheet's own barcodes were added to by every workgroup at the same moment (21-25 % of a wave's lifetime,
+		// profiles/r04_census_stamps.txt).  With the partition path behind it the table leaves as RECORDS instead: a key counted
+		// c times is the non-zero base-32 digits of c (at most four 16-byte stores, one for most keys), each with the key's
+		// first row; the combine pass adds them up with the other workgroups' before anything touches HBM.  Such records stand
+		// for rows that were NOT spilled, so the workgroup's region (one record per row) has room for them.
+		all_records = a.sp.merge_copies != 0u;
+		if (all_records) for (int i = tid; i < kLdsSlots; i += blockDim.x) {
+			const u64 sk = lt->klo[i];
+			const u32 sc = lt->count[i];
+			const bool rec = sk != 0 && sc < (1u << 20);                   // (a count beyond four digits is inserted below: never in a launch of 2^25 rows over 256 workgroups)
+			u32 digit[4], c = 0u;
+#pragma unroll
+			for (int v = 0; v < 4; v++) {
+				digit[v] = rec ? (sc >> (5 * v)) & 31u : 0u;
+				c += digit[v] != 0u ? 1u : 0u;
+			}
+			u32 incl = c;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const u32 up = __shfl_up(incl, o);
+				if (lane >= o) incl += up;
+			}
+			const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+			u32 base = 0u;
+			if (tot != 0u) {
+				if (lane == 0) base = atomicAdd(&lh[kSpillBuckets], tot);
+				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			}
+			const u64 khi = ~lt->khi_inv[i];
+			const u32 row = (u32)(~lt->first_inv[i] - (u64)a.row_base);
+			u32 pos = base + incl - c;
+#pragma unroll
+			for (int v = 0; v < 4; v++) {
+				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+				const u32x4_t kq = {(u32)(sk >> 32), (u32)khi, (u32)(khi >> 32), row | ((u32)v << kRecRowBits) | ((digit[v] - 1u) << 27)};
+				const u32 at = digit[v] != 0u ? pos : 0x07ffffffu;             // beyond the region: dropped by the descriptor
+				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
+				pos += digit[v] != 0u ? 1u : 0u;
+			}
+			if (c != 0u) {
+				atomicAdd(&lh[(u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift)], c);
+				lt->klo[i] = 0ull;                                             // (this thread's own slot: gone from the table)
+			}
+		}
+		__syncthreads();
 		for (int i = tid; i < kSpillBuckets; i += blockDim.x) a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + i] = lh[i];
 		if (tid == 0) a.sp.wg_count[blockIdx.x] = lh[kSpillBuckets];
 	}
-	// merge the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of them
-	// hold (the frequent ones) are not hit by all of them at the same moment
+	// merge (what is left of) the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of
+	// them hold (the frequent ones) are not hit by all of them at the same moment
 	for (int i0 = tid; i0 < kLdsSlots; i0 += blockDim.x) {
 		const int i = (i0 + (int)blockIdx.x * 67) & (kLdsSlots - 1);
 		const u64 sk = lt->klo[i];
 		const u32 sc = lt->count[i];
 		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 	}
+	SK_STAMP(8);                                                       // front table merged into HBM
 	// one atomic per WORKGROUP and statistic: the waves of a launch end together, and 4 096 additions to one address are
 	// served one after the other (34 us of an 84 us launch of 1 M rows when every wave sent its own)
 	for (int o = 32; o > 0; o >>= 1) {
@@ -647,7 +743,13 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		if (overflow) atomicAdd(&wg_stats[3], overflow);
 	}
 	__syncthreads();
-	if (tid < kCensusStats && wg_stats[tid] != 0u) atomicAdd(&a.stats[tid], (u64)wg_stats[tid]);
+	if (SPILL) { if (tid < kCensusStats) a.sp.wg_stats[blockIdx.x * kCensusStats + tid] = wg_stats[tid]; }      // census_scan_kernel adds them up
+	else if (tid < kCensusStats && wg_stats[tid] != 0u) atomicAdd(&a.stats[tid], (u64)wg_stats[tid]);
+#ifdef SK_CENSUS_STAMPS
+	SK_STAMP(9);
+	if (lane == 0 && blockIdx.x * nwave + wave < 8192)
+		for (int i = 0; i < kStampSlots; i++) g_census_stamps[(blockIdx.x * nwave + wave) * kStampSlots + i] = st_acc[i];
+#endif
 }
 
 // ---- the partition path -------------------------------------------------------------------------------------------
@@ -655,10 +757,22 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 // workgroup takes 64 buckets; its 16 waves split the rows g among them (every load is one contiguous 256-byte piece of a
 // row, and none depends on another).
 constexpr int kScanBuckets = 64;
-__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, u32 *__restrict__ work, int grid)
+__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, u32 *__restrict__ work, int grid,
+                                                            const u32 *__restrict__ wg_stats, u64 *__restrict__ stats)
 {
 	if (blockIdx.x == 0 && threadIdx.x == 0) *work = 0u;
 	__shared__ u32 part[16][kScanBuckets];
+	if (blockIdx.x == 1) {                                             // the front kernel's statistics: 4 atomics per launch instead of 4 per workgroup
+		__shared__ u32 ssum[kCensusStats];
+		if (threadIdx.x < kCensusStats) ssum[threadIdx.x] = 0u;
+		__syncthreads();
+		u32 v = 0u;
+		for (int i = threadIdx.x; i < grid * kCensusStats; i += blockDim.x) v += wg_stats[i];      // (blockDim is a multiple of kCensusStats: thread x sums statistic x % 4)
+		for (int o = 32; o >= kCensusStats; o >>= 1) v += __shfl_xor(v, o);
+		if ((threadIdx.x & 63) < kCensusStats && v != 0u) atomicAdd(&ssum[threadIdx.x & 3], v);
+		__syncthreads();
+		if (threadIdx.x < kCensusStats && ssum[threadIdx.x] != 0u) atomicAdd(&stats[threadIdx.x], (u64)ssum[threadIdx.x]);
+	}
 	const int lb = threadIdx.x & (kScanBuckets - 1), grp = threadIdx.x / kScanBuckets;
 	const int b = blockIdx.x * kScanBuckets + lb;
 	const int per = (grid + 15) / 16;
@@ -822,7 +936,7 @@ __device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 ov
 // key (one that some front table had no room for) is split among workgroups, since what they add is additive — and the
 // workgroups take items from a counter until none is left.
 constexpr int kCombineThreads = 512;
-constexpr int kCombineChunk = 8192;
+constexpr int kCombineChunk = 16384;
 __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const CensusArgs a)
 {
 	__shared__ LdsTable lt_s;
@@ -858,11 +972,12 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 		for (u32 i = lo + tid; i < hi; i += blockDim.x) {
 			const uint4 k = a.sp.skey[i];
 			const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-			const u64 first_inv = ~(u64)(a.row_base + k.w);
+			const u64 first_inv = ~(u64)(a.row_base + census_rec_row(k.w));
+			const u32 cnt = census_rec_count(k.w);
 			const u32 h = census_hash(klo, khi);
-			if (!lds_count(lt, h, klo, khi, 1u, first_inv)) {      // the hash's LOW bits: its high bits are the bucket's, the same for every key here
+			if (!lds_count(lt, h, klo, khi, cnt, first_inv)) {     // the hash's LOW bits: its high bits are the bucket's, the same for every key here
 				const u64 idx = (u64)h & a.mask;
-				if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, 1ull, first_inv, claimed)) overflow++;
+				if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, (u64)cnt, first_inv, claimed)) overflow += cnt;
 			}
 		}
 		__syncthreads();
@@ -894,7 +1009,8 @@ __global__ __launch_bounds__(1024) void census_direct_kernel(const CensusArgs a)
 	for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
 		const uint4 k = key[i];
 		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-		if (!census_insert(a.tab, a.mask, klo, khi, 1ull, ~(u64)(a.row_base + k.w), claimed)) overflow++;
+		const u32 cnt = census_rec_count(k.w);
+		if (!census_insert(a.tab, a.mask, klo, khi, (u64)cnt, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += cnt;
 	}
 	census_add_stats(a.stats, claimed, overflow, red);
 }
@@ -1039,7 +1155,7 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 
 static void census_spill_free(Census *cs)
 {
-	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count, cs->sp.work};
+	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count, cs->sp.wg_stats, cs->sp.work};
 	for (void *q : ptrs) if (q) (void)hipFree(q);
 	cs->sp = CensusSpill();
 	cs->sp_records = 0;
@@ -1061,6 +1177,7 @@ static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.btot, kSpillBuckets * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.bstart, (kSpillBuckets + 1) * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_count, (size_t)want_grid * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_stats, (size_t)want_grid * kCensusStats * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.work, sizeof(u32));
 	if (e != hipSuccess) { (void)hipGetLastError(); census_spill_free(cs); return e; }
 	cs->sp_records = want_records;
@@ -1099,11 +1216,13 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_SPILL_MAX_PCT")) { const int v = atoi(ev); if (v >= 0 && v <= 100) direct_pct = v; }
 	int64_t spill_min_rows = kSpillMinRows;                 // SK_CENSUS_SPILL_MIN_ROWS_LOG2: tests lower it
 	if (const char *ev = getenv("SK_CENSUS_SPILL_MIN_ROWS_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) spill_min_rows = (int64_t)1 << lg; }
+	int merge_copies = 1;                                   // SK_CENSUS_MERGE_RECORDS=0: the front kernel inserts its tables itself, as small launches do (A/B, tests)
+	if (const char *ev = getenv("SK_CENSUS_MERGE_RECORDS")) merge_copies = atoi(ev) != 0;
 	int spill_mode = -1;                                    // SK_CENSUS_SPILL=0/1: never / always (tests, experiments)
 	if (const char *ev = getenv("SK_CENSUS_SPILL")) spill_mode = atoi(ev) != 0;
 	// (SK_CENSUS_CHUNK_LOG2 / SK_CENSUS_MIN_CHUNK_LOG2: tests shrink the launches to walk the grow / smaller-bite decisions)
 	int64_t chunk = kCensusChunk, min_chunk = kCensusMinChunk;
-	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) chunk = (int64_t)1 << lg; }
+	if (const char *ev = getenv("SK_CENSUS_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= kRecRowBits) chunk = (int64_t)1 << lg; }      // (a record's row index has kRecRowBits bits)
 	if (const char *ev = getenv("SK_CENSUS_MIN_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) min_chunk = (int64_t)1 << lg; }
 	{	// a launch's matrix stays below 2 GiB: the front kernel addresses it through one descriptor with 32-bit offsets
 		const int64_t max_rows = ((((int64_t)1 << 31) - (1 << 24)) / bc_stride) & ~(int64_t)63;
@@ -1155,6 +1274,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 				a.sp.cap = (u32)cap;
 				a.sp.grid = (u32)grid;
 				a.sp.direct_above = (u32)((uint64_t)nr * (uint64_t)direct_pct / 100);
+				a.sp.merge_copies = (u32)merge_copies;
 				int lg = 0;
 				while ((1ull << lg) < cs->slots) lg++;
 				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
@@ -1163,7 +1283,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
 		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, alias_entries);
 		if (spill) {
-			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid);
+			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid, a.sp.wg_stats, a.stats);
 			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
 			census_combine_kernel<<<2 * n_cu, kCombineThreads, 0, st>>>(a);
 			census_direct_kernel<<<grid, 1024, 0, st>>>(a);
@@ -1241,3 +1361,10 @@ hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint
 }
 
 }  // namespace sk
+
+#ifdef SK_CENSUS_STAMPS
+extern "C" int sk_debug_census_stamps(unsigned long long *out, int waves)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sk::g_census_stamps), (size_t)waves * sk::kStampSlots * sizeof(unsigned long long));
+}
+#endif

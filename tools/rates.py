@@ -42,6 +42,39 @@ for n in (1_000_000, 16_000_000):
     s = torch.randint(65, 85, (n, 150), dtype=torch.uint8, device=dev, generator=g)
     o = torch.empty_like(s)
     timeit(f"cfg1-shape mask by quality {n} x 150bp (450 B/read)", lambda: ctx.mask_by_quality_dev(s.data_ptr(), q.data_ptr(), 150, n, 20, o.data_ptr()), n, 450)
+    if n == 16_000_000:
+        # the fused pass in the forms BASELINE.md §3 names beside the paired headline (same rows as bench.py's extra.rates)
+        from seqkit_amd import capi as _capi
+        t16 = synth.make_sheet(16, 8, dual=False, seed=3)
+        ctx.set_barcodes(t16, 1)
+        b_np, _ = synth.observe_barcodes(t16, 1_000_000, seed=3)
+        bc1 = torch.from_numpy(b_np).to(dev).repeat(16, 1).contiguous()
+        assign = torch.empty((n,), dtype=torch.int32, device=dev)
+        cnt = torch.zeros((96 + 3,), dtype=torch.int64, device=dev)
+        n_mates = 1
+        mate = {"seq": s.data_ptr(), "qual": q.data_ptr(), "len": 0, "out_seq": o.data_ptr(), "lowest_k": lk.data_ptr()}
+        timeit("fused single-end 16M x 150bp + 8bp, 16 barcodes (464 B/read)",
+               lambda: ctx.fused_pass_dev(n, 150, 20, [mate], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 464)
+        ln = torch.randint(100, 151, (n,), dtype=torch.int16, device=dev, generator=g)
+        mate_r = dict(mate, len=ln.data_ptr())
+        timeit("fused single-end, ragged rows 100-150 (466 B/read)",
+               lambda: ctx.fused_pass_dev(n, 150, 20, [mate_r], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 466)
+        t96 = synth.make_sheet(96, 8, dual=True, seed=4)
+        ctx.set_barcodes(t96, 1)
+        b_np, _ = synth.observe_barcodes(t96, 1_000_000, seed=4, halves=2)
+        bc2 = torch.from_numpy(b_np).to(dev).repeat(16, 1).contiguous()
+        s2, q2, o2, lk2 = s.flip(0).contiguous(), q.flip(0).contiguous(), torch.empty_like(o), torch.empty_like(lk)
+        low = torch.empty((n,), dtype=torch.uint8, device=dev)
+        first = torch.empty((n,), dtype=torch.int16, device=dev)
+        last = torch.empty((n,), dtype=torch.int16, device=dev)
+        n_mates = 2
+        mates2 = [mate, {"seq": s2.data_ptr(), "qual": q2.data_ptr(), "len": 0, "out_seq": o2.data_ptr(), "lowest_k": lk2.data_ptr()}]
+        ctx.set_detail_mode(_capi.SK_DETAIL_MATCHED)
+        timeit("fused paired + detail of matched clusters, 16M x 2x150bp, 96 dual-index (930 B/cluster)",
+               lambda: ctx.fused_pass_dev(n, 150, 20, mates2, bc=bc2.data_ptr(), bc_stride=17, assign=assign.data_ptr(), lowest_diff=low.data_ptr(),
+                                          first_idx=first.data_ptr(), last_idx=last.data_ptr(), counts=cnt.data_ptr()), n, 930)
+        ctx.set_detail_mode(_capi.SK_DETAIL_FULL)
+        del bc1, bc2, s2, q2, o2, lk2, low, first, last, assign, cnt, ln
     del q, lk, s, o
 
 # cfg 3: demultiplex 10M x 8bp, 16 barcodes
