@@ -287,19 +287,39 @@ __device__ __forceinline__ int lds_count_at(LdsTable *lt, u32 at, u64 klo, u64 k
 }
 __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv) { return lds_count_at(lt, at, klo, khi, cnt, first_inv) >= 0; }
 
-// ---- the alias table: rows whose BYTES were seen before are counted without building their key --------------------------
-// Building a row's key — classify every character, pack, hash, probe the front table — is ~125 of the front kernel's vector
-// instructions per row, and the kernel is bound by the instructions it issues.  Most rows of a run repeat a few thousand
-// byte strings (the sheet's barcodes and their neighbours), so the workgroup keeps a second, smaller LDS table keyed by the
-// row's L raw bytes (masked dwords as they lie in the tile) whose entries name the front table's slot of that string's key:
-// a row that hits it is one hash of its dwords, one entry read, a compare and the LDS atomic.  An entry is written once — by
-// a lane that has just taken the long way with exactly these bytes, so whatever the long way checks (alphabet, an early NUL
-// and what follows it) holds for every row that matches the entry byte for byte — claimed with a CAS on its slot word,
-// published by the store of that word after the bytes; a reader that overlaps the writer sees zeros or the finished entry.
-// Two candidate places per string; a string that finds both taken keeps going the long way.
-constexpr u32 kAliasBusy = 0xFFFFFFFFu;
-constexpr int kAliasMaxEntries = 2048;
-template <int NW> struct AliasShape { static constexpr int EW = NW <= 2 ? 4 : (NW <= 5 ? 6 : 0); };      // dwords per entry (the last is the slot word); 0: no table for keys that long
+// ---- the workgroup's front table: keyed by a row's BYTES ---------------------------------------------------------------
+// Building a row's key — classify every character, pack, hash — is most of what the census does per row, and most rows of a
+// run repeat a few thousand byte strings (the sheet's barcodes and their neighbours).  So the table a workgroup keeps in LDS
+// in front of the HBM table is keyed by the row's L RAW bytes (its masked dwords as they lie in the tile): a row whose
+// string is there is one hash of its dwords, one entry read, a compare and the LDS add — no key is built for it at all.  A
+// string enters the table on the long way (below), after its characters were checked; what the long way checks — the
+// alphabet; a NUL before L ends the barcode, and the bytes behind it are zeroed before the string is looked up or stored —
+// then holds for every later row that matches the entry byte for byte.  Keys are built once per ENTRY, when the table
+// leaves the workgroup.  (Rounds 2-3 kept a table keyed by the packed key with this one as an "alias" in front of it: two
+// lookups, two installs and two sets of probes per new string.)
+//
+// The table is three or four arrays of `entries` elements, so that neighbouring entries lie in neighbouring banks (as one
+// 32-byte record per entry, the counts of ALL entries lay in four of the 32 banks — every add of a wave queued up behind
+// the others: SQ_LDS_BANK_CONFLICT was 61 % of SQ_LDS_IDX_ACTIVE): chunk B {string dword 4, 0, first row, state}, chunk A
+// {string dwords 0..3}, for strings of more than 20 bytes chunk C {dwords 4..7} (B's first dword is then unused), and the
+// counts (u32).  The first row is the index within the launch.  Two candidate places per string.
+// Protocol: a writer claims an EMPTY entry with a CAS on the state (-> BUSY), writes chunk A (and C), then chunk B — its
+// row, READY — as ONE 16-byte store; its count goes in with an add like everybody's.  A reader loads chunk B FIRST: the LDS
+// executes a wave's operations in order and a lane's 16 bytes in one cycle, so a READY seen there means the string read after
+// it is complete (the loads are volatile asm for that: nothing may reorder them).
+constexpr u32 kFrontEmpty = 0u, kFrontBusy = 1u, kFrontReady = 2u;
+template <int NW> struct FrontShape { static constexpr int CH = NW <= 5 ? 2 : 3; static constexpr int kEntryBytes = CH * 16 + 4; };
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+template <int NW> struct FrontWords {
+	u32x4_t b, a, c;                                                   // (c: only for NW > 5)
+	__device__ __forceinline__ u32 word(int q) const { return q < 4 ? a[q & 3] : (NW <= 5 ? b[q & 3] : c[q & 3]); }
+	__device__ __forceinline__ u32 first() const { return b[2]; }
+	__device__ __forceinline__ u32 state() const { return b[3]; }
+};
+// where the table's arrays begin (LDS byte addresses) and how many entries they have
+struct FrontTable {
+	u32 b, a, c, cnt, entries;
+};
 
 // (need_last, wave-uniform: some row's L bytes reach into dword NW of its span — not so for L = 17, whose 17 bytes lie in five
 // dwords wherever they begin, and every LDS read of this 17-byte-pitch walk is a conflicted one)
@@ -315,7 +335,7 @@ template <int NW> __device__ __forceinline__ void census_row_raw(const uint8_t *
 #pragma unroll
 	for (int q = 0; q < NW; q++) xs[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh) & kms[q];
 }
-template <int NW> __device__ __forceinline__ u32 alias_hash(const u32 (&xs)[NW])
+template <int NW> __device__ __forceinline__ u32 front_hash(const u32 (&xs)[NW])
 {
 	u32 h = xs[0];
 #pragma unroll
@@ -323,35 +343,75 @@ template <int NW> __device__ __forceinline__ u32 alias_hash(const u32 (&xs)[NW])
 	h *= 0x9E3779B1u;
 	return h ^ (h >> 15);
 }
-// an entry's words, and the front table's slot they name for these bytes (or -1)
-template <int NW> __device__ __forceinline__ void alias_load(const u32 *e, u32 (&w)[AliasShape<NW>::EW])
+// the string's two places (entry indices)
+__device__ __forceinline__ u32 front_place(u32 h, int which, u32 entries)
 {
-	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-	for (int i = 0; i < AliasShape<NW>::EW / 2; i++) { const u32x2_t v = *reinterpret_cast<const u32x2_t *>(e + 2 * i); w[2 * i] = v[0]; w[2 * i + 1] = v[1]; }
+	const u32 g = which == 0 ? h : h * 0x85EBCA77u + 0x165667B1u;
+	return __umulhi(g, entries);
 }
-template <int NW> __device__ __forceinline__ int alias_match(const u32 (&w)[AliasShape<NW>::EW], const u32 (&xs)[NW])
+// issue the loads of entry e (the chunk with the state first); front_wait() before the words are used
+template <int NW> __device__ __forceinline__ void front_issue(const FrontTable &ft, u32 e, FrontWords<NW> &w)
+{
+	asm volatile("ds_read_b128 %0, %1" : "=&v"(w.b) : "v"(ft.b + e * 16u) : "memory");
+	asm volatile("ds_read_b128 %0, %1" : "=&v"(w.a) : "v"(ft.a + e * 16u) : "memory");
+	if (NW > 5) asm volatile("ds_read_b128 %0, %1" : "=&v"(w.c) : "v"(ft.c + e * 16u) : "memory");
+}
+template <int NW> __device__ __forceinline__ void front_wait(FrontWords<NW> &w)
+{
+	__builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): the compiler does not know of the loads above
+	asm volatile("" : "+v"(w.b));
+	asm volatile("" : "+v"(w.a));
+	if (NW > 5) asm volatile("" : "+v"(w.c));
+}
+// a claimed entry's string, then its row and READY
+template <int NW> __device__ __forceinline__ void front_publish(const FrontTable &ft, u32 e, const u32 (&xs)[NW], u32 row)
+{
+	u32 x[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++) x[q] = q < NW ? xs[q < NW ? q : 0] : 0u;
+	const u32x4_t wa = {x[0], x[1], x[2], x[3]};
+	const u32x4_t wc = {x[4], x[5], x[6], x[7]};
+	const u32x4_t wb = {NW <= 5 ? x[4] : 0u, 0u, row, kFrontReady};
+	asm volatile("ds_write_b128 %0, %1" :: "v"(ft.a + e * 16u), "v"(wa) : "memory");
+	if (NW > 5) asm volatile("ds_write_b128 %0, %1" :: "v"(ft.c + e * 16u), "v"(wc) : "memory");
+	asm volatile("ds_write_b128 %0, %1" :: "v"(ft.b + e * 16u), "v"(wb) : "memory");
+}
+template <int NW> __device__ __forceinline__ bool front_match(const FrontWords<NW> &w, const u32 (&xs)[NW])
 {
 	u32 df = 0u;
 #pragma unroll
-	for (int q = 0; q < NW; q++) df |= w[q] ^ xs[q];
-	const u32 slot1 = w[AliasShape<NW>::EW - 1];                    // slot + 1; 0 = empty, kAliasBusy = being written
-	return (df == 0u && slot1 - 1u < (u32)kLdsSlots) ? (int)(slot1 - 1u) : -1;
+	for (int q = 0; q < NW; q++) df |= w.word(q) ^ xs[q];
+	return df == 0u && w.state() == kFrontReady;
 }
-template <int NW> __device__ __forceinline__ void alias_install(u32 *alias, u32 amask, u32 h, const u32 (&xs)[NW], int slot)
+// Four characters of a dword of a (canonical) string -> their codes in the key's layout; `bad` collects the bytes outside the alphabet
+template <int NW> __device__ __forceinline__ void census_key_of(const u32 (&xs)[NW], u64 &klo, u64 &khi, u32 &bad)
 {
-	constexpr int EW = AliasShape<NW>::EW;
-	u32 *e = alias + (h & amask) * EW;
-	u32 old = atomicCAS(&e[EW - 1], 0u, kAliasBusy);
-	if (old != 0u) {
-		e = alias + ((h >> 16) & amask) * EW;
-		old = atomicCAS(&e[EW - 1], 0u, kAliasBusy);
-	}
-	if (old == 0u) {
+	u32 c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	bad = 0u;
 #pragma unroll
-		for (int q = 0; q < NW; q++) e[q] = xs[q];
-		__hip_atomic_store(&e[EW - 1], (u32)slot + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	for (int q = 0; q < NW; q++) {
+		u32 d;
+		c[q] = census_classify(xs[q], d);
+		bad |= d;
 	}
+	const u32 kw0 = c[0] | (c[1] << 4), kw1 = c[2] | (c[3] << 4), kw2 = c[4] | (c[5] << 4), kw3 = c[6] | (c[7] << 4) | 0xF0000000u;
+	klo = (u64)kw3 | ((u64)kw0 << 32);
+	khi = (u64)kw1 | ((u64)kw2 << 32);
+}
+// zero the bytes from the string's first NUL on (kms: the bytes before L); returns false when there was none
+template <int NW> __device__ __forceinline__ bool census_canonical(u32 (&xs)[NW], const u32 (&kms)[NW])
+{
+	u32 alive = 0xFFFFFFFFu;
+	bool any = false;
+#pragma unroll
+	for (int q = 0; q < NW; q++) {
+		const u32 x = xs[q];
+		const u32 zf = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & 0x80808080u & kms[q];      // bit 7 of the bytes that are NUL
+		const u32 m = (zf != 0u ? (1u << (__builtin_ctz(zf) & 31)) - 1u : 0xFFFFFFFFu) & alive;
+		xs[q] = x & m;
+		if (zf != 0u) { alive = 0u; any = true; }
+	}
+	return any;
 }
 
 extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
@@ -435,31 +495,39 @@ __device__ __forceinline__ void census_load_tile(const CensusStreams &cs, bool h
 
 // One row per lane, R 64-row tiles per wave and step.  A wave keeps the next step's bytes in registers while it
 // works on the current one (its private LDS tile), so the only workgroup barriers are the two around the loop.
-// Keys are counted in the workgroup's LDS table; a key that finds no room there within kLdsProbes slots goes
-// straight to HBM.  The LDS table is merged into HBM when the workgroup is done.
+// Rows are counted in the workgroup's front table (above); a string that finds neither of its two places free goes
+// straight to HBM as a packed key.  The table is merged into HBM when the workgroup is done.
 // SPILL: such keys are not inserted but appended to the workgroup's region of the spill arrays (unconditional, clipped
-// stores: nothing waits for them), counted per bucket; census_scatter_kernel / census_combine_kernel take them from there.
-template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot, const int alias_entries)
+// stores: nothing waits for them), counted per bucket, and so is the table at the end; census_scatter_kernel /
+// census_combine_kernel take them from there.
+template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves * 64, 1) void census_kernel(const CensusArgs a, const int tile_slot, const int front_entries)
 {
-	LdsTable *lt = reinterpret_cast<LdsTable *>(census_smem);
+	constexpr int CH = FrontShape<NW>::CH;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int nwave = blockDim.x >> 6;
-	uint8_t *tile = census_smem + sizeof(LdsTable) + (size_t)wave * tile_slot;
-	u32 *lh = reinterpret_cast<u32 *>(census_smem + sizeof(LdsTable) + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
-	// the wave's queue of rows that take the long way (a byte each: a step has at most 256 rows), then the alias table
-	constexpr int EW = AliasShape<NW>::EW;
+	const u32 front_bytes = ((u32)front_entries * (u32)FrontShape<NW>::kEntryBytes + 15u) & ~15u;
+	u32 *front = reinterpret_cast<u32 *>(census_smem);
+	FrontTable ft;                                                     // LDS addresses, for the asm loads and stores
+	ft.entries = (u32)front_entries;
+	ft.b = (u32)(uintptr_t)census_smem;
+	ft.a = ft.b + ft.entries * 16u;
+	ft.c = ft.a + (CH > 2 ? ft.entries * 16u : 0u);
+	ft.cnt = ft.b + ft.entries * (CH * 16u);
+	u32 *const fb = front;                                             // the same arrays as pointers: chunk B ...
+	u32 *const fa = front + front_entries * 4;                        // ... A ...
+	u32 *const fc = fa + (CH > 2 ? front_entries * 4 : 0);            // ... C ...
+	u32 *const fcnt = front + front_entries * (CH * 4);               // ... and the counts
+	uint8_t *tile = census_smem + front_bytes + (size_t)wave * tile_slot;
+	u32 *lh = reinterpret_cast<u32 *>(census_smem + front_bytes + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
+	// the wave's queue of rows that take the long way (a byte each: a step has at most 256 rows)
 	uint8_t *queue = reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + wave * (kCensusMaxSub * 64);
-	u32 *alias = reinterpret_cast<u32 *>(reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + nwave * (kCensusMaxSub * 64));
-	const bool use_alias = EW > 0 && alias_entries > 0;
-	const u32 amask = (u32)alias_entries - 1u;
-	if (EW > 0) for (int i = tid; i < alias_entries * EW; i += blockDim.x) alias[i] = 0u;
-	for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+	for (int i = tid; i < (int)(front_bytes / 16u); i += blockDim.x) reinterpret_cast<uint4 *>(front)[i] = make_uint4(0u, 0u, 0u, 0u);
 	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
 	// The workgroup's steps are dealt to its waves as they come free (an LDS counter): the waves of a SIMD do not advance at
 	// the same rate, and with a fixed deal the workgroup waited 9-16 % of its lifetime at the barrier behind the loop for its
-	// slowest wave (profiles/r04_census_stamps.txt).  Step c of workgroup b is tile-step ((c / nwave) * grid + b) * nwave +
+	// slowest wave (profiles/r04_census_stamps_before.txt).  Step c of workgroup b is tile-step ((c / nwave) * grid + b) * nwave +
 	// c % nwave — the same set of steps as the fixed deal, so what the chip reads at any moment is still one advancing window.
 	u32 *step_ctr = lh + kSpillBuckets + 1;
 	if (tid == 0) *step_ctr = (u32)nwave;                              // the first nwave steps are the waves' own
@@ -493,6 +561,11 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	CensusTileRegs rg;
 	uint4 *qkey = reinterpret_cast<uint4 *>(tile);                 // the flush queue reuses the wave's tile
 	u32 *qrel = reinterpret_cast<u32 *>(tile + kCensusQueue * 16);
+	// one more row for the entry at LDS address ea, whose first row was `first` when it was read
+	auto front_count = [&](u32 e, u32 first, u32 r) {
+		__hip_atomic_fetch_add(&fcnt[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (r < first) __hip_atomic_fetch_min(&fb[e * 4u + 2u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (rows come in roughly ascending order: rare)
+	};
 	int t = (int)blockIdx.x * nwave + wave;
 	census_load_tile(streams, a.assign != nullptr, t, step_bytes, offk, R, lane, rg);
 	while (t < nsteps) {
@@ -520,51 +593,69 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 #endif
 		census_load_tile(streams, a.assign != nullptr, tn, step_bytes, offk, R, lane, rg);       // in flight while this step is counted
 		SK_STAMP(2);                                                   // fence, next step's loads issued
-		// Counting touches LDS only.  Keys the LDS table had no room for are parked in registers (one per lane and tile)
-		// and go to HBM after the step's last tile: any memory operation in between would make the compiler wait for
-		// the loads just issued (vmcnt is one in-order counter), and a loop header does the same, hence the unrolling.
+		// Counting touches LDS only.  Keys the table had no room for are parked in registers (one per lane and pass) and go to
+		// HBM after the step's last pass: any global memory operation in between would make the compiler wait for the loads
+		// just issued (vmcnt is one in-order counter).
 		u64 pklo[R], pkhi[R];
 		u32 ph[R], prid[R];
 		u32 parked = 0u;
-		// ---- rows whose bytes the alias table knows are counted where it says; the others queue up for the long way -----
-		u32 qn = (u32)(R * 64);                                        // without the table every row of the step takes it
-		if constexpr (EW > 0) if (use_alias) {
-			qn = 0u;
+		// ---- rows whose bytes the table knows are counted there; the others queue up for the long way ------------------------
+		u32 qn = 0u;
+		{
 			// all of the step's row reads first, then all of its table reads, then the counting: three LDS round trips per
 			// step instead of three per 64 rows
-			u32 xs[R][NW], hs[R], ew[R][EW];
+			u32 xs[R][NW], hs[R], en[R], first[R];
+			bool hit[R];
+			{
+				FrontWords<NW> fw[R];
 #pragma unroll
-			for (int j = 0; j < R; j++) {
-				census_row_raw<NW>(tile, (j * 64 + lane) * stride, kms, xs[j], need_last);
-				hs[j] = alias_hash<NW>(xs[j]);
+				for (int j = 0; j < R; j++) {
+					census_row_raw<NW>(tile, (j * 64 + lane) * stride, kms, xs[j], need_last);
+					hs[j] = front_hash<NW>(xs[j]);
+					en[j] = front_place(hs[j], 0, ft.entries);
+				}
+#pragma unroll
+				for (int j = 0; j < R; j++) front_issue<NW>(ft, en[j], fw[j]);
+#pragma unroll
+				for (int j = 0; j < R; j++) front_wait<NW>(fw[j]);
+#pragma unroll
+				for (int j = 0; j < R; j++) {
+					hit[j] = front_match<NW>(fw[j], xs[j]);
+					first[j] = fw[j].first();
+				}
 			}
+			{	// the strings' other places, for the lanes that need them (one more round trip for the whole step)
+				FrontWords<NW> f2[R];
+				u32 e2[R];
 #pragma unroll
-			for (int j = 0; j < R; j++) alias_load<NW>(alias + (hs[j] & amask) * EW, ew[j]);
+				for (int j = 0; j < R; j++) {
+					e2[j] = front_place(hs[j], 1, ft.entries);
+					front_issue<NW>(ft, hit[j] ? 0u : e2[j], f2[j]);              // (no branch around asm loads; lanes that need nothing read ONE address: a broadcast)
+				}
+#pragma unroll
+				for (int j = 0; j < R; j++) front_wait<NW>(f2[j]);
+#pragma unroll
+				for (int j = 0; j < R; j++)
+					if (!hit[j] && front_match<NW>(f2[j], xs[j])) { hit[j] = true; en[j] = e2[j]; first[j] = f2[j].first(); }
+			}
 #pragma unroll
 			for (int j = 0; j < R; j++) {
 				const int r = (t * R + j) * 64 + lane;
 				const bool want = r < n32 && ((take >> j) & 1u);
-				int slot = alias_match<NW>(ew[j], xs[j]);
-				if (want && slot < 0) {                                        // the string's other place
-					u32 w2[EW];
-					alias_load<NW>(alias + ((hs[j] >> 16) & amask) * EW, w2);
-					slot = alias_match<NW>(w2, xs[j]);
-				}
-				if (want && slot >= 0) {
-					const u64 first_inv = ~(u64)(a.row_base + r);
-					atomicAdd(&lt->count[slot], 1u);
-					if (__hip_atomic_load(&lt->first_inv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first_inv) atomicMax(&lt->first_inv[slot], first_inv);
+				if (want && hit[j]) {
+					front_count(en[j], first[j], (u32)r);
 					counted++;
 				}
-				const bool miss = want && slot < 0;
+				const bool miss = want && !hit[j];
 				const u64 bal = __ballot(miss);
 				if (miss) queue[qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (uint8_t)(j * 64 + lane);
 				qn += (u32)__popcll(bal);
 			}
 			census_wave_fence();
 		}
-		SK_STAMP(3);                                                   // rows the alias table knows
-		// ---- the long way, 64 queued rows at a time ------------------------------------------------------------------------
+		SK_STAMP(3);                                                   // rows the table knows
+		// ---- the long way, 64 queued rows at a time: check the string, look for it again (another lane may have put it there
+		// meanwhile), else claim one of its places, else build its key and park it -----------------------------------------------
 #pragma unroll
 		for (int j = 0; j < R; j++) {
 			ph[j] = 0u;
@@ -573,29 +664,47 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			if ((u32)(j * 64) < qn) {
 				const u32 qi = (u32)(j * 64 + lane);
 				const bool have = qi < qn;
-				const u32 rid = use_alias ? (have ? (u32)queue[qi] : 0u) : qi;
+				const u32 rid = have ? (u32)queue[qi] : 0u;
 				prid[j] = rid;
+				u32 xs[NW];
+				census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
+				{	// a NUL before L ends the barcode and what follows it is padding: zeroed, only when some row of the pass has one
+					u32 z = 0u;
+#pragma unroll
+					for (int q = 0; q < NW; q++) z |= ~((((xs[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xs[q])) & 0x80808080u & kms[q];
+					if (__any(z != 0u)) (void)census_canonical<NW>(xs, kms);
+				}
 				u32 bad;
-				const u32 nz = census_row_key<NW, false>(tile, (int)rid * stride, kms, pklo[j], pkhi[j], bad);
-				// A NUL before L ends the barcode and what follows it is padding: only then (any row of the wave's tile) the
-				// keys are worked out again, exactly.
-				if (__any((nz & 0x80808080u) != 0x80808080u)) (void)census_row_key<NW, true>(tile, (int)rid * stride, kms, pklo[j], pkhi[j], bad);
-				const int r = t * R * 64 + (int)rid;
-				if (have && (use_alias || (r < n32 && ((take >> j) & 1u)))) {
+				census_key_of<NW>(xs, pklo[j], pkhi[j], bad);
+				const u32 r = (u32)(t * R * 64) + rid;
+				if (have) {
 					if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
 					else {
 						counted++;
-						const u64 first_inv = ~(u64)(a.row_base + r);
-						const u32 h = census_hash(pklo[j], pkhi[j]);
-						const int slot = lds_count_at(lt, h >> 16, pklo[j], pkhi[j], 1u, first_inv);
-						if (slot < 0) { ph[j] = h; parked |= 1u << j; }
-						else if constexpr (EW > 0) if (use_alias && !(slot & kLdsClaimed)) {
-							// (a key's second occurrence earns the entry: one in ten rows of a noisy run is a string never seen
-							// again, and an entry is written once)
-							u32 xs[NW];
-							census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
-							alias_install<NW>(alias, amask, alias_hash<NW>(xs), xs, slot);
+						const u32 h = front_hash<NW>(xs);
+						bool done = false;
+#pragma unroll 1
+						for (int pl = 0; pl < 2 && !done; pl++) {
+							const u32 e = front_place(h, pl, ft.entries);
+#pragma unroll 1
+							for (int spin = 0; spin < 256; spin++) {               // (a BUSY entry is published by its writer a few LDS operations later)
+								FrontWords<NW> f;
+								front_issue<NW>(ft, e, f);
+								front_wait<NW>(f);
+								const u32 st = f.state();
+								if (st == kFrontReady) {
+									if (front_match<NW>(f, xs)) { front_count(e, f.first(), r); done = true; }
+									break;                                             // another string's: on to the other place
+								}
+								if (st == kFrontEmpty && atomicCAS(&fb[e * 4u + 3u], kFrontEmpty, kFrontBusy) == kFrontEmpty) {
+									front_publish<NW>(ft, e, xs, r);
+									__hip_atomic_fetch_add(&fcnt[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+									done = true;
+									break;
+								}
+							}
 						}
+						if (!done) { ph[j] = census_hash(pklo[j], pkhi[j]); parked |= 1u << j; }
 					}
 				}
 			}
@@ -623,7 +732,6 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			for (int j = 0; j < R; j++) {
 				const bool has = ((parked >> j) & 1u) != 0u;
 				const u32 at = has ? base + pos[j] : 0x07ffffffu;          // beyond the region: dropped by the descriptor
-				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), (u32)(t * R * 64) + prid[j]};
 				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
 				if (has) atomicAdd(&lh[(u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift)], 1u);
@@ -663,20 +771,34 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	SK_STAMP(6);                                                       // (loop exit)
 	__syncthreads();
 	SK_STAMP(7);                                                       // waiting for the workgroup's other waves
-	bool all_records = false;
-	if (SPILL) {
-		// The table of a noisy run is full of keys this workgroup saw a few times — and 255 other workgroups hold the same
-		// keys: inserting them from here was half a million CAS / adds at the end of the launch with nothing to hide behind,
-		// and the sheet's own barcodes were added to by every workgroup at the same moment (21-25 % of a wave's lifetime,
-		// profiles/r04_census_stamps.txt).  With the partition path behind it the table leaves as RECORDS instead: a key counted
-		// c times is the non-zero base-32 digits of c (at most four 16-byte stores, one for most keys), each with the key's
-		// first row; the combine pass adds them up with the other workgroups' before anything touches HBM.  Such records stand
-		// for rows that were NOT spilled, so the workgroup's region (one record per row) has room for them.
-		all_records = a.sp.merge_copies != 0u;
-		if (all_records) for (int i = tid; i < kLdsSlots; i += blockDim.x) {
-			const u64 sk = lt->klo[i];
-			const u32 sc = lt->count[i];
-			const bool rec = sk != 0 && sc < (1u << 20);                   // (a count beyond four digits is inserted below: never in a launch of 2^25 rows over 256 workgroups)
+	// ---- the table leaves the workgroup: a key is built per ENTRY ----------------------------------------------------------
+	// Into HBM directly (small launches), every workgroup starting somewhere else so that the strings all of them hold are not
+	// hit by all of them at the same moment.  With the partition path behind it (SPILL) the table leaves as RECORDS instead:
+	// a noisy run's table is full of strings this workgroup saw a few times — and 255 other workgroups hold the same ones:
+	// inserting them from here was half a million CAS / adds at the end of the launch with nothing to hide behind, and the
+	// sheet's own barcodes were added to by every workgroup at once (21-25 % of a wave's lifetime,
+	// profiles/r04_census_stamps_before.txt).  An entry counted c times is the non-zero base-32 digits of c — at most four
+	// 16-byte stores, one for most — each with the entry's first row; the combine pass adds them up with the other workgroups'
+	// before anything touches HBM.  Such records stand for rows that were NOT spilled, so the workgroup's region (one record
+	// per row) has room for them.
+	const bool as_records = SPILL && a.sp.merge_copies != 0u;
+	for (int i0 = tid; i0 < ((front_entries + 63) & ~63); i0 += blockDim.x) {          // (whole waves: the record positions are a wave scan)
+		int i = i0 + (as_records ? 0 : (int)blockIdx.x * 67);
+		if (i >= front_entries) i -= front_entries * (i / front_entries);
+		const bool in = i0 < front_entries;
+		const u32 ei = in ? (u32)i : 0u;
+		u32 xs[NW];
+#pragma unroll
+		for (int q = 0; q < NW; q++) xs[q] = q < 4 ? fa[ei * 4u + (q & 3)] : (CH > 2 ? fc[ei * 4u + (q & 3)] : fb[ei * 4u + (q & 3)]);
+		const u32 sc = fcnt[ei], first = fb[ei * 4u + 2u];
+		const bool live = in && fb[ei * 4u + 3u] == kFrontReady;
+		u64 sk, khi;
+		u32 bad;
+		census_key_of<NW>(xs, sk, khi, bad);
+		const u64 first_inv = ~(u64)(a.row_base + first);
+		bool rec = false;
+		if (SPILL) {
+			rec = live && as_records && sc < (1u << 20);                       // (a count beyond four digits is inserted below: never in a launch of 2^25 rows over 256 workgroups)
 			u32 digit[4], c = 0u;
 #pragma unroll
 			for (int v = 0; v < 4; v++) {
@@ -695,33 +817,22 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				if (lane == 0) base = atomicAdd(&lh[kSpillBuckets], tot);
 				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
 			}
-			const u64 khi = ~lt->khi_inv[i];
-			const u32 row = (u32)(~lt->first_inv[i] - (u64)a.row_base);
 			u32 pos = base + incl - c;
 #pragma unroll
 			for (int v = 0; v < 4; v++) {
-				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-				const u32x4_t kq = {(u32)(sk >> 32), (u32)khi, (u32)(khi >> 32), row | ((u32)v << kRecRowBits) | ((digit[v] - 1u) << 27)};
+				const u32x4_t kq = {(u32)(sk >> 32), (u32)khi, (u32)(khi >> 32), first | ((u32)v << kRecRowBits) | ((digit[v] - 1u) << 27)};
 				const u32 at = digit[v] != 0u ? pos : 0x07ffffffu;             // beyond the region: dropped by the descriptor
 				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
 				pos += digit[v] != 0u ? 1u : 0u;
 			}
-			if (c != 0u) {
-				atomicAdd(&lh[(u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift)], c);
-				lt->klo[i] = 0ull;                                             // (this thread's own slot: gone from the table)
-			}
+			if (c != 0u) atomicAdd(&lh[(u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift)], c);
 		}
+		if (live && !rec && !census_insert(a.tab, a.mask, sk, khi, (u64)sc, first_inv, claimed)) overflow += sc;
+	}
+	if (SPILL) {
 		__syncthreads();
 		for (int i = tid; i < kSpillBuckets; i += blockDim.x) a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + i] = lh[i];
 		if (tid == 0) a.sp.wg_count[blockIdx.x] = lh[kSpillBuckets];
-	}
-	// merge (what is left of) the workgroup's table into HBM; every workgroup starts somewhere else, so that the keys all of
-	// them hold (the frequent ones) are not hit by all of them at the same moment
-	for (int i0 = tid; i0 < kLdsSlots; i0 += blockDim.x) {
-		const int i = (i0 + (int)blockIdx.x * 67) & (kLdsSlots - 1);
-		const u64 sk = lt->klo[i];
-		const u32 sc = lt->count[i];
-		if (sk != 0 && !census_insert(a.tab, a.mask, sk, ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
 	}
 	SK_STAMP(8);                                                       // front table merged into HBM
 	// one atomic per WORKGROUP and statistic: the waves of a launch end together, and 4 096 additions to one address are
@@ -732,8 +843,8 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		rejected += __shfl_xor(rejected, o);
 		overflow += __shfl_xor(overflow, o);
 	}
-	__syncthreads();                                                   // the LDS table is dead: its first words take the sums
-	u32 *wg_stats = reinterpret_cast<u32 *>(lt);
+	__syncthreads();                                                   // the front table is dead: its first words take the sums
+	u32 *wg_stats = front;
 	if (tid < kCensusStats) wg_stats[tid] = 0u;
 	__syncthreads();
 	if (lane == 0) {
@@ -1197,19 +1308,15 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
 	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
-	size_t lds = sizeof(LdsTable) + (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32)      // + slack: a row is read as 9 dwords; the spill counters
+	size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32)      // + slack: a row is read as 9 dwords; the spill counters
 	             + (size_t)kCensusWaves * kCensusMaxSub * 64;          // the waves' queues of rows that take the long way
-	// the alias table takes what is left of the CU's LDS (SK_CENSUS_ALIAS=0: none — tests run both forms)
+	// the front table takes what is left of the CU's 160 KiB (SK_CENSUS_FRONT_ENTRIES: tests shrink it so that small inputs
+	// walk "no room in either place")
 	const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
-	const int alias_ew = nw_class == 0 ? 4 : (nw_class == 1 ? 6 : 0);
-	int alias_entries = 0;
-	if (alias_ew > 0) {
-		alias_entries = kAliasMaxEntries;
-		while (alias_entries >= 256 && lds + (size_t)alias_entries * alias_ew * 4 > 160 * 1024) alias_entries >>= 1;
-		if (alias_entries < 256) alias_entries = 0;
-		if (const char *ev = getenv("SK_CENSUS_ALIAS")) { if (atoi(ev) == 0) alias_entries = 0; }
-	}
-	lds += (size_t)alias_entries * alias_ew * 4;
+	const int front_entry_bytes = nw_class == 2 ? 52 : 36;            // FrontShape<NW>::kEntryBytes
+	int front_entries = (int)((160 * 1024 - 16 - lds) / front_entry_bytes) & ~63;
+	if (const char *ev = getenv("SK_CENSUS_FRONT_ENTRIES")) { const int v = atoi(ev) & ~63; if (v >= 64 && v <= front_entries) front_entries = v; }
+	lds += ((size_t)front_entries * front_entry_bytes + 15) & ~(size_t)15;
 	int wgs_per_cu = 1;
 	if (const char *ev = getenv("SK_CENSUS_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= 4) wgs_per_cu = v; }      // experiments
 	int direct_pct = 50;                                    // SK_CENSUS_SPILL_MAX_PCT: more spilled rows than this share of a launch are inserted directly
@@ -1281,7 +1388,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 			}
 		}
 		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
-		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, alias_entries);
+		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, front_entries);
 		if (spill) {
 			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid, a.sp.wg_stats, a.stats);
 			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
