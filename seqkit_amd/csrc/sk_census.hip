@@ -975,17 +975,24 @@ __global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u6
 	}
 	const u32 cnt = sp.wg_count[g];
 	const uint4 *key = sp.key + (size_t)g * sp.cap;
+	// (the next chunk's records are asked for while this one is sorted: a chunk is eight barriers, and with its loads at the
+	// top every chunk began with a memory latency)
+	uint4 rec[kScatterPer], nrec[kScatterPer];
+#pragma unroll
+	for (int q = 0; q < kScatterPer; q++) {
+		const u32 i = (u32)q * 1024u + (u32)b;
+		rec[q] = i < cnt ? key[i] : make_uint4(0u, 0u, 0u, 0u);
+	}
 	for (u32 c0 = 0; c0 < cnt; c0 += kScatterChunk) {
 		const u32 nc = min((u32)kScatterChunk, cnt - c0);
 		__syncthreads();
 		lcnt[b] = 0u;
 		__syncthreads();
-		uint4 rec[kScatterPer];
 		u32 bk[kScatterPer], rank[kScatterPer];
 #pragma unroll
 		for (int q = 0; q < kScatterPer; q++) {
-			const u32 i = (u32)q * 1024u + (u32)b;
-			if (i < nc) rec[q] = key[c0 + i];
+			const u32 i = c0 + (u32)kScatterChunk + (u32)q * 1024u + (u32)b;
+			nrec[q] = i < cnt ? key[i] : make_uint4(0u, 0u, 0u, 0u);
 		}
 #pragma unroll
 		for (int q = 0; q < kScatterPer; q++) {
@@ -1019,6 +1026,8 @@ __global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u6
 		}
 		__syncthreads();
 		gofs[b] += mine;
+#pragma unroll
+		for (int q = 0; q < kScatterPer; q++) rec[q] = nrec[q];
 	}
 }
 
@@ -1080,15 +1089,28 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 		for (int o = kSpillBuckets / 2; o > 0; o >>= 1) if (cpre[b + o] <= item) b += o;
 		const u32 lo = a.sp.bstart[b] + (item - cpre[b]) * kCombineChunk;
 		const u32 hi = min(a.sp.bstart[b + 1], lo + kCombineChunk);
-		for (u32 i = lo + tid; i < hi; i += blockDim.x) {
-			const uint4 k = a.sp.skey[i];
-			const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-			const u64 first_inv = ~(u64)(a.row_base + census_rec_row(k.w));
-			const u32 cnt = census_rec_count(k.w);
-			const u32 h = census_hash(klo, khi);
-			if (!lds_count(lt, h, klo, khi, cnt, first_inv)) {     // the hash's LOW bits: its high bits are the bucket's, the same for every key here
-				const u64 idx = (u64)h & a.mask;
-				if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, (u64)cnt, first_inv, claimed)) overflow += cnt;
+		// (four records of a thread are asked for before the first is counted: with one load per trip the loop was a chain of
+		// memory latencies — 32 of them for a full item)
+		constexpr int kAhead = 4;
+		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
+			uint4 kk[kAhead];
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) {
+				const u32 i = i0 + (u32)q * blockDim.x;
+				kk[q] = i < hi ? a.sp.skey[i] : make_uint4(0u, 0u, 0u, 0u);
+			}
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) {
+				if (i0 + (u32)q * blockDim.x >= hi) break;
+				const uint4 k = kk[q];
+				const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
+				const u64 first_inv = ~(u64)(a.row_base + census_rec_row(k.w));
+				const u32 cnt = census_rec_count(k.w);
+				const u32 h = census_hash(klo, khi);
+				if (!lds_count(lt, h, klo, khi, cnt, first_inv)) {     // the hash's LOW bits: its high bits are the bucket's, the same for every key here
+					const u64 idx = (u64)h & a.mask;
+					if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, (u64)cnt, first_inv, claimed)) overflow += cnt;
+				}
 			}
 		}
 		__syncthreads();
@@ -1110,14 +1132,18 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 
 // When most rows of a launch were spilled there is little to combine (the keys hardly repeat): workgroup g inserts the
 // records of its region as they lie.
-__global__ __launch_bounds__(1024) void census_direct_kernel(const CensusArgs a)
+// (an insert is a chain of four memory round trips, so what this kernel needs is inserts in flight: `split` workgroups of 512
+// threads share a region, as many resident per CU as the registers allow)
+constexpr int kDirectThreads = 512;
+__global__ __launch_bounds__(kDirectThreads) void census_direct_kernel(const CensusArgs a, const int split)
 {
 	__shared__ u32 red[16];
 	if (census_spill_total(a.sp, red) <= a.sp.direct_above) return;
-	const u32 cnt = a.sp.wg_count[blockIdx.x];
-	const uint4 *key = a.sp.key + (size_t)blockIdx.x * a.sp.cap;
+	const u32 g = blockIdx.x / (u32)split, part = blockIdx.x % (u32)split;
+	const u32 cnt = a.sp.wg_count[g];
+	const uint4 *key = a.sp.key + (size_t)g * a.sp.cap;
 	u32 claimed = 0, overflow = 0;
-	for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+	for (u32 i = part * blockDim.x + threadIdx.x; i < cnt; i += (u32)split * blockDim.x) {
 		const uint4 k = key[i];
 		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
 		const u32 cnt = census_rec_count(k.w);
@@ -1323,6 +1349,8 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	if (const char *ev = getenv("SK_CENSUS_SPILL_MAX_PCT")) { const int v = atoi(ev); if (v >= 0 && v <= 100) direct_pct = v; }
 	int64_t spill_min_rows = kSpillMinRows;                 // SK_CENSUS_SPILL_MIN_ROWS_LOG2: tests lower it
 	if (const char *ev = getenv("SK_CENSUS_SPILL_MIN_ROWS_LOG2")) { const int lg = atoi(ev); if (lg >= 6 && lg <= 30) spill_min_rows = (int64_t)1 << lg; }
+	int direct_split = 8;                                   // SK_CENSUS_DIRECT_SPLIT: workgroups per region of census_direct_kernel (experiments)
+	if (const char *ev = getenv("SK_CENSUS_DIRECT_SPLIT")) { const int v = atoi(ev); if (v >= 1 && v <= 64) direct_split = v; }
 	int merge_copies = 1;                                   // SK_CENSUS_MERGE_RECORDS=0: the front kernel inserts its tables itself, as small launches do (A/B, tests)
 	if (const char *ev = getenv("SK_CENSUS_MERGE_RECORDS")) merge_copies = atoi(ev) != 0;
 	int spill_mode = -1;                                    // SK_CENSUS_SPILL=0/1: never / always (tests, experiments)
@@ -1393,7 +1421,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid, a.sp.wg_stats, a.stats);
 			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
 			census_combine_kernel<<<2 * n_cu, kCombineThreads, 0, st>>>(a);
-			census_direct_kernel<<<grid, 1024, 0, st>>>(a);
+			census_direct_kernel<<<grid * direct_split, kDirectThreads, 0, st>>>(a, direct_split);
 		}
 		e = hipGetLastError();
 		if (e != hipSuccess) return e;

@@ -956,15 +956,19 @@ def random_barcodes(n, L, stride, n_hot, hot_frac, seed, alphabet=b"ACGTN"):
     return m
 
 
-@pytest.fixture(params=["direct", "partition", "spilled_direct", "direct_no_alias", "partition_no_alias"])
+@pytest.fixture(params=["direct", "partition", "spilled_direct", "direct_tiny_front", "partition_tiny_front", "partition_front_inserts"])
 def census_path(request, monkeypatch):
     """The three ways a launch can take (sk_census.hip, census_add): keys the front tables have no room for are inserted by
     the front kernel itself (small launches), or written out and then partitioned + combined per table region, or — when
     most rows were written out — inserted as they lie.  Large launches choose between the last two by themselves; the
     environment forces each here so that the small cases below walk all of them.  In front of all three, rows whose bytes the
-    workgroup's alias table knows are counted without building their key; `_no_alias` runs without that table."""
-    if request.param.endswith("_no_alias"):
-        monkeypatch.setenv("SK_CENSUS_ALIAS", "0")
+    workgroup's front table knows are counted there without building their key; `_tiny_front` shrinks that table to 64
+    entries, so that even small inputs find both places of a string taken; `_front_inserts` makes the front kernel insert its
+    table itself although the partition path is behind it (otherwise the table leaves as weighted records)."""
+    if request.param.endswith("_tiny_front"):
+        monkeypatch.setenv("SK_CENSUS_FRONT_ENTRIES", "64")
+    if request.param.endswith("_front_inserts"):
+        monkeypatch.setenv("SK_CENSUS_MERGE_RECORDS", "0")
     if request.param.startswith("direct"):
         monkeypatch.setenv("SK_CENSUS_SPILL", "0")
     else:
@@ -1148,7 +1152,9 @@ def test_fuzz_census(ctx, oracle, monkeypatch, seed):
     monkeypatch.setenv("SK_CENSUS_SPILL", "0" if path == "direct" else "1")
     monkeypatch.setenv("SK_CENSUS_SPILL_MAX_PCT", "0" if path == "spilled_direct" else "100")
     if seed % 4 == 3:
-        monkeypatch.setenv("SK_CENSUS_ALIAS", "0")           # without the alias table in front of the path
+        monkeypatch.setenv("SK_CENSUS_FRONT_ENTRIES", "64")  # a front table that is full at once: both places of most strings taken
+    if seed % 5 == 4:
+        monkeypatch.setenv("SK_CENSUS_MERGE_RECORDS", "0")   # the front kernel inserts its table itself
     L = int(rng.integers(1, 32))
     stride = int(rng.integers(L, min(64, L + 9) + 1))
     n = int(rng.integers(1, 250_000))

@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32_000_000
 dev = torch.device("cuda", 0)
 ctx = seqkit_amd.Context(0, lib_path=LIB)
 lib = C.CDLL(LIB)
-PHASES = ["init", "wait loads + tile write", "fence + issue next loads", "alias phase", "long way", "parked: spill/insert", "loop exit", "end barrier",
+PHASES = ["init", "wait loads + tile write", "fence + issue next loads", "rows the front table knows", "long way", "parked: spill/insert", "loop exit", "end barrier",
           "merge front table", "stats"]
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 CASES = os.environ.get("SK_STAMPS_CASES", "exact,clean,noisy").split(",")
@@ -28,8 +28,7 @@ for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact
         continue
     b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
     bc = torch.from_numpy(b_np).to(dev).repeat(max(1, n // 1_000_000), 1).contiguous()
-    for alias in os.environ.get("SK_STAMPS_ALIAS", "1,0").split(","):
-        os.environ["SK_CENSUS_ALIAS"] = alias
+    for alias in ("-",):
         for _ in range(2):
             ctx.census_reset(); ctx.sync(); ctx.timer_start()
             ctx.census_add_dev(bc.data_ptr(), 17, 17, bc.shape[0], 0, 0)
@@ -38,7 +37,7 @@ for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact
         buf = np.zeros((waves, 16), dtype=np.uint64)
         rc = lib.sk_debug_census_stamps(buf.ctypes.data_as(C.c_void_p), waves)
         tot = buf[:, :10].sum(axis=1).astype(np.float64)
-        print(f"== {case}, alias {alias}: launch sequence {ms:.3f} ms; wave lifetime mean {tot.mean():.0f} cycles (min {tot.min():.0f} max {tot.max():.0f}) rc {rc}")
+        print(f"== {case}: launch sequence {ms:.3f} ms; wave lifetime mean {tot.mean():.0f} cycles (min {tot.min():.0f} max {tot.max():.0f}) rc {rc}")
         for i, name in enumerate(PHASES):
             c = buf[:, i].astype(np.float64)
             print(f"   {name:28s} {c.mean():10.0f} cycles  {100 * c.mean() / tot.mean():5.1f} %   (min {c.min():.0f} max {c.max():.0f})")
