@@ -389,6 +389,13 @@ def secondary_rates(torch, ctx, dev):
     timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch",
            lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr()), n, 26)
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+    # four plates: 384 dual-index samples (24 x 16 combinations).  The full-key table would be 512 KiB, so the sheet is looked
+    # up half by half from LDS (sk_lut.h, the factored form)
+    table = synth.make_sheet(384, 8, dual=True, seed=384)
+    ctx.set_barcodes(table, 1)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+    bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+    timeit("demultiplex only 10M x 17ch, 384 dual-index (four plates)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
     del bc, assign, low, first, last
     n = 200_000_000
     flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)

@@ -394,14 +394,18 @@ static int ensure_neighbour_table(sk_ctx *c)
 	if (c->nbr_tried || !c->have_table) return SK_OK;
 	c->nbr_tried = true;
 	sk::LutHost h;
-	if (getenv("SK_NO_HASH_DEMUX") || !sk::lut_build(c->sheet.data(), c->S, c->L, c->max_diff, h)) return SK_OK;
+	// (SK_DEMUX_PAIR=0: never the factored form — a table too large for the LDS is then probed through the vector cache; tests)
+	const char *env_pair = getenv("SK_DEMUX_PAIR");
+	const int lds_budget = (env_pair && atoi(env_pair) == 0) ? 0 : (128 << 10);
+	if (getenv("SK_NO_HASH_DEMUX") || !sk::lut_build(c->sheet.data(), c->S, c->L, c->max_diff, h, lds_budget)) return SK_OK;
 	const size_t slot_bytes = h.slots.size() * 4, amb_bytes = h.amb.size() * 2;
 	SK_HIP(c, hipMalloc((void **)&c->d_nbr, slot_bytes + amb_bytes + 16));
 	SK_HIP(c, hipMemcpy(c->d_nbr, h.slots.data(), slot_bytes, hipMemcpyHostToDevice));
 	if (amb_bytes) SK_HIP(c, hipMemcpy(c->d_nbr + slot_bytes, h.amb.data(), amb_bytes, hipMemcpyHostToDevice));
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx streams are non-blocking: make the upload visible to them
 	c->nbr = h.dev;
-	c->nbr.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);
+	if (h.dev.pair.bytes != 0) c->nbr.pair.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);      // the factored form: three tables in one blob
+	else c->nbr.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);
 	c->nbr.amb = reinterpret_cast<const int16_t *>(c->d_nbr + slot_bytes);
 	return SK_OK;
 }
@@ -710,7 +714,12 @@ static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
 static int prepare_demux(sk_ctx *c, const sk_fused_args *a)
 {
 	if (!a->bc) return SK_OK;
-	for (int m = 0; m < a->n_mates; m++) if (a->mate[m].out_seq || a->mate[m].lowest_k) return SK_OK;
+	// (a pass with mates matches in the tile pass itself when the bit-sliced matcher applies — at most 128 samples, the tile's
+	// barcodes in two register chunks: launch_tile_pass's fuse_demux; otherwise its barcode phase is a launch of its own and
+	// takes the table like a demultiplex-alone call)
+	bool any_mate = false;
+	for (int m = 0; m < a->n_mates; m++) any_mate = any_mate || a->mate[m].out_seq || a->mate[m].lowest_k;
+	if (any_mate && c->d_bs && c->G <= 4 && 64 * a->bc_stride <= 2048 && !getenv("SK_NO_FUSED_DEMUX")) return SK_OK;
 	const bool want_detail = a->lowest_diff || a->first_idx || a->last_idx;
 	if (want_detail && c->detail_mode != SK_DETAIL_MATCHED) return SK_OK;
 	return ensure_neighbour_table(c);

@@ -1330,12 +1330,15 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 // Two tiles per wave are always in flight (register slots), so that a CU of sixteen waves has ~34 KiB on the way.  There
 // is no branch around a VMEM instruction in the loop: the waits for the register slots are counted, not drained.
 // ---------------------------------------------------------------------------------------------------
-template <int W1, int W2, bool DIRECT, bool LDSTAB, bool DETAIL>
+//   PAIR   : the factored form of sk_lut.h (a sheet `i7+i5` whose full-key table would not fit the LDS): one lookup per half
+//            (-> half id, distance) and one of the pair of ids (-> first / last sample); three small tables in one LDS blob
+template <int W1, int W2, bool DIRECT, bool LDSTAB, bool DETAIL, bool PAIR = false>
 __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const TileArgs a, const LdsPlan lp)
 {
 	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 	constexpr int W = W1 + W2;
 	static_assert(W >= 1 && W <= 5 && (W2 == 0 || W2 == W1) && !(DIRECT && (W2 > 0 || W1 > 2)), "shape");
+	static_assert(!PAIR || (W2 == W1 && W1 <= 2 && LDSTAB && !DIRECT), "the factored form: two halves of one or two dwords, tables in LDS");
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int nwave = blockDim.x >> 6;
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
 				const int i = i0 + j * (int)blockDim.x;
-				if (i < n16) tv[j] = reinterpret_cast<const u32x4 *>(t.tab)[i];
+				if (i < n16) tv[j] = reinterpret_cast<const u32x4 *>(PAIR ? t.pair.tab : t.tab)[i];
 			}
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
@@ -1450,30 +1453,58 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				const u32 m = nz - (nz >> 7);                              // 0x7f there
 				c[w] = (m & t.other) | (~m & sel);
 			}
-			u32 A, B;
-			lut_pack(c, A, B);
-			A &= t.keepA; B &= t.keepB;
-			const u32 x = lut_mix(A, B, t.seed);
-			const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);     // table 2 takes the next nb bits
-			const u32x2_t e1 = entry(x & mask);
-			const u32x2_t e2 = entry(mask + 1u + (y & mask));
-			const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
-			const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
-			const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
-			const int tot = (int)(w0 >> 31) + (int)sepbad;
-			const bool found = (m1 == 0u || m2 == 0u) && tot <= t.max_diff;
-			const int idx = (int)((w1 >> 24) & 0x7fu);
-			const bool amb = (int)w1 < 0;
+			bool found, amb;
+			int tot, idx, pfirst = 0, plast = 0;
+			if constexpr (PAIR) {
+				// each half on its own: its word -> (half id, distance); then the pair of ids -> (first, last) sample.  All three
+				// tables are two-choice cuckoo tables of 8-byte entries that hold their key whole.
+				const LutPairDev &pr = t.pair;
+				constexpr int k2 = W1 < 4 ? W1 : 0, k3 = W1 + 1 < 5 ? W1 + 1 : 0;      // (PAIR: W1 <= 2)
+				const u32 A1 = (W1 == 1 ? c[0] : lut_pack_half(c[0], c[1])) & pr.keep1;
+				const u32 A2 = (W1 == 1 ? c[k2] : lut_pack_half(c[k2], c[k3])) & pr.keep2;
+				const u32 x1 = lut_mix(A1, 0u, pr.seed1), x2 = lut_mix(A2, 0u, pr.seed2);
+				const u32 m1 = (1u << pr.nb1) - 1u, m2 = (1u << pr.nb2) - 1u;
+				const u32x2_t e11 = entry(x1 & m1), e12 = entry(m1 + 1u + (__builtin_amdgcn_alignbit(x1, x1, (u32)pr.nb1) & m1));
+				const u32x2_t e21 = entry(pr.off2 + (x2 & m2)), e22 = entry(pr.off2 + m2 + 1u + (__builtin_amdgcn_alignbit(x2, x2, (u32)pr.nb2) & m2));
+				const bool f1 = e11[0] == A1 || e12[0] == A1, f2 = e21[0] == A2 || e22[0] == A2;
+				const u32 v1 = e11[0] == A1 ? e11[1] : e12[1], v2 = e21[0] == A2 ? e21[1] : e22[1];
+				tot = (int)(v1 >> 16) + (int)(v2 >> 16) + (int)sepbad;
+				const u32 pk = (v1 & 0x3ffu) | ((v2 & 0x3ffu) << 10);
+				const u32 xp = lut_mix(pk, 0u, pr.seedp), mp = (1u << pr.nbp) - 1u;
+				const u32x2_t ep1 = entry(pr.offp + (xp & mp)), ep2 = entry(pr.offp + mp + 1u + (__builtin_amdgcn_alignbit(xp, xp, (u32)pr.nbp) & mp));
+				const bool fp = ep1[0] == pk || ep2[0] == pk;
+				const u32 pv = ep1[0] == pk ? ep1[1] : ep2[1];
+				pfirst = (int)(pv & 0xffffu); plast = (int)(pv >> 16);
+				found = f1 && f2 && fp && tot <= t.max_diff;
+				amb = pfirst != plast;
+				idx = pfirst;
+			} else {
+				u32 A, B;
+				lut_pack(c, A, B);
+				A &= t.keepA; B &= t.keepB;
+				const u32 x = lut_mix(A, B, t.seed);
+				const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);     // table 2 takes the next nb bits
+				const u32x2_t e1 = entry(x & mask);
+				const u32x2_t e2 = entry(mask + 1u + (y & mask));
+				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
+				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
+				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
+				tot = (int)(w0 >> 31) + (int)sepbad;
+				found = (m1 == 0u || m2 == 0u) && tot <= t.max_diff;
+				idx = (int)((w1 >> t.idx_shift) & t.idx_mask);
+				amb = (int)w1 < 0;
+			}
 			const int code = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
 			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, ro * 4, rows * 4), lane * 4, 0, 0);
 			if (DETAIL) {
 				int first = idx, last = idx;
-				if (found && amb) { first = t.amb[2 * idx]; last = t.amb[2 * idx + 1]; }
+				if (PAIR) { first = pfirst; last = plast; }
+				else if (found && amb) { first = t.amb[2 * idx]; last = t.amb[2 * idx + 1]; }
 				__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(found ? tot : 255), make_rsrc(a.lowest_diff, ro, rows), lane, 0, 0);
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? first : -1), make_rsrc(a.first_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? last : -1), make_rsrc(a.last_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 			}
-			if (active && code >= 0) atomicAdd(&hist[code], 1u);           // S <= 128: the histogram is always in LDS
+			if (active && code >= 0) atomicAdd(&hist[code], 1u);           // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
 			n_ident += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code >= 0));
 			n_ambig += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code == kAssignAmbiguous));
@@ -1574,7 +1605,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
 				tot[r] = (int)(w0 >> 31);
 				found[r] = (m1 == 0u || m2 == 0u) && tot[r] <= t.max_diff;
-				const int idx = (int)((w1 >> 24) & 0x7fu);
+				const int idx = (int)((w1 >> t.idx_shift) & t.idx_mask);
 				const bool amb = (int)w1 < 0;
 				code[r] = found[r] ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
 				first[r] = last[r] = idx;
@@ -1811,7 +1842,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		// only (TileArgs::detail_matched): one lookup per read
 		const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
 		const bool want_detail = b.lowest_diff || b.first_idx || b.last_idx;
-		const bool by_table = b.table.nbr.tab && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
+		const bool by_table = (b.table.nbr.tab || b.table.nbr.pair.tab) && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
 		hipError_t e;
 		TileArgs bb = b;
 		if (by_table) {
@@ -1820,22 +1851,25 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			// load for 8-byte rows).  Longer keys go through the LDS image even when the rows are aligned: five dword loads at
 			// a 24-byte stride walk the same lines five times.  (SK_DEMUX_DIRECT=0 / SK_DEMUX_LDSTAB=0 force the other forms:
 			// the tests run every kernel on the same inputs)
+			const bool pair = t.pair.tab != nullptr;                  // the factored form (sk_lut.h): always from LDS, through the image
 			const char *env_direct = getenv("SK_DEMUX_DIRECT");
-			const bool direct = (b.bc_stride & 3) == 0 && t.W2 == 0 && t.W1 <= 2 && 4 * t.W1 <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
+			const bool direct = !pair && (b.bc_stride & 3) == 0 && t.W2 == 0 && t.W1 <= 2 && 4 * t.W1 <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
-			const int table_bytes = (t.mask + 1) * 2 * 8;
-			const bool ldstab = table_bytes <= (128 << 10) && (!env_ldstab || atoi(env_ldstab) != 0);
+			const int table_bytes = pair ? t.pair.bytes : (t.mask + 1) * 2 * 8;
+			const bool ldstab = pair || (table_bytes <= (128 << 10) && (!env_ldstab || atoi(env_ldstab) != 0));
 			// rows of exactly 8 key bytes on an 8-byte pitch: two rows per lane when the detail columns are written too (17 B/read:
 			// 10 M reads 249 -> 290 G reads/s; the decision alone is faster with one row per lane at 10 M, 364 against 333, and
 			// the same at 100 M).  SK_DEMUX_ROWS2=0 / 1 force the choice (tools/demux_ab.py, tests).
 			const char *env_rows2 = getenv("SK_DEMUX_ROWS2");
 			const bool rows2 = direct && t.W1 == 2 && b.bc_stride == 8 && (env_rows2 ? atoi(env_rows2) != 0 : want_detail);
-			const void *fn = rows2 ? (ldstab ? (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false>))
+			const void *fn = pair ? (t.W1 == 1 ? (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<1, 1, false, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<1, 1, false, true, false, true>))
+			                                   : (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, true>)))
+			                 : rows2 ? (ldstab ? (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false>))
 			                                 : (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<false, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<false, false>)))
 			                 : ldstab ? (want_detail ? demux_lut_fn<true, true>(t.W1, t.W2, direct) : demux_lut_fn<true, false>(t.W1, t.W2, direct))
 			                          : (want_detail ? demux_lut_fn<false, true>(t.W1, t.W2, direct) : demux_lut_fn<false, false>(t.W1, t.W2, direct));
 			LdsPlan lp{};
-			lp.use_lds_hist = 1;                                      // S <= 128
+			lp.use_lds_hist = 1;                                      // S + 3 <= kMaxLdsHist
 			lp.hist_off = 0;
 			lp.table_bytes = ldstab ? table_bytes : 0;
 			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
@@ -1871,8 +1905,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		}
-		if (by_table && bb.counts_wide) return e;                       // nothing to fold behind the launch
-		if (e == hipSuccess) e = launch_counts_fold(bb, st);
+		if (e == hipSuccess && !(by_table && bb.counts_wide)) e = launch_counts_fold(bb, st);      // (the wide counters are folded when somebody reads them)
 		if (e != hipSuccess) return e;
 	}
 	if (!any_mate) return hipSuccess;

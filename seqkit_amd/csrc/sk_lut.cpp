@@ -23,12 +23,176 @@ void pack_classes(const uint8_t *cls, uint32_t &A, uint32_t &B)
 }
 }  // namespace
 
-bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
+// two-choice cuckoo placement of n keys whose mixed word under seed sd is xof(q, sd): table 1 is indexed by the low nb bits,
+// table 2 by the next nb; at most 42 % full, nb in [nb_min, nb_max].  where[slot] = key or -1.
+template <typename XOf> bool cuckoo_place(size_t n, int nb_min, int nb_max, XOf xof, int &nb_out, uint32_t &seed_out, std::vector<int> &where)
+{
+	int nb = nb_min;
+	while (nb < nb_max && ((size_t)1 << nb) * 84 < n * 100) nb++;
+	for (; nb <= nb_max; nb++) {
+		const size_t nslots = (size_t)1 << nb;
+		const uint32_t mask = (uint32_t)(nslots - 1);
+		for (uint32_t tr = 1; tr <= 32; tr++) {
+			const uint32_t sd = tr * 0x9E3779B9u;
+			where.assign(2 * nslots, -1);
+			bool placed = true;
+			for (size_t q = 0; q < n && placed; q++) {
+				int cur = (int)q, side = 0, kicks = 0;
+				for (;;) {
+					const uint32_t x = xof((size_t)cur, sd);
+					const size_t at = side == 0 ? (x & mask) : nslots + (rotr32(x, nb) & mask);
+					std::swap(cur, where[at]);
+					if (cur < 0) break;
+					side ^= 1;                                                  // the evicted key goes to its slot in the other table
+					if (++kicks > 500) { placed = false; break; }
+				}
+			}
+			if (placed) { nb_out = nb; seed_out = sd; return true; }
+		}
+	}
+	return false;
+}
+
+struct SheetShape {                      // what both forms need to know about a sheet
+	int S, L, max_diff, sep, W1, W2, sh, other;
+	bool counting[kLutMaxLen];
+	uint8_t tab[8];
+	std::vector<uint8_t> alts;
+	std::vector<Key> rows;               // the rows in class space, key positions
+	int key_pos(int k) const { return sep < 0 || k < sep ? k : 4 * W1 + (k - sep - 1); }
+};
+
+static void fill_common(const SheetShape &sh, const uint8_t *sheet, LutDev &d)
+{
+	d = LutDev{};
+	d.W1 = sh.W1; d.W2 = sh.W2;
+	d.sh = sh.sh;
+	d.tab_lo = (uint32_t)sh.tab[0] | ((uint32_t)sh.tab[1] << 8) | ((uint32_t)sh.tab[2] << 16) | ((uint32_t)sh.tab[3] << 24);
+	d.tab_hi = (uint32_t)sh.tab[4] | ((uint32_t)sh.tab[5] << 8) | ((uint32_t)sh.tab[6] << 16) | ((uint32_t)sh.tab[7] << 24);
+	d.other = (uint32_t)sh.other * 0x01010101u;
+	uint8_t keep[kLutMaxLen] = {0};
+	for (int k = 0; k < sh.L; k++) if (sh.counting[k] && k != sh.sep) keep[sh.key_pos(k)] = 7;
+	pack_classes(keep, d.keepA, d.keepB);
+	d.sep_off = sh.sep;
+	d.sep_val = sh.sep < 0 ? 0u : (uint32_t)sheet[sh.sep];
+	d.max_diff = sh.max_diff;
+	d.idx_shift = 24;
+	d.idx_mask = 0x7fu;
+}
+
+// The factored form (sk_lut.h): one table per half of an `i7+i5` sheet, one of the sheet's pairs.  false: some half key lies
+// within distance 1 of two different half-barcodes (the halves are not all >= 3 apart), or a table does not fit.
+static bool build_pair(const SheetShape &sh, const uint8_t *sheet, LutHost &out, int lds_budget)
+{
+	if (sh.sep < 0 || sh.W1 != sh.W2 || sh.W1 > 2) return false;
+	const int hw = 4 * sh.W1;                                                   // key positions per half
+	auto half_word = [&](const uint8_t *cls) {
+		uint32_t c[2] = {0, 0};
+		for (int k = 0; k < hw; k++) c[k >> 2] |= (uint32_t)cls[k] << (8 * (k & 3));
+		return sh.W1 == 1 ? c[0] : lut_pack_half(c[0], c[1]);
+	};
+	struct HalfKey { uint32_t A; int h, d; };
+	std::vector<HalfKey> hk[2];
+	std::vector<int> half_of[2];                                                // sample -> half id
+	int nh[2] = {0, 0};
+	for (int side = 0; side < 2; side++) {
+		std::unordered_map<uint32_t, int> id_of;                                // a half-barcode's word -> its id
+		std::vector<const uint8_t *> first_row;
+		half_of[side].resize((size_t)sh.S);
+		for (int s = 0; s < sh.S; s++) {
+			const uint8_t *cls = sh.rows[(size_t)s].cls + side * hw;
+			auto it = id_of.find(half_word(cls));
+			if (it == id_of.end()) { it = id_of.emplace(half_word(cls), (int)first_row.size()).first; first_row.push_back(cls); }
+			half_of[side][(size_t)s] = it->second;
+		}
+		nh[side] = (int)first_row.size();
+		if (nh[side] > 1024) return false;                                      // a half id has 10 bits
+		std::unordered_map<uint32_t, int> owner;                                // a half KEY's word -> the one half-barcode within distance 1 of it
+		auto add = [&](uint32_t A, int h, int d) {
+			auto ins = owner.emplace(A, h);
+			if (!ins.second) return ins.first->second == h;                         // another half-barcode's key as well: the factoring would not be the loop
+			hk[side].push_back({A, h, d});
+			return true;
+		};
+		for (int h = 0; h < nh[side]; h++) {
+			uint8_t v[8];
+			memcpy(v, first_row[(size_t)h], (size_t)hw);
+			if (!add(half_word(v), h, 0)) return false;
+			if (sh.max_diff < 1) continue;
+			for (int k = 0; k < sh.L; k++) {
+				if (!sh.counting[k] || k == sh.sep) continue;
+				const int kp = sh.key_pos(k) - side * hw;
+				if (kp < 0 || kp >= hw) continue;
+				const uint8_t own = v[kp];
+				for (uint8_t alt : sh.alts) {
+					if (alt == own) continue;
+					v[kp] = alt;
+					if (!add(half_word(v), h, 1)) return false;
+				}
+				v[kp] = own;
+			}
+		}
+	}
+	struct PairKey { uint32_t pk; int first, last; };
+	std::vector<PairKey> pairs;
+	{
+		std::unordered_map<uint32_t, size_t> at;
+		for (int s = 0; s < sh.S; s++) {
+			const uint32_t pk = (uint32_t)half_of[0][(size_t)s] | ((uint32_t)half_of[1][(size_t)s] << 10);
+			auto it = at.find(pk);
+			if (it == at.end()) { at.emplace(pk, pairs.size()); pairs.push_back({pk, s, s}); }
+			else pairs[it->second].last = s;                                        // rows in sheet order: the last one seen is the last argmin
+		}
+	}
+	int nb[3];
+	uint32_t seed[3];
+	std::vector<int> where[3];
+	for (int tb = 0; tb < 3; tb++) {
+		const size_t n = tb < 2 ? hk[tb].size() : pairs.size();
+		auto xof = [&](size_t q, uint32_t sd) { return lut_mix(tb < 2 ? hk[tb][q].A : pairs[q].pk, 0u, sd); };
+		if (!cuckoo_place(n, 4, 14, xof, nb[tb], seed[tb], where[tb])) return false;
+	}
+	const size_t n1 = (size_t)2 << nb[0], n2 = (size_t)2 << nb[1], np = (size_t)2 << nb[2];
+	const size_t bytes = (n1 + n2 + np) * 8;
+	if (bytes > (size_t)lds_budget) return false;
+	out.slots.assign((n1 + n2 + np) * 2, 0u);
+	for (int tb = 0; tb < 3; tb++) {
+		const size_t base = tb == 0 ? 0 : (tb == 1 ? n1 : n1 + n2);
+		for (size_t i = 0; i < where[tb].size(); i++) {
+			uint32_t *e = &out.slots[2 * (base + i)];
+			const int q = where[tb][i];
+			if (q < 0) { e[0] = kLutPairFree; e[1] = 0; }
+			else if (tb < 2) { e[0] = hk[tb][(size_t)q].A; e[1] = (uint32_t)hk[tb][(size_t)q].h | ((uint32_t)hk[tb][(size_t)q].d << 16); }
+			else { e[0] = pairs[(size_t)q].pk; e[1] = (uint32_t)pairs[(size_t)q].first | ((uint32_t)pairs[(size_t)q].last << 16); }
+		}
+	}
+	out.amb.clear();
+	out.n_keys = hk[0].size() + hk[1].size() + pairs.size();
+	fill_common(sh, sheet, out.dev);
+	LutPairDev &p = out.dev.pair;
+	p.nb1 = nb[0]; p.nb2 = nb[1]; p.nbp = nb[2];
+	p.off2 = (uint32_t)n1; p.offp = (uint32_t)(n1 + n2);
+	p.seed1 = seed[0]; p.seed2 = seed[1]; p.seedp = seed[2];
+	{	// the halves' keep masks: the counting columns' class bits in each half's word
+		uint8_t keep[2][8] = {{0}, {0}};
+		for (int k = 0; k < sh.L; k++)
+			if (sh.counting[k] && k != sh.sep) { const int kp = sh.key_pos(k); keep[kp / hw][kp % hw] = 7; }
+		p.keep1 = half_word(keep[0]);
+		p.keep2 = half_word(keep[1]);
+	}
+	p.bytes = (int)bytes;
+	return true;
+}
+
+bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, int lds_budget)
 {
 	if (!sheet || S < 1 || S > kLutMaxSamples || L < 1 || L > kLutMaxLen || max_diff < 0 || max_diff > 1) return false;
+	SheetShape shp;
+	shp.S = S; shp.L = L; shp.max_diff = max_diff;
 	// columns: counting (no row has a wildcard there) or ignored (every row has one); a wildcard in some rows only would
 	// make the key depend on the row
-	bool counting[kLutMaxLen] = {false};
+	bool (&counting)[kLutMaxLen] = shp.counting;
+	for (int k = 0; k < kLutMaxLen; k++) counting[k] = false;
 	for (int k = 0; k < L; k++) {
 		int nw = 0;
 		for (int s = 0; s < S; s++) nw += is_wildcard(sheet[(size_t)s * L + k]) ? 1 : 0;
@@ -53,7 +217,8 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
 		if (ok) sep = k;
 	}
 	const int W1 = sep < 0 ? (L + 3) / 4 : (sep + 3) / 4, W2 = sep < 0 ? 0 : W1;
-	auto key_pos = [&](int k) { return sep < 0 || k < sep ? k : 4 * W1 + (k - sep - 1); };      // column -> position in the key
+	shp.sep = sep; shp.W1 = W1; shp.W2 = W2;
+	auto key_pos = [&](int k) { return shp.key_pos(k); };                       // column -> position in the key
 	// the letters of the key columns and a 3-bit function of a byte that separates them
 	bool is_letter[256] = {false};
 	std::vector<uint8_t> letters;
@@ -76,25 +241,39 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
 		if (ok) sh = t;
 	}
 	if (sh < 0) return false;
+	shp.sh = sh;
 	auto index_of = [&](uint8_t b) { return (b >> sh) & 7; };
-	uint8_t tab[8];
+	uint8_t (&tab)[8] = shp.tab;
 	bool used[8] = {false};
 	for (int i = 0; i < 8; i++) tab[i] = (uint8_t)(((i ^ 1) & 7) << sh);      // a byte with ANOTHER index: nothing with index i equals it
 	for (uint8_t b : letters) { tab[index_of(b)] = b; used[index_of(b)] = true; }
 	int other = 0;
 	while (used[other]) other++;                                              // <= 7 letters: one of the 8 is free
-	std::vector<uint8_t> alts;
+	shp.other = other;
+	std::vector<uint8_t> &alts = shp.alts;
 	for (uint8_t b : letters) alts.push_back((uint8_t)index_of(b));
 	alts.push_back((uint8_t)other);
 
-	// rows in class space; enumerate every row and every row with one key column changed
-	std::vector<Key> rows((size_t)S);
+	// rows in class space
+	std::vector<Key> &rows = shp.rows;
+	rows.resize((size_t)S);
+	int n_key_cols = 0;
+	for (int k = 0; k < L; k++) n_key_cols += (counting[k] && k != sep) ? 1 : 0;
 	for (int s = 0; s < S; s++) {
 		memset(&rows[(size_t)s], 0, sizeof(Key));
 		for (int k = 0; k < L; k++)
 			if (counting[k] && k != sep) rows[(size_t)s].cls[key_pos(k)] = (uint8_t)index_of(sheet[(size_t)s * L + k]);
 		pack_classes(rows[(size_t)s].cls, rows[(size_t)s].A, rows[(size_t)s].B);
 	}
+	// A full-key table that will not fit the workgroup's LDS: a sheet with a separator is looked up half by half when that is
+	// exact and those tables fit
+	{
+		const size_t bound = (size_t)S * (1 + (max_diff ? (size_t)n_key_cols * (alts.size() - 1) : 0));
+		int nbe = kLutMinBits;
+		while (((size_t)1 << nbe) * 84 < bound * 100) nbe++;
+		if (lds_budget > 0 && ((size_t)16 << nbe) > (size_t)lds_budget && build_pair(shp, sheet, out, lds_budget)) return true;
+	}
+	// enumerate every row and every row with one key column changed
 	std::vector<Key> keys;
 	{
 		std::unordered_map<uint64_t, int> seen;
@@ -116,20 +295,29 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
 			}
 		}
 	}
-	// decide: src/fasta_demultiplex.rs:154-166 (first / last argmin over the rows in sheet order)
+	// decide: src/fasta_demultiplex.rs:154-166 (first / last argmin over the rows in sheet order).  (1 000 samples x 20 columns
+	// are 80 k keys x 1 000 rows: equal packed words answer "distance 0" at once, and a row's count stops where it passes the
+	// lowest seen so far — a key is a row or one step from one, so that is after a few columns for all rows but its own.)
 	struct Decision { int diff, first, last; };
 	std::vector<Decision> dec(keys.size());
 	for (size_t q = 0; q < keys.size(); q++) {
 		int lowest = 0x7fffffff, first = 0, last = 0;
 		for (int s = 0; s < S; s++) {
+			if (keys[q].A == rows[(size_t)s].A && keys[q].B == rows[(size_t)s].B) {   // (the common early answer: distance 0)
+				if (0 < lowest) { lowest = 0; first = s; last = s; }
+				else if (lowest == 0) last = s;
+				continue;
+			}
+			if (lowest == 0) continue;                                            // only another exact row could still matter
 			int d = 0;
-			for (int k = 0; k < kLutMaxLen; k++) d += (keys[q].cls[k] != rows[(size_t)s].cls[k]) ? 1 : 0;      // ignored positions are 0 on both sides
+			for (int k = 0; k < kLutMaxLen && d <= lowest; k++) d += (keys[q].cls[k] != rows[(size_t)s].cls[k]) ? 1 : 0;      // ignored positions are 0 on both sides
 			if (d < lowest) { lowest = d; first = s; last = s; }
 			else if (d == lowest) last = s;
 		}
 		if (lowest > max_diff) return false;                                  // cannot happen: every key is a row or one step from one
 		dec[q] = {lowest, first, last};
 	}
+	const int idx_bits = S <= 128 ? 7 : 10;
 	std::vector<int16_t> amb;
 	std::vector<int> idx(keys.size());
 	{
@@ -139,43 +327,21 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
 			const uint32_t pr = ((uint32_t)dec[q].first << 16) | (uint32_t)dec[q].last;
 			auto it = pair_at.find(pr);
 			if (it == pair_at.end()) {
-				if (amb.size() / 2 >= 128) return false;
+				if (amb.size() / 2 >= ((size_t)1 << idx_bits)) return false;
 				it = pair_at.emplace(pr, (int)(amb.size() / 2)).first;
 				amb.push_back((int16_t)dec[q].first); amb.push_back((int16_t)dec[q].last);
 			}
 			idx[q] = it->second;
 		}
 	}
-	// two-choice cuckoo, at most 42 % full
-	int nb = kLutMinBits;
-	while (((size_t)1 << nb) * 84 < keys.size() * 100) nb++;
-	std::vector<int> where;
+	// two-choice cuckoo, at most 42 % full; the tag (32 - nb bits) must leave room for idx and the flag
+	int nb = 0;
 	uint32_t seed = 0;
-	bool placed = false;
-	for (; nb <= 16 && !placed; nb++) {
-		const size_t nslots = (size_t)1 << nb;
-		const uint32_t mask = (uint32_t)(nslots - 1);
-		for (uint32_t tr = 1; tr <= 32 && !placed; tr++) {
-			const uint32_t sd = tr * 0x9E3779B9u;
-			where.assign(2 * nslots, -1);
-			placed = true;
-			for (size_t q = 0; q < keys.size() && placed; q++) {
-				int cur = (int)q, side = 0, kicks = 0;
-				for (;;) {
-					const uint32_t x = lut_mix(keys[(size_t)cur].A, keys[(size_t)cur].B, sd);
-					const size_t at = side == 0 ? (x & mask) : nslots + (rotr32(x, nb) & mask);
-					std::swap(cur, where[at]);
-					if (cur < 0) break;
-					side ^= 1;                                                  // the evicted key goes to its slot in the other table
-					if (++kicks > 500) { placed = false; break; }
-				}
-			}
-			if (placed) seed = sd;
-		}
-		if (placed) break;
-	}
-	if (!placed) return false;
+	std::vector<int> where;
+	auto xof = [&](size_t q, uint32_t sd) { return lut_mix(keys[q].A, keys[q].B, sd); };
+	if (!cuckoo_place(keys.size(), idx_bits + 1, 18, xof, nb, seed, where)) return false;
 	const size_t nslots = (size_t)1 << nb;
+	const int idx_shift = 31 - idx_bits;
 	out.slots.assign(2 * nslots * 2, 0u);
 	for (size_t i = 0; i < 2 * nslots; i++) {
 		uint32_t *e = &out.slots[2 * i];
@@ -185,25 +351,16 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out)
 		const uint32_t tag = (i < nslots ? x : rotr32(x, nb)) >> nb;
 		const bool ambiguous = dec[q].first != dec[q].last;
 		e[0] = keys[q].B | ((uint32_t)dec[q].diff << 31);
-		e[1] = tag | ((uint32_t)idx[q] << 24) | (ambiguous ? 0x80000000u : 0u);
+		e[1] = tag | ((uint32_t)idx[q] << idx_shift) | (ambiguous ? 0x80000000u : 0u);
 	}
 	out.amb = amb;
 	out.n_keys = keys.size();
 	LutDev &d = out.dev;
-	d = LutDev{};
-	d.W1 = W1; d.W2 = W2;
+	fill_common(shp, sheet, d);
 	d.nb = nb; d.mask = (int)(nslots - 1);
 	d.seed = seed; d.tag_mask = (uint32_t)(((uint64_t)1 << (32 - nb)) - 1);
-	d.sh = sh;
-	d.tab_lo = (uint32_t)tab[0] | ((uint32_t)tab[1] << 8) | ((uint32_t)tab[2] << 16) | ((uint32_t)tab[3] << 24);
-	d.tab_hi = (uint32_t)tab[4] | ((uint32_t)tab[5] << 8) | ((uint32_t)tab[6] << 16) | ((uint32_t)tab[7] << 24);
-	d.other = (uint32_t)other * 0x01010101u;
-	uint8_t keep[kLutMaxLen] = {0};
-	for (int k = 0; k < L; k++) if (counting[k] && k != sep) keep[key_pos(k)] = 7;
-	pack_classes(keep, d.keepA, d.keepB);
-	d.sep_off = sep;
-	d.sep_val = sep < 0 ? 0u : (uint32_t)sheet[sep];
-	d.max_diff = max_diff;
+	d.idx_shift = idx_shift;
+	d.idx_mask = (1u << idx_bits) - 1u;
 	return true;
 }
 

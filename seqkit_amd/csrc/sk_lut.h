@@ -19,9 +19,19 @@
 // slot index is nb bits of X, the entry keeps the other 32 - nb bits of X and B — equality of those IS equality of the
 // key (quotienting).  Table 1 is indexed by the low nb bits of X, table 2 by the next nb bits (X rotated right by nb).
 //     w0 = B (31 bits, bit 7 of every byte is never set) | lowest_diff << 31
-//     w1 = tag (32 - nb bits of X) | idx << 24 | ambiguous << 31
-// idx = the sample (first == last), or for an ambiguous key the index of its (first, last) pair in a side list.
+//     w1 = tag (32 - nb bits of X) | idx << idx_shift | ambiguous << 31
+// idx = the sample (first == last), or for an ambiguous key the index of its (first, last) pair in a side list: 7 bits for
+// sheets of at most 128 samples (idx_shift 24, nb >= 8), 10 bits up to kLutMaxSamples (idx_shift 21, nb >= 11).
 // A free slot has w0 = kLutFree (bit 7 set: equals no key).
+//
+// The factored form (LutDev::pair): 384 dual-index samples x (16 x 4 + 1) keys are 25 k entries — 512 KiB, served from L2 at
+// half the rate of a table in LDS.  A sheet `i7+i5` with a separator is then looked up HALF BY HALF: one small table per
+// half (its distinct half-barcodes and their one-substitution neighbours -> half id h, distance d) and one table of the
+// sheet's (h7, h5) pairs -> (first, last) sample.  An observed barcode is within max_diff of a row iff both halves are
+// found, d7 + d5 + (separator differs) <= max_diff and the pair is a row of the sheet.  That is the reference's loop
+// (src/fasta_demultiplex.rs:154-194) exactly when every half key lies within distance 1 of ONE half-barcode only — the
+// host checks it while it enumerates (half-barcodes at distance >= 3 of each other always pass) and builds the full-key
+// table otherwise.  Entries are 8 bytes: half tables {key word, h | d << 16}, pair table {h7 | h5 << 10, first | last << 16}.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -36,9 +46,20 @@
 namespace sk {
 
 constexpr int kLutMaxLen = 20;           // columns the packing holds
-constexpr int kLutMaxSamples = 128;      // idx is 7 bits
-constexpr int kLutMinBits = 8;           // tag + idx + flag must fit 32 bits
+constexpr int kLutMaxSamples = 1021;     // idx is 7 or 10 bits; S + 3 counters fit the kernels' LDS histogram (kMaxLdsHist)
+constexpr int kLutMinBits = 8;           // tag + idx + flag must fit 32 bits: nb >= idx bits + 1
 constexpr uint32_t kLutFree = 0x00000080u;
+constexpr uint32_t kLutPairFree = 0xFFFFFFFFu;
+
+// the factored form: three cuckoo tables of 8-byte entries in one blob (half 1, half 2, pairs), each 2 x 2^nb slots
+struct LutPairDev {
+	const uint32_t *tab;       // or nullptr: the sheet is served by the full-key table (or by none)
+	int nb1, nb2, nbp;         // slot bits
+	uint32_t off2, offp;       // where the second half's table and the pair table begin, in entries
+	uint32_t seed1, seed2, seedp;
+	uint32_t keep1, keep2;     // class bits of the counting columns of each half's packed word
+	int bytes;                 // of the blob
+};
 
 struct LutDev {
 	const uint32_t *tab;       // 2 tables x (mask + 1) slots x 2 dwords, or nullptr: the sheet has no table
@@ -53,6 +74,9 @@ struct LutDev {
 	int sep_off;               // separator: its byte offset in the row (-1 = none; then W2 == 0) ...
 	uint32_t sep_val;          // ... and its letter
 	int max_diff;              // 0 or 1
+	int idx_shift;             // w1's idx field: 24 (7 bits) or 21 (10 bits) ...
+	uint32_t idx_mask;         // ... and its mask
+	LutPairDev pair;           // the factored form (then tab above is nullptr)
 };
 
 // classes of 4 consecutive columns (one per byte, 3 bits each) x 5 dwords -> two words; no two fields overlap
@@ -73,13 +97,18 @@ SK_HD inline uint32_t lut_mix(uint32_t A, uint32_t B, uint32_t seed)
 	return x;
 }
 
+// one half's key word: the classes of its (at most 8) columns, dwords 0 and 1 of the half interleaved as in lut_pack
+SK_HD inline uint32_t lut_pack_half(uint32_t c0, uint32_t c1) { return c0 | (c1 << 3); }
+
 // Host side: what sk_set_barcodes' sheet becomes.  false = this sheet has no table (the matchers serve it).
+// A table of more than lds_budget bytes is served from L2; a sheet with a separator then gets the factored form instead when
+// its half tables exist and fit (lds_budget 0: never factored).
 struct LutHost {
-	LutDev dev{};                        // tab / amb are null here
-	std::vector<uint32_t> slots;         // the two tables
+	LutDev dev{};                        // tab / amb / pair.tab are null here
+	std::vector<uint32_t> slots;         // the two tables (full-key form) or the blob of three (factored form: dev.pair.bytes != 0)
 	std::vector<int16_t> amb;            // pairs
 	size_t n_keys = 0;
 };
-bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out);
+bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, int lds_budget = 128 << 10);
 
 }  // namespace sk

@@ -2,6 +2,7 @@
 // observed barcode up with the arithmetic the kernel uses (classify, pack, mix, two probes, separator), against the
 // reference's loop written out plainly (src/fasta_demultiplex.rs:154-194, :269-277).  No GPU; the lookup below is a test
 // model of demux_lut_kernel, not a product path.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,34 @@ static uint32_t perm_lookup(uint32_t hi, uint32_t lo, uint32_t sel)       // v_p
 
 struct Result { int assign, diff, first, last; };
 
+static inline uint32_t rotr(uint32_t x, int r) { return r ? (x >> r) | (x << (32 - r)) : x; }
+
+// the factored form (demux_lut_kernel<.., PAIR = true>): each half -> (half id, distance), the pair of ids -> (first, last)
+static Result lookup_pair(const LutHost &h, const uint32_t (&c)[5], uint32_t sepbad)
+{
+	const LutDev &t = h.dev;
+	const sk::LutPairDev &pr = t.pair;
+	auto probe = [&](uint32_t base, int nb, uint32_t key, uint32_t seed, uint32_t &val) {
+		const uint32_t x = sk::lut_mix(key, 0u, seed), m = (1u << nb) - 1u;
+		const uint32_t *e1 = &h.slots[2 * (size_t)(base + (x & m))], *e2 = &h.slots[2 * (size_t)(base + m + 1u + (rotr(x, nb) & m))];
+		if (e1[0] == key && e2[0] == key) { fprintf(stderr, "key in both tables\n"); exit(1); }
+		if (e1[0] == key) { val = e1[1]; return true; }
+		if (e2[0] == key) { val = e2[1]; return true; }
+		return false;
+	};
+	const uint32_t A1 = (t.W1 == 1 ? c[0] : sk::lut_pack_half(c[0], c[1])) & pr.keep1;
+	const uint32_t A2 = (t.W1 == 1 ? c[1] : sk::lut_pack_half(c[2], c[3])) & pr.keep2;
+	Result r = {-1, 255, -1, -1};
+	uint32_t v1 = 0, v2 = 0, pv = 0;
+	if (!probe(0u, pr.nb1, A1, pr.seed1, v1) || !probe(pr.off2, pr.nb2, A2, pr.seed2, v2)) return r;
+	const int tot = (int)(v1 >> 16) + (int)(v2 >> 16) + (int)sepbad;
+	if (tot > t.max_diff) return r;
+	if (!probe(pr.offp, pr.nbp, (v1 & 0x3ffu) | ((v2 & 0x3ffu) << 10), pr.seedp, pv)) return r;
+	r.diff = tot; r.first = (int)(pv & 0xffffu); r.last = (int)(pv >> 16);
+	r.assign = r.first == r.last ? r.first : -2;
+	return r;
+}
+
 static Result lookup(const LutHost &h, const uint8_t *obs, int L)
 {
 	const LutDev &t = h.dev;
@@ -45,6 +74,7 @@ static Result lookup(const LutHost &h, const uint8_t *obs, int L)
 		const uint32_t m = nz - (nz >> 7);
 		c[w] = (m & t.other) | (~m & sel);
 	}
+	if (t.pair.bytes != 0) return lookup_pair(h, c, sepbad);
 	uint32_t A, B;
 	sk::lut_pack(c, A, B);
 	A &= t.keepA; B &= t.keepB;
@@ -60,7 +90,7 @@ static Result lookup(const LutHost &h, const uint8_t *obs, int L)
 	const uint32_t *e = h1 ? e1 : e2;
 	const int tot = (int)(e[0] >> 31) + (int)sepbad;
 	if (tot > t.max_diff) return r;
-	const int idx = (int)((e[1] >> 24) & 0x7f);
+	const int idx = (int)((e[1] >> t.idx_shift) & t.idx_mask);
 	r.diff = tot;
 	if (e[1] >> 31) { r.assign = -2; r.first = h.amb[2 * (size_t)idx]; r.last = h.amb[2 * (size_t)idx + 1]; }
 	else { r.assign = idx; r.first = r.last = idx; }
@@ -91,16 +121,47 @@ int main(int argc, char **argv)
 	std::mt19937_64 rng(12345);
 	auto pick = [&](int n) { return (int)(rng() % (uint64_t)n); };
 	const char *alphabets[] = {"ACGT", "ACGTN", "ACGT+", "ACGTacg", "AC", "ACGTN+U", "ACGT-_", "ACGTRYK"};
-	int built = 0, refused = 0;
+	int built = 0, refused = 0, factored = 0, wide = 0;
 	size_t checked = 0;
+	// half-barcodes of `hl` letters, pairwise at least `dist` apart (greedy)
+	auto distant = [&](int count, int hl, int dist) {
+		std::vector<std::string> out;
+		for (int tries = 0; (int)out.size() < count && tries < 200000; tries++) {
+			std::string c((size_t)hl, 'A');
+			for (auto &ch : c) ch = "ACGT"[pick(4)];
+			bool ok = true;
+			for (const auto &o : out) { int d = 0; for (int k = 0; k < hl; k++) d += c[(size_t)k] != o[(size_t)k]; if (d < dist) { ok = false; break; } }
+			if (ok) out.push_back(c);
+		}
+		return out;
+	};
 	for (int it = 0; it < rounds; it++) {
-		const int Ss[] = {1, 2, 3, 16, 40, 96, 128};
+		const int Ss[] = {1, 2, 3, 16, 40, 96, 128, 129, 384, 1000};
 		const int Ls[] = {1, 3, 4, 8, 9, 12, 17, 20};
-		const int S = Ss[pick(7)], L = Ls[pick(8)];
+		int S = Ss[pick(it % 8 == 0 ? 10 : 7)], L = Ls[pick(8)];
 		const std::string al = alphabets[pick(8)];
 		std::vector<uint8_t> sheet((size_t)S * L);
 		for (auto &b : sheet) b = (uint8_t)al[(size_t)pick((int)al.size())];
-		const int kind = pick(5);
+		int kind = pick(5);
+		if (it % 4 == 1) {
+			// a dual-index sheet `i7+i5` out of two sets of half-barcodes: combinations of n7 x n5, some twice, halves >= 3 apart
+			// (the factored form's case when the full-key table is large) or only >= 1 apart (then it must fall back)
+			const int hl = pick(2) ? 8 : 4, dist = pick(4) ? 3 : 1;
+			const int want = hl == 8 ? (pick(2) ? 384 : (pick(2) ? 1000 : 200)) : 40;
+			const int n7 = 2 + pick(hl == 8 ? 60 : 6), n5 = 1 + (want + n7 - 1) / n7;
+			const auto i7 = distant(n7, hl, dist), i5 = distant(n5, hl, dist);
+			S = std::min(want, (int)(i7.size() * i5.size()));
+			L = 2 * hl + 1;
+			sheet.assign((size_t)S * L, 0);
+			for (int s2 = 0; s2 < S; s2++) {
+				const int combo = pick(7) == 0 ? pick((int)(i7.size() * i5.size())) : s2;      // mostly distinct combinations, some repeated
+				memcpy(&sheet[(size_t)s2 * L], i7[(size_t)combo % i7.size()].data(), (size_t)hl);
+				sheet[(size_t)s2 * L + hl] = '+';
+				memcpy(&sheet[(size_t)s2 * L + hl + 1], i5[(size_t)combo / i7.size()].data(), (size_t)hl);
+			}
+			kind = 0;
+			if (pick(4) == 0) for (int s2 = 0; s2 < S; s2++) sheet[(size_t)s2 * L + L - 1] = 'U';      // a UMI column at the end
+		}
 		if (kind == 1 && L >= 4) for (int s = 0; s < S; s++) for (int k = L - 3; k < L; k++) sheet[(size_t)s * L + k] = 'U';
 		if (kind == 2) for (auto &b : sheet) if (pick(10) == 0) b = 'N';
 		if (kind >= 3 && L >= 3) { const int c = pick(L); for (int s = 0; s < S; s++) sheet[(size_t)s * L + c] = '+'; }      // a separator (when '+' is nowhere else)
@@ -109,6 +170,8 @@ int main(int argc, char **argv)
 		LutHost h;
 		if (!sk::lut_build(sheet.data(), S, L, max_diff, h)) { refused++; continue; }
 		built++;
+		factored += h.dev.pair.bytes != 0;
+		wide += h.dev.pair.bytes == 0 && h.dev.idx_shift != 24;
 		const char noise[] = "ACGTNacgtn+U\x00\xff#-_";
 		for (int r = 0; r < 3000; r++) {
 			uint8_t obs[32];
@@ -129,6 +192,6 @@ int main(int argc, char **argv)
 		}
 	}
 	// the two sheets of the benchmark: sizes (informative)
-	printf("ok: %d tables built, %d sheets refused, %zu lookups\n", built, refused, checked);
+	printf("ok: %d tables built (%d factored, %d with 10-bit sample indices), %d sheets refused, %zu lookups\n", built, factored, wide, refused, checked);
 	return 0;
 }

@@ -320,11 +320,14 @@ def check_demux_matched(ctx, oracle, table, bc, max_diff=1):
     return int(m.sum())
 
 
-@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache", "two rows per lane", "one row per lane"])
+@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache", "two rows per lane", "one row per lane",
+                        "never half by half"])
 def lut_form(request, monkeypatch):
     """The forms of the lookup kernel (and the matchers, without a table) on the same inputs."""
     if request.param == "no table":
         monkeypatch.setenv("SK_NO_HASH_DEMUX", "1")
+    elif request.param == "never half by half":
+        monkeypatch.setenv("SK_DEMUX_PAIR", "0")            # a table too large for the LDS is then probed through the vector cache
     elif request.param == "two rows per lane":
         monkeypatch.setenv("SK_DEMUX_ROWS2", "1")
     elif request.param == "one row per lane":
@@ -360,6 +363,55 @@ def test_demux_by_table_cfg3_cfg4(ctx, oracle, lut_form):
         ctx.set_barcodes(table, 1)
         assign, *_ = ctx.demux_assign(padded, want_detail=False)
         assert np.array_equal(assign, oracle.demux_batch(table, bc, 1)[0])
+
+
+@pytest.mark.parametrize("S,dual", [(129, False), (384, True), (1000, True), (1000, False), (1021, False)])
+def test_demux_by_table_many_samples(ctx, oracle, lut_form, S, dual):
+    """Sheets of more than 128 samples take the lookup too (sk_lut.h): sample indices of 10 bits; a dual-index sheet whose
+    full-key table would not fit the LDS is looked up half by half (384 = 24 x 16 combinations: two small tables and the
+    pair table), with duplicates (always ambiguous), a broken separator, foreign bytes and a UMI column behind it."""
+    rng = np.random.default_rng(S)
+    if S >= 1000 and not dual:                                       # (a thousand 8-mers three apart take the greedy generator minutes: random 12- / 10-mers)
+        table = np.unique(synth.BASES[rng.integers(0, 4, size=(2 * S, 12 if S == 1000 else 10))], axis=0)
+        table = np.ascontiguousarray(table[rng.permutation(table.shape[0])[:S]])
+    else:
+        table = synth.make_sheet(S, 8, dual=dual, seed=S)
+    if S >= 384:
+        table[7] = table[3]                                          # duplicate rows: ambiguous whatever the read
+        table[S - 1] = table[S // 2]
+    n = 120_001 if S < 384 else (40_001 if S == 384 else 12_001)   # (the oracle's loop is S x n x L on the host)
+    bc, _ = synth.observe_barcodes(table, n, seed=S + 1, halves=2 if dual else 1)
+    bc[::13, 5] = ord("N")
+    bc[::29, 3] = ord("+")
+    if dual:
+        bc[::19, 8] = ord("A")                                       # a broken separator costs one mismatch for every sample
+    check_demux_decision_only(ctx, oracle, table, bc)
+    check_demux_decision_only(ctx, oracle, table, bc, max_diff=0)
+    assert check_demux_matched(ctx, oracle, table, bc) > n // 3
+    check_demux_matched(ctx, oracle, table, bc, max_diff=0)
+    e = oracle.demux_batch(table, bc, 1)
+    if S >= 384:
+        assert (e[0] == -2).sum() > 20
+    if dual:                                                         # ... and with a UMI column behind the second index
+        t2 = np.concatenate([table, np.full((S, 3), ord("U"), dtype=np.uint8)], axis=1)
+        b2 = np.concatenate([bc, rng.choice(synth.BASES, size=(bc.shape[0], 3))], axis=1)
+        check_demux_matched(ctx, oracle, np.ascontiguousarray(t2), np.ascontiguousarray(b2))
+
+
+def test_fused_pass_of_a_large_sheet_takes_the_table(ctx, oracle):
+    """384 samples are beyond the tile pass's own matcher (128): the barcode phase of a fused call is then a launch of its own
+    and takes the lookup like a demultiplex-alone call — same answers as the oracle's three commands."""
+    n, L = 20_011, 150
+    table = synth.make_sheet(384, 8, dual=True, seed=384)
+    bc, _ = synth.observe_barcodes(table, n, seed=5, halves=2)
+    seq, qual = synth.make_reads(n, L, seed=70)
+    qual = synth.add_forced_classes(qual, seed=80)
+    ctx.set_barcodes(table, 1)
+    r = ctx.fused_pass([(seq, qual, None)], 20, bc=bc, want_detail=False)
+    e = oracle.demux_batch(table, bc, 1)
+    assert np.array_equal(r["assign"], e[0]) and np.array_equal(ctx.counts(), e[4])
+    assert np.array_equal(r["lowest_k"][0], oracle.trim_batch(qual, None, 20))
+    assert np.array_equal(r["out_seq"][0], oracle.mask_batch(seq, qual, None, 20))
 
 
 def test_demux_by_table_ambiguity_duplicates_umi(ctx, oracle, lut_form):
@@ -427,11 +479,21 @@ def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
     if seed % 4 == 3:
         monkeypatch.setenv("SK_DEMUX_ROWS2", "1")           # 8-byte rows two per lane also for the decision alone
     rng = np.random.default_rng(12000 + seed)
-    S = int(rng.choice([1, 2, 3, 16, 40, 96, 128, 150]))
+    S = int(rng.choice([1, 2, 3, 16, 40, 96, 128, 150, 129, 384, 1000]))
     L = int(rng.choice([1, 3, 4, 8, 9, 12, 16, 17, 20, 21, 24, 33]))
     alphabet = [b"ACGT", b"ACGTN", b"ACGT+", b"ACGTacgt", b"ACGTRYKM", b"AC", b"ACGTN+U", b"ACGT-_x"][int(rng.integers(0, 8))]
     table = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=(S, L)).astype(np.uint8)
     kind = int(rng.integers(0, 5))
+    if seed % 6 == 5:                             # a dual-index sheet out of two sets of half-barcodes (the half-by-half form when they are far apart)
+        S = int(rng.choice([150, 384, 1000]))
+        hl = int(rng.choice([4, 8]))
+        n7 = int(rng.integers(8, 40)) if hl == 8 else int(rng.integers(2, 8))
+        i7 = synth._distant_kmers(n7, hl, int(rng.choice([1, 3])), rng)
+        i5 = synth._distant_kmers(min((S + n7 - 1) // n7 + 1, 130 if hl == 8 else 10), hl, 3, rng)      # (at most 16 4-mers are 3 apart)
+        S = min(S, n7 * i5.shape[0])
+        combo = np.where(rng.random(S) < 0.1, rng.integers(0, n7 * i5.shape[0], size=S), np.arange(S))      # mostly distinct combinations, some twice
+        table = np.concatenate([i7[combo % n7], np.full((S, 1), ord("+"), dtype=np.uint8), i5[combo // n7]], axis=1).astype(np.uint8)
+        L, kind = 2 * hl + 1, 0
     if kind == 1 and L >= 4:                     # UMI columns: a wildcard in every row
         table[:, L - 3:] = ord("U")
     elif kind == 2:                               # wildcards here and there (no table then)

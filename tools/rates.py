@@ -90,6 +90,11 @@ ctx.set_barcodes(table, 1)
 bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
 bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
 timeit("demultiplex only 10M x 17ch, 96 dual-index (21 B/pair)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
+table = synth.make_sheet(384, 8, dual=True, seed=384)
+ctx.set_barcodes(table, 1)
+bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
+timeit("demultiplex only 10M x 17ch, 384 dual-index, half by half (21 B/pair)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
 del bc, assign
 
 # cfg 5: BAM flag + TLEN, 200M records
