@@ -107,17 +107,37 @@ def launch_ranks(args) -> int:
 
 
 def run_ranks(cmd, n, port):
-    procs = []
+    """Start the n ranks, relay rank 0's stdout, and keep every rank's stderr readable: each line goes to this process's stderr
+    behind `[rank r]`, and when a rank fails its last lines are repeated under the verdict.  Returns (exit code, rank 0's stdout)."""
+    import select
+    import threading
+    procs, tails, readers = [], [], []
     for r in range(n):
         env = dict(os.environ)
+        # HSA_ENABLE_IPC_MODE_LEGACY: a DEFAULT, not an override — the pool's host driver only has dmabuf IPC, and without
+        # the variable RCCL's (and torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`; the
+        # image exports it already, a caller's own value is kept, and a bare environment (a scheduler's) still gets the working one
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(p)
+        tails.append([])
+
+        def pump(r=r, p=p):
+            for raw in iter(p.stderr.readline, b""):
+                line = raw.decode(errors="replace").rstrip("\n")
+                tails[r].append(line)
+                del tails[r][:-30]
+                sys.stderr.write(f"[rank {r}] {line}\n")
+                sys.stderr.flush()
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        readers.append(th)
     out0 = b""
     failed = None
+    codes = {}
     deadline = time.time() + float(os.environ.get("SK_BENCH_LAUNCH_TIMEOUT", "3000"))
     pending = set(range(n))
-    import select
     while pending:
         if 0 in pending:
             rd, _, _ = select.select([procs[0].stdout], [], [], 0.2)
@@ -133,9 +153,20 @@ def run_ranks(cmd, n, port):
             if r == 0:
                 out0 += procs[0].stdout.read() or b""
             pending.discard(r)
+            codes[r] = rc
             if rc != 0 and failed is None:
                 failed = (r, rc)
         if failed is not None or time.time() > deadline:
+            # Only rank 0 binds the rendezvous port: when another process took it, the OTHER ranks can fail first (a refused
+            # connection, exit code 1) — give rank 0 a moment to say so itself before the run is judged
+            grace = time.time() + 5.0
+            while failed is not None and 0 in pending and time.time() < grace:
+                rc = procs[0].poll()
+                if rc is not None:
+                    pending.discard(0)
+                    codes[0] = rc
+                    break
+                time.sleep(0.1)
             for r in pending:                                   # the exact children started above, nothing else
                 procs[r].kill()
             for r in pending:
@@ -143,10 +174,17 @@ def run_ranks(cmd, n, port):
             if failed is None:
                 failed = (-1, 124)
             break
+    for th in readers:
+        th.join(timeout=2.0)
     if failed is not None:
-        if failed[1] == EXIT_PORT_TAKEN:
+        if EXIT_PORT_TAKEN in codes.values():
             return EXIT_PORT_TAKEN, b""
-        sys.stderr.write(f"[bench] rank {failed[0]} failed with exit code {failed[1]}\n")
+        if failed[0] < 0:
+            sys.stderr.write(f"[bench] no rank finished within SK_BENCH_LAUNCH_TIMEOUT; still running at the end: {sorted(pending)}\n")
+        else:
+            sys.stderr.write(f"[bench] rank {failed[0]} failed with exit code {failed[1]}\n")
+            for line in tails[failed[0]][-12:]:
+                sys.stderr.write(f"[bench]   rank {failed[0]} said: {line}\n")
         return (failed[1] if 0 < failed[1] < 256 else 1), b""
     return 0, out0
 
@@ -635,11 +673,30 @@ def main():
     # library's context, RCCL or any temporary exists; the input candidates get the same bytes; then, BEFORE the warm-up,
     # sk_fused_tune_placement_dev (SoA matrices) / a probe of every input x output pair (blocked) keeps the fastest
     # combination and the rest is freed.  What was probed and chosen goes into the JSON line (config.placement).
-    n = args.pairs
+    # The job is ONE index space of args.pairs x world clusters (BASELINE configs[3]: 500 M over 8 GPUs), cut into contiguous
+    # tile-aligned shards, one per rank (seqkit_amd/shard.py): weak scaling — every rank gets args.pairs clusters
+    # to within a tile.  Nothing crosses shards but the S + 3 counters.
+    from seqkit_amd import shard
+    total_clusters = args.pairs * world
+    shard_lo, shard_hi = shard.shard_bounds(total_clusters, rank, world)
+    n = shard_hi - shard_lo
     nt = (n + 63) // 64
     npad = nt * 64                                           # whole tiles
     lay = None
     K = max(1, min(args.placements, 8))
+    # Pre-flight: the candidates are the bulk of what this rank allocates (K x 56 GB at the full shard).  Ask the device what is
+    # free BEFORE allocating, take as many candidates as fit beside the fixed part, and say so — a rank that cannot hold even one
+    # set ends here with a sentence instead of an allocator trace somewhere in the middle of the run.
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    per_candidate = npad * 930                               # six matrices of 150 B per cluster; a blocked candidate pair is 926 B per cluster
+    fixed = npad * (L_BC + 2 * 2 + 4) + (3 << 30)             # barcodes, lowest_k x 2, assign, and room for the library's tables and the runtime
+    if free_b < per_candidate + fixed:
+        raise SystemExit(f"[bench] rank {rank}: {n} clusters need {(per_candidate + fixed) / 1e9:.1f} GB on device {local_rank}, "
+                         f"{free_b / 1e9:.1f} of {total_b / 1e9:.1f} GB are free — a smaller --pairs, or a device nobody else is using")
+    k_fit = int((free_b - fixed) // per_candidate)
+    if k_fit < K:
+        sys.stderr.write(f"[bench] rank {rank}: {k_fit} candidate allocation(s) per matrix fit the {free_b / 1e9:.1f} GB free on device {local_rank}, not {K}\n")
+        K = max(1, k_fit)
     if args.layout == "blocked":
         lay = capi.blocked_layout(2, L_READ, L_BC, capi.SK_BLK_MASK | capi.SK_BLK_TRIM)
         cands = [(torch.empty(nt * lay.in_block, dtype=torch.uint8, device=dev), torch.empty(nt * lay.out_block, dtype=torch.uint8, device=dev))
@@ -778,7 +835,7 @@ def main():
                 ctx.allreduce_u64_dev(counts.data_ptr(), S_SAMPLES + 3)     # the path's only cross-shard state (nothing to do at N=1)
             else:
                 h = counts.cpu()
-                dist.all_reduce(h)
+                shard.reduce_counts(h)                                      # the same sum over gloo, with a host round trip
                 counts.copy_(h)
             if ev is not None:
                 ev[2].record(stream)
@@ -815,7 +872,7 @@ def main():
     # ---- size-independent checks on the full shard + bit-exact parity on a sample (oracle = checker only) -----
     total_counts = counts.cpu().numpy().astype(np.uint64)
     S = S_SAMPLES
-    assert int(total_counts[S]) == n * world, (int(total_counts[S]), n * world)
+    assert int(total_counts[S]) == total_clusters, (int(total_counts[S]), total_clusters)
     assert int(total_counts[:S].sum()) == int(total_counts[S + 1])
     cpu_baseline = None
     parity = None
@@ -885,7 +942,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n * world / (elapsed / args.steps) / 1e6
+        value = total_clusters / (elapsed / args.steps) / 1e6
         achieved = BYTES_PER_PAIR * n / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes (tools/profile_bench.sh) and
         # recorded in profiles/pmc_traffic.json together with the digest of the kernel sources they were taken on; the record is
@@ -914,7 +971,7 @@ def main():
             "config": {"workload": "fasta add barcode + demultiplex fused with trim+mask by quality: "
                                    f"{n} clusters/GPU x 2x150bp paired, 96 dual-index 8+8 barcodes (17 chars), <=1 mismatch, "
                                    "min_baseq 20 (= BASELINE configs[3], 500M clusters read-sharded over 8 GPUs)",
-                       "clusters_per_gpu": n, "read_len": L_READ, "barcodes": S_SAMPLES, "barcode_len": L_BC,
+                       "clusters_per_gpu": n, "clusters": total_clusters, "shard_of_rank_0": [shard_lo, shard_hi], "read_len": L_READ, "barcodes": S_SAMPLES, "barcode_len": L_BC,
                        "min_baseq": MIN_BASEQ, "read_unit": "cluster (as the reference's total_reads counts)",
                        "layout": args.layout,
                        "placement": dict(placement, what=("candidate input and output buffers allocated at start-up; the pass timed on every (input, output) "

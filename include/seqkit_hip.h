@@ -16,7 +16,10 @@
  *    are ignored on input; on output (masked sequence) they are unspecified.
  *  - functions without suffix take HOST pointers and are synchronous (they stage through device
  *    workspace owned by the ctx).  `_dev` functions take DEVICE pointers, enqueue on the ctx stream
- *    and return immediately; sk_sync() waits.  Device byte matrices must be 16-byte aligned.
+ *    and return immediately; sk_sync() waits.  Device byte matrices must be 16-byte aligned, and readable up
+ *    to the next 4-byte boundary behind their last row (the kernels read whole dwords: when n * stride is not a
+ *    multiple of 4, up to 3 bytes past the matrix are fetched and ignored — any allocation of a whole number of
+ *    dwords, every hipMalloc, provides them).
  *  - there is no CPU fallback: without a usable GPU sk_create() fails and nothing else can be called.
  */
 #ifndef SEQKIT_HIP_H
@@ -58,6 +61,8 @@ void *sk_stream(sk_ctx *ctx);                            /* the ctx's hipStream_
 /* ---- device / pinned memory for hosts that do not link HIP themselves ------------------------ */
 int sk_malloc_device(sk_ctx *ctx, size_t bytes, void **out);
 int sk_free_device(sk_ctx *ctx, void *p);
+/* the two pinned calls may come from any thread while another runs a pass on the ctx: they write nothing to it (a failure is
+ * the return code only; sk_last_error is unchanged) and bind the ctx's device to the calling thread */
 int sk_malloc_pinned(sk_ctx *ctx, size_t bytes, void **out);
 int sk_free_pinned(sk_ctx *ctx, void *p);
 int sk_copy_h2d(sk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* async on ctx stream */

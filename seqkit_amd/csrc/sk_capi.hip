@@ -231,32 +231,25 @@ int sk_free_device(sk_ctx *c, void *p)
 	if (p) SK_HIP(c, hipFree(p));
 	return SK_OK;
 }
-// Pinned memory belongs to the process, not to a ctx (hipHostMallocPortable: page-locked for every device): these two
-// touch no ctx state on the way — no device is bound, nothing is written to the ctx — so the hosts' worker threads may
-// call them on a ctx that another thread is running a pass on.  Only a failure is noted in the ctx, under a lock.
-static std::mutex g_pinned_err_m;
+// Pinned memory belongs to the process, not to a ctx (hipHostMallocPortable: page-locked for every device).  These two write
+// NOTHING to the ctx — not even an error message: the hosts' worker threads call them on a ctx that another thread is running a
+// pass on, and the message buffer of a ctx has one writer at a time — they return the code and sk_last_error is unchanged.
+// They do make the ctx's device the calling thread's current one first (hipSetDevice is thread-local and touches no ctx state):
+// on a thread that has no current device yet, the runtime would otherwise bring up a context on device 0 for the allocation.
 int sk_malloc_pinned(sk_ctx *c, size_t bytes, void **out)
 {
 	if (!c || !out) return SK_ERR_INVALID;
 	*out = nullptr;
-	hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
-	if (e != hipSuccess) {
-		(void)hipGetLastError();
-		std::lock_guard<std::mutex> lk(g_pinned_err_m);
-		return fail(c, SK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
-	}
+	if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
+	if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return SK_ERR_NOMEM; }
 	return SK_OK;
 }
 int sk_free_pinned(sk_ctx *c, void *p)
 {
 	if (!c) return SK_ERR_INVALID;
 	if (!p) return SK_OK;
-	hipError_t e = hipHostFree(p);
-	if (e != hipSuccess) {
-		(void)hipGetLastError();
-		std::lock_guard<std::mutex> lk(g_pinned_err_m);
-		return fail(c, SK_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
-	}
+	if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
+	if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
 	return SK_OK;
 }
 int sk_copy_h2d(sk_ctx *c, void *dst, const void *src, size_t bytes)
@@ -530,12 +523,22 @@ __global__ void counts_add_kernel(unsigned long long *dst, const unsigned long l
 // fd 1 is process-wide state: one redirection at a time (two callers could otherwise put each other's descriptor back),
 // and only the calls that make a communicator take it — a host thread that prints a result at that very moment would see
 // it on stderr, which is why the command-line hosts make their communicators before their workers start.
+// The lock is held only around the descriptor swaps, never across the RCCL call: two ranks of ONE process joining from two
+// threads both block in the bootstrap until the other has arrived — the first redirection stays in place (a count) until the
+// last of them is back.
 static std::mutex g_stdout_m;
+static int g_stdout_depth = 0, g_stdout_saved = -1;
 struct StdoutToStderr {
-	std::lock_guard<std::mutex> lk{g_stdout_m};
-	int saved = -1;
-	StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
-	~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
+	StdoutToStderr()
+	{
+		std::lock_guard<std::mutex> lk(g_stdout_m);
+		if (g_stdout_depth++ == 0) { fflush(stdout); g_stdout_saved = dup(1); if (g_stdout_saved >= 0) (void)dup2(2, 1); }
+	}
+	~StdoutToStderr()
+	{
+		std::lock_guard<std::mutex> lk(g_stdout_m);
+		if (--g_stdout_depth == 0) { fflush(stdout); if (g_stdout_saved >= 0) { (void)dup2(g_stdout_saved, 1); close(g_stdout_saved); g_stdout_saved = -1; } }
+	}
 };
 
 #define SK_NCCL(c, call)                                                                                  \

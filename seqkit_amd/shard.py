@@ -1,4 +1,4 @@
-"""Read sharding across GPUs: every cluster is independent, so a batch is cut into contiguous,
+"""Read sharding across GPUs (used by bench.py for its shards and its gloo fallback sum): every cluster is independent, so a batch is cut into contiguous,
 tile-aligned shards, one per rank, and the only cross-shard state — the additive counters
 (src/fasta_demultiplex.rs:108-109,169,177-178; BAM: 3 counters + histogram) — is summed with ONE all-reduce.
 One process per GPU; `torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.

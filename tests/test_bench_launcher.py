@@ -41,6 +41,25 @@ def test_launcher_fails_when_a_rank_fails_and_ends_the_others(tmp_path):
     assert time.time() - t0 < 25          # the sleeping ranks were ended, not waited for
 
 
+def test_a_failing_rank_is_quoted(tmp_path):
+    """Every rank's stderr is relayed line by line behind its rank, and the failing rank's last lines are repeated under the verdict."""
+    r = run(tmp_path, 3, {"SK_STUB_FAIL_RANK": "2"})
+    assert r.returncode == 7
+    assert "[rank 2] hipErrorOutOfMemory while allocating the candidates" in r.stderr
+    assert "[bench] rank 2 failed with exit code 7" in r.stderr and "[bench]   rank 2 said: the last thing this rank said" in r.stderr
+
+
+def test_a_taken_port_is_redrawn_even_when_another_rank_fails_first(tmp_path):
+    """Only rank 0 binds the rendezvous port.  When it is taken the other ranks can fail first, with an ordinary error: the
+    launcher waits a moment for rank 0's own verdict, draws a new port and starts all ranks again."""
+    r = run(tmp_path, 3, {"SK_STUB_PORT_TAKEN_ONCE": "1"})
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"n_gpus": 3, "stub": True}
+    ports = [open(tmp_path / f"attempt_rank{k}").read().split() for k in range(3)]
+    assert all(len(p) == 2 for p in ports) and len({p[1] for p in ports}) == 1       # two attempts, the second on one port for all
+    assert "was taken before rank 0 could listen" in r.stderr
+
+
 def test_under_a_launcher_bench_is_one_rank(tmp_path):
     """With WORLD_SIZE in the environment (torchrun) bench.py does not spawn: it is a rank, and a --gpus that disagrees is an error."""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
