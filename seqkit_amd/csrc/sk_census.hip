@@ -523,6 +523,15 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	u32 *lh = reinterpret_cast<u32 *>(census_smem + front_bytes + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
 	// the wave's queue of rows that take the long way (a byte each: a step has at most 256 rows)
 	uint8_t *queue = reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + wave * (kCensusMaxSub * 64);
+	// Rows that miss wait until 64 of them are together: a pass of the long way costs its ~300 instructions whether 6 lanes or
+	// 64 have a row (a clean run missed 6-15 rows per step and paid a pass for them in every step: 23-27 % of a wave's
+	// lifetime, profiles/r04_census_stamps_before.txt).  What is left over at the end of a step — fewer than 64 rows — is copied
+	// out of the tile into the wave's CARRY area behind it (the string's NW masked dwords on a 4 NW-byte pitch, so the same
+	// reader serves both; the rows' indices beside them) and goes first in the next step's queue.
+	constexpr int kCarryPitch = 4 * NW;
+	const int carry_off = tile_slot - 64 * (kCarryPitch + 4);           // (census_add sized the wave's slot for it)
+	u32 *carry_row = reinterpret_cast<u32 *>(tile + carry_off + 64 * kCarryPitch);
+	u32 n_carry = 0u;                                                  // wave-uniform
 	for (int i = tid; i < (int)(front_bytes / 16u); i += blockDim.x) reinterpret_cast<uint4 *>(front)[i] = make_uint4(0u, 0u, 0u, 0u);
 	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
 	// The workgroup's steps are dealt to its waves as they come free (an LDS counter): the waves of a SIMD do not advance at
@@ -568,13 +577,15 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	};
 	int t = (int)blockIdx.x * nwave + wave;
 	census_load_tile(streams, a.assign != nullptr, t, step_bytes, offk, R, lane, rg);
-	while (t < nsteps) {
+	for (;;) {
+		const bool drain = t >= nsteps;                                // no step left: one more turn for the rows still waiting in the carry area
+		if (drain && n_carry == 0u) break;
 		u32 next_c = 0u;                                               // asked for before the tile is written: the answer is there when the fence is
 		if (lane == 0) next_c = atomicAdd(step_ctr, 1u);
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
 			const int off = lane * 16 + k * 1024;
-			if (off < step_bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];
+			if (off < step_bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];      // (a drain turn writes what the clipped loads gave: zeros nobody reads)
 		}
 		SK_STAMP(1);                                                   // the step's loads waited for, tile written
 		// which of the step's rows are counted, worked out BEFORE the next step's loads are issued: nothing below may
@@ -601,7 +612,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		u32 parked = 0u;
 		// ---- rows whose bytes the table knows are counted there; the others queue up for the long way ------------------------
 		u32 qn = 0u;
-		{
+		if (!drain) {
 			// all of the step's row reads first, then all of its table reads, then the counting: three LDS round trips per
 			// step instead of three per 64 rows
 			u32 xs[R][NW], hs[R], en[R], first[R];
@@ -656,18 +667,27 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		SK_STAMP(3);                                                   // rows the table knows
 		// ---- the long way, 64 queued rows at a time: check the string, look for it again (another lane may have put it there
 		// meanwhile), else claim one of its places, else build its key and park it -----------------------------------------------
+		// (the lane index as a value the compiler cannot see through: what the long way computes from it — queue and carry
+		// addresses — is then worked out here, per step, instead of being kept in registers across the whole loop; the kernel sits
+		// at its 128 registers, and one more live value was a scratch slot whose reload waited for the step's prefetch)
+		u32 lane_l = (u32)lane;
+		asm volatile("" : "+v"(lane_l));
+		const u32 q_total = n_carry + qn;                              // the carried rows first, then the step's
+		const u32 n_pass = drain ? (q_total + 63u) >> 6 : q_total >> 6;    // whole passes only, but for the last turn
 #pragma unroll
 		for (int j = 0; j < R; j++) {
 			ph[j] = 0u;
 			prid[j] = 0u;
 			pklo[j] = pkhi[j] = 0ull;                                 // (only read where `parked` says so: these cost nothing)
-			if ((u32)(j * 64) < qn) {
-				const u32 qi = (u32)(j * 64 + lane);
-				const bool have = qi < qn;
-				const u32 rid = have ? (u32)queue[qi] : 0u;
-				prid[j] = rid;
+			if ((u32)j < n_pass) {
+				const u32 qi = (u32)(j * 64) + lane_l;
+				const bool have = qi < q_total;
+				const bool carried = qi < n_carry;
+				const u32 rid = have && !carried ? (u32)queue[qi - n_carry] : 0u;
+				const u32 r = carried ? carry_row[qi] : (u32)(t * R * 64) + rid;      // the row's index within the launch
+				prid[j] = r;
 				u32 xs[NW];
-				census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
+				census_row_raw<NW>(tile, carried ? carry_off + (int)qi * kCarryPitch : (int)rid * stride, kms, xs);
 				{	// a NUL before L ends the barcode and what follows it is padding: zeroed, only when some row of the pass has one
 					u32 z = 0u;
 #pragma unroll
@@ -676,7 +696,6 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				}
 				u32 bad;
 				census_key_of<NW>(xs, pklo[j], pkhi[j], bad);
-				const u32 r = (u32)(t * R * 64) + rid;
 				if (have) {
 					if (bad != 0u) rejected++;                                 // a byte outside the alphabet before the barcode's end
 					else {
@@ -709,6 +728,27 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				}
 			}
 		}
+		{	// what is left — fewer than 64 rows, all of them this step's when a pass ran (it took the carried ones first) — waits
+			const u32 done = n_pass << 6;
+			const u32 left = q_total > done ? q_total - done : 0u;
+			const u32 keep = done == 0u ? n_carry : 0u;                   // carried rows no pass took stay where they are
+			const u32 q0 = done > n_carry ? done - n_carry : 0u;          // the first queue entry that waits
+			const u32 m = left - keep;                                    // rows to copy out of the tile
+			if (m != 0u) {
+				census_wave_fence();
+				const bool mine = lane_l < m;
+				const u32 rid = mine ? (u32)queue[q0 + lane_l] : 0u;
+				u32 xs[NW];
+				census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
+				if (mine) {
+					u32 *dst = reinterpret_cast<u32 *>(tile + carry_off + (int)(keep + lane_l) * kCarryPitch);
+#pragma unroll
+					for (int q = 0; q < NW; q++) dst[q] = xs[q];
+					carry_row[keep + lane_l] = (u32)(t * R * 64) + rid;
+				}
+			}
+			n_carry = left;
+		}
 		census_wave_fence();
 		SK_STAMP(4);                                                   // the long way
 		// The parked keys, packed densely through the (now dead) tile so that one insert serves up to 64 of them: its
@@ -732,7 +772,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			for (int j = 0; j < R; j++) {
 				const bool has = ((parked >> j) & 1u) != 0u;
 				const u32 at = has ? base + pos[j] : 0x07ffffffu;          // beyond the region: dropped by the descriptor
-				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), (u32)(t * R * 64) + prid[j]};
+				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), prid[j]};
 				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
 				if (has) atomicAdd(&lh[(u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift)], 1u);
 			}
@@ -756,7 +796,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 						const uint4 kq = qkey[qn - cnt + lane];
 						const u32 rel = qrel[qn - cnt + lane];
 						const u64 klo = (u64)kq.x | ((u64)kq.y << 32), khi = (u64)kq.z | ((u64)kq.w << 32);
-						const u64 first_inv = ~(u64)(a.row_base + t * R * 64 + rel);
+						const u64 first_inv = ~(u64)(a.row_base + rel);
 						if (!census_insert(a.tab, a.mask, klo, khi, 1ull, first_inv, claimed)) overflow++;
 					}
 					qn -= cnt;
@@ -1332,8 +1372,10 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	int R = kCensusStepBytes / (64 * bc_stride);
 	R = R < 1 ? 1 : (R > kCensusMaxSub ? kCensusMaxSub : R);
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
-	int tile_slot = (R * 64 * bc_stride + 15) & ~15;
+	const int nw_dwords = L <= 8 ? 2 : (L <= 20 ? 5 : 8);
+	int tile_slot = (R * 64 * bc_stride + 4 + 15) & ~15;             // (+ 4: a row is read as NW + 1 dwords)
 	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
+	tile_slot += 64 * (4 * nw_dwords + 4);                          // the wave's carry area: 64 strings and their rows' indices
 	size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32)      // + slack: a row is read as 9 dwords; the spill counters
 	             + (size_t)kCensusWaves * kCensusMaxSub * 64;          // the waves' queues of rows that take the long way
 	// the front table takes what is left of the CU's 160 KiB (SK_CENSUS_FRONT_ENTRIES: tests shrink it so that small inputs
@@ -1415,7 +1457,17 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
 			}
 		}
-		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((R - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
+		// (the variants that insert by themselves need more registers than those that write records: with four tiles of <= 20
+		// characters, or three of more, they would keep values in scratch — and a scratch reload waits for the step's prefetch)
+		int Rk = R;
+		if (!spill) {
+			if (nw_class == 1 && Rk > 3) Rk = 3;
+			if (nw_class == 2 && Rk > 2) Rk = 2;
+			const int64_t groups_k = (nr + (int64_t)64 * Rk * kCensusWaves - 1) / ((int64_t)64 * Rk * kCensusWaves);
+			grid = n_cu * wgs_per_cu;
+			if (grid > groups_k) grid = (int)groups_k;
+		}
+		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((Rk - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
 		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, front_entries);
 		if (spill) {
 			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid, a.sp.wg_stats, a.stats);
