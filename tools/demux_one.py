@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Demultiplex alone on one sheet, a few launches: the thing to put under rocprofv3 (tools/profile_cmd.sh).
-usage: python tools/demux_one.py [dual|cfg3] [rows] [detail]"""
+usage: python tools/demux_one.py [dual|dual384|cfg3] [rows] [detail]"""
 import os
 import sys
 
@@ -17,6 +17,9 @@ dev = torch.device("cuda", 0)
 ctx = seqkit_amd.Context(0)
 if kind == "dual":
     table = synth.make_sheet(96, 8, dual=True, seed=4)
+    bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
+elif kind == "dual384":                       # four plates: the sheet is looked up half by half (sk_lut.h)
+    table = synth.make_sheet(384, 8, dual=True, seed=384)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
 else:
     table = synth.make_sheet(16, 8, dual=False, seed=3)

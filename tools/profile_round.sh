@@ -3,7 +3,7 @@
 # the N = 2 same-device line, the CLI's kernel trace, PMC of the lookup kernel and of trim alone, the rates of every tool, the
 # census kernels' trace and PMC, the GPU test run.  usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,8 +14,13 @@ bash tools/profile_cli_demux.sh $TAG 2000000 > $OUT/cli_demux.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_lut_dual "demux_lut" tools/demux_one.py dual 10000000 > $OUT/lut_dual_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_lut_cfg3 "demux_lut" tools/demux_one.py cfg3 10000000 > $OUT/lut_cfg3_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_trim_uniform "tile_pass_kernel" tools/trim_one.py uniform 16000000 > $OUT/trim_uniform_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_fused_single "tile_pass_kernel" tools/fused_one.py single 16000000 > $OUT/fused_single_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_lut_384 "demux_lut" tools/demux_one.py dual384 10000000 > $OUT/lut_384_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_census_noisy "census_" tools/census_one.py noisy 32000000 3 > $OUT/census_noisy_pmc.log 2>&1
 bash tools/census_trace.sh ${TAG}_census > $OUT/census_trace.log 2>&1
+( cd seqkit_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSK_CENSUS_STAMPS -o ../../tools/ab/census_stamps.so sk_kernels.hip sk_census.hip sk_capi.hip sk_lut.cpp -ldl ) > $OUT/census_stamps_build.log 2>&1
+python3 tools/census_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/census_stamps.txt
+{ tools/ab/insert_exp; } > $OUT/insert_exp.txt 2>&1
 {
   echo "== tools/rates.py"; python3 tools/rates.py 2>&1 | grep -v amdgpu.ids
   echo "== tools/demux_ab.py (DEMUX_DETAIL=1, forms default / table in the vector cache / no table)"
@@ -25,5 +30,5 @@ bash tools/census_trace.sh ${TAG}_census > $OUT/census_trace.log 2>&1
   echo "== tools/seq_ab.py (pitch 152, 148)"; python3 tools/seq_ab.py 2>&1 | grep -v amdgpu.ids; SEQ_STRIDE=148 python3 tools/seq_ab.py 2>&1 | grep -v amdgpu.ids
 } > $OUT/rates.txt 2>&1
 { echo "== tools/bam_scale.sh 20"; bash tools/bam_scale.sh 20 2>&1; echo "== tools/bam_paths.sh 20"; bash tools/bam_paths.sh 20 2>&1; } > $OUT/bam_host.txt 2>&1
-python3 -m pytest tests -q -m gpu 2>&1 | tail -15 > $OUT/gpu_tests.txt
+timeout 1500 python3 -m pytest tests -q -m gpu 2>&1 | tail -15 > $OUT/gpu_tests.txt
 ls -la $OUT
