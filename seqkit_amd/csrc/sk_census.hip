@@ -4,9 +4,11 @@
 //   src/fasta_demultiplex.rs:190-194   `*extra_barcodes.entry(barcode).or_insert(0) += 1`  (dry run, unmatched reads)
 //   src/fasta_statistics.rs:23-27      `*sample_barcodes.entry(sample_barcode).or_insert(0) += 1`
 // Both are a HashMap<String, u64> fed one barcode per read.  Here the map is an open-addressing table in HBM
-// keyed by the barcode packed at 4 bits per character, in front of which every workgroup keeps a small LDS
-// table: the barcodes that dominate a run (the sample sheet's, plus their one-error neighbours) are counted
-// with LDS atomics and reach HBM once per workgroup instead of once per read.
+// keyed by the barcode packed at 4 bits per character, in front of which every workgroup keeps a table in LDS keyed by
+// the rows' raw bytes: the barcodes that dominate a run (the sample sheet's, plus their one-error neighbours) are
+// counted with LDS atomics — no key is built for them — and reach HBM once per launch (large launches: the workgroups'
+// tables and the rows they had no room for are written out as records, partitioned by table region and combined) or
+// once per workgroup (small launches) instead of once per read.
 //
 // Key: the alphabet is what the reference's regexes admit, " BC:[ACGTNacgtn+]+" — 11 symbols, code 1..11, code 0
 // ends the barcode.  Nibble 0 of the low word is the marker 0xF (so a key is never 0, the empty-slot value);
@@ -84,7 +86,7 @@ constexpr int kLdsSlots = 2048;
 constexpr int kLdsProbes = 3;
 constexpr u32 kMaxProbes = 1u << 16;
 
-// The workgroup's front table, one array per field: slot i of a u64 array lies in bank pair i mod 32, so the 64 probes of a
+// The combine pass's table (keyed by the packed key), one array per field: slot i of a u64 array lies in bank pair i mod 32, so the 64 probes of a
 // wave spread over all banks.  (As 32-byte records every slot began in one of 8 bank groups: SQ_LDS_BANK_CONFLICT was
 // 1.5 x SQ_ACTIVE_INST_LDS, profiles/r02_census_pmc_summary.txt.)
 struct LdsTable {
@@ -242,7 +244,7 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
 }
 
-// count (cnt, first) for one key in the workgroup's LDS table; returns the key's slot — plus kLdsClaimed when this call put
+// count (cnt, first) for one key in the combine pass's LDS table; returns the key's slot — plus kLdsClaimed when this call put
 // the key there — or -1 when it found no room within kLdsProbes slots
 constexpr int kLdsClaimed = 1 << 16;
 __device__ __forceinline__ int lds_count_at(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv)
@@ -440,7 +442,7 @@ struct CensusArgs {
 	CensusSpill sp;
 };
 
-constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the LDS table
+constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the front table
 constexpr int kCensusMaxStride = 64;      // 64 rows x 64 B = 4 KiB per wave tile = 4 x 16 B per lane
 
 __device__ __forceinline__ void census_wave_fence()
