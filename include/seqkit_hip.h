@@ -93,9 +93,12 @@ int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n
  *   SK_DETAIL_MATCHED rows with assign != SK_ASSIGN_NONE; the detail of SK_ASSIGN_NONE rows is unspecified (255 / -1 /
  *                     -1 when the lookup table answers).  A demultiplex-alone call with max_diff <= 1 is then ONE table
  *                     lookup per read — the sheet's rows and their one-substitution neighbours, decided on the host with
- *                     the same loop — instead of S x L compares, for sheets of <= 128 samples, <= 20 columns, <= 7
- *                     letters; other sheets run the matchers and fill every row.  The decision-only form (all three
- *                     pointers NULL) takes the table under either mode.
+ *                     the same loop — instead of S x L compares, for sheets of <= 1021 samples, <= 20 columns, <= 7
+ *                     letters (wildcards in whole columns only); a dual-index sheet whose table would not fit a
+ *                     workgroup's LDS is looked up half by half when that is exact (its half-barcodes at least 3
+ *                     apart); other sheets run the matchers and fill every row.  The decision-only form (all three
+ *                     pointers NULL) takes the table under either mode, and so does the barcode phase of a fused call
+ *                     whose sheet is beyond the tile pass's own matcher (128 samples).
  * Applies to sk_demux_assign(_dev) and sk_fused_pass(_dev) of this ctx from the next call on.                        */
 #define SK_DETAIL_FULL    0
 #define SK_DETAIL_MATCHED 1
