@@ -118,12 +118,11 @@ def test_mask_cli_quirks(bins, tmp_path):
 
 
 # ---- demultiplex ------------------------------------------------------------------------------------------------
-def demux_inputs(tmp_path, n, paired, dual, seed, umi=False):
-    S = 24
+def demux_inputs(tmp_path, n, paired, dual, seed, umi=False, S=24):
     table = synth.make_sheet(S, 8, dual=dual, seed=seed)
     if umi:
         table[:, -4:] = ord("U")
-    names = [f"S{i:02d}" for i in range(S)]
+    names = [f"S{i:03d}" if S > 99 else f"S{i:02d}" for i in range(S)]
     sheet = tmp_path / "sheet.tsv"
     sheet.write_bytes(b"# comment line\n" + b"".join(f"{nm}\t".encode() + table[i].tobytes() + b"\textra col\n" for i, nm in enumerate(names)) + b"\nloner\n")
     obs_table = table.copy()
@@ -152,6 +151,16 @@ def test_demultiplex_header_mode(bins, tmp_path, monkeypatch, paired, dual, bloc
     assert a[0] == 0 and b"clusters carried a barcode matching" in a[2]
     outs = cu.gunzip_dir(da)
     assert len(outs) == 24 * (2 if paired else 1) and sum(len(v) for v in outs.values()) > 0
+
+
+def test_demultiplex_four_plates(bins, tmp_path):
+    """384 dual-index samples: beyond the tile pass's own matcher, and the sheet's full-key table would not fit the LDS — the
+    command's lookups go half by half (sk_lut.h, the factored form); files, warnings and the summary as the oracle's."""
+    sheet, files, table, bc = demux_inputs(tmp_path, 5000, False, True, seed=384, S=384)
+    a, b, da, _ = both(bins, "fasta", ["demultiplex", sheet] + files, tmp_path)
+    assert a[0] == 0 and b"clusters carried a barcode matching" in a[2]
+    outs = cu.gunzip_dir(da)
+    assert len(outs) == 384 and sum(1 for v in outs.values() if v) > 300
 
 
 @pytest.mark.parametrize("gpus,per", [("0,0", "1"), ("0,0,0", "2"), ("0", "1")])

@@ -41,4 +41,13 @@ for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact
         for i, name in enumerate(PHASES):
             c = buf[:, i].astype(np.float64)
             print(f"   {name:28s} {c.mean():10.0f} cycles  {100 * c.mean() / tot.mean():5.1f} %   (min {c.min():.0f} max {c.max():.0f})")
+        cw = 2 * 256 * 8
+        cbuf = np.zeros((cw, 16), dtype=np.uint64)
+        if hasattr(lib, "sk_debug_combine_stamps") and lib.sk_debug_combine_stamps(cbuf.ctypes.data_as(C.c_void_p), cw) == 0:
+            ctot = cbuf[:, :8].sum(axis=1).astype(np.float64)
+            print(f"   -- combine kernel, mean cycles per wave {ctot.mean():.0f}")
+            for i, name in enumerate(["records counted + items scanned", "take an item, clear the table", "find bucket and range", "count the records", "barrier", "list occupied slots",
+                                      "insert distinct keys", "statistics"]):
+                c = cbuf[:, i].astype(np.float64)
+                print(f"      {name:32s} {c.mean():10.0f} cycles  {100 * c.mean() / max(ctot.mean(), 1):5.1f} %")
         sys.stdout.flush()
