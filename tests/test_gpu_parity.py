@@ -1,4 +1,6 @@
 """GPU: the HIP path, called through the C-ABI, against the CPU oracle — bit-exact (all integer/byte work)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -466,7 +468,7 @@ def test_demux_counters_across_launches(ctx, oracle, monkeypatch, want_detail, c
         assert np.array_equal(ctx.counts().astype(np.uint64), counts_of(e_assign[:5000]))
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SK_FUZZ_SEEDS", "48"))))      # SK_FUZZ_SEEDS=400: the long run, once per round on the GPU box
 def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
     """Sheets with and without a lookup table: wildcard columns (all rows / some rows), a separator, duplicates, lower case
     next to upper case, up to 7 letters and more, any length to 20 and above, more than 128 samples, max_diff 0 / 1 / 2,
@@ -1204,7 +1206,7 @@ def test_census_anything_after_the_first_nul_is_padding(ctx, oracle, census_path
     assert ctx.census_stats()["rejected"] == 0 and ctx.census_stats()["counted"] == n
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SK_FUZZ_SEEDS", "24"))))      # SK_FUZZ_SEEDS=400: the long run, once per round on the GPU box
 def test_fuzz_census(ctx, oracle, monkeypatch, seed):
     """Random shapes through a random path: length, pitch, row count, alphabet, share and number of frequent barcodes, early
     NULs, bytes outside the alphabet, assignment codes, batches with row_base — every distinct barcode, its count and its
