@@ -1131,16 +1131,20 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 		for (int o = kSpillBuckets / 2; o > 0; o >>= 1) if (cpre[b + o] <= item) b += o;
 		const u32 lo = a.sp.bstart[b] + (item - cpre[b]) * kCombineChunk;
 		const u32 hi = min(a.sp.bstart[b + 1], lo + kCombineChunk);
-		// (four records of a thread are asked for before the first is counted: with one load per trip the loop was a chain of
-		// memory latencies — 32 of them for a full item)
+		// (four records of a thread are counted while its next four are on their way: with one load per trip the loop was a
+		// chain of memory latencies — 32 of them for a full item —, with four loads per trip still one per trip)
 		constexpr int kAhead = 4;
-		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
-			uint4 kk[kAhead];
+		uint4 kk[kAhead], kn[kAhead];
+		auto fetch = [&](u32 i0, uint4 (&dst)[kAhead]) {
 #pragma unroll
 			for (int q = 0; q < kAhead; q++) {
 				const u32 i = i0 + (u32)q * blockDim.x;
-				kk[q] = i < hi ? a.sp.skey[i] : make_uint4(0u, 0u, 0u, 0u);
+				dst[q] = i < hi ? a.sp.skey[i] : make_uint4(0u, 0u, 0u, 0u);
 			}
+		};
+		fetch(lo + tid, kk);
+		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
+			fetch(i0 + kAhead * blockDim.x, kn);
 #pragma unroll
 			for (int q = 0; q < kAhead; q++) {
 				if (i0 + (u32)q * blockDim.x >= hi) break;
@@ -1154,6 +1158,8 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 					if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, (u64)cnt, first_inv, claimed)) overflow += cnt;
 				}
 			}
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
 		}
 		__syncthreads();
 		// the occupied slots first go to a list: an insert is three dependent round trips to HBM, and a wave that walks
@@ -1364,8 +1370,9 @@ static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
 	return hipSuccess;
 }
 
-constexpr int64_t kSpillMinRows = 1 << 23;      // smaller launches insert directly: the partition path is four more kernels; measured (tools/census_rates.py, noisy run,
-                                                // insert-in-place / partition): 4 M rows 0.168 / 0.176 ms, 8 M 0.279 / 0.228, 16 M 0.523 / 0.317, 32 M 0.96 / 0.52
+constexpr int64_t kSpillMinRows = 1 << 19;      // smaller launches insert directly: the partition path is four more kernels.  Measured (tools/census_small.py, round 4,
+                                                // insert-in-place / partition, noisy run): 250 k rows 58 / 68 us, 1 M 100 / 80, 4 M 187 / 110, 8 M 308 / 149; rows that
+                                                // are all sheet barcodes: 250 k 40 / 47, 1 M 65 / 55, 4 M 84 / 68 (round 3's crossover was at 8 M rows)
 
 hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
                       int n_cu, hipStream_t st)
