@@ -534,6 +534,11 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	const int carry_off = tile_slot - 64 * (kCarryPitch + 4);           // (census_add sized the wave's slot for it)
 	u32 *carry_row = reinterpret_cast<u32 *>(tile + carry_off + 64 * kCarryPitch);
 	u32 n_carry = 0u;                                                  // wave-uniform
+	// Once the table is full a string that is not in it finds both its places taken, every time: after kFullAfter rows in a
+	// row (of this wave) for which that was so, the long way no longer looks — it builds the key and parks the row.  (A string
+	// that another lane put into the table a moment ago is then parked instead of counted there: the sums are the same.)
+	constexpr u32 kFullAfter = 256u;
+	u32 fails_in_a_row = 0u;                                           // wave-uniform
 	for (int i = tid; i < (int)(front_bytes / 16u); i += blockDim.x) reinterpret_cast<uint4 *>(front)[i] = make_uint4(0u, 0u, 0u, 0u);
 	if (SPILL) for (int i = tid; i <= kSpillBuckets; i += blockDim.x) lh[i] = 0u;
 	// The workgroup's steps are dealt to its waves as they come free (an LDS counter): the waves of a SIMD do not advance at
@@ -705,7 +710,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 						const u32 h = front_hash<NW>(xs);
 						bool done = false;
 #pragma unroll 1
-						for (int pl = 0; pl < 2 && !done; pl++) {
+						for (int pl = 0; pl < 2 && !done && fails_in_a_row < kFullAfter; pl++) {
 							const u32 e = front_place(h, pl, ft.entries);
 #pragma unroll 1
 							for (int spin = 0; spin < 256; spin++) {               // (a BUSY entry is published by its writer a few LDS operations later)
@@ -727,6 +732,11 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 						}
 						if (!done) { ph[j] = census_hash(pklo[j], pkhi[j]); parked |= 1u << j; }
 					}
+				}
+				if (fails_in_a_row < kFullAfter) {                             // (uniform) how did the pass's rows fare?
+					const u32 np = (u32)__popcll(__ballot(((parked >> j) & 1u) != 0u));
+					const u32 nr = (u32)__popcll(__ballot(have && bad == 0u));
+					fails_in_a_row = np == nr ? fails_in_a_row + np : 0u;      // a pass in which any row found or claimed a place starts the count again
 				}
 			}
 		}
