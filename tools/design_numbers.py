@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The numbers DESIGN.md §6 quotes, from the round's profile set: prints the extra.rates table (markdown) and the headline /
+census figures.  usage: python tools/design_numbers.py [r04] [--write]   (--write replaces the table between DESIGN.md's markers)"""
+import json
+import os
+import re
+import sys
+
+tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r04")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench.json")).read().strip().splitlines()[-1])
+bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "4 tile-rounds of 7.3 µs + 5.5 µs launch", "cfg2 read": "HBM", "fused single-end:": "HBM",
+         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "issue (70 VALU + 63 SALU per tile) + 4 µs launch", "cfg3 with": "stream",
+         "cfg3 sheet": "issue", "demultiplex only 10M x 17ch, 96": "issue (97 + 60 per tile)", "96 dual": "stream",
+         "demultiplex only 10M x 17ch, 384": "issue: three lookups per read", "cfg5": "HBM", "f2:": "HBM", "f4:": "latency / occupancy",
+         "f3: census 32M rows, clean": "front kernel issue-bound (§3.7)", "f3: census 32M rows, noisy": "front kernel 0.19–0.20 + partition passes 0.17–0.19 ms",
+         "f3: census 32M rows, every": "memory side: one CAS + two stores per new key"}
+rows = []
+for x in d["extra"]["rates"]:
+    b = next((v for k, v in bound.items() if x["config"].startswith(k)), "")
+    placed = f" (as placed {x['frac_as_placed']:.3f})" if x.get("frac_as_placed") else ""
+    rows.append(f"| {x['config']} | {x['ms'] * 1000:.1f} µs, {x['G_units_per_s']:.1f} G units/s | {x['frac']:.3f}{placed} | {b} |")
+table = "| config (device-resident; `bench.py` `extra.rates`) | rate | of 8 TB/s | bound |\n|---|---|---|---|\n" + "\n".join(rows)
+r = d["roofline"]
+print(f"headline: value {d['value']} M reads/s, ms_per_step {d['ms_per_step']}, kernel_ms {r['kernel_ms']}, achieved {r['achieved']} GB/s, frac {r['frac']}, "
+      f"frac_as_placed {r['frac_as_placed']}, read_frac {r['read_frac']}, traffic {r['traffic']}")
+print("placement:", d["config"]["placement"].get("ms_before"), "->", d["config"]["placement"].get("ms_after"))
+print("cpu:", d["cpu_baseline"]["value"], {k: v["M_reads_per_s"] for k, v in d["cpu_baseline"].get("faithful", {}).items() if isinstance(v, dict)})
+print(table)
+if "--write" in sys.argv:
+    p = os.path.join(root, "DESIGN.md")
+    s = open(p).read()
+    s2 = re.sub(r"(<!-- rates:begin -->\n).*?(\n<!-- rates:end -->)", lambda m: m.group(1) + table + m.group(2), s, flags=re.S)
+    assert s2 != s or table in s, "markers not found"
+    open(p, "w").write(s2)
