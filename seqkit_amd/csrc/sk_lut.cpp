@@ -273,16 +273,25 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 		while (((size_t)1 << nbe) * 84 < bound * 100) nbe++;
 		if (lds_budget > 0 && ((size_t)16 << nbe) > (size_t)lds_budget && build_pair(shp, sheet, out, lds_budget)) return true;
 	}
-	// enumerate every row and every row with one key column changed
+	// Enumerate every row and every row with one key column changed, and DECIDE on the way (src/fasta_demultiplex.rs:154-166:
+	// lowest distance, first and last row attaining it, rows in sheet order).  The rows within distance 1 of a key are exactly
+	// the rows that generate it here — it is that row, or one substitution away from it — so a key's decision is the minimum
+	// over its generators: no loop over all rows per key (that loop was 1 s for 1 000 samples x 20 columns).
+	struct Decision { int diff, first, last; };
 	std::vector<Key> keys;
+	std::vector<Decision> dec;
 	{
-		std::unordered_map<uint64_t, int> seen;
-		auto add = [&](Key k) {
+		std::unordered_map<uint64_t, size_t> at;
+		auto add = [&](Key k, int s, int d) {
 			pack_classes(k.cls, k.A, k.B);
-			if (seen.emplace(((uint64_t)k.A << 32) | k.B, 0).second) keys.push_back(k);
+			auto ins = at.emplace(((uint64_t)k.A << 32) | k.B, keys.size());
+			if (ins.second) { keys.push_back(k); dec.push_back({d, s, s}); return; }
+			Decision &e = dec[ins.first->second];
+			if (d < e.diff) e = {d, s, s};                                      // rows come in ascending order: the first to attain a distance is the first argmin
+			else if (d == e.diff) e.last = s;
 		};
 		for (int s = 0; s < S; s++) {
-			add(rows[(size_t)s]);
+			add(rows[(size_t)s], s, 0);
 			if (max_diff < 1) continue;
 			for (int k = 0; k < L; k++) {
 				if (!counting[k] || k == sep) continue;
@@ -290,32 +299,10 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 				for (uint8_t alt : alts) {
 					if (alt == rows[(size_t)s].cls[key_pos(k)]) continue;
 					v.cls[key_pos(k)] = alt;
-					add(v);
+					add(v, s, 1);
 				}
 			}
 		}
-	}
-	// decide: src/fasta_demultiplex.rs:154-166 (first / last argmin over the rows in sheet order).  (1 000 samples x 20 columns
-	// are 80 k keys x 1 000 rows: equal packed words answer "distance 0" at once, and a row's count stops where it passes the
-	// lowest seen so far — a key is a row or one step from one, so that is after a few columns for all rows but its own.)
-	struct Decision { int diff, first, last; };
-	std::vector<Decision> dec(keys.size());
-	for (size_t q = 0; q < keys.size(); q++) {
-		int lowest = 0x7fffffff, first = 0, last = 0;
-		for (int s = 0; s < S; s++) {
-			if (keys[q].A == rows[(size_t)s].A && keys[q].B == rows[(size_t)s].B) {   // (the common early answer: distance 0)
-				if (0 < lowest) { lowest = 0; first = s; last = s; }
-				else if (lowest == 0) last = s;
-				continue;
-			}
-			if (lowest == 0) continue;                                            // only another exact row could still matter
-			int d = 0;
-			for (int k = 0; k < kLutMaxLen && d <= lowest; k++) d += (keys[q].cls[k] != rows[(size_t)s].cls[k]) ? 1 : 0;      // ignored positions are 0 on both sides
-			if (d < lowest) { lowest = d; first = s; last = s; }
-			else if (d == lowest) last = s;
-		}
-		if (lowest > max_diff) return false;                                  // cannot happen: every key is a row or one step from one
-		dec[q] = {lowest, first, last};
 	}
 	const int idx_bits = S <= 128 ? 7 : 10;
 	std::vector<int16_t> amb;
