@@ -781,6 +781,21 @@ __device__ __forceinline__ void demux_commit(const TileArgs &a, const LdsPlan &l
 	wc.ambig += (u32)__popcll(__ballot(active && code == kAssignAmbiguous));
 }
 
+// The lookup kernels keep no per-wave `identified` / `ambiguous` tallies: two ballots and two popcounts per tile were 5-7 % of
+// their time.  An ambiguous row adds to hist[S + 2] where an identified one adds to its sample; identified = the sum of the
+// samples' bins, taken by the kernel that folds the counter copies behind the launch (counts_fold_wide_kernel,
+// counts_fold_kernel) — or here, when the workgroup ends, if the launch adds to the caller's vector directly (a barrier and
+// a reduction at the end of every workgroup: 0.7 us of cfg 3's 27 at 10 M rows, which is why the folds do it).
+__device__ __forceinline__ void lut_identified_from_hist(int S, u32 *hist, int lane)
+{
+	__syncthreads();
+	u32 sum = 0;
+	for (int i = threadIdx.x; i < S; i += blockDim.x) sum += hist[i];
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) sum += (u32)__shfl_xor((int)sum, d);
+	if (lane == 0 && sum) atomicAdd(&hist[S + 1], sum);
+}
+
 // shift: counter i lives at counts[i << shift] (4: one 128-byte line per counter, TileArgs::counts_shift)
 __device__ __forceinline__ void flush_counts(int S, unsigned long long *counts, const LdsPlan &lp, u32 *hist, int lane, const WaveCounts &wc, int shift = 0)
 {
@@ -818,6 +833,10 @@ __device__ __forceinline__ void flush_counts_spread(const BarcodeDev &tb, unsign
 // the ctx's wide counters (one line each) into its u64[S+3], leaving them zero (sk_capi.hip folds before anything reads)
 __global__ __launch_bounds__(256) void counts_fold_wide_kernel(unsigned long long *__restrict__ wide, int nc, unsigned long long *__restrict__ counts)
 {
+	__shared__ unsigned long long identified;           // only the lookup kernels add to these copies: see lut_identified_from_hist
+	if (threadIdx.x == 0) identified = 0;
+	__syncthreads();
+	unsigned long long mine = 0;
 	for (int i = threadIdx.x; i < nc; i += blockDim.x) {
 		unsigned long long sum = 0;
 #pragma unroll
@@ -827,27 +846,41 @@ __global__ __launch_bounds__(256) void counts_fold_wide_kernel(unsigned long lon
 			if (v) { sum += v; *p = 0; }
 		}
 		if (sum) counts[i] += sum;
+		if (i < nc - 3) mine += sum;
 	}
+	if (mine) atomicAdd(&identified, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && identified) counts[nc - 2] += identified;
 }
 hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, unsigned long long *counts, hipStream_t st)
 {
 	counts_fold_wide_kernel<<<1, 256, 0, st>>>(wide, nc, counts);
 	return hipGetLastError();
 }
-__global__ __launch_bounds__(256) void counts_fold_kernel(unsigned long long *__restrict__ rep, int pitch, int nc, unsigned long long *__restrict__ counts)
+// derive: the copies were filled by a lookup kernel, which leaves `identified` to be summed from the samples' bins here
+__global__ __launch_bounds__(256) void counts_fold_kernel(unsigned long long *__restrict__ rep, int pitch, int nc, unsigned long long *__restrict__ counts, int derive)
 {
+	__shared__ unsigned long long identified;
+	if (threadIdx.x == 0) identified = 0;
+	__syncthreads();
+	unsigned long long mine = 0;
 	for (int i = threadIdx.x; i < nc; i += blockDim.x) {
 		unsigned long long sum = 0;
 #pragma unroll
 		for (int r = 0; r < kCountReplicas; r++) { sum += rep[(size_t)r * pitch + i]; rep[(size_t)r * pitch + i] = 0; }
 		if (sum) atomicAdd(&counts[i], sum);
+		if (i < nc - 3) mine += sum;
 	}
+	if (!derive) return;
+	if (mine) atomicAdd(&identified, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && identified) atomicAdd(&counts[nc - 2], identified);
 }
 // what launch_tile_pass puts behind a demultiplex-alone kernel: the same condition as flush_counts_spread's
-static hipError_t launch_counts_fold(const TileArgs &b, hipStream_t st)
+static hipError_t launch_counts_fold(const TileArgs &b, bool by_table, hipStream_t st)
 {
 	if (b.table.count_rep == nullptr || b.table.S + 3 > kMaxLdsHist) return hipSuccess;
-	counts_fold_kernel<<<1, 256, 0, st>>>(b.table.count_rep, b.table.count_rep_pitch, b.table.S + 3, b.counts);
+	counts_fold_kernel<<<1, 256, 0, st>>>(b.table.count_rep, b.table.count_rep_pitch, b.table.S + 3, b.counts, by_table ? 1 : 0);
 	return hipGetLastError();
 }
 
@@ -1405,7 +1438,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;
 	const u32 *x1 = reinterpret_cast<const u32 *>(tile + (rs & ~3)), *x2 = reinterpret_cast<const u32 *>(tile + (rs2 & ~3));
 	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
-	u32 n_total = 0, n_ident = 0, n_ambig = 0;
+	u32 n_total = 0;
 	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
@@ -1464,14 +1497,14 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				const u32 A2 = (W1 == 1 ? c[k2] : lut_pack_half(c[k2], c[k3])) & pr.keep2;
 				const u32 x1 = lut_mix(A1, 0u, pr.seed1), x2 = lut_mix(A2, 0u, pr.seed2);
 				const u32 m1 = (1u << pr.nb1) - 1u, m2 = (1u << pr.nb2) - 1u;
-				const u32x2_t e11 = entry(x1 & m1), e12 = entry(m1 + 1u + (__builtin_amdgcn_alignbit(x1, x1, (u32)pr.nb1) & m1));
-				const u32x2_t e21 = entry(pr.off2 + (x2 & m2)), e22 = entry(pr.off2 + m2 + 1u + (__builtin_amdgcn_alignbit(x2, x2, (u32)pr.nb2) & m2));
+				const u32x2_t e11 = entry(lut_slot(x1, pr.nb1)), e12 = entry(m1 + 1u + lut_slot(x1 << pr.nb1, pr.nb1));
+				const u32x2_t e21 = entry(pr.off2 + lut_slot(x2, pr.nb2)), e22 = entry(pr.off2 + m2 + 1u + lut_slot(x2 << pr.nb2, pr.nb2));
 				const bool f1 = e11[0] == A1 || e12[0] == A1, f2 = e21[0] == A2 || e22[0] == A2;
 				const u32 v1 = e11[0] == A1 ? e11[1] : e12[1], v2 = e21[0] == A2 ? e21[1] : e22[1];
 				tot = (int)(v1 >> 16) + (int)(v2 >> 16) + (int)sepbad;
 				const u32 pk = (v1 & 0x3ffu) | ((v2 & 0x3ffu) << 10);
 				const u32 xp = lut_mix(pk, 0u, pr.seedp), mp = (1u << pr.nbp) - 1u;
-				const u32x2_t ep1 = entry(pr.offp + (xp & mp)), ep2 = entry(pr.offp + mp + 1u + (__builtin_amdgcn_alignbit(xp, xp, (u32)pr.nbp) & mp));
+				const u32x2_t ep1 = entry(pr.offp + lut_slot(xp, pr.nbp)), ep2 = entry(pr.offp + mp + 1u + lut_slot(xp << pr.nbp, pr.nbp));
 				const bool fp = ep1[0] == pk || ep2[0] == pk;
 				const u32 pv = ep1[0] == pk ? ep1[1] : ep2[1];
 				pfirst = (int)(pv & 0xffffu); plast = (int)(pv >> 16);
@@ -1483,11 +1516,11 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				lut_pack(c, A, B);
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
-				const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);     // table 2 takes the next nb bits
-				const u32x2_t e1 = entry(x & mask);
-				const u32x2_t e2 = entry(mask + 1u + (y & mask));
-				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
-				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
+				const u32 y = lut_side2(x, t.nb);                             // table 2 takes the next nb bits
+				const u32x2_t e1 = entry(lut_slot(x, t.nb));
+				const u32x2_t e2 = entry(mask + 1u + lut_slot(y, t.nb));
+				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ x) & t.tag_mask);
+				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ y) & t.tag_mask);
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
 				tot = (int)(w0 >> 31) + (int)sepbad;
 				found = (m1 == 0u || m2 == 0u) && tot <= t.max_diff;
@@ -1504,14 +1537,13 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? first : -1), make_rsrc(a.first_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? last : -1), make_rsrc(a.last_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 			}
-			if (active && code >= 0) atomicAdd(&hist[code], 1u);           // S + 3 <= kMaxLdsHist: the histogram is always in LDS
+			if (active && code != kAssignNone) atomicAdd(&hist[code >= 0 ? code : S + 2], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
-			n_ident += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code >= 0));
-			n_ambig += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code == kAssignAmbiguous));
 			if (!DIRECT) wave_lds_fence();
 		}
 	}
-	const WaveCounts wc = {n_total, n_ident, n_ambig};
+	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
+	const WaveCounts wc = {n_total, 0u, 0u};
 	// a few hundred workgroups end together, and an addition to an address that others add to takes about 10 ns: 512 x 19
 	// of them into two lines were 4.5 of cfg 3's 31 us at 10 M reads.  When the counters are the ctx's they go to one of
 	// sixteen copies with a line per counter (folded before anything reads them), else to the caller's vector as it is
@@ -1569,7 +1601,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
 		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)slot * 2);
 	};
-	u32 n_total = 0, n_ident = 0, n_ambig = 0;
+	u32 n_total = 0;
 	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
@@ -1597,11 +1629,11 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				lut_pack(c, A, B);
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
-				const u32 y = __builtin_amdgcn_alignbit(x, x, (u32)t.nb);
-				const u32x2_t e1 = entry(x & mask);
-				const u32x2_t e2 = entry(mask + 1u + (y & mask));
-				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ (x >> t.nb)) & t.tag_mask);
-				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ (y >> t.nb)) & t.tag_mask);
+				const u32 y = lut_side2(x, t.nb);
+				const u32x2_t e1 = entry(lut_slot(x, t.nb));
+				const u32x2_t e2 = entry(mask + 1u + lut_slot(y, t.nb));
+				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ x) & t.tag_mask);
+				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ y) & t.tag_mask);
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
 				tot[r] = (int)(w0 >> 31);
 				found[r] = (m1 == 0u || m2 == 0u) && tot[r] <= t.max_diff;
@@ -1611,9 +1643,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				first[r] = last[r] = idx;
 				if (DETAIL && found[r] && amb) { first[r] = t.amb[2 * idx]; last[r] = t.amb[2 * idx + 1]; }
 				const bool active = 2 * lane + r < rows;
-				if (active && code[r] >= 0) atomicAdd(&hist[code[r]], 1u);
-				n_ident += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code[r] >= 0));
-				n_ambig += (u32)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active && code[r] == kAssignAmbiguous));
+				if (active && code[r] != kAssignNone) atomicAdd(&hist[code[r] >= 0 ? code[r] : S + 2], 1u);
 			}
 			n_total += (u32)rows;
 			u32x2_t cv;
@@ -1631,7 +1661,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 			}
 		}
 	}
-	const WaveCounts wc = {n_total, n_ident, n_ambig};
+	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
+	const WaveCounts wc = {n_total, 0u, 0u};
 	if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
 	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
@@ -1905,7 +1936,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		} else {
 			e = plan_and_launch(reinterpret_cast<const void *>(demux_tile_kernel), b, b.bc_stride, true, 4, n_cu, st);
 		}
-		if (e == hipSuccess && !(by_table && bb.counts_wide)) e = launch_counts_fold(bb, st);      // (the wide counters are folded when somebody reads them)
+		if (e == hipSuccess && !(by_table && bb.counts_wide)) e = launch_counts_fold(bb, by_table, st);      // (the wide counters are folded when somebody reads them)
 		if (e != hipSuccess) return e;
 	}
 	if (!any_mate) return hipSuccess;

@@ -11,7 +11,6 @@ namespace sk {
 
 namespace {
 inline bool is_wildcard(uint8_t b) { return b == 'N' || b == 'U'; }      // src/fasta_demultiplex.rs:273
-inline uint32_t rotr32(uint32_t x, int r) { return r ? (x >> r) | (x << (32 - r)) : x; }
 
 struct Key { uint8_t cls[kLutMaxLen]; uint32_t A, B; };
 
@@ -23,15 +22,14 @@ void pack_classes(const uint8_t *cls, uint32_t &A, uint32_t &B)
 }
 }  // namespace
 
-// two-choice cuckoo placement of n keys whose mixed word under seed sd is xof(q, sd): table 1 is indexed by the low nb bits,
-// table 2 by the next nb; at most 42 % full, nb in [nb_min, nb_max].  where[slot] = key or -1.
+// two-choice cuckoo placement of n keys whose mixed word under seed sd is xof(q, sd): table 1 is indexed by the top nb bits,
+// table 2 by the next nb (lut_slot, lut_side2); at most 42 % full, nb in [nb_min, nb_max].  where[slot] = key or -1.
 template <typename XOf> bool cuckoo_place(size_t n, int nb_min, int nb_max, XOf xof, int &nb_out, uint32_t &seed_out, std::vector<int> &where)
 {
 	int nb = nb_min;
 	while (nb < nb_max && ((size_t)1 << nb) * 84 < n * 100) nb++;
 	for (; nb <= nb_max; nb++) {
 		const size_t nslots = (size_t)1 << nb;
-		const uint32_t mask = (uint32_t)(nslots - 1);
 		for (uint32_t tr = 1; tr <= 32; tr++) {
 			const uint32_t sd = tr * 0x9E3779B9u;
 			where.assign(2 * nslots, -1);
@@ -40,7 +38,7 @@ template <typename XOf> bool cuckoo_place(size_t n, int nb_min, int nb_max, XOf 
 				int cur = (int)q, side = 0, kicks = 0;
 				for (;;) {
 					const uint32_t x = xof((size_t)cur, sd);
-					const size_t at = side == 0 ? (x & mask) : nslots + (rotr32(x, nb) & mask);
+					const size_t at = side == 0 ? lut_slot(x, nb) : nslots + lut_slot(lut_side2(x, nb), nb);
 					std::swap(cur, where[at]);
 					if (cur < 0) break;
 					side ^= 1;                                                  // the evicted key goes to its slot in the other table
@@ -335,7 +333,7 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 		if (where[i] < 0) { e[0] = kLutFree; e[1] = 0; continue; }
 		const size_t q = (size_t)where[i];
 		const uint32_t x = lut_mix(keys[q].A, keys[q].B, seed);
-		const uint32_t tag = (i < nslots ? x : rotr32(x, nb)) >> nb;
+		const uint32_t tag = (i < nslots ? x : lut_side2(x, nb)) & (uint32_t)(((uint64_t)1 << (32 - nb)) - 1);
 		const bool ambiguous = dec[q].first != dec[q].last;
 		e[0] = keys[q].B | ((uint32_t)dec[q].diff << 31);
 		e[1] = tag | ((uint32_t)idx[q] << idx_shift) | (ambiguous ? 0x80000000u : 0u);

@@ -17,9 +17,9 @@
 // Table.  Two-choice cuckoo, one 8-byte entry per slot, two tables of 2^nb slots.  (A, B) -> (X, B) with
 // X = mix(A ^ f(B) ^ seed) is a bijection (f any function, mix invertible), so an entry does not hold the key: the
 // slot index is nb bits of X, the entry keeps the other 32 - nb bits of X and B — equality of those IS equality of the
-// key (quotienting).  Table 1 is indexed by the low nb bits of X, table 2 by the next nb bits (X rotated right by nb).
+// key (quotienting).  Table 1 is indexed by the top nb bits of X, table 2 by the nb bits below them (X rotated left by nb).
 //     w0 = B (31 bits, bit 7 of every byte is never set) | lowest_diff << 31
-//     w1 = tag (32 - nb bits of X) | idx << idx_shift | ambiguous << 31
+//     w1 = tag (the low 32 - nb bits of X, or of X rotated) | idx << idx_shift | ambiguous << 31
 // idx = the sample (first == last), or for an ambiguous key the index of its (first, last) pair in a side list: 7 bits for
 // sheets of at most 128 samples (idx_shift 24, nb >= 8), 10 bits up to kLutMaxSamples (idx_shift 21, nb >= 11).
 // A free slot has w0 = kLutFree (bit 7 set: equals no key).
@@ -90,12 +90,18 @@ SK_HD inline uint32_t lut_mix(uint32_t A, uint32_t B, uint32_t seed)
 {
 	uint32_t t = B + (B << 10);
 	t ^= t >> 6;
-	uint32_t x = A ^ t ^ seed;
-	x ^= x >> 15;                       // every step is invertible: (A, B) -> (x, B) is a bijection
-	x += x << 10; x ^= x >> 6;
-	x += x << 3; x ^= x >> 11;
-	return x;
+	uint32_t x = (A ^ t ^ seed) * 0x85EBCA6Bu;     // odd multipliers and an xor-shift: every step is invertible,
+	x ^= x >> 15;                                  // (A, B) -> (x, B) is a bijection; the TOP bits of x are the best mixed
+	return x * 0x9E3779B1u;
 }
+// Table 1 is indexed by the top nb bits of x, table 2 by the nb bits below them: side 2 looks at x rotated left by nb, and for
+// either side v the slot is v's top nb bits and the tag its low 32 - nb bits (nb in [1, 31]).
+// v_mul_lo_u32 issues at the rate of an add on gfx950 (tools/micro/mulrate_exp.hip), so this mix is 5 instructions where the
+// shift-and-add mix of rounds 2-3 was 9, and the tag compare needs no shift: 6 of the 63 VALU instructions the 8-column
+// lookup spent per row, in a kernel bound by instruction issue.  Tables come out the same size or smaller
+// (40 random sheets of each of 8 shapes; a single multiply without the xor-shift made them 8 x larger).
+SK_HD inline uint32_t lut_side2(uint32_t x, int nb) { return (x << nb) | (x >> (32 - nb)); }
+SK_HD inline uint32_t lut_slot(uint32_t v, int nb) { return v >> (32 - nb); }
 
 // one half's key word: the classes of its (at most 8) columns, dwords 0 and 1 of the half interleaved as in lut_pack
 SK_HD inline uint32_t lut_pack_half(uint32_t c0, uint32_t c1) { return c0 | (c1 << 3); }

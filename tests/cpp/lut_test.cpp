@@ -28,7 +28,6 @@ static uint32_t perm_lookup(uint32_t hi, uint32_t lo, uint32_t sel)       // v_p
 
 struct Result { int assign, diff, first, last; };
 
-static inline uint32_t rotr(uint32_t x, int r) { return r ? (x >> r) | (x << (32 - r)) : x; }
 
 // the factored form (demux_lut_kernel<.., PAIR = true>): each half -> (half id, distance), the pair of ids -> (first, last)
 static Result lookup_pair(const LutHost &h, const uint32_t (&c)[5], uint32_t sepbad)
@@ -37,7 +36,7 @@ static Result lookup_pair(const LutHost &h, const uint32_t (&c)[5], uint32_t sep
 	const sk::LutPairDev &pr = t.pair;
 	auto probe = [&](uint32_t base, int nb, uint32_t key, uint32_t seed, uint32_t &val) {
 		const uint32_t x = sk::lut_mix(key, 0u, seed), m = (1u << nb) - 1u;
-		const uint32_t *e1 = &h.slots[2 * (size_t)(base + (x & m))], *e2 = &h.slots[2 * (size_t)(base + m + 1u + (rotr(x, nb) & m))];
+		const uint32_t *e1 = &h.slots[2 * (size_t)(base + (x >> (32 - nb)))], *e2 = &h.slots[2 * (size_t)(base + m + 1u + ((x >> (32 - 2 * nb)) & m))];
 		if (e1[0] == key && e2[0] == key) { fprintf(stderr, "key in both tables\n"); exit(1); }
 		if (e1[0] == key) { val = e1[1]; return true; }
 		if (e2[0] == key) { val = e2[1]; return true; }
@@ -79,11 +78,11 @@ static Result lookup(const LutHost &h, const uint8_t *obs, int L)
 	sk::lut_pack(c, A, B);
 	A &= t.keepA; B &= t.keepB;
 	const uint32_t x = sk::lut_mix(A, B, t.seed);
-	const uint32_t y = t.nb ? (x >> t.nb) | (x << (32 - t.nb)) : x;
-	const uint32_t *e1 = &h.slots[2 * (size_t)(x & (uint32_t)t.mask)];
-	const uint32_t *e2 = &h.slots[2 * ((size_t)t.mask + 1 + (y & (uint32_t)t.mask))];
+	const uint32_t y = (x << t.nb) | (x >> (32 - t.nb));          // table 2: the nb bits below table 1's
+	const uint32_t *e1 = &h.slots[2 * (size_t)(x >> (32 - t.nb))];
+	const uint32_t *e2 = &h.slots[2 * ((size_t)t.mask + 1 + (y >> (32 - t.nb)))];
 	auto hit = [&](const uint32_t *e, uint32_t tag) { return (((e[0] ^ B) & 0x7fffffffu) | ((e[1] ^ tag) & t.tag_mask)) == 0; };
-	const bool h1 = hit(e1, x >> t.nb), h2 = hit(e2, y >> t.nb);
+	const bool h1 = hit(e1, x), h2 = hit(e2, y);
 	if (h1 && h2) { fprintf(stderr, "key in both tables\n"); exit(1); }
 	Result r = {-1, 255, -1, -1};
 	if (!h1 && !h2) return r;
