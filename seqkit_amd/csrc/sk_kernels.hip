@@ -1383,7 +1383,6 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int bstride = a.bc_stride;
 	const int voff = lane * 16;
 	const int img = (kTileRows * bstride + 15) & ~15;
-	const u32 mask = (u32)t.mask;
 	u32 raw[2][W];
 	u32x4 v0[2], v1[2];
 	// tiles are counted in 32 bits (launch_tile_pass checks); a tile past the last clips to nothing (zero-record descriptors)
@@ -1434,6 +1433,20 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
 		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)slot * 2);
 	};
+	const int ltab_off2 = ltab_off + (t.mask + 1) * 8;           // table 2 behind table 1: its base is a constant, not an add per row
+	auto entry2 = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off2 + (int)slot * 8);
+		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)(t.mask + 1) * 2 + (size_t)slot * 2);
+	};
+	auto entry_w1 = [&](u32 slot) {                              // the second word alone: all a key without B needs (sk_lut.h)
+		if (LDSTAB) return *reinterpret_cast<const u32 *>(sk_smem + ltab_off + 4 + (int)slot * 8);
+		return t.tab[(size_t)slot * 2 + 1];
+	};
+	auto entry2_w1 = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32 *>(sk_smem + ltab_off2 + 4 + (int)slot * 8);
+		return t.tab[(size_t)(t.mask + 1) * 2 + (size_t)slot * 2 + 1];
+	};
+	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
 	// where the lane's row lies in the image does not depend on the tile
 	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;
 	const u32 *x1 = reinterpret_cast<const u32 *>(tile + (rs & ~3)), *x2 = reinterpret_cast<const u32 *>(tile + (rs2 & ~3));
@@ -1487,7 +1500,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				c[w] = (m & t.other) | (~m & sel);
 			}
 			bool found, amb;
-			int tot, idx, pfirst = 0, plast = 0;
+			int tot = 0, idx, pfirst = 0, plast = 0;
 			if constexpr (PAIR) {
 				// each half on its own: its word -> (half id, distance); then the pair of ids -> (first, last) sample.  All three
 				// tables are two-choice cuckoo tables of 8-byte entries that hold their key whole.
@@ -1517,14 +1530,20 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
 				const u32 y = lut_side2(x, t.nb);                             // table 2 takes the next nb bits
-				const u32x2_t e1 = entry(lut_slot(x, t.nb));
-				const u32x2_t e2 = entry(mask + 1u + lut_slot(y, t.nb));
-				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ x) & t.tag_mask);
-				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ y) & t.tag_mask);
+				// at most 8 columns and no separator: B is zero for every key, and the tag compare alone decides (a free slot's
+				// tag matches no key of its slot); the first word is fetched only for the distance SK_DETAIL wants
+				constexpr bool kNoB = W2 == 0 && W1 <= 2;
+				u32x2_t e1, e2;
+				if (kNoB && !DETAIL) { e1[0] = e2[0] = 0u; e1[1] = entry_w1(lut_slot(x, t.nb)); e2[1] = entry2_w1(lut_slot(y, t.nb)); }
+				else { e1 = entry(lut_slot(x, t.nb)); e2 = entry2(lut_slot(y, t.nb)); }
+				const u32 m1 = (kNoB ? 0u : ((e1[0] ^ B) & 0x7fffffffu)) | ((e1[1] ^ x) & t.tag_mask);
+				const u32 m2 = (kNoB ? 0u : ((e2[0] ^ B) & 0x7fffffffu)) | ((e2[1] ^ y) & t.tag_mask);
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
-				tot = (int)(w0 >> 31) + (int)sepbad;
-				found = (m1 == 0u || m2 == 0u) && tot <= t.max_diff;
-				idx = (int)((w1 >> t.idx_shift) & t.idx_mask);
+				found = m1 == 0u || m2 == 0u;
+				// the table holds no key beyond max_diff: only a differing separator can push a hit over it
+				if (W2 > 0) { tot = (int)(w0 >> 31) + (int)sepbad; found = found && tot <= t.max_diff; }
+				else if (DETAIL) tot = (int)(w0 >> 31);
+				idx = (int)__builtin_amdgcn_ubfe(w1, (u32)t.idx_shift, idx_bits);
 				amb = (int)w1 < 0;
 			}
 			const int code = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
@@ -1537,7 +1556,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? first : -1), make_rsrc(a.first_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? last : -1), make_rsrc(a.last_idx, ro * 2, rows * 2), lane * 2, 0, 0);
 			}
-			if (active && code != kAssignNone) atomicAdd(&hist[code >= 0 ? code : S + 2], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
+			if (active && found) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
 			if (!DIRECT) wave_lds_fence();
 		}
@@ -1566,7 +1585,6 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	const LutDev &t = a.table.nbr;
 	const int S = a.table.S;
 	const int64_t ntiles = (a.n + kRows - 1) / kRows;
-	const u32 mask = (u32)t.mask;
 	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kRows);
 	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kRows : (ti == nt32 - 1 ? last_rows : 0); };
 	u32x4 raw[2];
@@ -1601,6 +1619,20 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off + (int)slot * 8);
 		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)slot * 2);
 	};
+	const int ltab_off2 = ltab_off + (t.mask + 1) * 8;           // table 2 behind table 1: its base is a constant, not an add per row
+	auto entry2 = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32x2_t *>(sk_smem + ltab_off2 + (int)slot * 8);
+		return *reinterpret_cast<const u32x2_t *>(t.tab + (size_t)(t.mask + 1) * 2 + (size_t)slot * 2);
+	};
+	auto entry_w1 = [&](u32 slot) {                              // the second word alone: all a key without B needs (sk_lut.h)
+		if (LDSTAB) return *reinterpret_cast<const u32 *>(sk_smem + ltab_off + 4 + (int)slot * 8);
+		return t.tab[(size_t)slot * 2 + 1];
+	};
+	auto entry2_w1 = [&](u32 slot) {
+		if (LDSTAB) return *reinterpret_cast<const u32 *>(sk_smem + ltab_off2 + 4 + (int)slot * 8);
+		return t.tab[(size_t)(t.mask + 1) * 2 + (size_t)slot * 2 + 1];
+	};
+	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
 	u32 n_total = 0;
 	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
@@ -1630,20 +1662,22 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
 				const u32 y = lut_side2(x, t.nb);
-				const u32x2_t e1 = entry(lut_slot(x, t.nb));
-				const u32x2_t e2 = entry(mask + 1u + lut_slot(y, t.nb));
-				const u32 m1 = ((e1[0] ^ B) & 0x7fffffffu) | ((e1[1] ^ x) & t.tag_mask);
-				const u32 m2 = ((e2[0] ^ B) & 0x7fffffffu) | ((e2[1] ^ y) & t.tag_mask);
+				// 8 columns: B is zero for every key and the tag compare alone decides (a free slot's tag matches no key of its
+				// slot, sk_lut.h); the first word is fetched only for the distance SK_DETAIL wants
+				u32x2_t e1, e2;
+				if (!DETAIL) { e1[0] = e2[0] = 0u; e1[1] = entry_w1(lut_slot(x, t.nb)); e2[1] = entry2_w1(lut_slot(y, t.nb)); }
+				else { e1 = entry(lut_slot(x, t.nb)); e2 = entry2(lut_slot(y, t.nb)); }
+				const u32 m1 = (e1[1] ^ x) & t.tag_mask, m2 = (e2[1] ^ y) & t.tag_mask;
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
-				tot[r] = (int)(w0 >> 31);
-				found[r] = (m1 == 0u || m2 == 0u) && tot[r] <= t.max_diff;
-				const int idx = (int)((w1 >> t.idx_shift) & t.idx_mask);
+				tot[r] = (int)(w0 >> 31);                         // (the table holds no key beyond max_diff, and these rows have no separator)
+				found[r] = m1 == 0u || m2 == 0u;
+				const int idx = (int)__builtin_amdgcn_ubfe(w1, (u32)t.idx_shift, idx_bits);
 				const bool amb = (int)w1 < 0;
 				code[r] = found[r] ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
 				first[r] = last[r] = idx;
 				if (DETAIL && found[r] && amb) { first[r] = t.amb[2 * idx]; last[r] = t.amb[2 * idx + 1]; }
 				const bool active = 2 * lane + r < rows;
-				if (active && code[r] != kAssignNone) atomicAdd(&hist[code[r] >= 0 ? code[r] : S + 2], 1u);
+				if (active && found[r]) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);
 			}
 			n_total += (u32)rows;
 			u32x2_t cv;

@@ -319,21 +319,24 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 			idx[q] = it->second;
 		}
 	}
-	// two-choice cuckoo, at most 42 % full; the tag (32 - nb bits) must leave room for idx and the flag
+	// two-choice cuckoo, at most 42 % full; the tag (33 - nb bits) must leave room for idx and the flag
 	int nb = 0;
 	uint32_t seed = 0;
 	std::vector<int> where;
 	auto xof = [&](size_t q, uint32_t sd) { return lut_mix(keys[q].A, keys[q].B, sd); };
-	if (!cuckoo_place(keys.size(), idx_bits + 1, 18, xof, nb, seed, where)) return false;
+	if (!cuckoo_place(keys.size(), idx_bits + 2, 18, xof, nb, seed, where)) return false;
 	const size_t nslots = (size_t)1 << nb;
 	const int idx_shift = 31 - idx_bits;
 	out.slots.assign(2 * nslots * 2, 0u);
 	for (size_t i = 0; i < 2 * nslots; i++) {
 		uint32_t *e = &out.slots[2 * i];
-		if (where[i] < 0) { e[0] = kLutFree; e[1] = 0; continue; }
+		// the tag is one bit wider than what the slot index leaves: its top bit is the slot's lowest bit, so a free slot holds
+		// the tag no key of this slot can have and the kernels need no "is it free" test beside the tag compare
+		const uint32_t tag_mask = (uint32_t)(((uint64_t)1 << (33 - nb)) - 1);
+		if (where[i] < 0) { e[0] = kLutFree; e[1] = (uint32_t)(~i & 1u) << (32 - nb); continue; }
 		const size_t q = (size_t)where[i];
 		const uint32_t x = lut_mix(keys[q].A, keys[q].B, seed);
-		const uint32_t tag = (i < nslots ? x : lut_side2(x, nb)) & (uint32_t)(((uint64_t)1 << (32 - nb)) - 1);
+		const uint32_t tag = (i < nslots ? x : lut_side2(x, nb)) & tag_mask;
 		const bool ambiguous = dec[q].first != dec[q].last;
 		e[0] = keys[q].B | ((uint32_t)dec[q].diff << 31);
 		e[1] = tag | ((uint32_t)idx[q] << idx_shift) | (ambiguous ? 0x80000000u : 0u);
@@ -343,7 +346,7 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 	LutDev &d = out.dev;
 	fill_common(shp, sheet, d);
 	d.nb = nb; d.mask = (int)(nslots - 1);
-	d.seed = seed; d.tag_mask = (uint32_t)(((uint64_t)1 << (32 - nb)) - 1);
+	d.seed = seed; d.tag_mask = (uint32_t)(((uint64_t)1 << (33 - nb)) - 1);
 	d.idx_shift = idx_shift;
 	d.idx_mask = (1u << idx_bits) - 1u;
 	return true;

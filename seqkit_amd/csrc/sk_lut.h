@@ -19,9 +19,12 @@
 // slot index is nb bits of X, the entry keeps the other 32 - nb bits of X and B — equality of those IS equality of the
 // key (quotienting).  Table 1 is indexed by the top nb bits of X, table 2 by the nb bits below them (X rotated left by nb).
 //     w0 = B (31 bits, bit 7 of every byte is never set) | lowest_diff << 31
-//     w1 = tag (the low 32 - nb bits of X, or of X rotated) | idx << idx_shift | ambiguous << 31
+//     w1 = tag (the low 33 - nb bits of X, or of X rotated) | idx << idx_shift | ambiguous << 31
+// The tag is one bit wider than quotienting needs: its top bit repeats the slot's lowest bit, and a FREE slot holds the other
+// value there (w1 = (~slot & 1) << (32 - nb), w0 = kLutFree) — no key that hashes to the slot can match it, so a key whose B is
+// always zero (at most 8 columns, no separator) is looked up in w1 alone.
 // idx = the sample (first == last), or for an ambiguous key the index of its (first, last) pair in a side list: 7 bits for
-// sheets of at most 128 samples (idx_shift 24, nb >= 8), 10 bits up to kLutMaxSamples (idx_shift 21, nb >= 11).
+// sheets of at most 128 samples (idx_shift 24, nb >= 9), 10 bits up to kLutMaxSamples (idx_shift 21, nb >= 12).
 // A free slot has w0 = kLutFree (bit 7 set: equals no key).
 //
 // The factored form (LutDev::pair): 384 dual-index samples x (16 x 4 + 1) keys are 25 k entries — 512 KiB, served from L2 at
@@ -47,7 +50,7 @@ namespace sk {
 
 constexpr int kLutMaxLen = 20;           // columns the packing holds
 constexpr int kLutMaxSamples = 1021;     // idx is 7 or 10 bits; S + 3 counters fit the kernels' LDS histogram (kMaxLdsHist)
-constexpr int kLutMinBits = 8;           // tag + idx + flag must fit 32 bits: nb >= idx bits + 1
+constexpr int kLutMinBits = 9;           // tag + idx + flag must fit 32 bits: nb >= idx bits + 2
 constexpr uint32_t kLutFree = 0x00000080u;
 constexpr uint32_t kLutPairFree = 0xFFFFFFFFu;
 
@@ -66,7 +69,7 @@ struct LutDev {
 	const int16_t *amb;        // (first, last) pairs of the ambiguous keys
 	int W1, W2;                // key dwords: the row's first W1 dwords, and (with a separator) W2 dwords from the byte after it
 	int nb, mask;              // slot bits, slots per table - 1
-	uint32_t seed, tag_mask;   // tag_mask = (1 << (32 - nb)) - 1
+	uint32_t seed, tag_mask;   // tag_mask = (1 << (33 - nb)) - 1
 	int sh;                    // byte -> letter index: (b >> sh) & 7
 	uint32_t tab_lo, tab_hi;   // the letters by index (v_perm table); an unused index holds a byte with another index
 	uint32_t other;            // the class of "a byte the sheet never uses", in every byte
@@ -100,7 +103,14 @@ SK_HD inline uint32_t lut_mix(uint32_t A, uint32_t B, uint32_t seed)
 // shift-and-add mix of rounds 2-3 was 9, and the tag compare needs no shift: 6 of the 63 VALU instructions the 8-column
 // lookup spent per row, in a kernel bound by instruction issue.  Tables come out the same size or smaller
 // (40 random sheets of each of 8 shapes; a single multiply without the xor-shift made them 8 x larger).
-SK_HD inline uint32_t lut_side2(uint32_t x, int nb) { return (x << nb) | (x >> (32 - nb)); }
+SK_HD inline uint32_t lut_side2(uint32_t x, int nb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_alignbit(x, x, (uint32_t)(32 - nb));      // one instruction where shift, shift, or were three
+#else
+	return (x << nb) | (x >> (32 - nb));
+#endif
+}
 SK_HD inline uint32_t lut_slot(uint32_t v, int nb) { return v >> (32 - nb); }
 
 // one half's key word: the classes of its (at most 8) columns, dwords 0 and 1 of the half interleaved as in lut_pack
