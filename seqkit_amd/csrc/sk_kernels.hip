@@ -1345,6 +1345,19 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
+// The class of each of a dword's four bytes: the index of the sheet letter the byte equals, `other` for a byte the sheet never
+// uses (sk_lut.h).  8 instructions.  The byte -> mask step leans on v_perm_b32's selector rule (12 -> 0x00, 13 and above ->
+// 0xff): with x = byte ^ its candidate letter, (x & 0x7f) + 12 is 12 for x in {0, 0x80} and 13 ... 0x8b otherwise (no carry
+// leaves the byte); or-ing x back in lifts 0x80 to 0x8c; the selector 12 is then "equal" and everything else is not.
+__device__ __forceinline__ u32 lut_classes(u32 dw, const LutDev &t)
+{
+	const u32 sel = (dw >> t.sh) & 0x07070707u;
+	const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
+	const u32 df = dw ^ letter;                                        // zero byte <=> the observed byte is that letter
+	const u32 m = __builtin_amdgcn_perm(0u, 0u, ((df & kLo7) + 0x0c0c0c0cu) | df);     // 0xff in every byte that is not
+	return (m & t.other) | (~m & sel);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // D1+D2+D3 by table lookup (sk_lut.h): demultiplex alone.  With max_diff <= 1 the barcodes that get a sample or the
 // ambiguity verdict are the sheet rows and their one-substitution neighbours — 96 x (16 x 4 + 1) = 6 240 keys for the 96
@@ -1492,12 +1505,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			u32 c[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
 			for (int w = 0; w < W; w++) {
-				const u32 sel = (d[w] >> t.sh) & 0x07070707u;
-				const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
-				const u32 df = d[w] ^ letter;                              // zero byte <=> the observed byte is that letter
-				const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;        // 0x80 in every byte that is not
-				const u32 m = nz - (nz >> 7);                              // 0x7f there
-				c[w] = (m & t.other) | (~m & sel);
+				c[w] = lut_classes(d[w], t);
 			}
 			bool found, amb;
 			int tot = 0, idx, pfirst = 0, plast = 0;
@@ -1649,13 +1657,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				u32 c[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
 				for (int w = 0; w < 2; w++) {
-					const u32 dw = d[2 * r + w];
-					const u32 sel = (dw >> t.sh) & 0x07070707u;
-					const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
-					const u32 df = dw ^ letter;
-					const u32 nz = (((df & kLo7) + kLo7) | df) & kHi1;
-					const u32 m = nz - (nz >> 7);
-					c[w] = (m & t.other) | (~m & sel);
+					c[w] = lut_classes(d[2 * r + w], t);
 				}
 				u32 A, B;
 				lut_pack(c, A, B);
