@@ -304,6 +304,44 @@ def check_demux_decision_only(ctx, oracle, table, bc, max_diff=1):
     assert np.array_equal(ctx.counts(), e_counts)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["16 x 8", "96 x 8+8", "200 x 8+8"])
+@pytest.mark.parametrize("n", [3000, 700_000])
+@pytest.mark.parametrize("table_in", ["LDS", "vector cache"])
+def test_demux_by_table_into_the_callers_counters(ctx, oracle, monkeypatch, shape, n, table_in):
+    """The lookup kernels leave `identified` to whoever sums the histogram: the fold kernel behind a launch of thousands of
+    workgroups, the workgroup itself behind a small one that adds to the caller's vector directly (sk_kernels.hip,
+    lut_identified_from_hist).  Both, twice into the same vector, against the oracle's counters.  (A table in LDS means one
+    workgroup of 16 waves per CU: only the form that reads its table through the vector cache launches thousands.)"""
+    from seqkit_amd import synth
+    if table_in == "vector cache":
+        monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")
+    S = int(shape.split(" x ")[0])
+    dual = "+" in shape
+    table = synth.make_sheet(S, 8, dual=dual, seed=S)
+    bc, _ = synth.observe_barcodes(table, n, seed=S + 1, halves=2 if dual else 1)
+    ctx.set_barcodes(table, 1)
+    ctx.counts_reset()
+    zeros = np.zeros(S + 3, dtype=np.uint64)
+    d_bc, d_assign, d_counts = ctx.malloc_device(bc.nbytes), ctx.malloc_device(4 * n), ctx.malloc_device(zeros.nbytes)
+    try:
+        ctx.copy_h2d(d_bc, bc)
+        ctx.copy_h2d(d_counts, zeros)
+        for _ in range(2):
+            ctx.demux_assign_dev(d_bc, bc.shape[1], n, d_assign, counts=d_counts)
+        ctx.sync()
+        assign, got = np.empty(n, dtype=np.int32), np.empty(S + 3, dtype=np.uint64)
+        ctx.copy_d2h(assign, d_assign)
+        ctx.copy_d2h(got, d_counts)
+    finally:
+        for p in (d_bc, d_assign, d_counts):
+            ctx.free_device(p)
+    e_assign, _, _, _, e_counts = oracle.demux_batch(table, bc, 1)
+    assert np.array_equal(assign, e_assign)
+    assert np.array_equal(got, 2 * e_counts.astype(np.uint64)), (got[S:], 2 * e_counts[S:])
+    assert ctx.counts().sum() == 0                      # nothing went to the ctx's own counters
+
+
 def check_demux_matched(ctx, oracle, table, bc, max_diff=1):
     """SK_DETAIL_MATCHED: assign and counters of every row, lowest_diff / first / last of the rows that matched something
     (the only rows the reference reads them for: src/fasta_demultiplex.rs:184-188)."""
