@@ -94,7 +94,8 @@ int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n
  *                     -1 when the lookup table answers).  A demultiplex-alone call with max_diff <= 1 is then ONE table
  *                     lookup per read — the sheet's rows and their one-substitution neighbours, decided on the host with
  *                     the same loop — instead of S x L compares, for sheets of <= 1021 samples, <= 20 columns, <= 7
- *                     letters (wildcards in whole columns only); a dual-index sheet whose table would not fit a
+ *                     letters (a row with `N` / `U` where other rows hold a letter is entered once per class of that
+ *                     column: a few such columns per row, up to 220 000 keys in all); a dual-index sheet whose table would not fit a
  *                     workgroup's LDS is looked up half by half when that is exact (its half-barcodes at least 3
  *                     apart); other sheets run the matchers and fill every row.  The decision-only form (all three
  *                     pointers NULL) takes the table under either mode, and so does the barcode phase of a fused call

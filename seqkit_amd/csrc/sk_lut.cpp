@@ -22,6 +22,8 @@ void pack_classes(const uint8_t *cls, uint32_t &A, uint32_t &B)
 }
 }  // namespace
 
+constexpr size_t kMaxKeys = 220000;      // what two tables of 2^18 slots hold at 42 %
+
 // two-choice cuckoo placement of n keys whose mixed word under seed sd is xof(q, sd): table 1 is indexed by the top nb bits,
 // table 2 by the next nb (lut_slot, lut_side2); at most 42 % full, nb in [nb_min, nb_max].  where[slot] = key or -1.
 template <typename XOf> bool cuckoo_place(size_t n, int nb_min, int nb_max, XOf xof, int &nb_out, uint32_t &seed_out, std::vector<int> &where)
@@ -187,15 +189,17 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 	if (!sheet || S < 1 || S > kLutMaxSamples || L < 1 || L > kLutMaxLen || max_diff < 0 || max_diff > 1) return false;
 	SheetShape shp;
 	shp.S = S; shp.L = L; shp.max_diff = max_diff;
-	// columns: counting (no row has a wildcard there) or ignored (every row has one); a wildcard in some rows only would
-	// make the key depend on the row
+	// columns: counting (part of the key) or ignored (every row has a wildcard there).  A row that has a wildcard in a counting
+	// column matches any byte there: it is enumerated once per class of that column (below), so a few such columns per row
+	// are affordable and many are not (the bound further down refuses the sheet then)
 	bool (&counting)[kLutMaxLen] = shp.counting;
 	for (int k = 0; k < kLutMaxLen; k++) counting[k] = false;
+	bool mixed = false;
 	for (int k = 0; k < L; k++) {
 		int nw = 0;
 		for (int s = 0; s < S; s++) nw += is_wildcard(sheet[(size_t)s * L + k]) ? 1 : 0;
-		if (nw != 0 && nw != S) return false;
-		counting[k] = nw == 0;
+		counting[k] = nw != S;
+		mixed = mixed || (nw != 0 && nw != S);
 	}
 	// the separator: a counting column with one letter in every row, a letter no other counting column uses, that cuts the
 	// row into two segments of equally many dwords (1 + 1 or 2 + 2: `i7+i5`); the kernel reads the segments on their own,
@@ -224,7 +228,7 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 		if (!counting[k] || k == sep) continue;
 		for (int s = 0; s < S; s++) {
 			const uint8_t b = sheet[(size_t)s * L + k];
-			if (!is_letter[b]) { is_letter[b] = true; letters.push_back(b); }
+			if (!is_wildcard(b) && !is_letter[b]) { is_letter[b] = true; letters.push_back(b); }
 		}
 	}
 	if (letters.size() > 7) return false;
@@ -257,16 +261,26 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 	rows.resize((size_t)S);
 	int n_key_cols = 0;
 	for (int k = 0; k < L; k++) n_key_cols += (counting[k] && k != sep) ? 1 : 0;
+	std::vector<std::vector<int>> wild((size_t)S);                              // per row: the key positions where it has a wildcard
+	size_t bound = 0;                                                           // keys the enumeration below will produce, at most
 	for (int s = 0; s < S; s++) {
 		memset(&rows[(size_t)s], 0, sizeof(Key));
-		for (int k = 0; k < L; k++)
-			if (counting[k] && k != sep) rows[(size_t)s].cls[key_pos(k)] = (uint8_t)index_of(sheet[(size_t)s * L + k]);
+		for (int k = 0; k < L; k++) {
+			if (!counting[k] || k == sep) continue;
+			const uint8_t b = sheet[(size_t)s * L + k];
+			if (is_wildcard(b)) wild[(size_t)s].push_back(key_pos(k));
+			else rows[(size_t)s].cls[key_pos(k)] = (uint8_t)index_of(b);
+		}
 		pack_classes(rows[(size_t)s].cls, rows[(size_t)s].A, rows[(size_t)s].B);
+		size_t variants = 1;
+		for (size_t j = 0; j < wild[(size_t)s].size() && variants <= kMaxKeys; j++) variants *= alts.size();
+		const size_t fixed = (size_t)n_key_cols - wild[(size_t)s].size();
+		bound += variants * (1 + (max_diff ? fixed * (alts.size() - 1) : 0));
+		if (bound > kMaxKeys) return false;
 	}
 	// A full-key table that will not fit the workgroup's LDS: a sheet with a separator is looked up half by half when that is
-	// exact and those tables fit
-	{
-		const size_t bound = (size_t)S * (1 + (max_diff ? (size_t)n_key_cols * (alts.size() - 1) : 0));
+	// exact and those tables fit (its exactness argument is about rows without wildcards in key columns)
+	if (!mixed) {
 		int nbe = kLutMinBits;
 		while (((size_t)1 << nbe) * 84 < bound * 100) nbe++;
 		if (lds_budget > 0 && ((size_t)16 << nbe) > (size_t)lds_budget && build_pair(shp, sheet, out, lds_budget)) return true;
@@ -289,16 +303,26 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 			else if (d == e.diff) e.last = s;
 		};
 		for (int s = 0; s < S; s++) {
-			add(rows[(size_t)s], s, 0);
-			if (max_diff < 1) continue;
-			for (int k = 0; k < L; k++) {
-				if (!counting[k] || k == sep) continue;
-				Key v = rows[(size_t)s];
-				for (uint8_t alt : alts) {
-					if (alt == rows[(size_t)s].cls[key_pos(k)]) continue;
-					v.cls[key_pos(k)] = alt;
-					add(v, s, 1);
+			const std::vector<int> &ws = wild[(size_t)s];
+			bool is_wild[kLutMaxLen] = {false};
+			for (int kp : ws) is_wild[kp] = true;
+			std::vector<size_t> odo(ws.size(), 0);                               // one variant of the row per assignment of classes to its wildcards
+			for (;;) {
+				Key base = rows[(size_t)s];
+				for (size_t j = 0; j < ws.size(); j++) base.cls[ws[j]] = alts[odo[j]];
+				add(base, s, 0);
+				for (int k = 0; k < L && max_diff >= 1; k++) {
+					if (!counting[k] || k == sep || is_wild[key_pos(k)]) continue;
+					Key v = base;
+					for (uint8_t alt : alts) {
+						if (alt == base.cls[key_pos(k)]) continue;
+						v.cls[key_pos(k)] = alt;
+						add(v, s, 1);
+					}
 				}
+				size_t j = 0;
+				while (j < odo.size() && ++odo[j] == alts.size()) odo[j++] = 0;
+				if (j == odo.size()) break;
 			}
 		}
 	}

@@ -5,10 +5,12 @@
 //     key -> (lowest_diff, first argmin, last argmin)
 // in a table small enough for a workgroup's LDS; a read is then: classify its bytes, pack, hash, two probes.
 //
-// Key.  Every byte of a counting column (not a wildcard in the sheet, not the separator) becomes a 3-bit class: the
+// Key.  Every byte of a counting column (not a wildcard in EVERY row of the sheet, not the separator) becomes a 3-bit class: the
 // index of the sheet letter it equals, or `other` (an index no letter has) for any byte the sheet never uses.  The
 // classes of up to 20 columns are packed into two words without a carry or a multiply (lut_pack).  Columns that are a
-// wildcard in EVERY row (UMI columns), the separator and the bytes past L are masked out (keepA / keepB).
+// wildcard in EVERY row (UMI columns), the separator and the bytes past L are masked out (keepA / keepB).  A row that has a
+// wildcard in a counting column matches every byte there (src/fasta_demultiplex.rs:272-273): the host enters it once per
+// class of that column — (letters + 1)^w variants for w such columns, refused beyond kMaxKeys keys in all.
 // A separator is a column that holds the same letter in every row, a letter no other column uses ('+' of `i7+i5`):
 // a mismatch there adds one to the distance of EVERY row, so it is compared on its own and not part of the key — the
 // argmin set does not depend on it, and the table is a quarter smaller.  The two segments beside it are read on their

@@ -438,6 +438,30 @@ def test_demux_by_table_many_samples(ctx, oracle, lut_form, S, dual):
         check_demux_matched(ctx, oracle, np.ascontiguousarray(t2), np.ascontiguousarray(b2))
 
 
+def test_demux_by_table_rows_with_wildcards(ctx, oracle, lut_form):
+    """A sheet row may hold `N` / `U` where other rows hold a letter (src/fasta_demultiplex.rs:272: such a column does not count
+    for THAT row).  The table's builder enumerates the row once per class of the column (sk_lut.cpp), so these sheets take the
+    lookup as well: SURVEY.md Appendix A's pair, and 40 samples with up to two wildcards per row."""
+    table = np.frombuffer(b"ACGTACGTACGTNCGTTTGCAANNNGGATCCACATGCATG", dtype=np.uint8).reshape(5, 8).copy()
+    rng = np.random.default_rng(5)
+    bc, _ = synth.observe_barcodes(np.where(table == ord("N"), ord("A"), table).astype(np.uint8), 60_001, seed=5)
+    bc[::7, 4] = ord("N")
+    bc[::11, 6:] = rng.choice(synth.BASES, size=(bc[::11].shape[0], 2))
+    check_demux_decision_only(ctx, oracle, table, bc)
+    assert check_demux_matched(ctx, oracle, table, bc) > 20_000
+    check_demux_matched(ctx, oracle, table, bc, max_diff=0)
+    table = synth.make_sheet(40, 8, dual=True, seed=40)
+    clean = table.copy()
+    for s in range(0, 40, 3):
+        table[s, rng.integers(0, 8)] = ord("N")
+        if s % 2 == 0:
+            table[s, 9 + rng.integers(0, 8)] = ord("U")
+    bc, _ = synth.observe_barcodes(clean, 80_001, seed=41, halves=2)
+    bc[::13, 2] = ord("N")
+    check_demux_decision_only(ctx, oracle, table, bc)
+    assert check_demux_matched(ctx, oracle, table, bc) > 40_000
+
+
 def test_fused_pass_of_a_large_sheet_takes_the_table(ctx, oracle):
     """384 samples are beyond the tile pass's own matcher (128): the barcode phase of a fused call is then a launch of its own
     and takes the lookup like a demultiplex-alone call — same answers as the oracle's three commands."""
