@@ -1398,6 +1398,15 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int img = (kTileRows * bstride + 15) & ~15;
 	u32 raw[2][W];
 	u32x4 v0[2], v1[2];
+	// GATHER (a sheet with a separator): a lane fetches the dwords its row's two segments lie in straight from memory, at any
+	// alignment — W1 + 1 dwords from the one that holds the row's first byte, W2 + 1 from the one that holds the byte after
+	// the separator.  The image path costs such a tile 2 LDS writes and 5 reads at a 17-byte pitch (8-way bank conflicts):
+	// the LDS pipe was busier than HBM.  The separator itself is one byte of the first window's last two dwords (v_perm_b32).
+	constexpr bool GATHER = !DIRECT && W2 > 0;
+	u32 g1[2][W1 + 1], g2[2][W2 + 1];
+	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;            // where the lane's row lies in a tile does not depend on the tile
+	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
+	const u32 sep_sel = 0x0c0c0c00u | (sh1 + (u32)(t.sep_off - 4 * (W1 - 1)));      // the separator among the 8 bytes of dwords W1 - 1 and W1: 1 ... 7
 	// tiles are counted in 32 bits (launch_tile_pass checks); a tile past the last clips to nothing (zero-record descriptors)
 	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kTileRows);
 	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kTileRows : (ti == nt32 - 1 ? last_rows : 0); };
@@ -1410,6 +1419,15 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				raw[s][0] = v[0]; raw[s][W - 1] = v[1];
 			} else {
 				raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride, 0, 0);
+			}
+		} else if (GATHER) {
+			if constexpr (W1 == 1) {
+				const u32x2_t a1 = __builtin_amdgcn_raw_buffer_load_b64(rb, rs & ~3, 0, 0), a2 = __builtin_amdgcn_raw_buffer_load_b64(rb, rs2 & ~3, 0, 0);
+				g1[s][0] = a1[0]; g1[s][W1] = a1[1]; g2[s][0] = a2[0]; g2[s][W2] = a2[1];
+			} else {
+				typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
+				const u32x3_t a1 = __builtin_amdgcn_raw_buffer_load_b96(rb, rs & ~3, 0, 0), a2 = __builtin_amdgcn_raw_buffer_load_b96(rb, rs2 & ~3, 0, 0);
+				g1[s][0] = a1[0]; g1[s][1] = a1[1]; g1[s][W1] = a1[2]; g2[s][0] = a2[0]; g2[s][1] = a2[1]; g2[s][W2] = a2[2];
 			}
 		} else {
 			v0[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAuxStream);
@@ -1460,10 +1478,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		return t.tab[(size_t)(t.mask + 1) * 2 + (size_t)slot * 2 + 1];
 	};
 	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
-	// where the lane's row lies in the image does not depend on the tile
-	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;
 	const u32 *x1 = reinterpret_cast<const u32 *>(tile + (rs & ~3)), *x2 = reinterpret_cast<const u32 *>(tile + (rs2 & ~3));
-	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
 	u32 n_total = 0;
 	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
@@ -1477,6 +1492,13 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			if (DIRECT) {
 #pragma unroll
 				for (int w = 0; w < W; w++) d[w] = raw[s][w];
+				fetch(ti + 2 * tstep, s);
+			} else if (GATHER) {
+#pragma unroll
+				for (int w = 0; w < W1; w++) d[w] = __builtin_amdgcn_alignbyte(g1[s][w + 1], g1[s][w], sh1);
+#pragma unroll
+				for (int w = 0; w < W2; w++) d[W1 + w] = __builtin_amdgcn_alignbyte(g2[s][w + 1], g2[s][w], sh2);
+				sepbad = __builtin_amdgcn_perm(g1[s][W1], g1[s][W1 - 1], sep_sel) != t.sep_val ? 1u : 0u;
 				fetch(ti + 2 * tstep, s);
 			} else {
 				if (voff < img) *reinterpret_cast<u32x4 *>(tile + voff) = v0[s];           // the image is as long as the tile's rows, not 2 KiB
@@ -1566,7 +1588,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			}
 			if (active && found) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
-			if (!DIRECT) wave_lds_fence();
+			if (!DIRECT && !GATHER) wave_lds_fence();
 		}
 	}
 	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
@@ -1940,7 +1962,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			lp.hist_off = 0;
 			lp.table_bytes = ldstab ? table_bytes : 0;
 			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
-			lp.tile_slot = kLdsPad + (direct ? 0 : (kTileRows * b.bc_stride + 15) & ~15) + kLdsPad;    // rows straight from memory need no image
+			lp.tile_slot = kLdsPad + (direct || t.W2 > 0 ? 0 : (kTileRows * b.bc_stride + 15) & ~15) + kLdsPad;    // rows straight from memory need no image
 			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy; fewer when long rows leave no room for their images
 			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
 			const int lds = lp.tiles_off + nw * lp.tile_slot;
