@@ -1345,6 +1345,22 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
+// N consecutive dwords at a dword-aligned byte offset of a raw buffer (clipped per dword): the widest loads that cover them
+template <int N> __device__ __forceinline__ void gather_dwords(rsrc_t rb, int off, u32 (&d)[N])
+{
+	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+	typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
+	static_assert(N >= 2 && N <= 6, "a key segment of one to five dwords and the dword behind it");
+	if constexpr (N == 2) { const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, 0); d[0] = v[0]; d[1] = v[1]; }
+	else if constexpr (N == 3) { const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rb, off, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+	else {
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
+		d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+		if constexpr (N == 5) d[4] = __builtin_amdgcn_raw_buffer_load_b32(rb, off + 16, 0, 0);
+		if constexpr (N == 6) { const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rb, off + 16, 0, 0); d[4] = w[0]; d[5] = w[1]; }
+	}
+}
+
 // The class of each of a dword's four bytes: the index of the sheet letter the byte equals, `other` for a byte the sheet never
 // uses (sk_lut.h).  8 instructions.  The byte -> mask step leans on v_perm_b32's selector rule (12 -> 0x00, 13 and above ->
 // 0xff): with x = byte ^ its candidate letter, (x & 0x7f) + 12 is 12 for x in {0, 0x80} and 13 ... 0x8b otherwise (no carry
@@ -1388,22 +1404,19 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int lane = threadIdx.x & (kWave - 1);
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int nwave = blockDim.x >> 6;
-	uint8_t *tile = sk_smem + lp.tiles_off + wave * lp.tile_slot + kLdsPad;
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
 	const LutDev &t = a.table.nbr;
 	const int S = a.table.S;
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int bstride = a.bc_stride;
-	const int voff = lane * 16;
-	const int img = (kTileRows * bstride + 15) & ~15;
 	u32 raw[2][W];
-	u32x4 v0[2], v1[2];
-	// GATHER (a sheet with a separator): a lane fetches the dwords its row's two segments lie in straight from memory, at any
-	// alignment — W1 + 1 dwords from the one that holds the row's first byte, W2 + 1 from the one that holds the byte after
-	// the separator.  The image path costs such a tile 2 LDS writes and 5 reads at a 17-byte pitch (8-way bank conflicts):
-	// the LDS pipe was busier than HBM.  The separator itself is one byte of the first window's last two dwords (v_perm_b32).
-	constexpr bool GATHER = !DIRECT && W2 > 0;
-	u32 g1[2][W1 + 1], g2[2][W2 + 1];
+	// GATHER (every shape but DIRECT): a lane fetches the dwords its row's key lies in straight from memory, at any alignment —
+	// W1 + 1 dwords from the one that holds the row's first byte and, with a separator, W2 + 1 from the one that holds the byte
+	// after it.  (Through round 4's first sessions such tiles went through an image in LDS: 2 writes and 5 reads at a 17-byte
+	// pitch per dual-index tile kept the LDS pipe busier than HBM — 42.3 us against 35.8 at 10 M pairs.)  The separator itself is
+	// one byte of the first window's last two dwords (v_perm_b32).
+	constexpr int G2 = W2 > 0 ? W2 + 1 : 2;
+	u32 g1[2][W1 + 1], g2[2][G2];
 	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;            // where the lane's row lies in a tile does not depend on the tile
 	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
 	const u32 sep_sel = 0x0c0c0c00u | (sh1 + (u32)(t.sep_off - 4 * (W1 - 1)));      // the separator among the 8 bytes of dwords W1 - 1 and W1: 1 ... 7
@@ -1420,18 +1433,9 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			} else {
 				raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride, 0, 0);
 			}
-		} else if (GATHER) {
-			if constexpr (W1 == 1) {
-				const u32x2_t a1 = __builtin_amdgcn_raw_buffer_load_b64(rb, rs & ~3, 0, 0), a2 = __builtin_amdgcn_raw_buffer_load_b64(rb, rs2 & ~3, 0, 0);
-				g1[s][0] = a1[0]; g1[s][W1] = a1[1]; g2[s][0] = a2[0]; g2[s][W2] = a2[1];
-			} else {
-				typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
-				const u32x3_t a1 = __builtin_amdgcn_raw_buffer_load_b96(rb, rs & ~3, 0, 0), a2 = __builtin_amdgcn_raw_buffer_load_b96(rb, rs2 & ~3, 0, 0);
-				g1[s][0] = a1[0]; g1[s][1] = a1[1]; g1[s][W1] = a1[2]; g2[s][0] = a2[0]; g2[s][1] = a2[1]; g2[s][W2] = a2[2];
-			}
 		} else {
-			v0[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, 0, kAuxStream);
-			v1[s] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff + 1024, 0, kAuxStream);
+			gather_dwords<W1 + 1>(rb, rs & ~3, g1[s]);
+			if constexpr (W2 > 0) gather_dwords<W2 + 1>(rb, rs2 & ~3, g2[s]);
 		}
 	};
 	const int tstep = (int)gridDim.x * nwave;
@@ -1478,7 +1482,6 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		return t.tab[(size_t)(t.mask + 1) * 2 + (size_t)slot * 2 + 1];
 	};
 	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
-	const u32 *x1 = reinterpret_cast<const u32 *>(tile + (rs & ~3)), *x2 = reinterpret_cast<const u32 *>(tile + (rs2 & ~3));
 	u32 n_total = 0;
 	for (; tb < nt32; tb += 2 * tstep) {
 #pragma unroll
@@ -1493,35 +1496,15 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 #pragma unroll
 				for (int w = 0; w < W; w++) d[w] = raw[s][w];
 				fetch(ti + 2 * tstep, s);
-			} else if (GATHER) {
+			} else {
 #pragma unroll
 				for (int w = 0; w < W1; w++) d[w] = __builtin_amdgcn_alignbyte(g1[s][w + 1], g1[s][w], sh1);
+				if constexpr (W2 > 0) {
 #pragma unroll
-				for (int w = 0; w < W2; w++) d[W1 + w] = __builtin_amdgcn_alignbyte(g2[s][w + 1], g2[s][w], sh2);
-				sepbad = __builtin_amdgcn_perm(g1[s][W1], g1[s][W1 - 1], sep_sel) != t.sep_val ? 1u : 0u;
-				fetch(ti + 2 * tstep, s);
-			} else {
-				if (voff < img) *reinterpret_cast<u32x4 *>(tile + voff) = v0[s];           // the image is as long as the tile's rows, not 2 KiB
-				if (1024 + voff < img) *reinterpret_cast<u32x4 *>(tile + 1024 + voff) = v1[s];
-				fetch(ti + 2 * tstep, s);
-				wave_lds_fence();
-				u32 lo = x1[0];
-#pragma unroll
-				for (int w = 0; w < W1; w++) {
-					const u32 hi = x1[w + 1];
-					d[w] = __builtin_amdgcn_alignbyte(hi, lo, sh1);
-					lo = hi;
+					for (int w = 0; w < W2; w++) d[W1 + w] = __builtin_amdgcn_alignbyte(g2[s][w + 1], g2[s][w], sh2);
+					sepbad = __builtin_amdgcn_perm(g1[s][W1], g1[s][W1 - 1], sep_sel) != t.sep_val ? 1u : 0u;
 				}
-				if (W2 > 0) {
-					lo = x2[0];
-#pragma unroll
-					for (int w = 0; w < W2; w++) {
-						const u32 hi = x2[w + 1];
-						d[W1 + w] = __builtin_amdgcn_alignbyte(hi, lo, sh2);
-						lo = hi;
-					}
-					sepbad = (u32)tile[rs + t.sep_off] != t.sep_val ? 1u : 0u;
-				}
+				fetch(ti + 2 * tstep, s);
 			}
 			// classes: the index of the sheet letter a byte equals, `other` for every byte the sheet never uses
 			u32 c[5] = {0u, 0u, 0u, 0u, 0u};
@@ -1588,7 +1571,6 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			}
 			if (active && found) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
-			if (!DIRECT && !GATHER) wave_lds_fence();
 		}
 	}
 	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
@@ -1962,7 +1944,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			lp.hist_off = 0;
 			lp.table_bytes = ldstab ? table_bytes : 0;
 			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
-			lp.tile_slot = kLdsPad + (direct || t.W2 > 0 ? 0 : (kTileRows * b.bc_stride + 15) & ~15) + kLdsPad;    // rows straight from memory need no image
+			lp.tile_slot = 2 * kLdsPad;                               // rows come straight from memory: no image
 			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy; fewer when long rows leave no room for their images
 			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
 			const int lds = lp.tiles_off + nw * lp.tile_slot;
