@@ -786,6 +786,7 @@ __device__ __forceinline__ void demux_commit(const TileArgs &a, const LdsPlan &l
 // samples' bins, taken by the kernel that folds the counter copies behind the launch (counts_fold_wide_kernel,
 // counts_fold_kernel) — or here, when the workgroup ends, if the launch adds to the caller's vector directly (a barrier and
 // a reduction at the end of every workgroup: 0.7 us of cfg 3's 27 at 10 M rows, which is why the folds do it).
+static_assert(kLutMaxSamples + 3 <= kMaxLdsHist, "a sheet the table serves has its histogram in LDS, and a fold kernel behind every launch that spreads its counters");
 __device__ __forceinline__ void lut_identified_from_hist(int S, u32 *hist, int lane)
 {
 	__syncthreads();
@@ -1384,10 +1385,10 @@ __device__ __forceinline__ u32 lut_classes(u32 dw, const LutDev &t)
 // so the two probes of a read are two ds_read_b64 instead of two trips to L2.  Not found = nothing within max_diff =
 // SK_ASSIGN_NONE (its detail columns then say 255 / -1 / -1: SK_DETAIL_MATCHED of include/seqkit_hip.h).
 //   W1, W2 : key dwords — the row's first W1 dwords and, with a separator, W2 == W1 dwords from the byte after it
-//   DIRECT : rows start on dword boundaries, W1 <= 2, no separator: lane r loads row r straight from memory (8 B/lane
-//            coalesced for 8 bp); otherwise a tile goes through the wave's LDS image with 16 B/lane loads and the segments
-//            are read back at any alignment
-//   LDSTAB : the table fits beside the images (<= 128 KiB); else it is read through the vector cache
+//   DIRECT : rows start on dword boundaries, W1 <= 2, no separator: lane r loads row r as it lies (8 B/lane, coalesced, for
+//            8 bp); otherwise lane r gathers the dwords its row's segments lie in, at any alignment (see GATHER below) —
+//            either way a row goes from memory to its lane's registers, nothing passes through LDS but the table
+//   LDSTAB : the table fits the workgroup's LDS (<= 128 KiB); else it is read through the vector cache
 //   DETAIL : lowest_diff / first_idx / last_idx are written too
 // Two tiles per wave are always in flight (register slots), so that a CU of sixteen waves has ~34 KiB on the way.  There
 // is no branch around a VMEM instruction in the loop: the waits for the register slots are counted, not drained.
@@ -1444,7 +1445,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	fetch(tb + tstep, 1);
 	// the table and the histogram while the first tiles are on their way
 	if (lp.use_lds_hist) for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
-	const int ltab_off = lp.tiles_off - lp.table_bytes;                  // LDSTAB: the table sits right before the tile images
+	const int ltab_off = lp.tiles_off - lp.table_bytes;                  // LDSTAB: the table sits behind the histogram
 	if (LDSTAB) {
 		// eight loads per thread on their way before the first is written: the 128 KiB of a dual-index table are one round trip
 		// to L2 per workgroup, not eight
@@ -1918,11 +1919,10 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		TileArgs bb = b;
 		if (by_table) {
 			const LutDev &t = b.table.nbr;
-			// rows on dword boundaries whose key is one or two dwords: read straight from memory (lane r = row r, one 8 B/lane
-			// load for 8-byte rows).  Longer keys go through the LDS image even when the rows are aligned: five dword loads at
-			// a 24-byte stride walk the same lines five times.  (SK_DEMUX_DIRECT=0 / SK_DEMUX_LDSTAB=0 force the other forms:
+			// rows on dword boundaries whose key is one or two dwords: lane r loads row r as it lies (one 8 B/lane load for 8-byte
+			// rows); every other shape gathers (demux_lut_kernel).  (SK_DEMUX_DIRECT=0 / SK_DEMUX_LDSTAB=0 force the other forms:
 			// the tests run every kernel on the same inputs)
-			const bool pair = t.pair.tab != nullptr;                  // the factored form (sk_lut.h): always from LDS, through the image
+			const bool pair = t.pair.tab != nullptr;                  // the factored form (sk_lut.h): its three tables always in LDS
 			const char *env_direct = getenv("SK_DEMUX_DIRECT");
 			const bool direct = !pair && (b.bc_stride & 3) == 0 && t.W2 == 0 && t.W1 <= 2 && 4 * t.W1 <= b.bc_stride && (!env_direct || atoi(env_direct) != 0);
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
@@ -1945,7 +1945,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			lp.table_bytes = ldstab ? table_bytes : 0;
 			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
 			lp.tile_slot = 2 * kLdsPad;                               // rows come straight from memory: no image
-			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy; fewer when long rows leave no room for their images
+			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy
 			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
 			const int lds = lp.tiles_off + nw * lp.tile_slot;
 			struct Occ { int dev; const void *fn; int lds, wg; };

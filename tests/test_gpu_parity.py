@@ -360,7 +360,7 @@ def check_demux_matched(ctx, oracle, table, bc, max_diff=1):
     return int(m.sum())
 
 
-@pytest.fixture(params=["default", "no table", "rows through the LDS image", "table in the vector cache", "two rows per lane", "one row per lane",
+@pytest.fixture(params=["default", "no table", "aligned rows gathered too", "table in the vector cache", "two rows per lane", "one row per lane",
                         "never half by half"])
 def lut_form(request, monkeypatch):
     """The forms of the lookup kernel (and the matchers, without a table) on the same inputs."""
@@ -372,7 +372,7 @@ def lut_form(request, monkeypatch):
         monkeypatch.setenv("SK_DEMUX_ROWS2", "1")
     elif request.param == "one row per lane":
         monkeypatch.setenv("SK_DEMUX_ROWS2", "0")
-    elif request.param == "rows through the LDS image":
+    elif request.param == "aligned rows gathered too":
         monkeypatch.setenv("SK_DEMUX_DIRECT", "0")
     elif request.param == "table in the vector cache":
         monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")
@@ -539,7 +539,7 @@ def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
     if seed % 4 == 1:
         monkeypatch.setenv("SK_DEMUX_LDSTAB", "0")          # the table from the vector cache instead of LDS
     if seed % 4 == 2:
-        monkeypatch.setenv("SK_DEMUX_DIRECT", "0")          # aligned short rows through the LDS image too
+        monkeypatch.setenv("SK_DEMUX_DIRECT", "0")          # aligned short rows by the gather loads too
     if seed % 4 == 3:
         monkeypatch.setenv("SK_DEMUX_ROWS2", "1")           # 8-byte rows two per lane also for the decision alone
     rng = np.random.default_rng(12000 + seed)
