@@ -13,7 +13,7 @@ bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "4 t
          "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "issue (45 VALU per row) and stream, + 4 µs launch", "cfg3 with": "stream",
          "cfg3 sheet": "issue", "demultiplex only 10M x 17ch, 96": "stream, then issue (80 VALU + 54 SALU per 64-row tile)", "96 dual": "stream",
          "demultiplex only 10M x 17ch, 384": "issue: three lookups per read", "cfg5": "HBM", "f2:": "HBM", "f4:": "latency / occupancy",
-         "f3: census 32M rows, clean": "front kernel issue-bound (§3.7)", "f3: census 32M rows, noisy": "front kernel 0.19–0.20 + partition passes 0.17–0.19 ms",
+         "f3: census 32M rows, clean": "front kernel: LDS pipe 79 %, VALU 62 % busy (§8)", "f3: census 32M rows, noisy": "front kernel 0.19–0.20 + partition passes 0.17–0.19 ms",
          "f3: census 32M rows, every": "memory side: one CAS + two stores per new key"}
 rows = []
 for x in d["extra"]["rates"]:
