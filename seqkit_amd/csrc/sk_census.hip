@@ -456,14 +456,10 @@ constexpr int kCensusMaxSub = 4;          // 64-row tiles per wave and step
 constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step: 5 x 16 B per lane in flight
 constexpr int kCensusQueue = 128;         // flush queue entries (16 B key + 4 B row): fewer than 64 left over + one tile's 64
 
-struct CensusTileRegs { uint4 v[5]; int32_t code[kCensusMaxSub] = {0, 0, 0, 0}; };
+template <int R, int NW> struct CensusRowRegs { u32 g[R][NW + 1]; int32_t code[kCensusMaxSub] = {0, 0, 0, 0}; };
 
-// The R x 64 rows of step t are one contiguous, 16-byte aligned byte range: 16 bytes per lane and load, as unconditional
-// raw-buffer loads.  ONE descriptor serves the launch's whole matrix (census_add keeps a launch below 2 GiB) and ends at the
-// matrix's last valid dword: what lies beyond it — the tail of the last step, every step past it — the hardware drops (so
-// like the tile pass this may read up to 3 bytes past the end of the matrix); a step's place travels in the offset.  (A
-// descriptor per step was ~60 scalar instructions of 64-bit arithmetic per step.)  What a wave has in flight is what bounds
-// this kernel when everything is counted in LDS (one 1 KiB tile per wave: 2 TB/s), hence R tiles per step.
+// The input as raw-buffer descriptors over the whole launch (the rows, and the assignment codes when there are any): what
+// lies beyond the matrix is clipped by the descriptor (a load returns zeros there, dword by dword).
 struct CensusStreams { __amdgpu_buffer_rsrc_t bc, assign; };
 __device__ __forceinline__ CensusStreams census_streams(const CensusArgs &a)
 {
@@ -473,14 +469,19 @@ __device__ __forceinline__ CensusStreams census_streams(const CensusArgs &a)
 	cs.assign = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.assign), 0, a.assign ? (int)(a.n * 4) : 0, 0x00020000);
 	return cs;
 }
-// offk[k]: where the lane's k-th 16 bytes lie within a step, or 2^31 — past every launch — when that is behind the step's end
-// (those bytes are the next step's)
-__device__ __forceinline__ void census_load_tile(const CensusStreams &cs, bool has_assign, int t, int step_bytes, const u32 (&offk)[5], int R, int lane, CensusTileRegs &rg)
+// A lane fetches the dwords ITS rows of the step lie in (row j * 64 + lane for j < R), at any alignment: the NW dwords from
+// the one that holds the row's first byte, and the one behind them (which a row that begins late in its first dword reaches).
+// No image of the step in LDS: written once and read back at the rows' pitch (every read of a 17-byte-pitch walk a conflicted
+// one) it kept the LDS pipe, which the table probes need, busier than anything else in this kernel.
+// No branches around the loads — a load inside a conditional block is waited for at the end of that block, which serialises
+// them and the counting behind them.  (The assignment codes, when there are any, are asked for BEFORE the rows: the one
+// conditional block with loads in it then lies in front of the unconditional ones, and the wait for the rows counts the
+// same loads on both paths.)
+template <int R, int NW> __device__ __forceinline__ void census_load_rows(const CensusStreams &cs, bool has_assign, int t, int step_bytes, const u32 (&off)[R], int lane,
+                                                                          CensusRowRegs<R, NW> &rg)
 {
-	// No branches around the loads — a load inside a conditional block is waited for at the end of that block, which
-	// serialises the five of them and the counting behind them; what lies beyond the matrix is clipped by the descriptor.
-	// (the assignment codes, when there are any, are asked for BEFORE the tile: the one conditional block with loads in it
-	// then lies in front of the unconditional ones, and the wait for the tile counts the same loads on both paths)
+	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+	typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
 	if (has_assign) {
 		const int r0 = (t * R * 64 + lane) * 4;
 #pragma unroll
@@ -489,9 +490,22 @@ __device__ __forceinline__ void census_load_tile(const CensusStreams &cs, bool h
 	}
 	const u32 base = (u32)t * (u32)step_bytes;
 #pragma unroll
-	for (int k = 0; k < 5; k++) {
-		const auto v = __builtin_amdgcn_raw_buffer_load_b128(cs.bc, (int)(base + offk[k]), 0, 0);
-		memcpy(&rg.v[k], &v, 16);
+	for (int j = 0; j < R; j++) {
+		const int o = (int)(base + off[j]);
+		if constexpr (NW == 2) {
+			const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(cs.bc, o, 0, 0);
+			rg.g[j][0] = v[0]; rg.g[j][1] = v[1]; rg.g[j][2] = v[2];
+		} else if constexpr (NW == 5) {
+			const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(cs.bc, o, 0, 0);
+			const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(cs.bc, o + 16, 0, 0);
+			rg.g[j][0] = v[0]; rg.g[j][1] = v[1]; rg.g[j][2] = v[2]; rg.g[j][3] = v[3]; rg.g[j][4] = w[0]; rg.g[j][5] = w[1];
+		} else {
+			static_assert(NW == 8, "strings of at most 8, 20 or 32 bytes");
+			const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(cs.bc, o, 0, 0), w = __builtin_amdgcn_raw_buffer_load_b128(cs.bc, o + 16, 0, 0);
+			rg.g[j][0] = v[0]; rg.g[j][1] = v[1]; rg.g[j][2] = v[2]; rg.g[j][3] = v[3];
+			rg.g[j][4] = w[0]; rg.g[j][5] = w[1]; rg.g[j][6] = w[2]; rg.g[j][7] = w[3];
+			rg.g[j][8] = __builtin_amdgcn_raw_buffer_load_b32(cs.bc, o + 32, 0, 0);
+		}
 	}
 }
 
@@ -521,19 +535,18 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	u32 *const fa = front + front_entries * 4;                        // ... A ...
 	u32 *const fc = fa + (CH > 2 ? front_entries * 4 : 0);            // ... C ...
 	u32 *const fcnt = front + front_entries * (CH * 4);               // ... and the counts
-	uint8_t *tile = census_smem + front_bytes + (size_t)wave * tile_slot;
+	// The wave's slot: its QUEUE of rows that take the long way — a row that misses leaves its NW masked dwords and its index
+	// there (qx: 4 NW bytes per entry, qr: the row's index within the launch).  Rows that miss wait until 64 of them are
+	// together: a pass of the long way costs its ~300 instructions whether 6 lanes or 64 have a row (a clean run missed 6-15
+	// rows per step and paid a pass for them in every step: 23-27 % of a wave's lifetime,
+	// profiles/r04_census_stamps_before.txt).  What is left over at the end of a step — fewer than 64 entries — moves to the
+	// front of the queue and goes first in the next step's passes.  Capacity: 64 left over + the step's R x 64 rows.
+	uint8_t *slot = census_smem + front_bytes + (size_t)wave * tile_slot;
 	u32 *lh = reinterpret_cast<u32 *>(census_smem + front_bytes + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
-	// the wave's queue of rows that take the long way (a byte each: a step has at most 256 rows)
-	uint8_t *queue = reinterpret_cast<uint8_t *>(lh + kSpillBuckets + 4) + wave * (kCensusMaxSub * 64);
-	// Rows that miss wait until 64 of them are together: a pass of the long way costs its ~300 instructions whether 6 lanes or
-	// 64 have a row (a clean run missed 6-15 rows per step and paid a pass for them in every step: 23-27 % of a wave's
-	// lifetime, profiles/r04_census_stamps_before.txt).  What is left over at the end of a step — fewer than 64 rows — is copied
-	// out of the tile into the wave's CARRY area behind it (the string's NW masked dwords on a 4 NW-byte pitch, so the same
-	// reader serves both; the rows' indices beside them) and goes first in the next step's queue.
-	constexpr int kCarryPitch = 4 * NW;
-	const int carry_off = tile_slot - 64 * (kCarryPitch + 4);           // (census_add sized the wave's slot for it)
-	u32 *carry_row = reinterpret_cast<u32 *>(tile + carry_off + 64 * kCarryPitch);
-	u32 n_carry = 0u;                                                  // wave-uniform
+	constexpr int kQueueCap = 64 + R * 64;
+	u32 *const qr = reinterpret_cast<u32 *>(slot);
+	u32 *const qx = qr + kQueueCap;
+	u32 n_carry = 0u;                                                  // wave-uniform: entries left over from the step before
 	// Once the table is full a string that is not in it finds both its places taken, every time: after kFullAfter rows in a
 	// row (of this wave) for which that was so, the long way no longer looks — it builds the key and parks the row.  (A string
 	// that another lane put into the table a moment ago is then parked instead of counted there: the sums are the same.)
@@ -564,37 +577,41 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		const int keep = a.L - 4 * q;
 		kms[q] = keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : (1u << (8 * keep)) - 1u);
 	}
-	const bool need_last = ((a.L + 2) >> 2) >= NW;                 // a row that begins at byte 3 of a dword reaches dword (L + 2) / 4 of its span
 	const int nsteps = (int)((a.n + (int64_t)R * 64 - 1) / ((int64_t)R * 64));      // (a launch is fewer than 2^31 bytes: census_add)
 	const int n32 = (int)a.n;
 	const int nwave_lg = 31 - __builtin_clz((u32)nwave);              // (the launch is kCensusWaves = 16 waves: a power of two)
 	auto step_of = [&](u32 c) -> int { return (int)((((c >> nwave_lg) * gridDim.x + blockIdx.x) << nwave_lg) + (c & ((u32)nwave - 1u))); };
 	const CensusStreams streams = census_streams(a);
-	u32 offk[5];
+	u32 off[R], shf[R];                                                // where the lane's row j begins within a step: its dword, and the byte in it
 #pragma unroll
-	for (int k = 0; k < 5; k++) offk[k] = lane * 16 + k * 1024 < step_bytes ? (u32)(lane * 16 + k * 1024) : 0x80000000u;
+	for (int j = 0; j < R; j++) {
+		const u32 o = (u32)((j * 64 + lane) * stride);
+		off[j] = o & ~3u;
+		shf[j] = o & 3u;
+	}
 	u32 claimed = 0, counted = 0, rejected = 0, overflow = 0;
-	CensusTileRegs rg;
-	uint4 *qkey = reinterpret_cast<uint4 *>(tile);                 // the flush queue reuses the wave's tile
-	u32 *qrel = reinterpret_cast<u32 *>(tile + kCensusQueue * 16);
+	CensusRowRegs<R, NW> rg;
+	// (the flush queue of the launches that insert by themselves lies behind the first 64 queue entries: dead once the passes ran)
+	uint4 *qkey = reinterpret_cast<uint4 *>(slot + ((kQueueCap * 4 + 64 * 4 * NW + 15) & ~15));
+	u32 *qrel = reinterpret_cast<u32 *>(reinterpret_cast<uint8_t *>(qkey) + kCensusQueue * 16);
 	// one more row for the entry at LDS address ea, whose first row was `first` when it was read
 	auto front_count = [&](u32 e, u32 first, u32 r) {
 		__hip_atomic_fetch_add(&fcnt[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (r < first) __hip_atomic_fetch_min(&fb[e * 4u + 2u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (rows come in roughly ascending order: rare)
 	};
 	int t = (int)blockIdx.x * nwave + wave;
-	census_load_tile(streams, a.assign != nullptr, t, step_bytes, offk, R, lane, rg);
+	census_load_rows<R, NW>(streams, a.assign != nullptr, t, step_bytes, off, lane, rg);
 	for (;;) {
 		const bool drain = t >= nsteps;                                // no step left: one more turn for the rows still waiting in the carry area
 		if (drain && n_carry == 0u) break;
-		u32 next_c = 0u;                                               // asked for before the tile is written: the answer is there when the fence is
+		u32 next_c = 0u;                                               // asked for before the rows are taken out of their registers: the answer is there when they are
 		if (lane == 0) next_c = atomicAdd(step_ctr, 1u);
+		u32 xs[R][NW];                                                 // the step's rows: their first L bytes as dwords (a drain turn's are zeros nobody looks at)
 #pragma unroll
-		for (int k = 0; k < 5; k++) {
-			const int off = lane * 16 + k * 1024;
-			if (off < step_bytes) *reinterpret_cast<uint4 *>(tile + off) = rg.v[k];      // (a drain turn writes what the clipped loads gave: zeros nobody reads)
-		}
-		SK_STAMP(1);                                                   // the step's loads waited for, tile written
+		for (int j = 0; j < R; j++)
+#pragma unroll
+			for (int q = 0; q < NW; q++) xs[j][q] = __builtin_amdgcn_alignbyte(rg.g[j][q + 1], rg.g[j][q], shf[j]) & kms[q];
+		SK_STAMP(1);                                                   // the step's loads waited for, rows aligned
 		// which of the step's rows are counted, worked out BEFORE the next step's loads are issued: nothing below may
 		// wait for a register that a load of this or an earlier step wrote, or it waits for the new loads as well
 		u32 take = 0xFu;
@@ -609,7 +626,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 #else
 		const int tn = step_of((u32)__builtin_amdgcn_readfirstlane((int)next_c));
 #endif
-		census_load_tile(streams, a.assign != nullptr, tn, step_bytes, offk, R, lane, rg);       // in flight while this step is counted
+		census_load_rows<R, NW>(streams, a.assign != nullptr, tn, step_bytes, off, lane, rg);       // in flight while this step is counted
 		SK_STAMP(2);                                                   // fence, next step's loads issued
 		// Counting touches LDS only.  Keys the table had no room for are parked in registers (one per lane and pass) and go to
 		// HBM after the step's last pass: any global memory operation in between would make the compiler wait for the loads
@@ -622,13 +639,12 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		if (!drain) {
 			// all of the step's row reads first, then all of its table reads, then the counting: three LDS round trips per
 			// step instead of three per 64 rows
-			u32 xs[R][NW], hs[R], en[R], first[R];
+			u32 hs[R], en[R], first[R];
 			bool hit[R];
 			{
 				FrontWords<NW> fw[R];
 #pragma unroll
 				for (int j = 0; j < R; j++) {
-					census_row_raw<NW>(tile, (j * 64 + lane) * stride, kms, xs[j], need_last);
 					hs[j] = front_hash<NW>(xs[j]);
 					en[j] = front_place(hs[j], 0, ft.entries);
 				}
@@ -666,7 +682,12 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				}
 				const bool miss = want && !hit[j];
 				const u64 bal = __ballot(miss);
-				if (miss) queue[qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (uint8_t)(j * 64 + lane);
+				if (miss) {
+					const u32 at = n_carry + qn + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+					qr[at] = (u32)r;
+#pragma unroll
+					for (int q = 0; q < NW; q++) qx[at * NW + q] = xs[j][q];
+				}
 				qn += (u32)__popcll(bal);
 			}
 			census_wave_fence();
@@ -689,12 +710,12 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			if ((u32)j < n_pass) {
 				const u32 qi = (u32)(j * 64) + lane_l;
 				const bool have = qi < q_total;
-				const bool carried = qi < n_carry;
-				const u32 rid = have && !carried ? (u32)queue[qi - n_carry] : 0u;
-				const u32 r = carried ? carry_row[qi] : (u32)(t * R * 64) + rid;      // the row's index within the launch
+				const u32 qe = have ? qi : 0u;                             // (lanes without a row read entry 0: nothing of theirs is used)
+				const u32 r = qr[qe];                                      // the row's index within the launch
 				prid[j] = r;
 				u32 xs[NW];
-				census_row_raw<NW>(tile, carried ? carry_off + (int)qi * kCarryPitch : (int)rid * stride, kms, xs);
+#pragma unroll
+				for (int q = 0; q < NW; q++) xs[q] = qx[qe * NW + q];
 				{	// a NUL before L ends the barcode and what follows it is padding: zeroed, only when some row of the pass has one
 					u32 z = 0u;
 #pragma unroll
@@ -740,30 +761,29 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				}
 			}
 		}
-		{	// what is left — fewer than 64 rows, all of them this step's when a pass ran (it took the carried ones first) — waits
+		{	// what is left — fewer than 64 entries — moves to the front of the queue (read by every lane that has one, then written)
 			const u32 done = n_pass << 6;
 			const u32 left = q_total > done ? q_total - done : 0u;
-			const u32 keep = done == 0u ? n_carry : 0u;                   // carried rows no pass took stay where they are
-			const u32 q0 = done > n_carry ? done - n_carry : 0u;          // the first queue entry that waits
-			const u32 m = left - keep;                                    // rows to copy out of the tile
-			if (m != 0u) {
+			if (done != 0u && left != 0u) {
 				census_wave_fence();
-				const bool mine = lane_l < m;
-				const u32 rid = mine ? (u32)queue[q0 + lane_l] : 0u;
-				u32 xs[NW];
-				census_row_raw<NW>(tile, (int)rid * stride, kms, xs);
-				if (mine) {
-					u32 *dst = reinterpret_cast<u32 *>(tile + carry_off + (int)(keep + lane_l) * kCarryPitch);
+				const bool mine = lane_l < left;
+				const u32 from = mine ? done + lane_l : 0u;
+				const u32 r = qr[from];
+				u32 ys[NW];
 #pragma unroll
-					for (int q = 0; q < NW; q++) dst[q] = xs[q];
-					carry_row[keep + lane_l] = (u32)(t * R * 64) + rid;
+				for (int q = 0; q < NW; q++) ys[q] = qx[from * NW + q];
+				census_wave_fence();
+				if (mine) {
+					qr[lane_l] = r;
+#pragma unroll
+					for (int q = 0; q < NW; q++) qx[lane_l * NW + q] = ys[q];
 				}
 			}
 			n_carry = left;
 		}
 		census_wave_fence();
 		SK_STAMP(4);                                                   // the long way
-		// The parked keys, packed densely through the (now dead) tile so that one insert serves up to 64 of them: its
+		// The parked keys, packed densely through the dead part of the queue so that one insert serves up to 64 of them: its
 		// dependent round trips are paid per call, not per key.  (Fetching the slots a step ahead of the insert was tried:
 		// no gain — what bounds this leg is the rate of scattered atomics, not their latency.)
 		if (SPILL) {
@@ -1392,11 +1412,17 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	R = R < 1 ? 1 : (R > kCensusMaxSub ? kCensusMaxSub : R);
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	const int nw_dwords = L <= 8 ? 2 : (L <= 20 ? 5 : 8);
-	int tile_slot = (R * 64 * bc_stride + 4 + 15) & ~15;             // (+ 4: a row is read as NW + 1 dwords)
-	if (tile_slot < kCensusQueue * 20) tile_slot = kCensusQueue * 20;
-	tile_slot += 64 * (4 * nw_dwords + 4);                          // the wave's carry area: 64 strings and their rows' indices
-	size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32)      // + slack: a row is read as 9 dwords; the spill counters
-	             + (size_t)kCensusWaves * kCensusMaxSub * 64;          // the waves' queues of rows that take the long way
+	// a wave's slot: its queue of rows that take the long way, 64 left over + the step's R x 64, each its NW dwords and its
+	// row's index; behind the first 64 entries there must be room for the flush queue of the launches that insert by themselves.
+	// Two 64-row tiles per step at most: more buy nothing (R = 1 ... 4 time the same within the boxes' noise) and a tile's
+	// 64 queue entries are 43 front-table entries of a 17-byte sheet
+	if (R > 2) R = 2;
+	const int queue_cap = 64 + R * 64;
+	int tile_slot = queue_cap * (4 * nw_dwords + 4);
+	const int flush_end = ((queue_cap * 4 + 64 * 4 * nw_dwords + 15) & ~15) + kCensusQueue * 20;
+	if (tile_slot < flush_end) tile_slot = flush_end;
+	tile_slot = (tile_slot + 15) & ~15;
+	size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32);      // + the spill counters
 	// the front table takes what is left of the CU's 160 KiB (SK_CENSUS_FRONT_ENTRIES: tests shrink it so that small inputs
 	// walk "no room in either place")
 	const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
