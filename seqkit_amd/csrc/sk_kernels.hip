@@ -1928,11 +1928,12 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			const char *env_ldstab = getenv("SK_DEMUX_LDSTAB");
 			const int table_bytes = pair ? t.pair.bytes : (t.mask + 1) * 2 * 8;
 			const bool ldstab = pair || (table_bytes <= (128 << 10) && (!env_ldstab || atoi(env_ldstab) != 0));
-			// rows of exactly 8 key bytes on an 8-byte pitch: two rows per lane when the detail columns are written too (17 B/read:
-			// 10 M reads 249 -> 290 G reads/s; the decision alone is faster with one row per lane at 10 M, 364 against 333, and
-			// the same at 100 M).  SK_DEMUX_ROWS2=0 / 1 force the choice (tools/demux_ab.py, tests).
+			// rows of exactly 8 key bytes on an 8-byte pitch: two rows per lane (demux_lut8x2_kernel) — always when the detail columns
+			// are written too, and for the decision alone from 1.5 M rows (after round 4's instruction diet: 10 M rows 20.4 us
+			// against 23.6 with one row per lane, 2 M 8.3 / 9.5, 6 M 14.6 / 16.9, 100 M the same; 1 M 7.8 / 7.3: a workgroup's
+			// first tile is its whole share there).  SK_DEMUX_ROWS2=0 / 1 force the choice (tools/demux_ab.py, tests).
 			const char *env_rows2 = getenv("SK_DEMUX_ROWS2");
-			const bool rows2 = direct && t.W1 == 2 && b.bc_stride == 8 && (env_rows2 ? atoi(env_rows2) != 0 : want_detail);
+			const bool rows2 = direct && t.W1 == 2 && b.bc_stride == 8 && (env_rows2 ? atoi(env_rows2) != 0 : (want_detail || b.n >= 1500000));
 			const void *fn = pair ? (t.W1 == 1 ? (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<1, 1, false, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<1, 1, false, true, false, true>))
 			                                   : (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, true>)))
 			                 : rows2 ? (ldstab ? (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false>))
