@@ -10,7 +10,7 @@ tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r04")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench.json")).read().strip().splitlines()[-1])
 bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "4 tile-rounds of 7.3 µs + 5.5 µs launch", "cfg2 read": "HBM", "fused single-end:": "HBM",
-         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "issue (45 VALU per row) and stream, + 4 µs launch", "cfg3 with": "stream",
+         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "stream, then issue (43 VALU per row, two rows per lane), + 4 µs launch", "cfg3 with": "stream",
          "cfg3 sheet": "issue", "demultiplex only 10M x 17ch, 96": "stream, then issue (80 VALU + 54 SALU per 64-row tile)", "96 dual": "stream",
          "demultiplex only 10M x 17ch, 384": "issue: three lookups per read", "cfg5": "HBM", "f2:": "HBM", "f4:": "latency / occupancy",
          "f3: census 32M rows, clean": "front kernel: LDS pipe 79 %, VALU 62 % busy (§8)", "f3: census 32M rows, noisy": "front kernel 0.19–0.20 + partition passes 0.17–0.19 ms",
