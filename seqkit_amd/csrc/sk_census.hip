@@ -124,47 +124,6 @@ __device__ __forceinline__ u32 census_classify(u32 x, u32 &diff)
 	diff = y ^ __builtin_amdgcn_perm(kClassHi, kClassLo, sel);
 	return sel | (lower >> 2);
 }
-// The key of the row that begins at byte rs of the wave's tile, NW = ceil(L / 4) dwords of it: aligned LDS reads (all
-// issued before the first is used) funnel-shifted to the row's first byte, four characters per dword classified with
-// packed-byte arithmetic.  kms[q] masks the characters of dword q that lie before L (wave-uniform).  EXACT_NUL = false is the
-// common case — no row of the wave has a NUL before L, which the caller finds out from the returned word (bit 7 of a byte
-// clear: a code was 0); with EXACT_NUL the bytes from the first NUL on are masked away, whatever they are.
-// character 4q + b is nibble (q & 1) of byte b of word q / 2; the marker (a key is never 0) sits where character 31 would,
-// and that word is the key's FIRST so that barcodes of at most 24 characters are three dwords + a constant.
-template <int NW, bool EXACT_NUL> __device__ __forceinline__ u32 census_row_key(const uint8_t *tile, int rs, const u32 (&kms)[NW], u64 &klo, u64 &khi, u32 &badacc)
-{
-	const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
-	const u32 sh = (u32)rs & 3u;
-	u32 raw[NW + 1];
-#pragma unroll
-	for (int q = 0; q <= NW; q++) raw[q] = t32[q];
-	u32 c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-	u32 nzacc = 0xFFFFFFFFu, alive = 0xFFFFFFFFu;
-	badacc = 0u;
-#pragma unroll
-	for (int q = 0; q < NW; q++) {
-		const u32 x = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh);
-		const u32 km = kms[q];
-		u32 d;
-		const u32 cc = census_classify(x, d);
-		if (!EXACT_NUL) {
-			badacc |= d & km;
-			c[q] = cc & km;
-			nzacc &= (c[q] + 0x7f7f7f7fu) | ~km;              // bit 7 of a byte: its code is not 0, or it lies beyond L
-		} else {
-			const u32 zf = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & 0x80808080u & km;      // bit 7 of the bytes that are NUL
-			const u32 m = (zf != 0u ? (1u << (__builtin_ctz(zf) & 31)) - 1u : 0xFFFFFFFFu) & alive & km;
-			badacc |= d & m;
-			c[q] = cc & m;
-			if (zf != 0u) alive = 0u;
-		}
-	}
-	const u32 kw0 = c[0] | (c[1] << 4), kw1 = c[2] | (c[3] << 4), kw2 = c[4] | (c[5] << 4), kw3 = c[6] | (c[7] << 4) | 0xF0000000u;
-	klo = (u64)kw3 | ((u64)kw0 << 32);
-	khi = (u64)kw1 | ((u64)kw2 << 32);
-	return nzacc;
-}
-
 static const char kCensusAlphabet[17] = "\0C+ANGT??c?angt?";      // by code
 
 struct SlotView { u64 k, v; };          // klo and ~khi of a slot as loaded at some earlier time
@@ -292,7 +251,7 @@ __device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi
 // ---- the workgroup's front table: keyed by a row's BYTES ---------------------------------------------------------------
 // Building a row's key — classify every character, pack, hash — is most of what the census does per row, and most rows of a
 // run repeat a few thousand byte strings (the sheet's barcodes and their neighbours).  So the table a workgroup keeps in LDS
-// in front of the HBM table is keyed by the row's L RAW bytes (its masked dwords as they lie in the tile): a row whose
+// in front of the HBM table is keyed by the row's L RAW bytes (its masked dwords as they lie in memory): a row whose
 // string is there is one hash of its dwords, one entry read, a compare and the LDS add — no key is built for it at all.  A
 // string enters the table on the long way (below), after its characters were checked; what the long way checks — the
 // alphabet; a NUL before L ends the barcode, and the bytes behind it are zeroed before the string is looked up or stored —
@@ -323,20 +282,6 @@ struct FrontTable {
 	u32 b, a, c, cnt, entries;
 };
 
-// (need_last, wave-uniform: some row's L bytes reach into dword NW of its span — not so for L = 17, whose 17 bytes lie in five
-// dwords wherever they begin, and every LDS read of this 17-byte-pitch walk is a conflicted one)
-template <int NW> __device__ __forceinline__ void census_row_raw(const uint8_t *tile, int rs, const u32 (&kms)[NW], u32 (&xs)[NW], bool need_last = true)
-{
-	const u32 *t32 = reinterpret_cast<const u32 *>(tile) + (rs >> 2);
-	const u32 sh = (u32)rs & 3u;
-	u32 raw[NW + 1];
-#pragma unroll
-	for (int q = 0; q < NW; q++) raw[q] = t32[q];
-	raw[NW] = 0u;
-	if (need_last) raw[NW] = t32[NW];
-#pragma unroll
-	for (int q = 0; q < NW; q++) xs[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh) & kms[q];
-}
 template <int NW> __device__ __forceinline__ u32 front_hash(const u32 (&xs)[NW])
 {
 	u32 h = xs[0];
@@ -443,7 +388,7 @@ struct CensusArgs {
 };
 
 constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the front table
-constexpr int kCensusMaxStride = 64;      // 64 rows x 64 B = 4 KiB per wave tile = 4 x 16 B per lane
+constexpr int kCensusMaxStride = 64;      // a row's span is at most 9 dwords (census_load_rows)
 
 __device__ __forceinline__ void census_wave_fence()
 {
@@ -453,7 +398,7 @@ __device__ __forceinline__ void census_wave_fence()
 }
 
 constexpr int kCensusMaxSub = 4;          // 64-row tiles per wave and step
-constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step: 5 x 16 B per lane in flight
+constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step before the cap on R (census_add)
 constexpr int kCensusQueue = 128;         // flush queue entries (16 B key + 4 B row): fewer than 64 left over + one tile's 64
 
 template <int R, int NW> struct CensusRowRegs { u32 g[R][NW + 1]; int32_t code[kCensusMaxSub] = {0, 0, 0, 0}; };
@@ -509,8 +454,9 @@ template <int R, int NW> __device__ __forceinline__ void census_load_rows(const 
 	}
 }
 
-// One row per lane, R 64-row tiles per wave and step.  A wave keeps the next step's bytes in registers while it
-// works on the current one (its private LDS tile), so the only workgroup barriers are the two around the loop.
+// One row per lane, R 64-row tiles per wave and step.  A wave keeps the next step's rows in registers (census_load_rows)
+// while it counts the current one; what it shares with nobody — its queue of rows that take the long way — is its own
+// slot of LDS, so the only workgroup barriers are the two around the loop.
 // Rows are counted in the workgroup's front table (above); a string that finds neither of its two places free goes
 // straight to HBM as a packed key.  The table is merged into HBM when the workgroup is done.
 // SPILL: such keys are not inserted but appended to the workgroup's region of the spill arrays (unconditional, clipped
@@ -602,7 +548,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	int t = (int)blockIdx.x * nwave + wave;
 	census_load_rows<R, NW>(streams, a.assign != nullptr, t, step_bytes, off, lane, rg);
 	for (;;) {
-		const bool drain = t >= nsteps;                                // no step left: one more turn for the rows still waiting in the carry area
+		const bool drain = t >= nsteps;                                // no step left: one more turn for the rows still waiting in the queue
 		if (drain && n_carry == 0u) break;
 		u32 next_c = 0u;                                               // asked for before the rows are taken out of their registers: the answer is there when they are
 		if (lane == 0) next_c = atomicAdd(step_ctr, 1u);
@@ -695,7 +641,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		SK_STAMP(3);                                                   // rows the table knows
 		// ---- the long way, 64 queued rows at a time: check the string, look for it again (another lane may have put it there
 		// meanwhile), else claim one of its places, else build its key and park it -----------------------------------------------
-		// (the lane index as a value the compiler cannot see through: what the long way computes from it — queue and carry
+		// (the lane index as a value the compiler cannot see through: what the long way computes from it — queue
 		// addresses — is then worked out here, per step, instead of being kept in registers across the whole loop; the kernel sits
 		// at its 128 registers, and one more live value was a scratch slot whose reload waited for the step's prefetch)
 		u32 lane_l = (u32)lane;
