@@ -1410,14 +1410,18 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int S = a.table.S;
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int bstride = a.bc_stride;
-	u32 raw[2][W];
+	// tiles of a wave on their way: two — three and four are slower (96 dual-index 35.4 / 36.6 / 37.7 us at 10 M pairs, 12 columns
+	// 27.5 / - / 34.0) — but for the factored form, whose three lookups per row leave a tile's loads more time to hide in
+	// (384 dual-index 50.4 / 44.0 / 45.7 us)
+	constexpr int kDepth = PAIR ? 3 : 2;
+	u32 raw[kDepth][W];
 	// GATHER (every shape but DIRECT): a lane fetches the dwords its row's key lies in straight from memory, at any alignment —
 	// W1 + 1 dwords from the one that holds the row's first byte and, with a separator, W2 + 1 from the one that holds the byte
 	// after it.  (Through round 4's first sessions such tiles went through an image in LDS: 2 writes and 5 reads at a 17-byte
 	// pitch per dual-index tile kept the LDS pipe busier than HBM — 42.3 us against 35.8 at 10 M pairs.)  The separator itself is
 	// one byte of the first window's last two dwords (v_perm_b32).
 	constexpr int G2 = W2 > 0 ? W2 + 1 : 2;
-	u32 g1[2][W1 + 1], g2[2][G2];
+	u32 g1[kDepth][W1 + 1], g2[kDepth][G2];
 	const int rs = lane * bstride, rs2 = rs + t.sep_off + 1;            // where the lane's row lies in a tile does not depend on the tile
 	const u32 sh1 = (u32)rs & 3u, sh2 = (u32)rs2 & 3u;
 	const u32 sep_sel = 0x0c0c0c00u | (sh1 + (u32)(t.sep_off - 4 * (W1 - 1)));      // the separator among the 8 bytes of dwords W1 - 1 and W1: 1 ... 7
@@ -1441,8 +1445,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	};
 	const int tstep = (int)gridDim.x * nwave;
 	int tb = (int)blockIdx.x * nwave + wave;
-	fetch(tb, 0);
-	fetch(tb + tstep, 1);
+	for (int s = 0; s < kDepth; s++) fetch(tb + s * tstep, s);
+	
 	// the table and the histogram while the first tiles are on their way
 	if (lp.use_lds_hist) for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
 	const int ltab_off = lp.tiles_off - lp.table_bytes;                  // LDSTAB: the table sits behind the histogram
@@ -1484,9 +1488,9 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	};
 	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
 	u32 n_total = 0;
-	for (; tb < nt32; tb += 2 * tstep) {
+	for (; tb < nt32; tb += kDepth * tstep) {
 #pragma unroll
-		for (int s = 0; s < 2; s++) {
+		for (int s = 0; s < kDepth; s++) {
 			const int ti = tb + s * tstep;
 			const int rows = rows_of(ti);
 			const int64_t ro = (int64_t)(rows ? ti : 0) * kTileRows;
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 			if (DIRECT) {
 #pragma unroll
 				for (int w = 0; w < W; w++) d[w] = raw[s][w];
-				fetch(ti + 2 * tstep, s);
+				fetch(ti + kDepth * tstep, s);
 			} else {
 #pragma unroll
 				for (int w = 0; w < W1; w++) d[w] = __builtin_amdgcn_alignbyte(g1[s][w + 1], g1[s][w], sh1);
@@ -1505,7 +1509,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 					for (int w = 0; w < W2; w++) d[W1 + w] = __builtin_amdgcn_alignbyte(g2[s][w + 1], g2[s][w], sh2);
 					sepbad = __builtin_amdgcn_perm(g1[s][W1], g1[s][W1 - 1], sep_sel) != t.sep_val ? 1u : 0u;
 				}
-				fetch(ti + 2 * tstep, s);
+				fetch(ti + kDepth * tstep, s);
 			}
 			// classes: the index of the sheet letter a byte equals, `other` for every byte the sheet never uses
 			u32 c[5] = {0u, 0u, 0u, 0u, 0u};
@@ -1523,15 +1527,18 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				const u32 A1 = (W1 == 1 ? c[0] : lut_pack_half(c[0], c[1])) & pr.keep1;
 				const u32 A2 = (W1 == 1 ? c[k2] : lut_pack_half(c[k2], c[k3])) & pr.keep2;
 				const u32 x1 = lut_mix(A1, 0u, pr.seed1), x2 = lut_mix(A2, 0u, pr.seed2);
-				const u32 m1 = (1u << pr.nb1) - 1u, m2 = (1u << pr.nb2) - 1u;
-				const u32x2_t e11 = entry(lut_slot(x1, pr.nb1)), e12 = entry(m1 + 1u + lut_slot(x1 << pr.nb1, pr.nb1));
-				const u32x2_t e21 = entry(pr.off2 + lut_slot(x2, pr.nb2)), e22 = entry(pr.off2 + m2 + 1u + lut_slot(x2 << pr.nb2, pr.nb2));
+				// (the six tables' places in LDS are constants of the launch; a table-2 slot is the nb bits below the top nb: one v_bfe)
+				auto at = [&](int base, u32 slot) { return *reinterpret_cast<const u32x2_t *>(sk_smem + base + (int)slot * 8); };
+				const int b11 = ltab_off, b12 = b11 + (8 << pr.nb1), b21 = ltab_off + (int)pr.off2 * 8, b22 = b21 + (8 << pr.nb2);
+				const int bp1 = ltab_off + (int)pr.offp * 8, bp2 = bp1 + (8 << pr.nbp);
+				const u32x2_t e11 = at(b11, lut_slot(x1, pr.nb1)), e12 = at(b12, __builtin_amdgcn_ubfe(x1, 32u - 2u * (u32)pr.nb1, (u32)pr.nb1));
+				const u32x2_t e21 = at(b21, lut_slot(x2, pr.nb2)), e22 = at(b22, __builtin_amdgcn_ubfe(x2, 32u - 2u * (u32)pr.nb2, (u32)pr.nb2));
 				const bool f1 = e11[0] == A1 || e12[0] == A1, f2 = e21[0] == A2 || e22[0] == A2;
 				const u32 v1 = e11[0] == A1 ? e11[1] : e12[1], v2 = e21[0] == A2 ? e21[1] : e22[1];
 				tot = (int)(v1 >> 16) + (int)(v2 >> 16) + (int)sepbad;
 				const u32 pk = (v1 & 0x3ffu) | ((v2 & 0x3ffu) << 10);
-				const u32 xp = lut_mix(pk, 0u, pr.seedp), mp = (1u << pr.nbp) - 1u;
-				const u32x2_t ep1 = entry(pr.offp + lut_slot(xp, pr.nbp)), ep2 = entry(pr.offp + mp + 1u + lut_slot(xp << pr.nbp, pr.nbp));
+				const u32 xp = lut_mix(pk, 0u, pr.seedp);
+				const u32x2_t ep1 = at(bp1, lut_slot(xp, pr.nbp)), ep2 = at(bp2, __builtin_amdgcn_ubfe(xp, 32u - 2u * (u32)pr.nbp, (u32)pr.nbp));
 				const bool fp = ep1[0] == pk || ep2[0] == pk;
 				const u32 pv = ep1[0] == pk ? ep1[1] : ep2[1];
 				pfirst = (int)(pv & 0xffffu); plast = (int)(pv >> 16);
