@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=1,
                     help="threads for the CPU baseline (the reference's loops are single-threaded, so 1 is the faithful number; "
                          "more threads split the sample into slices)")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip cpu_baseline.all_cores (the restatement on every usable core)")
     ap.add_argument("--faithful-reads", type=int, default=1_000_000,
                     help="reads of cfg 2 / cfg 3 text run through the line-at-a-time oracle CLI for cpu_baseline.faithful (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.rates (device-resident rates of the other configs)")
@@ -280,6 +281,29 @@ def unpack_blocked(torch, lay, bout, nt):
     return res
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:                                                    # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def library_digest() -> str:
     import seqkit_amd
     h = hashlib.sha256()
@@ -294,6 +318,41 @@ def kernel_sources_digest() -> str:
     flags: the PMC traffic record in profiles/ is only quoted for the build it was measured on."""
     from seqkit_amd import build
     return build.library_inputs_digest()
+
+
+COLD_TRAFFIC = 512 << 20        # bytes of OTHER traffic between two uses of one buffer set (twice the 256 MiB Infinity Cache)
+
+
+def cold_sets(footprint_bytes):
+    """How many distinct input/output sets a call of this footprint needs so that, rotating over them, every set is met again
+    only after >= COLD_TRAFFIC bytes of other sets went by: what it reads then comes from HBM, not from the Infinity Cache."""
+    return int(-(-COLD_TRAFFIC // max(int(footprint_bytes), 1))) + 1
+
+
+def measure_rotating(torch, ctx, dev, calls, rounds=5, warm=1):
+    """Time `calls` (one closure per buffer set) in rotation on the ctx stream, ONE HIP event pair per call, nothing else between
+    the pairs and no host synchronisation inside a round (the queue stays full: launch latency is not what is timed).  With
+    len(calls) = cold_sets(footprint) a call never finds its bytes on-die.  Returns the median of the per-call durations (ms)."""
+    stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    torch.cuda.synchronize()
+    ts = []
+    with torch.cuda.stream(stream):
+        for _ in range(warm):
+            for fn in calls:
+                fn()
+        ctx.sync()
+        for _ in range(rounds):
+            evs = []
+            for fn in calls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                fn()
+                e1.record(stream)
+                evs.append((e0, e1))
+            ctx.sync()
+            ts += [e0.elapsed_time(e1) for e0, e1 in evs]
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def secondary_rates(torch, ctx, dev):
@@ -317,13 +376,32 @@ def secondary_rates(torch, ctx, dev):
             ts.append(ctx.timer_stop() / iters)
         return sorted(ts)[len(ts) // 2]
 
-    def timeit(name, fn, units, bpu, iters=10, rounds=3, cands=None):
+    def timeit(name, fn, units, bpu, iters=10, rounds=3, cands=None, sets=None):
         """cands = {array name: [candidate tensors with the same contents]} and fn(choice) — the streaming kernels are then also
         timed with the placement of their arrays chosen (one array at a time swapped for its other candidates, as
-        sk_fused_tune_placement_dev does for the fused pass): `frac` is the chosen placement, `frac_as_placed` the first candidates."""
-        if cands is None:
+        sk_fused_tune_placement_dev does for the fused pass): `frac` is the chosen placement, `frac_as_placed` the first candidates.
+        sets = one closure per distinct buffer set (cold_sets(footprint) of them) for a call whose bytes would fit the 256 MiB
+        Infinity Cache: `frac` is then the call with its rows coming from HBM (rotation over the sets, one event pair per call),
+        `frac_pipelined` the same rotation inside ONE event pair (launches overlap as in a stream of calls), `frac_warm` the
+        call replayed on one set (what rounds 1-4 reported for these rows: an on-die number)."""
+        first = None
+        if sets is not None:
+            warm = measure(sets[0], iters, rounds)
+            ms = measure_rotating(torch, ctx, dev, sets, rounds=5)
+            stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    for f in sets:
+                        f()
+                    e1.record(stream)
+                ctx.sync()
+                ts.append(e0.elapsed_time(e1) / len(sets))
+            piped = sorted(ts)[1]
+        elif cands is None:
             ms = measure(fn, iters, rounds)
-            first = None
         else:
             choice = {k: 0 for k in cands}
             first = best = measure(lambda: fn(choice), iters, 1)
@@ -345,6 +423,10 @@ def secondary_rates(torch, ctx, dev):
                "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         if first is not None:
             row["frac_as_placed"] = round(units * bpu / first / 1e6 / HBM_PEAK_GBS, 4)
+        if sets is not None:
+            row.update({"rows_from": f"HBM: rotation over {len(sets)} buffer sets, one event pair per call",
+                        "ms_pipelined": round(piped, 4), "frac_pipelined": round(units * bpu / piped / 1e6 / HBM_PEAK_GBS, 4),
+                        "ms_warm": round(warm, 4), "frac_warm": round(units * bpu / warm / 1e6 / HBM_PEAK_GBS, 4)})
         out.append(row)
 
     n = 16_000_000
@@ -359,7 +441,9 @@ def secondary_rates(torch, ctx, dev):
     del mc
     timeit("cfg2 worst case: trim by quality 16M x 150bp, uniform Q2-Q40 (no early break)",
            lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
-    timeit("cfg2: trim by quality 1M x 150bp, uniform Q2-Q40", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, 1_000_000, 20, lk.data_ptr()), 1_000_000, 152)
+    k = cold_sets(1_000_000 * 152)                  # 1 M-row slices of the 16 M-row matrix, each met again after >= 512 MiB of the others
+    timeit("cfg2: trim by quality 1M x 150bp, uniform Q2-Q40", None, 1_000_000, 152,
+           sets=[(lambda i=i: ctx.trim_by_quality_dev(q[i * 1_000_000:].data_ptr(), 0, 150, 1_000_000, 20, lk[i * 1_000_000:].data_ptr())) for i in range(k)])
     mu = 36.0 - 16.0 * (torch.arange(150, device=dev, dtype=torch.float32) / 149) ** 2
     for r0 in range(0, n, 2_000_000):
         q[r0:r0 + 2_000_000] = ((torch.randn((2_000_000, 150), generator=g, device=dev) * 6.0 + mu).round_().clamp_(2, 40) + 33).to(torch.uint8)
@@ -405,36 +489,59 @@ def secondary_rates(torch, ctx, dev):
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     assign = torch.empty((n,), dtype=torch.int32, device=dev)
-    timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+
+    def demux_sets(bc, L, bpu, detail=False):
+        """cold_sets(n x bpu) copies of the barcode matrix, each with output columns of its own"""
+        k = cold_sets(n * bpu)
+        keep = []
+        calls = []
+        for i in range(k):
+            b = bc if i == 0 else bc.clone()
+            o = [torch.empty((n,), dtype=torch.int32, device=dev)]
+            if detail:
+                o += [torch.empty((n,), dtype=torch.uint8, device=dev), torch.empty((n,), dtype=torch.int16, device=dev), torch.empty((n,), dtype=torch.int16, device=dev)]
+            keep.append((b, o))
+            calls.append(lambda b=b, o=o: ctx.demux_assign_dev(b.data_ptr(), L, n, *[x.data_ptr() for x in o]))
+        return calls, keep
+
+    calls, keep = demux_sets(bc, 8, 12)
+    timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", None, n, 12, sets=calls)
     # what `fasta demultiplex` asks for: the decision plus lowest_diff / first / last of the reads that matched something
     low = torch.empty((n,), dtype=torch.uint8, device=dev)
     first = torch.empty((n,), dtype=torch.int16, device=dev)
     last = torch.empty((n,), dtype=torch.int16, device=dev)
     ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
-    timeit("cfg3 with the detail columns of matched reads (SK_DETAIL_MATCHED, as the fasta demultiplex host calls it), 10M x 8bp",
-           lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr()), n, 17)
+    calls, keep = demux_sets(bc, 8, 17, detail=True)
+    timeit("cfg3 with the detail columns of matched reads (SK_DETAIL_MATCHED, as the fasta demultiplex host calls it), 10M x 8bp", None, n, 17, sets=calls)
+    del calls, keep
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()          # the same sheet on a call ten times as long: what the lookup does once the launch is out of the way
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
-    timeit("cfg3 sheet, 100M x 8bp in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 8, 10 * n, assign_l.data_ptr()), 10 * n, 12)
+    timeit("cfg3 sheet, 100M x 8bp in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 8, 10 * n, assign_l.data_ptr()), 10 * n, 12, iters=3)
     del bc_l, assign_l
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
-    timeit("demultiplex only 10M x 17ch, 96 dual-index", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
+    calls, keep = demux_sets(bc, 17, 21)
+    timeit("demultiplex only 10M x 17ch, 96 dual-index", None, n, 21, sets=calls)
     ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
-    timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch",
-           lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr(), low.data_ptr(), first.data_ptr(), last.data_ptr()), n, 26)
+    calls, keep = demux_sets(bc, 17, 26, detail=True)
+    timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch", None, n, 26, sets=calls)
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+    bc_l = bc.repeat(10, 1).contiguous()
+    assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
+    timeit("96 dual-index, 100M x 17ch in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 17, 10 * n, assign_l.data_ptr()), 10 * n, 21, iters=3)
+    del bc_l, assign_l, calls, keep
     # four plates: 384 dual-index samples (24 x 16 combinations).  The full-key table would be 512 KiB, so the sheet is looked
     # up half by half from LDS (sk_lut.h, the factored form)
     table = synth.make_sheet(384, 8, dual=True, seed=384)
     ctx.set_barcodes(table, 1)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
-    timeit("demultiplex only 10M x 17ch, 384 dual-index (four plates)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
-    del bc, assign, low, first, last
+    calls, keep = demux_sets(bc, 17, 21)
+    timeit("demultiplex only 10M x 17ch, 384 dual-index (four plates)", None, n, 21, sets=calls)
+    del bc, assign, low, first, last, calls, keep
     n = 200_000_000
     flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
     flag = torch.from_numpy(flag_np.view(np.int16)).to(dev).repeat(100)
@@ -887,23 +994,27 @@ def main():
         h_bc = bc[:ns].cpu().numpy()
         h_seq = [seq[i][:ns].cpu().numpy() for i in range(2)]
         h_qual = [qual[i][:ns].cpu().numpy() for i in range(2)]
+        def run_cpu(nthr):
+            """the sampled clusters through the C restatement on nthr threads (contiguous slices; ctypes releases the GIL around
+            the C calls): (per-slice results, seconds)"""
+            cuts = [ns * k // nthr for k in range(nthr + 1)]
+
+            def cpu_slice(k):
+                lo, hi = cuts[k], cuts[k + 1]
+                return (orc.demux_batch(table, h_bc[lo:hi], 1)[0],
+                        [orc.trim_batch(h_qual[i][lo:hi], None, MIN_BASEQ) for i in range(2)],
+                        [orc.mask_batch(h_seq[i][lo:hi], h_qual[i][lo:hi], None, MIN_BASEQ) for i in range(2)])
+            t1 = time.perf_counter()
+            if nthr == 1:
+                res = [cpu_slice(0)]
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(nthr) as ex:
+                    res = list(ex.map(cpu_slice, range(nthr)))
+            return res, time.perf_counter() - t1
+
         nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        cuts = [ns * k // nthr for k in range(nthr + 1)]
-
-        def cpu_slice(k):
-            lo, hi = cuts[k], cuts[k + 1]
-            return (orc.demux_batch(table, h_bc[lo:hi], 1)[0],
-                    [orc.trim_batch(h_qual[i][lo:hi], None, MIN_BASEQ) for i in range(2)],
-                    [orc.mask_batch(h_seq[i][lo:hi], h_qual[i][lo:hi], None, MIN_BASEQ) for i in range(2)])
-
-        t1 = time.perf_counter()
-        if nthr == 1:
-            parts = [cpu_slice(0)]
-        else:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(nthr) as ex:                     # ctypes releases the GIL around the C calls
-                parts = list(ex.map(cpu_slice, range(nthr)))
-        cpu_s = time.perf_counter() - t1
+        parts, cpu_s = run_cpu(nthr)
         e_assign = np.concatenate([p[0] for p in parts])
         e_k = [np.concatenate([p[1][i] for p in parts]) for i in range(2)]
         e_m = [np.concatenate([p[2][i] for p in parts]) for i in range(2)]
@@ -919,6 +1030,14 @@ def main():
                                   "not the Rust binary"}
         if not ok:
             raise SystemExit("PARITY FAILURE: GPU outputs differ from the oracle on the sampled clusters")
+        # the same restatement on every core this process may use (1 thread AND all host cores, count stated)
+        n_all = usable_cores()
+        if n_all > nthr and not args.no_all_cores:
+            best = min(run_cpu(n_all)[1] for _ in range(2))
+            cpu_baseline["all_cores"] = {"value": round(ns / best / 1e6, 4), "unit": "M reads/s", "cores": n_all,
+                                         "host_cores_present": os.cpu_count(),
+                                         "how": f"the same {ns} clusters cut into {n_all} contiguous slices, one thread each (affinity mask and cgroup CPU quota "
+                                                "of this process decide the count); best of two runs"}
         if args.faithful_reads > 0:
             try:
                 cpu_baseline["faithful"] = faithful_cpu(args.faithful_reads)
@@ -936,7 +1055,10 @@ def main():
         try:
             extra = {"rates": secondary_rates(torch, ctx, dev),
                      "note": "device-resident, outside the timed region, HIP events on the ctx stream; frac = algorithmic bytes / time / 8 TB/s; "
-                             "where frac_as_placed is given, frac is with the placement of the kernel's arrays chosen among 3 candidates each"}
+                             "where frac_as_placed is given, frac is with the placement of the kernel's arrays chosen among 3 candidates each; "
+                             "a row whose in+out bytes would fit the 256 MiB Infinity Cache says rows_from: its frac is measured with the rows "
+                             "coming from HBM (buffer sets in rotation, one event pair per call, ~6 us of launch + event in every call), "
+                             "frac_pipelined the same rotation inside one event pair, frac_warm the replay on one on-die set"}
         except Exception as e:
             extra = {"error": str(e)}
 

@@ -234,13 +234,32 @@ int sk_free_device(sk_ctx *c, void *p)
 // Pinned memory belongs to the process, not to a ctx (hipHostMallocPortable: page-locked for every device).  These two write
 // NOTHING to the ctx — not even an error message: the hosts' worker threads call them on a ctx that another thread is running a
 // pass on, and the message buffer of a ctx has one writer at a time — they return the code and sk_last_error is unchanged.
-// They do make the ctx's device the calling thread's current one first (hipSetDevice is thread-local and touches no ctx state):
-// on a thread that has no current device yet, the runtime would otherwise bring up a context on device 0 for the allocation.
+// They do make the ctx's device the calling thread's current one for the call (hipSetDevice is thread-local and touches no ctx
+// state): on a thread that has no current device yet, the runtime would otherwise bring up a context on device 0 for the
+// allocation.  The thread's own current device is put back before they return — a worker thread that also drives another ctx,
+// another device or torch keeps launching where it was.
+namespace {
+struct ThreadDevice {              // the calling thread's current device for the lifetime of the object
+	int saved = -1;
+	bool ok;
+	explicit ThreadDevice(int device)
+	{
+		if (hipGetDevice(&saved) != hipSuccess) { (void)hipGetLastError(); saved = -1; }
+		ok = hipSetDevice(device) == hipSuccess;
+		if (!ok) (void)hipGetLastError();
+	}
+	~ThreadDevice()
+	{
+		if (saved >= 0 && hipSetDevice(saved) != hipSuccess) (void)hipGetLastError();
+	}
+};
+}  // namespace
 int sk_malloc_pinned(sk_ctx *c, size_t bytes, void **out)
 {
 	if (!c || !out) return SK_ERR_INVALID;
 	*out = nullptr;
-	if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
+	ThreadDevice td(c->device);
+	if (!td.ok) return SK_ERR_HIP;
 	if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return SK_ERR_NOMEM; }
 	return SK_OK;
 }
@@ -248,9 +267,10 @@ int sk_free_pinned(sk_ctx *c, void *p)
 {
 	if (!c) return SK_ERR_INVALID;
 	if (!p) return SK_OK;
-	if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
+	ThreadDevice td(c->device);
+	// (the pointer is freed even when the device could not be bound: portable pinned memory belongs to the process)
 	if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return SK_ERR_HIP; }
-	return SK_OK;
+	return td.ok ? SK_OK : SK_ERR_HIP;
 }
 int sk_copy_h2d(sk_ctx *c, void *dst, const void *src, size_t bytes)
 {
@@ -722,7 +742,7 @@ static int prepare_demux(sk_ctx *c, const sk_fused_args *a)
 	// takes the table like a demultiplex-alone call)
 	bool any_mate = false;
 	for (int m = 0; m < a->n_mates; m++) any_mate = any_mate || a->mate[m].out_seq || a->mate[m].lowest_k;
-	if (any_mate && c->d_bs && c->G <= 4 && 64 * a->bc_stride <= 2048 && !getenv("SK_NO_FUSED_DEMUX")) return SK_OK;
+	if (sk::tile_pass_fuses_demux(true, any_mate, a->stride, c->d_bs != nullptr, c->G, c->S, a->bc_stride)) return SK_OK;
 	const bool want_detail = a->lowest_diff || a->first_idx || a->last_idx;
 	if (want_detail && c->detail_mode != SK_DETAIL_MATCHED) return SK_OK;
 	return ensure_neighbour_table(c);

@@ -101,6 +101,8 @@ bool blocked_shape_ok(const BlockedArgs &a);
 
 // launchers (all asynchronous on `st`); return hipError_t of the launch
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st);
+// whether launch_tile_pass matches the barcodes inside the tile pass (bit-sliced matcher) instead of with a launch of their own
+bool tile_pass_fuses_demux(bool has_bc, bool any_mate, int stride, bool has_bitsliced, int G, int S, int bc_stride);
 hipError_t launch_mask_flat(const uint8_t *seq, const uint8_t *qual, uint8_t *out, int64_t bytes,
                             const QualConsts &qc, int n_cu, hipStream_t st);
 hipError_t launch_bam_flag_tlen(const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,

@@ -846,7 +846,9 @@ __global__ __launch_bounds__(256) void counts_fold_wide_kernel(unsigned long lon
 			const unsigned long long v = *p;
 			if (v) { sum += v; *p = 0; }
 		}
-		if (sum) counts[i] += sum;
+		// `identified` IS the sum of the samples' bins (src/fasta_demultiplex.rs:177-178 add to both or to neither): it is taken
+		// from them, and whatever a kernel may have added to the copies' own `identified` is dropped, not added on top
+		if (sum && i != nc - 2) counts[i] += sum;
 		if (i < nc - 3) mine += sum;
 	}
 	if (mine) atomicAdd(&identified, mine);
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256) void counts_fold_kernel(unsigned long long *__
 		unsigned long long sum = 0;
 #pragma unroll
 		for (int r = 0; r < kCountReplicas; r++) { sum += rep[(size_t)r * pitch + i]; rep[(size_t)r * pitch + i] = 0; }
-		if (sum) atomicAdd(&counts[i], sum);
+		if (sum && !(derive && i == nc - 2)) atomicAdd(&counts[i], sum);      // (derive: `identified` comes from the samples' bins alone)
 		if (i < nc - 3) mine += sum;
 	}
 	if (!derive) return;
@@ -1346,19 +1348,41 @@ __global__ __launch_bounds__(256) void demux_tile_kernel(const TileArgs a, const
 	flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
+// Tuning knobs of the lookup kernels (tools/lut_cold_ab.py builds variants and times them with their rows coming from HBM).
+// Round 5's cold measurements, 100 M rows in one call: tiles of a wave on their way 1 / 2 / 4 — the same time (the launch waits
+// for the memory side, not for latency); nt on the result stores -2.5 ... -3 % for every shape; nt on the row loads -5 % for the
+// coalesced 16-byte loads of demux_lut8x2_kernel and +3 ... +5 % for gathered rows (a line serves two or three wave instructions
+// there; nt drops it after the first).
+#ifndef SK_LUT_DEPTH
+#define SK_LUT_DEPTH 2
+#endif
+#ifndef SK_LUT_PAIR_DEPTH
+#define SK_LUT_PAIR_DEPTH 4
+#endif
+#ifndef SK_LUT_AUX
+#define SK_LUT_AUX 0                     // cache policy of gathered and one-row-per-lane loads (2 = nt)
+#endif
+#ifndef SK_LUT8_AUX
+#define SK_LUT8_AUX 2                    // of demux_lut8x2_kernel's coalesced 16-byte loads
+#endif
+#ifndef SK_LUT_ST_AUX
+#define SK_LUT_ST_AUX 2                  // of the result stores
+#endif
+constexpr int kLutAux = SK_LUT_AUX, kLut8Aux = SK_LUT8_AUX, kLutStAux = SK_LUT_ST_AUX;
+
 // N consecutive dwords at a dword-aligned byte offset of a raw buffer (clipped per dword): the widest loads that cover them
 template <int N> __device__ __forceinline__ void gather_dwords(rsrc_t rb, int off, u32 (&d)[N])
 {
 	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 	typedef u32 u32x3_t __attribute__((ext_vector_type(3)));
 	static_assert(N >= 2 && N <= 6, "a key segment of one to five dwords and the dword behind it");
-	if constexpr (N == 2) { const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, 0); d[0] = v[0]; d[1] = v[1]; }
-	else if constexpr (N == 3) { const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rb, off, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+	if constexpr (N == 2) { const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, kLutAux); d[0] = v[0]; d[1] = v[1]; }
+	else if constexpr (N == 3) { const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rb, off, 0, kLutAux); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
 	else {
-		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, kLutAux);
 		d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-		if constexpr (N == 5) d[4] = __builtin_amdgcn_raw_buffer_load_b32(rb, off + 16, 0, 0);
-		if constexpr (N == 6) { const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rb, off + 16, 0, 0); d[4] = w[0]; d[5] = w[1]; }
+		if constexpr (N == 5) d[4] = __builtin_amdgcn_raw_buffer_load_b32(rb, off + 16, 0, kLutAux);
+		if constexpr (N == 6) { const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rb, off + 16, 0, kLutAux); d[4] = w[0]; d[5] = w[1]; }
 	}
 }
 
@@ -1391,7 +1415,8 @@ __device__ __forceinline__ u32 lut_classes(u32 dw, const LutDev &t)
 //   LDSTAB : the table fits the workgroup's LDS (<= 128 KiB); else it is read through the vector cache
 //   DETAIL : lowest_diff / first_idx / last_idx are written too
 // Two tiles per wave are always in flight (register slots), so that a CU of sixteen waves has ~34 KiB on the way.  There
-// is no branch around a VMEM instruction in the loop: the waits for the register slots are counted, not drained.
+// is no branch around a VMEM instruction in the loop but the narrow columns of a call's last, partial quad: the waits for the
+// register slots are counted, not drained.
 // ---------------------------------------------------------------------------------------------------
 //   PAIR   : the factored form of sk_lut.h (a sheet `i7+i5` whose full-key table would not fit the LDS): one lookup per half
 //            (-> half id, distance) and one of the pair of ids (-> first / last sample); three small tables in one LDS blob
@@ -1410,10 +1435,11 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int S = a.table.S;
 	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
 	const int bstride = a.bc_stride;
-	// tiles of a wave on their way: two — three and four are slower (96 dual-index 35.4 / 36.6 / 37.7 us at 10 M pairs, 12 columns
-	// 27.5 / - / 34.0) — but for the factored form, whose three lookups per row leave a tile's loads more time to hide in
-	// (384 dual-index 50.4 / 44.0 / 45.7 us)
-	constexpr int kDepth = PAIR ? 3 : 2;
+	// tiles of a wave on their way: two (a quad's four tiles take the register slots in turn: 1, 2 or 4; replayed on on-die rows
+	// at 10 M pairs more were slower in round 4, from HBM 1 / 2 / 4 take the same time); four for the factored form, whose three
+	// lookups per row leave a tile's loads more time to hide in
+	constexpr int kDepth = PAIR ? SK_LUT_PAIR_DEPTH : SK_LUT_DEPTH;
+	static_assert(kDepth == 1 || kDepth == 2 || kDepth == 4, "a quad's four tiles take the register slots in turn");
 	u32 raw[kDepth][W];
 	// GATHER (every shape but DIRECT): a lane fetches the dwords its row's key lies in straight from memory, at any alignment —
 	// W1 + 1 dwords from the one that holds the row's first byte and, with a separator, W2 + 1 from the one that holds the byte
@@ -1433,19 +1459,25 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		const rsrc_t rb = make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kTileRows * bstride), (rows * bstride + 3) & ~3);
 		if (DIRECT) {
 			if (W == 2) {
-				const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, lane * bstride, 0, 0);
+				const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, lane * bstride, 0, kLutAux);
 				raw[s][0] = v[0]; raw[s][W - 1] = v[1];
 			} else {
-				raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride, 0, 0);
+				raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * bstride, 0, kLutAux);
 			}
 		} else {
 			gather_dwords<W1 + 1>(rb, rs & ~3, g1[s]);
 			if constexpr (W2 > 0) gather_dwords<W2 + 1>(rb, rs2 & ~3, g2[s]);
 		}
 	};
-	const int tstep = (int)gridDim.x * nwave;
-	int tb = (int)blockIdx.x * nwave + wave;
-	for (int s = 0; s < kDepth; s++) fetch(tb + s * tstep, s);
+	// A wave's unit of work is a QUAD: four consecutive tiles = 256 consecutive rows, whose codes leave as ONE 16-byte store per
+	// lane.  (Through round 5's first session a tile's codes left as a 4-byte store per lane: at 100 M pairs the kernel took
+	// 410 us with those stores and 293 without them, and the same 410 with the lookups taken out — the narrow stores were what
+	// the launch waited for, tools/lut_cold_ab.py.)  The four codes of a lane belong to rows 64 j + lane; they change places
+	// through 1 KiB of LDS per wave (four ds_write_b32, one ds_read_b128, all conflict-free; a wave's LDS operations execute in
+	// order, so nothing waits but the read's consumer).
+	const int qstep = (int)gridDim.x * nwave;
+	int qb = (int)blockIdx.x * nwave + wave;
+	for (int s = 0; s < kDepth; s++) fetch(4 * qb + s, s);
 	
 	// the table and the histogram while the first tiles are on their way
 	if (lp.use_lds_hist) for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
@@ -1488,19 +1520,25 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	};
 	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
 	u32 n_total = 0;
-	for (; tb < nt32; tb += kDepth * tstep) {
+	u32 *tp = reinterpret_cast<u32 *>(sk_smem + lp.tiles_off + wave * lp.tile_slot);
+	const int nq32 = (nt32 + 3) >> 2;
+	for (; qb < nq32; qb += qstep) {
+		int code[4], dtot[4], dfirst[4], dlast[4];
 #pragma unroll
-		for (int s = 0; s < kDepth; s++) {
-			const int ti = tb + s * tstep;
+		for (int j = 0; j < 4; j++) {
+			constexpr int kD = kDepth;
+			const int s = j % kD;
+			const int ti = 4 * qb + j;
 			const int rows = rows_of(ti);
-			const int64_t ro = (int64_t)(rows ? ti : 0) * kTileRows;
 			const bool active = lane < rows;
+			const int nj = j + kD;                                       // the tile that takes this one's register slot
+			const int tnext = nj < 4 ? 4 * qb + nj : 4 * (qb + qstep) + (nj - 4);
 			u32 d[W];
 			u32 sepbad = 0u;
 			if (DIRECT) {
 #pragma unroll
 				for (int w = 0; w < W; w++) d[w] = raw[s][w];
-				fetch(ti + kDepth * tstep, s);
+				fetch(tnext, s);
 			} else {
 #pragma unroll
 				for (int w = 0; w < W1; w++) d[w] = __builtin_amdgcn_alignbyte(g1[s][w + 1], g1[s][w], sh1);
@@ -1509,7 +1547,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 					for (int w = 0; w < W2; w++) d[W1 + w] = __builtin_amdgcn_alignbyte(g2[s][w + 1], g2[s][w], sh2);
 					sepbad = __builtin_amdgcn_perm(g1[s][W1], g1[s][W1 - 1], sep_sel) != t.sep_val ? 1u : 0u;
 				}
-				fetch(ti + kDepth * tstep, s);
+				fetch(tnext, s);
 			}
 			// classes: the index of the sheet letter a byte equals, `other` for every byte the sheet never uses
 			u32 c[5] = {0u, 0u, 0u, 0u, 0u};
@@ -1567,18 +1605,59 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				idx = (int)__builtin_amdgcn_ubfe(w1, (u32)t.idx_shift, idx_bits);
 				amb = (int)w1 < 0;
 			}
-			const int code = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
-			__builtin_amdgcn_raw_buffer_store_b32((u32)code, make_rsrc(a.assign, ro * 4, rows * 4), lane * 4, 0, 0);
+			code[j] = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
 			if (DETAIL) {
 				int first = idx, last = idx;
 				if (PAIR) { first = pfirst; last = plast; }
 				else if (found && amb) { first = t.amb[2 * idx]; last = t.amb[2 * idx + 1]; }
-				__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(found ? tot : 255), make_rsrc(a.lowest_diff, ro, rows), lane, 0, 0);
-				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? first : -1), make_rsrc(a.first_idx, ro * 2, rows * 2), lane * 2, 0, 0);
-				__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found ? last : -1), make_rsrc(a.last_idx, ro * 2, rows * 2), lane * 2, 0, 0);
+				dtot[j] = found ? tot : 255; dfirst[j] = found ? first : -1; dlast[j] = found ? last : -1;
 			}
 			if (active && found) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);   // S + 3 <= kMaxLdsHist: the histogram is always in LDS
 			n_total += (u32)rows;
+		}
+		// the quad's outputs
+		const int64_t ro = (int64_t)qb * (4 * kTileRows);
+		const int rows_q = (int)(a.n - ro < 4 * kTileRows ? a.n - ro : 4 * kTileRows);
+#pragma unroll
+		for (int j = 0; j < 4; j++) tp[kTileRows * j + lane] = (u32)code[j];
+		wave_lds_fence();
+		const u32x4 cv = *reinterpret_cast<const u32x4 *>(tp + 4 * lane);
+		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(a.assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
+		if (DETAIL) {
+			if (rows_q == 4 * kTileRows) {
+				// (the same exchange for the three narrow columns, one after the other through the same 1 KiB: 4 bytes, 8 and 8 per lane)
+				wave_lds_fence();
+				uint8_t *tp8 = reinterpret_cast<uint8_t *>(tp);
+#pragma unroll
+				for (int j = 0; j < 4; j++) tp8[kTileRows * j + lane] = (uint8_t)dtot[j];
+				wave_lds_fence();
+				const u32 dv = tp[lane];
+				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(a.lowest_diff, ro, rows_q), lane * 4, 0, kLutStAux);
+				wave_lds_fence();
+				unsigned short *tp16 = reinterpret_cast<unsigned short *>(tp);
+#pragma unroll
+				for (int j = 0; j < 4; j++) tp16[kTileRows * j + lane] = (unsigned short)dfirst[j];
+				wave_lds_fence();
+				const u32x2_t fv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
+				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(a.first_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				wave_lds_fence();
+#pragma unroll
+				for (int j = 0; j < 4; j++) tp16[kTileRows * j + lane] = (unsigned short)dlast[j];
+				wave_lds_fence();
+				const u32x2_t lv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
+				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(a.last_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				wave_lds_fence();
+			} else {
+				// the call's last, partial quad: a descriptor clips whole elements, so the narrow columns go row by row
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const int rj = rows_q - kTileRows * j < 0 ? 0 : (rows_q - kTileRows * j > kTileRows ? kTileRows : rows_q - kTileRows * j);
+					const int64_t rt = ro + kTileRows * j;
+					__builtin_amdgcn_raw_buffer_store_b8((uint8_t)dtot[j], make_rsrc(a.lowest_diff, rj ? rt : 0, rj), lane, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dfirst[j], make_rsrc(a.first_idx, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dlast[j], make_rsrc(a.last_idx, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
+				}
+			}
 		}
 	}
 	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
@@ -1591,8 +1670,9 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 }
 
 // The same lookup for rows of exactly 8 bytes on an 8-byte pitch (cfg 3), TWO rows per lane: a tile is 128 rows, a lane loads
-// its two rows with one 16-byte load (1 KiB per wave instruction instead of 512 B) and stores their two codes with one 8-byte
-// store; the per-tile scalar work (descriptors, clipping, counters) is paid once per 128 rows.  Everything per row is as above.
+// its two rows with one 16-byte load (1 KiB per wave instruction instead of 512 B, nt: read once); a wave's step is two
+// consecutive tiles, whose four codes per lane leave as one 16-byte store after changing lanes through LDS; the per-tile scalar
+// work (descriptors, clipping, counters) is paid once per 128 rows.  Everything per row is as above.
 template <bool LDSTAB, bool DETAIL>
 __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const TileArgs a, const LdsPlan lp)
 {
@@ -1607,15 +1687,18 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	const int64_t ntiles = (a.n + kRows - 1) / kRows;
 	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kRows);
 	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kRows : (ti == nt32 - 1 ? last_rows : 0); };
-	u32x4 raw[2];
+	constexpr int kDepth = 2;                                            // halves of a step on their way (one step = 2 KiB per wave)
+	u32x4 raw[kDepth];
 	auto fetch = [&](int ti, int s) {
 		const int rows = rows_of(ti);
-		raw[s] = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kRows * 8), rows * 8), lane * 16, 0, 0);
+		raw[s] = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kRows * 8), rows * 8), lane * 16, 0, kLut8Aux);
 	};
-	const int tstep = (int)gridDim.x * nwave;
-	int tb = (int)blockIdx.x * nwave + wave;
-	fetch(tb, 0);
-	fetch(tb + tstep, 1);
+	// a wave's step is two consecutive tiles = 256 consecutive rows, whose four codes per lane leave as ONE 16-byte store (as
+	// demux_lut_kernel's quads: two ds_write_b64, one ds_read_b128 through 1 KiB of LDS per wave)
+	const int qstep = (int)gridDim.x * nwave;
+	int qb = (int)blockIdx.x * nwave + wave;
+#pragma unroll
+	for (int s = 0; s < kDepth; s++) fetch(2 * qb + s, s);
 	for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
 	const int ltab_off = lp.tiles_off - lp.table_bytes;
 	if (LDSTAB) {
@@ -1654,16 +1737,16 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	};
 	const u32 idx_bits = (u32)__builtin_popcount(t.idx_mask);
 	u32 n_total = 0;
-	for (; tb < nt32; tb += 2 * tstep) {
+	u32 *tp = reinterpret_cast<u32 *>(sk_smem + lp.tiles_off + wave * lp.tile_slot);
+	const int nq32 = (nt32 + 1) >> 1;
+	for (; qb < nq32; qb += qstep) {
+		int code[2][2], tot[2][2], first[2][2], last[2][2];
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
-			const int ti = tb + s * tstep;
+			const int ti = 2 * qb + s;
 			const int rows = rows_of(ti);
-			const int64_t ro = (int64_t)(rows ? ti : 0) * kRows;
 			const u32x4 d = raw[s];
-			fetch(ti + 2 * tstep, s);
-			int code[2], tot[2], first[2], last[2];
-			bool found[2];
+			fetch(2 * (qb + qstep) + s, s);
 #pragma unroll
 			for (int r = 0; r < 2; r++) {
 				u32 c[5] = {0u, 0u, 0u, 0u, 0u};
@@ -1683,28 +1766,68 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				else { e1 = entry(lut_slot(x, t.nb)); e2 = entry2(lut_slot(y, t.nb)); }
 				const u32 m1 = (e1[1] ^ x) & t.tag_mask, m2 = (e2[1] ^ y) & t.tag_mask;
 				const u32 w0 = m1 == 0u ? e1[0] : e2[0], w1 = m1 == 0u ? e1[1] : e2[1];
-				tot[r] = (int)(w0 >> 31);                         // (the table holds no key beyond max_diff, and these rows have no separator)
-				found[r] = m1 == 0u || m2 == 0u;
+				const bool found = m1 == 0u || m2 == 0u;
 				const int idx = (int)__builtin_amdgcn_ubfe(w1, (u32)t.idx_shift, idx_bits);
 				const bool amb = (int)w1 < 0;
-				code[r] = found[r] ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
-				first[r] = last[r] = idx;
-				if (DETAIL && found[r] && amb) { first[r] = t.amb[2 * idx]; last[r] = t.amb[2 * idx + 1]; }
+				code[s][r] = found ? (amb ? kAssignAmbiguous : idx) : kAssignNone;
+				if (DETAIL) {
+					int f = idx, l = idx;
+					if (found && amb) { f = t.amb[2 * idx]; l = t.amb[2 * idx + 1]; }
+					tot[s][r] = found ? (int)(w0 >> 31) : 255;       // (the table holds no key beyond max_diff, and these rows have no separator)
+					first[s][r] = found ? f : -1; last[s][r] = found ? l : -1;
+				}
 				const bool active = 2 * lane + r < rows;
-				if (active && found[r]) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);
+				if (active && found) atomicAdd(amb ? &hist[S + 2] : &hist[idx], 1u);
 			}
 			n_total += (u32)rows;
-			u32x2_t cv;
-			cv[0] = (u32)code[0]; cv[1] = (u32)code[1];
-			__builtin_amdgcn_raw_buffer_store_b64(cv, make_rsrc(a.assign, ro * 4, rows * 4), lane * 8, 0, 0);
-			if (DETAIL) {
-				// narrow stores per row: a descriptor clips whole elements, and a two-row element at an odd row count would lose its first row
-				const rsrc_t rd = make_rsrc(a.lowest_diff, ro, rows), rf = make_rsrc(a.first_idx, ro * 2, rows * 2), rl = make_rsrc(a.last_idx, ro * 2, rows * 2);
+		}
+		// the step's outputs: lane l holds rows 2 l, 2 l + 1 of either tile; it leaves with rows 4 l ... 4 l + 3 of the step
+		const int64_t ro = (int64_t)qb * (2 * kRows);
+		const int rows_q = (int)(a.n - ro < 2 * kRows ? a.n - ro : 2 * kRows);
 #pragma unroll
-				for (int r = 0; r < 2; r++) {
-					__builtin_amdgcn_raw_buffer_store_b8((uint8_t)(found[r] ? tot[r] : 255), rd, lane * 2 + r, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found[r] ? first[r] : -1), rf, lane * 4 + 2 * r, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(found[r] ? last[r] : -1), rl, lane * 4 + 2 * r, 0, 0);
+		for (int s = 0; s < 2; s++) {
+			u32x2_t v;
+			v[0] = (u32)code[s][0]; v[1] = (u32)code[s][1];
+			*reinterpret_cast<u32x2_t *>(tp + kRows * s + 2 * lane) = v;
+		}
+		wave_lds_fence();
+		const u32x4 cv = *reinterpret_cast<const u32x4 *>(tp + 4 * lane);
+		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(a.assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
+		if (DETAIL) {
+			if (rows_q == 2 * kRows) {
+				wave_lds_fence();
+				unsigned short *tp16 = reinterpret_cast<unsigned short *>(tp);
+#pragma unroll
+				for (int s = 0; s < 2; s++) tp16[(kRows * s) / 2 + lane] = (unsigned short)((tot[s][0] & 0xff) | (tot[s][1] << 8));
+				wave_lds_fence();
+				const u32 dv = tp[lane];
+				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(a.lowest_diff, ro, rows_q), lane * 4, 0, kLutStAux);
+				wave_lds_fence();
+#pragma unroll
+				for (int s = 0; s < 2; s++) tp[(kRows * s) / 2 + lane] = ((u32)first[s][0] & 0xffffu) | ((u32)first[s][1] << 16);
+				wave_lds_fence();
+				const u32x2_t fv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
+				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(a.first_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				wave_lds_fence();
+#pragma unroll
+				for (int s = 0; s < 2; s++) tp[(kRows * s) / 2 + lane] = ((u32)last[s][0] & 0xffffu) | ((u32)last[s][1] << 16);
+				wave_lds_fence();
+				const u32x2_t lv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
+				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(a.last_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				wave_lds_fence();
+			} else {
+				// the call's last, partial step: a descriptor clips whole elements, so the narrow columns go row by row
+#pragma unroll
+				for (int s = 0; s < 2; s++) {
+					const int rj = rows_q - kRows * s < 0 ? 0 : (rows_q - kRows * s > kRows ? kRows : rows_q - kRows * s);
+					const int64_t rt = rj ? ro + kRows * s : 0;
+					const rsrc_t rd = make_rsrc(a.lowest_diff, rt, rj), rf = make_rsrc(a.first_idx, rt * 2, rj * 2), rl = make_rsrc(a.last_idx, rt * 2, rj * 2);
+#pragma unroll
+					for (int r = 0; r < 2; r++) {
+						__builtin_amdgcn_raw_buffer_store_b8((uint8_t)tot[s][r], rd, lane * 2 + r, 0, 0);
+						__builtin_amdgcn_raw_buffer_store_b16((unsigned short)first[s][r], rf, lane * 4 + 2 * r, 0, 0);
+						__builtin_amdgcn_raw_buffer_store_b16((unsigned short)last[s][r], rl, lane * 4 + 2 * r, 0, 0);
+					}
 				}
 			}
 		}
@@ -1886,6 +2009,17 @@ static const void *tile_pass_fn(int mode)
 	}
 }
 
+// ONE statement of when the barcode phase rides in the tile pass: launch_tile_pass decides with it, and the C-ABI layer asks it
+// whether a call needs the neighbourhood table built (a call that does not fuse takes the table for its barcode launch; were
+// the two to disagree, no table would be there and the S x L matchers would run instead: correct, 10-50 x slower).
+// any_mate = some mate has work; a stride beyond kMaxTileStride sends the mates to the fallback kernels, which fuse nothing.
+// SK_NO_FUSED_DEMUX (tests, tools) is read once per process.
+bool tile_pass_fuses_demux(bool has_bc, bool any_mate, int stride, bool has_bitsliced, int G, int S, int bc_stride)
+{
+	static const bool env_no_fuse = getenv("SK_NO_FUSED_DEMUX") != nullptr;
+	return has_bc && any_mate && stride <= kMaxTileStride && has_bitsliced && G <= 4 && S > 0 && kTileRows * bc_stride <= 2048 && !env_no_fuse;
+}
+
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
@@ -1914,8 +2048,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 	}
 	// the barcode phase rides in the tile pass when the bit-sliced matcher applies (S <= 128) and the tile's
 	// barcodes fit two 1 KiB register chunks; otherwise it is its own launch beside the mate pass
-	static const bool env_no_fuse = getenv("SK_NO_FUSED_DEMUX") != nullptr;
-	const bool fuse_demux = b.bc && any_mate && b.table.bs && b.table.G <= 4 && b.table.S > 0 && kTileRows * b.bc_stride <= 2048 && !env_no_fuse;
+	const bool fuse_demux = tile_pass_fuses_demux(b.bc != nullptr, any_mate, b.stride, b.table.bs != nullptr, b.table.G, b.table.S, b.bc_stride);
 	if (b.bc && !fuse_demux) {
 		// the sheet has a neighbourhood table and the call wants the decision alone, or the detail columns of matched rows
 		// only (TileArgs::detail_matched): one lookup per read
@@ -1952,8 +2085,11 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			lp.hist_off = 0;
 			lp.table_bytes = ldstab ? table_bytes : 0;
 			lp.tiles_off = (((b.table.S + 3) * 4 + 15) & ~15) + lp.table_bytes;
-			lp.tile_slot = 2 * kLdsPad;                               // rows come straight from memory: no image
-			int nw = ldstab ? 16 : 4;                                 // sixteen waves share a table copy
+			lp.tile_slot = 4 * kTileRows * 4;                         // rows come straight from memory: no image; 1 KiB per wave in which a quad's codes change lanes
+			// sixteen waves share a table copy; eight once the call is long and the table leaves room for one workgroup per CU only
+			// (rows from HBM, 100 M pairs of the 96 dual-index sheet: 381 us against 398; shorter calls want the waves)
+			int nw = ldstab ? ((lp.table_bytes > (64 << 10) && b.n >= 4000000) ? 8 : 16) : 4;
+			if (const char *env_nw = getenv("SK_LUT_NW")) { const int v = atoi(env_nw); if (v >= 1 && v <= 16) nw = v; }      // tuning (tools/lut_cold_ab.py)
 			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
 			const int lds = lp.tiles_off + nw * lp.tile_slot;
 			struct Occ { int dev; const void *fn; int lds, wg; };
@@ -1974,7 +2110,8 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 				std::lock_guard<std::mutex> lk(occ_m);
 				occ.push_back({dev, fn, lds, wg});
 			}
-			const int tile_rows = rows2 ? 2 * kTileRows : kTileRows;
+			if (const char *env_wg = getenv("SK_LUT_WG")) { const int v = atoi(env_wg); if (v >= 1 && v < wg) wg = v; }
+			const int tile_rows = 4 * kTileRows;                      // a wave's unit: 256 rows in either kernel
 			const int64_t ntiles = (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;
 			// a few hundred workgroups add to the counters directly; thousands go through the spread copies and the fold

@@ -163,6 +163,11 @@ int main(int argc, char **argv)
 		}
 		if (kind == 1 && L >= 4) for (int s = 0; s < S; s++) for (int k = L - 3; k < L; k++) sheet[(size_t)s * L + k] = 'U';
 		if (kind == 2) for (auto &b : sheet) if (pick(10) == 0) b = 'N';
+		// wildcards of single rows beside a separator: sprinkled BEFORE the separator column is written (kind 4) and into the letter
+		// columns of a dual-index sheet — the per-class enumeration of such rows together with sep_off / the keep masks, and the
+		// `mixed` gate that keeps such a sheet out of the factored form
+		const bool sprinkle = (kind == 4 || (it % 4 == 1 && it % 3 == 0)) && pick(2) == 0;
+		if (sprinkle) for (auto &b : sheet) if (b != '+' && pick(12) == 0) b = pick(2) ? 'N' : 'U';
 		if (kind >= 3 && L >= 3) { const int c = pick(L); for (int s = 0; s < S; s++) sheet[(size_t)s * L + c] = '+'; }      // a separator (when '+' is nowhere else)
 		if (S >= 3 && pick(3) == 0) memcpy(&sheet[2 * (size_t)L], &sheet[0], (size_t)L);                                       // duplicate rows
 		const int max_diff = pick(4) == 0 ? 0 : 1;

@@ -14,7 +14,11 @@ from seqkit_amd import build
 @pytest.fixture(scope="module")
 def census_isa(tmp_path_factory):
     out = tmp_path_factory.mktemp("isa") / "census.s"
-    r = subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+    try:
+        hipcc = build._hipcc()
+    except RuntimeError as e:                           # no compiler on this machine: nothing to check (the build check fails elsewhere)
+        pytest.skip(str(e))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                         "-o", str(out), os.path.join(build.CSRC, "sk_census.hip")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     return out.read_text(), r.stdout

@@ -530,6 +530,24 @@ def test_demux_counters_across_launches(ctx, oracle, monkeypatch, want_detail, c
         assert np.array_equal(ctx.counts().astype(np.uint64), counts_of(e_assign[:5000]))
 
 
+def test_matcher_and_table_launches_share_the_ctx_counters(ctx, oracle):
+    """A call with the full detail columns runs the matchers, a call without them the table lookup; both add to the ctx's
+    counters, the lookups through the wide copies whose `identified` the fold derives from the samples' bins (sk_kernels.hip,
+    counts_fold_wide_kernel).  Interleaved on one sheet: the counters are the oracle's, and identified == sum of the samples."""
+    for S, dual in ((16, False), (96, True), (200, True)):
+        table = synth.make_sheet(S, 8, dual=dual, seed=21)
+        bc, _ = synth.observe_barcodes(table, 300_000, seed=22, halves=2 if dual else 1)
+        ctx.set_barcodes(table, 1)
+        ctx.counts_reset()
+        e = oracle.demux_batch(table, bc, 1)
+        for k, want_detail in enumerate((True, False, False, True, False)):
+            assign, *_ = ctx.demux_assign(bc, want_detail=want_detail)
+            assert np.array_equal(assign, e[0])
+            got = ctx.counts().astype(np.uint64)
+            assert np.array_equal(got, (k + 1) * e[4].astype(np.uint64)), (S, k, got[S:], e[4][S:])
+            assert int(got[S + 1]) == int(got[:S].sum())
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SK_FUZZ_SEEDS", "48"))))      # SK_FUZZ_SEEDS=400: the long run, once per round on the GPU box
 def test_fuzz_demux_by_table(ctx, oracle, seed, monkeypatch):
     """Sheets with and without a lookup table: wildcard columns (all rows / some rows), a separator, duplicates, lower case

@@ -34,82 +34,17 @@ def timeit(name, fn, units, bytes_per_unit, iters=10, rounds=5):
     print(f"{name:58s} {ms:9.4f} ms  {units / ms / 1e3:10.1f} M units/s  {units * bytes_per_unit / ms / 1e6:8.1f} GB/s ({units * bytes_per_unit / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
 
 
-# cfg 2: trim by quality, 1M x 150 (and 16M for a bandwidth-sized run)
-for n in (1_000_000, 16_000_000):
-    q = torch.randint(35, 74, (n, 150), dtype=torch.uint8, device=dev, generator=g)
-    lk = torch.empty((n,), dtype=torch.int16, device=dev)
-    timeit(f"cfg2 trim by quality {n} x 150bp (152 B/read)", lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
-    s = torch.randint(65, 85, (n, 150), dtype=torch.uint8, device=dev, generator=g)
-    o = torch.empty_like(s)
-    timeit(f"cfg1-shape mask by quality {n} x 150bp (450 B/read)", lambda: ctx.mask_by_quality_dev(s.data_ptr(), q.data_ptr(), 150, n, 20, o.data_ptr()), n, 450)
-    if n == 16_000_000:
-        # the fused pass in the forms BASELINE.md §3 names beside the paired headline (same rows as bench.py's extra.rates)
-        from seqkit_amd import capi as _capi
-        t16 = synth.make_sheet(16, 8, dual=False, seed=3)
-        ctx.set_barcodes(t16, 1)
-        b_np, _ = synth.observe_barcodes(t16, 1_000_000, seed=3)
-        bc1 = torch.from_numpy(b_np).to(dev).repeat(16, 1).contiguous()
-        assign = torch.empty((n,), dtype=torch.int32, device=dev)
-        cnt = torch.zeros((96 + 3,), dtype=torch.int64, device=dev)
-        n_mates = 1
-        mate = {"seq": s.data_ptr(), "qual": q.data_ptr(), "len": 0, "out_seq": o.data_ptr(), "lowest_k": lk.data_ptr()}
-        timeit("fused single-end 16M x 150bp + 8bp, 16 barcodes (464 B/read)",
-               lambda: ctx.fused_pass_dev(n, 150, 20, [mate], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 464)
-        ln = torch.randint(100, 151, (n,), dtype=torch.int16, device=dev, generator=g)
-        mate_r = dict(mate, len=ln.data_ptr())
-        timeit("fused single-end, ragged rows 100-150 (466 B/read)",
-               lambda: ctx.fused_pass_dev(n, 150, 20, [mate_r], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 466)
-        t96 = synth.make_sheet(96, 8, dual=True, seed=4)
-        ctx.set_barcodes(t96, 1)
-        b_np, _ = synth.observe_barcodes(t96, 1_000_000, seed=4, halves=2)
-        bc2 = torch.from_numpy(b_np).to(dev).repeat(16, 1).contiguous()
-        s2, q2, o2, lk2 = s.flip(0).contiguous(), q.flip(0).contiguous(), torch.empty_like(o), torch.empty_like(lk)
-        low = torch.empty((n,), dtype=torch.uint8, device=dev)
-        first = torch.empty((n,), dtype=torch.int16, device=dev)
-        last = torch.empty((n,), dtype=torch.int16, device=dev)
-        n_mates = 2
-        mates2 = [mate, {"seq": s2.data_ptr(), "qual": q2.data_ptr(), "len": 0, "out_seq": o2.data_ptr(), "lowest_k": lk2.data_ptr()}]
-        ctx.set_detail_mode(_capi.SK_DETAIL_MATCHED)
-        timeit("fused paired + detail of matched clusters, 16M x 2x150bp, 96 dual-index (930 B/cluster)",
-               lambda: ctx.fused_pass_dev(n, 150, 20, mates2, bc=bc2.data_ptr(), bc_stride=17, assign=assign.data_ptr(), lowest_diff=low.data_ptr(),
-                                          first_idx=first.data_ptr(), last_idx=last.data_ptr(), counts=cnt.data_ptr()), n, 930)
-        ctx.set_detail_mode(_capi.SK_DETAIL_FULL)
-        del bc1, bc2, s2, q2, o2, lk2, low, first, last, assign, cnt, ln
-    del q, lk, s, o
-
-# cfg 3: demultiplex 10M x 8bp, 16 barcodes
-n = 10_000_000
-table = synth.make_sheet(16, 8, dual=False, seed=3)
-ctx.set_barcodes(table, 1)
-bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=3)
-bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
-assign = torch.empty((n,), dtype=torch.int32, device=dev)
-timeit("cfg3 demultiplex 10M x 8bp, 16 barcodes (12 B/read)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 8, n, assign.data_ptr()), n, 12)
+# the rows of bench.py's extra.rates (one source for both): every BASELINE config device-resident; rows whose bytes would fit
+# the Infinity Cache are timed with their rows coming from HBM (frac), pipelined and replayed on-die (frac_warm)
+for r in bench.secondary_rates(torch, ctx, dev):
+    extra = ""
+    if "frac_warm" in r:
+        extra = f"   [pipelined {r['ms_pipelined'] * 1e3:.1f} us {r['frac_pipelined']:.3f}; on-die replay {r['ms_warm'] * 1e3:.1f} us {r['frac_warm']:.3f}]"
+    if "frac_as_placed" in r:
+        extra += f"   [as placed {r['frac_as_placed']:.3f}]"
+    print(f"{r['config'][:100]:100s} {r['ms'] * 1e3:9.1f} us {r['G_units_per_s']:8.2f} G units/s  {r['frac']:.3f} of 8 TB/s{extra}", flush=True)
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 ctx.set_barcodes(table, 1)
-bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
-bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
-timeit("demultiplex only 10M x 17ch, 96 dual-index (21 B/pair)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
-table = synth.make_sheet(384, 8, dual=True, seed=384)
-ctx.set_barcodes(table, 1)
-bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
-bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
-timeit("demultiplex only 10M x 17ch, 384 dual-index, half by half (21 B/pair)", lambda: ctx.demux_assign_dev(bc.data_ptr(), 17, n, assign.data_ptr()), n, 21)
-del bc, assign
-
-# cfg 5: BAM flag + TLEN, 200M records
-n = 200_000_000
-flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
-flag = torch.from_numpy(flag_np.view(np.int16)).to(dev).repeat(100)
-tid = torch.from_numpy(tid_np).to(dev).repeat(100)
-mtid = torch.from_numpy(mtid_np).to(dev).repeat(100)
-tlen = torch.from_numpy(tlen_np).to(dev).repeat(100)
-out = torch.zeros((4 + 5001,), dtype=torch.int64, device=dev)
-timeit("cfg5 sam statistics + fragment lengths 200M records (14 B)", lambda: ctx.bam_flag_tlen_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 5000, out.data_ptr()), n, 14, iters=3, rounds=3)
-bits = torch.zeros((n // 8 + 8,), dtype=torch.uint8, device=dev)
-kept = torch.zeros((1,), dtype=torch.int64, device=dev)
-timeit("f2 sam fragments filter 200M records (14 B)", lambda: ctx.bam_fragments_dev(flag.data_ptr(), tid.data_ptr(), mtid.data_ptr(), tlen.data_ptr(), n, 0, 5000, bits.data_ptr(), kept.data_ptr()), n, 14.125, iters=3, rounds=3)
-del flag, tid, mtid, tlen, bits
 
 # sam count: 100M coordinate-sorted paired records on 24 references, 20k regions of 1 kb (31 B/record)
 n = 100_000_000
