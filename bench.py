@@ -225,26 +225,33 @@ def gen_shard(torch, dev, n, table_np, seed, chunk, into=None, sink=None):
                 seq[mi][r0:r0 + m] = s
                 qual[mi][r0:r0 + m] = q
             del idx, s, q
-        truth = torch.randint(0, S_SAMPLES, (m,), generator=g, device=dev)
-        b = table[truth].clone()
-        rows = torch.arange(m, device=dev)
-        for lo in (0, 9):                      # error mix per half: 85 % exact, 10 % one substitution, 5 % random 8-mer
-            u = torch.rand((m,), generator=g, device=dev)
-            sub = (u >= 0.85) & (u < 0.95)
-            pos = lo + torch.randint(0, 8, (m,), generator=g, device=dev)
-            ai = torch.randint(0, 5, (m,), generator=g, device=dev)
-            cur = b[rows, pos]
-            ai = torch.where(alphabet[ai] == cur, (ai + 1) % 5, ai)
-            b[rows[sub], pos[sub]] = alphabet[ai[sub]]
-            rnd = u >= 0.95
-            nr = int(rnd.sum())
-            if nr:
-                b[rnd, lo:lo + 8] = bases[torch.randint(0, 4, (nr, 8), generator=g, device=dev)]
+        b = observed_barcodes(torch, g, dev, m, table, bases, alphabet)
         if sink is not None:
             sink(r0, cs, cq, b)
         else:
             bc[r0:r0 + m] = b
     return seq, qual, bc
+
+
+def observed_barcodes(torch, g, dev, m, table, bases, alphabet, p_exact=0.85, p_sub=0.10):
+    """m observed dual-index barcodes drawn on the device (SURVEY.md §8d cfg 4): a sheet row, then per half p_exact as it is,
+    p_sub one substitution (uniform position, uniform from ACGTN other than the letter there), the rest a uniform random 8-mer."""
+    truth = torch.randint(0, table.shape[0], (m,), generator=g, device=dev)
+    b = table[truth].clone()
+    rows = torch.arange(m, device=dev)
+    for lo in (0, 9):
+        u = torch.rand((m,), generator=g, device=dev)
+        sub = (u >= p_exact) & (u < p_exact + p_sub)
+        pos = lo + torch.randint(0, 8, (m,), generator=g, device=dev)
+        ai = torch.randint(0, 5, (m,), generator=g, device=dev)
+        cur = b[rows, pos]
+        ai = torch.where(alphabet[ai] == cur, (ai + 1) % 5, ai)
+        b[rows[sub], pos[sub]] = alphabet[ai[sub]]
+        rnd = u >= p_exact + p_sub
+        nr = int(rnd.sum())
+        if nr:
+            b[rnd, lo:lo + 8] = bases[torch.randint(0, 4, (nr, 8), generator=g, device=dev)]
+    return b
 
 
 def pack_blocked(torch, lay, seq, qual, bc, nt, dst=None):
@@ -572,8 +579,8 @@ def secondary_rates(torch, ctx, dev):
     # f3: barcode census (`fasta statistics`, `--dry-run`): rows/s; every launch starts from an empty table
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
-    for name, kw in (("f3: census 32M rows, clean run (per index 97 % exact, 2.5 % one substitution, 0.5 % random)", dict(p_exact=0.97, p_sub=0.025)),
-                     ("f3: census 32M rows, noisy run (per index 85 % / 10 % / 5 %)", {})):
+    for name, kw in (("f3: census 32M rows (1 M drawn rows x 32), clean run (per index 97 % exact, 2.5 % one substitution, 0.5 % random)", dict(p_exact=0.97, p_sub=0.025)),
+                     ("f3: census 32M rows (1 M drawn rows x 32), noisy run (per index 85 % / 10 % / 5 %)", {})):
         b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
         bc = torch.from_numpy(b_np).to(dev).repeat(32, 1).contiguous()
 
@@ -589,6 +596,31 @@ def secondary_rates(torch, ctx, dev):
         rows = bc.shape[0]
         out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
                     "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4)})
+        del bc
+    # The two rows above repeat ONE million drawn rows 32 times (rounds 3-4's input, kept for the comparison): their random halves
+    # come back 32 times each — 110 k distinct keys in 32 M rows.  Drawn independently, the noisy mix has ~2.4 M distinct keys in
+    # 32 M rows (a random half is one of 65 536): every one of them is an insert into the HBM table, whatever is combined before.
+    bases_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    alpha_t = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+    table_t = torch.tensor(table, dtype=torch.uint8, device=dev)
+    for name, kw in (("f3: census 32M independently drawn rows, clean mix (97 % / 2.5 % / 0.5 % per index)", dict(p_exact=0.97, p_sub=0.025)),
+                     ("f3: census 32M independently drawn rows, noisy mix (85 % / 10 % / 5 % per index)", {})):
+        gi = torch.Generator(device=dev)
+        gi.manual_seed(11)
+        bc = torch.cat([observed_barcodes(torch, gi, dev, 4_000_000, table_t, bases_t, alpha_t, **kw) for _ in range(8)]).contiguous()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            ctx.census_reset()
+            ctx.sync()
+            ctx.timer_start()
+            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], 17, bc.shape[0], 0, 0)
+            ts.append(ctx.timer_stop())
+        ms = sorted(ts[1:])[1]
+        rows = bc.shape[0]
+        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
+                    "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "distinct": int(ctx.census_stats()["distinct"])})
         del bc
     # the floor of the census: every row a key never seen before (random 16-mers: 32 M distinct keys enter the HBM table)
     rows = 32_000_000

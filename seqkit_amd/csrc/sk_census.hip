@@ -35,26 +35,32 @@ struct CensusSlot {          // 32 bytes, one HBM sector pair
 	u64 first_inv;           // ~(lowest row index seen): atomicMax keeps the first occurrence
 };
 
-// The partition path (large launches): keys the front tables had no room for are written out, sorted by the region of
-// the HBM table their slot lies in, and combined per region in LDS before they touch the table (census_add below).
-constexpr int kSpillBucketsLog2 = 10;
+// The partition path (large launches): keys the front tables had no room for leave the front kernel as 16-byte records,
+// partitioned by the region of the HBM table their slot lies in (kSpillBuckets regions) INSIDE that kernel: a record draws
+// its place in the (workgroup, bucket) region of the record array from the workgroup's cursor of that bucket (an LDS add with
+// return) and goes there with one 16-byte store.  A wave's 64 records go to 64 different lines; the lines of the
+// workgroups' open regions (256 x 128 x 128 B = 4 MiB) stay in L2 until they are full.  The records are combined per bucket in
+// LDS before they touch the table (census_add below).  (Through round 4 the records were written as they came, then
+// counted, scanned and moved to 1 024 buckets by two more kernels: every record crossed HBM four times — 62 + 7 of a noisy
+// launch's 314 us of kernels and two of its five kernel boundaries.  A first form of this round staged the records per
+// bucket in each wave's LDS and flushed whole pieces: the stages took the front table's room and the flushes its time.)
+constexpr int kSpillBucketsLog2 = 8;
 constexpr int kSpillBuckets = 1 << kSpillBucketsLog2;
 constexpr int kSpillMaxLen = 24;         // 24 characters = 96 bits; the key's fourth dword is then the marker alone
+constexpr int kSpillMaxGrid = 1024;      // workgroups of the front kernel the combine pass can address
 
 struct CensusSpill {
-	uint4 *key = nullptr;        // [grid][cap] as the workgroups of the front kernel wrote them: a record is the key's first
-	                             // three dwords (barcodes of at most kSpillMaxLen characters) and the row index within the launch
-	uint4 *skey = nullptr;       // the same records, bucket after bucket
-	u32 *hist = nullptr;         // [grid][kSpillBuckets]: records per workgroup and bucket
-	u32 *offs = nullptr;         // [grid][kSpillBuckets]: where the workgroup's records begin within the bucket
-	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket
-	u32 *bstart = nullptr;       // [kSpillBuckets + 1]
-	u32 *wg_count = nullptr;     // [grid]
-	u32 *wg_stats = nullptr;     // [grid][kCensusStats]: the front kernel's statistics per workgroup (summed by census_scan_kernel)
-	u32 *work = nullptr;         // census_combine_kernel's item counter (zeroed by census_scan_kernel)
-	u32 cap = 0;                 // records per workgroup region
+	uint4 *key = nullptr;        // [grid][kSpillBuckets][cap]: a record is the key's first three dwords (barcodes of at most
+	                             // kSpillMaxLen characters) and the row index within the launch | the weight
+	u32 *hist = nullptr;         // [grid][kSpillBuckets]: records per workgroup and bucket (what lies in the region)
+	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket (added to by the front kernel's workgroups; census_direct_kernel,
+	                             // the launch's last kernel, leaves it zero for the next launch)
+	u32 *wg_count = nullptr;     // [grid]: records per workgroup
+	u32 *wg_stats = nullptr;     // [grid][kCensusStats]: the front kernel's statistics per workgroup (summed by census_combine_kernel)
+	u32 *work = nullptr;         // census_combine_kernel's item counter (left zero by census_direct_kernel)
+	u32 cap = 0;                 // records per (workgroup, bucket) region
 	u32 bucket_shift = 0;        // bucket = (hash & mask) >> bucket_shift
-	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not partitioned
+	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not combined
 	u32 grid = 0;                // workgroups of the front kernel
 	u32 merge_copies = 0;        // != 0: the front kernel's tables leave their workgroup as records, not as inserts
 };
@@ -83,7 +89,8 @@ constexpr u64 kInitialSlots = 1ull << 26;   // 2 GiB of the 288: one launch may 
 constexpr int64_t kCensusChunk = 1 << 25;   // most rows per launch; the table is grown between launches so that it is never
 constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
 constexpr int kLdsSlots = 2048;
-constexpr int kLdsProbes = 3;
+constexpr int kLdsProbes = 8;             // (3 through round 4, when an item met a hundred distinct keys: with 256 buckets a noisy item meets 430 in 2 048
+                                          // slots, and a key that finds no place sends every one of its records to HBM by itself)
 constexpr u32 kMaxProbes = 1u << 16;
 
 // The combine pass's table (keyed by the packed key), one array per field: slot i of a u64 array lies in bank pair i mod 32, so the 64 probes of a
@@ -203,50 +210,124 @@ __device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo
 	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
 }
 
-// count (cnt, first) for one key in the combine pass's LDS table; returns the key's slot — plus kLdsClaimed when this call put
-// the key there — or -1 when it found no room within kLdsProbes slots
-constexpr int kLdsClaimed = 1 << 16;
-__device__ __forceinline__ int lds_count_at(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv)
+// N keys of a thread at once: what bounds an insert is its chain of dependent memory round trips (the slot, the CAS, the
+// acknowledged store, the publishing store), and a loop over keys pays the chain per key — with lanes that have nothing to
+// insert waiting beside those that have.  Here the N home slots are fetched together, the CAS of those found empty are in
+// flight together, the winners' stores are acknowledged by ONE wait; a key already there takes its add (and the first-row
+// check) likewise.  Whatever is left — a slot taken by another key, a lost race — goes the long way, census_insert_at.
+template <int N>
+__device__ __forceinline__ void census_insert_many(CensusSlot *tab, u64 mask, const bool (&want)[N], const u64 (&klo)[N], const u64 (&khi)[N], const u32 (&cnt)[N],
+                                                   const u64 (&first_inv)[N], u32 &claimed, u32 &overflow)
 {
-	const u64 want = ~khi;
-	u32 idx = at & (kLdsSlots - 1);
-	{	// the common case, without the loop's bookkeeping: the key sits in its home slot (three loads in flight together)
-		const u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		const u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		const u64 f = __hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (k == klo && v == want) {
-			atomicAdd(&lt->count[idx], cnt);
-			if (f < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
-			return (int)idx;
+	typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+	u64 idx[N];
+	u32x4_t w[N];
+#pragma unroll
+	for (int q = 0; q < N; q++) {
+		idx[q] = want[q] ? ((u64)census_hash(klo[q], khi[q]) & mask) : 0ull;
+		asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[q]) : "v"(tab + idx[q]) : "memory");
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): the compiler does not know of the loads above
+	u64 k[N], v[N], old[N];
+	bool tryc[N], won[N], hit[N];
+#pragma unroll
+	for (int q = 0; q < N; q++) {
+		asm volatile("" : "+v"(w[q]));
+		k[q] = (u64)w[q][0] | ((u64)w[q][1] << 32);
+		v[q] = (u64)w[q][2] | ((u64)w[q][3] << 32);
+		tryc[q] = want[q] && k[q] == 0ull;
+		old[q] = 1ull;
+		if (tryc[q]) old[q] = atomicCAS(&tab[idx[q]].klo, 0ull, klo[q]);
+	}
+	bool any_won = false;
+#pragma unroll
+	for (int q = 0; q < N; q++) {
+		won[q] = tryc[q] && old[q] == 0ull;
+		any_won = any_won || won[q];
+		if (won[q]) {                                                  // ours until the high word is published (census_insert_at)
+			const u32x4_t cw = {cnt[q], 0u, (u32)first_inv[q], (u32)(first_inv[q] >> 32)};
+			asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&tab[idx[q]].count), "v"(cw) : "memory");
 		}
 	}
-	int claimed = 0;
-	for (int p = 0; p < kLdsProbes;) {
-		u64 k = __hip_atomic_load(&lt->klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (k == 0) {
-			k = atomicCAS(&lt->klo[idx], 0ull, klo);
-			if (k == 0) {
-				__hip_atomic_store(&lt->khi_inv[idx], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				k = klo;
-				claimed = kLdsClaimed;
-			}
-		}
-		if (k == klo) {                                      // (one 8-byte load per probe; the high word only where the low one matched)
-			const u64 v = __hip_atomic_load(&lt->khi_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (v == 0) continue;                            // claimed, high word not published yet: look again
-			if (v == want) {
-				atomicAdd(&lt->count[idx], cnt);
-				// rows come in roughly ascending order, so the first row rarely moves: look before the (serialising) atomic
-				if (__hip_atomic_load(&lt->first_inv[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first_inv) atomicMax(&lt->first_inv[idx], first_inv);
-				return (int)idx | claimed;
-			}
-		}
-		idx = (idx + 1) & (kLdsSlots - 1);
-		p++;
+	if (any_won) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the stores are acknowledged
 	}
-	return -1;
+	u64 f[N];
+#pragma unroll
+	for (int q = 0; q < N; q++) {
+		if (won[q]) {
+			__hip_atomic_store(&tab[idx[q]].khi_inv, ~khi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			claimed++;
+		}
+		hit[q] = want[q] && !tryc[q] && k[q] == klo[q] && v[q] == ~khi[q];
+		f[q] = ~0ull;
+		if (hit[q]) {
+			atomicAdd(&tab[idx[q]].count, (u64)cnt[q]);
+			f[q] = __hip_atomic_load(&tab[idx[q]].first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < N; q++) {
+		if (hit[q] && f[q] < first_inv[q]) atomicMax(&tab[idx[q]].first_inv, first_inv[q]);
+		if (want[q] && !won[q] && !hit[q]) {
+			SlotView sv;
+			sv.k = tryc[q] ? old[q] : k[q];
+			sv.v = tryc[q] ? __hip_atomic_load(&tab[idx[q]].khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v[q];
+			if (!census_insert_at(tab, mask, idx[q], sv, klo[q], khi[q], (u64)cnt[q], first_inv[q], claimed)) overflow += cnt[q];
+		}
+	}
 }
-__device__ __forceinline__ bool lds_count(LdsTable *lt, u32 at, u64 klo, u64 khi, u32 cnt, u64 first_inv) { return lds_count_at(lt, at, klo, khi, cnt, first_inv) >= 0; }
+
+// N records of a thread counted in the combine pass's table together.  A wave walks a probe sequence as long as its longest lane
+// does, and a thread's records one after the other summed those walks.  Here every turn of the loop serves all the thread's records that are still looking —
+// their slots' three words are fetched together — so the loop is as long as the longest walk among 64 N records, not the sum
+// of N longest walks among 64.  fail[q]: no place within kLdsProbes slots (the key then goes to HBM by itself).
+template <int N>
+__device__ __forceinline__ void lds_count_many(LdsTable *lt, const bool (&have)[N], const u32 (&h)[N], const u64 (&klo)[N], const u64 (&khi)[N], const u32 (&cnt)[N],
+                                               const u64 (&first_inv)[N], bool (&fail)[N])
+{
+	u32 idx[N];
+	int p[N];
+	bool todo[N];
+#pragma unroll
+	for (int q = 0; q < N; q++) { idx[q] = h[q] & (kLdsSlots - 1); p[q] = 0; todo[q] = have[q]; fail[q] = false; }
+	for (;;) {
+		bool any = false;
+#pragma unroll
+		for (int q = 0; q < N; q++) any = any || todo[q];
+		if (!__any(any)) break;                                            // (uniform)
+		u64 k[N], v[N], f[N];
+#pragma unroll
+		for (int q = 0; q < N; q++) {
+			k[q] = __hip_atomic_load(&lt->klo[idx[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			v[q] = __hip_atomic_load(&lt->khi_inv[idx[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			f[q] = __hip_atomic_load(&lt->first_inv[idx[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+#pragma unroll
+		for (int q = 0; q < N; q++) {
+			if (!todo[q]) continue;
+			const u64 want = ~khi[q];
+			bool mine = k[q] == klo[q] && v[q] == want;
+			if (!mine && k[q] == 0ull) {
+				if (atomicCAS(&lt->klo[idx[q]], 0ull, klo[q]) == 0ull) {
+					__hip_atomic_store(&lt->khi_inv[idx[q]], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					mine = true;
+					f[q] = 0ull;
+				}
+				// (lost to another lane: the slot is looked at again in the next turn — it may have become this key's)
+			} else if (!mine && !(k[q] == klo[q] && v[q] == 0ull)) {         // another key's (a claimed slot whose high word is not there yet is looked at again)
+				idx[q] = (idx[q] + 1u) & (kLdsSlots - 1);
+				if (++p[q] >= kLdsProbes) { fail[q] = true; todo[q] = false; }
+			}
+			if (mine) {
+				atomicAdd(&lt->count[idx[q]], cnt[q]);
+				if (f[q] < first_inv[q]) atomicMax(&lt->first_inv[idx[q]], first_inv[q]);
+				todo[q] = false;
+			}
+		}
+	}
+}
 
 // ---- the workgroup's front table: keyed by a row's BYTES ---------------------------------------------------------------
 // Building a row's key — classify every character, pack, hash — is most of what the census does per row, and most rows of a
@@ -369,6 +450,12 @@ extern __shared__ __attribute__((aligned(16))) uint8_t census_smem[];
 #ifdef SK_CENSUS_STAMPS
 constexpr int kStampSlots = 16;
 __device__ u64 g_census_stamps[8192 * kStampSlots];
+__device__ u64 g_combine_stamps[8192 * kStampSlots];
+#define SK_CSTAMP(i) do { const u64 now_ = __builtin_amdgcn_s_memtime(); cst_acc[i] += now_ - cst_last; cst_last = now_; } while (0)
+#else
+#define SK_CSTAMP(i) do { } while (0)
+#endif
+#ifdef SK_CENSUS_STAMPS
 #define SK_STAMP(i) do { const u64 now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
 #else
 #define SK_STAMP(i) do { } while (0)
@@ -397,11 +484,11 @@ __device__ __forceinline__ void census_wave_fence()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kCensusMaxSub = 4;          // 64-row tiles per wave and step
+constexpr int kCensusMaxSub = 2;          // 64-row tiles per wave and step (three and four timed the same and needed scratch for the longest strings)
 constexpr int kCensusStepBytes = 5120;    // most bytes per wave and step before the cap on R (census_add)
 constexpr int kCensusQueue = 128;         // flush queue entries (16 B key + 4 B row): fewer than 64 left over + one tile's 64
 
-template <int R, int NW> struct CensusRowRegs { u32 g[R][NW + 1]; int32_t code[kCensusMaxSub] = {0, 0, 0, 0}; };
+template <int R, int NW> struct CensusRowRegs { u32 g[R][NW + 1]; int32_t code[kCensusMaxSub] = {0, 0}; };
 
 // The input as raw-buffer descriptors over the whole launch (the rows, and the assignment codes when there are any): what
 // lies beyond the matrix is clipped by the descriptor (a load returns zeros there, dword by dword).
@@ -488,7 +575,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	// profiles/r04_census_stamps_before.txt).  What is left over at the end of a step — fewer than 64 entries — moves to the
 	// front of the queue and goes first in the next step's passes.  Capacity: 64 left over + the step's R x 64 rows.
 	uint8_t *slot = census_smem + front_bytes + (size_t)wave * tile_slot;
-	u32 *lh = reinterpret_cast<u32 *>(census_smem + front_bytes + (size_t)nwave * tile_slot + 64);      // SPILL: records per bucket, then the cursor
+	u32 *lh = reinterpret_cast<u32 *>(census_smem + front_bytes + (size_t)nwave * tile_slot + 64);      // SPILL: the workgroup's records per bucket (its cursors into the bucket regions)
 	constexpr int kQueueCap = 64 + R * 64;
 	u32 *const qr = reinterpret_cast<u32 *>(slot);
 	u32 *const qx = qr + kQueueCap;
@@ -512,8 +599,8 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 #endif
 	__syncthreads();
 	SK_STAMP(0);                                                       // tables cleared
-	__amdgpu_buffer_rsrc_t sp_key;
-	if (SPILL) sp_key = __builtin_amdgcn_make_buffer_rsrc(a.sp.key + (size_t)blockIdx.x * a.sp.cap, 0, (int)(a.sp.cap * 16u), 0x00020000);
+	__amdgpu_buffer_rsrc_t sp_key;                                     // the workgroup's kSpillBuckets regions of a.sp.cap records each
+	if (SPILL) sp_key = __builtin_amdgcn_make_buffer_rsrc(a.sp.key + (size_t)blockIdx.x * kSpillBuckets * a.sp.cap, 0, (int)(kSpillBuckets * a.sp.cap * 16u), 0x00020000);
 
 	const int stride = a.bc_stride;
 	const int step_bytes = R * 64 * stride;
@@ -545,6 +632,20 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		__hip_atomic_fetch_add(&fcnt[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (r < first) __hip_atomic_fetch_min(&fb[e * 4u + 2u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (rows come in roughly ascending order: rare)
 	};
+	// ---- SPILL: a record on its way out: its place in the workgroup's region of bucket b from the bucket's cursor, one store.  A
+	// region is twice a workgroup's share of a launch in which every row is spilled: a record that finds its region full
+	// (thousands of rows of ONE key that came too late for the front table) is inserted from here.
+	auto record_put = [&](bool has, u32 b, const u32x4_t &rec) {
+		u32 at = 0xffffffffu;
+		if (has) at = atomicAdd(&lh[b], 1u);
+		const bool fits = has && at < a.sp.cap;
+		__builtin_amdgcn_raw_buffer_store_b128(rec, sp_key, fits ? (int)((b * a.sp.cap + at) * 16u) : 0x7ffffff0, 0, 0);      // (beyond the regions: dropped by the descriptor)
+		if (has && !fits) {
+			const u64 klo = 0xF0000000ull | ((u64)rec[0] << 32), khi = (u64)rec[1] | ((u64)rec[2] << 32);
+			const u32 cnt = census_rec_count(rec[3]);
+			if (!census_insert(a.tab, a.mask, klo, khi, (u64)cnt, ~(u64)(a.row_base + census_rec_row(rec[3])), claimed)) overflow += cnt;
+		}
+	};
 	int t = (int)blockIdx.x * nwave + wave;
 	census_load_rows<R, NW>(streams, a.assign != nullptr, t, step_bytes, off, lane, rg);
 	for (;;) {
@@ -560,7 +661,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		SK_STAMP(1);                                                   // the step's loads waited for, rows aligned
 		// which of the step's rows are counted, worked out BEFORE the next step's loads are issued: nothing below may
 		// wait for a register that a load of this or an earlier step wrote, or it waits for the new loads as well
-		u32 take = 0xFu;
+		u32 take = (1u << kCensusMaxSub) - 1u;
 		if (a.assign != nullptr) {
 			take = 0u;
 #pragma unroll
@@ -734,26 +835,12 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		// no gain — what bounds this leg is the rate of scattered atomics, not their latency.)
 		if (SPILL) {
 			if (__any(parked != 0u)) {                                     // (stores inside a branch are fine: nothing waits for them)
-			u32 pos[R], tot = 0u;
 #pragma unroll
-			for (int j = 0; j < R; j++) {
-				const u64 bal = __ballot(((parked >> j) & 1u) != 0u);
-				pos[j] = tot + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-				tot += (u32)__popcll(bal);
-			}
-			u32 base = 0u;
-			if (tot != 0u) {                                               // LDS only: no memory operation inside a branch
-				if (lane == 0) base = atomicAdd(&lh[kSpillBuckets], tot);
-				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-			}
-#pragma unroll
-			for (int j = 0; j < R; j++) {
-				const bool has = ((parked >> j) & 1u) != 0u;
-				const u32 at = has ? base + pos[j] : 0x07ffffffu;          // beyond the region: dropped by the descriptor
-				const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), prid[j]};
-				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
-				if (has) atomicAdd(&lh[(u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift)], 1u);
-			}
+				for (int j = 0; j < R; j++) {
+					const bool has = ((parked >> j) & 1u) != 0u;
+					const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), prid[j]};
+					record_put(has, (u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift), kq);
+				}
 			}
 		} else if (__any(parked != 0u)) {
 			int qn = 0;
@@ -800,7 +887,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 	// before anything touches HBM.  Such records stand for rows that were NOT spilled, so the workgroup's region (one record
 	// per row) has room for them.
 	const bool as_records = SPILL && a.sp.merge_copies != 0u;
-	for (int i0 = tid; i0 < ((front_entries + 63) & ~63); i0 += blockDim.x) {          // (whole waves: the record positions are a wave scan)
+	for (int i0 = tid; i0 < ((front_entries + 63) & ~63); i0 += blockDim.x) {
 		int i = i0 + (as_records ? 0 : (int)blockIdx.x * 67);
 		if (i >= front_entries) i -= front_entries * (i / front_entries);
 		const bool in = i0 < front_entries;
@@ -817,40 +904,32 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		bool rec = false;
 		if (SPILL) {
 			rec = live && as_records && sc < (1u << 20);                       // (a count beyond four digits is inserted below: never in a launch of 2^25 rows over 256 workgroups)
-			u32 digit[4], c = 0u;
+			u32 digit[4];
 #pragma unroll
-			for (int v = 0; v < 4; v++) {
-				digit[v] = rec ? (sc >> (5 * v)) & 31u : 0u;
-				c += digit[v] != 0u ? 1u : 0u;
-			}
-			u32 incl = c;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const u32 up = __shfl_up(incl, o);
-				if (lane >= o) incl += up;
-			}
-			const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-			u32 base = 0u;
-			if (tot != 0u) {
-				if (lane == 0) base = atomicAdd(&lh[kSpillBuckets], tot);
-				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-			}
-			u32 pos = base + incl - c;
+			for (int v = 0; v < 4; v++) digit[v] = rec ? (sc >> (5 * v)) & 31u : 0u;
+			const u32 bkt = (u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift);
 #pragma unroll
 			for (int v = 0; v < 4; v++) {
 				const u32x4_t kq = {(u32)(sk >> 32), (u32)khi, (u32)(khi >> 32), first | ((u32)v << kRecRowBits) | ((digit[v] - 1u) << 27)};
-				const u32 at = digit[v] != 0u ? pos : 0x07ffffffu;             // beyond the region: dropped by the descriptor
-				__builtin_amdgcn_raw_buffer_store_b128(kq, sp_key, (int)(at * 16u), 0, 0);
-				pos += digit[v] != 0u ? 1u : 0u;
+				record_put(digit[v] != 0u, bkt, kq);
 			}
-			if (c != 0u) atomicAdd(&lh[(u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift)], c);
 		}
 		if (live && !rec && !census_insert(a.tab, a.mask, sk, khi, (u64)sc, first_inv, claimed)) overflow += sc;
 	}
 	if (SPILL) {
 		__syncthreads();
-		for (int i = tid; i < kSpillBuckets; i += blockDim.x) a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + i] = lh[i];
-		if (tid == 0) a.sp.wg_count[blockIdx.x] = lh[kSpillBuckets];
+		if (tid < 64) {                                                    // what lies in the workgroup's regions (a cursor beyond the region: the records behind it were inserted)
+			u32 sum = 0u;
+			for (int b = tid; b < kSpillBuckets; b += 64) {
+				const u32 v = lh[b] < a.sp.cap ? lh[b] : a.sp.cap;
+				a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + b] = v;
+				if (v != 0u) atomicAdd(&a.sp.btot[b], v);
+				sum += v;
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+			if (tid == 0) a.sp.wg_count[blockIdx.x] = sum;
+		}
 	}
 	SK_STAMP(8);                                                       // front table merged into HBM
 	// one atomic per WORKGROUP and statistic: the waves of a launch end together, and 4 096 additions to one address are
@@ -882,44 +961,6 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 }
 
 // ---- the partition path -------------------------------------------------------------------------------------------
-// hist[g][b] -> offs[g][b], the offset of workgroup g's records within bucket b, and btot[b], the bucket's size.  A
-// workgroup takes 64 buckets; its 16 waves split the rows g among them (every load is one contiguous 256-byte piece of a
-// row, and none depends on another).
-constexpr int kScanBuckets = 64;
-__global__ __launch_bounds__(1024) void census_scan_kernel(const u32 *__restrict__ hist, u32 *__restrict__ offs, u32 *__restrict__ btot, u32 *__restrict__ work, int grid,
-                                                            const u32 *__restrict__ wg_stats, u64 *__restrict__ stats)
-{
-	if (blockIdx.x == 0 && threadIdx.x == 0) *work = 0u;
-	__shared__ u32 part[16][kScanBuckets];
-	if (blockIdx.x == 1) {                                             // the front kernel's statistics: 4 atomics per launch instead of 4 per workgroup
-		__shared__ u32 ssum[kCensusStats];
-		if (threadIdx.x < kCensusStats) ssum[threadIdx.x] = 0u;
-		__syncthreads();
-		u32 v = 0u;
-		for (int i = threadIdx.x; i < grid * kCensusStats; i += blockDim.x) v += wg_stats[i];      // (blockDim is a multiple of kCensusStats: thread x sums statistic x % 4)
-		for (int o = 32; o >= kCensusStats; o >>= 1) v += __shfl_xor(v, o);
-		if ((threadIdx.x & 63) < kCensusStats && v != 0u) atomicAdd(&ssum[threadIdx.x & 3], v);
-		__syncthreads();
-		if (threadIdx.x < kCensusStats && ssum[threadIdx.x] != 0u) atomicAdd(&stats[threadIdx.x], (u64)ssum[threadIdx.x]);
-	}
-	const int lb = threadIdx.x & (kScanBuckets - 1), grp = threadIdx.x / kScanBuckets;
-	const int b = blockIdx.x * kScanBuckets + lb;
-	const int per = (grid + 15) / 16;
-	const int g0 = grp * per, g1 = min(grid, g0 + per);
-	u32 sum = 0u;
-	for (int g = g0; g < g1; g++) sum += hist[(size_t)g * kSpillBuckets + b];
-	part[grp][lb] = sum;
-	__syncthreads();
-	u32 run = 0u;
-	for (int q = 0; q < grp; q++) run += part[q][lb];
-	if (grp == 15) btot[b] = run + sum;
-	for (int g = g0; g < g1; g++) {
-		const u32 v = hist[(size_t)g * kSpillBuckets + b];
-		offs[(size_t)g * kSpillBuckets + b] = run;
-		run += v;
-	}
-}
-
 // exclusive prefix sum of one value per thread over the workgroup (at most 16 waves): shuffles inside a wave, the wave sums
 // through LDS (ws: 17 words) — three barriers where the textbook loop over LDS has two per doubling
 __device__ __forceinline__ u32 census_block_exclusive(u32 mine, u32 *ws, u32 *total)
@@ -964,91 +1005,6 @@ __device__ __forceinline__ u32 census_spill_total(const CensusSpill &sp, u32 *re
 	return tot;
 }
 
-// workgroup g moves its records to their buckets (every workgroup scans the 1024 bucket sizes for itself; the first one
-// leaves the bucket starts behind for census_combine_kernel).  A scattered 16-byte store per record is what the chip does
-// 30-60 G of per second, so a chunk of 8 192 records is first sorted by bucket in LDS: neighbouring lanes then write
-// neighbouring records of a bucket (8 on average: a 128-byte line).
-constexpr int kScatterChunk = 8192;
-constexpr int kScatterPer = kScatterChunk / 1024;
-constexpr size_t kScatterLds = (size_t)kScatterChunk * 16 + 4 * kSpillBuckets * sizeof(u32);
-__global__ __launch_bounds__(1024) void census_scatter_kernel(CensusSpill sp, u64 mask)
-{
-	uint4 *stage = reinterpret_cast<uint4 *>(census_smem);
-	u32 *gofs = reinterpret_cast<u32 *>(stage + kScatterChunk);      // where the workgroup's next record of a bucket goes
-	u32 *lcnt = gofs + kSpillBuckets;                                // records per bucket in this chunk
-	u32 *loff = lcnt + kSpillBuckets;                                // where they begin in the sorted chunk (+ one scratch copy)
-	u32 *sc = loff + kSpillBuckets;
-	const int g = blockIdx.x;
-	const int b = threadIdx.x;
-	if (census_spill_total(sp, sc) > sp.direct_above) return;          // census_direct_kernel takes them
-	auto exclusive = [&](u32 mine) -> u32 { return census_block_exclusive(mine, sc, nullptr); };
-	{
-		const u32 mine = sp.btot[b];
-		const u32 start = exclusive(mine);
-		gofs[b] = start + sp.offs[(size_t)g * kSpillBuckets + b];
-		if (g == 0) {
-			sp.bstart[b] = start;
-			if (b == kSpillBuckets - 1) sp.bstart[kSpillBuckets] = start + mine;
-		}
-	}
-	const u32 cnt = sp.wg_count[g];
-	const uint4 *key = sp.key + (size_t)g * sp.cap;
-	// (the next chunk's records are asked for while this one is sorted: a chunk is eight barriers, and with its loads at the
-	// top every chunk began with a memory latency)
-	uint4 rec[kScatterPer], nrec[kScatterPer];
-#pragma unroll
-	for (int q = 0; q < kScatterPer; q++) {
-		const u32 i = (u32)q * 1024u + (u32)b;
-		rec[q] = i < cnt ? key[i] : make_uint4(0u, 0u, 0u, 0u);
-	}
-	for (u32 c0 = 0; c0 < cnt; c0 += kScatterChunk) {
-		const u32 nc = min((u32)kScatterChunk, cnt - c0);
-		__syncthreads();
-		lcnt[b] = 0u;
-		__syncthreads();
-		u32 bk[kScatterPer], rank[kScatterPer];
-#pragma unroll
-		for (int q = 0; q < kScatterPer; q++) {
-			const u32 i = c0 + (u32)kScatterChunk + (u32)q * 1024u + (u32)b;
-			nrec[q] = i < cnt ? key[i] : make_uint4(0u, 0u, 0u, 0u);
-		}
-#pragma unroll
-		for (int q = 0; q < kScatterPer; q++) {
-			const u32 i = (u32)q * 1024u + (u32)b;
-			if (i < nc) {
-				const u32 h = census_hash(0xF0000000ull | ((u64)rec[q].x << 32), (u64)rec[q].y | ((u64)rec[q].z << 32));
-				bk[q] = (u32)(((u64)h & mask) >> sp.bucket_shift);
-				rank[q] = atomicAdd(&lcnt[bk[q]], 1u);
-			}
-		}
-		__syncthreads();
-		const u32 mine = lcnt[b];
-		const u32 start = exclusive(mine);
-		loff[b] = start;
-		__syncthreads();
-#pragma unroll
-		for (int q = 0; q < kScatterPer; q++) {
-			const u32 i = (u32)q * 1024u + (u32)b;
-			if (i < nc) stage[loff[bk[q]] + rank[q]] = rec[q];
-		}
-		__syncthreads();
-#pragma unroll
-		for (int q = 0; q < kScatterPer; q++) {
-			const u32 i = (u32)q * 1024u + (u32)b;
-			if (i < nc) {
-				const uint4 r = stage[i];
-				const u32 h = census_hash(0xF0000000ull | ((u64)r.x << 32), (u64)r.y | ((u64)r.z << 32));
-				const u32 bb = (u32)(((u64)h & mask) >> sp.bucket_shift);
-				sp.skey[gofs[bb] + (i - loff[bb])] = r;
-			}
-		}
-		__syncthreads();
-		gofs[b] += mine;
-#pragma unroll
-		for (int q = 0; q < kScatterPer; q++) rec[q] = nrec[q];
-	}
-}
-
 // claimed / overflow of a workgroup's threads -> stats[0] / stats[3], one atomic per workgroup and statistic (red: two words
 // of LDS; every thread of the workgroup calls this)
 __device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 overflow, u32 *red)
@@ -1070,43 +1026,90 @@ __device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 ov
 }
 
 // Combine the buckets in LDS tables and insert every distinct key once.  All keys of a bucket hash into ONE region of the
-// HBM table (1/1024 of it).  A work item is at most kCombineChunk records of one bucket — a bucket that holds a frequent
-// key (one that some front table had no room for) is split among workgroups, since what they add is additive — and the
-// workgroups take items from a counter until none is left.
+// HBM table (1/128 of it); its records lie in the front kernel's workgroups' regions of that bucket, one behind the other in
+// workgroup order.  A work item is at most kCombineChunk consecutive records of that sequence — a bucket is split among
+// workgroups, since what they add is additive — and the workgroups take items from a counter until none is left.
 constexpr int kCombineThreads = 512;
 constexpr int kCombineChunk = 16384;
-__global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const CensusArgs a)
+__global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(const CensusArgs a)
 {
 	__shared__ LdsTable lt_s;
 	__shared__ u32 cpre[kSpillBuckets + 1];                            // items before bucket b
+	__shared__ u32 gpre[kSpillMaxGrid + 1];                            // records of the item's bucket before workgroup g's
 	__shared__ u32 red[kCombineThreads / 64];
+	__shared__ u32 ws[17];
 	__shared__ u32 item_s, nlist;
 	__shared__ uint16_t list[kLdsSlots];
 	LdsTable *lt = &lt_s;
 	const int tid = threadIdx.x;
+	const u32 grid = a.sp.grid;
+#ifdef SK_CENSUS_STAMPS
+	u64 cst_acc[kStampSlots] = {};
+	u64 cst_last = __builtin_amdgcn_s_memtime();
+#endif
+	if (blockIdx.x == 0) {                                             // the front kernel's statistics: 4 atomics per launch instead of 4 per workgroup
+		__shared__ u32 ssum[kCensusStats];
+		if (tid < kCensusStats) ssum[tid] = 0u;
+		__syncthreads();
+		u32 v = 0u;
+		for (u32 i = tid; i < grid * kCensusStats; i += blockDim.x) v += a.sp.wg_stats[i];      // (blockDim is a multiple of kCensusStats: thread x sums statistic x % 4)
+		for (int o = 32; o >= kCensusStats; o >>= 1) v += __shfl_xor(v, o);
+		if ((tid & 63) < kCensusStats && v != 0u) atomicAdd(&ssum[tid & 3], v);
+		__syncthreads();
+		if (tid < kCensusStats && ssum[tid] != 0u) atomicAdd(&a.stats[tid], (u64)ssum[tid]);
+	}
 	if (census_spill_total(a.sp, red) > a.sp.direct_above) return;
-	{	// items per bucket, scanned (two buckets per thread)
-		const u32 c0 = (a.sp.bstart[2 * tid + 1] - a.sp.bstart[2 * tid] + kCombineChunk - 1) / kCombineChunk;
-		const u32 c1 = (a.sp.bstart[2 * tid + 2] - a.sp.bstart[2 * tid + 1] + kCombineChunk - 1) / kCombineChunk;
-		const u32 before = census_block_exclusive(c0 + c1, reinterpret_cast<u32 *>(lt), nullptr);
-		cpre[2 * tid] = before;
-		cpre[2 * tid + 1] = before + c0;
-		if (tid == kCombineThreads - 1) cpre[kSpillBuckets] = before + c0 + c1;
+	{	// items per bucket, scanned (a bucket per thread)
+		static_assert(kSpillBuckets <= kCombineThreads, "one bucket per thread");
+		const u32 c = tid < kSpillBuckets ? (a.sp.btot[tid] + kCombineChunk - 1) / kCombineChunk : 0u;
+		u32 total;
+		const u32 before = census_block_exclusive(c, ws, &total);
+		if (tid < kSpillBuckets) cpre[tid] = before;
+		if (tid == 0) cpre[kSpillBuckets] = total;
 		__syncthreads();
 	}
 	const u32 items = cpre[kSpillBuckets];
+	SK_CSTAMP(0);                                                      // statistics, records counted, items scanned
 	u32 claimed = 0, overflow = 0;
+	int b_have = -1;                                                   // the bucket gpre was made for
 	for (;;) {
 		__syncthreads();
 		if (tid == 0) item_s = atomicAdd(a.sp.work, 1u);
 		for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
 		__syncthreads();
 		const u32 item = item_s;
+		SK_CSTAMP(1);                                                  // an item taken, the table cleared
 		if (item >= items) break;
 		int b = 0;                                                     // the last bucket with cpre[b] <= item
 		for (int o = kSpillBuckets / 2; o > 0; o >>= 1) if (cpre[b + o] <= item) b += o;
-		const u32 lo = a.sp.bstart[b] + (item - cpre[b]) * kCombineChunk;
-		const u32 hi = min(a.sp.bstart[b + 1], lo + kCombineChunk);
+		if (b != b_have) {                                             // (a workgroup's items come in ascending order: mostly the bucket it has)
+			u32 carry = 0u;
+			for (u32 g0 = 0; g0 < grid; g0 += blockDim.x) {
+				const u32 g = g0 + tid;
+				const u32 v = g < grid ? a.sp.hist[(size_t)g * kSpillBuckets + b] : 0u;
+				u32 total;
+				const u32 before = census_block_exclusive(v, ws, &total);
+				if (g < grid) gpre[g] = carry + before;
+				carry += total;
+			}
+			if (tid == 0) gpre[grid] = carry;
+			__syncthreads();
+			b_have = b;
+		}
+		const u32 lo = (item - cpre[b]) * kCombineChunk;
+		const u32 hi = min(gpre[grid], lo + kCombineChunk);
+		// record i of the bucket's sequence lies in the region of the workgroup g with gpre[g] <= i < gpre[g + 1]: found once by
+		// bisection, then g only moves forward (a thread's records are blockDim apart)
+		u32 gcur = 0u;
+		{
+			const u32 i = lo + tid;
+			u32 l = 0u, r = grid;                                      // the last g with gpre[g] <= i
+			while (r - l > 1u) { const u32 m = (l + r) >> 1; if (gpre[m] <= i) l = m; else r = m; }
+			gcur = l;
+		}
+		SK_CSTAMP(2);                                                  // the bucket's regions scanned, the thread's first record found
+		const uint4 *const base = a.sp.key + (size_t)b * a.sp.cap;
+		const size_t gpitch = (size_t)kSpillBuckets * a.sp.cap;
 		// (four records of a thread are counted while its next four are on their way: with one load per trip the loop was a
 		// chain of memory latencies — 32 of them for a full item —, with four loads per trip still one per trip)
 		constexpr int kAhead = 4;
@@ -1115,43 +1118,69 @@ __global__ __launch_bounds__(kCombineThreads) void census_combine_kernel(const C
 #pragma unroll
 			for (int q = 0; q < kAhead; q++) {
 				const u32 i = i0 + (u32)q * blockDim.x;
-				dst[q] = i < hi ? a.sp.skey[i] : make_uint4(0u, 0u, 0u, 0u);
+				if (i < hi) {
+					while (gpre[gcur + 1] <= i) gcur++;
+					dst[q] = base[(size_t)gcur * gpitch + (i - gpre[gcur])];
+				} else dst[q] = make_uint4(0u, 0u, 0u, 0u);
 			}
 		};
 		fetch(lo + tid, kk);
 		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
 			fetch(i0 + kAhead * blockDim.x, kn);
+			// (a key the table has no room for goes to HBM with the others of the thread's four records)
+			bool dir[kAhead], have[kAhead];
+			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+			u32 cnt[kAhead], hh[kAhead];
 #pragma unroll
 			for (int q = 0; q < kAhead; q++) {
-				if (i0 + (u32)q * blockDim.x >= hi) break;
 				const uint4 k = kk[q];
-				const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-				const u64 first_inv = ~(u64)(a.row_base + census_rec_row(k.w));
-				const u32 cnt = census_rec_count(k.w);
-				const u32 h = census_hash(klo, khi);
-				if (!lds_count(lt, h, klo, khi, cnt, first_inv)) {     // the hash's LOW bits: its high bits are the bucket's, the same for every key here
-					const u64 idx = (u64)h & a.mask;
-					if (!census_insert_at(a.tab, a.mask, idx, census_peek(a.tab + idx), klo, khi, (u64)cnt, first_inv, claimed)) overflow += cnt;
-				}
+				have[q] = i0 + (u32)q * blockDim.x < hi;
+				klo[q] = 0xF0000000ull | ((u64)k.x << 32);
+				khi[q] = (u64)k.y | ((u64)k.z << 32);
+				first_inv[q] = ~(u64)(a.row_base + census_rec_row(k.w));
+				cnt[q] = census_rec_count(k.w);
+				hh[q] = census_hash(klo[q], khi[q]);                     // (the table takes the hash's LOW bits: its high bits are the bucket's, the same for every key here)
 			}
+			SK_CSTAMP(3);                                              // next records asked for, keys and hashes
+			lds_count_many<kAhead>(lt, have, hh, klo, khi, cnt, first_inv, dir);
+			SK_CSTAMP(4);                                              // counted in the table
+			bool any_dir = false;
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) any_dir = any_dir || dir[q];
+			if (__any(any_dir)) census_insert_many<kAhead>(a.tab, a.mask, dir, klo, khi, cnt, first_inv, claimed, overflow);      // (rare: its wait is for the next records' loads too)
+			SK_CSTAMP(5);                                              // keys without a place: to HBM
 #pragma unroll
 			for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
 		}
 		__syncthreads();
-		// the occupied slots first go to a list: an insert is three dependent round trips to HBM, and a wave that walks
-		// the table pays them in every one of its four rounds in which any of its lanes finds a key (24 us per item)
+		SK_CSTAMP(6);                                                  // barrier behind the records
+		// the occupied slots go to a list, and the list to HBM four keys of a thread at a time
 		if (tid == 0) nlist = 0u;
 		__syncthreads();
 		for (int i = tid; i < kLdsSlots; i += blockDim.x)
 			if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
 		__syncthreads();
-		for (u32 j = tid; j < nlist; j += blockDim.x) {
-			const int i = list[j];
-			const u32 sc = lt->count[i];
-			if (!census_insert(a.tab, a.mask, lt->klo[i], ~lt->khi_inv[i], (u64)sc, lt->first_inv[i], claimed)) overflow += sc;
+		for (u32 j0 = tid; j0 < nlist; j0 += kAhead * blockDim.x) {
+			bool want[kAhead];
+			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+			u32 cnt[kAhead];
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) {
+				const u32 j = j0 + (u32)q * blockDim.x;
+				want[q] = j < nlist;
+				const int i = list[want[q] ? j : 0u];
+				klo[q] = lt->klo[i]; khi[q] = ~lt->khi_inv[i]; first_inv[q] = lt->first_inv[i]; cnt[q] = lt->count[i];
+			}
+			census_insert_many<kAhead>(a.tab, a.mask, want, klo, khi, cnt, first_inv, claimed, overflow);
 		}
+		SK_CSTAMP(7);                                                  // occupied slots listed and inserted
 	}
 	census_add_stats(a.stats, claimed, overflow, red);
+#ifdef SK_CENSUS_STAMPS
+	SK_CSTAMP(8);
+	if ((tid & 63) == 0 && blockIdx.x * (kCombineThreads / 64) + (tid >> 6) < 8192)
+		for (int i = 0; i < kStampSlots; i++) g_combine_stamps[(blockIdx.x * (kCombineThreads / 64) + (tid >> 6)) * kStampSlots + i] = cst_acc[i];
+#endif
 }
 
 // When most rows of a launch were spilled there is little to combine (the keys hardly repeat): workgroup g inserts the
@@ -1162,16 +1191,44 @@ constexpr int kDirectThreads = 512;
 __global__ __launch_bounds__(kDirectThreads) void census_direct_kernel(const CensusArgs a, const int split)
 {
 	__shared__ u32 red[16];
-	if (census_spill_total(a.sp, red) <= a.sp.direct_above) return;
+	const bool mine = census_spill_total(a.sp, red) > a.sp.direct_above;
+	// the launch's last kernel leaves the bucket totals and the combine pass's counter zero for the next launch (every kernel
+	// that reads them has finished: this one is behind them on the stream)
+	if (blockIdx.x == 0) {
+		if (threadIdx.x < (u32)kSpillBuckets) a.sp.btot[threadIdx.x] = 0u;
+		if (threadIdx.x == 0) *a.sp.work = 0u;
+	}
+	if (!mine) return;
 	const u32 g = blockIdx.x / (u32)split, part = blockIdx.x % (u32)split;
-	const u32 cnt = a.sp.wg_count[g];
-	const uint4 *key = a.sp.key + (size_t)g * a.sp.cap;
 	u32 claimed = 0, overflow = 0;
-	for (u32 i = part * blockDim.x + threadIdx.x; i < cnt; i += (u32)split * blockDim.x) {
-		const uint4 k = key[i];
+	// the records of workgroup g's regions as one sequence, bucket after bucket; a thread takes four of them at a time
+	__shared__ u32 bpre[kSpillBuckets + 1];
+	__shared__ u32 ws[17];
+	{
+		static_assert(kSpillBuckets <= kDirectThreads, "one bucket per thread");
+		const u32 v = threadIdx.x < (u32)kSpillBuckets ? a.sp.hist[(size_t)g * kSpillBuckets + threadIdx.x] : 0u;
+		u32 total;
+		const u32 before = census_block_exclusive(v, ws, &total);
+		if (threadIdx.x < (u32)kSpillBuckets) bpre[threadIdx.x] = before;
+		if (threadIdx.x == 0) bpre[kSpillBuckets] = total;
+		__syncthreads();
+	}
+	const u32 n = bpre[kSpillBuckets];
+	const u32 rot = n != 0u ? (u32)(((u64)g * 0x9E3779B1ull) % n) : 0u;
+	const uint4 *const key = a.sp.key + (size_t)g * kSpillBuckets * a.sp.cap;
+	// (four keys of a thread at a time, census_insert_many, was measured here: 3.0 ms against 2.5 for 32 M new keys — what bounds
+	// this kernel is the memory side's rate of scattered atomics and stores, not the chain's latency, and the plain loop asks less of it)
+	for (u32 jj = part * blockDim.x + threadIdx.x; jj < n; jj += (u32)split * blockDim.x) {
+		// (every workgroup begins somewhere else in its sequence: with all of them in the same bucket at the same time the
+		// whole chip inserts into 1/256 of the table — the same few DRAM rows)
+		u32 j = jj + rot;
+		j = j >= n ? j - n : j;
+		u32 l = 0u, r = (u32)kSpillBuckets;                               // the last bucket with bpre[b] <= j
+		while (r - l > 1u) { const u32 m = (l + r) >> 1; if (bpre[m] <= j) l = m; else r = m; }
+		const uint4 k = key[(size_t)l * a.sp.cap + (j - bpre[l])];
 		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-		const u32 cnt = census_rec_count(k.w);
-		if (!census_insert(a.tab, a.mask, klo, khi, (u64)cnt, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += cnt;
+		const u32 c = census_rec_count(k.w);
+		if (!census_insert(a.tab, a.mask, klo, khi, (u64)c, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += c;
 	}
 	census_add_stats(a.stats, claimed, overflow, red);
 }
@@ -1217,7 +1274,7 @@ __global__ __launch_bounds__(256) void census_compact_kernel(const CensusSlot *t
 }
 
 // the instantiations: R tiles per step x dwords per row (2, 5, 8: barcodes of at most 8, 20, 31 characters) x spill
-constexpr int kCensusVariants = 4 * 3 * 2;
+constexpr int kCensusVariants = kCensusMaxSub * 3 * 2;
 static const void *census_variant(int v)
 {
 	static const void *const tab[kCensusVariants] = {
@@ -1225,10 +1282,6 @@ static const void *census_variant(int v)
 		(const void *)census_kernel<1, 8, false>, (const void *)census_kernel<1, 8, true>,
 		(const void *)census_kernel<2, 2, false>, (const void *)census_kernel<2, 2, true>, (const void *)census_kernel<2, 5, false>, (const void *)census_kernel<2, 5, true>,
 		(const void *)census_kernel<2, 8, false>, (const void *)census_kernel<2, 8, true>,
-		(const void *)census_kernel<3, 2, false>, (const void *)census_kernel<3, 2, true>, (const void *)census_kernel<3, 5, false>, (const void *)census_kernel<3, 5, true>,
-		(const void *)census_kernel<3, 8, false>, (const void *)census_kernel<3, 8, true>,
-		(const void *)census_kernel<4, 2, false>, (const void *)census_kernel<4, 2, true>, (const void *)census_kernel<4, 5, false>, (const void *)census_kernel<4, 5, true>,
-		(const void *)census_kernel<4, 8, false>, (const void *)census_kernel<4, 8, true>,
 	};
 	return tab[v];
 }
@@ -1258,7 +1311,6 @@ hipError_t census_create(Census **out, hipStream_t st)
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
 	for (int v = 0; v < kCensusVariants; v++)
 		if (e == hipSuccess) e = hipFuncSetAttribute(census_variant(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)census_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLds);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
 	*out = cs;
 	return hipSuccess;
@@ -1316,30 +1368,31 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 
 static void census_spill_free(Census *cs)
 {
-	void *ptrs[] = {cs->sp.key, cs->sp.skey, cs->sp.hist, cs->sp.offs, cs->sp.btot, cs->sp.bstart, cs->sp.wg_count, cs->sp.wg_stats, cs->sp.work};
+	void *ptrs[] = {cs->sp.key, cs->sp.hist, cs->sp.btot, cs->sp.wg_count, cs->sp.wg_stats, cs->sp.work};
 	for (void *q : ptrs) if (q) (void)hipFree(q);
 	cs->sp = CensusSpill();
 	cs->sp_records = 0;
 	cs->sp_grid = 0;
 }
 
-// room for `grid` workgroup regions of `cap` records each (32 B per record: as spilled and as sorted)
-static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap)
+// room for `grid` workgroups x kSpillBuckets regions of `cap` records each
+static hipError_t census_spill_reserve(Census *cs, int grid, u32 cap, hipStream_t st)
 {
-	const size_t records = (size_t)grid * cap;
+	const size_t records = (size_t)grid * kSpillBuckets * cap;
 	if (records <= cs->sp_records && grid <= cs->sp_grid) return hipSuccess;
 	const size_t want_records = std::max(records, cs->sp_records);
 	const int want_grid = std::max(grid, cs->sp_grid);
+	hipError_t e = hipStreamSynchronize(st);                           // (an earlier launch may still be reading the arrays that go)
+	if (e != hipSuccess) return e;
 	census_spill_free(cs);
-	hipError_t e = hipMalloc((void **)&cs->sp.key, want_records * sizeof(uint4));
-	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.skey, want_records * sizeof(uint4));
+	e = hipMalloc((void **)&cs->sp.key, want_records * sizeof(uint4));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.hist, (size_t)want_grid * kSpillBuckets * sizeof(u32));
-	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.offs, (size_t)want_grid * kSpillBuckets * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.btot, kSpillBuckets * sizeof(u32));
-	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.bstart, (kSpillBuckets + 1) * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_count, (size_t)want_grid * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.wg_stats, (size_t)want_grid * kCensusStats * sizeof(u32));
 	if (e == hipSuccess) e = hipMalloc((void **)&cs->sp.work, sizeof(u32));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->sp.btot, 0, kSpillBuckets * sizeof(u32), st);      // (later launches find them zero: census_direct_kernel)
+	if (e == hipSuccess) e = hipMemsetAsync(cs->sp.work, 0, sizeof(u32), st);
 	if (e != hipSuccess) { (void)hipGetLastError(); census_spill_free(cs); return e; }
 	cs->sp_records = want_records;
 	cs->sp_grid = want_grid;
@@ -1358,24 +1411,30 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	R = R < 1 ? 1 : (R > kCensusMaxSub ? kCensusMaxSub : R);
 	if (const char *ev = getenv("SK_CENSUS_TILES")) { const int v = atoi(ev); if (v >= 1 && v <= R) R = v; }      // experiments
 	const int nw_dwords = L <= 8 ? 2 : (L <= 20 ? 5 : 8);
+	// (two 64-row tiles per step at most: more bought nothing — R = 1 ... 4 timed the same within the boxes' noise in round 4 — and
+	// a tile's 64 queue entries are 43 front-table entries of a 17-byte sheet)
 	// a wave's slot: its queue of rows that take the long way, 64 left over + the step's R x 64, each its NW dwords and its
-	// row's index; behind the first 64 entries there must be room for the flush queue of the launches that insert by themselves.
-	// Two 64-row tiles per step at most: more buy nothing (R = 1 ... 4 time the same within the boxes' noise) and a tile's
-	// 64 queue entries are 43 front-table entries of a 17-byte sheet
-	if (R > 2) R = 2;
-	const int queue_cap = 64 + R * 64;
-	int tile_slot = queue_cap * (4 * nw_dwords + 4);
-	const int flush_end = ((queue_cap * 4 + 64 * 4 * nw_dwords + 15) & ~15) + kCensusQueue * 20;
-	if (tile_slot < flush_end) tile_slot = flush_end;
-	tile_slot = (tile_slot + 15) & ~15;
-	size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32);      // + the spill counters
+	// row's index; behind it the flush queue of the launches that insert by themselves (over the queue's dead part)
+	auto slot_bytes = [&](int r, bool spill_layout) {
+		const int queue_cap = 64 + r * 64;
+		int bytes = queue_cap * (4 * nw_dwords + 4);
+		if (!spill_layout) {
+			const int flush_end = ((queue_cap * 4 + 64 * 4 * nw_dwords + 15) & ~15) + kCensusQueue * 20;
+			if (bytes < flush_end) bytes = flush_end;
+		}
+		return (bytes + 15) & ~15;
+	};
 	// the front table takes what is left of the CU's 160 KiB (SK_CENSUS_FRONT_ENTRIES: tests shrink it so that small inputs
 	// walk "no room in either place")
 	const int nw_class = L <= 8 ? 0 : (L <= 20 ? 1 : 2);
 	const int front_entry_bytes = nw_class == 2 ? 52 : 36;            // FrontShape<NW>::kEntryBytes
-	int front_entries = (int)((160 * 1024 - 16 - lds) / front_entry_bytes) & ~63;
-	if (const char *ev = getenv("SK_CENSUS_FRONT_ENTRIES")) { const int v = atoi(ev) & ~63; if (v >= 64 && v <= front_entries) front_entries = v; }
-	lds += ((size_t)front_entries * front_entry_bytes + 15) & ~(size_t)15;
+	auto plan_lds = [&](int r, bool spill_layout, int &tile_slot, int &front_entries) {
+		tile_slot = slot_bytes(r, spill_layout);
+		size_t lds = (size_t)kCensusWaves * tile_slot + 64 + (kSpillBuckets + 4) * sizeof(u32);      // + the workgroup's cursors and its step counter
+		front_entries = (int)((160 * 1024 - 16 - lds) / front_entry_bytes) & ~63;
+		if (const char *ev = getenv("SK_CENSUS_FRONT_ENTRIES")) { const int v = atoi(ev) & ~63; if (v >= 64 && v <= front_entries) front_entries = v; }
+		return lds + (((size_t)front_entries * front_entry_bytes + 15) & ~(size_t)15);
+	};
 	int wgs_per_cu = 1;
 	if (const char *ev = getenv("SK_CENSUS_WGS")) { const int v = atoi(ev); if (v >= 1 && v <= 4) wgs_per_cu = v; }      // experiments
 	int direct_pct = 50;                                    // SK_CENSUS_SPILL_MAX_PCT: more spilled rows than this share of a launch are inserted directly
@@ -1426,17 +1485,24 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.tab = cs->tab;
 		a.mask = cs->slots - 1;
 		a.stats = cs->stats;
-		const int64_t groups = (nr + (int64_t)64 * R * kCensusWaves - 1) / ((int64_t)64 * R * kCensusWaves);
-		int grid = n_cu * wgs_per_cu;
-		if (grid > groups) grid = (int)groups;
 		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
+		const int Rk = R;
+		auto grid_of = [&](int r) {
+			const int64_t groups = (nr + (int64_t)64 * r * kCensusWaves - 1) / ((int64_t)64 * r * kCensusWaves);
+			const int g = n_cu * wgs_per_cu;
+			return g > groups ? (int)groups : g;
+		};
+		int grid = grid_of(Rk);
 		a.sp = CensusSpill();
 		if (spill) {
-			const int64_t nsteps = (nr + (int64_t)64 * R - 1) / ((int64_t)64 * R);
+			// a (workgroup, bucket) region: twice the workgroup's share of a launch in which EVERY row is spilled and spreads evenly, and
+			// room for its front table's records; a piece that finds its region full is inserted by the front kernel itself
+			const int64_t nsteps = (nr + (int64_t)64 * Rk - 1) / ((int64_t)64 * Rk);
 			const int64_t per_wave = (nsteps + (int64_t)grid * kCensusWaves - 1) / ((int64_t)grid * kCensusWaves);
-			const int64_t cap = per_wave * kCensusWaves * R * 64;
-			e = cap < (1 << 26) ? census_spill_reserve(cs, grid, (u32)cap) : hipErrorInvalidValue;
-			if (e != hipSuccess) { (void)hipGetLastError(); spill = false; }      // no room for the records: insert directly
+			const int64_t wg_rows = per_wave * kCensusWaves * Rk * 64;
+			const int64_t cap = (((wg_rows + kSpillBuckets - 1) / kSpillBuckets) * 2 + 256 + 7) & ~(int64_t)7;
+			e = (grid <= kSpillMaxGrid && cap * kSpillBuckets < ((int64_t)1 << 27)) ? census_spill_reserve(cs, grid, (u32)cap, st) : hipErrorInvalidValue;
+			if (e != hipSuccess) { (void)hipGetLastError(); spill = false; grid = grid_of(Rk); }      // no room for the records: insert directly
 			else {
 				a.sp = cs->sp;
 				a.sp.cap = (u32)cap;
@@ -1448,21 +1514,11 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
 			}
 		}
-		// (the variants that insert by themselves need more registers than those that write records: with four tiles of <= 20
-		// characters, or three of more, they would keep values in scratch — and a scratch reload waits for the step's prefetch)
-		int Rk = R;
-		if (!spill) {
-			if (nw_class == 1 && Rk > 3) Rk = 3;
-			if (nw_class == 2 && Rk > 2) Rk = 2;
-			const int64_t groups_k = (nr + (int64_t)64 * Rk * kCensusWaves - 1) / ((int64_t)64 * Rk * kCensusWaves);
-			grid = n_cu * wgs_per_cu;
-			if (grid > groups_k) grid = (int)groups_k;
-		}
+		int tile_slot = 0, front_entries = 0;
+		const size_t lds = plan_lds(Rk, spill, tile_slot, front_entries);
 		hipLaunchKernelGGL(reinterpret_cast<void (*)(const CensusArgs, const int, const int)>(const_cast<void *>(census_variant(((Rk - 1) * 3 + nw_class) * 2 + (spill ? 1 : 0)))),
 		                   dim3(grid), dim3(kCensusWaves * 64), lds, st, a, tile_slot, front_entries);
 		if (spill) {
-			census_scan_kernel<<<kSpillBuckets / kScanBuckets, 1024, 0, st>>>(a.sp.hist, a.sp.offs, a.sp.btot, a.sp.work, grid, a.sp.wg_stats, a.stats);
-			census_scatter_kernel<<<grid, 1024, kScatterLds, st>>>(a.sp, a.mask);
 			census_combine_kernel<<<2 * n_cu, kCombineThreads, 0, st>>>(a);
 			census_direct_kernel<<<grid * direct_split, kDirectThreads, 0, st>>>(a, direct_split);
 		}
@@ -1544,5 +1600,9 @@ hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint
 extern "C" int sk_debug_census_stamps(unsigned long long *out, int waves)
 {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sk::g_census_stamps), (size_t)waves * sk::kStampSlots * sizeof(unsigned long long));
+}
+extern "C" int sk_debug_combine_stamps(unsigned long long *out, int waves)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sk::g_combine_stamps), (size_t)waves * sk::kStampSlots * sizeof(unsigned long long));
 }
 #endif

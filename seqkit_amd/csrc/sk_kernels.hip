@@ -2110,7 +2110,11 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 				std::lock_guard<std::mutex> lk(occ_m);
 				occ.push_back({dev, fn, lds, wg});
 			}
-			if (const char *env_wg = getenv("SK_LUT_WG")) { const int v = atoi(env_wg); if (v >= 1 && v < wg) wg = v; }
+			// sixteen waves per CU whatever the table leaves room for: with its rows coming from HBM a 10 M-row call of the cfg 3 sheet
+			// took 25.3 us on sixteen and 26.7 on thirty-two (each wave's first load is a full HBM round trip before anything
+			// moves, and twice the waves end in twice the stragglers); 100 M rows the same (tools/lut_cold_ab.py)
+			if (ldstab && wg > 1) wg = 1;
+			if (const char *env_wg = getenv("SK_LUT_WG")) { const int v = atoi(env_wg); if (v >= 1) wg = v; }
 			const int tile_rows = 4 * kTileRows;                      // a wave's unit: 256 rows in either kernel
 			const int64_t ntiles = (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;

@@ -19,8 +19,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32_000_000
 dev = torch.device("cuda", 0)
 ctx = seqkit_amd.Context(0, lib_path=LIB)
 lib = C.CDLL(LIB)
-PHASES = ["init", "wait loads + tile write", "fence + issue next loads", "rows the front table knows", "long way", "parked: spill/insert", "loop exit", "end barrier",
-          "merge front table", "stats"]
+PHASES = ["tables cleared", "step's loads waited for, rows aligned", "fence + next step's loads issued", "rows the front table knows", "long way", "parked keys: records / inserts",
+          "loop exit", "end barrier", "front table leaves the workgroup", "statistics"]
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 CASES = os.environ.get("SK_STAMPS_CASES", "exact,clean,noisy").split(",")
 for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact=0.97, p_sub=0.025)), ("noisy", {})):
@@ -44,10 +44,10 @@ for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact
         cw = 2 * 256 * 8
         cbuf = np.zeros((cw, 16), dtype=np.uint64)
         if hasattr(lib, "sk_debug_combine_stamps") and lib.sk_debug_combine_stamps(cbuf.ctypes.data_as(C.c_void_p), cw) == 0:
-            ctot = cbuf[:, :8].sum(axis=1).astype(np.float64)
+            ctot = cbuf[:, :9].sum(axis=1).astype(np.float64)
             print(f"   -- combine kernel, mean cycles per wave {ctot.mean():.0f}")
-            for i, name in enumerate(["records counted + items scanned", "take an item, clear the table", "find bucket and range", "count the records", "barrier", "list occupied slots",
-                                      "insert distinct keys", "statistics"]):
+            for i, name in enumerate(["statistics, records counted, items scanned", "an item taken, the table cleared", "the bucket's regions scanned", "next records asked for, keys hashed",
+                                      "counted in the table", "keys without a place: to HBM", "barrier behind the records", "occupied slots listed and inserted", "end"]):
                 c = cbuf[:, i].astype(np.float64)
                 print(f"      {name:32s} {c.mean():10.0f} cycles  {100 * c.mean() / max(ctot.mean(), 1):5.1f} %")
         sys.stdout.flush()
