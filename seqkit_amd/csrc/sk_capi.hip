@@ -382,7 +382,8 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	SK_HIP(c, hipMalloc((void **)&c->d_counts, (size_t)(S + 3) * 8));
 	SK_HIP(c, hipMemset(c->d_counts, 0, (size_t)(S + 3) * 8));
 	if (S <= sk::kLutMaxSamples) {
-		const size_t wide_bytes = (((size_t)sk::kCountReplicas * (S + 3)) << sk::kCountWideShift) * 8;
+		const size_t wide_bytes = S + 3 > sk::kCountDenseFrom ? (size_t)sk::kCountDenseRows * (S + 3) * 8
+		                                                        : (((size_t)sk::kCountReplicas * (S + 3)) << sk::kCountWideShift) * 8;
 		SK_HIP(c, hipMalloc((void **)&c->d_counts_wide, wide_bytes));
 		SK_HIP(c, hipMemset(c->d_counts_wide, 0, wide_bytes));
 	}
@@ -439,7 +440,7 @@ static sk::BarcodeDev table_of(const sk_ctx *c)
 static int fold_counts(sk_ctx *c)
 {
 	if (!c->wide_dirty) return SK_OK;
-	SK_HIP(c, sk::launch_counts_fold_wide(c->d_counts_wide, c->S + 3, c->d_counts, c->stream));
+	SK_HIP(c, sk::launch_counts_fold_wide(c->d_counts_wide, c->S + 3, c->S + 3 > sk::kCountDenseFrom ? sk::kCountDenseRows : 0, c->d_counts, c->stream));
 	c->wide_dirty = false;
 	return SK_OK;
 }
@@ -764,6 +765,7 @@ static sk::TileArgs tile_args_of(const sk_ctx *c, const sk_fused_args *a)
 	t.detail_matched = c->detail_mode == SK_DETAIL_MATCHED ? 1 : 0;
 	t.counts = a->counts ? (unsigned long long *)a->counts : c->d_counts;
 	t.counts_wide = a->counts ? nullptr : c->d_counts_wide;
+	t.counts_wide_rows = (t.counts_wide && c->S + 3 > sk::kCountDenseFrom) ? sk::kCountDenseRows : 0;
 	return t;
 }
 

@@ -72,12 +72,18 @@ struct TileArgs {
 	int16_t *last_idx;
 	int detail_matched;             // SK_DETAIL_MATCHED: the detail columns of SK_ASSIGN_NONE rows are unspecified
 	unsigned long long *counts;     // device u64[S+3]
-	unsigned long long *counts_wide;    // or nullptr: kCountReplicas copies of the ctx's counters with one 128-byte line each (counter i of
-	                                    // copy r at [(r * (S+3) + i) << kCountWideShift]); the lookup kernel adds there instead of to `counts`,
-	                                    // the ctx folds before anything reads
+	unsigned long long *counts_wide;    // or nullptr: copies of the ctx's counters that the lookup kernel adds to instead of `counts`; the ctx folds
+	                                    // them before anything reads.  counts_wide_rows == 0: kCountReplicas copies with one 128-byte line per
+	                                    // counter (counter i of copy r at [(r * (S+3) + i) << kCountWideShift]: a few counters that hundreds of
+	                                    // workgroups add to at once); > 0 (sheets of more than kCountDenseFrom counters): that many dense rows of
+	                                    // S + 3, a workgroup adds to row blockIdx.x % rows — a thousand counters at a line each are a thousand
+	                                    // uncoalesced atomics per workgroup, 17 us at the end of a 10 M-pair call of a 1 000-sample sheet
+	int counts_wide_rows;
 };
 constexpr int kCountWideShift = 4;
-hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, unsigned long long *counts, hipStream_t st);
+constexpr int kCountDenseFrom = 160;     // S + 3 above this: dense rows
+constexpr int kCountDenseRows = 512;
+hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, int dense_rows, unsigned long long *counts, hipStream_t st);
 
 // Tile-blocked batch (include/seqkit_hip.h: sk_blocked_layout): tile t of 64 clusters reads the ONE byte range
 // in + t*in_block .. +in_block and writes out + t*out_block .. +out_block; the offsets say where each segment of the

@@ -855,9 +855,31 @@ __global__ __launch_bounds__(256) void counts_fold_wide_kernel(unsigned long lon
 	__syncthreads();
 	if (threadIdx.x == 0 && identified) counts[nc - 2] += identified;
 }
-hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, unsigned long long *counts, hipStream_t st)
+// the dense rows (TileArgs::counts_wide_rows): block (x, y) sums counters 256 x ... of rows y, y + gridDim.y, ... — a thread's loads
+// are independent, neighbouring threads read neighbouring counters
+__global__ __launch_bounds__(256) void counts_fold_dense_kernel(unsigned long long *__restrict__ wide, int nc, int rows, unsigned long long *__restrict__ counts)
 {
-	counts_fold_wide_kernel<<<1, 256, 0, st>>>(wide, nc, counts);
+	__shared__ unsigned long long identified;
+	if (threadIdx.x == 0) identified = 0;
+	__syncthreads();
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	unsigned long long sum = 0;
+	if (i < nc) {
+		for (int r = (int)blockIdx.y; r < rows; r += (int)gridDim.y) {
+			unsigned long long *p = wide + (size_t)r * nc + i;
+			const unsigned long long v = *p;
+			if (v) { sum += v; *p = 0; }
+		}
+		if (sum && i != nc - 2) atomicAdd(&counts[i], sum);          // (as above: `identified` comes from the samples' bins alone)
+	}
+	if (i < nc - 3 && sum) atomicAdd(&identified, sum);
+	__syncthreads();
+	if (threadIdx.x == 0 && identified) atomicAdd(&counts[nc - 2], identified);
+}
+hipError_t launch_counts_fold_wide(unsigned long long *wide, int nc, int dense_rows, unsigned long long *counts, hipStream_t st)
+{
+	if (dense_rows > 0) counts_fold_dense_kernel<<<dim3((unsigned)((nc + 255) / 256), 16), 256, 0, st>>>(wide, nc, dense_rows, counts);
+	else counts_fold_wide_kernel<<<1, 256, 0, st>>>(wide, nc, counts);
 	return hipGetLastError();
 }
 // derive: the copies were filled by a lookup kernel, which leaves `identified` to be summed from the samples' bins here
@@ -1665,7 +1687,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	// a few hundred workgroups end together, and an addition to an address that others add to takes about 10 ns: 512 x 19
 	// of them into two lines were 4.5 of cfg 3's 31 us at 10 M reads.  When the counters are the ctx's they go to one of
 	// sixteen copies with a line per counter (folded before anything reads them), else to the caller's vector as it is
-	if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
+	if (a.counts_wide && a.counts_wide_rows) flush_counts(S, a.counts_wide + (size_t)(blockIdx.x % (unsigned)a.counts_wide_rows) * (S + 3), lp, hist, lane, wc, 0);
+	else if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
 	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
@@ -1834,7 +1857,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	}
 	if (!a.counts_wide && !a.table.count_rep) lut_identified_from_hist(S, hist, lane);      // nobody folds behind this launch
 	const WaveCounts wc = {n_total, 0u, 0u};
-	if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
+	if (a.counts_wide && a.counts_wide_rows) flush_counts(S, a.counts_wide + (size_t)(blockIdx.x % (unsigned)a.counts_wide_rows) * (S + 3), lp, hist, lane, wc, 0);
+	else if (a.counts_wide) flush_counts(S, a.counts_wide + (((size_t)(blockIdx.x & (kCountReplicas - 1)) * (S + 3)) << kCountWideShift), lp, hist, lane, wc, kCountWideShift);
 	else flush_counts_spread(a.table, a.counts, lp, hist, lane, wc);
 }
 
