@@ -540,9 +540,10 @@ def secondary_rates(torch, ctx, dev):
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
     timeit("96 dual-index, 100M x 17ch in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 17, 10 * n, assign_l.data_ptr()), 10 * n, 21, iters=3)
     del bc_l, assign_l, calls, keep
-    # a sheet OUTSIDE the lookup table's domain: the 96 dual-index sheet with every other sample typed in lower case — nine letters
-    # and the separator, where the table's 3-bit classes hold seven (the reference compares raw bytes, src/fasta_demultiplex.rs:273-274,
-    # so such a sheet is legal).  It is served by the S x L matchers (demux_tile_kernel): VALU-bound, ~350 instructions per read.
+    # the 96 dual-index sheet with every other sample typed in lower case — nine letters and the separator, where the table's
+    # 3-bit classes hold seven (the reference compares raw bytes, src/fasta_demultiplex.rs:273-274, so such a sheet is legal).
+    # Through round 4 it ran the S x L matchers (demux_tile_kernel: VALU-bound, ~350 instructions per read, 0.15-0.19); since round 5
+    # it gets 4-bit classes and the factored form (sk_lut.h, "Wide classes") — the row says which, from sk_barcode_table_info.
     table_mc = table.copy()
     table_mc[1::2] = np.where((table_mc[1::2] >= 65) & (table_mc[1::2] <= 90), table_mc[1::2] + 32, table_mc[1::2])
     ctx.set_barcodes(table_mc, 1)
@@ -550,7 +551,10 @@ def secondary_rates(torch, ctx, dev):
     odd = torch.arange(n, device=dev) % 2 == 1                  # (half of the reads in lower case too, so that both halves of the sheet are matched)
     bc_mc[odd] = torch.where((bc_mc[odd] >= 65) & (bc_mc[odd] <= 90), bc_mc[odd] + 32, bc_mc[odd])
     calls, keep = demux_sets(bc_mc, 17, 21)
-    timeit("demultiplex only 10M x 17ch, 96 dual-index, a mixed-case sheet (no lookup table: the matchers)", None, n, 21, sets=calls)
+    kind = ctx.barcode_table_info()["kind"]
+    served = ("the matchers" if kind == capi.SK_TABLE_NONE else ("looked up half by half" if kind & capi.SK_TABLE_FACTORED else "full-key table")
+              + (", wide classes" if kind & capi.SK_TABLE_WIDE_CLASSES else ""))
+    timeit(f"demultiplex only 10M x 17ch, 96 dual-index, a mixed-case sheet (9 letters: {served})", None, n, 21, sets=calls)
     del calls, keep, bc_mc, odd
     # four plates: 384 dual-index samples (24 x 16 combinations).  The full-key table would be 512 KiB, so the sheet is looked
     # up half by half from LDS (sk_lut.h, the factored form)

@@ -94,7 +94,8 @@ int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n
  *                     -1 when the lookup table answers).  A demultiplex-alone call with max_diff <= 1 is then ONE table
  *                     lookup per read — the sheet's rows and their one-substitution neighbours, decided on the host with
  *                     the same loop — instead of S x L compares, for sheets of <= 1021 samples, <= 20 columns, <= 7
- *                     letters (a row with `N` / `U` where other rows hold a letter is entered once per class of that
+ *                     letters (8 to 15 letters — a sheet typed partly in lower case — when its rows, or the two halves
+ *                     beside a separator, are at most 8 columns; a row with `N` / `U` where other rows hold a letter is entered once per class of that
  *                     column: a few such columns per row, up to 220 000 keys in all); a dual-index sheet whose table would not fit a
  *                     workgroup's LDS is looked up half by half when that is exact (its half-barcodes at least 3
  *                     apart); other sheets run the matchers and fill every row.  The decision-only form (all three
@@ -104,6 +105,15 @@ int sk_demux_assign_dev(sk_ctx *ctx, const uint8_t *bc, int bc_stride, int64_t n
 #define SK_DETAIL_FULL    0
 #define SK_DETAIL_MATCHED 1
 int sk_set_detail_mode(sk_ctx *ctx, int mode);
+/* What serves the calls described above for the current sheet (the table is built here if no call has asked for it yet;
+ * src/fasta_demultiplex.rs:154-194 is what it answers either way): *kind = SK_TABLE_NONE (the S x L matchers), SK_TABLE_FULL_KEY
+ * or SK_TABLE_FACTORED, or-ed with SK_TABLE_WIDE_CLASSES for a sheet of 8 to 15 letters; *keys = its entries, *bytes = its size
+ * on the device.  Any of the three pointers may be NULL.  A host logs it; the tests assert which path they exercise.       */
+#define SK_TABLE_NONE         0
+#define SK_TABLE_FULL_KEY     1
+#define SK_TABLE_FACTORED     2
+#define SK_TABLE_WIDE_CLASSES 4
+int sk_barcode_table_info(sk_ctx *ctx, int *kind, int64_t *keys, int64_t *bytes);
 
 /* ---- T1: 3' running-sum quality trim --------------------------------------------------------------
  * src/fasta_trim_by_quality.rs:28-42.  qual rows are the quality line after trim_end(); writes

@@ -22,7 +22,7 @@ SK_ASSIGN_AMBIGUOUS = -2
 EXPORTED_SYMBOLS = [
     "sk_version", "sk_device_count", "sk_create", "sk_destroy", "sk_last_error", "sk_sync", "sk_stream",
     "sk_malloc_device", "sk_free_device", "sk_malloc_pinned", "sk_free_pinned", "sk_copy_h2d", "sk_copy_d2h",
-    "sk_set_barcodes", "sk_set_detail_mode", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
+    "sk_set_barcodes", "sk_set_detail_mode", "sk_barcode_table_info", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
     "sk_blocked_layout_init", "sk_fused_pass_blocked_dev", "sk_fused_tune_placement_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
@@ -56,6 +56,7 @@ class _FusedCandidates(C.Structure):
 
 SK_BLK_MASK, SK_BLK_TRIM, SK_BLK_LEN, SK_BLK_DETAIL = 1, 2, 4, 8
 SK_DETAIL_FULL, SK_DETAIL_MATCHED = 0, 1
+SK_TABLE_NONE, SK_TABLE_FULL_KEY, SK_TABLE_FACTORED, SK_TABLE_WIDE_CLASSES = 0, 1, 2, 4
 
 
 class BlockedLayout(C.Structure):
@@ -152,6 +153,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_malloc_pinned": (i32, [vp, C.c_size_t, C.POINTER(vp)]), "sk_free_pinned": (i32, [vp, vp]),
         "sk_copy_h2d": (i32, [vp, vp, vp, C.c_size_t]), "sk_copy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
         "sk_set_barcodes": (i32, [vp, vp, i32, i32, i32]), "sk_set_detail_mode": (i32, [vp, i32]),
+        "sk_barcode_table_info": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "sk_demux_assign": (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
         "sk_demux_assign_dev": (i32, [vp, vp, i32, i64, vp, vp, vp, vp, vp]),
         "sk_trim_by_quality": (i32, [vp, vp, vp, i32, i64, u8, vp]),
@@ -325,6 +327,12 @@ class Context:
     def set_detail_mode(self, mode: int) -> None:
         """DETAIL_FULL: lowest_diff/first/last of every row; DETAIL_MATCHED: of rows with assign != -1 only (include/seqkit_hip.h)."""
         self._check(self._lib.sk_set_detail_mode(self._h, mode), "sk_set_detail_mode")
+
+    def barcode_table_info(self) -> dict:
+        """What serves demultiplex-alone calls of the current sheet: kind (TABLE_NONE / TABLE_FULL_KEY / TABLE_FACTORED, | TABLE_WIDE_CLASSES), keys, bytes."""
+        kind, keys, nbytes = C.c_int(), C.c_int64(), C.c_int64()
+        self._check(self._lib.sk_barcode_table_info(self._h, C.byref(kind), C.byref(keys), C.byref(nbytes)), "sk_barcode_table_info")
+        return {"kind": int(kind.value), "keys": int(keys.value), "bytes": int(nbytes.value)}
 
     def counts_reset(self) -> None:
         self._check(self._lib.sk_counts_reset(self._h), "sk_counts_reset")

@@ -37,6 +37,7 @@ struct sk_ctx {
 	sk::LutDev nbr{};
 	std::vector<uint8_t> sheet;        // the sheet as given to sk_set_barcodes (the table is built from it on first use)
 	bool nbr_tried = false;
+	int64_t nbr_keys = 0, nbr_bytes = 0;
 	int detail_mode = SK_DETAIL_FULL;
 	unsigned long long *d_counts = nullptr;    // u64[S+3]
 	unsigned long long *d_counts_wide = nullptr;   // TileArgs::counts_wide: 16 x (S+3) lines; folded into d_counts by fold_counts()
@@ -418,9 +419,23 @@ static int ensure_neighbour_table(sk_ctx *c)
 	if (amb_bytes) SK_HIP(c, hipMemcpy(c->d_nbr + slot_bytes, h.amb.data(), amb_bytes, hipMemcpyHostToDevice));
 	SK_HIP(c, hipDeviceSynchronize());     // the ctx streams are non-blocking: make the upload visible to them
 	c->nbr = h.dev;
+	c->nbr_keys = (int64_t)h.n_keys; c->nbr_bytes = (int64_t)(slot_bytes + amb_bytes);
 	if (h.dev.pair.bytes != 0) c->nbr.pair.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);      // the factored form: three tables in one blob
 	else c->nbr.tab = reinterpret_cast<const uint32_t *>(c->d_nbr);
 	c->nbr.amb = reinterpret_cast<const int16_t *>(c->d_nbr + slot_bytes);
+	return SK_OK;
+}
+
+int sk_barcode_table_info(sk_ctx *c, int *kind, int64_t *keys, int64_t *bytes)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (!c->have_table) return fail(c, SK_ERR_STATE, "sk_set_barcodes has not been called");
+	if (int r = bind(c)) return r;
+	if (int r = ensure_neighbour_table(c)) return r;
+	const bool full = c->nbr.tab != nullptr, pair = c->nbr.pair.tab != nullptr;
+	if (kind) *kind = (full ? SK_TABLE_FULL_KEY : pair ? SK_TABLE_FACTORED : SK_TABLE_NONE) | ((full || pair) && c->nbr.wide ? SK_TABLE_WIDE_CLASSES : 0);
+	if (keys) *keys = (full || pair) ? c->nbr_keys : 0;
+	if (bytes) *bytes = (full || pair) ? c->nbr_bytes : 0;
 	return SK_OK;
 }
 

@@ -1408,18 +1408,8 @@ template <int N> __device__ __forceinline__ void gather_dwords(rsrc_t rb, int of
 	}
 }
 
-// The class of each of a dword's four bytes: the index of the sheet letter the byte equals, `other` for a byte the sheet never
-// uses (sk_lut.h).  8 instructions.  The byte -> mask step leans on v_perm_b32's selector rule (12 -> 0x00, 13 and above ->
-// 0xff): with x = byte ^ its candidate letter, (x & 0x7f) + 12 is 12 for x in {0, 0x80} and 13 ... 0x8b otherwise (no carry
-// leaves the byte); or-ing x back in lifts 0x80 to 0x8c; the selector 12 is then "equal" and everything else is not.
-__device__ __forceinline__ u32 lut_classes(u32 dw, const LutDev &t)
-{
-	const u32 sel = (dw >> t.sh) & 0x07070707u;
-	const u32 letter = __builtin_amdgcn_perm(t.tab_hi, t.tab_lo, sel);
-	const u32 df = dw ^ letter;                                        // zero byte <=> the observed byte is that letter
-	const u32 m = __builtin_amdgcn_perm(0u, 0u, ((df & kLo7) + 0x0c0c0c0cu) | df);     // 0xff in every byte that is not
-	return (m & t.other) | (~m & sel);
-}
+// (the class of each of a dword's four bytes — the index of the sheet letter the byte equals, `other` for a byte the sheet never
+// uses — is sk_lut.h's lut_classes: the CPU model of the table shares it)
 
 // ---------------------------------------------------------------------------------------------------
 // D1+D2+D3 by table lookup (sk_lut.h): demultiplex alone.  With max_diff <= 1 the barcodes that get a sample or the
@@ -1584,8 +1574,8 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				// tables are two-choice cuckoo tables of 8-byte entries that hold their key whole.
 				const LutPairDev &pr = t.pair;
 				constexpr int k2 = W1 < 4 ? W1 : 0, k3 = W1 + 1 < 5 ? W1 + 1 : 0;      // (PAIR: W1 <= 2)
-				const u32 A1 = (W1 == 1 ? c[0] : lut_pack_half(c[0], c[1])) & pr.keep1;
-				const u32 A2 = (W1 == 1 ? c[k2] : lut_pack_half(c[k2], c[k3])) & pr.keep2;
+				const u32 A1 = (W1 == 1 ? c[0] : lut_pack_half(c[0], c[1], t.wide)) & pr.keep1;
+				const u32 A2 = (W1 == 1 ? c[k2] : lut_pack_half(c[k2], c[k3], t.wide)) & pr.keep2;
 				const u32 x1 = lut_mix(A1, 0u, pr.seed1), x2 = lut_mix(A2, 0u, pr.seed2);
 				// (the six tables' places in LDS are constants of the launch; a table-2 slot is the nb bits below the top nb: one v_bfe)
 				auto at = [&](int base, u32 slot) { return *reinterpret_cast<const u32x2_t *>(sk_smem + base + (int)slot * 8); };
@@ -1607,7 +1597,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				idx = pfirst;
 			} else {
 				u32 A, B;
-				lut_pack(c, A, B);
+				lut_pack(c, A, B, t.wide);
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
 				const u32 y = lut_side2(x, t.nb);                             // table 2 takes the next nb bits
@@ -1778,7 +1768,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 					c[w] = lut_classes(d[2 * r + w], t);
 				}
 				u32 A, B;
-				lut_pack(c, A, B);
+				lut_pack(c, A, B, t.wide);
 				A &= t.keepA; B &= t.keepB;
 				const u32 x = lut_mix(A, B, t.seed);
 				const u32 y = lut_side2(x, t.nb);

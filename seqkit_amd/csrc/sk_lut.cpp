@@ -14,11 +14,11 @@ inline bool is_wildcard(uint8_t b) { return b == 'N' || b == 'U'; }      // src/
 
 struct Key { uint8_t cls[kLutMaxLen]; uint32_t A, B; };
 
-void pack_classes(const uint8_t *cls, uint32_t &A, uint32_t &B)
+void pack_classes(const uint8_t *cls, uint32_t &A, uint32_t &B, int wide)
 {
 	uint32_t c[5] = {0, 0, 0, 0, 0};
-	for (int k = 0; k < kLutMaxLen; k++) c[k >> 2] |= (uint32_t)cls[k] << (8 * (k & 3));
-	lut_pack(c, A, B);
+	for (int k = 0; k < (wide ? 8 : kLutMaxLen); k++) c[k >> 2] |= (uint32_t)cls[k] << (8 * (k & 3));
+	lut_pack(c, A, B, wide);
 }
 }  // namespace
 
@@ -55,6 +55,8 @@ template <typename XOf> bool cuckoo_place(size_t n, int nb_min, int nb_max, XOf 
 
 struct SheetShape {                      // what both forms need to know about a sheet
 	int S, L, max_diff, sep, W1, W2, sh, other;
+	int wide = 0, sh2 = 0;               // wide classes (sk_lut.h): 4 bits, the top one g[(b >> sh2) & 7]
+	uint8_t g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tab2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool counting[kLutMaxLen];
 	uint8_t tab[8];
 	std::vector<uint8_t> alts;
@@ -70,9 +72,13 @@ static void fill_common(const SheetShape &sh, const uint8_t *sheet, LutDev &d)
 	d.tab_lo = (uint32_t)sh.tab[0] | ((uint32_t)sh.tab[1] << 8) | ((uint32_t)sh.tab[2] << 16) | ((uint32_t)sh.tab[3] << 24);
 	d.tab_hi = (uint32_t)sh.tab[4] | ((uint32_t)sh.tab[5] << 8) | ((uint32_t)sh.tab[6] << 16) | ((uint32_t)sh.tab[7] << 24);
 	d.other = (uint32_t)sh.other * 0x01010101u;
+	d.wide = sh.wide; d.sh2 = sh.sh2;
+	auto word = [](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+	d.g_lo = word(sh.g); d.g_hi = word(sh.g + 4);
+	d.tab2_lo = word(sh.tab2); d.tab2_hi = word(sh.tab2 + 4);
 	uint8_t keep[kLutMaxLen] = {0};
-	for (int k = 0; k < sh.L; k++) if (sh.counting[k] && k != sh.sep) keep[sh.key_pos(k)] = 7;
-	pack_classes(keep, d.keepA, d.keepB);
+	for (int k = 0; k < sh.L; k++) if (sh.counting[k] && k != sh.sep) keep[sh.key_pos(k)] = sh.wide ? 15 : 7;
+	pack_classes(keep, d.keepA, d.keepB, sh.wide);
 	d.sep_off = sh.sep;
 	d.sep_val = sh.sep < 0 ? 0u : (uint32_t)sheet[sh.sep];
 	d.max_diff = sh.max_diff;
@@ -89,7 +95,7 @@ static bool build_pair(const SheetShape &sh, const uint8_t *sheet, LutHost &out,
 	auto half_word = [&](const uint8_t *cls) {
 		uint32_t c[2] = {0, 0};
 		for (int k = 0; k < hw; k++) c[k >> 2] |= (uint32_t)cls[k] << (8 * (k & 3));
-		return sh.W1 == 1 ? c[0] : lut_pack_half(c[0], c[1]);
+		return sh.W1 == 1 ? c[0] : lut_pack_half(c[0], c[1], sh.wide);
 	};
 	struct HalfKey { uint32_t A; int h, d; };
 	std::vector<HalfKey> hk[2];
@@ -176,7 +182,7 @@ static bool build_pair(const SheetShape &sh, const uint8_t *sheet, LutHost &out,
 	{	// the halves' keep masks: the counting columns' class bits in each half's word
 		uint8_t keep[2][8] = {{0}, {0}};
 		for (int k = 0; k < sh.L; k++)
-			if (sh.counting[k] && k != sh.sep) { const int kp = sh.key_pos(k); keep[kp / hw][kp % hw] = 7; }
+			if (sh.counting[k] && k != sh.sep) { const int kp = sh.key_pos(k); keep[kp / hw][kp % hw] = sh.wide ? 15 : 7; }
 		p.keep1 = half_word(keep[0]);
 		p.keep2 = half_word(keep[1]);
 	}
@@ -231,9 +237,9 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 			if (!is_wildcard(b) && !is_letter[b]) { is_letter[b] = true; letters.push_back(b); }
 		}
 	}
-	if (letters.size() > 7) return false;
+	if (letters.size() > 15) return false;
 	int sh = -1;
-	for (int t = 0; t <= 5 && sh < 0; t++) {
+	for (int t = 0; t <= 5 && sh < 0 && letters.size() <= 7; t++) {
 		bool used[8] = {false}, ok = true;
 		for (uint8_t b : letters) {
 			const int i = (b >> t) & 7;
@@ -242,15 +248,36 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 		}
 		if (ok) sh = t;
 	}
-	if (sh < 0) return false;
+	if (sh < 0) {
+		// Wide classes (sk_lut.h): a 3-bit window that leaves at most two letters per index, and a function g of another window
+		// that tells the two apart wherever there are two.  Only shapes whose key is one word per table: at most 8 columns
+		// without a separator, or two halves of at most 8 beside one (the factored form; no row with wildcards of its own then)
+		if (sep < 0 ? W1 > 2 : (W1 > 2 || mixed)) return false;
+		for (int t = 0; t <= 5 && sh < 0; t++) {
+			for (int t2 = 0; t2 <= 5 && sh < 0; t2++) {
+				for (int gm = 0; gm < 256 && sh < 0; gm++) {
+					bool used[16] = {false}, ok = true;
+					for (uint8_t b : letters) {
+						const int i = ((b >> t) & 7) | (((gm >> ((b >> t2) & 7)) & 1) << 3);
+						if (used[i]) { ok = false; break; }
+						used[i] = true;
+					}
+					if (ok) { sh = t; shp.wide = 1; shp.sh2 = t2; for (int j = 0; j < 8; j++) shp.g[j] = (uint8_t)(((gm >> j) & 1) << 3); }
+				}
+			}
+		}
+		if (sh < 0) return false;
+	}
 	shp.sh = sh;
-	auto index_of = [&](uint8_t b) { return (b >> sh) & 7; };
+	const int n_classes = shp.wide ? 16 : 8;
+	auto index_of = [&](uint8_t b) { return ((b >> sh) & 7) | (shp.wide ? shp.g[(b >> shp.sh2) & 7] : 0); };
 	uint8_t (&tab)[8] = shp.tab;
-	bool used[8] = {false};
-	for (int i = 0; i < 8; i++) tab[i] = (uint8_t)(((i ^ 1) & 7) << sh);      // a byte with ANOTHER index: nothing with index i equals it
-	for (uint8_t b : letters) { tab[index_of(b)] = b; used[index_of(b)] = true; }
+	bool used[16] = {false};
+	for (int i = 0; i < 8; i++) tab[i] = shp.tab2[i] = (uint8_t)(((i ^ 1) & 7) << sh);      // a byte with ANOTHER index: nothing with index i equals it
+	for (uint8_t b : letters) { (index_of(b) < 8 ? tab : shp.tab2)[index_of(b) & 7] = b; used[index_of(b)] = true; }
 	int other = 0;
-	while (used[other]) other++;                                              // <= 7 letters: one of the 8 is free
+	while (other < n_classes && used[other]) other++;                         // <= 7 (15) letters: one of the 8 (16) is free
+	if (other >= n_classes) return false;
 	shp.other = other;
 	std::vector<uint8_t> &alts = shp.alts;
 	for (uint8_t b : letters) alts.push_back((uint8_t)index_of(b));
@@ -271,7 +298,7 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 			if (is_wildcard(b)) wild[(size_t)s].push_back(key_pos(k));
 			else rows[(size_t)s].cls[key_pos(k)] = (uint8_t)index_of(b);
 		}
-		pack_classes(rows[(size_t)s].cls, rows[(size_t)s].A, rows[(size_t)s].B);
+		pack_classes(rows[(size_t)s].cls, rows[(size_t)s].A, rows[(size_t)s].B, shp.wide);
 		size_t variants = 1;
 		for (size_t j = 0; j < wild[(size_t)s].size() && variants <= kMaxKeys; j++) variants *= alts.size();
 		const size_t fixed = (size_t)n_key_cols - wild[(size_t)s].size();
@@ -283,8 +310,9 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 	if (!mixed) {
 		int nbe = kLutMinBits;
 		while (((size_t)1 << nbe) * 84 < bound * 100) nbe++;
-		if (lds_budget > 0 && ((size_t)16 << nbe) > (size_t)lds_budget && build_pair(shp, sheet, out, lds_budget)) return true;
+		if (lds_budget > 0 && (shp.wide || ((size_t)16 << nbe) > (size_t)lds_budget) && build_pair(shp, sheet, out, lds_budget)) return true;
 	}
+	if (shp.wide && sep >= 0) return false;                                     // (wide classes with a separator: the factored form or none)
 	// Enumerate every row and every row with one key column changed, and DECIDE on the way (src/fasta_demultiplex.rs:154-166:
 	// lowest distance, first and last row attaining it, rows in sheet order).  The rows within distance 1 of a key are exactly
 	// the rows that generate it here — it is that row, or one substitution away from it — so a key's decision is the minimum
@@ -295,7 +323,7 @@ bool lut_build(const uint8_t *sheet, int S, int L, int max_diff, LutHost &out, i
 	{
 		std::unordered_map<uint64_t, size_t> at;
 		auto add = [&](Key k, int s, int d) {
-			pack_classes(k.cls, k.A, k.B);
+			pack_classes(k.cls, k.A, k.B, shp.wide);
 			auto ins = at.emplace(((uint64_t)k.A << 32) | k.B, keys.size());
 			if (ins.second) { keys.push_back(k); dec.push_back({d, s, s}); return; }
 			Decision &e = dec[ins.first->second];

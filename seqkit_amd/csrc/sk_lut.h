@@ -29,6 +29,12 @@
 // sheets of at most 128 samples (idx_shift 24, nb >= 9), 10 bits up to kLutMaxSamples (idx_shift 21, nb >= 12).
 // A free slot has w0 = kLutFree (bit 7 set: equals no key).
 //
+// Wide classes.  A sheet with 8 to 15 letters in its counting columns (one typed partly in lower case: the reference compares raw
+// bytes, src/fasta_demultiplex.rs:273-274) gets 4-bit classes when some 3-bit window of a byte plus ONE more bit — a function g
+// of another 3-bit window — tells its letters apart: class = (b >> sh) & 7 | g[(b >> sh2) & 7] << 3.  Eight columns then fill a
+// word, so the forms are: at most 8 columns and no separator (the full-key table, B == 0 for every key), or two halves of at most
+// 8 columns beside a separator in the factored form; any other shape keeps the matchers.
+//
 // The factored form (LutDev::pair): 384 dual-index samples x (16 x 4 + 1) keys are 25 k entries — 512 KiB, served from L2 at
 // half the rate of a table in LDS.  A sheet `i7+i5` with a separator is then looked up HALF BY HALF: one small table per
 // half (its distinct half-barcodes and their one-substitution neighbours -> half id h, distance d) and one table of the
@@ -75,6 +81,11 @@ struct LutDev {
 	int sh;                    // byte -> letter index: (b >> sh) & 7
 	uint32_t tab_lo, tab_hi;   // the letters by index (v_perm table); an unused index holds a byte with another index
 	uint32_t other;            // the class of "a byte the sheet never uses", in every byte
+	// wide classes (8 to 15 letters: a sheet typed in both cases; sk_lut.h "Wide classes"): the class is 4 bits, its top bit
+	// g[(b >> sh2) & 7]; classes 8 ... 15 have their letters in tab2; the key is one word (at most 8 columns per word)
+	int wide, sh2;
+	uint32_t g_lo, g_hi;       // eight bytes, 0x00 or 0x08
+	uint32_t tab2_lo, tab2_hi;
 	uint32_t keepA, keepB;     // class bits of the counting columns in the packed words
 	int sep_off;               // separator: its byte offset in the row (-1 = none; then W2 == 0) ...
 	uint32_t sep_val;          // ... and its letter
@@ -84,11 +95,40 @@ struct LutDev {
 	LutPairDev pair;           // the factored form (then tab above is nullptr)
 };
 
-// classes of 4 consecutive columns (one per byte, 3 bits each) x 5 dwords -> two words; no two fields overlap
-SK_HD inline void lut_pack(const uint32_t (&c)[5], uint32_t &A, uint32_t &B)
+// classes of 4 consecutive columns (one per byte, 3 bits each) x 5 dwords -> two words; no two fields overlap.
+// Wide classes (4 bits): eight columns at most, one word.
+SK_HD inline void lut_pack(const uint32_t (&c)[5], uint32_t &A, uint32_t &B, int wide = 0)
 {
+	if (wide) { A = c[0] | (c[1] << 4); B = 0u; return; }
 	A = c[0] | (c[1] << 3) | ((c[4] & 0x03030303u) << 6);
 	B = c[2] | (c[3] << 3) | ((c[4] & 0x04040404u) << 4);
+}
+
+// eight bytes (hi : lo) selected by the four bytes of sel, each 0 ... 7 (v_perm_b32)
+SK_HD inline uint32_t lut_perm8(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+	uint32_t out = 0;
+	for (int j = 0; j < 4; j++) {
+		const uint32_t q = (sel >> (8 * j)) & 0xffu;
+		out |= ((q < 4 ? lo >> (8 * q) : hi >> (8 * (q - 4))) & 0xffu) << (8 * j);
+	}
+	return out;
+#endif
+}
+// 0xff in every byte of df that is not zero.  On the device one v_perm_b32 whose selector rule does the work (12 -> 0x00, 13
+// and above -> 0xff): (df & 0x7f) + 12 is 12 for a byte in {0, 0x80} and 13 ... 0x8b otherwise (no carry leaves the byte);
+// or-ing df back in lifts 0x80 to 0x8c.
+SK_HD inline uint32_t lut_ne_mask(uint32_t df)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(0u, 0u, ((df & 0x7f7f7f7fu) + 0x0c0c0c0cu) | df);
+#else
+	const uint32_t nz = (((df & 0x7f7f7f7fu) + 0x7f7f7f7fu) | df) & 0x80808080u;
+	return nz - (nz >> 7) + nz;                     // 0x80 -> 0xff per byte
+#endif
 }
 
 SK_HD inline uint32_t lut_mix(uint32_t A, uint32_t B, uint32_t seed)
@@ -116,7 +156,23 @@ SK_HD inline uint32_t lut_side2(uint32_t x, int nb)
 SK_HD inline uint32_t lut_slot(uint32_t v, int nb) { return v >> (32 - nb); }
 
 // one half's key word: the classes of its (at most 8) columns, dwords 0 and 1 of the half interleaved as in lut_pack
-SK_HD inline uint32_t lut_pack_half(uint32_t c0, uint32_t c1) { return c0 | (c1 << 3); }
+SK_HD inline uint32_t lut_pack_half(uint32_t c0, uint32_t c1, int wide = 0) { return c0 | (c1 << (wide ? 4 : 3)); }
+
+// The class of each of a dword's four bytes: the index of the sheet letter the byte equals, `other` for a byte the sheet never
+// uses.  8 instructions on the device (16 with wide classes); the kernels and the CPU model of tests/cpp/lut_test.cpp share it.
+SK_HD inline uint32_t lut_classes(uint32_t dw, const LutDev &t)
+{
+	const uint32_t sel = (dw >> t.sh) & 0x07070707u;
+	uint32_t letter = lut_perm8(t.tab_hi, t.tab_lo, sel), cls = sel;
+	if (t.wide) {
+		const uint32_t g = lut_perm8(t.g_hi, t.g_lo, (dw >> t.sh2) & 0x07070707u);      // 0x00 or 0x08 per byte
+		const uint32_t m8 = (g >> 3) * 0xffu;
+		letter = (lut_perm8(t.tab2_hi, t.tab2_lo, sel) & m8) | (letter & ~m8);
+		cls = sel | g;
+	}
+	const uint32_t m = lut_ne_mask(dw ^ letter);                                       // 0xff in every byte that is not its candidate letter
+	return (m & t.other) | (~m & cls);
+}
 
 // Host side: what sk_set_barcodes' sheet becomes.  false = this sheet has no table (the matchers serve it).
 // A table of more than lds_budget bytes is served from L2; a sheet with a separator then gets the factored form instead when

@@ -15,17 +15,6 @@
 using sk::LutDev;
 using sk::LutHost;
 
-static uint32_t perm_lookup(uint32_t hi, uint32_t lo, uint32_t sel)       // v_perm_b32 with selectors 0..7
-{
-	uint32_t out = 0;
-	for (int j = 0; j < 4; j++) {
-		const uint32_t s = (sel >> (8 * j)) & 0xff;
-		const uint32_t byte = s < 4 ? (lo >> (8 * s)) & 0xff : (hi >> (8 * (s - 4))) & 0xff;
-		out |= byte << (8 * j);
-	}
-	return out;
-}
-
 struct Result { int assign, diff, first, last; };
 
 
@@ -42,8 +31,8 @@ static Result lookup_pair(const LutHost &h, const uint32_t (&c)[5], uint32_t sep
 		if (e2[0] == key) { val = e2[1]; return true; }
 		return false;
 	};
-	const uint32_t A1 = (t.W1 == 1 ? c[0] : sk::lut_pack_half(c[0], c[1])) & pr.keep1;
-	const uint32_t A2 = (t.W1 == 1 ? c[1] : sk::lut_pack_half(c[2], c[3])) & pr.keep2;
+	const uint32_t A1 = (t.W1 == 1 ? c[0] : sk::lut_pack_half(c[0], c[1], t.wide)) & pr.keep1;
+	const uint32_t A2 = (t.W1 == 1 ? c[1] : sk::lut_pack_half(c[2], c[3], t.wide)) & pr.keep2;
 	Result r = {-1, 255, -1, -1};
 	uint32_t v1 = 0, v2 = 0, pv = 0;
 	if (!probe(0u, pr.nb1, A1, pr.seed1, v1) || !probe(pr.off2, pr.nb2, A2, pr.seed2, v2)) return r;
@@ -65,17 +54,10 @@ static Result lookup(const LutHost &h, const uint8_t *obs, int L)
 	for (int w = 0; w < t.W1; w++) memcpy(&d[w], padded + 4 * w, 4);
 	for (int w = 0; w < t.W2; w++) memcpy(&d[t.W1 + w], padded + t.sep_off + 1 + 4 * w, 4);
 	const uint32_t sepbad = (t.sep_off >= 0 && padded[t.sep_off] != t.sep_val) ? 1u : 0u;
-	for (int w = 0; w < t.W1 + t.W2; w++) {
-		const uint32_t sel = (d[w] >> t.sh) & 0x07070707u;
-		const uint32_t letter = perm_lookup(t.tab_hi, t.tab_lo, sel);
-		const uint32_t df = d[w] ^ letter;
-		const uint32_t nz = (((df & 0x7f7f7f7fu) + 0x7f7f7f7fu) | df) & 0x80808080u;
-		const uint32_t m = nz - (nz >> 7);
-		c[w] = (m & t.other) | (~m & sel);
-	}
+	for (int w = 0; w < t.W1 + t.W2; w++) c[w] = sk::lut_classes(d[w], t);      // (the function the kernels call; its byte permutes are loops here)
 	if (t.pair.bytes != 0) return lookup_pair(h, c, sepbad);
 	uint32_t A, B;
-	sk::lut_pack(c, A, B);
+	sk::lut_pack(c, A, B, t.wide);
 	A &= t.keepA; B &= t.keepB;
 	const uint32_t x = sk::lut_mix(A, B, t.seed);
 	const uint32_t y = (x << t.nb) | (x >> (32 - t.nb));          // table 2: the nb bits below table 1's
@@ -119,8 +101,9 @@ int main(int argc, char **argv)
 	const int rounds = argc > 1 ? atoi(argv[1]) : 300;
 	std::mt19937_64 rng(12345);
 	auto pick = [&](int n) { return (int)(rng() % (uint64_t)n); };
-	const char *alphabets[] = {"ACGT", "ACGTN", "ACGT+", "ACGTacg", "AC", "ACGTN+U", "ACGT-_", "ACGTRYK"};
-	int built = 0, refused = 0, factored = 0, wide = 0;
+	const char *alphabets[] = {"ACGT", "ACGTN", "ACGT+", "ACGTacg", "AC", "ACGTN+U", "ACGT-_", "ACGTRYK", "ACGTacgt", "ACGTNacgtn", "ACGTacgtRY", "ACGTRYKMSWBDHV"};
+	const int n_alpha = 12;
+	int built = 0, refused = 0, factored = 0, wide = 0, wide_classes = 0;
 	size_t checked = 0;
 	// half-barcodes of `hl` letters, pairwise at least `dist` apart (greedy)
 	auto distant = [&](int count, int hl, int dist) {
@@ -138,7 +121,9 @@ int main(int argc, char **argv)
 		const int Ss[] = {1, 2, 3, 16, 40, 96, 128, 129, 384, 1000};
 		const int Ls[] = {1, 3, 4, 8, 9, 12, 17, 20};
 		int S = Ss[pick(it % 8 == 0 ? 10 : 7)], L = Ls[pick(8)];
-		const std::string al = alphabets[pick(8)];
+		const int ai = it % 5 == 2 ? 8 + pick(n_alpha - 8) : pick(8);          // every fifth sheet from an alphabet of more than seven letters
+		const std::string al = alphabets[ai];
+		if (ai >= 8) L = Ls[pick(4)];                                          // (wide classes serve at most 8 columns per word: short rows, or the dual sheets below)
 		std::vector<uint8_t> sheet((size_t)S * L);
 		for (auto &b : sheet) b = (uint8_t)al[(size_t)pick((int)al.size())];
 		int kind = pick(5);
@@ -160,6 +145,8 @@ int main(int argc, char **argv)
 			}
 			kind = 0;
 			if (pick(4) == 0) for (int s2 = 0; s2 < S; s2++) sheet[(size_t)s2 * L + L - 1] = 'U';      // a UMI column at the end
+			// every other row typed in lower case: eight letters — wide classes, served by the factored form or not at all
+			if (it % 8 == 5) for (int s2 = 1; s2 < S; s2 += 2) for (int k = 0; k < L; k++) { uint8_t &b = sheet[(size_t)s2 * L + k]; if (b >= 'A' && b <= 'T' && b != 'U') b = (uint8_t)(b + 32); }
 		}
 		if (kind == 1 && L >= 4) for (int s = 0; s < S; s++) for (int k = L - 3; k < L; k++) sheet[(size_t)s * L + k] = 'U';
 		if (kind == 2) for (auto &b : sheet) if (pick(10) == 0) b = 'N';
@@ -175,6 +162,7 @@ int main(int argc, char **argv)
 		if (!sk::lut_build(sheet.data(), S, L, max_diff, h)) { refused++; continue; }
 		built++;
 		factored += h.dev.pair.bytes != 0;
+		wide_classes += h.dev.wide != 0;
 		wide += h.dev.pair.bytes == 0 && h.dev.idx_shift != 24;
 		const char noise[] = "ACGTNacgtn+U\x00\xff#-_";
 		for (int r = 0; r < 3000; r++) {
@@ -211,6 +199,6 @@ int main(int argc, char **argv)
 		}
 	}
 	// the two sheets of the benchmark: sizes (informative)
-	printf("ok: %d tables built (%d factored, %d with 10-bit sample indices), %d sheets refused, %zu lookups\n", built, factored, wide, refused, checked);
+	printf("ok: %d tables built (%d factored, %d with 10-bit sample indices, %d with wide classes), %d sheets refused, %zu lookups\n", built, factored, wide, wide_classes, refused, checked);
 	return 0;
 }

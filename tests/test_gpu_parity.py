@@ -438,6 +438,65 @@ def test_demux_by_table_many_samples(ctx, oracle, lut_form, S, dual):
         check_demux_matched(ctx, oracle, np.ascontiguousarray(t2), np.ascontiguousarray(b2))
 
 
+@pytest.mark.parametrize("shape", ["16 x 8", "96 x 8+8", "384 x 8+8", "40 x 4+4", "24 x 6"])
+def test_demux_by_table_mixed_case_sheets(ctx, oracle, lut_form, shape):
+    """The reference compares raw bytes (src/fasta_demultiplex.rs:273-274), so a sheet may be typed partly in lower case: eight
+    letters and more, where the table's 3-bit classes hold seven.  Such sheets get 4-bit classes (sk_lut.h, "Wide classes") when
+    a row — or each half beside the separator — is at most 8 columns: the full-key table for the single-index shapes, the
+    factored form for the dual-index ones.  Reads in both cases, `N`s, a broken separator, foreign bytes; every form of the
+    lookup kernels; the table really is what runs (sk_barcode_table_info)."""
+    from seqkit_amd import capi
+    S = int(shape.split(" x ")[0])
+    cols = shape.split(" x ")[1]
+    dual = "+" in cols
+    hl = int(cols.split("+")[0])
+    rng = np.random.default_rng(S + hl)
+    if hl == 8:
+        table = synth.make_sheet(S, 8, dual=dual, seed=S + 5)
+    else:                                                          # short barcodes: distinct random rows
+        half = lambda k: np.unique(synth.BASES[rng.integers(0, 4, size=(4 * k, hl))], axis=0)[:k]
+
+        def apart(k):                                              # k rows pairwise at least 3 apart (what the factored form needs of its halves)
+            out = []
+            while len(out) < k:
+                c = synth.BASES[rng.integers(0, 4, size=hl)]
+                if all((c != o).sum() >= 3 for o in out):
+                    out.append(c)
+            return np.array(out, dtype=np.uint8)
+        if dual:
+            a, b = apart(7), apart(7)
+            combos = rng.permutation(len(a) * len(b))[:S]
+            table = np.concatenate([a[combos % len(a)], np.full((S, 1), ord("+"), dtype=np.uint8), b[combos // len(a)]], axis=1)
+        else:
+            table = half(S)
+        table = np.ascontiguousarray(table.astype(np.uint8))
+    lower = lambda x: np.where((x >= 65) & (x <= 90), x + 32, x).astype(np.uint8)
+    table[1::2] = lower(table[1::2])                               # every other sample in lower case
+    if not dual:
+        table[0, 0] = ord("N")                                     # a wildcard of ONE row (entered once per class of that column): only without a separator
+    n = 60_001
+    src = table.copy()
+    src[src == ord("N")] = ord("A")
+    bc, _ = synth.observe_barcodes(src, n, seed=S + 9, halves=2 if dual else 1)
+    flip = rng.random(n) < 0.3                                     # a third of the reads in the other case
+    bc[flip] = np.where((bc[flip] >= 97) & (bc[flip] <= 122), bc[flip] - 32, lower(bc[flip])).astype(np.uint8)
+    bc[::13, 1] = ord("N")
+    bc[::31, 2] = ord("#")
+    if dual:
+        bc[::19, hl] = ord("a")                                    # a broken separator costs one mismatch for every sample
+    ctx.set_barcodes(table, 1)
+    kind = ctx.barcode_table_info()["kind"]
+    if lut_form == "no table" or (dual and lut_form == "never half by half"):      # (wide classes beside a separator: the factored form or the matchers)
+        assert kind == capi.SK_TABLE_NONE, kind
+    else:
+        assert kind & capi.SK_TABLE_WIDE_CLASSES, kind
+        assert (kind & 3) == (capi.SK_TABLE_FACTORED if dual else capi.SK_TABLE_FULL_KEY), kind
+    check_demux_decision_only(ctx, oracle, table, bc)
+    check_demux_decision_only(ctx, oracle, table, bc, max_diff=0)
+    assert check_demux_matched(ctx, oracle, table, bc) > n // 4
+    check_demux_matched(ctx, oracle, table, bc, max_diff=0)
+
+
 def test_demux_by_table_rows_with_wildcards(ctx, oracle, lut_form):
     """A sheet row may hold `N` / `U` where other rows hold a letter (src/fasta_demultiplex.rs:272: such a column does not count
     for THAT row).  The table's builder enumerates the row once per class of the column (sk_lut.cpp), so these sheets take the
