@@ -2691,6 +2691,118 @@ __global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__res
 	}
 }
 
+// The same decoding for rows of a pitch that is a multiple of 8 and at most NQ KiB / 64 (NQ = 10: 150-base reads at pitch 152
+// or 160) — through an LDS image of the tile.  A WAVE owns a tile of 64 rows: its qualities and packed bases arrive as NQ + NS
+// fully coalesced 16-byte loads per lane (1 KiB per wave instruction, nt: read once) and are written to the wave's LDS slot;
+// the NEXT tile's loads are issued right behind (the whole next tile is in flight while this one is worked on: 15 KiB per
+// wave, 120 KiB per CU); lane l then computes units l, l + 64, ... of the tile (a unit = 8 output bytes, exactly
+// bam_sequence8_kernel's arithmetic with its dwords read from LDS — two lanes per bank), keeps them in registers until every
+// lane has read what it needs, writes them over the quality image, and the tile leaves as NQ coalesced 16-byte stores per
+// lane.  No workgroup barrier: a wave's LDS operations execute in order.  (bam_sequence8_kernel asks memory for 4-, 8- and
+// 8-byte pieces per lane and stores 8: 60-65 % of the HBM peak whatever was tried on it — EXPERIMENTS.md A.7; it stays for
+// every other pitch.)
+template <bool SMALL_M, int NQ, int ROWS>
+__global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
+                                                                   int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
+                                                                   int64_t n, u32 m4, u32 inv_upr, uint8_t *__restrict__ out)
+{
+	constexpr int NS = (NQ + 1) / 2;
+	constexpr int kSlot = (NQ + NS) * 1024 + 256;
+	constexpr int kMaxU = NQ * 2;                                  // units per lane at most: ROWS x (pitch / 8) units / 64 lanes
+	static_assert(ROWS == 64 || ROWS == 32, "a tile is one or half a row per lane");
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint8_t *img = sk_smem + wave * kSlot;                         // the qualities (then the output) ...
+	uint8_t *simg = img + NQ * 1024;                               // ... the packed bases ...
+	u32 *info = reinterpret_cast<u32 *>(img + (NQ + NS) * 1024);   // ... len | reverse << 16 per row
+	const int upr = stride >> 3;
+	const int64_t ntiles = (n + ROWS - 1) / ROWS;
+	const int64_t tstep = (int64_t)gridDim.x * 4;
+	u32x4 rq[NQ], rs[NS];
+	u32 rinfo = 0u;
+	auto fetch = [&](int64_t t) {
+		const int rows = t < ntiles ? (int)((n - t * ROWS) < ROWS ? (n - t * ROWS) : ROWS) : 0;
+		const int64_t row0 = rows ? t * ROWS : 0;
+		const rsrc_t dq = make_rsrc(qual, row0 * (int64_t)stride, rows * stride), ds = make_rsrc(seq4, row0 * (int64_t)seq4_stride, (rows * seq4_stride + 3) & ~3);
+#pragma unroll
+		for (int c = 0; c < NQ; c++) rq[c] = __builtin_amdgcn_raw_buffer_load_b128(dq, c * 1024 + lane * 16, 0, kAuxStream);
+#pragma unroll
+		for (int c = 0; c < NS; c++) rs[c] = __builtin_amdgcn_raw_buffer_load_b128(ds, c * 1024 + lane * 16, 0, kAuxStream);
+		const u32 lv = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(make_rsrc(len, row0 * 2, rows * 2), lane * 2, 0, 0);
+		const u32 fv = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(make_rsrc(flag, row0 * 2, rows * 2), lane * 2, 0, 0);
+		rinfo = (len ? lv : (u32)stride) | ((fv >> 4) & 1u) << 16;
+	};
+	int64_t t = (int64_t)blockIdx.x * 4 + wave;
+	fetch(t);
+	for (; t < ntiles; t += tstep) {
+		const int64_t row0 = t * ROWS;
+		const int rows = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
+		const u32 units = (u32)(ROWS * upr);
+#pragma unroll
+		for (int c = 0; c < NQ; c++) *reinterpret_cast<u32x4 *>(img + c * 1024 + lane * 16) = rq[c];
+#pragma unroll
+		for (int c = 0; c < NS; c++) *reinterpret_cast<u32x4 *>(simg + c * 1024 + lane * 16) = rs[c];
+		info[lane] = rinfo;
+		wave_lds_fence();
+		fetch(t + tstep);                                              // the next tile: on its way while this one is worked on
+		u32x2 ov[kMaxU];
+#pragma unroll
+		for (int i = 0; i < kMaxU; i++) {
+			ov[i][0] = ov[i][1] = 0u;
+			if (64u * (u32)i < units) {                                // (uniform)
+				const u32 ee = (u32)lane + 64u * (u32)i;
+				const u32 e = ee < units ? ee : units - 1u;               // (half a wave in the last turn of a 32-row tile: recompute the last unit)
+				const u32 rl = inv_upr ? __umulhi(e, inv_upr) : e / (u32)upr;
+				const int j = (int)(e - rl * (u32)upr);
+				const u32 inf = info[rl];
+				const int l = (int)(inf & 0xFFFFu);
+				const bool rev = (inf >> 16) != 0u;
+				int s0 = rev ? l - 8 - 8 * j : 8 * j;
+				if (s0 < -8) s0 = -8;                                  // every byte of this unit is past the read already
+				// qualities s0 .. s0 + 7 in source order: three dwords of the row's image, funnel-shifted (a dword that would start
+				// before the row is replaced by the row's first one: what it contributes lies before the read's first base)
+				const int qrow = (int)rl * stride, qd = s0 >> 2;
+				const u32 *qw = reinterpret_cast<const u32 *>(img + qrow);
+				const u32 w0 = qw[qd < 0 ? 0 : qd], w1 = qw[qd + 1 < 0 ? 0 : qd + 1], w2 = qw[qd + 2 < 0 ? 0 : qd + 2];
+				const u32 sh = (u32)s0 & 3u;
+				const u32 qa = __builtin_amdgcn_alignbyte(w1, w0, sh), qb = __builtin_amdgcn_alignbyte(w2, w1, sh);
+				// base codes s0 .. s0 + 7: the 8 bytes from the dword that holds byte a = s0 >> 1 cover bytes a .. a + 4
+				const int a = s0 >> 1, sd = a >> 2;
+				const u32 *sw = reinterpret_cast<const u32 *>(simg + (int)rl * seq4_stride);
+				const u32 d0 = sw[sd < 0 ? 0 : sd], d1 = sw[sd + 1 < 0 ? 0 : sd + 1];
+				const u32 b03 = __builtin_amdgcn_alignbyte(d1, d0, (u32)a & 3u);          // bytes a .. a + 3
+				const u32 b4 = __builtin_amdgcn_alignbyte(0u, d1, (u32)a & 3u) & 0xFFu;   // byte a + 4
+				const u32 be = __builtin_bswap32(b03);                                    // codes 2a .. 2a + 7, the first in the top nibble
+				const u32 n8 = (s0 & 1) ? ((be << 4) | (b4 >> 4)) : be;                   // codes s0 .. s0 + 7, likewise
+				const u32 c_first = spread_nibbles(n8 >> 16), c_last = spread_nibbles(n8 & 0xFFFFu);
+				u32 q_lo, q_hi, n_lo, n_hi;
+				if (rev) {          // output byte k = source position s0 + 7 - k
+					q_lo = __builtin_amdgcn_perm(0u, qb, 0x00010203u); q_hi = __builtin_amdgcn_perm(0u, qa, 0x00010203u);
+					n_lo = c_last; n_hi = c_first;
+				} else {
+					q_lo = qa; q_hi = qb;
+					n_lo = __builtin_amdgcn_perm(0u, c_first, 0x00010203u); n_hi = __builtin_amdgcn_perm(0u, c_last, 0x00010203u);
+				}
+				const u32 lo_low = bytes_below<SMALL_M>(q_lo, m4), hi_low = bytes_below<SMALL_M>(q_hi, m4);
+				ov[i][0] = (kN4 & lo_low) | (bases_from_codes(n_lo, rev) & ~lo_low);
+				ov[i][1] = (kN4 & hi_low) | (bases_from_codes(n_hi, rev) & ~hi_low);
+			}
+		}
+		wave_lds_fence();                                              // every lane has read what it needs: the units go over the quality image
+#pragma unroll
+		for (int i = 0; i < kMaxU; i++)
+			if ((u32)lane + 64u * (u32)i < units) *reinterpret_cast<u32x2 *>(img + 8 * (lane + 64 * i)) = ov[i];
+		wave_lds_fence();
+		const rsrc_t dout = make_rsrc(out, row0 * (int64_t)stride, rows * stride);
+#pragma unroll
+		for (int c = 0; c < NQ; c++) {
+			const u32x4 v = *reinterpret_cast<const u32x4 *>(img + c * 1024 + lane * 16);
+			__builtin_amdgcn_raw_buffer_store_b128(v, dout, c * 1024 + lane * 16, 0, kAuxStreamSt);
+		}
+		wave_lds_fence();
+	}
+}
+
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st)
 {
@@ -2702,6 +2814,25 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 	// rl = e / upr as a multiply-high: exact while e * upr < 2^32, and e < 64 * upr
 	const u32 upr = ((u32)stride + 7u) >> 3;
 	const u32 inv8 = (upr > 1 && upr < 8192u) ? (u32)(((1ull << 32) + upr - 1) / upr) : 0u;
+	// pitches the LDS-tile kernel serves: a multiple of 8, a tile's qualities in ten 1 KiB chunks and its packed bases in five
+	// (150-base reads at pitch 152 / 160); matrices 16-byte aligned (SK_SEQ_TILE=0: the other kernel, for A/B and the tests)
+	const char *env_tile = getenv("SK_SEQ_TILE");                      // (read per launch: the tests run both kernels in one process)
+	const bool env_no_tile = env_tile && atoi(env_tile) == 0;
+	if (!env_no_tile && (stride & 7) == 0 && 64 * stride <= 10 * 1024 && (seq4_stride & 3) == 0 && 64 * seq4_stride <= 5 * 1024 &&
+	    ((uintptr_t)seq4 & 15) == 0 && ((uintptr_t)qual & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+		// (tiles of 32 rows with twice the waves were measured too: 62.1 % of the HBM peak against 63.2 % on the box where the
+		// 8-byte kernel did 60.0 %; one workgroup per CU 53.8 %)
+		const bool small = (min_baseq & 0xFF) < 128;
+		constexpr int kNQ = 10;
+		const int lds = 4 * ((kNQ + (kNQ + 1) / 2) * 1024 + 256);
+		const void *fn = small ? reinterpret_cast<const void *>(bam_sequence_tile_kernel<true, kNQ, 64>) : reinterpret_cast<const void *>(bam_sequence_tile_kernel<false, kNQ, 64>);
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		if (e != hipSuccess) return e;
+		const int64_t want = (ntiles + 3) / 4;
+		const int g2 = (int)(want < (int64_t)n_cu * 2 ? want : (int64_t)n_cu * 2);
+		void *kargs[] = {(void *)&seq4, (void *)&seq4_stride, (void *)&qual, (void *)&stride, (void *)&len, (void *)&flag, (void *)&n, (void *)&m4, (void *)&inv8, (void *)&out};
+		return hipLaunchKernel(fn, dim3((unsigned)g2), dim3(256), kargs, (size_t)lds, st);
+	}
 	if ((min_baseq & 0xFF) < 128)
 		bam_sequence8_kernel<true><<<grid, 256, 0, st>>>(seq4, seq4_stride, qual, stride, len, flag, n, m4, inv8, out);
 	else

@@ -1090,9 +1090,18 @@ def test_bam_sequence_kat_gpu(ctx, golden):
         assert out[0, :ln[0]].tobytes() == c["out"].encode(), c
 
 
-@pytest.mark.parametrize("n,stride,seq4_stride", [(1, 4, 4), (63, 8, 4), (65, 12, 8), (1000, 152, 76), (3000, 152, 80), (257, 100, 52),
+@pytest.fixture(params=["LDS tile where the pitch allows", "8-byte units everywhere"])
+def seq_kernel(request, monkeypatch):
+    """sequence() has two kernels (sk_kernels.hip): bam_sequence_tile_kernel for pitches that are a multiple of 8 up to 160,
+    bam_sequence8_kernel for the rest — and for every pitch with SK_SEQ_TILE=0."""
+    if request.param.startswith("8-byte"):
+        monkeypatch.setenv("SK_SEQ_TILE", "0")
+    return request.param
+
+
+@pytest.mark.parametrize("n,stride,seq4_stride", [(1, 4, 4), (63, 8, 4), (65, 12, 8), (1000, 152, 76), (3000, 152, 80), (257, 100, 52), (130, 160, 80), (5000, 104, 52),
                                                   (70, 252, 128), (40, 40000, 20000)])
-def test_bam_sequence_matches_oracle(ctx, oracle, n, stride, seq4_stride):
+def test_bam_sequence_matches_oracle(ctx, oracle, seq_kernel, n, stride, seq4_stride):
     seq4, qual, ln, flag = bam_rows(n, stride, seed=n + stride, seq4_stride=seq4_stride)
     for m in (10, 0, 31, 200, 255):
         got = ctx.bam_sequence(seq4, qual, ln, flag, m)
@@ -1102,7 +1111,7 @@ def test_bam_sequence_matches_oracle(ctx, oracle, n, stride, seq4_stride):
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_fuzz_bam_sequence(ctx, oracle, seed):
+def test_fuzz_bam_sequence(ctx, oracle, seq_kernel, seed):
     """Random row pitches (multiples of 8, and odd multiples of 4 whose last unit is clipped to its first dword), packed-row
     pitches with and without slack, row counts around the 64-row tile, any threshold, ragged lengths on both strands."""
     rng = np.random.default_rng(7000 + seed)
@@ -1118,7 +1127,7 @@ def test_fuzz_bam_sequence(ctx, oracle, seed):
         assert np.array_equal(got, oracle.bam_sequence_batch(seq4, qual, None, flag, m))
 
 
-def test_bam_sequence_every_length_and_strand(ctx, oracle):
+def test_bam_sequence_every_length_and_strand(ctx, oracle, seq_kernel):
     """Every length 0..40 on both strands: the reverse path's funnel shifts and its partial last dword."""
     stride = 40
     lens = np.repeat(np.arange(0, 41, dtype=np.uint16), 2)
