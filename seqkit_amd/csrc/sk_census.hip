@@ -472,6 +472,10 @@ struct CensusArgs {
 	u64 mask;
 	u64 *stats;
 	CensusSpill sp;
+	int long_way_only;        // SK_CENSUS_LONG_WAY_ONLY=1: no row is counted by the fast look at the front table (its ordered, compiler-
+	                          // invisible reads of an entry another wave may be publishing): every row queues up for the long way, whose
+	                          // reads are waited for one entry at a time.  A fallback should a compiler or a part ever break the
+	                          // protocol the fast look leans on (tests/test_census_isa.py guards the compiler side); ~3 x slower
 };
 
 constexpr int kCensusWaves = 16;          // waves per workgroup (one per CU): they share the front table
@@ -701,7 +705,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				for (int j = 0; j < R; j++) front_wait<NW>(fw[j]);
 #pragma unroll
 				for (int j = 0; j < R; j++) {
-					hit[j] = front_match<NW>(fw[j], xs[j]);
+					hit[j] = !a.long_way_only && front_match<NW>(fw[j], xs[j]);
 					first[j] = fw[j].first();
 				}
 			}
@@ -717,7 +721,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				for (int j = 0; j < R; j++) front_wait<NW>(f2[j]);
 #pragma unroll
 				for (int j = 0; j < R; j++)
-					if (!hit[j] && front_match<NW>(f2[j], xs[j])) { hit[j] = true; en[j] = e2[j]; first[j] = f2[j].first(); }
+					if (!hit[j] && !a.long_way_only && front_match<NW>(f2[j], xs[j])) { hit[j] = true; en[j] = e2[j]; first[j] = f2[j].first(); }
 			}
 #pragma unroll
 			for (int j = 0; j < R; j++) {
@@ -1485,6 +1489,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.tab = cs->tab;
 		a.mask = cs->slots - 1;
 		a.stats = cs->stats;
+		a.long_way_only = getenv("SK_CENSUS_LONG_WAY_ONLY") && atoi(getenv("SK_CENSUS_LONG_WAY_ONLY")) != 0;
 		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
 		const int Rk = R;
 		auto grid_of = [&](int r) {

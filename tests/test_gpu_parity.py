@@ -1168,7 +1168,8 @@ def random_barcodes(n, L, stride, n_hot, hot_frac, seed, alphabet=b"ACGTN"):
     return m
 
 
-@pytest.fixture(params=["direct", "partition", "spilled_direct", "direct_tiny_front", "partition_tiny_front", "partition_front_inserts"])
+@pytest.fixture(params=["direct", "partition", "spilled_direct", "direct_tiny_front", "partition_tiny_front", "partition_front_inserts", "partition_long_way_only",
+                        "direct_long_way_only"])
 def census_path(request, monkeypatch):
     """The three ways a launch can take (sk_census.hip, census_add): keys the front tables have no room for are inserted by
     the front kernel itself (small launches), or written out and then partitioned + combined per table region, or — when
@@ -1181,6 +1182,8 @@ def census_path(request, monkeypatch):
         monkeypatch.setenv("SK_CENSUS_FRONT_ENTRIES", "64")
     if request.param.endswith("_front_inserts"):
         monkeypatch.setenv("SK_CENSUS_MERGE_RECORDS", "0")
+    if request.param.endswith("_long_way_only"):                   # the fallback switch: no row takes the fast look at the front table
+        monkeypatch.setenv("SK_CENSUS_LONG_WAY_ONLY", "1")
     if request.param.startswith("direct"):
         monkeypatch.setenv("SK_CENSUS_SPILL", "0")
     else:
@@ -1367,6 +1370,8 @@ def test_fuzz_census(ctx, oracle, monkeypatch, seed):
         monkeypatch.setenv("SK_CENSUS_FRONT_ENTRIES", "64")  # a front table that is full at once: both places of most strings taken
     if seed % 5 == 4:
         monkeypatch.setenv("SK_CENSUS_MERGE_RECORDS", "0")   # the front kernel inserts its table itself
+    if seed % 7 == 6:
+        monkeypatch.setenv("SK_CENSUS_LONG_WAY_ONLY", "1")   # the fallback switch
     L = int(rng.integers(1, 32))
     stride = int(rng.integers(L, min(64, L + 9) + 1))
     n = int(rng.integers(1, 250_000))

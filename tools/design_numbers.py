@@ -6,25 +6,31 @@ import os
 import re
 import sys
 
-tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r04")
+tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r05")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench.json")).read().strip().splitlines()[-1])
-bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "4 tile-rounds of 7.3 µs + 5.5 µs launch", "cfg2 read": "HBM", "fused single-end:": "HBM",
-         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "stream, then issue (43 VALU per row, two rows per lane), + 4 µs launch", "cfg3 with": "stream",
-         "cfg3 sheet": "issue", "demultiplex only 10M x 17ch, 96": "stream, then issue (80 VALU + 54 SALU per 64-row tile)", "96 dual": "stream",
-         "demultiplex only 10M x 17ch, 384": "issue: three lookups per read", "cfg5": "HBM", "f2:": "HBM", "f4:": "latency / occupancy",
-         "f3: census 32M rows, clean": "front kernel: LDS pipe 79 %, VALU 62 % busy (§8)", "f3: census 32M rows, noisy": "front kernel 0.19–0.20 + partition passes 0.17–0.19 ms",
+bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "25 µs of streaming + 6 µs of launch and events per call", "cfg2 read": "HBM", "fused single-end:": "HBM",
+         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "memory side as placed; 20 µs of streaming + 6 µs of launch and events", "cfg3 with": "the same",
+         "cfg3 sheet": "memory side as placed (§3.2b)", "demultiplex only 10M x 17ch, 96 dual-index, a mixed": "as the 384-sample sheet: three lookups per read",
+         "demultiplex only 10M x 17ch, 96": "memory side as placed + the call's fixed part", "96 dual-index with": "the same", "96 dual-index, 100M": "memory side as placed (§3.2b)",
+         "demultiplex only 10M x 17ch, 384": "three lookups per read, then the memory side", "cfg5": "HBM", "f2:": "HBM", "f4:": "HBM as placed (LDS-tile kernel, §3.8)",
+         "f3: census 32M rows (1 M drawn rows x 32), clean": "front kernel (LDS pipe + issue) 0.18 ms + combine 0.05 ms",
+         "f3: census 32M rows (1 M drawn rows x 32), noisy": "front kernel 0.19–0.21 ms + combine 0.11 ms (§8)",
+         "f3: census 32M independently": "the distinct keys' inserts into the HBM table",
          "f3: census 32M rows, every": "memory side: one CAS + two stores per new key"}
 rows = []
 for x in d["extra"]["rates"]:
     b = next((v for k, v in bound.items() if x["config"].startswith(k)), "")
     placed = f" (as placed {x['frac_as_placed']:.3f})" if x.get("frac_as_placed") else ""
+    if "frac_warm" in x:                                       # rows timed from HBM: buffer sets in rotation, one event pair per call
+        placed += f" from HBM; pipelined {x['frac_pipelined']:.3f}, on-die replay {x['frac_warm']:.3f} ({x['ms_warm'] * 1000:.1f} µs)"
     rows.append(f"| {x['config']} | {x['ms'] * 1000:.1f} µs, {x['G_units_per_s']:.1f} G units/s | {x['frac']:.3f}{placed} | {b} |")
 table = "| config (device-resident; `bench.py` `extra.rates`) | rate | of 8 TB/s | bound |\n|---|---|---|---|\n" + "\n".join(rows)
 r = d["roofline"]
 print(f"headline: value {d['value']} M reads/s, ms_per_step {d['ms_per_step']}, kernel_ms {r['kernel_ms']}, achieved {r['achieved']} GB/s, frac {r['frac']}, "
       f"frac_as_placed {r['frac_as_placed']}, read_frac {r['read_frac']}, traffic {r['traffic']}")
 print("placement:", d["config"]["placement"].get("ms_before"), "->", d["config"]["placement"].get("ms_after"))
+print("cpu all cores:", d["cpu_baseline"].get("all_cores"))
 print("cpu:", d["cpu_baseline"]["value"], {k: v["M_reads_per_s"] for k, v in d["cpu_baseline"].get("faithful", {}).items() if isinstance(v, dict)})
 print(table)
 if "--write" in sys.argv:

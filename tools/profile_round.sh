@@ -3,7 +3,7 @@
 # the N = 2 same-device line, the CLI's kernel trace, PMC of the lookup kernel and of trim alone, the rates of every tool, the
 # census kernels' trace and PMC, the GPU test run.  usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -16,6 +16,10 @@ bash tools/profile_cmd.sh ${TAG}_lut_cfg3 "demux_lut" tools/demux_one.py cfg3 10
 bash tools/profile_cmd.sh ${TAG}_trim_uniform "tile_pass_kernel" tools/trim_one.py uniform 16000000 > $OUT/trim_uniform_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_fused_single "tile_pass_kernel" tools/fused_one.py single 16000000 > $OUT/fused_single_pmc.log 2>&1
 bash tools/profile_cmd.sh ${TAG}_lut_384 "demux_lut" tools/demux_one.py dual384 10000000 > $OUT/lut_384_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_lut_dual_100m "demux_lut" tools/demux_one.py dual 100000000 > $OUT/lut_dual_100m_pmc.log 2>&1
+bash tools/profile_cmd.sh ${TAG}_lut_cfg3_100m "demux_lut" tools/demux_one.py cfg3 100000000 > $OUT/lut_cfg3_100m_pmc.log 2>&1
+python3 tools/lut_cold_ab.py --sheets 16,96,384,1000 cur 2>&1 | grep -v amdgpu.ids > $OUT/lut_cold.txt
+python3 tools/lut_cold_ab.py --detail --sheets 16,96 cur 2>&1 | grep -v amdgpu.ids >> $OUT/lut_cold.txt
 bash tools/profile_cmd.sh ${TAG}_census_noisy "census_" tools/census_one.py noisy 32000000 3 > $OUT/census_noisy_pmc.log 2>&1
 bash tools/census_trace.sh ${TAG}_census > $OUT/census_trace.log 2>&1
 ( cd seqkit_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSK_CENSUS_STAMPS -o ../../tools/ab/census_stamps.so sk_kernels.hip sk_census.hip sk_capi.hip sk_lut.cpp -ldl ) > $OUT/census_stamps_build.log 2>&1
