@@ -464,13 +464,18 @@ def secondary_rates(torch, ctx, dev):
     bc1 = torch.from_numpy(bc_np).to(dev).repeat(16, 1).contiguous()
     assign = torch.empty((n,), dtype=torch.int32, device=dev)
     cnt = torch.zeros((16 + 3,), dtype=torch.int64, device=dev)
-    mate = {"seq": s.data_ptr(), "qual": q.data_ptr(), "len": 0, "out_seq": o.data_ptr(), "lowest_k": lk.data_ptr()}
+    # (the fused rows choose the placement of their big matrices among three candidates each, like the headline and the other
+    # streaming rows: `frac` is the chosen placement, `frac_as_placed` the first candidates — one box's buffers as they come time
+    # this pass 12 % apart from another's)
+    fc = {"seq": [s, s.clone(), s.clone()], "qual": [q, q.clone(), q.clone()], "out": [o, torch.empty_like(o), torch.empty_like(o)]}
+
+    def mate_of(ch, ln_ptr=0):
+        return {"seq": fc["seq"][ch["seq"]].data_ptr(), "qual": fc["qual"][ch["qual"]].data_ptr(), "len": ln_ptr, "out_seq": fc["out"][ch["out"]].data_ptr(), "lowest_k": lk.data_ptr()}
     timeit("fused single-end: demultiplex + trim + mask, 16M x 150bp + 8bp, 16 barcodes",
-           lambda: ctx.fused_pass_dev(n, 150, 20, [mate], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 464)
+           lambda ch: ctx.fused_pass_dev(n, 150, 20, [mate_of(ch)], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 464, cands=fc)
     ln = torch.randint(100, 151, (n,), dtype=torch.int16, device=dev, generator=g)
-    mate_r = dict(mate, len=ln.data_ptr())
     timeit("fused single-end, ragged rows (u16 lengths 100-150): 16M x <=150bp + 8bp, 16 barcodes",
-           lambda: ctx.fused_pass_dev(n, 150, 20, [mate_r], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 466)
+           lambda ch: ctx.fused_pass_dev(n, 150, 20, [mate_of(ch, ln.data_ptr())], bc=bc1.data_ptr(), bc_stride=8, assign=assign.data_ptr(), counts=cnt.data_ptr()), n, 466, cands=fc)
     del bc1, ln
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
@@ -483,11 +488,16 @@ def secondary_rates(torch, ctx, dev):
     first = torch.empty((n,), dtype=torch.int16, device=dev)
     last = torch.empty((n,), dtype=torch.int16, device=dev)
     cnt2 = torch.zeros((96 + 3,), dtype=torch.int64, device=dev)
-    mates2 = [mate, {"seq": s2.data_ptr(), "qual": q2.data_ptr(), "len": 0, "out_seq": o2.data_ptr(), "lowest_k": lk2.data_ptr()}]
+    fc.update({"seq2": [s2, s2.clone(), s2.clone()], "qual2": [q2, q2.clone(), q2.clone()], "out2": [o2, torch.empty_like(o2), torch.empty_like(o2)]})
+
+    def mates_of(ch):
+        return [mate_of(ch), {"seq": fc["seq2"][ch["seq2"]].data_ptr(), "qual": fc["qual2"][ch["qual2"]].data_ptr(), "len": 0, "out_seq": fc["out2"][ch["out2"]].data_ptr(),
+                              "lowest_k": lk2.data_ptr()}]
     ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
     timeit("fused paired with the detail columns of matched clusters (SK_DETAIL_MATCHED): 16M x 2x150bp, 96 dual-index",
-           lambda: ctx.fused_pass_dev(n, 150, 20, mates2, bc=bc2.data_ptr(), bc_stride=17, assign=assign.data_ptr(), lowest_diff=low.data_ptr(),
-                                      first_idx=first.data_ptr(), last_idx=last.data_ptr(), counts=cnt2.data_ptr()), n, 930)
+           lambda ch: ctx.fused_pass_dev(n, 150, 20, mates_of(ch), bc=bc2.data_ptr(), bc_stride=17, assign=assign.data_ptr(), lowest_diff=low.data_ptr(),
+                                         first_idx=first.data_ptr(), last_idx=last.data_ptr(), counts=cnt2.data_ptr()), n, 930, cands=fc)
+    del fc
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     del q, s, o, lk, s2, q2, o2, lk2, bc2, low, first, last, assign, cnt, cnt2
     n = 10_000_000

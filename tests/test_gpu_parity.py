@@ -537,6 +537,35 @@ def test_fused_pass_of_a_large_sheet_takes_the_table(ctx, oracle):
     assert np.array_equal(r["out_seq"][0], oracle.mask_batch(seq, qual, None, 20))
 
 
+@pytest.mark.parametrize("S", [96, 384])
+def test_fused_pass_of_a_mixed_case_sheet(ctx, oracle, S):
+    """A sheet typed partly in lower case has more letters than the tile pass's own matcher knows (seven): the barcode phase of a
+    fused call is a launch of its own, served by the table with wide classes (sk_lut.h) — the oracle's three commands' answers,
+    with and without the detail columns of matched rows."""
+    from seqkit_amd import capi
+    n, L = 30_011, 150
+    table = synth.make_sheet(S, 8, dual=True, seed=S + 1)
+    table[1::2] = np.where((table[1::2] >= 65) & (table[1::2] <= 90), table[1::2] + 32, table[1::2]).astype(np.uint8)
+    bc, _ = synth.observe_barcodes(table, n, seed=6, halves=2)
+    bc[::17, 3] = ord("N")
+    seq, qual = synth.make_reads(n, L, seed=71)
+    qual = synth.add_forced_classes(qual, seed=81)
+    ctx.set_barcodes(table, 1)
+    assert ctx.barcode_table_info()["kind"] == capi.SK_TABLE_FACTORED | capi.SK_TABLE_WIDE_CLASSES
+    e = oracle.demux_batch(table, bc, 1)
+    for detail_mode, want_detail in ((capi.SK_DETAIL_FULL, False), (capi.SK_DETAIL_MATCHED, True), (capi.SK_DETAIL_FULL, True)):
+        ctx.set_detail_mode(detail_mode)
+        ctx.counts_reset()
+        r = ctx.fused_pass([(seq, qual, None)], 20, bc=bc, want_detail=want_detail)
+        assert np.array_equal(r["assign"], e[0]) and np.array_equal(ctx.counts(), e[4])
+        if want_detail:
+            m = e[0] != -1 if detail_mode == capi.SK_DETAIL_MATCHED else np.ones(n, dtype=bool)
+            assert np.array_equal(r["lowest_diff"][m], e[1][m]) and np.array_equal(r["first_idx"][m], e[2][m]) and np.array_equal(r["last_idx"][m], e[3][m])
+        assert np.array_equal(r["lowest_k"][0], oracle.trim_batch(qual, None, 20))
+        assert np.array_equal(r["out_seq"][0], oracle.mask_batch(seq, qual, None, 20))
+    ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+
+
 def test_demux_by_table_ambiguity_duplicates_umi(ctx, oracle, lut_form):
     """Ambiguous keys keep their (first, last) pair in the side list; duplicates are always ambiguous; UMI columns do not count."""
     table = np.array([list(b"ACGTACGTAAAA"), list(b"ACGTACGAAAAT"), list(b"TTCTTTTTUUUU"), list(b"GGGGGGGGUUUU"),

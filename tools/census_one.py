@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One shape of the census, a few launches (for rocprofv3 runs).  usage: census_one.py exact|clean|noisy|sub|distinct [rows] [reps]"""
+"""One shape of the census, a few launches (for rocprofv3 runs).  usage: census_one.py exact|clean|noisy|sub|distinct|noisy_indep|clean_indep [rows] [reps]
+(*_indep: every row drawn independently on the device — bench.observed_barcodes — instead of one million drawn rows repeated)"""
 import os
 import sys
 
@@ -17,7 +18,16 @@ ctx = seqkit_amd.Context(0)
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 kw = {"exact": dict(p_exact=1.0, p_sub=0.0), "clean": dict(p_exact=0.97, p_sub=0.025), "noisy": {}, "sub": dict(p_exact=0.85, p_sub=0.15)}
 reps = max(1, n // 1_000_000)
-if case == "distinct":
+if case.endswith("_indep"):
+    import bench
+    gi = torch.Generator(device=dev)
+    gi.manual_seed(11)
+    tt = torch.tensor(table, dtype=torch.uint8, device=dev)
+    bases_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    alpha_t = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+    bc = torch.cat([bench.observed_barcodes(torch, gi, dev, min(4_000_000, n), tt, bases_t, alpha_t, **kw[case[:-6]]) for _ in range(max(1, n // 4_000_000))]).contiguous()
+    L = 17
+elif case == "distinct":
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     bc = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n, 16), device=dev, generator=g)].contiguous()

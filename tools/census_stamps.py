@@ -23,11 +23,19 @@ PHASES = ["tables cleared", "step's loads waited for, rows aligned", "fence + ne
           "loop exit", "end barrier", "front table leaves the workgroup", "statistics"]
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 CASES = os.environ.get("SK_STAMPS_CASES", "exact,clean,noisy").split(",")
-for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact=0.97, p_sub=0.025)), ("noisy", {})):
+for case, kw in (("exact", dict(p_exact=1.0, p_sub=0.0)), ("clean", dict(p_exact=0.97, p_sub=0.025)), ("noisy", {}), ("noisy_indep", {})):
     if case not in CASES:
         continue
-    b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
-    bc = torch.from_numpy(b_np).to(dev).repeat(max(1, n // 1_000_000), 1).contiguous()
+    if case.endswith("_indep"):                                # every row drawn independently (bench.observed_barcodes), not one million rows repeated
+        import bench
+        gi = torch.Generator(device=dev)
+        gi.manual_seed(11)
+        tt = torch.tensor(table, dtype=torch.uint8, device=dev)
+        bases_t, alpha_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev), torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+        bc = torch.cat([bench.observed_barcodes(torch, gi, dev, 4_000_000, tt, bases_t, alpha_t, **kw) for _ in range(max(1, n // 4_000_000))]).contiguous()
+    else:
+        b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
+        bc = torch.from_numpy(b_np).to(dev).repeat(max(1, n // 1_000_000), 1).contiguous()
     for alias in ("-",):
         for _ in range(2):
             ctx.census_reset(); ctx.sync(); ctx.timer_start()
