@@ -52,7 +52,7 @@ constexpr int kSpillMaxGrid = 1024;      // workgroups of the front kernel the c
 struct CensusSpill {
 	uint4 *key = nullptr;        // [grid][kSpillBuckets][cap]: a record is the key's first three dwords (barcodes of at most
 	                             // kSpillMaxLen characters) and the row index within the launch | the weight
-	u32 *hist = nullptr;         // [grid][kSpillBuckets]: records per workgroup and bucket (what lies in the region)
+	u32 *hist = nullptr;         // [kSpillBuckets][grid]: records per bucket and workgroup (what lies in the region)
 	u32 *btot = nullptr;         // [kSpillBuckets]: records per bucket (added to by the front kernel's workgroups; census_direct_kernel,
 	                             // the launch's last kernel, leaves it zero for the next launch)
 	u32 *wg_count = nullptr;     // [grid]: records per workgroup
@@ -926,7 +926,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			u32 sum = 0u;
 			for (int b = tid; b < kSpillBuckets; b += 64) {
 				const u32 v = lh[b] < a.sp.cap ? lh[b] : a.sp.cap;
-				a.sp.hist[(size_t)blockIdx.x * kSpillBuckets + b] = v;
+				a.sp.hist[(size_t)b * a.sp.grid + blockIdx.x] = v;
 				if (v != 0u) atomicAdd(&a.sp.btot[b], v);
 				sum += v;
 			}
@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 	int b_have = -1;                                                   // the bucket gpre was made for
 	for (;;) {
 		__syncthreads();
+		// (items dealt round-robin instead — no returning atomic, two round trips less per workgroup — were measured: the clean
+		// launch 0.24 -> 0.23 ms, the noisy one 0.31 -> 0.34)
 		if (tid == 0) item_s = atomicAdd(a.sp.work, 1u);
 		for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
 		__syncthreads();
@@ -1090,7 +1092,7 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 			u32 carry = 0u;
 			for (u32 g0 = 0; g0 < grid; g0 += blockDim.x) {
 				const u32 g = g0 + tid;
-				const u32 v = g < grid ? a.sp.hist[(size_t)g * kSpillBuckets + b] : 0u;
+				const u32 v = g < grid ? a.sp.hist[(size_t)b * grid + g] : 0u;          // (bucket-major: a bucket's region sizes are one contiguous piece)
 				u32 total;
 				const u32 before = census_block_exclusive(v, ws, &total);
 				if (g < grid) gpre[g] = carry + before;
@@ -1210,7 +1212,7 @@ __global__ __launch_bounds__(kDirectThreads) void census_direct_kernel(const Cen
 	__shared__ u32 ws[17];
 	{
 		static_assert(kSpillBuckets <= kDirectThreads, "one bucket per thread");
-		const u32 v = threadIdx.x < (u32)kSpillBuckets ? a.sp.hist[(size_t)g * kSpillBuckets + threadIdx.x] : 0u;
+		const u32 v = threadIdx.x < (u32)kSpillBuckets ? a.sp.hist[(size_t)threadIdx.x * a.sp.grid + g] : 0u;
 		u32 total;
 		const u32 before = census_block_exclusive(v, ws, &total);
 		if (threadIdx.x < (u32)kSpillBuckets) bpre[threadIdx.x] = before;
