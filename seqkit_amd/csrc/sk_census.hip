@@ -1493,7 +1493,10 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.stats = cs->stats;
 		a.long_way_only = getenv("SK_CENSUS_LONG_WAY_ONLY") && atoi(getenv("SK_CENSUS_LONG_WAY_ONLY")) != 0;
 		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
-		const int Rk = R;
+		// One tile per step for the launches that write records: the step's queue is a third smaller, and what it gives back goes
+		// to the front table (2 270 -> 2 950 entries for 17-byte rows) — the table's size is worth more than the second tile (32 M
+		// noisy rows 0.320 -> 0.312 ms, clean 0.245 -> 0.231; with 1 024 entries 0.34-0.41, with 512 0.53; tools/ab/census_env_ab.py)
+		const int Rk = (spill && nw_class >= 1 && !getenv("SK_CENSUS_TILES")) ? 1 : R;
 		auto grid_of = [&](int r) {
 			const int64_t groups = (nr + (int64_t)64 * r * kCensusWaves - 1) / ((int64_t)64 * r * kCensusWaves);
 			const int g = n_cu * wgs_per_cu;
