@@ -10,7 +10,7 @@ tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r05")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench.json")).read().strip().splitlines()[-1])
 bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "25 µs of streaming + 6 µs of launch and events per call", "cfg2 read": "HBM", "fused single-end:": "HBM",
-         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demux": "memory side as placed; 20 µs of streaming + 6 µs of launch and events", "cfg3 with": "the same",
+         "fused single-end, ragged": "HBM", "fused paired": "HBM", "cfg3: demul": "memory side as placed; 20 µs of streaming + 6 µs of launch and events", "cfg3 with": "the same",
          "cfg3 sheet": "memory side as placed (§3.2b)", "demultiplex only 10M x 17ch, 96 dual-index, a mixed": "as the 384-sample sheet: three lookups per read",
          "demultiplex only 10M x 17ch, 96": "memory side as placed + the call's fixed part", "96 dual-index with": "the same", "96 dual-index, 100M": "memory side as placed (§3.2b)",
          "demultiplex only 10M x 17ch, 384": "three lookups per read, then the memory side", "cfg5": "HBM", "f2:": "HBM", "f4:": "HBM as placed (LDS-tile kernel, §3.8)",
