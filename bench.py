@@ -534,8 +534,9 @@ def secondary_rates(torch, ctx, dev):
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()          # the same sheet on a call ten times as long: what the lookup does once the launch is out of the way
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
-    timeit("cfg3 sheet, 100M x 8bp in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 8, 10 * n, assign_l.data_ptr()), 10 * n, 12, iters=3)
-    del bc_l, assign_l
+    lc = {"bc": [bc_l, bc_l.clone(), bc_l.clone()], "assign": [assign_l, torch.empty_like(assign_l), torch.empty_like(assign_l)]}
+    timeit("cfg3 sheet, 100M x 8bp in one call", lambda ch: ctx.demux_assign_dev(lc["bc"][ch["bc"]].data_ptr(), 8, 10 * n, lc["assign"][ch["assign"]].data_ptr()), 10 * n, 12, iters=3, cands=lc)
+    del bc_l, assign_l, lc
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
@@ -548,8 +549,9 @@ def secondary_rates(torch, ctx, dev):
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
-    timeit("96 dual-index, 100M x 17ch in one call", lambda: ctx.demux_assign_dev(bc_l.data_ptr(), 17, 10 * n, assign_l.data_ptr()), 10 * n, 21, iters=3)
-    del bc_l, assign_l, calls, keep
+    lc = {"bc": [bc_l, bc_l.clone(), bc_l.clone()], "assign": [assign_l, torch.empty_like(assign_l), torch.empty_like(assign_l)]}
+    timeit("96 dual-index, 100M x 17ch in one call", lambda ch: ctx.demux_assign_dev(lc["bc"][ch["bc"]].data_ptr(), 17, 10 * n, lc["assign"][ch["assign"]].data_ptr()), 10 * n, 21, iters=3, cands=lc)
+    del bc_l, assign_l, calls, keep, lc
     # the 96 dual-index sheet with every other sample typed in lower case — nine letters and the separator, where the table's
     # 3-bit classes hold seven (the reference compares raw bytes, src/fasta_demultiplex.rs:273-274, so such a sheet is legal).
     # Through round 4 it ran the S x L matchers (demux_tile_kernel: VALU-bound, ~350 instructions per read, 0.15-0.19); since round 5
