@@ -497,6 +497,48 @@ def test_demux_by_table_mixed_case_sheets(ctx, oracle, lut_form, shape):
     check_demux_matched(ctx, oracle, table, bc, max_diff=0)
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 512, 513, 1023, 1025])
+def test_demux_by_table_around_the_quad(ctx, oracle, lut_form, n):
+    """The lookup kernels' unit is 256 rows whose codes (and detail columns) change lanes through LDS and leave as wide stores; a
+    call's last, partial unit writes its narrow columns row by row (sk_kernels.hip): row counts around every boundary of the
+    64-row tile, the 128-row tile of the two-rows-per-lane kernel and the 256-row unit, on both benchmark sheets, decision alone
+    and with the detail columns of matched rows; nothing is written behind row n."""
+    for S, dual in ((16, False), (96, True)):
+        table = synth.make_sheet(S, 8, dual=dual, seed=S)
+        bc, _ = synth.observe_barcodes(table, n, seed=n, halves=2 if dual else 1)
+        check_demux_decision_only(ctx, oracle, table, bc)
+        check_demux_matched(ctx, oracle, table, bc)
+        # device entry point with guard rows behind the outputs
+        ctx.set_barcodes(table, 1)
+        from seqkit_amd import capi
+        ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
+        pad = 300
+        d_bc = ctx.malloc_device(bc.nbytes + 64)
+        outs = [(np.int32, 4), (np.uint8, 1), (np.int16, 2), (np.int16, 2)]
+        d_out = [ctx.malloc_device((n + pad) * w) for _, w in outs]
+        try:
+            ctx.copy_h2d(d_bc, bc)
+            guards = [np.full(n + pad, 0x5A5A5A5A if w == 4 else (0x5A if w == 1 else 0x5A5A), dtype=t) for t, w in outs]
+            for p, g in zip(d_out, guards):
+                ctx.copy_h2d(p, g)
+            ctx.demux_assign_dev(d_bc, bc.shape[1], n, *d_out)
+            ctx.sync()
+            got = [np.empty(n + pad, dtype=t) for t, _ in outs]
+            for p, g in zip(d_out, got):
+                ctx.copy_d2h(g, p)
+        finally:
+            ctx.free_device(d_bc)
+            for p in d_out:
+                ctx.free_device(p)
+            ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+        e = oracle.demux_batch(table, bc, 1)
+        assert np.array_equal(got[0][:n], e[0])
+        m = e[0] != -1
+        assert np.array_equal(got[1][:n][m], e[1][m]) and np.array_equal(got[2][:n][m], e[2][m]) and np.array_equal(got[3][:n][m], e[3][m])
+        for g, gd in zip(got, guards):
+            assert np.array_equal(g[n:], gd[n:]), "a store behind the last row"
+
+
 def test_demux_by_table_rows_with_wildcards(ctx, oracle, lut_form):
     """A sheet row may hold `N` / `U` where other rows hold a letter (src/fasta_demultiplex.rs:272: such a column does not count
     for THAT row).  The table's builder enumerates the row once per class of the column (sk_lut.cpp), so these sheets take the
