@@ -19,7 +19,9 @@
  *    and return immediately; sk_sync() waits.  Device byte matrices must be 16-byte aligned, and readable up
  *    to the next 4-byte boundary behind their last row (the kernels read whole dwords: when n * stride is not a
  *    multiple of 4, up to 3 bytes past the matrix are fetched and ignored — any allocation of a whole number of
- *    dwords, every hipMalloc, provides them).
+ *    dwords, every hipMalloc, provides them).  Device OUTPUT columns of a demultiplex call are written with wide
+ *    stores: assign must be 16-byte aligned, lowest_diff 4-byte, first_idx / last_idx 8-byte (any hipMalloc'ed base
+ *    is; a column sliced at an odd row is refused with SK_ERR_INVALID).
  *  - there is no CPU fallback: without a usable GPU sk_create() fails and nothing else can be called.
  */
 #ifndef SEQKIT_HIP_H

@@ -742,6 +742,10 @@ static int check_fused(sk_ctx *c, const sk_fused_args *a, bool dev)
 		if (a->bc_stride > sk::kMaxTileStride) return fail(c, SK_ERR_INVALID, "bc_stride = %d above %d", a->bc_stride, sk::kMaxTileStride);
 		if (!a->assign) return fail(c, SK_ERR_INVALID, "assign is NULL");
 		if (dev && !aligned16(a->bc)) return fail(c, SK_ERR_INVALID, "bc must be 16-byte aligned");
+		// the lookup kernels write a wave's 256 rows of every output column with ONE wide store per lane (16 bytes of assign, 4 of
+		// lowest_diff, 8 of first_idx / last_idx): the columns' natural alignment is not enough for a device pointer
+		if (dev && (!aligned16(a->assign) || ((uintptr_t)a->lowest_diff & 3u) || ((uintptr_t)a->first_idx & 7u) || ((uintptr_t)a->last_idx & 7u)))
+			return fail(c, SK_ERR_INVALID, "device output columns: assign must be 16-byte, lowest_diff 4-byte, first_idx / last_idx 8-byte aligned");
 	} else if (!any) {
 		return fail(c, SK_ERR_INVALID, "nothing to do: no bc, no out_seq, no lowest_k");
 	}

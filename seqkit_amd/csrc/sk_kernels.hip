@@ -2103,10 +2103,14 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			// sixteen waves share a table copy; eight once the call is long and the table leaves room for one workgroup per CU only
 			// (rows from HBM, 100 M pairs of the 96 dual-index sheet: 381 us against 398; shorter calls want the waves)
 			int nw = ldstab ? ((lp.table_bytes > (64 << 10) && b.n >= 4000000) ? 8 : 16) : 4;
-			if (const char *env_nw = getenv("SK_LUT_NW")) { const int v = atoi(env_nw); if (v >= 1 && v <= 16) nw = v; }      // tuning (tools/lut_cold_ab.py)
+			// tuning knobs (tools/lut_cold_ab.py), read once per process; the kernels that keep their table in the vector cache are
+			// compiled for 256 threads, so they take 4 waves at most
+			static const int env_nw = [] { const char *v = getenv("SK_LUT_NW"); return v ? atoi(v) : 0; }();
+			static const int env_wg = [] { const char *v = getenv("SK_LUT_WG"); return v ? atoi(v) : 0; }();
+			if (env_nw >= 1 && env_nw <= (ldstab ? 16 : 4)) nw = env_nw;
 			while (nw > 4 && lp.tiles_off + nw * lp.tile_slot > 160 * 1024) nw >>= 1;
 			const int lds = lp.tiles_off + nw * lp.tile_slot;
-			struct Occ { int dev; const void *fn; int lds, wg; };
+			struct Occ { int dev; const void *fn; int lds, nw, wg; };
 			static std::mutex occ_m;
 			static std::vector<Occ> occ;
 			int dev = 0, wg = 0;
@@ -2114,7 +2118,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			if (e != hipSuccess) return e;
 			{
 				std::lock_guard<std::mutex> lk(occ_m);
-				for (const Occ &o : occ) if (o.dev == dev && o.fn == fn && o.lds == lds) wg = o.wg;
+				for (const Occ &o : occ) if (o.dev == dev && o.fn == fn && o.lds == lds && o.nw == nw) wg = o.wg;
 			}
 			if (wg == 0) {
 				e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2122,13 +2126,13 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 				if (e != hipSuccess) return e;
 				if (wg < 1) return hipErrorInvalidValue;
 				std::lock_guard<std::mutex> lk(occ_m);
-				occ.push_back({dev, fn, lds, wg});
+				occ.push_back({dev, fn, lds, nw, wg});
 			}
 			// sixteen waves per CU whatever the table leaves room for: with its rows coming from HBM a 10 M-row call of the cfg 3 sheet
 			// took 25.3 us on sixteen and 26.7 on thirty-two (each wave's first load is a full HBM round trip before anything
 			// moves, and twice the waves end in twice the stragglers); 100 M rows the same (tools/lut_cold_ab.py)
 			if (ldstab && wg > 1) wg = 1;
-			if (const char *env_wg = getenv("SK_LUT_WG")) { const int v = atoi(env_wg); if (v >= 1) wg = v; }
+			if (env_wg >= 1) wg = env_wg;
 			const int tile_rows = 4 * kTileRows;                      // a wave's unit: 256 rows in either kernel
 			const int64_t ntiles = (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace sk {
 
@@ -158,6 +159,17 @@ static bool build_pair(const SheetShape &sh, const uint8_t *sheet, LutHost &out,
 		auto xof = [&](size_t q, uint32_t sd) { return lut_mix(tb < 2 ? hk[tb][q].A : pairs[q].pk, 0u, sd); };
 		if (!cuckoo_place(n, 4, 14, xof, nb[tb], seed[tb], where[tb])) return false;
 	}
+	// What a free slot holds.  With 4-bit classes eight columns fill the word, so EVERY 32-bit value is some observed half
+	// (0xFFFFFFFF = eight bytes of class 15: a poly-G index read on a mixed-case sheet): the free word is a value that is no KEY of
+	// its table, and a free slot's second word carries a distance no max_diff admits — an observed half that equals the free word
+	// "hits" the free slot and is refused by `tot <= max_diff` like any other miss, at no instruction in the kernel.  (A pair key
+	// has 20 bits: 0xFFFFFFFF is none.)
+	uint32_t free_word[3] = {kLutPairFree, kLutPairFree, kLutPairFree};
+	for (int tb = 0; tb < 2; tb++) {
+		std::unordered_set<uint32_t> keys;
+		for (const HalfKey &k : hk[tb]) keys.insert(k.A);
+		while (keys.count(free_word[tb])) free_word[tb]--;
+	}
 	const size_t n1 = (size_t)2 << nb[0], n2 = (size_t)2 << nb[1], np = (size_t)2 << nb[2];
 	const size_t bytes = (n1 + n2 + np) * 8;
 	if (bytes > (size_t)lds_budget) return false;
@@ -167,7 +179,7 @@ static bool build_pair(const SheetShape &sh, const uint8_t *sheet, LutHost &out,
 		for (size_t i = 0; i < where[tb].size(); i++) {
 			uint32_t *e = &out.slots[2 * (base + i)];
 			const int q = where[tb][i];
-			if (q < 0) { e[0] = kLutPairFree; e[1] = 0; }
+			if (q < 0) { e[0] = free_word[tb]; e[1] = tb < 2 ? kLutPairFreeVal : 0u; }
 			else if (tb < 2) { e[0] = hk[tb][(size_t)q].A; e[1] = (uint32_t)hk[tb][(size_t)q].h | ((uint32_t)hk[tb][(size_t)q].d << 16); }
 			else { e[0] = pairs[(size_t)q].pk; e[1] = (uint32_t)pairs[(size_t)q].first | ((uint32_t)pairs[(size_t)q].last << 16); }
 		}

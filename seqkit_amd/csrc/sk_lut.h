@@ -43,6 +43,7 @@
 // (src/fasta_demultiplex.rs:154-194) exactly when every half key lies within distance 1 of ONE half-barcode only — the
 // host checks it while it enumerates (half-barcodes at distance >= 3 of each other always pass) and builds the full-key
 // table otherwise.  Entries are 8 bytes: half tables {key word, h | d << 16}, pair table {h7 | h5 << 10, first | last << 16}.
+// A free slot of a half table holds {a word that is no key of the table, d = 0xFFFF}: matching it is a miss (tot > max_diff).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -60,7 +61,8 @@ constexpr int kLutMaxLen = 20;           // columns the packing holds
 constexpr int kLutMaxSamples = 1021;     // idx is 7 or 10 bits; S + 3 counters fit the kernels' LDS histogram (kMaxLdsHist)
 constexpr int kLutMinBits = 9;           // tag + idx + flag must fit 32 bits: nb >= idx bits + 2
 constexpr uint32_t kLutFree = 0x00000080u;
-constexpr uint32_t kLutPairFree = 0xFFFFFFFFu;
+constexpr uint32_t kLutPairFree = 0xFFFFFFFFu;     // a free slot's key word in the factored form (the builder steps down from here past any real key)
+constexpr uint32_t kLutPairFreeVal = 0xFFFF0000u;  // ... and its value word in the two half tables: distance 65 535, so a half that equals the free word is a miss
 
 // the factored form: three cuckoo tables of 8-byte entries in one blob (half 1, half 2, pairs), each 2 x 2^nb slots
 struct LutPairDev {

@@ -484,6 +484,19 @@ def test_demux_by_table_mixed_case_sheets(ctx, oracle, lut_form, shape):
     bc[::31, 2] = ord("#")
     if dual:
         bc[::19, hl] = ord("a")                                    # a broken separator costs one mismatch for every sample
+    # ONE byte repeated over a whole half (or row) beside a valid other half: eight bytes of class 15 pack to 0xFFFFFFFF, the word a
+    # free slot of the factored form held alone until round 6 — a poly-G index read got the sample of half 0
+    probe_bytes = b"ACGTNacgtn+#\x00\xff"
+    for j, b in enumerate(probe_bytes):
+        for part in range(3 if dual else 1):
+            r = 1000 + 3 * j + part
+            bc[r] = table[(7 * j + part) % S]
+            bc[r][bc[r] == ord("N")] = ord("A")
+            lo, hi = (0, hl) if part == 0 else ((hl + 1, 2 * hl + 1) if part == 1 else (0, bc.shape[1]))
+            keep_sep = bc[r, hl] if dual else None
+            bc[r, lo:hi] = b
+            if dual:
+                bc[r, hl] = keep_sep
     ctx.set_barcodes(table, 1)
     kind = ctx.barcode_table_info()["kind"]
     if lut_form == "no table" or (dual and lut_form == "never half by half"):      # (wide classes beside a separator: the factored form or the matchers)
