@@ -383,7 +383,7 @@ def secondary_rates(torch, ctx, dev):
             ts.append(ctx.timer_stop() / iters)
         return sorted(ts)[len(ts) // 2]
 
-    def timeit(name, fn, units, bpu, iters=10, rounds=3, cands=None, sets=None):
+    def timeit(name, fn, units, bpu, iters=10, rounds=3, cands=None, sets=None, many=None):
         """cands = {array name: [candidate tensors with the same contents]} and fn(choice) — the streaming kernels are then also
         timed with the placement of their arrays chosen (one array at a time swapped for its other candidates, as
         sk_fused_tune_placement_dev does for the fused pass): `frac` is the chosen placement, `frac_as_placed` the first candidates.
@@ -407,6 +407,22 @@ def secondary_rates(torch, ctx, dev):
                 ctx.sync()
                 ts.append(e0.elapsed_time(e1) / len(sets))
             piped = sorted(ts)[1]
+            many_ms = None
+            if many is not None:
+                # the same buffer sets through the many-batch entry point (sk_demux_assign_many_dev / sk_trim_by_quality_many_dev): ONE call,
+                # one event pair around it; per batch = the call / len(sets)
+                tm = []
+                many()
+                ctx.sync()
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    with torch.cuda.stream(stream):
+                        e0.record(stream)
+                        many()
+                        e1.record(stream)
+                    ctx.sync()
+                    tm.append(e0.elapsed_time(e1) / len(sets))
+                many_ms = sorted(tm)[2]
         elif cands is None:
             ms = measure(fn, iters, rounds)
         else:
@@ -434,6 +450,9 @@ def secondary_rates(torch, ctx, dev):
             row.update({"rows_from": f"HBM: rotation over {len(sets)} buffer sets, one event pair per call",
                         "ms_pipelined": round(piped, 4), "frac_pipelined": round(units * bpu / piped / 1e6 / HBM_PEAK_GBS, 4),
                         "ms_warm": round(warm, 4), "frac_warm": round(units * bpu / warm / 1e6 / HBM_PEAK_GBS, 4)})
+            if many_ms is not None:
+                row.update({"ms_many": round(many_ms, 4), "frac_many": round(units * bpu / many_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "many": f"the {len(sets)} buffer sets as the batches of ONE many-batch call (rows from HBM), per batch"})
         out.append(row)
 
     n = 16_000_000
@@ -450,7 +469,8 @@ def secondary_rates(torch, ctx, dev):
            lambda: ctx.trim_by_quality_dev(q.data_ptr(), 0, 150, n, 20, lk.data_ptr()), n, 152)
     k = cold_sets(1_000_000 * 152)                  # 1 M-row slices of the 16 M-row matrix, each met again after >= 512 MiB of the others
     timeit("cfg2: trim by quality 1M x 150bp, uniform Q2-Q40", None, 1_000_000, 152,
-           sets=[(lambda i=i: ctx.trim_by_quality_dev(q[i * 1_000_000:].data_ptr(), 0, 150, 1_000_000, 20, lk[i * 1_000_000:].data_ptr())) for i in range(k)])
+           sets=[(lambda i=i: ctx.trim_by_quality_dev(q[i * 1_000_000:].data_ptr(), 0, 150, 1_000_000, 20, lk[i * 1_000_000:].data_ptr())) for i in range(k)],
+           many=lambda: ctx.trim_by_quality_many_dev([(q[i * 1_000_000:].data_ptr(), 0, 1_000_000, lk[i * 1_000_000:].data_ptr()) for i in range(k)], 150, 20))
     mu = 36.0 - 16.0 * (torch.arange(150, device=dev, dtype=torch.float32) / 149) ** 2
     for r0 in range(0, n, 2_000_000):
         q[r0:r0 + 2_000_000] = ((torch.randn((2_000_000, 150), generator=g, device=dev) * 6.0 + mu).round_().clamp_(2, 40) + 33).to(torch.uint8)
@@ -519,17 +539,18 @@ def secondary_rates(torch, ctx, dev):
                 o += [torch.empty((n,), dtype=torch.uint8, device=dev), torch.empty((n,), dtype=torch.int16, device=dev), torch.empty((n,), dtype=torch.int16, device=dev)]
             keep.append((b, o))
             calls.append(lambda b=b, o=o: ctx.demux_assign_dev(b.data_ptr(), L, n, *[x.data_ptr() for x in o]))
-        return calls, keep
+        calls_many = lambda: ctx.demux_assign_many_dev([(b.data_ptr(), n, *[x.data_ptr() for x in o]) for b, o in keep], L)
+        return calls, (keep, calls_many)
 
     calls, keep = demux_sets(bc, 8, 12)
-    timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", None, n, 12, sets=calls)
+    timeit("cfg3: demultiplex 10M x 8bp, 16 barcodes", None, n, 12, sets=calls, many=keep[1])
     # what `fasta demultiplex` asks for: the decision plus lowest_diff / first / last of the reads that matched something
     low = torch.empty((n,), dtype=torch.uint8, device=dev)
     first = torch.empty((n,), dtype=torch.int16, device=dev)
     last = torch.empty((n,), dtype=torch.int16, device=dev)
     ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
     calls, keep = demux_sets(bc, 8, 17, detail=True)
-    timeit("cfg3 with the detail columns of matched reads (SK_DETAIL_MATCHED, as the fasta demultiplex host calls it), 10M x 8bp", None, n, 17, sets=calls)
+    timeit("cfg3 with the detail columns of matched reads (SK_DETAIL_MATCHED, as the fasta demultiplex host calls it), 10M x 8bp", None, n, 17, sets=calls, many=keep[1])
     del calls, keep
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()          # the same sheet on a call ten times as long: what the lookup does once the launch is out of the way
@@ -542,10 +563,10 @@ def secondary_rates(torch, ctx, dev):
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     calls, keep = demux_sets(bc, 17, 21)
-    timeit("demultiplex only 10M x 17ch, 96 dual-index", None, n, 21, sets=calls)
+    timeit("demultiplex only 10M x 17ch, 96 dual-index", None, n, 21, sets=calls, many=keep[1])
     ctx.set_detail_mode(capi.SK_DETAIL_MATCHED)
     calls, keep = demux_sets(bc, 17, 26, detail=True)
-    timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch", None, n, 26, sets=calls)
+    timeit("96 dual-index with the detail columns of matched reads (SK_DETAIL_MATCHED), 10M x 17ch", None, n, 26, sets=calls, many=keep[1])
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     bc_l = bc.repeat(10, 1).contiguous()
     assign_l = torch.empty((10 * n,), dtype=torch.int32, device=dev)
@@ -575,7 +596,7 @@ def secondary_rates(torch, ctx, dev):
     bc_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2)
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     calls, keep = demux_sets(bc, 17, 21)
-    timeit("demultiplex only 10M x 17ch, 384 dual-index (four plates)", None, n, 21, sets=calls)
+    timeit("demultiplex only 10M x 17ch, 384 dual-index (four plates)", None, n, 21, sets=calls, many=keep[1])
     del bc, assign, low, first, last, calls, keep
     n = 200_000_000
     flag_np, tid_np, mtid_np, tlen_np = synth.make_bam_cores(2_000_000, seed=5)
@@ -607,30 +628,38 @@ def secondary_rates(torch, ctx, dev):
                                            sc["out"][ch["out"]].data_ptr()),
            n, 76 + 152 + 152 + 4, iters=5, cands=sc)
     del s4, q, ln, fl, o, sc
-    # f3: barcode census (`fasta statistics`, `--dry-run`): rows/s; every launch starts from an empty table
+    # f3: barcode census (`fasta statistics`, `--dry-run`): rows/s.  Every launch starts from an empty table, and emptying it is
+    # part of the job: `ms` is the count alone (one event pair around sk_census_add_dev), `reset_ms` the sk_census_reset before it,
+    # `reset_plus_count_ms` both inside one event pair.  The rows whose inputs are drawn independently are the census figure;
+    # rounds 3-5 quoted one million drawn rows repeated 32 times (kept below them): their random halves come back 32 times each —
+    # 110 k distinct keys in 32 M rows where the independent noisy mix has 1.6 M.
     table = synth.make_sheet(96, 8, dual=True, seed=4)
     ctx.set_barcodes(table, 1)
-    for name, kw in (("f3: census 32M rows (1 M drawn rows x 32), clean run (per index 97 % exact, 2.5 % one substitution, 0.5 % random)", dict(p_exact=0.97, p_sub=0.025)),
-                     ("f3: census 32M rows (1 M drawn rows x 32), noisy run (per index 85 % / 10 % / 5 %)", {})):
-        b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
-        bc = torch.from_numpy(b_np).to(dev).repeat(32, 1).contiguous()
 
+    def census_row(name, bc, L, reps=5):
         torch.cuda.synchronize()
-        ts = []
-        for _ in range(4):
-            ctx.census_reset()                   # clearing the 2 GiB table is not part of the count
+        ts, rs, both = [], [], []
+        for _ in range(reps):
             ctx.sync()
             ctx.timer_start()
-            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], 17, bc.shape[0], 0, 0)
+            ctx.census_reset()
+            rs.append(ctx.timer_stop())
+            ctx.timer_start()
+            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], L, bc.shape[0], 0, 0)
             ts.append(ctx.timer_stop())
-        ms = sorted(ts[1:])[1]
+        for _ in range(3):
+            ctx.sync()
+            ctx.timer_start()
+            ctx.census_reset()
+            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], L, bc.shape[0], 0, 0)
+            both.append(ctx.timer_stop())
+        ms, rms, bms = sorted(ts[1:])[len(ts[1:]) // 2], sorted(rs[1:])[len(rs[1:]) // 2], sorted(both)[1]
         rows = bc.shape[0]
-        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
-                    "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4)})
-        del bc
-    # The two rows above repeat ONE million drawn rows 32 times (rounds 3-4's input, kept for the comparison): their random halves
-    # come back 32 times each — 110 k distinct keys in 32 M rows.  Drawn independently, the noisy mix has ~2.4 M distinct keys in
-    # 32 M rows (a random half is one of 65 536): every one of them is an insert into the HBM table, whatever is combined before.
+        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": L,
+                    "GBps": round(rows * L / ms / 1e6, 1), "frac": round(rows * L / ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "reset_ms": round(rms, 4), "reset_plus_count_ms": round(bms, 4),
+                    "G_units_per_s_with_reset": round(rows / bms / 1e6, 2), "distinct": int(ctx.census_stats()["distinct"])})
+
     bases_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     alpha_t = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
     table_t = torch.tensor(table, dtype=torch.uint8, device=dev)
@@ -639,36 +668,22 @@ def secondary_rates(torch, ctx, dev):
         gi = torch.Generator(device=dev)
         gi.manual_seed(11)
         bc = torch.cat([observed_barcodes(torch, gi, dev, 4_000_000, table_t, bases_t, alpha_t, **kw) for _ in range(8)]).contiguous()
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(4):
-            ctx.census_reset()
-            ctx.sync()
-            ctx.timer_start()
-            ctx.census_add_dev(bc.data_ptr(), bc.shape[1], 17, bc.shape[0], 0, 0)
-            ts.append(ctx.timer_stop())
-        ms = sorted(ts[1:])[1]
-        rows = bc.shape[0]
-        out.append({"config": name, "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2), "bytes_per_unit": 17,
-                    "GBps": round(rows * 17 / ms / 1e6, 1), "frac": round(rows * 17 / ms / 1e6 / HBM_PEAK_GBS, 4),
-                    "distinct": int(ctx.census_stats()["distinct"])})
+        census_row(name, bc, 17)
         del bc
-    # the floor of the census: every row a key never seen before (random 16-mers: 32 M distinct keys enter the HBM table)
+    for name, kw in (("f3: census 32M rows (1 M drawn rows x 32: rounds 3-5's input), clean run (per index 97 % exact, 2.5 % one substitution, 0.5 % random)", dict(p_exact=0.97, p_sub=0.025)),
+                     ("f3: census 32M rows (1 M drawn rows x 32: rounds 3-5's input), noisy run (per index 85 % / 10 % / 5 %)", {})):
+        b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw)
+        bc = torch.from_numpy(b_np).to(dev).repeat(32, 1).contiguous()
+        census_row(name, bc, 17)
+        del bc
+    # the floor of the census: every row a key never seen before (random 16-mers: 32 M distinct keys; level 1 of the table holds the first
+    # four million, the rest go through to level 2 — and the reset behind such a launch clears level 2 as well)
     rows = 32_000_000
     bc = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (rows, 16), device=dev, generator=g)].contiguous()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(3):
-        ctx.census_reset()
-        ctx.sync()
-        ctx.timer_start()
-        ctx.census_add_dev(bc.data_ptr(), 16, 16, rows, 0, 0)
-        ts.append(ctx.timer_stop())
-    ms = sorted(ts[1:])[0]
-    out.append({"config": "f3: census 32M rows, every row a new key (random 16-mers)", "ms": round(ms, 4), "G_units_per_s": round(rows / ms / 1e6, 2),
-                "bytes_per_unit": 16, "GBps": round(rows * 16 / ms / 1e6, 1), "frac": round(rows * 16 / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "distinct": int(ctx.census_stats()["distinct"])})
+    census_row("f3: census 32M rows, every row a new key (random 16-mers)", bc, 16, reps=3)
     del bc
+    ctx.census_reset()
+    ctx.sync()
     return out
 
 

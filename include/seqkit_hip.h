@@ -167,6 +167,27 @@ typedef struct {
 
 int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
 int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
+/* Many independent batches in one call: what n_batches calls of sk_fused_pass_dev compute (same outputs; counters are sums, so
+ * their order does not matter), enqueued so that the batches overlap on the device — a batch of a few million rows streams for
+ * 20 us, and one call after the other each pays its launch gap, ramp and tail alone (src/fasta_demultiplex.rs:154-194 per read,
+ * src/fasta_trim_by_quality.rs:28-42 per read: reads are independent, so are batches).  Asynchronous like the _dev calls: the
+ * ctx stream continues when every batch is done; sk_sync() waits.  The two conveniences below build the argument blocks. */
+int sk_fused_pass_many_dev(sk_ctx *ctx, const sk_fused_args *batches, int n_batches);
+typedef struct sk_demux_batch {
+	const uint8_t *bc;          /* n x bc_stride */
+	int64_t n;
+	int32_t *assign;            /* n */
+	uint8_t *lowest_diff;       /* n or NULL */
+	int16_t *first_idx, *last_idx;
+} sk_demux_batch;
+int sk_demux_assign_many_dev(sk_ctx *ctx, const sk_demux_batch *batches, int n_batches, int bc_stride);
+typedef struct sk_trim_batch {
+	const uint8_t *qual;        /* n x stride */
+	const uint16_t *len;        /* n or NULL */
+	int64_t n;
+	uint16_t *lowest_k;         /* n */
+} sk_trim_batch;
+int sk_trim_by_quality_many_dev(sk_ctx *ctx, const sk_trim_batch *batches, int n_batches, int stride, uint8_t min_baseq);
 
 /* ---- placement tuning for resident batches ---------------------------------------------------------------------------
  * WHERE the pages of a device buffer lie moves the fused pass by up to 12 % on one and the same GPU: measured on MI355X,
@@ -263,6 +284,54 @@ int sk_bam_flag_tlen(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, cons
 /* out = device u64[3 + 1 + (max_frag+1)]: counters, hist_total, hist; ADDED to. */
 int sk_bam_flag_tlen_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, const int32_t *mtid,
                          const int32_t *tlen, int64_t n, int32_t max_frag, uint64_t *out);
+
+/* ---- B1 on the device: BGZF inflate and the BAM record walk ------------------------------------
+ * src/common.rs:121-157: the reference reads a BAM through htslib, which inflates every BGZF block (SAMv1 §4.1: a gzip
+ * member of at most 64 KiB, self-contained), checks its CRC-32 and walks the records (block_size + 32-byte core + ...).
+ * Here the compressed file crosses PCIe and the device does all three.
+ *
+ * sk_bgzf_inflate_dev: blocks[i] says where block i's raw DEFLATE payload lies in comp (in_off, in_len: what is between
+ * the gzip header and the 8-byte trailer), how many bytes it inflates to (out_len = the trailer's ISIZE), where they go
+ * in out (out_off) and the trailer's CRC32.  comp must be readable up to the next 4-byte boundary behind the last
+ * payload; out 16-byte aligned.  status[i] (device u32): 0 = block i was inflated (and, with check_crc, its CRC
+ * matched); 1..8 = the decoder gave the block up (an irregular code, a distance before the block, sizes that do not
+ * match: what zlib would call a data error, and a few legal rarities) — nothing is decided here: the caller inflates
+ * such a block with zlib, whose verdict stands; bit 8 (0x100) = CRC mismatch.  All pointers are device pointers.
+ *
+ * sk_bam_walk_dev: stream = the inflated blocks back to back (out above, stream_len bytes, readable 8 bytes beyond),
+ * block_end[c] = where block c ends in it (device u64[n], ascending), first_record = where the first record begins
+ * (behind the BAM header).  Every block is walked from a guessed entry and the guesses are verified against the
+ * predecessors' exits until nothing changes (at most max_rounds rounds).  *verified = 1: entry[c] (device u64[n]) is
+ * where the first record that begins in block c begins, for every c — the chain from first_record, proven block by
+ * block — and it ends exactly at stream_len; *n_records = records in the stream.  *verified = 0: the stream is not a
+ * well-formed sequence of records (or did not settle): the caller's record-at-a-time path reports it as the reference
+ * would.  exit_scratch (device u64[n]) and nrec_scratch (device u32[n + 1]) are work space.
+ *
+ * sk_bam_walk_reduce_dev: S1 + H1 (sk_bam_flag_tlen's predicates) over the records of a verified chain, read straight
+ * from the inflated bytes.  out = device u64[3 + 1 + (max_frag + 1)] as sk_bam_flag_tlen_dev, ADDED to.
+ *
+ * sk_bam_file_reduce: the three above over a whole BAM file: reads it (pread into pinned buffers), ships the compressed
+ * bytes, inflates, walks, reduces; blocks the device gave up are inflated with zlib on the host.  counters / hist as
+ * sk_bam_flag_tlen (ADDED to; either may be NULL).  *handled = 0 (and nothing added): the file is not one this path
+ * serves — not a regular file, not BGZF, cut short, a record chain that does not verify, a block zlib rejects too —
+ * and the caller falls back to its record-at-a-time reader, which produces the reference's output and messages.
+ * info (may be NULL): [0] compressed bytes, [1] inflated bytes, [2] BGZF blocks, [3] records, [4] blocks inflated by
+ * zlib on the host, [5] walk rounds, [6] ms reading + copying, [7] ms of device work behind the last copy.          */
+typedef struct sk_bgzf_block {
+	uint64_t in_off;               /* of the DEFLATE payload in comp */
+	uint32_t in_len, out_len;
+	uint64_t out_off;
+	uint32_t crc32, reserved;
+} sk_bgzf_block;
+int sk_bgzf_inflate_dev(sk_ctx *ctx, const uint8_t *comp, const sk_bgzf_block *blocks, int64_t n_blocks, uint8_t *out,
+                        uint32_t *status, int check_crc);
+int sk_bam_walk_dev(sk_ctx *ctx, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, int64_t n,
+                    uint64_t first_record, uint64_t *entry, uint64_t *exit_scratch, uint32_t *nrec_scratch, int max_rounds,
+                    int *verified, uint64_t *n_records, int *rounds);
+int sk_bam_walk_reduce_dev(sk_ctx *ctx, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end,
+                           const uint64_t *entry, int64_t n, int32_t max_frag, int want_counters, int want_hist, uint64_t *out);
+int sk_bam_file_reduce(sk_ctx *ctx, const char *path, int32_t max_frag, uint64_t counters[3], uint64_t *hist,
+                       uint64_t *hist_total, int *handled, double info[8]);
 
 /* ---- f2: `sam fragments` record filter ---------------------------------------------------------------------
  * src/sam_fragments.rs:27-38: keep the forward mate of a converging, mapped, primary, non-duplicate, QC-passing pair on

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(ROOT, "lib")
 BINDIR = os.path.join(ROOT, "bin")
 LIB_PATH = os.path.join(LIBDIR, "libseqkit_hip.so")
 
-HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_capi.hip", "sk_lut.cpp"]
+HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_inflate.hip", "sk_capi.hip", "sk_bamfile.cpp", "sk_lut.cpp"]
 HIP_DEPS = HIP_SOURCES + ["sk_internal.h", "sk_lut.h", os.path.join(REPO, "include", "seqkit_hip.h")]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
@@ -65,7 +65,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> seqkit_amd/lib/libseqkit_hip.so (cross-compiles without a GPU)."""
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(LIB_PATH, HIP_DEPS):
-        cmd = [_hipcc()] + HIP_FLAGS + ["-o", LIB_PATH] + HIP_SOURCES + ["-ldl"]
+        cmd = [_hipcc()] + HIP_FLAGS + ["-o", LIB_PATH] + HIP_SOURCES + ["-ldl", "-lz", "-pthread"]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         _run(cmd, CSRC)

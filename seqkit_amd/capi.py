@@ -24,9 +24,11 @@ EXPORTED_SYMBOLS = [
     "sk_malloc_device", "sk_free_device", "sk_malloc_pinned", "sk_free_pinned", "sk_copy_h2d", "sk_copy_d2h",
     "sk_set_barcodes", "sk_set_detail_mode", "sk_barcode_table_info", "sk_demux_assign", "sk_demux_assign_dev", "sk_trim_by_quality", "sk_trim_by_quality_dev",
     "sk_mask_by_quality", "sk_mask_by_quality_dev", "sk_fused_pass", "sk_fused_pass_dev",
+    "sk_fused_pass_many_dev", "sk_demux_assign_many_dev", "sk_trim_by_quality_many_dev",
     "sk_blocked_layout_init", "sk_fused_pass_blocked_dev", "sk_fused_tune_placement_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
     "sk_comm_ready", "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
+    "sk_bgzf_inflate_dev", "sk_bam_walk_dev", "sk_bam_walk_reduce_dev", "sk_bam_file_reduce",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
     "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get", "sk_gc_set_genome", "sk_gc_count",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
@@ -48,6 +50,14 @@ class _FusedArgs(C.Structure):
                 ("mate", _Mate * 2), ("bc", C.c_void_p), ("bc_stride", C.c_int), ("assign", C.c_void_p),
                 ("lowest_diff", C.c_void_p), ("first_idx", C.c_void_p), ("last_idx", C.c_void_p),
                 ("counts", C.c_void_p)]
+
+
+class _DemuxBatch(C.Structure):
+    _fields_ = [("bc", C.c_void_p), ("n", C.c_int64), ("assign", C.c_void_p), ("lowest_diff", C.c_void_p), ("first_idx", C.c_void_p), ("last_idx", C.c_void_p)]
+
+
+class _TrimBatch(C.Structure):
+    _fields_ = [("qual", C.c_void_p), ("len", C.c_void_p), ("n", C.c_int64), ("lowest_k", C.c_void_p)]
 
 
 class _FusedCandidates(C.Structure):
@@ -162,6 +172,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_mask_by_quality_dev": (i32, [vp, vp, vp, i32, i64, u8, vp]),
         "sk_fused_pass": (i32, [vp, C.POINTER(_FusedArgs)]),
         "sk_fused_pass_dev": (i32, [vp, C.POINTER(_FusedArgs)]),
+        "sk_fused_pass_many_dev": (i32, [vp, C.POINTER(_FusedArgs), i32]),
+        "sk_demux_assign_many_dev": (i32, [vp, C.POINTER(_DemuxBatch), i32, i32]),
+        "sk_trim_by_quality_many_dev": (i32, [vp, C.POINTER(_TrimBatch), i32, i32, u8]),
         "sk_blocked_layout_init": (i32, [C.POINTER(BlockedLayout), i32, i32, i32, i32]),
         "sk_fused_pass_blocked_dev": (i32, [vp, C.POINTER(BlockedLayout), vp, vp, i64, u8, vp]),
         "sk_fused_tune_placement_dev": (i32, [vp, C.POINTER(_FusedArgs), C.POINTER(_FusedCandidates), i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -171,6 +184,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_counts_allreduce": (i32, [C.POINTER(vp), i32]), "sk_allreduce_u64_dev": (i32, [vp, vp, C.c_size_t]),
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
+        "sk_bgzf_inflate_dev": (i32, [vp, vp, vp, i64, vp, vp, i32]),
+        "sk_bam_walk_dev": (i32, [vp, vp, C.c_uint64, vp, i64, C.c_uint64, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(i32)]),
+        "sk_bam_walk_reduce_dev": (i32, [vp, vp, C.c_uint64, vp, vp, i64, i32, i32, i32, vp]),
+        "sk_bam_file_reduce": (i32, [vp, C.c_char_p, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_double)]),
         "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_bam_fragments_dev": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
         "sk_bam_sequence": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, C.c_uint8, vp]),
@@ -272,6 +289,35 @@ class Context:
     # ---- lifetime / memory --------------------------------------------------------------
     def sync(self) -> None:
         self._check(self._lib.sk_sync(self._h), "sk_sync")
+
+    # ---- B1 on the device: BGZF inflate, record walk (all pointers are device addresses) ----
+    BGZF_BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8"), ("crc32", "<u4"), ("reserved", "<u4")])
+
+    def bgzf_inflate_dev(self, comp: int, blocks: int, n_blocks: int, out: int, status: int, check_crc: bool = True) -> None:
+        self._check(self._lib.sk_bgzf_inflate_dev(self._h, comp, blocks, n_blocks, out, status, 1 if check_crc else 0), "sk_bgzf_inflate_dev")
+
+    def bam_walk_dev(self, stream: int, stream_len: int, block_end: int, n: int, first_record: int, entry: int, exit_scratch: int, nrec_scratch: int,
+                     max_rounds: int = 64):
+        ver, nrec, rounds = C.c_int32(0), C.c_uint64(0), C.c_int32(0)
+        self._check(self._lib.sk_bam_walk_dev(self._h, stream, stream_len, block_end, n, first_record, entry, exit_scratch, nrec_scratch, max_rounds,
+                                              C.byref(ver), C.byref(nrec), C.byref(rounds)), "sk_bam_walk_dev")
+        return bool(ver.value), int(nrec.value), int(rounds.value)
+
+    def bam_walk_reduce_dev(self, stream: int, stream_len: int, block_end: int, entry: int, n: int, max_frag: int, out: int,
+                            want_counters: bool = True, want_hist: bool = True) -> None:
+        self._check(self._lib.sk_bam_walk_reduce_dev(self._h, stream, stream_len, block_end, entry, n, max_frag, 1 if want_counters else 0,
+                                                     1 if want_hist else 0, out), "sk_bam_walk_reduce_dev")
+
+    def bam_file_reduce(self, path: str, max_frag: int = 5000, want_counters: bool = True, want_hist: bool = True):
+        """sk_bam_file_reduce: (handled, counters u64[3], hist u64[max_frag + 1], hist_total, info f64[8])."""
+        counters = np.zeros(3, dtype=np.uint64)
+        hist = np.zeros(max_frag + 1, dtype=np.uint64)
+        total = np.zeros(1, dtype=np.uint64)
+        handled = C.c_int32(0)
+        info = (C.c_double * 8)()
+        self._check(self._lib.sk_bam_file_reduce(self._h, os.fsencode(path), max_frag, counters.ctypes.data if want_counters else None,
+                                                 hist.ctypes.data if want_hist else None, total.ctypes.data, C.byref(handled), info), "sk_bam_file_reduce")
+        return bool(handled.value), counters, hist, int(total[0]), [float(x) for x in info]
 
     def stream(self) -> int:
         return int(self._lib.sk_stream(self._h) or 0)
@@ -674,6 +720,21 @@ class Context:
     def mask_by_quality_dev(self, seq: int, qual: int, stride: int, n: int, min_baseq: int, out_seq: int) -> None:
         self._check(self._lib.sk_mask_by_quality_dev(self._h, seq, qual, stride, n, min_baseq, out_seq),
                     "sk_mask_by_quality_dev")
+
+    def demux_assign_many_dev(self, batches, bc_stride: int) -> None:
+        """batches: [(bc, n, assign, lowest_diff or 0, first_idx or 0, last_idx or 0)] of device addresses: sk_demux_assign_many_dev"""
+        arr = (_DemuxBatch * len(batches))()
+        for i, b in enumerate(batches):
+            bc, n, assign, low, first, last = (list(b) + [0, 0, 0])[:6]
+            arr[i] = _DemuxBatch(bc, n, assign, low or None, first or None, last or None)
+        self._check(self._lib.sk_demux_assign_many_dev(self._h, arr, len(batches), bc_stride), "sk_demux_assign_many_dev")
+
+    def trim_by_quality_many_dev(self, batches, stride: int, min_baseq: int) -> None:
+        """batches: [(qual, len or 0, n, lowest_k)] of device addresses: sk_trim_by_quality_many_dev"""
+        arr = (_TrimBatch * len(batches))()
+        for i, (qual, ln, n, lowest_k) in enumerate(batches):
+            arr[i] = _TrimBatch(qual, ln or None, n, lowest_k)
+        self._check(self._lib.sk_trim_by_quality_many_dev(self._h, arr, len(batches), stride, min_baseq), "sk_trim_by_quality_many_dev")
 
     def bam_flag_tlen_dev(self, flag: int, tid: int, mtid: int, tlen: int, n: int, max_frag: int, out: int) -> None:
         self._check(self._lib.sk_bam_flag_tlen_dev(self._h, flag, tid, mtid, tlen, n, max_frag, out),

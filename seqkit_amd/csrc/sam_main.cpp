@@ -254,6 +254,27 @@ static int statistics(int argc, char **argv)
 	const std::string bam_path = expand_home(pos[0]), targets_path = expand_home(opts[0].value);     // :17-18
 	const int64_t max_frag_len = 5000;                                                                 // :19
 	host::gpu_warmup();
+	auto print_counters = [](const uint64_t counters[3]) {                                             // :109-112
+		char buf[256];
+		snprintf(buf, sizeof buf, "Total reads: %llu\n", (unsigned long long)counters[0]);
+		host::out().write(buf, strlen(buf));
+		snprintf(buf, sizeof buf, "Aligned reads: %llu (%s%% of all reads)\n", (unsigned long long)counters[1],
+		         host::fmt_pct((double)counters[1] / (double)counters[0] * 100.0).c_str());
+		host::out().write(buf, strlen(buf));
+		snprintf(buf, sizeof buf, "Duplicate reads: %llu (%s%% of aligned reads)\n", (unsigned long long)counters[2],
+		         host::fmt_pct((double)counters[2] / (double)counters[1] * 100.0).c_str());
+		host::out().write(buf, strlen(buf));
+	};
+	// S1 over the FILE (round 6): the compressed bytes cross PCIe, the device inflates the BGZF blocks, walks the records and counts
+	// (include/seqkit_hip.h: sk_bam_file_reduce).  It serves well-formed regular files only and says so (handled): everything else —
+	// stdin, plain gzip, a file cut short, a record chain that does not verify — is read record by record below, which reports it as
+	// the reference does.  (--on-target needs pos / cigar of every record in order: the host's sweep, below.)
+	if (targets_path.empty() && bam_path != "-" && !getenv("SEQKIT_HOST_INFLATE")) {
+		int handled = 0;
+		uint64_t fc[3] = {0, 0, 0};
+		check(sk_bam_file_reduce(host::gpu(), bam_path.c_str(), 0, fc, nullptr, nullptr, &handled, nullptr), "sk_bam_file_reduce");
+		if (handled) { print_counters(fc); return 0; }
+	}
 	BamStream bam(bam_path);
 
 	std::vector<std::vector<Region>> target_regions;                                                   // :26-54
@@ -326,15 +347,8 @@ static int statistics(int argc, char **argv)
 		}
 	}
 	bam.raise_deferred();
-	char buf[256];                                                                                     // :109-115
-	snprintf(buf, sizeof buf, "Total reads: %llu\n", (unsigned long long)counters[0]);
-	host::out().write(buf, strlen(buf));
-	snprintf(buf, sizeof buf, "Aligned reads: %llu (%s%% of all reads)\n", (unsigned long long)counters[1],
-	         host::fmt_pct((double)counters[1] / (double)counters[0] * 100.0).c_str());
-	host::out().write(buf, strlen(buf));
-	snprintf(buf, sizeof buf, "Duplicate reads: %llu (%s%% of aligned reads)\n", (unsigned long long)counters[2],
-	         host::fmt_pct((double)counters[2] / (double)counters[1] * 100.0).c_str());
-	host::out().write(buf, strlen(buf));
+	print_counters(counters);                                                                          // :109-115
+	char buf[256];
 	if (on_target) {
 		snprintf(buf, sizeof buf, "On-target: %s%%\n", host::fmt_pct((double)on_target_fragments / (double)total_fragments * 100.0).c_str());
 		host::out().write(buf, strlen(buf));
@@ -365,13 +379,22 @@ static int fragment_lengths(int argc, char **argv)
 	std::vector<uint64_t> hist(max_frag + 1, 0);                                                       // :27
 	uint64_t total = 0;
 	host::gpu_warmup();
-	BamStream bam(pos[0]);                                                                            // :30
+	// H1 over the file on the device (see statistics()); the --reads=N stop depends on record order and keeps the host's path
+	bool by_file = false;
+	if (stop == UINT64_MAX && pos[0] != "-" && !getenv("SEQKIT_HOST_INFLATE")) {
+		int handled = 0;
+		uint64_t ft = 0;
+		std::vector<uint64_t> fh(max_frag + 1, 0);
+		check(sk_bam_file_reduce(host::gpu(), pos[0].c_str(), (int32_t)max_frag, nullptr, fh.data(), &ft, &handled, nullptr), "sk_bam_file_reduce");
+		if (handled) { hist.swap(fh); total = ft; by_file = true; }
+	}
+	std::unique_ptr<BamStream> bam_p(by_file ? nullptr : new BamStream(pos[0]));                      // :30
 	Columns col;
 	std::vector<BamCore> chunk;
-	bool more = true, stopped = false;
+	bool more = !by_file, stopped = false;
 	while (more && !stopped) {
 		col.clear();
-		while (col.flag.size() < kBatch && (more = bam.next_chunk(chunk, false)))
+		while (col.flag.size() < kBatch && (more = bam_p->next_chunk(chunk, false)))
 			for (const BamCore &c : chunk) col.push(c, false);
 		const int64_t n = (int64_t)col.flag.size();
 		if (n == 0) break;
@@ -393,7 +416,7 @@ static int fragment_lengths(int argc, char **argv)
 			}
 		}
 	}
-	if (!stopped) bam.raise_deferred();
+	if (!stopped && bam_p) bam_p->raise_deferred();
 	char buf[64];
 	for (uint64_t size = 1; size < max_frag + 1; size++) {                                             // :45-47
 		snprintf(buf, sizeof buf, "%llu\t%llu\n", (unsigned long long)size, (unsigned long long)hist[size]);

@@ -1,0 +1,321 @@
+// sk_bamfile.cpp — sk_bam_file_reduce (include/seqkit_hip.h): `sam statistics` / `sam fragment lengths` over a BAM FILE with
+// the device doing what htslib does for the reference (src/common.rs:121-157): inflate every BGZF block, check its CRC-32, walk
+// the records — and then the reduction (src/sam_statistics.rs:63-69, src/sam_fragment_lengths.rs:29-43).
+//
+// The host's part is what only it can do: read the file (a few threads pread it into pinned buffers, in order), ship the
+// COMPRESSED bytes, and follow the chain of BGZF headers — 18 bytes per block that say where the next one begins (BSIZE) —
+// reading, next to each, the trailer's CRC32 and ISIZE: that is the block table the inflate kernel takes.  Blocks are inflated
+// in batches as their bytes arrive (the copy of the next chunk runs under the kernel of the last), into ONE buffer that holds
+// the whole inflated stream: records may straddle blocks as they like, the walk sees a plain byte stream.
+//
+// Nothing here decides that a file is bad.  Whatever is not a regular, complete BGZF file whose every block inflates (on the
+// device, or — the blocks the device gave up — with zlib here) to the size and CRC its trailer states, and whose records
+// chain from the end of the header exactly to the end of the stream, is left to the caller's record-at-a-time reader
+// (*handled = 0), which produces what the reference would.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/seqkit_hip.h"
+#include "sk_internal.h"
+
+namespace {
+
+struct Cleanup {                                 // frees what was allocated, whichever way the function is left
+	std::vector<void *> dev, pinned;
+	std::vector<hipEvent_t> events;
+	int fd = -1;
+	~Cleanup()
+	{
+		for (void *p : dev) if (p) (void)hipFree(p);
+		for (void *p : pinned) if (p) (void)hipHostFree(p);
+		for (hipEvent_t e : events) (void)hipEventDestroy(e);
+		if (fd >= 0) close(fd);
+	}
+};
+
+double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool pread_full(int fd, uint8_t *dst, size_t n, uint64_t off)
+{
+	size_t got = 0;
+	while (got < n) {
+		const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+		if (r < 0) { if (errno == EINTR) continue; return false; }
+		if (r == 0) return false;
+		got += (size_t)r;
+	}
+	return true;
+}
+
+// [off, off + n) of the file into dst, by `threads` threads
+bool read_parallel(int fd, uint8_t *dst, size_t n, uint64_t off, int threads)
+{
+	if (threads <= 1 || n < ((size_t)4 << 20)) return pread_full(fd, dst, n, off);
+	std::vector<std::thread> th;
+	std::vector<char> ok((size_t)threads, 1);
+	const size_t piece = ((n + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
+	for (int t = 0; t < threads; t++) {
+		const size_t lo = std::min(n, piece * (size_t)t), hi = std::min(n, lo + piece);
+		if (hi <= lo) break;
+		th.emplace_back([=, &ok] { ok[(size_t)t] = pread_full(fd, dst + lo, hi - lo, off + lo) ? 1 : 0; });
+	}
+	for (auto &t : th) t.join();
+	for (char o : ok) if (!o) return false;
+	return true;
+}
+
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+}  // namespace
+
+#define BF_HIP(call)                                                                                                    \
+	do {                                                                                                                \
+		hipError_t e_ = (call);                                                                                         \
+		if (e_ != hipSuccess) return sk::ctx_fail(c, SK_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));               \
+	} while (0)
+
+extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag, uint64_t counters[3], uint64_t *hist, uint64_t *hist_total,
+                                  int *handled, double info[8])
+{
+	if (!c || !path || !handled) return SK_ERR_INVALID;
+	*handled = 0;
+	if (info) for (int i = 0; i < 8; i++) info[i] = 0.0;
+	if (max_frag < 0) return sk::ctx_fail(c, SK_ERR_INVALID, "max_frag = %d", max_frag);
+	if (!counters && !hist) return sk::ctx_fail(c, SK_ERR_INVALID, "nothing to do");
+	if (int r = sk::ctx_bind(c)) return r;
+	Cleanup cl;
+	cl.fd = open(path, O_RDONLY);
+	if (cl.fd < 0) return SK_OK;                                        // (the caller's reader says so in the reference's words)
+	struct stat sb;
+	if (fstat(cl.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28) return SK_OK;
+	const uint64_t fsize = (uint64_t)sb.st_size;
+	const double t0 = now_ms();
+	hipStream_t st = sk::ctx_stream(c), st2 = sk::ctx_stream2(c);
+
+	// ---- device buffers: the compressed file, and room for the inflated stream (its size is known only when the last
+	// trailer has been read: six times the file — a BAM inflates three- to fourfold — or what the device has left)
+	uint8_t *d_comp = nullptr, *d_out = nullptr;
+	BF_HIP(hipMalloc((void **)&d_comp, fsize + 64));
+	cl.dev.push_back(d_comp);
+	size_t free_b = 0, total_b = 0;
+	BF_HIP(hipMemGetInfo(&free_b, &total_b));
+	uint64_t out_cap = std::max<uint64_t>(fsize * 6, (uint64_t)256 << 20);
+	if (const char *ev = getenv("SK_BAMFILE_OUT_FACTOR")) { const int f = atoi(ev); if (f >= 1 && f <= 1100) out_cap = std::max<uint64_t>(fsize * (uint64_t)f, (uint64_t)1 << 20); }
+	out_cap = std::min<uint64_t>(out_cap, (uint64_t)(free_b * 0.8));
+	{
+		hipError_t e = hipMalloc((void **)&d_out, out_cap + 64);
+		if (e != hipSuccess) { (void)hipGetLastError(); return SK_OK; }
+	}
+	cl.dev.push_back(d_out);
+
+	// ---- read, ship, follow the headers; inflate batch by batch
+	size_t chunk = (size_t)32 << 20;
+	if (const char *ev = getenv("SK_BAMFILE_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 12 && lg <= 30) chunk = (size_t)1 << lg; }
+	int threads = 4;
+	if (const char *ev = getenv("SK_BAMFILE_THREADS")) { const int t = atoi(ev); if (t >= 1 && t <= 64) threads = t; }
+	constexpr int kBufs = 3;
+	uint8_t *pin[kBufs];
+	hipEvent_t ev_copied[kBufs];
+	for (int i = 0; i < kBufs; i++) {
+		void *p = nullptr;
+		BF_HIP(hipHostMalloc(&p, chunk, hipHostMallocDefault));
+		cl.pinned.push_back(p);
+		pin[i] = (uint8_t *)p;
+		BF_HIP(hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming));
+		cl.events.push_back(ev_copied[i]);
+	}
+	hipEvent_t ev_batch;
+	BF_HIP(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
+	cl.events.push_back(ev_batch);
+
+	std::vector<sk_bgzf_block> blocks;
+	std::vector<uint64_t> bend;
+	blocks.reserve((size_t)(fsize / 16384) + 16);
+	bend.reserve(blocks.capacity());
+	// device copies of the block table grow with it (capacity: a block is at least 28 bytes, in practice > 4 KiB; start at file / 8 KiB)
+	size_t tab_cap = (size_t)(fsize / 8192) + 1024;
+	sk_bgzf_block *d_blocks = nullptr;
+	uint32_t *d_status = nullptr;
+	BF_HIP(hipMalloc((void **)&d_blocks, tab_cap * sizeof(sk_bgzf_block)));
+	cl.dev.push_back(d_blocks);
+	BF_HIP(hipMalloc((void **)&d_status, tab_cap * sizeof(uint32_t)));
+	cl.dev.push_back(d_status);
+
+	uint64_t scan = 0, out_off = 0;                                     // the next header's file offset; bytes of the stream so far
+	size_t launched = 0;                                                // blocks handed to the device
+	bool eof_block_last = false;
+	const uint64_t n_chunks = (fsize + chunk - 1) / chunk;
+	uint8_t carry[65536 + 64];                                          // a header or trailer that straddles two chunks is read again (pread: rare, and cached)
+	for (uint64_t k = 0; k < n_chunks; k++) {
+		const uint64_t c_off = k * chunk;
+		const size_t c_len = (size_t)std::min<uint64_t>(chunk, fsize - c_off);
+		uint8_t *buf = pin[k % kBufs];
+		if (k >= kBufs) BF_HIP(hipEventSynchronize(ev_copied[k % kBufs]));
+		if (!read_parallel(cl.fd, buf, c_len, c_off, threads)) return SK_OK;
+		BF_HIP(hipMemcpyAsync(d_comp + c_off, buf, c_len, hipMemcpyHostToDevice, st2));
+		BF_HIP(hipEventRecord(ev_copied[k % kBufs], st2));
+		// the blocks that are complete with this chunk
+		const uint64_t have = c_off + c_len;
+		auto bytes = [&](uint64_t off, size_t n) -> const uint8_t * {   // n bytes of the file at off (off + n <= have)
+			if (off >= c_off) return buf + (off - c_off);
+			if (n > sizeof carry || !pread_full(cl.fd, carry, n, off)) return nullptr;
+			return carry;
+		};
+		const size_t first_new = blocks.size();
+		while (scan + 18 <= have) {
+			const uint8_t *h = bytes(scan, 18);
+			if (!h) return SK_OK;
+			if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return SK_OK;          // not a BGZF block: the caller's reader sorts it out
+			const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+			if (scan + 12 + xlen > have) break;
+			const uint8_t *x = bytes(scan, 12 + xlen);
+			if (!x) return SK_OK;
+			size_t bsize = 0;
+			for (size_t o = 12; o + 4 <= 12 + xlen;) {
+				const size_t slen = (size_t)x[o + 2] | ((size_t)x[o + 3] << 8);
+				if (x[o] == 'B' && x[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) { bsize = ((size_t)x[o + 4] | ((size_t)x[o + 5] << 8)) + 1; break; }
+				o += 4 + slen;
+			}
+			if (bsize == 0 || bsize < 12 + xlen + 8) return SK_OK;
+			if (scan + bsize > have) break;                                 // its trailer comes with a later chunk
+			const uint8_t *tr = bytes(scan + bsize - 8, 8);
+			if (!tr) return SK_OK;
+			sk_bgzf_block b;
+			b.in_off = scan + 12 + xlen;
+			b.in_len = (uint32_t)(bsize - 12 - xlen - 8);
+			b.crc32 = le32(tr);
+			b.out_len = le32(tr + 4);
+			b.out_off = out_off;
+			b.reserved = 0;
+			if (b.out_len > 65536u) return SK_OK;                            // (BGZF: at most 64 KiB per block)
+			out_off += b.out_len;
+			if (out_off > out_cap) return SK_OK;                             // inflates further than the room taken: the caller's reader streams it
+			blocks.push_back(b);
+			bend.push_back(out_off);
+			eof_block_last = b.out_len == 0;
+			scan += bsize;
+		}
+		// this batch: copied on st2, inflated on st behind the copy
+		const size_t n_new = blocks.size() - first_new;
+		if (n_new) {
+			if (blocks.size() > tab_cap) return SK_OK;                       // (blocks of less than 8 KiB on average: not a file worth this path)
+			BF_HIP(hipMemcpyAsync(d_blocks + first_new, blocks.data() + first_new, n_new * sizeof(sk_bgzf_block), hipMemcpyHostToDevice, st2));
+			BF_HIP(hipEventRecord(ev_batch, st2));
+			BF_HIP(hipStreamWaitEvent(st, ev_batch, 0));
+			if (int r = sk_bgzf_inflate_dev(c, d_comp, d_blocks + first_new, (int64_t)n_new, d_out, d_status + first_new, 1)) return r;
+			launched = blocks.size();
+		}
+	}
+	if (scan != fsize) return SK_OK;                                     // bytes behind the last whole block: a file cut short, or not BGZF to its end
+	(void)eof_block_last;                                               // (htslib only warns when the EOF marker is missing; the data are the same)
+	(void)launched;
+	const int64_t nb = (int64_t)blocks.size();
+	const uint64_t stream_len = out_off;
+	const double t_read = now_ms();
+	BF_HIP(hipStreamSynchronize(st2));
+	// ---- blocks the device gave up: zlib here
+	std::vector<uint32_t> status((size_t)nb);
+	BF_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+	BF_HIP(hipStreamSynchronize(st));
+	uint64_t n_host = 0;
+	{
+		std::vector<uint8_t> cbuf, obuf;
+		for (int64_t i = 0; i < nb; i++) {
+			if (status[(size_t)i] == 0) continue;
+			const sk_bgzf_block &b = blocks[(size_t)i];
+			cbuf.resize(b.in_len ? b.in_len : 1);
+			obuf.resize(b.out_len ? b.out_len : 1);
+			if (b.in_len && !pread_full(cl.fd, cbuf.data(), b.in_len, b.in_off)) return SK_OK;
+			z_stream z;
+			memset(&z, 0, sizeof z);
+			if (inflateInit2(&z, -15) != Z_OK) return SK_OK;
+			z.next_in = cbuf.data(); z.avail_in = b.in_len;
+			z.next_out = obuf.data(); z.avail_out = b.out_len;
+			const int zr = inflate(&z, Z_FINISH);
+			const bool ok = zr == Z_STREAM_END && z.total_out == b.out_len;
+			inflateEnd(&z);
+			if (!ok) return SK_OK;                                           // zlib rejects it too: the caller's reader reports it
+			if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), obuf.data(), b.out_len) != b.crc32) return SK_OK;
+			if (b.out_len) BF_HIP(hipMemcpy(d_out + b.out_off, obuf.data(), b.out_len, hipMemcpyHostToDevice));
+			n_host++;
+		}
+	}
+	// ---- the BAM header: magic, text, references (SAMv1 §4.2) — where the first record begins
+	uint64_t first = 0;
+	{
+		std::vector<uint8_t> hd;
+		size_t want = (size_t)std::min<uint64_t>(stream_len, (uint64_t)1 << 20);
+		for (;;) {
+			hd.resize(want);
+			if (want) BF_HIP(hipMemcpy(hd.data(), d_out, want, hipMemcpyDeviceToHost));
+			bool more = false, bad = false;
+			auto need = [&](uint64_t end) { if (end > want) { (end > stream_len ? bad : more) = true; return false; } return true; };
+			uint64_t o = 0;
+			do {
+				if (!need(12)) break;
+				if (memcmp(hd.data(), "BAM\1", 4) != 0) { bad = true; break; }
+				o = 8 + (uint64_t)le32(hd.data() + 4);
+				if (!need(o + 4)) break;
+				const uint32_t n_ref = le32(hd.data() + o);
+				o += 4;
+				for (uint32_t r = 0; r < n_ref && !bad && !more; r++) {
+					if (!need(o + 4)) break;
+					const uint64_t l_name = le32(hd.data() + o);
+					if (l_name > (1u << 20)) { bad = true; break; }              // (the caller's reader refuses such a header)
+					o += 4 + l_name + 4;
+					if (!need(o)) break;
+				}
+			} while (false);
+			if (bad) return SK_OK;
+			if (!more) { first = o; break; }
+			if (want >= stream_len) return SK_OK;
+			want = (size_t)std::min<uint64_t>(stream_len, (uint64_t)want * 4);
+		}
+	}
+	// ---- the records: walk, verify, reduce
+	uint64_t *d_bend = nullptr, *d_entry = nullptr, *d_exit = nullptr, *d_red = nullptr;
+	uint32_t *d_nrec = nullptr;
+	BF_HIP(hipMalloc((void **)&d_bend, (size_t)(nb + 1) * 8)); cl.dev.push_back(d_bend);
+	BF_HIP(hipMalloc((void **)&d_entry, (size_t)(nb + 1) * 8)); cl.dev.push_back(d_entry);
+	BF_HIP(hipMalloc((void **)&d_exit, (size_t)(nb + 1) * 8)); cl.dev.push_back(d_exit);
+	BF_HIP(hipMalloc((void **)&d_nrec, (size_t)(nb + 2) * 4)); cl.dev.push_back(d_nrec);
+	const size_t nred = 4 + (size_t)max_frag + 1;
+	BF_HIP(hipMalloc((void **)&d_red, nred * 8)); cl.dev.push_back(d_red);
+	BF_HIP(hipMemcpyAsync(d_bend, bend.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+	BF_HIP(hipMemsetAsync(d_red, 0, nred * 8, st));
+	BF_HIP(hipMemsetAsync(d_out + stream_len, 0, 64, st));               // (the walk reads whole dwords)
+	int verified = 0, rounds = 0;
+	uint64_t n_records = 0;
+	int max_rounds = 64;
+	if (const char *ev = getenv("SK_BAMFILE_MAX_ROUNDS")) { const int v = atoi(ev); if (v >= 1) max_rounds = v; }
+	if (int r = sk_bam_walk_dev(c, d_out, stream_len, d_bend, nb, first, d_entry, d_exit, d_nrec, max_rounds, &verified, &n_records, &rounds)) return r;
+	if (!verified) return SK_OK;
+	if (int r = sk_bam_walk_reduce_dev(c, d_out, stream_len, d_bend, d_entry, nb, max_frag, counters ? 1 : 0, hist ? 1 : 0, d_red)) return r;
+	std::vector<uint64_t> red(nred);
+	BF_HIP(hipMemcpyAsync(red.data(), d_red, nred * 8, hipMemcpyDeviceToHost, st));
+	BF_HIP(hipStreamSynchronize(st));
+	if (counters) for (int i = 0; i < 3; i++) counters[i] += red[(size_t)i];
+	if (hist) {
+		if (hist_total) *hist_total += red[3];
+		for (size_t i = 0; i <= (size_t)max_frag; i++) hist[i] += red[4 + i];
+	}
+	*handled = 1;
+	if (info) {
+		info[0] = (double)fsize; info[1] = (double)stream_len; info[2] = (double)nb; info[3] = (double)n_records;
+		info[4] = (double)n_host; info[5] = (double)rounds; info[6] = t_read - t0; info[7] = now_ms() - t_read;
+	}
+	return SK_OK;
+}

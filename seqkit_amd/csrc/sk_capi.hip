@@ -24,6 +24,11 @@ struct sk_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;     // second lane of the host entry points' chunk pipeline (H2D of chunk i+1 under kernel / D2H of chunk i)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_pipe = nullptr;
+	// lanes of sk_fused_pass_many_dev (created on first use): independent batches go to kManyLanes streams so that a batch's
+	// workgroups start on the CUs its predecessor's have left, instead of behind its last one
+	static constexpr int kManyLanes = 4;
+	hipStream_t lane[kManyLanes] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t lane_ev[kManyLanes] = {nullptr, nullptr, nullptr, nullptr};
 	std::string err;
 	// barcode table
 	bool have_table = false;
@@ -100,6 +105,22 @@ static int ensure_ws(sk_ctx *c, size_t bytes)
 }
 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+namespace sk {
+hipStream_t ctx_stream(sk_ctx *c) { return c->stream; }
+hipStream_t ctx_stream2(sk_ctx *c) { return c->stream2; }
+int ctx_n_cu(sk_ctx *c) { return c->n_cu; }
+int ctx_bind(sk_ctx *c) { return bind(c); }
+int ctx_fail(sk_ctx *c, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	return fail(c, code, "%s", buf);
+}
+}  // namespace sk
 
 // The host-pointer entry points cut a batch into chunks and run them as a two-deep software pipeline: chunk k uses
 // stream (k & 1) and half (k & 1) of the workspace, so the H2D copies of chunk k+1 run under the kernel and the D2H
@@ -198,6 +219,10 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_genome) (void)hipFree(c->d_genome);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	for (int i = 0; i < sk_ctx::kManyLanes; i++) {
+		if (c->lane[i]) { (void)hipStreamSynchronize(c->lane[i]); (void)hipStreamDestroy(c->lane[i]); }
+		if (c->lane_ev[i]) (void)hipEventDestroy(c->lane_ev[i]);
+	}
 	if (c->ev_pipe) (void)hipEventDestroy(c->ev_pipe);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -801,6 +826,72 @@ int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
 	return SK_OK;
 }
 
+static void one_mate(sk_fused_args &a, const uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
+                     uint8_t min_baseq, uint8_t *out_seq, uint16_t *lowest_k);
+
+// Many independent batches in one call.  A 10 M-row lookup streams for 20 us; as one launch after the other on
+// one stream every batch pays its launch gap, the ramp of its first loads and the tail of its last workgroups by itself.  Here the
+// batches are dealt to kManyLanes streams behind ONE fork event and joined by one wait each: the queues' launches overlap, and a
+// batch's workgroups are dispatched onto the CUs the batch before it has already left.  Counters: every launch adds to the same
+// ctx counters (or to its own a->counts) with atomics, so the sums do not depend on the order in which the lanes ran.
+int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batches)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_batches < 0 || (n_batches > 0 && !batches)) return fail(c, SK_ERR_INVALID, "n_batches = %d", n_batches);
+	if (n_batches == 0) return SK_OK;
+	if (int r = bind(c)) return r;
+	for (int i = 0; i < n_batches; i++) if (int r = check_fused(c, &batches[i], true)) return r;
+	if (n_batches == 1) return sk_fused_pass_dev(c, &batches[0]);
+	const int lanes = std::min(n_batches, (int)sk_ctx::kManyLanes);
+	for (int i = 0; i < lanes; i++) {
+		if (!c->lane[i]) SK_HIP(c, hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking));
+		if (!c->lane_ev[i]) SK_HIP(c, hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
+	}
+	for (int i = 0; i < n_batches; i++) if (batches[i].n > 0) { if (int r = prepare_demux(c, &batches[i])) return r; break; }      // (the sheet's table goes up once, before the fork)
+	SK_HIP(c, hipEventRecord(c->ev_pipe, c->stream));
+	for (int i = 0; i < lanes; i++) SK_HIP(c, hipStreamWaitEvent(c->lane[i], c->ev_pipe, 0));
+	for (int i = 0; i < n_batches; i++) {
+		const sk_fused_args *a = &batches[i];
+		if (a->n == 0) continue;
+		if (int r = prepare_demux(c, a)) return r;
+		sk::TileArgs t = tile_args_of(c, a);
+		if (t.bc && t.counts_wide) c->wide_dirty = true;
+		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->lane[i % lanes]));
+	}
+	for (int i = 0; i < lanes; i++) {
+		SK_HIP(c, hipEventRecord(c->lane_ev[i], c->lane[i]));
+		SK_HIP(c, hipStreamWaitEvent(c->stream, c->lane_ev[i], 0));
+	}
+	return SK_OK;
+}
+
+int sk_demux_assign_many_dev(sk_ctx *c, const sk_demux_batch *b, int n_batches, int bc_stride)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_batches < 0 || (n_batches > 0 && !b)) return fail(c, SK_ERR_INVALID, "n_batches = %d", n_batches);
+	std::vector<sk_fused_args> v((size_t)n_batches);
+	for (int i = 0; i < n_batches; i++) {
+		sk_fused_args &a = v[(size_t)i];
+		memset(&a, 0, sizeof a);
+		if (!b[i].bc && b[i].n > 0) return fail(c, SK_ERR_INVALID, "batch %d: bc is NULL", i);
+		a.n = b[i].n; a.bc = b[i].bc; a.bc_stride = bc_stride; a.assign = b[i].assign;
+		a.lowest_diff = b[i].lowest_diff; a.first_idx = b[i].first_idx; a.last_idx = b[i].last_idx;
+	}
+	return sk_fused_pass_many_dev(c, v.data(), n_batches);
+}
+
+int sk_trim_by_quality_many_dev(sk_ctx *c, const sk_trim_batch *b, int n_batches, int stride, uint8_t min_baseq)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_batches < 0 || (n_batches > 0 && !b)) return fail(c, SK_ERR_INVALID, "n_batches = %d", n_batches);
+	std::vector<sk_fused_args> v((size_t)n_batches);
+	for (int i = 0; i < n_batches; i++) {
+		if (b[i].n > 0 && !b[i].lowest_k) return fail(c, SK_ERR_INVALID, "batch %d: lowest_k is NULL", i);
+		one_mate(v[(size_t)i], nullptr, b[i].qual, b[i].len, stride, b[i].n, min_baseq, nullptr, b[i].lowest_k);
+	}
+	return sk_fused_pass_many_dev(c, v.data(), n_batches);
+}
+
 // Host-pointer form: chunks of rows are staged through the device workspace.
 int sk_fused_pass(sk_ctx *c, const sk_fused_args *a)
 {
@@ -1182,6 +1273,74 @@ int sk_bam_flag_tlen(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const 
 	return SK_OK;
 }
 
+// ---- B1 on the device (sk_inflate.hip) -----------------------------------------------------------------------------
+int sk_bgzf_inflate_dev(sk_ctx *c, const uint8_t *comp, const sk_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status, int check_crc)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_blocks < 0) return fail(c, SK_ERR_INVALID, "n_blocks = %lld", (long long)n_blocks);
+	if (n_blocks == 0) return SK_OK;
+	if (!comp || !blocks || !out || !status) return fail(c, SK_ERR_INVALID, "NULL comp, blocks, out or status");
+	if (!aligned16(out)) return fail(c, SK_ERR_INVALID, "out must be 16-byte aligned");
+	if ((uintptr_t)blocks & 7u) return fail(c, SK_ERR_INVALID, "blocks must be 8-byte aligned");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bgzf_inflate(comp, blocks, n_blocks, out, status, check_crc, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_bam_walk_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, int64_t n, uint64_t first_record,
+                    uint64_t *entry, uint64_t *exit_scratch, uint32_t *nrec_scratch, int max_rounds, int *verified, uint64_t *n_records, int *rounds)
+{
+	if (!c || !verified) return SK_ERR_INVALID;
+	*verified = 0;
+	if (n_records) *n_records = 0;
+	if (rounds) *rounds = 0;
+	if (n < 0) return fail(c, SK_ERR_INVALID, "n = %lld", (long long)n);
+	if (n == 0) { *verified = first_record == stream_len; return SK_OK; }
+	if (!stream || !block_end || !entry || !exit_scratch || !nrec_scratch) return fail(c, SK_ERR_INVALID, "NULL stream, block_end, entry or scratch");
+	if (int r = bind(c)) return r;
+	uint32_t *changed = nrec_scratch + n;
+	SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 0, c->stream));
+	int r_done = 1;
+	for (;; r_done++) {
+		SK_HIP(c, hipMemsetAsync(changed, 0, 4, c->stream));
+		SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 1, c->stream));
+		uint32_t ch = 0;
+		SK_HIP(c, hipMemcpyAsync(&ch, changed, 4, hipMemcpyDeviceToHost, c->stream));
+		SK_HIP(c, hipStreamSynchronize(c->stream));
+		if (ch == 0) break;
+		if (r_done >= max_rounds) { if (rounds) *rounds = r_done; return SK_OK; }      // did not settle: not verified
+	}
+	if (rounds) *rounds = r_done;
+	// settled: every entry is its predecessor's exit.  The chain is the file's when it also ends where the stream ends (and no walk met a record it could not take)
+	std::vector<uint64_t> ex((size_t)n);
+	std::vector<uint32_t> nr((size_t)n);
+	SK_HIP(c, hipMemcpy(ex.data(), exit_scratch, (size_t)n * 8, hipMemcpyDeviceToHost));
+	SK_HIP(c, hipMemcpy(nr.data(), nrec_scratch, (size_t)n * 4, hipMemcpyDeviceToHost));
+	uint64_t total = 0;
+	for (int64_t i = 0; i < n; i++) {
+		if (ex[(size_t)i] >= ~0ull - 2ull) return SK_OK;
+		total += nr[(size_t)i];
+	}
+	const uint64_t last = ex[(size_t)n - 1] < first_record ? first_record : ex[(size_t)n - 1];
+	if (last != stream_len) return SK_OK;
+	*verified = 1;
+	if (n_records) *n_records = total;
+	return SK_OK;
+}
+
+int sk_bam_walk_reduce_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, const uint64_t *entry, int64_t n,
+                           int32_t max_frag, int want_counters, int want_hist, uint64_t *out)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n < 0 || max_frag < 0) return fail(c, SK_ERR_INVALID, "n = %lld, max_frag = %d", (long long)n, max_frag);
+	if (n == 0) return SK_OK;
+	if (!stream || !block_end || !entry || !out) return fail(c, SK_ERR_INVALID, "NULL stream, block_end, entry or out");
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bam_walk_reduce(stream, stream_len, block_end, entry, n, max_frag, want_counters, want_hist, (unsigned long long *)out, c->stream));
+	return SK_OK;
+}
+
+
 // ---- f2: sam fragments filter ----------------------------------------------------------------------------------
 int sk_bam_fragments_dev(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,
                          int64_t n, int64_t min_size, int64_t max_size, uint8_t *keep_bits, uint64_t *kept)
@@ -1486,7 +1645,7 @@ int sk_census_reset(sk_ctx *c)
 	if (!c) return SK_ERR_INVALID;
 	if (int r = bind(c)) return r;
 	if (!c->census) return census_ready(c);
-	SK_HIP(c, sk::census_reset(c->census, c->stream));
+	SK_HIP(c, sk::census_reset(c->census, c->n_cu, c->stream));
 	return SK_OK;
 }
 

@@ -46,6 +46,8 @@ struct CensusSlot {          // 32 bytes, one HBM sector pair
 // bucket in each wave's LDS and flushed whole pieces: the stages took the front table's room and the flushes its time.)
 constexpr int kSpillBucketsLog2 = 8;
 constexpr int kSpillBuckets = 1 << kSpillBucketsLog2;
+// a key's bucket: the top bits of its hash — the 1/256 of LEVEL 1 its home slot lies in, whatever the tables' sizes
+__device__ __forceinline__ uint32_t census_bucket(uint32_t h) { return h >> (32 - kSpillBucketsLog2); }
 constexpr int kSpillMaxLen = 24;         // 24 characters = 96 bits; the key's fourth dword is then the marker alone
 constexpr int kSpillMaxGrid = 1024;      // workgroups of the front kernel the combine pass can address
 
@@ -59,7 +61,6 @@ struct CensusSpill {
 	u32 *wg_stats = nullptr;     // [grid][kCensusStats]: the front kernel's statistics per workgroup (summed by census_combine_kernel)
 	u32 *work = nullptr;         // census_combine_kernel's item counter (left zero by census_direct_kernel)
 	u32 cap = 0;                 // records per (workgroup, bucket) region
-	u32 bucket_shift = 0;        // bucket = (hash & mask) >> bucket_shift
 	u32 direct_above = 0;        // more records than this in the launch: they are inserted as they lie (census_direct_kernel), not combined
 	u32 grid = 0;                // workgroups of the front kernel
 	u32 merge_copies = 0;        // != 0: the front kernel's tables leave their workgroup as records, not as inserts
@@ -76,8 +77,12 @@ struct Census {
 	CensusSpill sp;
 	size_t sp_records = 0;       // capacity of key / skey
 	int sp_grid = 0;             // capacity of hist / wg_count in workgroups
-	CensusSlot *tab = nullptr;
+	CensusSlot *tab = nullptr;   // level 2 (sk_census.hip, "the HBM table has TWO levels")
 	u64 slots = 0;           // power of two
+	CensusSlot *tab1 = nullptr;  // level 1
+	int lg1 = 0;             // its slots, log2 (>= kL1GroupLog2)
+	u32 *used2 = nullptr;    // device: a key was claimed in level 2 since the last reset
+	bool used2_host = false; // ... as census_level2_used() last read it
 	u64 *stats = nullptr;    // device u64[kCensusStats]
 	u64 distinct = 0;        // host mirror of stats[0], valid after sync_stats()
 	u64 *scratch = nullptr;  // device: entry compaction output / histogram
@@ -85,7 +90,8 @@ struct Census {
 };
 
 constexpr int kCensusStats = 4;          // [0] distinct keys, [1] rows counted, [2] rows rejected, [3] probe overflows
-constexpr u64 kInitialSlots = 1ull << 26;   // 2 GiB of the 288: one launch may then take 32 M rows (SK_CENSUS_SLOTS_LOG2 overrides; tests use it)
+constexpr u64 kInitialSlots = 1ull << 26;   // level 2: 2 GiB of the 288: one launch may then take 32 M rows (SK_CENSUS_SLOTS_LOG2 overrides; tests use it)
+constexpr int kL1SlotsLog2 = 22;            // level 1: 128 MiB (SK_CENSUS_L1_LOG2 overrides; a small level 2 — the tests' — gets a level 1 of a sixteenth of it)
 constexpr int64_t kCensusChunk = 1 << 25;   // most rows per launch; the table is grown between launches so that it is never
 constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
 constexpr int kLdsSlots = 2048;
@@ -151,81 +157,145 @@ __device__ __forceinline__ SlotView census_peek(const CensusSlot *s)
 	return sv;
 }
 
-// add (cnt, first) for one key to the HBM table, starting at slot idx whose contents were fetched before (sv);
-// returns false when the probe budget ran out.  sv may be stale: a slot's key never changes once it is published, and an
-// empty or unpublished view is checked again (CAS / reload).
+// ---- the HBM table has TWO levels (round 6) ----------------------------------------------------------------------------
+// Level 2 is the table of rounds 2-5: open addressing over 2^26 slots (2 GiB), never more than half full even if every row of a
+// launch is a new key — which no run of the reference's commands comes near (a noisy 32 M-row run has 1.6 M distinct barcodes),
+// and which made every reset a 2 GiB memset (0.32 ms, as long as the census of 32 M rows itself) and every insert a DRAM row miss.
+// Level 1 is a table of 2^22 slots (128 MiB: half the Infinity Cache) in FRONT of it: a key's home slot is the TOP bits of its
+// hash, and it is probed inside the aligned group of 8 slots (256 bytes) the home slot lies in, from the home slot on, wrapping
+// inside the group.  A key goes to level 2 only when its whole group is taken by other keys — slots are never given back, so
+// whoever looks for that key later finds the same eight slots taken and goes on to level 2 as well.  Level 2 keeps a flag
+// "something was claimed here": a reset clears level 1 and, only when the flag is up, level 2 (decided on the device).
+constexpr int kL1GroupLog2 = 3;
+constexpr u32 kL1Group = 1u << kL1GroupLog2;
+struct CensusTab {
+	CensusSlot *t1;          // level 1: 1 << (32 - sh1) slots
+	u32 sh1;                 // home slot = hash >> sh1
+	CensusSlot *t2;          // level 2
+	u64 mask2;               // home slot = hash & mask2 (the hash's LOW bits: level 1 has the top ones)
+	u32 *used2;              // set when a key is claimed in level 2
+};
+
+// One slot of a probe walk, its two key words (k, v) as fetched at some earlier time (a slot's key never changes once it is
+// published, and an empty or unpublished view is checked again: CAS / reload).  true = the key is in, claimed here or added
+// to; false = the slot is another key's.
+__device__ __forceinline__ bool census_try_slot(CensusSlot *s, u64 k, u64 v, u64 klo, u64 want, u64 cnt, u64 first_inv, u32 &claimed)
+{
+	bool done = false;
+	if (k == 0) {
+		k = atomicCAS(&s->klo, 0ull, klo);
+		const bool won = k == 0;
+		if (won) {
+			// The slot is ours until its high word is published: everybody else who finds klo here waits for that
+			// (v == 0 below).  So the first count and the first row go in as plain stores, and the store of the high
+			// word hands the slot over — ONE atomic for a new key instead of three.
+			// (the stores are write-through at agent scope and the wait is for their acknowledgement — an
+			// agent-scope release would write the whole L2 back for every key)
+			{	// count and first row are the slot's second half: ONE 16-byte store (scattered stores, like atomics, cost per operation)
+				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+				const u32x4_t w = {(u32)cnt, (u32)(cnt >> 32), (u32)first_inv, (u32)(first_inv >> 32)};
+				asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&s->count), "v"(w) : "memory");
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the store
+			__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			claimed++;
+		}
+		// The winner's lanes and the loser's meet again HERE, before anybody waits for a publishing store: a lane that lost the slot
+		// to another lane OF ITS OWN WAVE for the same key spins below until that lane has published — which it has, by now.  (The
+		// barrier is a convergent no-op: it keeps the compiler from threading the winner's path past this point to the exit and
+		// ordering the loser's spin loop in front of the winner's stores — a wave would then wait for itself.)
+		__builtin_amdgcn_wave_barrier();
+		done = won;
+		if (!won) v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (!done && k == klo) {
+		while (v == 0) {                                               // owner is between its CAS and its publishing store: look again
+			__builtin_amdgcn_s_sleep(1);
+			v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (v == want) {
+			atomicAdd(&s->count, cnt);
+			// (an unconditional atomicMax was measured: one more operation on an address every workgroup adds to — the
+			// duplicate-heavy shapes lost 8 %; the first row is read, on a hit only, and folded in when it is earlier)
+			if (__hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < first_inv) atomicMax(&s->first_inv, first_inv);
+			done = true;
+		}
+	}
+	return done;
+}
+
+// add (cnt, first) for one key to an open-addressing table (level 2; the rehash), starting at slot idx whose contents were
+// fetched before (sv); returns false when the probe budget ran out.
 __device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 idx, SlotView sv, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
 	const u64 want = ~khi;
-	u32 probes = 0;
-	u64 k = sv.k, v = sv.v;
-	while (probes < kMaxProbes) {
-		CensusSlot *s = tab + idx;
-		if (k == 0) {
-			k = atomicCAS(&s->klo, 0ull, klo);
-			if (k == 0) {
-				// The slot is ours until its high word is published: everybody else who finds klo here waits for that
-				// (v == 0 below).  So the first count and the first row go in as plain stores, and the store of the high
-				// word hands the slot over — ONE atomic for a new key instead of three.
-				// (the stores are write-through at agent scope and the wait is for their acknowledgement — an
-				// agent-scope release would write the whole L2 back for every key)
-				{	// count and first row are the slot's second half: ONE 16-byte store (scattered stores, like atomics, cost per operation)
-					typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-					const u32x4_t w = {(u32)cnt, (u32)(cnt >> 32), (u32)first_inv, (u32)(first_inv >> 32)};
-					asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&s->count), "v"(w) : "memory");
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the store
-				__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				claimed++;
-				return true;
-			}
-			v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		if (k == klo) {
-			if (v == 0) {                                              // owner is between its CAS and its publishing store: look again
-				__builtin_amdgcn_s_sleep(1);
-				v = __hip_atomic_load(&s->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				continue;
-			}
-			if (v == want) {
-				atomicAdd(&s->count, cnt);
-				// (an unconditional atomicMax was measured: one more operation on an address every workgroup adds to — the
-				// duplicate-heavy shapes lost 8 %; the first row is read, on a hit only, and folded in when it is earlier)
-				if (__hip_atomic_load(&s->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < first_inv) atomicMax(&s->first_inv, first_inv);
-				return true;
-			}
-		}
+	for (u32 probes = 0; probes < kMaxProbes; probes++) {
+		if (census_try_slot(tab + idx, sv.k, sv.v, klo, want, cnt, first_inv, claimed)) return true;
 		idx = (idx + 1) & mask;
-		probes++;
-		const SlotView nx = census_peek(tab + idx);
-		k = nx.k; v = nx.v;
+		sv = census_peek(tab + idx);
 	}
 	return false;
 }
 
-__device__ __forceinline__ bool census_insert(CensusSlot *tab, u64 mask, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+// the key's walk from its level-1 home slot on, whose contents were fetched before (home): the group's other seven slots are
+// fetched in two round trips when the home slot is another key's, level 2 is walked when all eight are
+__device__ __forceinline__ bool census_insert_from(const CensusTab &t, u32 h, SlotView home, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
-	const u64 idx = (u64)census_hash(klo, khi) & mask;
-	return census_insert_at(tab, mask, idx, census_peek(tab + idx), klo, khi, cnt, first_inv, claimed);
+	typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+	const u64 want = ~khi;
+	const u32 hs = h >> t.sh1;
+	CensusSlot *const grp = t.t1 + (size_t)(hs & ~(kL1Group - 1u));
+	const u32 o = hs & (kL1Group - 1u);
+	if (census_try_slot(grp + o, home.k, home.v, klo, want, cnt, first_inv, claimed)) return true;
+	// (the other seven: three fetched together, then four — all seven at once cost the combine pass 28 registers it does not have)
+#pragma unroll 1
+	for (u32 j0 = 1; j0 < kL1Group; j0 += (j0 == 1 ? 3u : 4u)) {
+		u32x4_t w[4];
+		const u32 nj = j0 == 1 ? 3u : 4u;
+#pragma unroll
+		for (u32 j = 0; j < 4; j++) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[j]) : "v"(grp + ((o + j0 + (j < nj ? j : 0u)) & (kL1Group - 1u))) : "memory");
+		__builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the compiler does not know of the loads above
+#pragma unroll
+		for (u32 j = 0; j < 4; j++) {
+			asm volatile("" : "+v"(w[j]));
+			const u64 k = (u64)w[j][0] | ((u64)w[j][1] << 32), v = (u64)w[j][2] | ((u64)w[j][3] << 32);
+			if (j < nj && census_try_slot(grp + ((o + j0 + j) & (kL1Group - 1u)), k, v, klo, want, cnt, first_inv, claimed)) return true;
+		}
+	}
+	const u32 before = claimed;
+	const u64 idx = (u64)h & t.mask2;
+	const bool ok = census_insert_at(t.t2, t.mask2, idx, census_peek(t.t2 + idx), klo, khi, cnt, first_inv, claimed);
+	if (claimed != before) __hip_atomic_store(t.used2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return ok;
+}
+
+__device__ __forceinline__ CensusSlot *census_home(const CensusTab &t, u32 h) { return t.t1 + (size_t)(h >> t.sh1); }
+
+__device__ __forceinline__ bool census_insert(const CensusTab &t, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+{
+	const u32 h = census_hash(klo, khi);
+	return census_insert_from(t, h, census_peek(census_home(t, h)), klo, khi, cnt, first_inv, claimed);
 }
 
 // N keys of a thread at once: what bounds an insert is its chain of dependent memory round trips (the slot, the CAS, the
 // acknowledged store, the publishing store), and a loop over keys pays the chain per key — with lanes that have nothing to
 // insert waiting beside those that have.  Here the N home slots are fetched together, the CAS of those found empty are in
 // flight together, the winners' stores are acknowledged by ONE wait; a key already there takes its add (and the first-row
-// check) likewise.  Whatever is left — a slot taken by another key, a lost race — goes the long way, census_insert_at.
+// check) likewise.  Whatever is left — a slot taken by another key, a lost race — goes the long way, census_insert_from.
 template <int N>
-__device__ __forceinline__ void census_insert_many(CensusSlot *tab, u64 mask, const bool (&want)[N], const u64 (&klo)[N], const u64 (&khi)[N], const u32 (&cnt)[N],
+__device__ __forceinline__ void census_insert_many(const CensusTab &t, const bool (&want)[N], const u64 (&klo)[N], const u64 (&khi)[N], const u32 (&cnt)[N],
                                                    const u64 (&first_inv)[N], u32 &claimed, u32 &overflow)
 {
 	typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-	u64 idx[N];
+	CensusSlot *hs[N];
+	u32 hh[N];
 	u32x4_t w[N];
 #pragma unroll
 	for (int q = 0; q < N; q++) {
-		idx[q] = want[q] ? ((u64)census_hash(klo[q], khi[q]) & mask) : 0ull;
-		asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[q]) : "v"(tab + idx[q]) : "memory");
+		hh[q] = want[q] ? census_hash(klo[q], khi[q]) : 0u;
+		hs[q] = census_home(t, hh[q]);
+		asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[q]) : "v"(hs[q]) : "memory");
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): the compiler does not know of the loads above
 	u64 k[N], v[N], old[N];
@@ -237,16 +307,16 @@ __device__ __forceinline__ void census_insert_many(CensusSlot *tab, u64 mask, co
 		v[q] = (u64)w[q][2] | ((u64)w[q][3] << 32);
 		tryc[q] = want[q] && k[q] == 0ull;
 		old[q] = 1ull;
-		if (tryc[q]) old[q] = atomicCAS(&tab[idx[q]].klo, 0ull, klo[q]);
+		if (tryc[q]) old[q] = atomicCAS(&hs[q]->klo, 0ull, klo[q]);
 	}
 	bool any_won = false;
 #pragma unroll
 	for (int q = 0; q < N; q++) {
 		won[q] = tryc[q] && old[q] == 0ull;
 		any_won = any_won || won[q];
-		if (won[q]) {                                                  // ours until the high word is published (census_insert_at)
+		if (won[q]) {                                                  // ours until the high word is published (census_try_slot)
 			const u32x4_t cw = {cnt[q], 0u, (u32)first_inv[q], (u32)(first_inv[q] >> 32)};
-			asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&tab[idx[q]].count), "v"(cw) : "memory");
+			asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&hs[q]->count), "v"(cw) : "memory");
 		}
 	}
 	if (any_won) {
@@ -257,24 +327,24 @@ __device__ __forceinline__ void census_insert_many(CensusSlot *tab, u64 mask, co
 #pragma unroll
 	for (int q = 0; q < N; q++) {
 		if (won[q]) {
-			__hip_atomic_store(&tab[idx[q]].khi_inv, ~khi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&hs[q]->khi_inv, ~khi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			claimed++;
 		}
 		hit[q] = want[q] && !tryc[q] && k[q] == klo[q] && v[q] == ~khi[q];
 		f[q] = ~0ull;
 		if (hit[q]) {
-			atomicAdd(&tab[idx[q]].count, (u64)cnt[q]);
-			f[q] = __hip_atomic_load(&tab[idx[q]].first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			atomicAdd(&hs[q]->count, (u64)cnt[q]);
+			f[q] = __hip_atomic_load(&hs[q]->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 #pragma unroll
 	for (int q = 0; q < N; q++) {
-		if (hit[q] && f[q] < first_inv[q]) atomicMax(&tab[idx[q]].first_inv, first_inv[q]);
+		if (hit[q] && f[q] < first_inv[q]) atomicMax(&hs[q]->first_inv, first_inv[q]);
 		if (want[q] && !won[q] && !hit[q]) {
 			SlotView sv;
 			sv.k = tryc[q] ? old[q] : k[q];
-			sv.v = tryc[q] ? __hip_atomic_load(&tab[idx[q]].khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v[q];
-			if (!census_insert_at(tab, mask, idx[q], sv, klo[q], khi[q], (u64)cnt[q], first_inv[q], claimed)) overflow += cnt[q];
+			sv.v = tryc[q] ? __hip_atomic_load(&hs[q]->khi_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v[q];
+			if (!census_insert_from(t, hh[q], sv, klo[q], khi[q], (u64)cnt[q], first_inv[q], claimed)) overflow += cnt[q];
 		}
 	}
 }
@@ -468,8 +538,7 @@ struct CensusArgs {
 	int64_t n;
 	const int32_t *assign;    // nullable: count row r only when assign[r] == SK_ASSIGN_NONE
 	int64_t row_base;
-	CensusSlot *tab;
-	u64 mask;
+	CensusTab t;
 	u64 *stats;
 	CensusSpill sp;
 	int long_way_only;        // SK_CENSUS_LONG_WAY_ONLY=1: no row is counted by the fast look at the front table (its ordered, compiler-
@@ -647,7 +716,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 		if (has && !fits) {
 			const u64 klo = 0xF0000000ull | ((u64)rec[0] << 32), khi = (u64)rec[1] | ((u64)rec[2] << 32);
 			const u32 cnt = census_rec_count(rec[3]);
-			if (!census_insert(a.tab, a.mask, klo, khi, (u64)cnt, ~(u64)(a.row_base + census_rec_row(rec[3])), claimed)) overflow += cnt;
+			if (!census_insert(a.t, klo, khi, (u64)cnt, ~(u64)(a.row_base + census_rec_row(rec[3])), claimed)) overflow += cnt;
 		}
 	};
 	int t = (int)blockIdx.x * nwave + wave;
@@ -843,7 +912,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 				for (int j = 0; j < R; j++) {
 					const bool has = ((parked >> j) & 1u) != 0u;
 					const u32x4_t kq = {(u32)(pklo[j] >> 32), (u32)pkhi[j], (u32)(pkhi[j] >> 32), prid[j]};
-					record_put(has, (u32)(((u64)ph[j] & a.mask) >> a.sp.bucket_shift), kq);
+					record_put(has, census_bucket(ph[j]), kq);
 				}
 			}
 		} else if (__any(parked != 0u)) {
@@ -866,7 +935,7 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 						const u32 rel = qrel[qn - cnt + lane];
 						const u64 klo = (u64)kq.x | ((u64)kq.y << 32), khi = (u64)kq.z | ((u64)kq.w << 32);
 						const u64 first_inv = ~(u64)(a.row_base + rel);
-						if (!census_insert(a.tab, a.mask, klo, khi, 1ull, first_inv, claimed)) overflow++;
+						if (!census_insert(a.t, klo, khi, 1ull, first_inv, claimed)) overflow++;
 					}
 					qn -= cnt;
 					census_wave_fence();
@@ -911,14 +980,14 @@ template <int R, int NW, bool SPILL> __global__ __launch_bounds__(kCensusWaves *
 			u32 digit[4];
 #pragma unroll
 			for (int v = 0; v < 4; v++) digit[v] = rec ? (sc >> (5 * v)) & 31u : 0u;
-			const u32 bkt = (u32)(((u64)census_hash(sk, khi) & a.mask) >> a.sp.bucket_shift);
+			const u32 bkt = census_bucket(census_hash(sk, khi));
 #pragma unroll
 			for (int v = 0; v < 4; v++) {
 				const u32x4_t kq = {(u32)(sk >> 32), (u32)khi, (u32)(khi >> 32), first | ((u32)v << kRecRowBits) | ((digit[v] - 1u) << 27)};
 				record_put(digit[v] != 0u, bkt, kq);
 			}
 		}
-		if (live && !rec && !census_insert(a.tab, a.mask, sk, khi, (u64)sc, first_inv, claimed)) overflow += sc;
+		if (live && !rec && !census_insert(a.t, sk, khi, (u64)sc, first_inv, claimed)) overflow += sc;
 	}
 	if (SPILL) {
 		__syncthreads();
@@ -1035,6 +1104,7 @@ __device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 ov
 // workgroups, since what they add is additive — and the workgroups take items from a counter until none is left.
 constexpr int kCombineThreads = 512;
 constexpr int kCombineChunk = 16384;
+constexpr int kCombinePasses = 6;         // counts of an item's table before what is left goes to HBM record by record
 __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(const CensusArgs a)
 {
 	__shared__ LdsTable lt_s;
@@ -1106,12 +1176,12 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 		const u32 hi = min(gpre[grid], lo + kCombineChunk);
 		// record i of the bucket's sequence lies in the region of the workgroup g with gpre[g] <= i < gpre[g + 1]: found once by
 		// bisection, then g only moves forward (a thread's records are blockDim apart)
-		u32 gcur = 0u;
+		u32 gfirst = 0u;
 		{
 			const u32 i = lo + tid;
 			u32 l = 0u, r = grid;                                      // the last g with gpre[g] <= i
 			while (r - l > 1u) { const u32 m = (l + r) >> 1; if (gpre[m] <= i) l = m; else r = m; }
-			gcur = l;
+			gfirst = l;
 		}
 		SK_CSTAMP(2);                                                  // the bucket's regions scanned, the thread's first record found
 		const uint4 *const base = a.sp.key + (size_t)b * a.sp.cap;
@@ -1119,65 +1189,95 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 		// (four records of a thread are counted while its next four are on their way: with one load per trip the loop was a
 		// chain of memory latencies — 32 of them for a full item —, with four loads per trip still one per trip)
 		constexpr int kAhead = 4;
-		uint4 kk[kAhead], kn[kAhead];
-		auto fetch = [&](u32 i0, uint4 (&dst)[kAhead]) {
+		static_assert(kCombineChunk / kCombineThreads <= 32, "a thread's records of an item are the bits of one word");
+		// PASSES (round 6).  The table holds the distinct keys of an item as long as there are fewer than its slots: an item of
+		// independently drawn noisy rows has 3 500 in 16 384 records, and every record whose key found no place within kLdsProbes
+		// slots went to HBM by itself — 4 M atomics where the launch has 1.6 M distinct keys, 0.47 ms of combine pass against 0.10
+		// when the same million rows repeat (profiles/r06_census_indep_attribution.txt).  A key that finds no place NEVER finds one
+		// (slots are not given back), so all its records fail alike: they are remembered (one bit per record of the thread), the
+		// table goes to HBM — one insert per distinct key —, is cleared, and the next pass counts the records that are left (read
+		// again from L2, where the item's 256 KiB still lie).  What is left after the last pass goes to HBM record by record.
+		u32 todo = 0xffffffffu;                                        // bit 4 * trip + q: the thread's record lo + tid + (4 * trip + q) * blockDim is still to be counted
+		for (int pass = 0; pass < kCombinePasses; pass++) {
+			const bool last_pass = pass == kCombinePasses - 1;
+			u32 gcur = gfirst, left = 0u;
+			uint4 kk[kAhead], kn[kAhead];
+			auto fetch = [&](u32 i0, u32 trip, uint4 (&dst)[kAhead]) {
 #pragma unroll
-			for (int q = 0; q < kAhead; q++) {
-				const u32 i = i0 + (u32)q * blockDim.x;
-				if (i < hi) {
-					while (gpre[gcur + 1] <= i) gcur++;
-					dst[q] = base[(size_t)gcur * gpitch + (i - gpre[gcur])];
-				} else dst[q] = make_uint4(0u, 0u, 0u, 0u);
+				for (int q = 0; q < kAhead; q++) {
+					const u32 i = i0 + (u32)q * blockDim.x;
+					dst[q] = make_uint4(0u, 0u, 0u, 0u);
+					if (i < hi) {
+						while (gpre[gcur + 1] <= i) gcur++;
+						if ((todo >> ((trip * kAhead + (u32)q) & 31u)) & 1u) dst[q] = base[(size_t)gcur * gpitch + (i - gpre[gcur])];
+					}
+				}
+			};
+			fetch(lo + tid, 0u, kk);
+			u32 trip = 0u;
+			for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x, trip++) {
+				fetch(i0 + kAhead * blockDim.x, trip + 1u, kn);
+				bool dir[kAhead], have[kAhead];
+				u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+				u32 cnt[kAhead], hh[kAhead];
+#pragma unroll
+				for (int q = 0; q < kAhead; q++) {
+					const uint4 k = kk[q];
+					have[q] = i0 + (u32)q * blockDim.x < hi && ((todo >> ((trip * kAhead + (u32)q) & 31u)) & 1u) != 0u;
+					klo[q] = 0xF0000000ull | ((u64)k.x << 32);
+					khi[q] = (u64)k.y | ((u64)k.z << 32);
+					first_inv[q] = ~(u64)(a.row_base + census_rec_row(k.w));
+					cnt[q] = census_rec_count(k.w);
+					hh[q] = census_hash(klo[q], khi[q]);                     // (the table takes the hash's LOW bits: its high bits are the bucket's, the same for every key here)
+				}
+				SK_CSTAMP(3);                                              // next records asked for, keys and hashes
+				lds_count_many<kAhead>(lt, have, hh, klo, khi, cnt, first_inv, dir);
+				SK_CSTAMP(4);                                              // counted in the table
+#pragma unroll
+				for (int q = 0; q < kAhead; q++) left |= (dir[q] ? 1u : 0u) << ((trip * kAhead + (u32)q) & 31u);
+				SK_CSTAMP(5);
+#pragma unroll
+				for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
 			}
-		};
-		fetch(lo + tid, kk);
-		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
-			fetch(i0 + kAhead * blockDim.x, kn);
-			// (a key the table has no room for goes to HBM with the others of the thread's four records)
-			bool dir[kAhead], have[kAhead];
-			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
-			u32 cnt[kAhead], hh[kAhead];
+			const int more = __syncthreads_or(!last_pass && left != 0u);
+			SK_CSTAMP(6);                                                  // barrier behind the records
+			// the occupied slots go to a list, and the list to HBM four keys of a thread at a time
+			if (tid == 0) nlist = 0u;
+			__syncthreads();
+			for (int i = tid; i < kLdsSlots; i += blockDim.x)
+				if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
+			__syncthreads();
+			for (u32 j0 = tid; j0 < nlist; j0 += kAhead * blockDim.x) {
+				bool want[kAhead];
+				u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+				u32 cnt[kAhead];
 #pragma unroll
-			for (int q = 0; q < kAhead; q++) {
-				const uint4 k = kk[q];
-				have[q] = i0 + (u32)q * blockDim.x < hi;
-				klo[q] = 0xF0000000ull | ((u64)k.x << 32);
-				khi[q] = (u64)k.y | ((u64)k.z << 32);
-				first_inv[q] = ~(u64)(a.row_base + census_rec_row(k.w));
-				cnt[q] = census_rec_count(k.w);
-				hh[q] = census_hash(klo[q], khi[q]);                     // (the table takes the hash's LOW bits: its high bits are the bucket's, the same for every key here)
+				for (int q = 0; q < kAhead; q++) {
+					const u32 j = j0 + (u32)q * blockDim.x;
+					want[q] = j < nlist;
+					const int i = list[want[q] ? j : 0u];
+					klo[q] = lt->klo[i]; khi[q] = ~lt->khi_inv[i]; first_inv[q] = lt->first_inv[i]; cnt[q] = lt->count[i];
+				}
+				census_insert_many<kAhead>(a.t, want, klo, khi, cnt, first_inv, claimed, overflow);
 			}
-			SK_CSTAMP(3);                                              // next records asked for, keys and hashes
-			lds_count_many<kAhead>(lt, have, hh, klo, khi, cnt, first_inv, dir);
-			SK_CSTAMP(4);                                              // counted in the table
-			bool any_dir = false;
-#pragma unroll
-			for (int q = 0; q < kAhead; q++) any_dir = any_dir || dir[q];
-			if (__any(any_dir)) census_insert_many<kAhead>(a.tab, a.mask, dir, klo, khi, cnt, first_inv, claimed, overflow);      // (rare: its wait is for the next records' loads too)
-			SK_CSTAMP(5);                                              // keys without a place: to HBM
-#pragma unroll
-			for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
-		}
-		__syncthreads();
-		SK_CSTAMP(6);                                                  // barrier behind the records
-		// the occupied slots go to a list, and the list to HBM four keys of a thread at a time
-		if (tid == 0) nlist = 0u;
-		__syncthreads();
-		for (int i = tid; i < kLdsSlots; i += blockDim.x)
-			if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
-		__syncthreads();
-		for (u32 j0 = tid; j0 < nlist; j0 += kAhead * blockDim.x) {
-			bool want[kAhead];
-			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
-			u32 cnt[kAhead];
-#pragma unroll
-			for (int q = 0; q < kAhead; q++) {
-				const u32 j = j0 + (u32)q * blockDim.x;
-				want[q] = j < nlist;
-				const int i = list[want[q] ? j : 0u];
-				klo[q] = lt->klo[i]; khi[q] = ~lt->khi_inv[i]; first_inv[q] = lt->first_inv[i]; cnt[q] = lt->count[i];
+			if (last_pass) {
+				// what is still left (an item of more distinct keys than kCombinePasses tables hold: launches of mostly new keys take
+				// census_direct_kernel instead) goes to HBM record by record
+				for (u32 m = left; m != 0u; m &= m - 1u) {
+					const u32 i = lo + tid + (u32)__builtin_ctz(m) * blockDim.x;
+					u32 l = 0u, r = grid;
+					while (r - l > 1u) { const u32 mid = (l + r) >> 1; if (gpre[mid] <= i) l = mid; else r = mid; }
+					const uint4 k = base[(size_t)l * gpitch + (i - gpre[l])];
+					const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
+					const u32 c = census_rec_count(k.w);
+					if (!census_insert(a.t, klo, khi, (u64)c, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += c;
+				}
 			}
-			census_insert_many<kAhead>(a.tab, a.mask, want, klo, khi, cnt, first_inv, claimed, overflow);
+			if (!more) break;
+			todo = left;
+			__syncthreads();                                               // everybody has read its slots: the table is cleared for the next pass
+			for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
+			__syncthreads();
 		}
 		SK_CSTAMP(7);                                                  // occupied slots listed and inserted
 	}
@@ -1234,18 +1334,20 @@ __global__ __launch_bounds__(kDirectThreads) void census_direct_kernel(const Cen
 		const uint4 k = key[(size_t)l * a.sp.cap + (j - bpre[l])];
 		const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
 		const u32 c = census_rec_count(k.w);
-		if (!census_insert(a.tab, a.mask, klo, khi, (u64)c, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += c;
+		if (!census_insert(a.t, klo, khi, (u64)c, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += c;
 	}
 	census_add_stats(a.stats, claimed, overflow, red);
 }
 
-// grow: re-insert every slot of the old table into the new one
+// grow (level 2): re-insert every slot of the old table into the new one.  (A key of level 2 stays one: its level-1 group is full.)
 __global__ __launch_bounds__(256) void census_rehash_kernel(const CensusSlot *old_tab, u64 old_slots, CensusSlot *tab, u64 mask, u64 *stats)
 {
 	u32 claimed = 0, overflow = 0;
 	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += (u64)gridDim.x * blockDim.x) {
 		const CensusSlot s = old_tab[i];
-		if (s.klo != 0 && !census_insert(tab, mask, s.klo, ~s.khi_inv, s.count, s.first_inv, claimed)) overflow++;
+		if (s.klo == 0) continue;
+		const u64 idx = (u64)census_hash(s.klo, ~s.khi_inv) & mask;
+		if (!census_insert_at(tab, mask, idx, census_peek(tab + idx), s.klo, ~s.khi_inv, s.count, s.first_inv, claimed)) overflow++;
 	}
 	if (overflow) atomicAdd(&stats[3], (u64)overflow);
 }
@@ -1315,6 +1417,16 @@ hipError_t census_create(Census **out, hipStream_t st)
 		if (lg >= 10 && lg <= 32) init_slots = 1ull << lg;
 	}
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
+	{
+		int lg2 = 0;
+		while ((1ull << lg2) < init_slots) lg2++;
+		cs->lg1 = std::max(kL1GroupLog2, std::min(kL1SlotsLog2, lg2 - 4));
+		if (const char *ev = getenv("SK_CENSUS_L1_LOG2")) { const int lg = atoi(ev); if (lg >= kL1GroupLog2 && lg <= 26) cs->lg1 = lg; }
+	}
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->tab1, ((size_t)1 << cs->lg1) * sizeof(CensusSlot));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->tab1, 0, ((size_t)1 << cs->lg1) * sizeof(CensusSlot), st);
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->used2, sizeof(u32));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->used2, 0, sizeof(u32), st);
 	for (int v = 0; v < kCensusVariants; v++)
 		if (e == hipSuccess) e = hipFuncSetAttribute(census_variant(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
@@ -1326,16 +1438,33 @@ void census_destroy(Census *cs)
 {
 	if (!cs) return;
 	if (cs->tab) (void)hipFree(cs->tab);
+	if (cs->tab1) (void)hipFree(cs->tab1);
+	if (cs->used2) (void)hipFree(cs->used2);
 	if (cs->stats) (void)hipFree(cs->stats);
 	if (cs->scratch) (void)hipFree(cs->scratch);
 	census_spill_free(cs);
 	delete cs;
 }
 
-hipError_t census_reset(Census *cs, hipStream_t st)
+// level 2 is cleared only when something was claimed there since the last reset — decided here, on the device: no run of the
+// reference's commands gets there (2 GiB of stores, 0.32 ms: as long as a census of 32 M rows)
+__global__ __launch_bounds__(256) void census_clear2_kernel(CensusSlot *tab, u64 slots, const u32 *used2)
+{
+	if (__hip_atomic_load(used2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+	uint4 *p = reinterpret_cast<uint4 *>(tab);
+	const u64 n = slots * (sizeof(CensusSlot) / 16);
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+hipError_t census_reset(Census *cs, int n_cu, hipStream_t st)
 {
 	hipError_t e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
-	if (e == hipSuccess) e = hipMemsetAsync(cs->tab, 0, cs->slots * sizeof(CensusSlot), st);
+	if (e == hipSuccess) e = hipMemsetAsync(cs->tab1, 0, ((size_t)1 << cs->lg1) * sizeof(CensusSlot), st);
+	if (e == hipSuccess) {
+		census_clear2_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->used2);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemsetAsync(cs->used2, 0, sizeof(u32), st);
 	cs->distinct = 0;
 	return e;
 }
@@ -1488,8 +1617,11 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.n = nr;
 		a.assign = assign ? assign + o : nullptr;
 		a.row_base = row_base + o;
-		a.tab = cs->tab;
-		a.mask = cs->slots - 1;
+		a.t.t1 = cs->tab1;
+		a.t.sh1 = (u32)(32 - cs->lg1);
+		a.t.t2 = cs->tab;
+		a.t.mask2 = cs->slots - 1;
+		a.t.used2 = cs->used2;
 		a.stats = cs->stats;
 		a.long_way_only = getenv("SK_CENSUS_LONG_WAY_ONLY") && atoi(getenv("SK_CENSUS_LONG_WAY_ONLY")) != 0;
 		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
@@ -1519,9 +1651,6 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 				a.sp.grid = (u32)grid;
 				a.sp.direct_above = (u32)((uint64_t)nr * (uint64_t)direct_pct / 100);
 				a.sp.merge_copies = (u32)merge_copies;
-				int lg = 0;
-				while ((1ull << lg) < cs->slots) lg++;
-				a.sp.bucket_shift = lg > kSpillBucketsLog2 ? (u32)(lg - kSpillBucketsLog2) : 0u;
 			}
 		}
 		int tile_slot = 0, front_entries = 0;
@@ -1538,6 +1667,16 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	return hipSuccess;
 }
 
+// has level 2 taken a key since the last reset?  (cs->used2_host; synchronises the stream)
+static hipError_t census_level2_used(Census *cs, hipStream_t st)
+{
+	u32 v = 0;
+	hipError_t e = hipMemcpyAsync(&v, cs->used2, sizeof v, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	cs->used2_host = v != 0u;
+	return e;
+}
+
 static hipError_t census_scratch(Census *cs, size_t bytes)
 {
 	if (bytes <= cs->scratch_bytes) return hipSuccess;
@@ -1552,8 +1691,10 @@ hipError_t census_count_hist(Census *cs, uint64_t hist[64], int n_cu, hipStream_
 	hipError_t e = census_scratch(cs, 64 * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 64 * sizeof(u64), st);
 	if (e != hipSuccess) return e;
-	census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->scratch);
-	e = hipGetLastError();
+	census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab1, 1ull << cs->lg1, cs->scratch);
+	e = census_level2_used(cs, st);                                    // (waits for the stream: level 2 is walked only when it holds something)
+	if (e == hipSuccess && cs->used2_host) census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->scratch);
+	if (e == hipSuccess) e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(hist, cs->scratch, 64 * sizeof(u64), hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	return e;
@@ -1569,8 +1710,10 @@ hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint
 	e = census_scratch(cs, (4 + room * 4) * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 4 * sizeof(u64), st);
 	if (e != hipSuccess) return e;
-	census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, min_count ? min_count : 1, cs->scratch, room);
-	e = hipGetLastError();
+	census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab1, 1ull << cs->lg1, min_count ? min_count : 1, cs->scratch, room);
+	e = census_level2_used(cs, st);
+	if (e == hipSuccess && cs->used2_host) census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, min_count ? min_count : 1, cs->scratch, room);
+	if (e == hipSuccess) e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	u64 found = 0;
 	e = hipMemcpyAsync(&found, cs->scratch, sizeof found, hipMemcpyDeviceToHost, st);

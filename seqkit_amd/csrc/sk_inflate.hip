@@ -1,0 +1,689 @@
+// sk_inflate.hip — B1 on the device: BGZF blocks inflated by the GPU, BAM records walked there.
+//
+// Reference behaviour served: src/common.rs:121-157 (BamReader: htslib inflates every BGZF block of the file, checks its
+// CRC-32 and hands out records one by one), in front of src/sam_statistics.rs:63-69 and src/sam_fragment_lengths.rs:29-43.
+// Through round 5 the hosts inflated on CPU threads: `sam statistics` on a 32 M-record BAM was 14 CPU-seconds of inflate for
+// 0.45 ms of kernel (profiles/r05_bam_host.txt).  A BGZF block (SAMv1 §4.1) is a gzip member of at most 64 KiB whose DEFLATE
+// stream (RFC 1951) depends on nothing outside it, and its header says how long it is: the file is thousands of independent
+// streams, and the compressed bytes are a third of what crosses PCIe when the host inflates.
+//
+// bgzf_inflate_kernel — ONE WAVE PER BLOCK.  DEFLATE decoding is a chain: a symbol's first bit is known only when the one
+// before it has been decoded.  So a wave decodes like one thread — every value of the decoder (bit buffer, table entry,
+// positions) is wave-uniform and lives in scalar registers — and brings its 64 lanes to bear on what IS parallel: building
+// the decoding tables of a block, copying a match, moving the output.  Throughput comes from thousands of waves decoding
+// their own blocks at once (8 per CU), not from one fast decoder.
+//   * input: 64 dwords of the compressed stream sit in ONE vector register (lane i: dword i of the window), the next window
+//     in a second one, loaded with one coalesced raw-buffer load each (clipped by its descriptor: beyond the payload it
+//     reads zeros); the bit buffer takes its next dword with v_readlane (lane index in a scalar register) — no memory
+//     access per symbol on the input side.
+//   * tables (LDS, per wave): the literal/length code resolved by its first 10 bits, the distance code by its first 8 — one
+//     ds_read per symbol; longer codes (rare by construction) are walked bit by bit against the canonical code's
+//     first-code / count arrays.  A block's tables are built by the whole wave: ranks of the symbols within their code
+//     length by ballots, then every lane resolves the table indices it owns by the canonical rule.
+//   * output: the wave keeps the last 4-8 KiB it produced in an LDS ring addressed by the OUTPUT address (mod the ring),
+//     so that a half of the ring is a 16-byte-aligned piece of the output: literals are one ds_write_b8, a match is
+//     ds_read_u8 / ds_write_b8 across the lanes (any overlap: lane k reads byte k mod dist of the source), and whenever the
+//     output crosses a half's boundary that half leaves for HBM as coalesced 16-byte stores.  A match that reaches back
+//     beyond the ring (the other half is already overwritten) reads what was flushed, from L2.
+// Anything irregular — a code that is over-subscribed or incomplete, a distance before the block's first byte, output or
+// input that ends early or late — gives the block a non-zero status, and the caller inflates THAT block on the CPU with
+// zlib, whose verdict stands: the device never decides that a file is corrupt.
+//
+// bgzf_crc_kernel — CRC-32 of every inflated block (RFC 1952), a wave per block: each lane the CRC of its 1/64, combined
+// with carry-less multiplication by x^(8 n) mod P.
+//
+// bam_walk_kernel — the records of the inflated stream.  Record i + 1 begins where record i's block_size says: a chain
+// through the whole file.  It is cut at the BGZF blocks: every block is walked by ONE LANE from a GUESSED entry offset
+// (htslib never splits a record across blocks when it fits one, so the guess "at the block's first byte" is right for the
+// files it wrote), and yields the offset at which the walk leaves the block.  The guesses are then VERIFIED: block c + 1's
+// entry must equal block c's exit, and block 0's the end of the header; blocks whose entry was wrong take their
+// predecessor's exit and walk again (bam_walk_fix_kernel).  When every entry equals its predecessor's exit the chain is
+// THE chain — by induction from the header, not by heuristics — and a last pass reduces flag / refID / next_refID / tlen of
+// every record straight from the inflated bytes (bam_record of sk_kernels.hip: the same predicate as the SoA kernel).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "sk_internal.h"
+
+namespace sk {
+
+typedef uint32_t u32;
+typedef unsigned long long u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kInfWaves = 4;             // waves per workgroup; each inflates blocks of its own, no barrier anywhere
+constexpr int kInfLitBits = 10, kInfDistBits = 8, kInfPreBits = 7;
+#ifndef SK_INF_RING
+#define SK_INF_RING 8192
+#endif
+constexpr u32 kRing = SK_INF_RING, kHalf = kRing / 2;
+static_assert((kRing & (kRing - 1)) == 0 && kHalf >= 1024, "ring: a power of two, a half holds a longest match");
+
+// table entry: bits 0-3 the code's length, 4-7 extra bits, 8-10 kind, 16-31 literal / base value
+enum : u32 { kKindLiteral = 0u, kKindBase = 1u, kKindEob = 2u, kKindLong = 3u, kKindBad = 4u };
+__device__ __forceinline__ u32 inf_entry(u32 kind, u32 len, u32 extra, u32 value) { return len | (extra << 4) | (kind << 8) | (value << 16); }
+
+struct InfLds {                          // one wave's
+	u32 lit[1 << kInfLitBits];
+	u32 dist[1 << kInfDistBits];
+	uint16_t pre[1 << kInfPreBits];      // code-length code: length | symbol << 4
+	uint16_t sorted[288 + 32];           // the symbols by (code length, symbol): literal/length alphabet, then distances
+	uint16_t first[2][16], offs[2][16], count[2][16];      // per alphabet and code length: first code, where its symbols begin in `sorted`, how many
+	uint8_t lens[320];
+	uint8_t ring[kRing] __attribute__((aligned(16)));
+};
+
+__device__ const uint16_t kInfLenBase[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
+__device__ const uint8_t kInfLenExtra[32] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0};
+__device__ const uint16_t kInfDistBase[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
+__device__ const uint8_t kInfDistExtra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+__device__ const uint8_t kInfPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// what a symbol of alphabet `which` (0 literal/length, 1 distance, 2 code lengths) decodes to, its code being `len` bits
+__device__ __forceinline__ u32 inf_symbol_entry(int which, u32 sym, u32 len)
+{
+	if (which == 0) {
+		if (sym < 256u) return inf_entry(kKindLiteral, len, 0u, sym);
+		if (sym == 256u) return inf_entry(kKindEob, len, 0u, 0u);
+		if (sym <= 285u) return inf_entry(kKindBase, len, kInfLenExtra[sym - 257u], kInfLenBase[sym - 257u]);
+		return inf_entry(kKindBad, len, 0u, 0u);                       // 286, 287: in the fixed code, never valid in data
+	}
+	if (which == 1) return sym < 30u ? inf_entry(kKindBase, len, kInfDistExtra[sym], kInfDistBase[sym]) : inf_entry(kKindBad, len, 0u, 0u);
+	return len | (sym << 4);
+}
+
+__device__ __forceinline__ void inf_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u32 inf_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Build the decoding table of one alphabet from its code lengths lens[0 .. nsym) (LDS), by the whole wave.
+// P: index bits of the table; MAXL: longest code of the alphabet.  Returns 0, or 3 for a set of lengths that is no prefix code
+// (over-subscribed; incomplete other than the two cases DEFLATE's writers produce: no distance code at all, one distance code).
+template <int WHICH, int P, int MAXL>
+__device__ __forceinline__ u32 inf_build(InfLds &L, const uint8_t *lens, int nsym, int lane)
+{
+	const int ngroups = (nsym + 63) >> 6;
+	u32 cnt[MAXL + 1];
+#pragma unroll
+	for (int l = 0; l <= MAXL; l++) cnt[l] = 0u;
+	for (int g = 0; g < ngroups; g++) {
+		const int s = g * 64 + lane;
+		const u32 ls = s < nsym ? lens[s] : 0u;
+#pragma unroll
+		for (int l = 1; l <= MAXL; l++) cnt[l] += (u32)__popcll(__ballot(ls == (u32)l));
+	}
+	u32 total = 0u, maxlen = 0u;
+	int left = 1;
+	bool over = false;
+#pragma unroll
+	for (int l = 1; l <= MAXL; l++) {
+		left = (left << 1) - (int)cnt[l];
+		over = over || left < 0;
+		total += cnt[l];
+		if (cnt[l]) maxlen = (u32)l;
+	}
+	if (over) return 3u;
+	if (left != 0) {
+		// incomplete: legal for the distance alphabet when it has no code (a block of literals) or one code of one bit
+		if (!(WHICH == 1 && (total == 0u || (total == 1u && cnt[1] == 1u)))) return 3u;
+	}
+	u32 first[MAXL + 2], offs[MAXL + 2];
+	{
+		u32 code = 0u, o = 0u;
+		first[0] = 0u; offs[0] = 0u;
+#pragma unroll
+		for (int l = 1; l <= MAXL; l++) {
+			code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
+			first[l] = code;
+			offs[l] = o;
+			o += cnt[l];
+		}
+	}
+	constexpr int A = WHICH == 1 ? 1 : 0;                              // (the code-length alphabet has no long codes: nothing of it is kept)
+	constexpr u32 sbase = WHICH == 1 ? 288u : 0u;
+	uint16_t *const sorted = WHICH == 2 ? reinterpret_cast<uint16_t *>(L.dist) : L.sorted + sbase;      // (the code-length alphabet borrows the distance table's room: it is built later)
+	if (WHICH != 2) {
+#pragma unroll
+		for (int l = 1; l <= MAXL; l++)
+			if (lane == l) { L.first[A][l] = (uint16_t)first[l]; L.offs[A][l] = (uint16_t)offs[l]; L.count[A][l] = (uint16_t)cnt[l]; }
+	}
+	// the symbols in the order of the canonical code: by length, then by symbol
+	u32 run[MAXL + 1];
+#pragma unroll
+	for (int l = 0; l <= MAXL; l++) run[l] = 0u;
+	for (int g = 0; g < ngroups; g++) {
+		const int s = g * 64 + lane;
+		const u32 ls = s < nsym ? lens[s] : 0u;
+#pragma unroll
+		for (int l = 1; l <= MAXL; l++) {
+			const u64 m = __ballot(ls == (u32)l);
+			if (ls == (u32)l) sorted[offs[l] + run[l] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = (uint16_t)s;
+			run[l] += (u32)__popcll(m);
+		}
+	}
+	inf_lds_fence();
+	// every index of the table: the first l for which its first l bits (the code, most significant bit first) are a code of length l
+	for (int i0 = 0; i0 < (1 << P); i0 += 64) {
+		const u32 i = (u32)(i0 + lane);
+		u32 code = 0u, e = maxlen > (u32)P ? inf_entry(kKindLong, 0u, 0u, 0u) : inf_entry(kKindBad, 0u, 0u, 0u);
+		bool found = false;
+#pragma unroll
+		for (int l = 1; l <= (MAXL < P ? MAXL : P); l++) {
+			code = (code << 1) | ((i >> (l - 1)) & 1u);
+			const u32 idx = code - first[l];
+			if (!found && idx < cnt[l]) {
+				found = true;
+				e = inf_symbol_entry(WHICH, sorted[offs[l] + idx], (u32)l);
+			}
+		}
+		if (WHICH == 0) L.lit[i] = e;
+		else if (WHICH == 1) L.dist[i] = e;
+		else L.pre[i] = (uint16_t)(found ? e : 0u);
+	}
+	inf_lds_fence();
+	return 0u;
+}
+
+// the bit reader: everything wave-uniform except the two windows
+struct InfBits {
+	u64 bb;                  // bits not yet consumed, the next one lowest
+	u32 cnt;                 // how many
+	u32 vin, vnext;          // (vector) the window the buffer is fed from, and the one behind it
+	u32 widx;                // the next dword of vin
+	u32 next_off;            // byte offset of the window after vnext
+	u32 taken;               // dwords taken out of the windows
+	__amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ void inf_refill(InfBits &b, int lane)
+{
+	if (b.cnt <= 32u) {
+		const u32 w = (u32)__builtin_amdgcn_readlane((int)b.vin, (int)b.widx);
+		b.bb |= (u64)w << b.cnt;
+		b.cnt += 32u;
+		b.widx++;
+		b.taken++;
+		if (b.widx == 64u) {
+			b.vin = b.vnext;
+			b.vnext = __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)(b.next_off + 4u * (u32)lane), 0, 0);
+			b.next_off += 256u;
+			b.widx = 0u;
+		}
+	}
+}
+__device__ __forceinline__ u32 inf_take(InfBits &b, u32 n)
+{
+	const u32 v = (u32)b.bb & ((1u << n) - 1u);
+	b.bb >>= n;
+	b.cnt -= n;
+	return v;
+}
+// position the reader at byte `at` of the descriptor's range
+__device__ __forceinline__ void inf_seek(InfBits &b, u32 at, int lane)
+{
+	const u32 a4 = at & ~3u;
+	b.vin = __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)(a4 + 4u * (u32)lane), 0, 0);
+	b.vnext = __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)(a4 + 256u + 4u * (u32)lane), 0, 0);
+	b.next_off = a4 + 512u;
+	b.widx = 0u;
+	b.bb = 0ull;
+	b.cnt = 0u;
+	b.taken = a4 >> 2;
+	inf_refill(b, lane);
+	const u32 skip = 8u * (at & 3u);
+	b.bb >>= skip;
+	b.cnt -= skip;
+	inf_refill(b, lane);
+}
+// bytes of the range consumed so far (rounded up to the byte the next bit lies in)
+__device__ __forceinline__ u32 inf_consumed(const InfBits &b) { return (b.taken * 32u - b.cnt + 7u) >> 3; }
+
+// a code longer than the table's index bits, walked bit by bit against the canonical code (returns kKindBad's entry when no code matches)
+template <int WHICH, int P>
+__device__ __forceinline__ u32 inf_long_code(const InfLds &L, u64 bb)
+{
+	constexpr int A = WHICH == 1 ? 1 : 0;
+	constexpr u32 sbase = WHICH == 1 ? 288u : 0u;
+	u32 code = 0u;
+#pragma unroll
+	for (int l = 1; l <= P; l++) code = (code << 1) | ((u32)(bb >> (l - 1)) & 1u);
+	for (int l = P + 1; l <= 15; l++) {
+		code = (code << 1) | ((u32)(bb >> (l - 1)) & 1u);
+		const u32 idx = code - inf_uniform(L.first[A][l]);
+		if (idx < inf_uniform(L.count[A][l])) return inf_symbol_entry(WHICH, inf_uniform(L.sorted[sbase + inf_uniform(L.offs[A][l]) + idx]), (u32)l);
+	}
+	return inf_entry(kKindBad, 1u, 0u, 0u);
+}
+
+// out[lo, hi) (positions within the block) leaves the ring for HBM.  a0 = the block's first output address modulo 2^32.
+__device__ __forceinline__ void inf_flush(const InfLds &L, uint8_t *out, u64 out_off, u32 a0, u32 lo, u32 hi, int lane)
+{
+	if (hi <= lo) return;
+	inf_lds_fence();
+	const u32 alo = a0 + lo, ahi = a0 + hi;                            // output addresses (mod 2^32: only their low bits are used, and differences)
+	u32 body_lo = (alo + 15u) & ~15u, body_hi = ahi & ~15u;
+	if (body_hi < body_lo) { body_lo = ahi; body_hi = ahi; }           // no aligned 16 bytes inside: all head
+	uint8_t *const dst = out + out_off - (u64)0;                        // out + out_off + p  ==  position p of the block
+	// head and tail: byte by byte (at most 15 + 15)
+	const u32 nhead = body_lo - alo, ntail = ahi - body_hi;
+	if ((u32)lane < nhead) dst[lo + (u32)lane] = L.ring[(alo + (u32)lane) & (kRing - 1u)];
+	if ((u32)lane < ntail) dst[hi - ntail + (u32)lane] = L.ring[(body_hi + (u32)lane) & (kRing - 1u)];
+	for (u32 a = body_lo + 16u * (u32)lane; a < body_hi; a += 1024u) {
+		const u32x4 v = *reinterpret_cast<const u32x4 *>(&L.ring[a & (kRing - 1u)]);
+		__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst + (lo + (a - alo))));
+	}
+}
+
+struct InfBlock { u64 in_off; u32 in_len, out_len; u64 out_off; u32 crc, pad; };
+static_assert(sizeof(InfBlock) == 32, "== sk_bgzf_block");
+
+// One block.  Returns its status (0 = inflated, out_len bytes written).
+__device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const InfBlock &blk, uint8_t *out, int lane)
+{
+	InfBits b;
+	const u64 in4 = blk.in_off & ~3ull;
+	const u32 head = (u32)(blk.in_off - in4);
+	const u32 range = (head + blk.in_len + 3u) & ~3u;
+	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(comp + in4), 0, (int)range, 0x00020000);
+	inf_seek(b, head, lane);
+	const u32 a0 = (u32)blk.out_off;
+	const u32 out_len = blk.out_len;
+	u32 op = 0u, flushed = 0u;
+	u32 err = 0u;
+	for (;;) {
+		inf_refill(b, lane);
+		const u32 bfinal = inf_take(b, 1u), btype = inf_take(b, 2u);
+		if (btype == 0u) {
+			// stored: LEN / NLEN behind the next byte boundary, then LEN bytes as they are
+			inf_take(b, b.cnt & 7u);
+			inf_refill(b, lane);
+			const u32 len = inf_take(b, 16u);
+			inf_refill(b, lane);
+			const u32 nlen = inf_take(b, 16u);
+			if ((len ^ nlen) != 0xffffu) { err = 2u; break; }
+			if (len > out_len - op) { err = 6u; break; }
+			const u32 src0 = b.taken * 4u - (b.cnt >> 3);                 // byte offset (in the descriptor's range) of the first stored byte
+			if (src0 + len > head + blk.in_len) { err = 8u; break; }
+			for (u32 done = 0u; done < len;) {
+				const u32 room = kHalf - ((a0 + op) & (kHalf - 1u));
+				const u32 seg = min(len - done, room);
+				for (u32 k = (u32)lane; k < seg; k += 64u) L.ring[(a0 + op + k) & (kRing - 1u)] = comp[in4 + src0 + done + k];
+				op += seg; done += seg;
+				if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
+			}
+			inf_seek(b, src0 + len, lane);
+		} else if (btype == 1u || btype == 2u) {
+			int hlit = 288, hdist = 32;
+			if (btype == 1u) {
+				for (int s = lane; s < 320; s += 64) L.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : (s < 288 ? 8 : 5))));
+				inf_lds_fence();
+			} else {
+				hlit = (int)inf_take(b, 5u) + 257;
+				hdist = (int)inf_take(b, 5u) + 1;
+				const int hclen = (int)inf_take(b, 4u) + 4;
+				if (hlit > 286 || hdist > 30) { err = 3u; break; }
+				if (lane < 19) L.lens[lane] = 0;
+				inf_lds_fence();
+				for (int i = 0; i < hclen; i++) {
+					inf_refill(b, lane);
+					const u32 v = inf_take(b, 3u);
+					if (lane == 0) L.lens[kInfPreOrder[i]] = (uint8_t)v;
+				}
+				inf_lds_fence();
+				err = inf_build<2, kInfPreBits, 7>(L, L.lens, 19, lane);
+				if (err) break;
+				const int total = hlit + hdist;
+				int n = 0;
+				u32 prev = 0u;
+				while (n < total) {
+					inf_refill(b, lane);
+					const u32 e = inf_uniform(L.pre[(u32)b.bb & ((1u << kInfPreBits) - 1u)]);
+					const u32 l = e & 15u, sym = e >> 4;
+					if (l == 0u) { err = 4u; break; }
+					inf_take(b, l);
+					if (sym < 16u) {
+						if (lane == 0) L.lens[n] = (uint8_t)sym;
+						prev = sym;
+						n++;
+						continue;
+					}
+					u32 rep, val = 0u;
+					if (sym == 16u) { if (n == 0) { err = 4u; break; } val = prev; rep = 3u + inf_take(b, 2u); }
+					else if (sym == 17u) rep = 3u + inf_take(b, 3u);
+					else rep = 11u + inf_take(b, 7u);
+					if (n + (int)rep > total) { err = 4u; break; }
+					for (u32 k = (u32)lane; k < rep; k += 64u) L.lens[n + (int)k] = (uint8_t)val;
+					prev = val;
+					n += (int)rep;
+				}
+				if (err) break;
+				inf_lds_fence();
+				if (inf_uniform(L.lens[256]) == 0u) { err = 3u; break; }      // no end-of-block code
+			}
+			// (the distance lengths are moved behind a literal/length alphabet of full size, so that `sorted` and the builders see fixed places)
+			err = inf_build<0, kInfLitBits, 15>(L, L.lens, hlit, lane);
+			if (err) break;
+			err = inf_build<1, kInfDistBits, 15>(L, L.lens + hlit, hdist, lane);
+			if (err) break;
+			// ---- the symbols of the block
+			for (;;) {
+				inf_refill(b, lane);
+				u32 e = inf_uniform(L.lit[(u32)b.bb & ((1u << kInfLitBits) - 1u)]);
+				if (((e >> 8) & 7u) == kKindLong) e = inf_long_code<0, kInfLitBits>(L, b.bb);
+				const u32 kind = (e >> 8) & 7u;
+				inf_take(b, e & 15u);
+				if (kind == kKindLiteral) {
+					if (op >= out_len) { err = 6u; break; }
+					if (lane == 0) L.ring[(a0 + op) & (kRing - 1u)] = (uint8_t)(e >> 16);
+					op++;
+					if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
+					continue;
+				}
+				if (kind == kKindEob) break;
+				if (kind != kKindBase) { err = 4u; break; }
+				const u32 len = (e >> 16) + inf_take(b, (e >> 4) & 15u);
+				inf_refill(b, lane);
+				u32 d = inf_uniform(L.dist[(u32)b.bb & ((1u << kInfDistBits) - 1u)]);
+				if (((d >> 8) & 7u) == kKindLong) d = inf_long_code<1, kInfDistBits>(L, b.bb);
+				if (((d >> 8) & 7u) != kKindBase) { err = 4u; break; }
+				inf_take(b, d & 15u);
+				const u32 dist = (d >> 16) + inf_take(b, (d >> 4) & 15u);
+				if (dist > op) { err = 5u; break; }
+				if (len > out_len - op) { err = 6u; break; }
+				// the copy, cut where the output crosses a half of the ring
+				const u32 m0 = op;                                             // where the match begins
+				for (u32 done = 0u; done < len;) {
+					const u32 room = kHalf - ((a0 + op) & (kHalf - 1u));
+					const u32 seg = min(len - done, room);
+					// what the ring holds: this half and the one before it (and nothing before the block's first byte)
+					const u32 half_base = (a0 + op) & ~(kHalf - 1u);
+					const u32 floor_addr = half_base - kHalf;
+					inf_lds_fence();
+					for (u32 k = (u32)lane; k < seg; k += 64u) {
+						const u32 j = done + k;                                   // byte j of the match
+						const u32 sj = dist >= len ? j : j % dist;               // (an overlapping match repeats its first dist bytes)
+						const u32 sp = m0 - dist + sj;                            // source position within the block
+						const u32 sa = a0 + sp;
+						uint8_t v;
+						// in the ring <=> its address is at or above the floor; addresses wrap at 2^32, differences do not (a block is 64 KiB)
+						if ((int)(sa - floor_addr) >= 0) v = L.ring[sa & (kRing - 1u)];
+						else v = __hip_atomic_load(out + blk.out_off + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // flushed long ago: from L2, past the vector cache
+						L.ring[(a0 + op + k) & (kRing - 1u)] = v;
+					}
+					op += seg; done += seg;
+					if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
+				}
+			}
+			if (err) break;
+		} else {
+			err = 1u;
+			break;
+		}
+		if (bfinal) break;
+	}
+	if (err) return err;
+	inf_flush(L, out, blk.out_off, a0, flushed, op, lane);
+	if (op != out_len) return 7u;
+	if (inf_consumed(b) > head + blk.in_len) return 8u;
+	return 0u;
+}
+
+__global__ __launch_bounds__(kInfWaves * 64) void bgzf_inflate_kernel(const uint8_t *comp, const InfBlock *blocks, int64_t n_blocks, uint8_t *out, u32 *status)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t inf_smem[];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[wave];
+	for (int64_t bi = (int64_t)blockIdx.x * kInfWaves + wave; bi < n_blocks; bi += (int64_t)gridDim.x * kInfWaves) {
+		InfBlock blk;
+		{	// (uniform: scalar loads)
+			const u64 *p = reinterpret_cast<const u64 *>(blocks + bi);
+			const u64 w0 = p[0], w1 = p[1], w2 = p[2];
+			blk.in_off = w0;
+			blk.in_len = (u32)__builtin_amdgcn_readfirstlane((int)(u32)w1);
+			blk.out_len = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(w1 >> 32));
+			blk.out_off = w2;
+			blk.in_off = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)w0) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w0 >> 32)) << 32);
+			blk.out_off = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)w2) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(w2 >> 32)) << 32);
+			blk.crc = 0u; blk.pad = 0u;
+		}
+		u32 st = 0u;
+		if (blk.out_len != 0u || blk.in_len != 0u) st = inf_block(L, comp, blk, out, lane);
+		if (lane == 0) status[bi] = st;
+		inf_lds_fence();
+	}
+}
+
+// ---- CRC-32 -------------------------------------------------------------------------------------------------------
+// reflected polynomial 0xEDB88320 (RFC 1952 §8).  A lane's piece byte by byte through a 256-entry table in LDS; the
+// pieces are joined with crc(A ++ B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (bit-reflected arithmetic).
+__device__ __forceinline__ u32 crc_mul(u32 a, u32 b)                     // a * b mod P, both bit-reflected (bit 31 = x^0)
+{
+	u32 r = 0u;
+	for (int i = 0; i < 32; i++) {
+		if (a & 0x80000000u) r ^= b;
+		a <<= 1;
+		b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+	}
+	return r;
+}
+__device__ __forceinline__ u32 crc_xpow8(u32 nbytes, const u32 *pw)     // x^(8 n) mod P: pw[k] = x^(8 * 2^k)
+{
+	u32 r = 0x80000000u;                                                 // x^0
+	for (int k = 0; nbytes != 0u; k++, nbytes >>= 1)
+		if (nbytes & 1u) r = crc_mul(r, pw[k]);
+	return r;
+}
+
+__global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t *out, const InfBlock *blocks, int64_t n_blocks, u32 *status)
+{
+	__shared__ u32 tab[256];
+	__shared__ u32 pw[20];
+	{
+		u32 c = threadIdx.x;
+		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+		tab[threadIdx.x] = c;
+		if (threadIdx.x == 0) {
+			u32 p = 0x00800000u;                                         // x^8
+			for (int k = 0; k < 20; k++) { pw[k] = p; p = crc_mul(p, p); }
+		}
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int64_t bi = (int64_t)blockIdx.x * 4 + wave; bi < n_blocks; bi += (int64_t)gridDim.x * 4) {
+		const InfBlock blk = blocks[bi];
+		const u32 n = blk.out_len;
+		const u32 piece = (n + 63u) >> 6;
+		const u32 lo = min(n, piece * (u32)lane), hi = min(n, lo + piece);
+		const uint8_t *p = out + blk.out_off;
+		u32 c = lane == 0 ? 0xFFFFFFFFu : 0u;                            // (the initial value rides through the first piece; the others start from 0: the register's linearity)
+		for (u32 i = lo; i < hi; i++) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+		// join: lane l takes over its right neighbour at distance 1, 2, 4 ...: c = c * x^(8 len_right) + c_right
+		u32 len = hi - lo;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 cr = __shfl_down(c, o), lr = __shfl_down(len, o);
+			if ((lane & (2 * o - 1)) == 0 && lane + o < 64) {
+				c = crc_mul(c, crc_xpow8(lr, pw)) ^ cr;
+				len += lr;
+			}
+		}
+		if (lane == 0 && (c ^ 0xFFFFFFFFu) != blk.crc) atomicOr(&status[bi], 0x100u);
+	}
+}
+
+// ---- the records of the inflated stream ----------------------------------------------------------------------------
+__device__ __forceinline__ u32 bam_le32(const uint8_t *p)
+{
+	// (any alignment: two aligned dwords and a byte shift)
+	const uintptr_t a = (uintptr_t)p;
+	const u32 *q = reinterpret_cast<const u32 *>(a & ~(uintptr_t)3);
+	const u32 sh = (u32)(a & 3u);
+	const u32 lo = q[0];
+	if (sh == 0u) return lo;
+	return __builtin_amdgcn_alignbyte(q[1], lo, sh);
+}
+
+// Walk block c from entry[c] (a position of the stream) to the first record that begins at or behind the block's end
+// (bend[c] = where block c + 1 begins): exitp[c] = that position, nrec[c] = records begun inside.  A record whose block_size
+// no record can have (< 32) or that reaches beyond the stream ends the walk with exitp = ~0 - (1 or 2): the caller's CPU path
+// reports such files.  One lane per block.
+struct WalkArgs {
+	const uint8_t *stream;
+	u64 stream_len;
+	const u64 *bend;         // [n]: end of block c in the stream (== beginning of block c + 1)
+	u64 *entry;              // [n + 1]
+	u64 *exitp;              // [n]
+	u32 *nrec;               // [n]
+	int64_t n;
+	u64 first;               // where the first record begins (behind the BAM header)
+	u32 *changed;            // bam_walk_fix_kernel: number of entries it replaced
+};
+constexpr u64 kWalkBadRecord = ~0ull - 1ull, kWalkTruncated = ~0ull - 2ull;
+
+__device__ __forceinline__ void bam_walk_one(const WalkArgs &a, int64_t c)
+{
+	u64 o = a.entry[c];
+	const u64 end = a.bend[c];
+	u32 n = 0u;
+	while (o < end) {
+		if (o + 4 > a.stream_len) { o = kWalkTruncated; break; }
+		const u32 bs = bam_le32(a.stream + o);
+		if (bs < 32u) { o = kWalkBadRecord; break; }
+		if (o + 4 + (u64)bs > a.stream_len) { o = kWalkTruncated; break; }
+		n++;
+		o += 4 + (u64)bs;
+	}
+	a.exitp[c] = o;
+	a.nrec[c] = n;
+}
+
+// first round: every block from its first byte (block 0 from the end of the header; a block the header covers wholly is entered where the header ends too)
+__global__ __launch_bounds__(256) void bam_walk_kernel(const WalkArgs a)
+{
+	const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= a.n) return;
+	const u64 begin = c == 0 ? 0ull : a.bend[c - 1];
+	a.entry[c] = begin < a.first ? a.first : begin;
+	bam_walk_one(a, c);
+}
+// later rounds: a block whose entry is not its predecessor's exit takes that exit and is walked again
+__global__ __launch_bounds__(256) void bam_walk_fix_kernel(const WalkArgs a)
+{
+	const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= a.n || c == 0) return;
+	u64 want = a.exitp[c - 1];
+	if (want >= kWalkTruncated) return;                                  // (the predecessor ran into a bad record: nothing to propagate; the verdict is the caller's)
+	if (want < a.first) want = a.first;
+	if (a.entry[c] == want) return;
+	a.entry[c] = want;
+	bam_walk_one(a, c);
+	atomicAdd(a.changed, 1u);
+}
+
+// S1 + H1 over the records of the verified chain, straight from the inflated bytes (sk_kernels.hip: bam_flag_tlen_kernel's
+// predicate, src/sam_statistics.rs:63-69, src/sam_fragment_lengths.rs:29-43).  out = u64[3 counters][1 hist_total][max_frag + 1 bins].
+// One lane per block; counters per lane, summed per workgroup; histogram bins by atomics on an LDS copy when it fits.
+constexpr int kWalkLdsBins = 8192;
+__global__ __launch_bounds__(256) void bam_walk_reduce_kernel(const WalkArgs a, int32_t max_frag, int want_counters, int want_hist, unsigned long long *out)
+{
+	__shared__ u32 lh[kWalkLdsBins];
+	__shared__ u32 red[4];
+	const bool lds_hist = want_hist && max_frag + 1 <= kWalkLdsBins;
+	if (lds_hist) for (int i = threadIdx.x; i <= max_frag; i += blockDim.x) lh[i] = 0u;
+	if (threadIdx.x < 4) red[threadIdx.x] = 0u;
+	__syncthreads();
+	const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	u32 total = 0u, aligned = 0u, dup = 0u, hist = 0u;
+	if (c < a.n) {
+		u64 o = a.entry[c];
+		const u64 end = a.bend[c];
+		while (o < end) {
+			const uint8_t *r = a.stream + o;
+			const u32 bs = bam_le32(r);
+			const u32 w14 = bam_le32(r + 4 + 12);                           // n_cigar_op (low half), flag (high half)
+			const u32 f = w14 >> 16;
+			if (want_counters) {
+				const bool primary = (f & (0x100u | 0x800u)) == 0u;            // src/sam_statistics.rs:64
+				const bool mapped = primary && !(f & 0x4u);                    // :66
+				total += primary ? 1u : 0u;
+				aligned += mapped ? 1u : 0u;
+				dup += (mapped && (f & 0x400u)) ? 1u : 0u;                     // :69
+			}
+			if (want_hist && (f & (0x1u | 0x40u | 0x4u | 0x8u | 0x400u | 0x100u | 0x800u)) == (0x1u | 0x40u)) {      // src/sam_fragment_lengths.rs:30-35
+				const int32_t tid = (int32_t)bam_le32(r + 4), mtid = (int32_t)bam_le32(r + 4 + 20), tl = (int32_t)bam_le32(r + 4 + 28);
+				if (tid == mtid) {                                             // :36
+					const u32 fl = tl < 0 ? 0u - (u32)tl : (u32)tl;             // |tlen| as the reference widens it (i32::MIN -> 2^31)
+					if (fl <= (u32)max_frag) {                                  // :38
+						hist++;
+						if (lds_hist) atomicAdd(&lh[fl], 1u);
+						else atomicAdd(&out[4 + fl], 1ull);
+					}
+				}
+			}
+			o += 4 + (u64)bs;
+		}
+	}
+	for (int s = 32; s > 0; s >>= 1) {
+		total += __shfl_xor(total, s); aligned += __shfl_xor(aligned, s); dup += __shfl_xor(dup, s); hist += __shfl_xor(hist, s);
+	}
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], total); atomicAdd(&red[1], aligned); atomicAdd(&red[2], dup); atomicAdd(&red[3], hist); }
+	__syncthreads();
+	if (threadIdx.x < 4 && red[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)red[threadIdx.x]);
+	if (lds_hist) for (int i = threadIdx.x; i <= max_frag; i += blockDim.x) if (lh[i]) atomicAdd(&out[4 + i], (unsigned long long)lh[i]);
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+hipError_t launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status, int check_crc, int n_cu, hipStream_t st)
+{
+	if (n_blocks <= 0) return hipSuccess;
+	static bool attr_set = false;
+	const size_t lds = sizeof(InfLds) * kInfWaves;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bgzf_inflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	const int per_cu = std::max(1, (int)((160 * 1024) / lds));
+	int64_t grid = (n_blocks + kInfWaves - 1) / kInfWaves;
+	const int64_t cap = (int64_t)n_cu * per_cu * 4;                       // a few rounds of resident workgroups: blocks differ in how long they take
+	if (grid > cap) grid = cap;
+	bgzf_inflate_kernel<<<dim3((unsigned)grid), dim3(kInfWaves * 64), lds, st>>>(comp, reinterpret_cast<const InfBlock *>(blocks), n_blocks, out, status);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess || !check_crc) return e;
+	int64_t cgrid = (n_blocks + 3) / 4;
+	if (cgrid > (int64_t)n_cu * 16) cgrid = (int64_t)n_cu * 16;
+	bgzf_crc_kernel<<<dim3((unsigned)cgrid), dim3(256), 0, st>>>(out, reinterpret_cast<const InfBlock *>(blocks), n_blocks, status);
+	return hipGetLastError();
+}
+
+hipError_t launch_bam_walk(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, uint64_t *entry, uint64_t *exitp, uint32_t *nrec, int64_t n,
+                           uint64_t first, uint32_t *changed, int fix_round, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	WalkArgs a;
+	a.stream = stream; a.stream_len = stream_len; a.bend = reinterpret_cast<const u64 *>(bend); a.entry = reinterpret_cast<u64 *>(entry);
+	a.exitp = reinterpret_cast<u64 *>(exitp); a.nrec = nrec; a.n = n; a.first = first; a.changed = changed;
+	const unsigned grid = (unsigned)((n + 255) / 256);
+	if (fix_round) bam_walk_fix_kernel<<<grid, 256, 0, st>>>(a);
+	else bam_walk_kernel<<<grid, 256, 0, st>>>(a);
+	return hipGetLastError();
+}
+
+hipError_t launch_bam_walk_reduce(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, const uint64_t *entry, int64_t n, int32_t max_frag,
+                                  int want_counters, int want_hist, unsigned long long *out, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	WalkArgs a;
+	a.stream = stream; a.stream_len = stream_len; a.bend = reinterpret_cast<const u64 *>(bend); a.entry = const_cast<u64 *>(reinterpret_cast<const u64 *>(entry));
+	a.exitp = nullptr; a.nrec = nullptr; a.n = n; a.first = 0; a.changed = nullptr;
+	bam_walk_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(a, max_frag, want_counters, want_hist, out);
+	return hipGetLastError();
+}
+
+}  // namespace sk

@@ -140,6 +140,14 @@ hipError_t launch_gc_count(const uint8_t *genome, const int64_t *seg_start, cons
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
                                int64_t n, int min_baseq, uint8_t *out, int n_cu, hipStream_t st);
 
+// ---- BGZF inflate and the BAM record walk on the device (sk_inflate.hip) ----
+// blocks: device array of sk_bgzf_block; status: device u32 per block (0 = inflated; 1..8 the decoder gave up; | 0x100 CRC mismatch)
+hipError_t launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status, int check_crc, int n_cu, hipStream_t st);
+hipError_t launch_bam_walk(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, uint64_t *entry, uint64_t *exitp, uint32_t *nrec, int64_t n,
+                           uint64_t first, uint32_t *changed, int fix_round, hipStream_t st);
+hipError_t launch_bam_walk_reduce(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, const uint64_t *entry, int64_t n, int32_t max_frag,
+                                  int want_counters, int want_hist, unsigned long long *out, hipStream_t st);
+
 // ---- barcode census (sk_census.hip) ----
 struct Census;
 struct CensusEntry {            // == sk_census_entry of include/seqkit_hip.h
@@ -149,7 +157,7 @@ struct CensusEntry {            // == sk_census_entry of include/seqkit_hip.h
 };
 hipError_t census_create(Census **out, hipStream_t st);
 void census_destroy(Census *cs);
-hipError_t census_reset(Census *cs, hipStream_t st);
+hipError_t census_reset(Census *cs, int n_cu, hipStream_t st);
 hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64_t n, const int32_t *assign, int64_t row_base,
                       int n_cu, hipStream_t st);
 hipError_t census_stats(Census *cs, uint64_t out[4], hipStream_t st);
@@ -158,4 +166,14 @@ hipError_t census_count_hist(Census *cs, uint64_t hist[64], int n_cu, hipStream_
 hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint64_t cap, uint64_t *total, int n_cu, hipStream_t st);
 constexpr int kMaxCensusLen = 31;
 
+}  // namespace sk
+
+// ---- what sk_bamfile.cpp needs of a ctx (sk_capi.hip owns the struct) ----
+struct sk_ctx;
+namespace sk {
+hipStream_t ctx_stream(sk_ctx *c);
+hipStream_t ctx_stream2(sk_ctx *c);
+int ctx_n_cu(sk_ctx *c);
+int ctx_bind(sk_ctx *c);                                        // hipSetDevice; SK_OK or an error code with the message set
+int ctx_fail(sk_ctx *c, int code, const char *fmt, ...);       // sets sk_last_error, returns code
 }  // namespace sk

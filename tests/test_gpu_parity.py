@@ -1603,3 +1603,95 @@ def test_errors_are_codes_not_crashes(ctx):
         ctx.demux_assign(np.zeros((4, 5), dtype=np.uint8))            # bc_stride < L
     with pytest.raises(seqkit_amd.SeqkitHipError):
         seqkit_amd.Context(4096)                                      # no such device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["16 x 8", "96 x 8+8", "384 x 8+8", "130 x 12"])
+def test_many_batches_in_one_call_equal_the_single_calls_and_the_oracle(ctx, oracle, shape):
+    """sk_demux_assign_many_dev: ragged batches (empty ones among them), with and without the detail columns of
+    matched rows, spread over the ctx's lanes — every batch's outputs are what its own call gives and what the oracle says
+    (src/fasta_demultiplex.rs:154-194), the counters are the sum over the batches."""
+    from seqkit_amd import capi, synth
+    S = int(shape.split(" x ")[0])
+    dual = "+" in shape
+    L = int(shape.split(" x ")[1].split("+")[0])
+    table = synth.make_sheet(S, L, dual=dual, seed=S + 2)
+    sizes = [70_001, 0, 1, 255, 256, 300_000, 64, 12_345, 1_500_001]
+    bcs = [synth.observe_barcodes(table, max(n, 1), seed=100 + i, halves=2 if dual else 1)[0][:n] for i, n in enumerate(sizes)]
+    ctx.set_barcodes(table, 1)
+    for detail in (False, True):
+        ctx.set_detail_mode(capi.SK_DETAIL_MATCHED if detail else capi.SK_DETAIL_FULL)
+        ctx.counts_reset()
+        ptrs, batches = [], []
+        try:
+            for bc in bcs:
+                n = len(bc)
+                d_bc = ctx.malloc_device(bc.nbytes + 64)
+                outs = [ctx.malloc_device(max(n, 1) * w + 64) for w in ((4, 1, 2, 2) if detail else (4,))]
+                ptrs += [d_bc] + outs
+                if n:
+                    ctx.copy_h2d(d_bc, np.ascontiguousarray(bc))
+                batches.append((d_bc, n, *outs))
+            ctx.sync()
+            ctx.demux_assign_many_dev(batches, bcs[0].shape[1])
+            ctx.sync()
+            total = np.zeros(S + 3, dtype=np.uint64)
+            for bc, b in zip(bcs, batches):
+                n = len(bc)
+                if n == 0:
+                    continue
+                e = oracle.demux_batch(table, bc, 1)
+                total += e[4].astype(np.uint64)
+                got = np.empty(n, dtype=np.int32)
+                ctx.copy_d2h(got, b[2])
+                ctx.sync()
+                assert np.array_equal(got, e[0])
+                if detail:
+                    m = e[0] != -1
+                    for k, (t, col) in enumerate(((np.uint8, 1), (np.int16, 2), (np.int16, 3))):
+                        g = np.empty(n, dtype=t)
+                        ctx.copy_d2h(g, b[3 + k])
+                        ctx.sync()
+                        assert np.array_equal(g[m], e[col][m])
+            assert np.array_equal(ctx.counts(), total)
+        finally:
+            ctx.set_detail_mode(capi.SK_DETAIL_FULL)
+            for p in ptrs:
+                ctx.free_device(p)
+
+
+@pytest.mark.gpu
+def test_trim_many_batches_equal_the_oracle(ctx, oracle):
+    """sk_trim_by_quality_many_dev: batches of cfg 2's classes with and without row lengths (src/fasta_trim_by_quality.rs:28-42)."""
+    from seqkit_amd import synth
+    stride = 150
+    ptrs, batches, expect = [], [], []
+    try:
+        for i, n in enumerate([40_000, 1, 0, 64, 100_001, 777]):
+            _, qual = synth.make_reads(max(n, 1), stride, seed=30 + i)
+            qual = synth.add_forced_classes(qual, seed=40 + i)[:n]
+            ln = None
+            if i % 2:
+                ln = np.random.default_rng(i).integers(0, stride + 1, size=n).astype(np.uint16)
+            d_q, d_k = ctx.malloc_device(qual.nbytes + 64), ctx.malloc_device(2 * max(n, 1) + 64)
+            d_l = ctx.malloc_device(2 * max(n, 1) + 64) if ln is not None else 0
+            ptrs += [p for p in (d_q, d_k, d_l) if p]
+            if n:
+                ctx.copy_h2d(d_q, np.ascontiguousarray(qual))
+                if ln is not None:
+                    ctx.copy_h2d(d_l, ln)
+            batches.append((d_q, d_l, n, d_k))
+            expect.append(oracle.trim_batch(qual, ln, 20) if n else None)
+        ctx.sync()
+        ctx.trim_by_quality_many_dev(batches, stride, 20)
+        ctx.sync()
+        for (d_q, d_l, n, d_k), e in zip(batches, expect):
+            if n == 0:
+                continue
+            got = np.empty(n, dtype=np.uint16)
+            ctx.copy_d2h(got, d_k)
+            ctx.sync()
+            assert np.array_equal(got, e)
+    finally:
+        for p in ptrs:
+            ctx.free_device(p)

@@ -36,12 +36,14 @@ else:
     b_np, _ = synth.observe_barcodes(table, 1_000_000, seed=4, halves=2, **kw[case])
     bc = torch.from_numpy(b_np).to(dev).repeat(reps, 1).contiguous()
     L = 17
-ts = []
+ts, rs = [], []
 for _ in range(reps_run):
-    ctx.census_reset()
     ctx.sync()
+    ctx.timer_start()
+    ctx.census_reset()
+    rs.append(ctx.timer_stop())
     ctx.timer_start()
     ctx.census_add_dev(bc.data_ptr(), bc.shape[1], L, bc.shape[0], 0, 0)
     ts.append(ctx.timer_stop())
 st = ctx.census_stats()
-print(f"{case} n={bc.shape[0]}: " + " ".join(f"{t:.3f}" for t in ts) + f" ms  distinct {st['distinct']} counted {st['counted']}")
+print(f"{case} n={bc.shape[0]}: " + " ".join(f"{t:.3f}" for t in ts) + " ms  reset " + " ".join(f"{t:.3f}" for t in rs) + f" ms  distinct {st['distinct']} counted {st['counted']}")
