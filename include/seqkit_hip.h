@@ -300,8 +300,10 @@ int sk_bam_flag_tlen_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, 
  *
  * sk_bam_walk_dev: stream = the inflated blocks back to back (out above, stream_len bytes, readable 8 bytes beyond),
  * block_end[c] = where block c ends in it (device u64[n], ascending), first_record = where the first record begins
- * (behind the BAM header).  Every block is walked from a guessed entry and the guesses are verified against the
- * predecessors' exits until nothing changes (at most max_rounds rounds).  *verified = 1: entry[c] (device u64[n]) is
+ * (behind the BAM header), n_ref = the header's number of references (or -1: not used by the guesses).  Every block is
+ * walked from a guessed entry — its first byte; for the blocks where that is no record's first byte, the first offset at
+ * which three records in a row look like records — and the guesses are verified against the predecessors' exits until
+ * nothing changes (at most max_rounds rounds).  *verified = 1: entry[c] (device u64[n]) is
  * where the first record that begins in block c begins, for every c — the chain from first_record, proven block by
  * block — and it ends exactly at stream_len; *n_records = records in the stream.  *verified = 0: the stream is not a
  * well-formed sequence of records (or did not settle): the caller's record-at-a-time path reports it as the reference
@@ -326,8 +328,8 @@ typedef struct sk_bgzf_block {
 int sk_bgzf_inflate_dev(sk_ctx *ctx, const uint8_t *comp, const sk_bgzf_block *blocks, int64_t n_blocks, uint8_t *out,
                         uint32_t *status, int check_crc);
 int sk_bam_walk_dev(sk_ctx *ctx, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, int64_t n,
-                    uint64_t first_record, uint64_t *entry, uint64_t *exit_scratch, uint32_t *nrec_scratch, int max_rounds,
-                    int *verified, uint64_t *n_records, int *rounds);
+                    uint64_t first_record, int32_t n_ref, uint64_t *entry, uint64_t *exit_scratch, uint32_t *nrec_scratch,
+                    int max_rounds, int *verified, uint64_t *n_records, int *rounds);
 int sk_bam_walk_reduce_dev(sk_ctx *ctx, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end,
                            const uint64_t *entry, int64_t n, int32_t max_frag, int want_counters, int want_hist, uint64_t *out);
 int sk_bam_file_reduce(sk_ctx *ctx, const char *path, int32_t max_frag, uint64_t counters[3], uint64_t *hist,

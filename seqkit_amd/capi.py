@@ -185,7 +185,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
         "sk_bgzf_inflate_dev": (i32, [vp, vp, vp, i64, vp, vp, i32]),
-        "sk_bam_walk_dev": (i32, [vp, vp, C.c_uint64, vp, i64, C.c_uint64, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(i32)]),
+        "sk_bam_walk_dev": (i32, [vp, vp, C.c_uint64, vp, i64, C.c_uint64, i32, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(i32)]),
         "sk_bam_walk_reduce_dev": (i32, [vp, vp, C.c_uint64, vp, vp, i64, i32, i32, i32, vp]),
         "sk_bam_file_reduce": (i32, [vp, C.c_char_p, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_double)]),
         "sk_bam_fragments": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]),
@@ -297,9 +297,9 @@ class Context:
         self._check(self._lib.sk_bgzf_inflate_dev(self._h, comp, blocks, n_blocks, out, status, 1 if check_crc else 0), "sk_bgzf_inflate_dev")
 
     def bam_walk_dev(self, stream: int, stream_len: int, block_end: int, n: int, first_record: int, entry: int, exit_scratch: int, nrec_scratch: int,
-                     max_rounds: int = 64):
+                     max_rounds: int = 64, n_ref: int = -1):
         ver, nrec, rounds = C.c_int32(0), C.c_uint64(0), C.c_int32(0)
-        self._check(self._lib.sk_bam_walk_dev(self._h, stream, stream_len, block_end, n, first_record, entry, exit_scratch, nrec_scratch, max_rounds,
+        self._check(self._lib.sk_bam_walk_dev(self._h, stream, stream_len, block_end, n, first_record, n_ref, entry, exit_scratch, nrec_scratch, max_rounds,
                                               C.byref(ver), C.byref(nrec), C.byref(rounds)), "sk_bam_walk_dev")
         return bool(ver.value), int(nrec.value), int(rounds.value)
 

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -81,6 +82,13 @@ inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 
 }  // namespace
 
+// not this path's file: say at which check (info[5] = -check) and leave it to the caller's reader
+#define BF_LEAVE(code)                                                                                                  \
+	do {                                                                                                                \
+		if (info) info[5] = -(double)(code);                                                                            \
+		return SK_OK;                                                                                                   \
+	} while (0)
+
 #define BF_HIP(call)                                                                                                    \
 	do {                                                                                                                \
 		hipError_t e_ = (call);                                                                                         \
@@ -98,9 +106,9 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	if (int r = sk::ctx_bind(c)) return r;
 	Cleanup cl;
 	cl.fd = open(path, O_RDONLY);
-	if (cl.fd < 0) return SK_OK;                                        // (the caller's reader says so in the reference's words)
+	if (cl.fd < 0) BF_LEAVE(1);                                        // (the caller's reader says so in the reference's words)
 	struct stat sb;
-	if (fstat(cl.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28) return SK_OK;
+	if (fstat(cl.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28) BF_LEAVE(2);
 	const uint64_t fsize = (uint64_t)sb.st_size;
 	const double t0 = now_ms();
 	hipStream_t st = sk::ctx_stream(c), st2 = sk::ctx_stream2(c);
@@ -117,7 +125,7 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	out_cap = std::min<uint64_t>(out_cap, (uint64_t)(free_b * 0.8));
 	{
 		hipError_t e = hipMalloc((void **)&d_out, out_cap + 64);
-		if (e != hipSuccess) { (void)hipGetLastError(); return SK_OK; }
+		if (e != hipSuccess) { (void)hipGetLastError(); BF_LEAVE(3); }
 	}
 	cl.dev.push_back(d_out);
 
@@ -141,12 +149,26 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	BF_HIP(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
 	cl.events.push_back(ev_batch);
 
-	std::vector<sk_bgzf_block> blocks;
+	// the block table (pinned: its batches are copied while the next ones are written) and its device copy: room for blocks of
+	// 8 KiB on average — a file of smaller ones is not worth this path
+	const size_t tab_cap = (size_t)(fsize / 8192) + 1024;
+	struct BlockTable {
+		sk_bgzf_block *p = nullptr;
+		size_t n = 0;
+		size_t size() const { return n; }
+		sk_bgzf_block *data() const { return p; }
+		sk_bgzf_block &operator[](size_t i) const { return p[i]; }
+	} blocks;
+	{
+		void *p = nullptr;
+		BF_HIP(hipHostMalloc(&p, tab_cap * sizeof(sk_bgzf_block), hipHostMallocDefault));
+		cl.pinned.push_back(p);
+		blocks.p = (sk_bgzf_block *)p;
+	}
 	std::vector<uint64_t> bend;
-	blocks.reserve((size_t)(fsize / 16384) + 16);
-	bend.reserve(blocks.capacity());
-	// device copies of the block table grow with it (capacity: a block is at least 28 bytes, in practice > 4 KiB; start at file / 8 KiB)
-	size_t tab_cap = (size_t)(fsize / 8192) + 1024;
+	bend.reserve(tab_cap);
+	const double t_alloc_pre = now_ms();
+	(void)t_alloc_pre;
 	sk_bgzf_block *d_blocks = nullptr;
 	uint32_t *d_status = nullptr;
 	BF_HIP(hipMalloc((void **)&d_blocks, tab_cap * sizeof(sk_bgzf_block)));
@@ -154,6 +176,9 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	BF_HIP(hipMalloc((void **)&d_status, tab_cap * sizeof(uint32_t)));
 	cl.dev.push_back(d_status);
 
+	const double t_alloc = now_ms();
+	size_t min_batch = 8192;
+	if (const char *ev = getenv("SK_BAMFILE_BATCH")) { const int v = atoi(ev); if (v >= 1) min_batch = (size_t)v; }
 	uint64_t scan = 0, out_off = 0;                                     // the next header's file offset; bytes of the stream so far
 	size_t launched = 0;                                                // blocks handed to the device
 	bool eof_block_last = false;
@@ -164,7 +189,7 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		const size_t c_len = (size_t)std::min<uint64_t>(chunk, fsize - c_off);
 		uint8_t *buf = pin[k % kBufs];
 		if (k >= kBufs) BF_HIP(hipEventSynchronize(ev_copied[k % kBufs]));
-		if (!read_parallel(cl.fd, buf, c_len, c_off, threads)) return SK_OK;
+		if (!read_parallel(cl.fd, buf, c_len, c_off, threads)) BF_LEAVE(4);
 		BF_HIP(hipMemcpyAsync(d_comp + c_off, buf, c_len, hipMemcpyHostToDevice, st2));
 		BF_HIP(hipEventRecord(ev_copied[k % kBufs], st2));
 		// the blocks that are complete with this chunk
@@ -177,22 +202,22 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		const size_t first_new = blocks.size();
 		while (scan + 18 <= have) {
 			const uint8_t *h = bytes(scan, 18);
-			if (!h) return SK_OK;
-			if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return SK_OK;          // not a BGZF block: the caller's reader sorts it out
+			if (!h) BF_LEAVE(5);
+			if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) BF_LEAVE(6);          // not a BGZF block: the caller's reader sorts it out
 			const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
 			if (scan + 12 + xlen > have) break;
 			const uint8_t *x = bytes(scan, 12 + xlen);
-			if (!x) return SK_OK;
+			if (!x) BF_LEAVE(7);
 			size_t bsize = 0;
 			for (size_t o = 12; o + 4 <= 12 + xlen;) {
 				const size_t slen = (size_t)x[o + 2] | ((size_t)x[o + 3] << 8);
 				if (x[o] == 'B' && x[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) { bsize = ((size_t)x[o + 4] | ((size_t)x[o + 5] << 8)) + 1; break; }
 				o += 4 + slen;
 			}
-			if (bsize == 0 || bsize < 12 + xlen + 8) return SK_OK;
+			if (bsize == 0 || bsize < 12 + xlen + 8) BF_LEAVE(8);
 			if (scan + bsize > have) break;                                 // its trailer comes with a later chunk
 			const uint8_t *tr = bytes(scan + bsize - 8, 8);
-			if (!tr) return SK_OK;
+			if (!tr) BF_LEAVE(9);
 			sk_bgzf_block b;
 			b.in_off = scan + 12 + xlen;
 			b.in_len = (uint32_t)(bsize - 12 - xlen - 8);
@@ -200,18 +225,21 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 			b.out_len = le32(tr + 4);
 			b.out_off = out_off;
 			b.reserved = 0;
-			if (b.out_len > 65536u) return SK_OK;                            // (BGZF: at most 64 KiB per block)
+			if (b.out_len > 65536u) BF_LEAVE(10);                            // (BGZF: at most 64 KiB per block)
 			out_off += b.out_len;
-			if (out_off > out_cap) return SK_OK;                             // inflates further than the room taken: the caller's reader streams it
-			blocks.push_back(b);
+			if (out_off > out_cap) BF_LEAVE(11);                             // inflates further than the room taken: the caller's reader streams it
+			if (blocks.n >= tab_cap) BF_LEAVE(12);
+			blocks.p[blocks.n++] = b;
 			bend.push_back(out_off);
 			eof_block_last = b.out_len == 0;
 			scan += bsize;
 		}
-		// this batch: copied on st2, inflated on st behind the copy
-		const size_t n_new = blocks.size() - first_new;
-		if (n_new) {
-			if (blocks.size() > tab_cap) return SK_OK;                       // (blocks of less than 8 KiB on average: not a file worth this path)
+		// a batch of blocks: copied on st2, inflated on st behind the copy.  A launch wants thousands of blocks (a wave per block,
+		// 16 waves per CU: 4 096 in flight): the blocks of several chunks go together
+		(void)first_new;
+		const size_t n_new = blocks.size() - launched;
+		if (n_new && (n_new >= min_batch || k + 1 == n_chunks)) {
+			const size_t first_new = launched;
 			BF_HIP(hipMemcpyAsync(d_blocks + first_new, blocks.data() + first_new, n_new * sizeof(sk_bgzf_block), hipMemcpyHostToDevice, st2));
 			BF_HIP(hipEventRecord(ev_batch, st2));
 			BF_HIP(hipStreamWaitEvent(st, ev_batch, 0));
@@ -219,9 +247,9 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 			launched = blocks.size();
 		}
 	}
-	if (scan != fsize) return SK_OK;                                     // bytes behind the last whole block: a file cut short, or not BGZF to its end
+	if (scan != fsize) BF_LEAVE(13);                                     // bytes behind the last whole block: a file cut short, or not BGZF to its end
 	(void)eof_block_last;                                               // (htslib only warns when the EOF marker is missing; the data are the same)
-	(void)launched;
+	if (launched != blocks.size()) BF_LEAVE(13);
 	const int64_t nb = (int64_t)blocks.size();
 	const uint64_t stream_len = out_off;
 	const double t_read = now_ms();
@@ -229,32 +257,41 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	// ---- blocks the device gave up: zlib here
 	std::vector<uint32_t> status((size_t)nb);
 	BF_HIP(hipMemcpyAsync(status.data(), d_status, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-	BF_HIP(hipStreamSynchronize(st));
+	{	// (a blocking event: the thread sleeps while the device inflates instead of spinning on the stream)
+		hipEvent_t ev_done;
+		BF_HIP(hipEventCreateWithFlags(&ev_done, hipEventBlockingSync | hipEventDisableTiming));
+		cl.events.push_back(ev_done);
+		BF_HIP(hipEventRecord(ev_done, st));
+		BF_HIP(hipEventSynchronize(ev_done));
+	}
+	const double t_inflated = now_ms();
 	uint64_t n_host = 0;
 	{
 		std::vector<uint8_t> cbuf, obuf;
 		for (int64_t i = 0; i < nb; i++) {
 			if (status[(size_t)i] == 0) continue;
 			const sk_bgzf_block &b = blocks[(size_t)i];
+			if (getenv("SK_BAMFILE_TRACE")) fprintf(stderr, "sk_bam_file_reduce: block %lld (in %u bytes at %llu, out %u) has status %#x: zlib\n", (long long)i, b.in_len, (unsigned long long)b.in_off, b.out_len, status[(size_t)i]);
 			cbuf.resize(b.in_len ? b.in_len : 1);
 			obuf.resize(b.out_len ? b.out_len : 1);
-			if (b.in_len && !pread_full(cl.fd, cbuf.data(), b.in_len, b.in_off)) return SK_OK;
+			if (b.in_len && !pread_full(cl.fd, cbuf.data(), b.in_len, b.in_off)) BF_LEAVE(14);
 			z_stream z;
 			memset(&z, 0, sizeof z);
-			if (inflateInit2(&z, -15) != Z_OK) return SK_OK;
+			if (inflateInit2(&z, -15) != Z_OK) BF_LEAVE(15);
 			z.next_in = cbuf.data(); z.avail_in = b.in_len;
 			z.next_out = obuf.data(); z.avail_out = b.out_len;
 			const int zr = inflate(&z, Z_FINISH);
 			const bool ok = zr == Z_STREAM_END && z.total_out == b.out_len;
 			inflateEnd(&z);
-			if (!ok) return SK_OK;                                           // zlib rejects it too: the caller's reader reports it
-			if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), obuf.data(), b.out_len) != b.crc32) return SK_OK;
+			if (!ok) BF_LEAVE(16);                                           // zlib rejects it too: the caller's reader reports it
+			if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), obuf.data(), b.out_len) != b.crc32) BF_LEAVE(17);
 			if (b.out_len) BF_HIP(hipMemcpy(d_out + b.out_off, obuf.data(), b.out_len, hipMemcpyHostToDevice));
 			n_host++;
 		}
 	}
 	// ---- the BAM header: magic, text, references (SAMv1 §4.2) — where the first record begins
 	uint64_t first = 0;
+	int32_t n_ref_hdr = -1;
 	{
 		std::vector<uint8_t> hd;
 		size_t want = (size_t)std::min<uint64_t>(stream_len, (uint64_t)1 << 20);
@@ -270,6 +307,7 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 				o = 8 + (uint64_t)le32(hd.data() + 4);
 				if (!need(o + 4)) break;
 				const uint32_t n_ref = le32(hd.data() + o);
+				n_ref_hdr = n_ref <= 0x7fffffffu ? (int32_t)n_ref : -1;
 				o += 4;
 				for (uint32_t r = 0; r < n_ref && !bad && !more; r++) {
 					if (!need(o + 4)) break;
@@ -279,12 +317,13 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 					if (!need(o)) break;
 				}
 			} while (false);
-			if (bad) return SK_OK;
+			if (bad) BF_LEAVE(18);
 			if (!more) { first = o; break; }
-			if (want >= stream_len) return SK_OK;
+			if (want >= stream_len) BF_LEAVE(19);
 			want = (size_t)std::min<uint64_t>(stream_len, (uint64_t)want * 4);
 		}
 	}
+	const double t_header = now_ms();
 	// ---- the records: walk, verify, reduce
 	uint64_t *d_bend = nullptr, *d_entry = nullptr, *d_exit = nullptr, *d_red = nullptr;
 	uint32_t *d_nrec = nullptr;
@@ -301,8 +340,9 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	uint64_t n_records = 0;
 	int max_rounds = 64;
 	if (const char *ev = getenv("SK_BAMFILE_MAX_ROUNDS")) { const int v = atoi(ev); if (v >= 1) max_rounds = v; }
-	if (int r = sk_bam_walk_dev(c, d_out, stream_len, d_bend, nb, first, d_entry, d_exit, d_nrec, max_rounds, &verified, &n_records, &rounds)) return r;
-	if (!verified) return SK_OK;
+	if (int r = sk_bam_walk_dev(c, d_out, stream_len, d_bend, nb, first, n_ref_hdr, d_entry, d_exit, d_nrec, max_rounds, &verified, &n_records, &rounds)) return r;
+	if (!verified) BF_LEAVE(20);
+	const double t_walk = now_ms();
 	if (int r = sk_bam_walk_reduce_dev(c, d_out, stream_len, d_bend, d_entry, nb, max_frag, counters ? 1 : 0, hist ? 1 : 0, d_red)) return r;
 	std::vector<uint64_t> red(nred);
 	BF_HIP(hipMemcpyAsync(red.data(), d_red, nred * 8, hipMemcpyDeviceToHost, st));
@@ -313,6 +353,9 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		for (size_t i = 0; i <= (size_t)max_frag; i++) hist[i] += red[4 + i];
 	}
 	*handled = 1;
+	if (getenv("SK_BAMFILE_TRACE"))
+		fprintf(stderr, "sk_bam_file_reduce: alloc %.1f ms, read + copy + launches %.1f ms, wait for the inflate %.1f ms, host blocks + header %.1f ms, walk %.1f ms, reduce %.1f ms; %lld blocks, %llu by zlib\n",
+		        t_alloc - t0, t_read - t_alloc, t_inflated - t_read, t_header - t_inflated, t_walk - t_header, now_ms() - t_walk, (long long)nb, (unsigned long long)n_host);
 	if (info) {
 		info[0] = (double)fsize; info[1] = (double)stream_len; info[2] = (double)nb; info[3] = (double)n_records;
 		info[4] = (double)n_host; info[5] = (double)rounds; info[6] = t_read - t0; info[7] = now_ms() - t_read;

@@ -1287,7 +1287,7 @@ int sk_bgzf_inflate_dev(sk_ctx *c, const uint8_t *comp, const sk_bgzf_block *blo
 	return SK_OK;
 }
 
-int sk_bam_walk_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, int64_t n, uint64_t first_record,
+int sk_bam_walk_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len, const uint64_t *block_end, int64_t n, uint64_t first_record, int32_t n_ref,
                     uint64_t *entry, uint64_t *exit_scratch, uint32_t *nrec_scratch, int max_rounds, int *verified, uint64_t *n_records, int *rounds)
 {
 	if (!c || !verified) return SK_ERR_INVALID;
@@ -1299,11 +1299,13 @@ int sk_bam_walk_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len, const
 	if (!stream || !block_end || !entry || !exit_scratch || !nrec_scratch) return fail(c, SK_ERR_INVALID, "NULL stream, block_end, entry or scratch");
 	if (int r = bind(c)) return r;
 	uint32_t *changed = nrec_scratch + n;
-	SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 0, c->stream));
+	SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 0, n_ref, c->stream));
 	int r_done = 1;
 	for (;; r_done++) {
 		SK_HIP(c, hipMemsetAsync(changed, 0, 4, c->stream));
-		SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 1, c->stream));
+		// (the first round behind the walk: blocks whose entry is not their predecessor's exit guess a record start and walk from it)
+		if (r_done == 1) SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 2, n_ref, c->stream));
+		SK_HIP(c, sk::launch_bam_walk(stream, stream_len, block_end, entry, exit_scratch, nrec_scratch, n, first_record, changed, 1, n_ref, c->stream));
 		uint32_t ch = 0;
 		SK_HIP(c, hipMemcpyAsync(&ch, changed, 4, hipMemcpyDeviceToHost, c->stream));
 		SK_HIP(c, hipStreamSynchronize(c->stream));

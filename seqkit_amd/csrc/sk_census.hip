@@ -77,12 +77,11 @@ struct Census {
 	CensusSpill sp;
 	size_t sp_records = 0;       // capacity of key / skey
 	int sp_grid = 0;             // capacity of hist / wg_count in workgroups
-	CensusSlot *tab = nullptr;   // level 2 (sk_census.hip, "the HBM table has TWO levels")
+	CensusSlot *tab = nullptr;
 	u64 slots = 0;           // power of two
-	CensusSlot *tab1 = nullptr;  // level 1
-	int lg1 = 0;             // its slots, log2 (>= kL1GroupLog2)
-	u32 *used2 = nullptr;    // device: a key was claimed in level 2 since the last reset
-	bool used2_host = false; // ... as census_level2_used() last read it
+	u32 *log = nullptr;      // the claim log ("the HBM table and its CLAIM LOG"): kLogRegions regions of log_cap slot indices ...
+	u32 *log_count = nullptr;    // ... and their counters, a 128-byte line each
+	u32 log_cap = 0;
 	u64 *stats = nullptr;    // device u64[kCensusStats]
 	u64 distinct = 0;        // host mirror of stats[0], valid after sync_stats()
 	u64 *scratch = nullptr;  // device: entry compaction output / histogram
@@ -90,8 +89,8 @@ struct Census {
 };
 
 constexpr int kCensusStats = 4;          // [0] distinct keys, [1] rows counted, [2] rows rejected, [3] probe overflows
-constexpr u64 kInitialSlots = 1ull << 26;   // level 2: 2 GiB of the 288: one launch may then take 32 M rows (SK_CENSUS_SLOTS_LOG2 overrides; tests use it)
-constexpr int kL1SlotsLog2 = 22;            // level 1: 128 MiB (SK_CENSUS_L1_LOG2 overrides; a small level 2 — the tests' — gets a level 1 of a sixteenth of it)
+constexpr u64 kInitialSlots = 1ull << 26;   // 2 GiB of the 288: one launch may then take 32 M rows (SK_CENSUS_SLOTS_LOG2 overrides; tests use it)
+constexpr u32 kLogCap = 1u << 16;           // claim-log entries per region: 256 x 65 536 slots = 64 MiB (SK_CENSUS_LOG_CAP_LOG2 overrides; tests shrink it)
 constexpr int64_t kCensusChunk = 1 << 25;   // most rows per launch; the table is grown between launches so that it is never
 constexpr int64_t kCensusMinChunk = 1 << 22;   // more than half full even if every row of the next launch is a new key
 constexpr int kLdsSlots = 2048;
@@ -157,29 +156,47 @@ __device__ __forceinline__ SlotView census_peek(const CensusSlot *s)
 	return sv;
 }
 
-// ---- the HBM table has TWO levels (round 6) ----------------------------------------------------------------------------
-// Level 2 is the table of rounds 2-5: open addressing over 2^26 slots (2 GiB), never more than half full even if every row of a
-// launch is a new key — which no run of the reference's commands comes near (a noisy 32 M-row run has 1.6 M distinct barcodes),
-// and which made every reset a 2 GiB memset (0.32 ms, as long as the census of 32 M rows itself) and every insert a DRAM row miss.
-// Level 1 is a table of 2^22 slots (128 MiB: half the Infinity Cache) in FRONT of it: a key's home slot is the TOP bits of its
-// hash, and it is probed inside the aligned group of 8 slots (256 bytes) the home slot lies in, from the home slot on, wrapping
-// inside the group.  A key goes to level 2 only when its whole group is taken by other keys — slots are never given back, so
-// whoever looks for that key later finds the same eight slots taken and goes on to level 2 as well.  Level 2 keeps a flag
-// "something was claimed here": a reset clears level 1 and, only when the flag is up, level 2 (decided on the device).
-constexpr int kL1GroupLog2 = 3;
-constexpr u32 kL1Group = 1u << kL1GroupLog2;
+// ---- the HBM table and its CLAIM LOG (round 6) ---------------------------------------------------------------------
+// The table is sized for the worst launch — 2^26 slots, 2 GiB, never more than half full even if every one of a launch's 32 M rows
+// is a new key — and no run of the reference's commands comes near that: a noisy 32 M-row run has 1.6 M distinct barcodes.  Through
+// round 5 every reset cleared the 2 GiB (0.32 ms: as long as the census of 32 M rows itself).  Now whoever claims a slot writes its
+// index into a log — the lanes of a wave that win their CAS in the same step append together: ONE atomic on the counter of their
+// workgroup's region of the log, so that the log costs a claim a 4-byte store and the counters are never contended — and a reset
+// clears the logged slots (two 16-byte stores each) and the counters.  A region that overflows (the log holds 16 M slots: a
+// launch of mostly new keys) makes the next reset clear the whole table as before, decided on the device.  (A first form of this
+// round put a small table of 2^22 slots in front of the big one: a key whose 8-slot group was full went on to the big table.  The
+// noisy run put 0.5 % of its keys there — the big table then had to be cleared after all — and a launch of 32 M new keys walked
+// eight slots of the saturated small table before every insert: 18.9 ms where this table takes 2.8.)
+// A key's home slot is the TOP bits of its hash: its bucket (census_bucket, the top 8) is then the 1/256 of the table it lies in
+// whatever the table's size, and the combine pass's LDS table takes the low bits.
+constexpr int kLogRegions = 256;           // regions of the claim log, one per workgroup modulo
 struct CensusTab {
-	CensusSlot *t1;          // level 1: 1 << (32 - sh1) slots
-	u32 sh1;                 // home slot = hash >> sh1
-	CensusSlot *t2;          // level 2
-	u64 mask2;               // home slot = hash & mask2 (the hash's LOW bits: level 1 has the top ones)
-	u32 *used2;              // set when a key is claimed in level 2
+	CensusSlot *tab;
+	u64 mask;                // slots - 1
+	u32 sh;                  // home slot = hash >> sh
+	u32 *log;                // [kLogRegions][log_cap]: slot indices claimed since the last reset
+	u32 *log_count;          // [kLogRegions * 32]: entries of region r at [32 r] (a 128-byte line each); beyond log_cap: the region overflowed
+	u32 log_cap;
 };
+
+// the lanes that are active here have each claimed slot s: they append to their workgroup's region of the log with one atomic
+__device__ __forceinline__ void census_log_claim(const CensusTab &t, const CensusSlot *s)
+{
+	if (t.log_cap == 0u) return;                                        // (SK_CENSUS_LOG_CAP_LOG2=-1: no log, every reset clears the whole table — A/B)
+	const u64 m = __ballot(1);
+	const int leader = __ffsll((unsigned long long)m) - 1;
+	const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+	const u32 region = blockIdx.x & (kLogRegions - 1);
+	u32 base = 0u;
+	if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&t.log_count[region * 32u], (u32)__popcll(m));
+	base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+	if (base + rank < t.log_cap) t.log[(size_t)region * t.log_cap + base + rank] = (u32)(s - t.tab);
+}
 
 // One slot of a probe walk, its two key words (k, v) as fetched at some earlier time (a slot's key never changes once it is
 // published, and an empty or unpublished view is checked again: CAS / reload).  true = the key is in, claimed here or added
 // to; false = the slot is another key's.
-__device__ __forceinline__ bool census_try_slot(CensusSlot *s, u64 k, u64 v, u64 klo, u64 want, u64 cnt, u64 first_inv, u32 &claimed)
+__device__ __forceinline__ bool census_try_slot(const CensusTab &t, CensusSlot *s, u64 k, u64 v, u64 klo, u64 want, u64 cnt, u64 first_inv, u32 &claimed)
 {
 	bool done = false;
 	if (k == 0) {
@@ -200,6 +217,7 @@ __device__ __forceinline__ bool census_try_slot(CensusSlot *s, u64 k, u64 v, u64
 			__builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the workgroup fence alone does not wait for the store
 			__hip_atomic_store(&s->khi_inv, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			claimed++;
+			census_log_claim(t, s);
 		}
 		// The winner's lanes and the loser's meet again HERE, before anybody waits for a publishing store: a lane that lost the slot
 		// to another lane OF ITS OWN WAVE for the same key spins below until that lane has published — which it has, by now.  (The
@@ -225,52 +243,27 @@ __device__ __forceinline__ bool census_try_slot(CensusSlot *s, u64 k, u64 v, u64
 	return done;
 }
 
-// add (cnt, first) for one key to an open-addressing table (level 2; the rehash), starting at slot idx whose contents were
-// fetched before (sv); returns false when the probe budget ran out.
-__device__ __forceinline__ bool census_insert_at(CensusSlot *tab, u64 mask, u64 idx, SlotView sv, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
+// add (cnt, first) for one key, starting at slot idx whose contents were fetched before (sv); returns false when the probe
+// budget ran out
+__device__ __forceinline__ bool census_insert_at(const CensusTab &t, u64 idx, SlotView sv, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
 	const u64 want = ~khi;
 	for (u32 probes = 0; probes < kMaxProbes; probes++) {
-		if (census_try_slot(tab + idx, sv.k, sv.v, klo, want, cnt, first_inv, claimed)) return true;
-		idx = (idx + 1) & mask;
-		sv = census_peek(tab + idx);
+		if (census_try_slot(t, t.tab + idx, sv.k, sv.v, klo, want, cnt, first_inv, claimed)) return true;
+		idx = (idx + 1) & t.mask;
+		sv = census_peek(t.tab + idx);
 	}
 	return false;
 }
 
-// the key's walk from its level-1 home slot on, whose contents were fetched before (home): the group's other seven slots are
-// fetched in two round trips when the home slot is another key's, level 2 is walked when all eight are
+__device__ __forceinline__ u64 census_home_idx(const CensusTab &t, u32 h) { return (u64)(h >> t.sh) & t.mask; }
+__device__ __forceinline__ CensusSlot *census_home(const CensusTab &t, u32 h) { return t.tab + census_home_idx(t, h); }
+
+// the key's walk from its home slot on, whose contents were fetched before (home)
 __device__ __forceinline__ bool census_insert_from(const CensusTab &t, u32 h, SlotView home, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
-	typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-	const u64 want = ~khi;
-	const u32 hs = h >> t.sh1;
-	CensusSlot *const grp = t.t1 + (size_t)(hs & ~(kL1Group - 1u));
-	const u32 o = hs & (kL1Group - 1u);
-	if (census_try_slot(grp + o, home.k, home.v, klo, want, cnt, first_inv, claimed)) return true;
-	// (the other seven: three fetched together, then four — all seven at once cost the combine pass 28 registers it does not have)
-#pragma unroll 1
-	for (u32 j0 = 1; j0 < kL1Group; j0 += (j0 == 1 ? 3u : 4u)) {
-		u32x4_t w[4];
-		const u32 nj = j0 == 1 ? 3u : 4u;
-#pragma unroll
-		for (u32 j = 0; j < 4; j++) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[j]) : "v"(grp + ((o + j0 + (j < nj ? j : 0u)) & (kL1Group - 1u))) : "memory");
-		__builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): the compiler does not know of the loads above
-#pragma unroll
-		for (u32 j = 0; j < 4; j++) {
-			asm volatile("" : "+v"(w[j]));
-			const u64 k = (u64)w[j][0] | ((u64)w[j][1] << 32), v = (u64)w[j][2] | ((u64)w[j][3] << 32);
-			if (j < nj && census_try_slot(grp + ((o + j0 + j) & (kL1Group - 1u)), k, v, klo, want, cnt, first_inv, claimed)) return true;
-		}
-	}
-	const u32 before = claimed;
-	const u64 idx = (u64)h & t.mask2;
-	const bool ok = census_insert_at(t.t2, t.mask2, idx, census_peek(t.t2 + idx), klo, khi, cnt, first_inv, claimed);
-	if (claimed != before) __hip_atomic_store(t.used2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return ok;
+	return census_insert_at(t, census_home_idx(t, h), home, klo, khi, cnt, first_inv, claimed);
 }
-
-__device__ __forceinline__ CensusSlot *census_home(const CensusTab &t, u32 h) { return t.t1 + (size_t)(h >> t.sh1); }
 
 __device__ __forceinline__ bool census_insert(const CensusTab &t, u64 klo, u64 khi, u64 cnt, u64 first_inv, u32 &claimed)
 {
@@ -329,6 +322,7 @@ __device__ __forceinline__ void census_insert_many(const CensusTab &t, const boo
 		if (won[q]) {
 			__hip_atomic_store(&hs[q]->khi_inv, ~khi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			claimed++;
+			census_log_claim(t, hs[q]);
 		}
 		hit[q] = want[q] && !tryc[q] && k[q] == klo[q] && v[q] == ~khi[q];
 		f[q] = ~0ull;
@@ -1103,8 +1097,10 @@ __device__ __forceinline__ void census_add_stats(u64 *stats, u32 claimed, u32 ov
 // workgroup order.  A work item is at most kCombineChunk consecutive records of that sequence — a bucket is split among
 // workgroups, since what they add is additive — and the workgroups take items from a counter until none is left.
 constexpr int kCombineThreads = 512;
-constexpr int kCombineChunk = 16384;
-constexpr int kCombinePasses = 6;         // counts of an item's table before what is left goes to HBM record by record
+#ifndef SK_COMBINE_CHUNK
+#define SK_COMBINE_CHUNK 16384
+#endif
+constexpr int kCombineChunk = SK_COMBINE_CHUNK;
 __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(const CensusArgs a)
 {
 	__shared__ LdsTable lt_s;
@@ -1176,12 +1172,12 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 		const u32 hi = min(gpre[grid], lo + kCombineChunk);
 		// record i of the bucket's sequence lies in the region of the workgroup g with gpre[g] <= i < gpre[g + 1]: found once by
 		// bisection, then g only moves forward (a thread's records are blockDim apart)
-		u32 gfirst = 0u;
+		u32 gcur = 0u;
 		{
 			const u32 i = lo + tid;
 			u32 l = 0u, r = grid;                                      // the last g with gpre[g] <= i
 			while (r - l > 1u) { const u32 m = (l + r) >> 1; if (gpre[m] <= i) l = m; else r = m; }
-			gfirst = l;
+			gcur = l;
 		}
 		SK_CSTAMP(2);                                                  // the bucket's regions scanned, the thread's first record found
 		const uint4 *const base = a.sp.key + (size_t)b * a.sp.cap;
@@ -1189,95 +1185,65 @@ __global__ __launch_bounds__(kCombineThreads, 4) void census_combine_kernel(cons
 		// (four records of a thread are counted while its next four are on their way: with one load per trip the loop was a
 		// chain of memory latencies — 32 of them for a full item —, with four loads per trip still one per trip)
 		constexpr int kAhead = 4;
-		static_assert(kCombineChunk / kCombineThreads <= 32, "a thread's records of an item are the bits of one word");
-		// PASSES (round 6).  The table holds the distinct keys of an item as long as there are fewer than its slots: an item of
-		// independently drawn noisy rows has 3 500 in 16 384 records, and every record whose key found no place within kLdsProbes
-		// slots went to HBM by itself — 4 M atomics where the launch has 1.6 M distinct keys, 0.47 ms of combine pass against 0.10
-		// when the same million rows repeat (profiles/r06_census_indep_attribution.txt).  A key that finds no place NEVER finds one
-		// (slots are not given back), so all its records fail alike: they are remembered (one bit per record of the thread), the
-		// table goes to HBM — one insert per distinct key —, is cleared, and the next pass counts the records that are left (read
-		// again from L2, where the item's 256 KiB still lie).  What is left after the last pass goes to HBM record by record.
-		u32 todo = 0xffffffffu;                                        // bit 4 * trip + q: the thread's record lo + tid + (4 * trip + q) * blockDim is still to be counted
-		for (int pass = 0; pass < kCombinePasses; pass++) {
-			const bool last_pass = pass == kCombinePasses - 1;
-			u32 gcur = gfirst, left = 0u;
-			uint4 kk[kAhead], kn[kAhead];
-			auto fetch = [&](u32 i0, u32 trip, uint4 (&dst)[kAhead]) {
+		uint4 kk[kAhead], kn[kAhead];
+		auto fetch = [&](u32 i0, uint4 (&dst)[kAhead]) {
 #pragma unroll
-				for (int q = 0; q < kAhead; q++) {
-					const u32 i = i0 + (u32)q * blockDim.x;
-					dst[q] = make_uint4(0u, 0u, 0u, 0u);
-					if (i < hi) {
-						while (gpre[gcur + 1] <= i) gcur++;
-						if ((todo >> ((trip * kAhead + (u32)q) & 31u)) & 1u) dst[q] = base[(size_t)gcur * gpitch + (i - gpre[gcur])];
-					}
-				}
-			};
-			fetch(lo + tid, 0u, kk);
-			u32 trip = 0u;
-			for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x, trip++) {
-				fetch(i0 + kAhead * blockDim.x, trip + 1u, kn);
-				bool dir[kAhead], have[kAhead];
-				u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
-				u32 cnt[kAhead], hh[kAhead];
-#pragma unroll
-				for (int q = 0; q < kAhead; q++) {
-					const uint4 k = kk[q];
-					have[q] = i0 + (u32)q * blockDim.x < hi && ((todo >> ((trip * kAhead + (u32)q) & 31u)) & 1u) != 0u;
-					klo[q] = 0xF0000000ull | ((u64)k.x << 32);
-					khi[q] = (u64)k.y | ((u64)k.z << 32);
-					first_inv[q] = ~(u64)(a.row_base + census_rec_row(k.w));
-					cnt[q] = census_rec_count(k.w);
-					hh[q] = census_hash(klo[q], khi[q]);                     // (the table takes the hash's LOW bits: its high bits are the bucket's, the same for every key here)
-				}
-				SK_CSTAMP(3);                                              // next records asked for, keys and hashes
-				lds_count_many<kAhead>(lt, have, hh, klo, khi, cnt, first_inv, dir);
-				SK_CSTAMP(4);                                              // counted in the table
-#pragma unroll
-				for (int q = 0; q < kAhead; q++) left |= (dir[q] ? 1u : 0u) << ((trip * kAhead + (u32)q) & 31u);
-				SK_CSTAMP(5);
-#pragma unroll
-				for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
+			for (int q = 0; q < kAhead; q++) {
+				const u32 i = i0 + (u32)q * blockDim.x;
+				if (i < hi) {
+					while (gpre[gcur + 1] <= i) gcur++;
+					dst[q] = base[(size_t)gcur * gpitch + (i - gpre[gcur])];
+				} else dst[q] = make_uint4(0u, 0u, 0u, 0u);
 			}
-			const int more = __syncthreads_or(!last_pass && left != 0u);
-			SK_CSTAMP(6);                                                  // barrier behind the records
-			// the occupied slots go to a list, and the list to HBM four keys of a thread at a time
-			if (tid == 0) nlist = 0u;
-			__syncthreads();
-			for (int i = tid; i < kLdsSlots; i += blockDim.x)
-				if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
-			__syncthreads();
-			for (u32 j0 = tid; j0 < nlist; j0 += kAhead * blockDim.x) {
-				bool want[kAhead];
-				u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
-				u32 cnt[kAhead];
+		};
+		fetch(lo + tid, kk);
+		for (u32 i0 = lo + tid; i0 < hi; i0 += kAhead * blockDim.x) {
+			fetch(i0 + kAhead * blockDim.x, kn);
+			// (a key the table has no room for goes to HBM with the others of the thread's four records)
+			bool dir[kAhead], have[kAhead];
+			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+			u32 cnt[kAhead], hh[kAhead];
 #pragma unroll
-				for (int q = 0; q < kAhead; q++) {
-					const u32 j = j0 + (u32)q * blockDim.x;
-					want[q] = j < nlist;
-					const int i = list[want[q] ? j : 0u];
-					klo[q] = lt->klo[i]; khi[q] = ~lt->khi_inv[i]; first_inv[q] = lt->first_inv[i]; cnt[q] = lt->count[i];
-				}
-				census_insert_many<kAhead>(a.t, want, klo, khi, cnt, first_inv, claimed, overflow);
+			for (int q = 0; q < kAhead; q++) {
+				const uint4 k = kk[q];
+				have[q] = i0 + (u32)q * blockDim.x < hi;
+				klo[q] = 0xF0000000ull | ((u64)k.x << 32);
+				khi[q] = (u64)k.y | ((u64)k.z << 32);
+				first_inv[q] = ~(u64)(a.row_base + census_rec_row(k.w));
+				cnt[q] = census_rec_count(k.w);
+				hh[q] = census_hash(klo[q], khi[q]);                     // (the table takes the hash's LOW bits: its high bits are the bucket's, the same for every key here)
 			}
-			if (last_pass) {
-				// what is still left (an item of more distinct keys than kCombinePasses tables hold: launches of mostly new keys take
-				// census_direct_kernel instead) goes to HBM record by record
-				for (u32 m = left; m != 0u; m &= m - 1u) {
-					const u32 i = lo + tid + (u32)__builtin_ctz(m) * blockDim.x;
-					u32 l = 0u, r = grid;
-					while (r - l > 1u) { const u32 mid = (l + r) >> 1; if (gpre[mid] <= i) l = mid; else r = mid; }
-					const uint4 k = base[(size_t)l * gpitch + (i - gpre[l])];
-					const u64 klo = 0xF0000000ull | ((u64)k.x << 32), khi = (u64)k.y | ((u64)k.z << 32);
-					const u32 c = census_rec_count(k.w);
-					if (!census_insert(a.t, klo, khi, (u64)c, ~(u64)(a.row_base + census_rec_row(k.w)), claimed)) overflow += c;
-				}
+			SK_CSTAMP(3);                                              // next records asked for, keys and hashes
+			lds_count_many<kAhead>(lt, have, hh, klo, khi, cnt, first_inv, dir);
+			SK_CSTAMP(4);                                              // counted in the table
+			bool any_dir = false;
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) any_dir = any_dir || dir[q];
+			if (__any(any_dir)) census_insert_many<kAhead>(a.t, dir, klo, khi, cnt, first_inv, claimed, overflow);      // (rare: its wait is for the next records' loads too)
+			SK_CSTAMP(5);                                              // keys without a place: to HBM
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) kk[q] = kn[q];
+		}
+		__syncthreads();
+		SK_CSTAMP(6);                                                  // barrier behind the records
+		// the occupied slots go to a list, and the list to HBM four keys of a thread at a time
+		if (tid == 0) nlist = 0u;
+		__syncthreads();
+		for (int i = tid; i < kLdsSlots; i += blockDim.x)
+			if (lt->klo[i] != 0) list[atomicAdd(&nlist, 1u)] = (uint16_t)i;
+		__syncthreads();
+		for (u32 j0 = tid; j0 < nlist; j0 += kAhead * blockDim.x) {
+			bool want[kAhead];
+			u64 klo[kAhead], khi[kAhead], first_inv[kAhead];
+			u32 cnt[kAhead];
+#pragma unroll
+			for (int q = 0; q < kAhead; q++) {
+				const u32 j = j0 + (u32)q * blockDim.x;
+				want[q] = j < nlist;
+				const int i = list[want[q] ? j : 0u];
+				klo[q] = lt->klo[i]; khi[q] = ~lt->khi_inv[i]; first_inv[q] = lt->first_inv[i]; cnt[q] = lt->count[i];
 			}
-			if (!more) break;
-			todo = left;
-			__syncthreads();                                               // everybody has read its slots: the table is cleared for the next pass
-			for (int i = tid; i < (int)(sizeof(LdsTable) / 8); i += blockDim.x) reinterpret_cast<u64 *>(lt)[i] = 0ull;
-			__syncthreads();
+			census_insert_many<kAhead>(a.t, want, klo, khi, cnt, first_inv, claimed, overflow);
 		}
 		SK_CSTAMP(7);                                                  // occupied slots listed and inserted
 	}
@@ -1339,15 +1305,14 @@ __global__ __launch_bounds__(kDirectThreads) void census_direct_kernel(const Cen
 	census_add_stats(a.stats, claimed, overflow, red);
 }
 
-// grow (level 2): re-insert every slot of the old table into the new one.  (A key of level 2 stays one: its level-1 group is full.)
-__global__ __launch_bounds__(256) void census_rehash_kernel(const CensusSlot *old_tab, u64 old_slots, CensusSlot *tab, u64 mask, u64 *stats)
+// grow: re-insert every slot of the old table into the new one (the claim log is started again for the new table)
+__global__ __launch_bounds__(256) void census_rehash_kernel(const CensusSlot *old_tab, u64 old_slots, const CensusTab t, u64 *stats)
 {
 	u32 claimed = 0, overflow = 0;
 	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += (u64)gridDim.x * blockDim.x) {
 		const CensusSlot s = old_tab[i];
 		if (s.klo == 0) continue;
-		const u64 idx = (u64)census_hash(s.klo, ~s.khi_inv) & mask;
-		if (!census_insert_at(tab, mask, idx, census_peek(tab + idx), s.klo, ~s.khi_inv, s.count, s.first_inv, claimed)) overflow++;
+		if (!census_insert(t, s.klo, ~s.khi_inv, s.count, s.first_inv, claimed)) overflow++;
 	}
 	if (overflow) atomicAdd(&stats[3], (u64)overflow);
 }
@@ -1417,16 +1382,11 @@ hipError_t census_create(Census **out, hipStream_t st)
 		if (lg >= 10 && lg <= 32) init_slots = 1ull << lg;
 	}
 	if (e == hipSuccess) e = census_alloc_table(cs, init_slots, st);
-	{
-		int lg2 = 0;
-		while ((1ull << lg2) < init_slots) lg2++;
-		cs->lg1 = std::max(kL1GroupLog2, std::min(kL1SlotsLog2, lg2 - 4));
-		if (const char *ev = getenv("SK_CENSUS_L1_LOG2")) { const int lg = atoi(ev); if (lg >= kL1GroupLog2 && lg <= 26) cs->lg1 = lg; }
-	}
-	if (e == hipSuccess) e = hipMalloc((void **)&cs->tab1, ((size_t)1 << cs->lg1) * sizeof(CensusSlot));
-	if (e == hipSuccess) e = hipMemsetAsync(cs->tab1, 0, ((size_t)1 << cs->lg1) * sizeof(CensusSlot), st);
-	if (e == hipSuccess) e = hipMalloc((void **)&cs->used2, sizeof(u32));
-	if (e == hipSuccess) e = hipMemsetAsync(cs->used2, 0, sizeof(u32), st);
+	cs->log_cap = kLogCap;
+	if (const char *ev = getenv("SK_CENSUS_LOG_CAP_LOG2")) { const int lg = atoi(ev); if (lg >= 0 && lg <= 20) cs->log_cap = 1u << lg; else if (lg == -1) cs->log_cap = 0u; }
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->log, (size_t)kLogRegions * std::max(cs->log_cap, 1u) * sizeof(u32));
+	if (e == hipSuccess) e = hipMalloc((void **)&cs->log_count, (size_t)kLogRegions * 32 * sizeof(u32));
+	if (e == hipSuccess) e = hipMemsetAsync(cs->log_count, 0, (size_t)kLogRegions * 32 * sizeof(u32), st);
 	for (int v = 0; v < kCensusVariants; v++)
 		if (e == hipSuccess) e = hipFuncSetAttribute(census_variant(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	if (e != hipSuccess) { census_destroy(cs); return e; }
@@ -1438,33 +1398,67 @@ void census_destroy(Census *cs)
 {
 	if (!cs) return;
 	if (cs->tab) (void)hipFree(cs->tab);
-	if (cs->tab1) (void)hipFree(cs->tab1);
-	if (cs->used2) (void)hipFree(cs->used2);
+	if (cs->log) (void)hipFree(cs->log);
+	if (cs->log_count) (void)hipFree(cs->log_count);
 	if (cs->stats) (void)hipFree(cs->stats);
 	if (cs->scratch) (void)hipFree(cs->scratch);
 	census_spill_free(cs);
 	delete cs;
 }
 
-// level 2 is cleared only when something was claimed there since the last reset — decided here, on the device: no run of the
-// reference's commands gets there (2 GiB of stores, 0.32 ms: as long as a census of 32 M rows)
-__global__ __launch_bounds__(256) void census_clear2_kernel(CensusSlot *tab, u64 slots, const u32 *used2)
+static CensusTab census_tab_of(const Census *cs)
 {
-	if (__hip_atomic_load(used2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-	uint4 *p = reinterpret_cast<uint4 *>(tab);
-	const u64 n = slots * (sizeof(CensusSlot) / 16);
-	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+	CensusTab t;
+	t.tab = cs->tab;
+	t.mask = cs->slots - 1;
+	int lg = 0;
+	while ((1ull << lg) < cs->slots) lg++;
+	t.sh = (u32)(32 - lg);
+	t.log = cs->log;
+	t.log_count = cs->log_count;
+	t.log_cap = cs->log_cap;
+	return t;
+}
+
+// Empty the table: the slots the claim log names — or, when a region of the log overflowed, all of them (decided here, on the
+// device: every workgroup reads the 256 counters) — then the counters (by the kernel behind this one on the stream).
+__global__ __launch_bounds__(256) void census_clear_kernel(const CensusTab t)
+{
+	__shared__ u32 cnt[kLogRegions];
+	__shared__ u32 over;
+	if (threadIdx.x == 0) over = 0u;
+	__syncthreads();
+	for (int r = threadIdx.x; r < kLogRegions; r += blockDim.x) {
+		const u32 c = t.log_count[r * 32];
+		cnt[r] = c < t.log_cap ? c : t.log_cap;
+		if (c > t.log_cap || t.log_cap == 0u) over = 1u;
+	}
+	__syncthreads();
+	uint4 *const p = reinterpret_cast<uint4 *>(t.tab);
+	if (over) {
+		const u64 n = (t.mask + 1) * (sizeof(CensusSlot) / 16);
+		for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+		return;
+	}
+	// region r's entries are cleared by the workgroups r, r + 256, ... : a thread per entry
+	const int r = blockIdx.x & (kLogRegions - 1);
+	const u32 per = gridDim.x / kLogRegions ? gridDim.x / kLogRegions : 1u, part = blockIdx.x / kLogRegions;
+	for (u32 i = part * blockDim.x + threadIdx.x; i < cnt[r]; i += per * blockDim.x) {
+		const u64 slot = t.log[(size_t)r * t.log_cap + i];
+		p[2 * slot] = make_uint4(0u, 0u, 0u, 0u);
+		p[2 * slot + 1] = make_uint4(0u, 0u, 0u, 0u);
+	}
 }
 
 hipError_t census_reset(Census *cs, int n_cu, hipStream_t st)
 {
 	hipError_t e = hipMemsetAsync(cs->stats, 0, kCensusStats * sizeof(u64), st);
-	if (e == hipSuccess) e = hipMemsetAsync(cs->tab1, 0, ((size_t)1 << cs->lg1) * sizeof(CensusSlot), st);
 	if (e == hipSuccess) {
-		census_clear2_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->used2);
+		census_clear_kernel<<<kLogRegions * 8, 256, 0, st>>>(census_tab_of(cs));
 		e = hipGetLastError();
 	}
-	if (e == hipSuccess) e = hipMemsetAsync(cs->used2, 0, sizeof(u32), st);
+	if (e == hipSuccess) e = hipMemsetAsync(cs->log_count, 0, (size_t)kLogRegions * 32 * sizeof(u32), st);
+	(void)n_cu;
 	cs->distinct = 0;
 	return e;
 }
@@ -1494,7 +1488,9 @@ static hipError_t census_reserve(Census *cs, u64 incoming, int n_cu, hipStream_t
 	const u64 old_slots = cs->slots;
 	hipError_t e = census_alloc_table(cs, slots, st);
 	if (e != hipSuccess) { (void)hipGetLastError(); cs->tab = old_tab; cs->slots = old_slots; return e; }
-	census_rehash_kernel<<<n_cu * 8, 256, 0, st>>>(old_tab, old_slots, cs->tab, slots - 1, cs->stats);
+	e = hipMemsetAsync(cs->log_count, 0, (size_t)kLogRegions * 32 * sizeof(u32), st);      // the log names slots of the table that goes
+	if (e != hipSuccess) return e;
+	census_rehash_kernel<<<n_cu * 8, 256, 0, st>>>(old_tab, old_slots, census_tab_of(cs), cs->stats);
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	(void)hipFree(old_tab);
@@ -1598,7 +1594,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		// (at least kCensusMinChunk rows: launches have a fixed cost) or grow the table.
 		nr = (n - o) < chunk ? (n - o) : chunk;
 		hipError_t e = hipSuccess;
-		if (2 * (cs->distinct + (u64)nr) > cs->slots) {
+		if (2 * (cs->distinct + (u64)nr) > cs->slots && !getenv("SK_CENSUS_TRUST_SLOTS")) {      // (the env: experiments with a table that is known to be large enough)
 			uint64_t s[4];
 			e = census_stats(cs, s, st);
 			if (e != hipSuccess) return e;
@@ -1617,11 +1613,7 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 		a.n = nr;
 		a.assign = assign ? assign + o : nullptr;
 		a.row_base = row_base + o;
-		a.t.t1 = cs->tab1;
-		a.t.sh1 = (u32)(32 - cs->lg1);
-		a.t.t2 = cs->tab;
-		a.t.mask2 = cs->slots - 1;
-		a.t.used2 = cs->used2;
+		a.t = census_tab_of(cs);
 		a.stats = cs->stats;
 		a.long_way_only = getenv("SK_CENSUS_LONG_WAY_ONLY") && atoi(getenv("SK_CENSUS_LONG_WAY_ONLY")) != 0;
 		bool spill = L <= kSpillMaxLen && (spill_mode < 0 ? nr >= spill_min_rows : spill_mode != 0);
@@ -1667,16 +1659,6 @@ hipError_t census_add(Census *cs, const uint8_t *bc, int bc_stride, int L, int64
 	return hipSuccess;
 }
 
-// has level 2 taken a key since the last reset?  (cs->used2_host; synchronises the stream)
-static hipError_t census_level2_used(Census *cs, hipStream_t st)
-{
-	u32 v = 0;
-	hipError_t e = hipMemcpyAsync(&v, cs->used2, sizeof v, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	cs->used2_host = v != 0u;
-	return e;
-}
-
 static hipError_t census_scratch(Census *cs, size_t bytes)
 {
 	if (bytes <= cs->scratch_bytes) return hipSuccess;
@@ -1691,10 +1673,8 @@ hipError_t census_count_hist(Census *cs, uint64_t hist[64], int n_cu, hipStream_
 	hipError_t e = census_scratch(cs, 64 * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 64 * sizeof(u64), st);
 	if (e != hipSuccess) return e;
-	census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab1, 1ull << cs->lg1, cs->scratch);
-	e = census_level2_used(cs, st);                                    // (waits for the stream: level 2 is walked only when it holds something)
-	if (e == hipSuccess && cs->used2_host) census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->scratch);
-	if (e == hipSuccess) e = hipGetLastError();
+	census_hist_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, cs->scratch);
+	e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(hist, cs->scratch, 64 * sizeof(u64), hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	return e;
@@ -1710,10 +1690,8 @@ hipError_t census_entries(Census *cs, uint64_t min_count, CensusEntry *out, uint
 	e = census_scratch(cs, (4 + room * 4) * sizeof(u64));
 	if (e == hipSuccess) e = hipMemsetAsync(cs->scratch, 0, 4 * sizeof(u64), st);
 	if (e != hipSuccess) return e;
-	census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab1, 1ull << cs->lg1, min_count ? min_count : 1, cs->scratch, room);
-	e = census_level2_used(cs, st);
-	if (e == hipSuccess && cs->used2_host) census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, min_count ? min_count : 1, cs->scratch, room);
-	if (e == hipSuccess) e = hipGetLastError();
+	census_compact_kernel<<<n_cu * 8, 256, 0, st>>>(cs->tab, cs->slots, min_count ? min_count : 1, cs->scratch, room);
+	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	u64 found = 0;
 	e = hipMemcpyAsync(&found, cs->scratch, sizeof found, hipMemcpyDeviceToHost, st);

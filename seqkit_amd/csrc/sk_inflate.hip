@@ -20,7 +20,7 @@
 //     ds_read per symbol; longer codes (rare by construction) are walked bit by bit against the canonical code's
 //     first-code / count arrays.  A block's tables are built by the whole wave: ranks of the symbols within their code
 //     length by ballots, then every lane resolves the table indices it owns by the canonical rule.
-//   * output: the wave keeps the last 4-8 KiB it produced in an LDS ring addressed by the OUTPUT address (mod the ring),
+//   * output: the wave keeps the last 1-2 KiB it produced in an LDS ring addressed by the OUTPUT address (mod the ring),
 //     so that a half of the ring is a 16-byte-aligned piece of the output: literals are one ds_write_b8, a match is
 //     ds_read_u8 / ds_write_b8 across the lanes (any overlap: lane k reads byte k mod dist of the source), and whenever the
 //     output crosses a half's boundary that half leaves for HBM as coalesced 16-byte stores.  A match that reaches back
@@ -57,7 +57,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kInfWaves = 4;             // waves per workgroup; each inflates blocks of its own, no barrier anywhere
 constexpr int kInfLitBits = 10, kInfDistBits = 8, kInfPreBits = 7;
 #ifndef SK_INF_RING
-#define SK_INF_RING 8192
+#define SK_INF_RING 2048
 #endif
 constexpr u32 kRing = SK_INF_RING, kHalf = kRing / 2;
 static_assert((kRing & (kRing - 1)) == 0 && kHalf >= 1024, "ring: a power of two, a half holds a longest match");
@@ -261,15 +261,15 @@ __device__ __forceinline__ u32 inf_long_code(const InfLds &L, u64 bb)
 	return inf_entry(kKindBad, 1u, 0u, 0u);
 }
 
-// out[lo, hi) (positions within the block) leaves the ring for HBM.  a0 = the block's first output address modulo 2^32.
-__device__ __forceinline__ void inf_flush(const InfLds &L, uint8_t *out, u64 out_off, u32 a0, u32 lo, u32 hi, int lane)
+// dst[lo, hi) (dst = where the block's output begins; positions within the block) leaves the ring for HBM.  a0 = the block's first
+// output address modulo 2^32.
+__device__ __forceinline__ void inf_flush(const InfLds &L, uint8_t *dst, u32 a0, u32 lo, u32 hi, int lane)
 {
 	if (hi <= lo) return;
 	inf_lds_fence();
 	const u32 alo = a0 + lo, ahi = a0 + hi;                            // output addresses (mod 2^32: only their low bits are used, and differences)
 	u32 body_lo = (alo + 15u) & ~15u, body_hi = ahi & ~15u;
 	if (body_hi < body_lo) { body_lo = ahi; body_hi = ahi; }           // no aligned 16 bytes inside: all head
-	uint8_t *const dst = out + out_off - (u64)0;                        // out + out_off + p  ==  position p of the block
 	// head and tail: byte by byte (at most 15 + 15)
 	const u32 nhead = body_lo - alo, ntail = ahi - body_hi;
 	if ((u32)lane < nhead) dst[lo + (u32)lane] = L.ring[(alo + (u32)lane) & (kRing - 1u)];
@@ -280,11 +280,82 @@ __device__ __forceinline__ void inf_flush(const InfLds &L, uint8_t *out, u64 out
 	}
 }
 
+extern __shared__ __attribute__((aligned(16))) uint8_t inf_smem[];      // kInfWaves x InfLds
+
+// The symbols of one DEFLATE block: the decoder's inner loop, kept out of line.  Inlined into inf_block it shared the scalar
+// registers with everything that function keeps alive across it (the block table, the header's fields, three table builders):
+// the allocator kept the bit buffer's count, the window index and the output position in lanes of a spill VGPR and moved them
+// in and out with v_readlane / v_writelane on every symbol (a 64 KiB block of literals took 1 300 cycles per symbol).  Arguments
+// of a device function arrive in vector registers: the state is made scalar again on entry (it is wave-uniform by construction).
+struct InfRun { InfBits b; u32 op, flushed, err; };
+__device__ __forceinline__ u64 inf_uniform64(u64 v) { return (u64)inf_uniform((u32)v) | ((u64)inf_uniform((u32)(v >> 32)) << 32); }
+__device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, const uint8_t *in_base, u32 in_range, u32 a0, u32 out_len, uint8_t *dst, int lane)
+{
+	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[inf_uniform((u32)wave)];      // (by index: a pointer argument would arrive as a generic address, and every table read as a flat load)
+	InfBits b = r.b;
+	b.bb = inf_uniform64(b.bb); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
+	in_base = reinterpret_cast<const uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)in_base));
+	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(in_base), 0, (int)inf_uniform(in_range), 0x00020000);      // (the descriptor, made again from scalars)
+	u32 op = inf_uniform(r.op), flushed = inf_uniform(r.flushed), err = 0u;
+	a0 = inf_uniform(a0); out_len = inf_uniform(out_len);
+	dst = reinterpret_cast<uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)dst));
+	for (;;) {
+		inf_refill(b, lane);
+		u32 e = inf_uniform(L.lit[(u32)b.bb & ((1u << kInfLitBits) - 1u)]);
+		if (((e >> 8) & 7u) == kKindLong) e = inf_long_code<0, kInfLitBits>(L, b.bb);
+		const u32 kind = (e >> 8) & 7u;
+		inf_take(b, e & 15u);
+		if (kind == kKindLiteral) {
+			if (op >= out_len) { err = 6u; break; }
+			if (lane == 0) L.ring[(a0 + op) & (kRing - 1u)] = (uint8_t)(e >> 16);
+			op++;
+			if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, dst, a0, flushed, op, lane); flushed = op; }
+			continue;
+		}
+		if (kind == kKindEob) break;
+		if (kind != kKindBase) { err = 4u; break; }
+		const u32 len = (e >> 16) + inf_take(b, (e >> 4) & 15u);
+		inf_refill(b, lane);
+		u32 d = inf_uniform(L.dist[(u32)b.bb & ((1u << kInfDistBits) - 1u)]);
+		if (((d >> 8) & 7u) == kKindLong) d = inf_long_code<1, kInfDistBits>(L, b.bb);
+		if (((d >> 8) & 7u) != kKindBase) { err = 4u; break; }
+		inf_take(b, d & 15u);
+		const u32 dist = (d >> 16) + inf_take(b, (d >> 4) & 15u);
+		if (dist > op) { err = 5u; break; }
+		if (len > out_len - op) { err = 6u; break; }
+		// the copy, cut where the output crosses a half of the ring
+		const u32 m0 = op;                                             // where the match begins
+		for (u32 done = 0u; done < len;) {
+			const u32 room = kHalf - ((a0 + op) & (kHalf - 1u));
+			const u32 seg = min(len - done, room);
+			// what the ring holds: this half and the one before it (and nothing before the block's first byte)
+			const u32 half_base = (a0 + op) & ~(kHalf - 1u);
+			const u32 floor_addr = half_base - kHalf;
+			inf_lds_fence();
+			for (u32 k = (u32)lane; k < seg; k += 64u) {
+				const u32 j = done + k;                                   // byte j of the match
+				const u32 sj = dist >= len ? j : j % dist;               // (an overlapping match repeats its first dist bytes)
+				const u32 sp = m0 - dist + sj;                            // source position within the block
+				const u32 sa = a0 + sp;
+				uint8_t v;
+				// in the ring <=> its address is at or above the floor; addresses wrap at 2^32, differences do not (a block is 64 KiB)
+				if ((int)(sa - floor_addr) >= 0) v = L.ring[sa & (kRing - 1u)];
+				else v = __hip_atomic_load(dst + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // flushed long ago: from L2, past the vector cache
+				L.ring[(a0 + op + k) & (kRing - 1u)] = v;
+			}
+			op += seg; done += seg;
+			if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, dst, a0, flushed, op, lane); flushed = op; }
+		}
+	}
+	r.b = b; r.op = op; r.flushed = flushed; r.err = err;
+	return r;
+}
+
 struct InfBlock { u64 in_off; u32 in_len, out_len; u64 out_off; u32 crc, pad; };
 static_assert(sizeof(InfBlock) == 32, "== sk_bgzf_block");
 
 // One block.  Returns its status (0 = inflated, out_len bytes written).
-__device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const InfBlock &blk, uint8_t *out, int lane)
+__device__ __forceinline__ u32 inf_block(InfLds &L, int wave, const uint8_t *comp, const InfBlock &blk, uint8_t *out, int lane)
 {
 	InfBits b;
 	const u64 in4 = blk.in_off & ~3ull;
@@ -292,7 +363,10 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const I
 	const u32 range = (head + blk.in_len + 3u) & ~3u;
 	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(comp + in4), 0, (int)range, 0x00020000);
 	inf_seek(b, head, lane);
-	const u32 a0 = (u32)blk.out_off;
+	// the block's first output address, modulo 2^20: what is used of it are its low bits (the ring's index, the halves' and the
+	// 16-byte boundaries) and differences inside the block's 64 KiB — which must not wrap (a block that straddled 2^32 in the
+	// inflated stream of a 3.6 GB file came out with its flushes cut short: its CRC told, zlib did it again)
+	const u32 a0 = (u32)blk.out_off & 0xFFFFFu;
 	const u32 out_len = blk.out_len;
 	u32 op = 0u, flushed = 0u;
 	u32 err = 0u;
@@ -315,7 +389,7 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const I
 				const u32 seg = min(len - done, room);
 				for (u32 k = (u32)lane; k < seg; k += 64u) L.ring[(a0 + op + k) & (kRing - 1u)] = comp[in4 + src0 + done + k];
 				op += seg; done += seg;
-				if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
+				if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out + blk.out_off, a0, flushed, op, lane); flushed = op; }
 			}
 			inf_seek(b, src0 + len, lane);
 		} else if (btype == 1u || btype == 2u) {
@@ -371,54 +445,12 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const I
 			if (err) break;
 			err = inf_build<1, kInfDistBits, 15>(L, L.lens + hlit, hdist, lane);
 			if (err) break;
-			// ---- the symbols of the block
-			for (;;) {
-				inf_refill(b, lane);
-				u32 e = inf_uniform(L.lit[(u32)b.bb & ((1u << kInfLitBits) - 1u)]);
-				if (((e >> 8) & 7u) == kKindLong) e = inf_long_code<0, kInfLitBits>(L, b.bb);
-				const u32 kind = (e >> 8) & 7u;
-				inf_take(b, e & 15u);
-				if (kind == kKindLiteral) {
-					if (op >= out_len) { err = 6u; break; }
-					if (lane == 0) L.ring[(a0 + op) & (kRing - 1u)] = (uint8_t)(e >> 16);
-					op++;
-					if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
-					continue;
-				}
-				if (kind == kKindEob) break;
-				if (kind != kKindBase) { err = 4u; break; }
-				const u32 len = (e >> 16) + inf_take(b, (e >> 4) & 15u);
-				inf_refill(b, lane);
-				u32 d = inf_uniform(L.dist[(u32)b.bb & ((1u << kInfDistBits) - 1u)]);
-				if (((d >> 8) & 7u) == kKindLong) d = inf_long_code<1, kInfDistBits>(L, b.bb);
-				if (((d >> 8) & 7u) != kKindBase) { err = 4u; break; }
-				inf_take(b, d & 15u);
-				const u32 dist = (d >> 16) + inf_take(b, (d >> 4) & 15u);
-				if (dist > op) { err = 5u; break; }
-				if (len > out_len - op) { err = 6u; break; }
-				// the copy, cut where the output crosses a half of the ring
-				const u32 m0 = op;                                             // where the match begins
-				for (u32 done = 0u; done < len;) {
-					const u32 room = kHalf - ((a0 + op) & (kHalf - 1u));
-					const u32 seg = min(len - done, room);
-					// what the ring holds: this half and the one before it (and nothing before the block's first byte)
-					const u32 half_base = (a0 + op) & ~(kHalf - 1u);
-					const u32 floor_addr = half_base - kHalf;
-					inf_lds_fence();
-					for (u32 k = (u32)lane; k < seg; k += 64u) {
-						const u32 j = done + k;                                   // byte j of the match
-						const u32 sj = dist >= len ? j : j % dist;               // (an overlapping match repeats its first dist bytes)
-						const u32 sp = m0 - dist + sj;                            // source position within the block
-						const u32 sa = a0 + sp;
-						uint8_t v;
-						// in the ring <=> its address is at or above the floor; addresses wrap at 2^32, differences do not (a block is 64 KiB)
-						if ((int)(sa - floor_addr) >= 0) v = L.ring[sa & (kRing - 1u)];
-						else v = __hip_atomic_load(out + blk.out_off + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // flushed long ago: from L2, past the vector cache
-						L.ring[(a0 + op + k) & (kRing - 1u)] = v;
-					}
-					op += seg; done += seg;
-					if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, out, blk.out_off, a0, flushed, op, lane); flushed = op; }
-				}
+			// ---- the symbols of the block (a function of its own: see inf_symbols)
+			{
+				InfRun r;
+				r.b = b; r.op = op; r.flushed = flushed; r.err = 0u;
+				r = inf_symbols(wave, r, comp + in4, range, a0, out_len, out + blk.out_off, lane);
+				b = r.b; op = r.op; flushed = r.flushed; err = r.err;
 			}
 			if (err) break;
 		} else {
@@ -428,7 +460,7 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const I
 		if (bfinal) break;
 	}
 	if (err) return err;
-	inf_flush(L, out, blk.out_off, a0, flushed, op, lane);
+	inf_flush(L, out + blk.out_off, a0, flushed, op, lane);
 	if (op != out_len) return 7u;
 	if (inf_consumed(b) > head + blk.in_len) return 8u;
 	return 0u;
@@ -436,7 +468,6 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, const uint8_t *comp, const I
 
 __global__ __launch_bounds__(kInfWaves * 64) void bgzf_inflate_kernel(const uint8_t *comp, const InfBlock *blocks, int64_t n_blocks, uint8_t *out, u32 *status)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t inf_smem[];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[wave];
@@ -454,15 +485,15 @@ __global__ __launch_bounds__(kInfWaves * 64) void bgzf_inflate_kernel(const uint
 			blk.crc = 0u; blk.pad = 0u;
 		}
 		u32 st = 0u;
-		if (blk.out_len != 0u || blk.in_len != 0u) st = inf_block(L, comp, blk, out, lane);
+		if (blk.out_len != 0u || blk.in_len != 0u) st = inf_block(L, wave, comp, blk, out, lane);
 		if (lane == 0) status[bi] = st;
 		inf_lds_fence();
 	}
 }
 
 // ---- CRC-32 -------------------------------------------------------------------------------------------------------
-// reflected polynomial 0xEDB88320 (RFC 1952 §8).  A lane's piece byte by byte through a 256-entry table in LDS; the
-// pieces are joined with crc(A ++ B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (bit-reflected arithmetic).
+// reflected polynomial 0xEDB88320 (RFC 1952 §8).  A lane's piece 16 bytes per load, a dword per step through four 256-entry
+// tables in LDS (slicing by four); the pieces are joined with crc(A ++ B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (bit-reflected arithmetic).
 __device__ __forceinline__ u32 crc_mul(u32 a, u32 b)                     // a * b mod P, both bit-reflected (bit 31 = x^0)
 {
 	u32 r = 0u;
@@ -483,12 +514,16 @@ __device__ __forceinline__ u32 crc_xpow8(u32 nbytes, const u32 *pw)     // x^(8 
 
 __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t *out, const InfBlock *blocks, int64_t n_blocks, u32 *status)
 {
-	__shared__ u32 tab[256];
+	// four tables (slicing by four: a dword of the message per step), 4 KiB of LDS
+	__shared__ u32 tab[4][256];
 	__shared__ u32 pw[20];
 	{
 		u32 c = threadIdx.x;
 		for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
-		tab[threadIdx.x] = c;
+		tab[0][threadIdx.x] = c;
+		__syncthreads();
+		u32 t = c;
+		for (int k = 1; k < 4; k++) { t = (t >> 8) ^ tab[0][t & 0xffu]; tab[k][threadIdx.x] = t; }
 		if (threadIdx.x == 0) {
 			u32 p = 0x00800000u;                                         // x^8
 			for (int k = 0; k < 20; k++) { pw[k] = p; p = crc_mul(p, p); }
@@ -499,13 +534,31 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t *out, const
 	for (int64_t bi = (int64_t)blockIdx.x * 4 + wave; bi < n_blocks; bi += (int64_t)gridDim.x * 4) {
 		const InfBlock blk = blocks[bi];
 		const u32 n = blk.out_len;
-		const u32 piece = (n + 63u) >> 6;
-		const u32 lo = min(n, piece * (u32)lane), hi = min(n, lo + piece);
+		// a lane's piece: 1/64 of the block rounded up to 16 bytes, from a 16-byte boundary of the output ADDRESS on (the first lane
+		// also takes the bytes before the first boundary)
 		const uint8_t *p = out + blk.out_off;
+		const u32 mis = (u32)((16u - ((uintptr_t)p & 15u)) & 15u);        // bytes before the first boundary
+		const u32 headn = mis < n ? mis : n;
+		const u32 body = n - headn;
+		const u32 piece = (((body + 63u) >> 6) + 15u) & ~15u;
+		const u32 lo = headn + min(body, piece * (u32)lane), hi = headn + min(body, piece * (u32)lane + piece);
 		u32 c = lane == 0 ? 0xFFFFFFFFu : 0u;                            // (the initial value rides through the first piece; the others start from 0: the register's linearity)
-		for (u32 i = lo; i < hi; i++) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
-		// join: lane l takes over its right neighbour at distance 1, 2, 4 ...: c = c * x^(8 len_right) + c_right
 		u32 len = hi - lo;
+		if (lane == 0) {
+			for (u32 i = 0; i < headn; i++) c = tab[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+			len += headn;
+		}
+		u32 i = lo;
+		for (; i + 16u <= hi; i += 16u) {
+			const u32x4 w = *reinterpret_cast<const u32x4 *>(p + i);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const u32 x = c ^ w[k];
+				c = tab[3][x & 0xffu] ^ tab[2][(x >> 8) & 0xffu] ^ tab[1][(x >> 16) & 0xffu] ^ tab[0][x >> 24];
+			}
+		}
+		for (; i < hi; i++) c = tab[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+		// join: lane l takes over its right neighbour at distance 1, 2, 4 ...: c = c * x^(8 len_right) + c_right
 		for (int o = 1; o < 64; o <<= 1) {
 			const u32 cr = __shfl_down(c, o), lr = __shfl_down(len, o);
 			if ((lane & (2 * o - 1)) == 0 && lane + o < 64) {
@@ -586,6 +639,56 @@ __global__ __launch_bounds__(256) void bam_walk_fix_kernel(const WalkArgs a)
 	atomicAdd(a.changed, 1u);
 }
 
+// A block whose entry is not its predecessor's exit — a file whose writer cut its blocks anywhere — would be put right one block per
+// round (its predecessor's exit is wrong until the one before THAT is right: the chain again).  So such a block first GUESSES: a wave
+// looks, 64 offsets at a time from the block's first byte on, for the first offset at which three records in a row look like records
+// (sizes that fit the stream, reference ids the header has, a read name that ends in NUL, a variable part that holds what the core
+// says it holds), and walks from there.  A guess is only a guess: the rounds that follow verify every entry against its
+// predecessor's exit as before, and replace the ones that fooled the test.
+__device__ __forceinline__ bool bam_plausible(const uint8_t *s, u64 len, u64 o, int32_t n_ref)
+{
+	for (int d = 0; d < 3; d++) {
+		if (o == len) return true;
+		if (o + 36 > len) return false;
+		const u32 bs = bam_le32(s + o);
+		if (bs < 32u || bs > (1u << 28) || o + 4 + (u64)bs > len) return false;
+		const int32_t tid = (int32_t)bam_le32(s + o + 4), pos = (int32_t)bam_le32(s + o + 8);
+		const u32 w8 = bam_le32(s + o + 12), w12 = bam_le32(s + o + 16);
+		const int32_t l_seq = (int32_t)bam_le32(s + o + 20), mtid = (int32_t)bam_le32(s + o + 24), mpos = (int32_t)bam_le32(s + o + 28);
+		const u32 l_name = w8 & 0xffu, n_cigar = w12 & 0xffffu;
+		if (tid < -1 || mtid < -1 || pos < -1 || mpos < -1 || l_seq < 0 || l_name == 0u) return false;
+		if (n_ref >= 0 && (tid >= n_ref || mtid >= n_ref)) return false;
+		if (32ull + l_name + 4ull * n_cigar + (((u64)l_seq + 1) >> 1) + (u64)l_seq > (u64)bs) return false;
+		if (s[o + 36 + l_name - 1] != 0) return false;
+		o += 4 + (u64)bs;
+	}
+	return true;
+}
+__global__ __launch_bounds__(256) void bam_walk_guess_kernel(const WalkArgs a, int32_t n_ref)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= a.n || c == 0) return;
+	u64 want = a.exitp[c - 1];
+	if (want < kWalkTruncated) {
+		if (want < a.first) want = a.first;
+		if (a.entry[c] == want) return;                                    // (already its predecessor's exit)
+	}
+	const u64 begin0 = a.bend[c - 1], end = a.bend[c];
+	const u64 begin = begin0 < a.first ? a.first : begin0;
+	u64 found = end;                                                       // no record begins in this block (one longer than the block covers it)
+	for (u64 base = begin; base < end; base += 64) {
+		const u64 o = base + (u64)lane;
+		const bool ok = o < end && bam_plausible(a.stream, a.stream_len, o, n_ref);
+		const u64 m = __ballot(ok);
+		if (m) { found = base + (u64)(__ffsll((unsigned long long)m) - 1); break; }
+	}
+	if (lane == 0) {
+		a.entry[c] = found;
+		bam_walk_one(a, c);
+	}
+}
+
 // S1 + H1 over the records of the verified chain, straight from the inflated bytes (sk_kernels.hip: bam_flag_tlen_kernel's
 // predicate, src/sam_statistics.rs:63-69, src/sam_fragment_lengths.rs:29-43).  out = u64[3 counters][1 hist_total][max_frag + 1 bins].
 // One lane per block; counters per lane, summed per workgroup; histogram bins by atomics on an LDS copy when it fits.
@@ -663,14 +766,15 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int64_t 
 }
 
 hipError_t launch_bam_walk(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, uint64_t *entry, uint64_t *exitp, uint32_t *nrec, int64_t n,
-                           uint64_t first, uint32_t *changed, int fix_round, hipStream_t st)
+                           uint64_t first, uint32_t *changed, int fix_round, int32_t n_ref, hipStream_t st)
 {
 	if (n <= 0) return hipSuccess;
 	WalkArgs a;
 	a.stream = stream; a.stream_len = stream_len; a.bend = reinterpret_cast<const u64 *>(bend); a.entry = reinterpret_cast<u64 *>(entry);
 	a.exitp = reinterpret_cast<u64 *>(exitp); a.nrec = nrec; a.n = n; a.first = first; a.changed = changed;
 	const unsigned grid = (unsigned)((n + 255) / 256);
-	if (fix_round) bam_walk_fix_kernel<<<grid, 256, 0, st>>>(a);
+	if (fix_round == 2) bam_walk_guess_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(a, n_ref);
+	else if (fix_round) bam_walk_fix_kernel<<<grid, 256, 0, st>>>(a);
 	else bam_walk_kernel<<<grid, 256, 0, st>>>(a);
 	return hipGetLastError();
 }

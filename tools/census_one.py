@@ -14,7 +14,7 @@ case = sys.argv[1] if len(sys.argv) > 1 else "exact"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 32_000_000
 reps_run = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda", 0)
-ctx = seqkit_amd.Context(0)
+ctx = seqkit_amd.Context(0, lib_path=os.path.abspath(os.environ["SK_LIB"])) if os.environ.get("SK_LIB") else seqkit_amd.Context(0)
 table = synth.make_sheet(96, 8, dual=True, seed=4)
 kw = {"exact": dict(p_exact=1.0, p_sub=0.0), "clean": dict(p_exact=0.97, p_sub=0.025), "noisy": {}, "sub": dict(p_exact=0.85, p_sub=0.15)}
 reps = max(1, n // 1_000_000)

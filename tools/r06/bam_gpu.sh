@@ -9,7 +9,7 @@ BAM_KEEP=/dev/shm/sk_scale.bam E2E_NO_ORACLE=1 timeout -k 10 600 python3 $R/tool
 ls -la /dev/shm/sk_scale.bam
 {
   echo "== sam statistics, device inflate (default)"
-  for i in 1 2 3; do time ($R/seqkit_amd/bin/sam statistics /dev/shm/sk_scale.bam); done
+  for i in 1 2 3; do time (SK_BAMFILE_TRACE=1 $R/seqkit_amd/bin/sam statistics /dev/shm/sk_scale.bam); done
   echo "== sam statistics, host inflate (SEQKIT_HOST_INFLATE=1)"
   for i in 1 2; do time (SEQKIT_HOST_INFLATE=1 $R/seqkit_amd/bin/sam statistics /dev/shm/sk_scale.bam); done
   echo "== sam fragment lengths, device inflate: md5 of the output against the host path's"
