@@ -687,6 +687,42 @@ def secondary_rates(torch, ctx, dev):
     return out
 
 
+def bam_file_rows(ctx):
+    """extra.bam_files: config 5 on a FILE — `sam statistics` + `sam fragment lengths` from the BGZF bytes (sk_bam_file_reduce: the compressed
+    file crosses PCIe, the device inflates, walks the records and reduces) — on two synthetic BAMs, checked against the oracle's
+    reduction of the same records.  `ms` is the whole call, file (page cache) to counters; the kernel's own rates are
+    tools/r06/inflate_rate.py's."""
+    import shutil
+    import tempfile
+    import time
+    from oracle import oracle as orc
+    from seqkit_amd import synth
+    rows = []
+    d = tempfile.mkdtemp(prefix="sk_bench_bam_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for kind, n_rec, what in (("random", 4_000_000, "bases and qualities drawn uniformly: literals, 1.5 : 1 (an inflater's worst case)"),
+                                  ("sorted", 8_000_000, "reads of a small genome in position order, binned qualities: 5 : 1")):
+            path = os.path.join(d, kind + ".bam")
+            n, flag, tid, mtid, tlen, reps = synth.write_bam_file(path, n_rec, seed=5, kind=kind)
+            e_counters, e_hist, e_total = orc.bam_flag_tlen(flag, tid, mtid, tlen, 5000)
+            ts, last = [], None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                last = ctx.bam_file_reduce(path, 5000)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            handled, counters, hist, total, info = last
+            ok = bool(handled) and (counters == e_counters * np.uint64(reps)).all() and (hist == e_hist * np.uint64(reps)).all() and total == e_total * reps
+            ms = sorted(ts[1:])[1]
+            rows.append({"config": f"cfg5 on a file: sam statistics + fragment lengths, {n // 1_000_000} M-record BAM ({what}), file to counters",
+                         "ms": round(ms, 2), "M_records_per_s": round(n / ms / 1e3, 2), "compressed_GBps": round(info[0] / ms / 1e6, 2),
+                         "inflated_GBps": round(info[1] / ms / 1e6, 2), "compressed_bytes": int(info[0]), "inflated_bytes": int(info[1]),
+                         "bgzf_blocks": int(info[2]), "blocks_inflated_by_zlib_on_the_host": int(info[4]), "walk_rounds": int(info[5]),
+                         "read_and_copy_ms": round(info[6], 2), "device_tail_ms": round(info[7], 2), "matches_oracle": bool(ok)})
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return rows
+
+
 def faithful_cpu(n_reads):
     """cpu_baseline.faithful: the line-at-a-time oracle CLI — same loops as the reference's commands,
     one thread — end to end on cfg 2 / cfg 3 text, stdout to /dev/null (per-sample gzip children included for
@@ -1131,7 +1167,7 @@ def main():
         del seq, qual, bc
         torch.cuda.empty_cache()
         try:
-            extra = {"rates": secondary_rates(torch, ctx, dev),
+            extra = {"rates": secondary_rates(torch, ctx, dev), "bam_files": bam_file_rows(ctx),
                      "note": "device-resident, outside the timed region, HIP events on the ctx stream; frac = algorithmic bytes / time / 8 TB/s; "
                              "where frac_as_placed is given, frac is with the placement of the kernel's arrays chosen among 3 candidates each; "
                              "a row whose in+out bytes would fit the 256 MiB Infinity Cache says rows_from: its frac is measured with the rows "

@@ -168,10 +168,9 @@ typedef struct {
 int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
 int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 /* Many independent batches in one call: what n_batches calls of sk_fused_pass_dev compute (same outputs; counters are sums, so
- * their order does not matter), enqueued so that the batches overlap on the device — a batch of a few million rows streams for
- * 20 us, and one call after the other each pays its launch gap, ramp and tail alone (src/fasta_demultiplex.rs:154-194 per read,
- * src/fasta_trim_by_quality.rs:28-42 per read: reads are independent, so are batches).  Asynchronous like the _dev calls: the
- * ctx stream continues when every batch is done; sk_sync() waits.  The two conveniences below build the argument blocks. */
+ * their order does not matter) — checked once, the sheet's table uploaded once, the launches back to back on the ctx stream
+ * (src/fasta_demultiplex.rs:154-194, src/fasta_trim_by_quality.rs:28-42 work per read: reads are independent, so are
+ * batches).  Asynchronous like the _dev calls; sk_sync() waits.  The two conveniences below build the argument blocks. */
 int sk_fused_pass_many_dev(sk_ctx *ctx, const sk_fused_args *batches, int n_batches);
 typedef struct sk_demux_batch {
 	const uint8_t *bc;          /* n x bc_stride */

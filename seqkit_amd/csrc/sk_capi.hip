@@ -24,11 +24,6 @@ struct sk_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;     // second lane of the host entry points' chunk pipeline (H2D of chunk i+1 under kernel / D2H of chunk i)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_pipe = nullptr;
-	// lanes of sk_fused_pass_many_dev (created on first use): independent batches go to kManyLanes streams so that a batch's
-	// workgroups start on the CUs its predecessor's have left, instead of behind its last one
-	static constexpr int kManyLanes = 4;
-	hipStream_t lane[kManyLanes] = {nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t lane_ev[kManyLanes] = {nullptr, nullptr, nullptr, nullptr};
 	std::string err;
 	// barcode table
 	bool have_table = false;
@@ -219,10 +214,6 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_genome) (void)hipFree(c->d_genome);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
-	for (int i = 0; i < sk_ctx::kManyLanes; i++) {
-		if (c->lane[i]) { (void)hipStreamSynchronize(c->lane[i]); (void)hipStreamDestroy(c->lane[i]); }
-		if (c->lane_ev[i]) (void)hipEventDestroy(c->lane_ev[i]);
-	}
 	if (c->ev_pipe) (void)hipEventDestroy(c->ev_pipe);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -829,11 +820,15 @@ int sk_fused_pass_dev(sk_ctx *c, const sk_fused_args *a)
 static void one_mate(sk_fused_args &a, const uint8_t *seq, const uint8_t *qual, const uint16_t *len, int stride, int64_t n,
                      uint8_t min_baseq, uint8_t *out_seq, uint16_t *lowest_k);
 
-// Many independent batches in one call.  A 10 M-row lookup streams for 20 us; as one launch after the other on
-// one stream every batch pays its launch gap, the ramp of its first loads and the tail of its last workgroups by itself.  Here the
-// batches are dealt to kManyLanes streams behind ONE fork event and joined by one wait each: the queues' launches overlap, and a
-// batch's workgroups are dispatched onto the CUs the batch before it has already left.  Counters: every launch adds to the same
-// ctx counters (or to its own a->counts) with atomics, so the sums do not depend on the order in which the lanes ran.
+// Many independent batches in one call: every batch is checked, the sheet's table goes up once, and the launches
+// follow each other on the ctx stream with nothing between them — what a host that has its batches at hand gets without a call,
+// an argument check and an event per batch (bench.py: `frac_many` against `frac`, one event pair per call).
+// What this does NOT yet do is run the batches as ONE persistent launch.  Measured first (round 6, gpurun_out/r06_l): the batches
+// dealt to four streams behind one fork event, so that a batch's workgroups start on the CUs its predecessor has left — SLOWER
+// than one stream (10 M x 8 bp: 0.47 of the HBM peak against 0.58 per call and 0.62 back to back; 96 dual-index 0.46 / 0.53 / 0.56):
+// two lookup kernels on a CU are thirty-two waves where sixteen stream best (launch_tile_pass), and every batch pays two more
+// events.  The remaining form — the quads of all batches dealt to one launch's waves, tables staged once — needs the batch
+// boundary inside the lookup kernels' prefetch and is not built.
 int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batches)
 {
 	if (!c) return SK_ERR_INVALID;
@@ -841,26 +836,13 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 	if (n_batches == 0) return SK_OK;
 	if (int r = bind(c)) return r;
 	for (int i = 0; i < n_batches; i++) if (int r = check_fused(c, &batches[i], true)) return r;
-	if (n_batches == 1) return sk_fused_pass_dev(c, &batches[0]);
-	const int lanes = std::min(n_batches, (int)sk_ctx::kManyLanes);
-	for (int i = 0; i < lanes; i++) {
-		if (!c->lane[i]) SK_HIP(c, hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking));
-		if (!c->lane_ev[i]) SK_HIP(c, hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
-	}
-	for (int i = 0; i < n_batches; i++) if (batches[i].n > 0) { if (int r = prepare_demux(c, &batches[i])) return r; break; }      // (the sheet's table goes up once, before the fork)
-	SK_HIP(c, hipEventRecord(c->ev_pipe, c->stream));
-	for (int i = 0; i < lanes; i++) SK_HIP(c, hipStreamWaitEvent(c->lane[i], c->ev_pipe, 0));
 	for (int i = 0; i < n_batches; i++) {
 		const sk_fused_args *a = &batches[i];
 		if (a->n == 0) continue;
 		if (int r = prepare_demux(c, a)) return r;
 		sk::TileArgs t = tile_args_of(c, a);
 		if (t.bc && t.counts_wide) c->wide_dirty = true;
-		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->lane[i % lanes]));
-	}
-	for (int i = 0; i < lanes; i++) {
-		SK_HIP(c, hipEventRecord(c->lane_ev[i], c->lane[i]));
-		SK_HIP(c, hipStreamWaitEvent(c->stream, c->lane_ev[i], 0));
+		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
 	}
 	return SK_OK;
 }

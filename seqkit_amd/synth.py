@@ -125,6 +125,68 @@ def make_bam_cores(n: int, seed: int = 5):
     return flag, tid, mtid, tlen
 
 
+def write_bam_file(path: str, n_records: int, seed: int = 5, kind: str = "random", unit_records: int = 100_000, level: int = 1):
+    """cfg 5 as a FILE: a BGZF / BAM file of n_records records (rounded down to whole units) whose core fields are make_bam_cores'
+    mix, written the way htslib writes (a block is flushed rather than a record split).  kind "random": bases and qualities drawn
+    uniformly (literals, about 1.5 : 1 — a worst case for an inflater); "sorted": reads drawn from a small genome in position order
+    with binned qualities (what a coordinate-sorted BAM of a current instrument looks like, about 5 : 1).  ONE unit of
+    unit_records records is built and compressed, then repeated.  Returns (records written, flag, tid, mtid, tlen of ONE unit,
+    repeats): the expected reduction is the unit's, times repeats."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(seed)
+    flag, tid, mtid, tlen = make_bam_cores(unit_records, seed=seed)
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+    genome = codes[rng.integers(0, 4, size=300_000)]
+    qbins = np.array([2, 12, 23, 37], dtype=np.uint8)
+    unit = bytearray()
+    ends = []
+    for i in range(unit_records):
+        name = b"A00123:45:HXXXXXXX:1:%d:%d:%d\0" % (1101 + i // 5000, 1000 + (i * 7) % 30000, 1000 + (i * 13) % 30000)
+        if kind == "random":
+            nib = codes[rng.integers(0, 4, size=150)]
+            q = rng.integers(2, 41, size=150, dtype=np.uint8)
+        else:
+            p = (i * 3) % (len(genome) - 150)
+            nib = genome[p:p + 150].copy()
+            if i % 3 == 0:
+                nib[(i * 7) % 150] = codes[i % 4]
+            q = qbins[np.minimum(3, rng.geometric(0.75, size=150) - 1)][::-1].copy()
+            q[:100] = 37
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
+        body = struct.pack("<iiBBHHHiiii", int(tid[i]), i * 3, len(name), 60, 4680, 1, int(flag[i]), 150, int(mtid[i]), i * 3 + 100, int(tlen[i])) + name
+        body += struct.pack("<I", 150 << 4) + packed + q.tobytes()
+        unit += struct.pack("<i", len(body)) + body
+        ends.append(len(unit))
+    unit = bytes(unit)
+
+    def bgzf(data):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+    blocks, lo, prev = [], 0, 0
+    for e in ends:
+        if e - lo > 0xff00:
+            blocks.append(bgzf(unit[lo:prev]))
+            lo = prev
+        prev = e
+    blocks.append(bgzf(unit[lo:]))
+    body = b"".join(blocks)
+    reps = max(1, n_records // unit_records)
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 24)
+    for r in range(24):
+        nm = b"chr%d\0" % (r + 1)
+        hdr += struct.pack("<i", len(nm)) + nm + struct.pack("<i", 1 << 28)
+    with open(path, "wb") as f:
+        f.write(bgzf(hdr))
+        for _ in range(reps):
+            f.write(body)
+        f.write(bgzf(b""))
+    return reps * unit_records, flag, tid, mtid, tlen, reps
+
+
 def fastq_text(seq: np.ndarray, qual: np.ndarray, prefix: str = "SIM:1", lengths=None, headers=None) -> bytes:
     """Four-line FASTQ text of a batch (header `@<prefix>:<i>` unless headers are given)."""
     out = []
