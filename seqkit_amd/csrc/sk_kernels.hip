@@ -2695,8 +2695,9 @@ __global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__res
 	}
 }
 
-// The same decoding for rows of a pitch that is a multiple of 8 and at most NQ KiB / 64 (NQ = 10: 150-base reads at pitch 152
-// or 160) — through an LDS image of the tile.  A WAVE owns a tile of 64 rows: its qualities and packed bases arrive as NQ + NS
+// The same decoding for rows of a pitch that is a multiple of 4 (8 through round 5; 148 = 2 x 74 bases is the common case of the other
+// residue: a row then ends in half a unit) and at most NQ KiB / 64 (NQ = 10: 150-base reads at pitch 152 or 160) — through an LDS
+// image of the tile.  A WAVE owns a tile of 64 rows: its qualities and packed bases arrive as NQ + NS
 // fully coalesced 16-byte loads per lane (1 KiB per wave instruction, nt: read once) and are written to the wave's LDS slot;
 // the NEXT tile's loads are issued right behind (the whole next tile is in flight while this one is worked on: 15 KiB per
 // wave, 120 KiB per CU); lane l then computes units l, l + 64, ... of the tile (a unit = 8 output bytes, exactly
@@ -2705,6 +2706,9 @@ __global__ __launch_bounds__(256) void bam_sequence8_kernel(const uint8_t *__res
 // lane.  No workgroup barrier: a wave's LDS operations execute in order.  (bam_sequence8_kernel asks memory for 4-, 8- and
 // 8-byte pieces per lane and stores 8: 60-65 % of the HBM peak whatever was tried on it — EXPERIMENTS.md A.7; it stays for
 // every other pitch.)
+#ifndef SK_SEQ_TWO
+#define SK_SEQ_TWO 0
+#endif
 template <bool SMALL_M, int NQ, int ROWS>
 __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_kernel(const uint8_t *__restrict__ seq4, int seq4_stride, const uint8_t *__restrict__ qual,
                                                                    int stride, const uint16_t *__restrict__ len, const uint16_t *__restrict__ flag,
@@ -2719,12 +2723,11 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_ker
 	uint8_t *img = sk_smem + wave * kSlot;                         // the qualities (then the output) ...
 	uint8_t *simg = img + NQ * 1024;                               // ... the packed bases ...
 	u32 *info = reinterpret_cast<u32 *>(img + (NQ + NS) * 1024);   // ... len | reverse << 16 per row
-	const int upr = stride >> 3;
+	const int upr = (stride + 7) >> 3;                             // units per row; a pitch that is 4 mod 8 (148: 2 x 74 bases) ends in half a unit
+	const bool half_tail = (stride & 4) != 0;
 	const int64_t ntiles = (n + ROWS - 1) / ROWS;
 	const int64_t tstep = (int64_t)gridDim.x * 4;
-	u32x4 rq[NQ], rs[NS];
-	u32 rinfo = 0u;
-	auto fetch = [&](int64_t t) {
+	auto fetch = [&](int64_t t, u32x4 (&rq)[NQ], u32x4 (&rs)[NS], u32 &rinfo) {
 		const int rows = t < ntiles ? (int)((n - t * ROWS) < ROWS ? (n - t * ROWS) : ROWS) : 0;
 		const int64_t row0 = rows ? t * ROWS : 0;
 		const rsrc_t dq = make_rsrc(qual, row0 * (int64_t)stride, rows * stride), ds = make_rsrc(seq4, row0 * (int64_t)seq4_stride, (rows * seq4_stride + 3) & ~3);
@@ -2736,9 +2739,8 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_ker
 		const u32 fv = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(make_rsrc(flag, row0 * 2, rows * 2), lane * 2, 0, 0);
 		rinfo = (len ? lv : (u32)stride) | ((fv >> 4) & 1u) << 16;
 	};
-	int64_t t = (int64_t)blockIdx.x * 4 + wave;
-	fetch(t);
-	for (; t < ntiles; t += tstep) {
+	// one tile: its registers into the wave's LDS slot, the tile `ahead` steps on asked for into the same registers, then the work
+	auto process = [&](int64_t t, int ahead, u32x4 (&rq)[NQ], u32x4 (&rs)[NS], u32 &rinfo) {
 		const int64_t row0 = t * ROWS;
 		const int rows = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
 		const u32 units = (u32)(ROWS * upr);
@@ -2748,7 +2750,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_ker
 		for (int c = 0; c < NS; c++) *reinterpret_cast<u32x4 *>(simg + c * 1024 + lane * 16) = rs[c];
 		info[lane] = rinfo;
 		wave_lds_fence();
-		fetch(t + tstep);                                              // the next tile: on its way while this one is worked on
+		fetch(t + ahead * tstep, rq, rs, rinfo);                       // a later tile: on its way while this one is worked on
 		u32x2 ov[kMaxU];
 #pragma unroll
 		for (int i = 0; i < kMaxU; i++) {
@@ -2793,9 +2795,24 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_ker
 			}
 		}
 		wave_lds_fence();                                              // every lane has read what it needs: the units go over the quality image
+		if (!half_tail) {
 #pragma unroll
-		for (int i = 0; i < kMaxU; i++)
-			if ((u32)lane + 64u * (u32)i < units) *reinterpret_cast<u32x2 *>(img + 8 * (lane + 64 * i)) = ov[i];
+			for (int i = 0; i < kMaxU; i++)
+				if ((u32)lane + 64u * (u32)i < units) *reinterpret_cast<u32x2 *>(img + 8 * (lane + 64 * i)) = ov[i];
+		} else {
+			// unit j of row rl lies at rl * stride + 8 j (4-byte aligned); the row's last unit is its first four bytes only
+#pragma unroll
+			for (int i = 0; i < kMaxU; i++) {
+				const u32 e = (u32)lane + 64u * (u32)i;
+				if (e < units) {
+					const u32 rl = inv_upr ? __umulhi(e, inv_upr) : e / (u32)upr;
+					const int j = (int)(e - rl * (u32)upr);
+					u32 *dst = reinterpret_cast<u32 *>(img + (int)rl * stride + 8 * j);
+					dst[0] = ov[i][0];
+					if (j != upr - 1) dst[1] = ov[i][1];
+				}
+			}
+		}
 		wave_lds_fence();
 		const rsrc_t dout = make_rsrc(out, row0 * (int64_t)stride, rows * stride);
 #pragma unroll
@@ -2804,7 +2821,24 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 4) void bam_sequence_tile_ker
 			__builtin_amdgcn_raw_buffer_store_b128(v, dout, c * 1024 + lane * 16, 0, kAuxStreamSt);
 		}
 		wave_lds_fence();
+	};
+	int64_t t = (int64_t)blockIdx.x * 4 + wave;
+#if SK_SEQ_TWO
+	// TWO register sets: while a tile is worked on, the next one AND the one behind it are on their way (30 KiB per wave)
+	u32x4 rqa[NQ], rsa[NS], rqb[NQ], rsb[NS];
+	u32 ia = 0u, ib = 0u;
+	fetch(t, rqa, rsa, ia);
+	fetch(t + tstep, rqb, rsb, ib);
+	for (; t < ntiles; t += 2 * tstep) {
+		process(t, 2, rqa, rsa, ia);
+		if (t + tstep < ntiles) process(t + tstep, 2, rqb, rsb, ib);
 	}
+#else
+	u32x4 rq[NQ], rs[NS];
+	u32 rinfo = 0u;
+	fetch(t, rq, rs, rinfo);
+	for (; t < ntiles; t += tstep) process(t, 1, rq, rs, rinfo);
+#endif
 }
 
 hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8_t *qual, int stride, const uint16_t *len, const uint16_t *flag,
@@ -2818,11 +2852,11 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 	// rl = e / upr as a multiply-high: exact while e * upr < 2^32, and e < 64 * upr
 	const u32 upr = ((u32)stride + 7u) >> 3;
 	const u32 inv8 = (upr > 1 && upr < 8192u) ? (u32)(((1ull << 32) + upr - 1) / upr) : 0u;
-	// pitches the LDS-tile kernel serves: a multiple of 8, a tile's qualities in ten 1 KiB chunks and its packed bases in five
+	// pitches the LDS-tile kernel serves: a multiple of 4, a tile's qualities in ten 1 KiB chunks and its packed bases in five
 	// (150-base reads at pitch 152 / 160); matrices 16-byte aligned (SK_SEQ_TILE=0: the other kernel, for A/B and the tests)
 	const char *env_tile = getenv("SK_SEQ_TILE");                      // (read per launch: the tests run both kernels in one process)
 	const bool env_no_tile = env_tile && atoi(env_tile) == 0;
-	if (!env_no_tile && (stride & 7) == 0 && 64 * stride <= 10 * 1024 && (seq4_stride & 3) == 0 && 64 * seq4_stride <= 5 * 1024 &&
+	if (!env_no_tile && (stride & 3) == 0 && stride >= 8 && 64 * stride <= 10 * 1024 && (seq4_stride & 3) == 0 && 64 * seq4_stride <= 5 * 1024 &&
 	    ((uintptr_t)seq4 & 15) == 0 && ((uintptr_t)qual & 15) == 0 && ((uintptr_t)out & 15) == 0) {
 		// (tiles of 32 rows with twice the waves were measured too: 62.1 % of the HBM peak against 63.2 % on the box where the
 		// 8-byte kernel did 60.0 %; one workgroup per CU 53.8 %)

@@ -1176,7 +1176,7 @@ def test_bam_sequence_kat_gpu(ctx, golden):
 
 @pytest.fixture(params=["LDS tile where the pitch allows", "8-byte units everywhere"])
 def seq_kernel(request, monkeypatch):
-    """sequence() has two kernels (sk_kernels.hip): bam_sequence_tile_kernel for pitches that are a multiple of 8 up to 160,
+    """sequence() has two kernels (sk_kernels.hip): bam_sequence_tile_kernel for pitches that are a multiple of 4 up to 160,
     bam_sequence8_kernel for the rest — and for every pitch with SK_SEQ_TILE=0."""
     if request.param.startswith("8-byte"):
         monkeypatch.setenv("SK_SEQ_TILE", "0")
@@ -1184,7 +1184,7 @@ def seq_kernel(request, monkeypatch):
 
 
 @pytest.mark.parametrize("n,stride,seq4_stride", [(1, 4, 4), (63, 8, 4), (65, 12, 8), (1000, 152, 76), (3000, 152, 80), (257, 100, 52), (130, 160, 80), (5000, 104, 52),
-                                                  (70, 252, 128), (40, 40000, 20000)])
+                                                  (70, 252, 128), (40, 40000, 20000), (2000, 148, 76), (129, 148, 80), (64, 156, 80), (100, 20, 12), (200, 12, 8)])
 def test_bam_sequence_matches_oracle(ctx, oracle, seq_kernel, n, stride, seq4_stride):
     seq4, qual, ln, flag = bam_rows(n, stride, seed=n + stride, seq4_stride=seq4_stride)
     for m in (10, 0, 31, 200, 255):

@@ -43,7 +43,11 @@ def run():
         ctx.demux_assign_dev(bc.data_ptr(), L, n, assign.data_ptr())
 
 
-for _ in range(3):
+# Warm-up: the device's memory-side clocks ramp for the first ~20 ms of work after idle — the same launch on the same bytes takes
+# 450-470 us at first and 390-395 us from the fiftieth launch on (tools/r06/lut_repro.py; profiles/r06_lut_repro.txt).  Round 5's
+# kernel trace of this script (3 warm-up launches, 13 traced: 400-509 us) sat inside that ramp.  SK_ONE_WARMUP overrides.
+warm = int(os.environ.get("SK_ONE_WARMUP", "150" if n >= 50_000_000 else "600"))
+for _ in range(warm):
     run()
 ctx.sync()
 ctx.timer_start()
