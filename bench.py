@@ -58,10 +58,11 @@ def parse(argv=None):
                     help="reads of cfg 2 / cfg 3 text run through the line-at-a-time oracle CLI for cpu_baseline.faithful (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.rates (device-resident rates of the other configs)")
     ap.add_argument("--gen-chunk", type=int, default=2_000_000)
-    ap.add_argument("--placements", type=int, default=3,
+    ap.add_argument("--placements", type=int, default=None,
                     help="candidate device buffers per big matrix (SoA) / per buffer (blocked): allocated at start-up, the pass is timed "
                          "while one matrix at a time is swapped for its other candidates (sk_fused_tune_placement_dev), the fastest combination "
-                         "is kept and the rest freed — where a buffer's pages lie moves the same kernel by up to 12 %%; 1 = take what comes")
+                         "is kept and the rest freed — where a buffer's pages lie moves the same kernel by up to 12 %%; 1 = take what comes. "
+                         "Default 3 on one GPU, 2 when --gpus N > 1 (every rank allocates its candidates at start-up: K x 56 GB each)")
     ap.add_argument("--test-worker", default=None, help=argparse.SUPPRESS)     # tests/test_bench_launcher.py: the script the launcher starts as a rank
     return ap.parse_args(argv)
 
@@ -875,7 +876,7 @@ def main():
         local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = device_identity(local_rank) if rank == 0 else None      # a child process: started before this one touches the GPU
+    device = device_identity(local_rank)                             # a child process: started before this one touches the GPU (every rank: its id goes into its line of `ranks`)
 
     import torch
     import torch.distributed as dist
@@ -904,7 +905,7 @@ def main():
     nt = (n + 63) // 64
     npad = nt * 64                                           # whole tiles
     lay = None
-    K = max(1, min(args.placements, 8))
+    K = max(1, min(args.placements if args.placements is not None else (3 if world == 1 else 2), 8))
     # Pre-flight: the candidates are the bulk of what this rank allocates (K x 56 GB at the full shard).  Ask the device what is
     # free BEFORE allocating, take as many candidates as fit beside the fixed part, and say so — a rank that cannot hold even one
     # set ends here with a sentence instead of an allocator trace somewhere in the middle of the run.
@@ -1085,10 +1086,16 @@ def main():
     reduce_us = sum(e[1].elapsed_time(e[2]) for e in events) / max(args.steps, 1) * 1e3
     rank_kernel_ms = [kern_ms]
     rank_reduce_us = [reduce_us]
+    # every rank's own line: its kernel time and what the placement probe found and chose on ITS device — a GPU in the slow
+    # placement mode (some boxes have no fast one) shows here, not only in the max over the ranks
+    mine = {"rank": rank, "local_rank": local_rank, "kernel_ms": round(kern_ms, 4), "count_reduce_us": round(reduce_us, 2),
+            "placement_candidates": placement.get("candidates"), "placement_ms_before": placement.get("ms_before"),
+            "placement_ms_after": placement.get("ms_after"), "gpu_unique_id": (device or {}).get("gpu_unique_id")}
+    rank_lines = [mine]
     if distributed:
         both = [None] * world
-        dist.all_gather_object(both, (kern_ms, reduce_us))
-        rank_kernel_ms, rank_reduce_us = [b[0] for b in both], [b[1] for b in both]
+        dist.all_gather_object(both, (kern_ms, reduce_us, mine))
+        rank_kernel_ms, rank_reduce_us, rank_lines = [b[0] for b in both], [b[1] for b in both], [b[2] for b in both]
 
     # ---- size-independent checks on the full shard + bit-exact parity on a sample (oracle = checker only) -----
     total_counts = counts.cpu().numpy().astype(np.uint64)
@@ -1226,6 +1233,7 @@ def main():
                          "algorithmic_bytes_per_cluster": BYTES_PER_PAIR,
                          "read_frac": round((617 * n / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)},
             **reduce_report(distributed, rccl_err, rank_kernel_ms, rank_reduce_us),
+            "ranks": rank_lines,
             "device": device,
             "cpu_baseline": cpu_baseline,
             "parity_sample_ok": parity,
