@@ -334,6 +334,29 @@ int sk_bam_walk_reduce_dev(sk_ctx *ctx, const uint8_t *stream, uint64_t stream_l
 int sk_bam_file_reduce(sk_ctx *ctx, const char *path, int32_t max_frag, uint64_t counters[3], uint64_t *hist,
                        uint64_t *hist_total, int *handled, double info[8]);
 
+/* ---- F2 on the device: the gzip writers' DEFLATE ------------------------------------------------
+ * src/common.rs:49-81: every output file of the reference is a pipe into a gzip / pigz child; what a test can hold it to is
+ * the decompressed stream.  sk_bgzf_deflate compresses n independent blocks of at most SK_DEFLATE_MAX_IN bytes (in +
+ * blocks[i].in_off, in_len bytes; host pointers) into n complete BGZF members (SAMv1 §4.1: gzip members with the BC
+ * subfield, CRC32 and ISIZE) written back to back into out: member i is out[out_off[i] .. out_off[i + 1]).  The device
+ * finds the matches (a hash of four bytes, greedy), builds a Huffman code per block and writes the bits; a block that does
+ * not shrink is framed as a stored block.  out_cap >= n * SK_DEFLATE_MAX_MEMBER always suffices.  in must be readable to the
+ * next 4-byte boundary behind its last byte.
+ * sk_bgzf_deflate_dev is the device half alone: slots[i * slot_stride ..] receives block i's DEFLATE payload (slot_stride
+ * >= SK_DEFLATE_SLOT, a multiple of 4), result[2 i] its byte count, crc[i] the CRC-32 of the block's input; tokens is
+ * scratch of n * SK_DEFLATE_MAX_IN dwords.  All pointers device pointers.                                             */
+#define SK_DEFLATE_MAX_IN     0xff00
+#define SK_DEFLATE_MAX_MEMBER 65536
+#define SK_DEFLATE_SLOT       81920
+typedef struct sk_deflate_block {
+	uint64_t in_off;
+	uint32_t in_len, reserved;
+} sk_deflate_block;
+int sk_bgzf_deflate(sk_ctx *ctx, const uint8_t *in, size_t in_bytes, const sk_deflate_block *blocks, int64_t n_blocks,
+                    uint8_t *out, size_t out_cap, uint64_t *out_off);
+int sk_bgzf_deflate_dev(sk_ctx *ctx, const uint8_t *in, const sk_deflate_block *blocks, int64_t n_blocks, uint8_t *slots,
+                        uint32_t slot_stride, uint32_t *tokens, uint32_t *result, uint32_t *crc);
+
 /* ---- f2: `sam fragments` record filter ---------------------------------------------------------------------
  * src/sam_fragments.rs:27-38: keep the forward mate of a converging, mapped, primary, non-duplicate, QC-passing pair on
  * one reference whose |tlen| lies in [min_size, max_size].  keep_bits: (n+7)/8 bytes, bit j of byte k <=> record 8k+j;

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(ROOT, "lib")
 BINDIR = os.path.join(ROOT, "bin")
 LIB_PATH = os.path.join(LIBDIR, "libseqkit_hip.so")
 
-HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_inflate.hip", "sk_capi.hip", "sk_bamfile.cpp", "sk_lut.cpp"]
+HIP_SOURCES = ["sk_kernels.hip", "sk_census.hip", "sk_inflate.hip", "sk_deflate.hip", "sk_capi.hip", "sk_bamfile.cpp", "sk_lut.cpp"]
 HIP_DEPS = HIP_SOURCES + ["sk_internal.h", "sk_lut.h", os.path.join(REPO, "include", "seqkit_hip.h")]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 

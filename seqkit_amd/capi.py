@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "sk_blocked_layout_init", "sk_fused_pass_blocked_dev", "sk_fused_tune_placement_dev",
     "sk_counts_reset", "sk_counts_get", "sk_counts_device_ptr",
     "sk_comm_ready", "sk_comm_get_unique_id", "sk_comm_init_rank", "sk_comm_destroy", "sk_counts_allreduce", "sk_allreduce_u64_dev", "sk_bam_flag_tlen", "sk_bam_flag_tlen_dev",
-    "sk_bgzf_inflate_dev", "sk_bam_walk_dev", "sk_bam_walk_reduce_dev", "sk_bam_file_reduce",
+    "sk_bgzf_deflate", "sk_bgzf_deflate_dev", "sk_bgzf_inflate_dev", "sk_bam_walk_dev", "sk_bam_walk_reduce_dev", "sk_bam_file_reduce",
     "sk_bam_fragments", "sk_bam_fragments_dev", "sk_bam_sequence", "sk_bam_sequence_dev",
     "sk_count_set_regions", "sk_count_add", "sk_count_add_dev", "sk_count_get", "sk_gc_set_genome", "sk_gc_count",
     "sk_census_reset", "sk_census_add", "sk_census_add_dev", "sk_census_stats", "sk_census_count_hist", "sk_census_entries",
@@ -184,6 +184,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "sk_counts_allreduce": (i32, [C.POINTER(vp), i32]), "sk_allreduce_u64_dev": (i32, [vp, vp, C.c_size_t]),
         "sk_bam_flag_tlen": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "sk_bam_flag_tlen_dev": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
+        "sk_bgzf_deflate": (i32, [vp, vp, C.c_size_t, vp, i64, vp, C.c_size_t, vp]),
+        "sk_bgzf_deflate_dev": (i32, [vp, vp, vp, i64, vp, C.c_uint32, vp, vp, vp]),
         "sk_bgzf_inflate_dev": (i32, [vp, vp, vp, i64, vp, vp, i32]),
         "sk_bam_walk_dev": (i32, [vp, vp, C.c_uint64, vp, i64, C.c_uint64, i32, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(i32)]),
         "sk_bam_walk_reduce_dev": (i32, [vp, vp, C.c_uint64, vp, vp, i64, i32, i32, i32, vp]),
@@ -289,6 +291,21 @@ class Context:
     # ---- lifetime / memory --------------------------------------------------------------
     def sync(self) -> None:
         self._check(self._lib.sk_sync(self._h), "sk_sync")
+
+    # ---- F2 on the device: BGZF deflate (host pointers) ----
+    DEFLATE_BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("reserved", "<u4")])
+
+    def bgzf_deflate(self, data: bytes, block: int = 0xff00) -> bytes:
+        """sk_bgzf_deflate: `data` cut into blocks of `block` bytes, every one a BGZF member; the members back to back."""
+        n = max(1, -(-len(data) // block)) if data else 0
+        blocks = np.zeros(n, dtype=self.DEFLATE_BLOCK_DTYPE)
+        for i in range(n):
+            blocks[i] = (i * block, min(block, len(data) - i * block), 0)
+        src = np.frombuffer(data + bytes(8), dtype=np.uint8)
+        out = np.empty(n * 65536 + 64, dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self._check(self._lib.sk_bgzf_deflate(self._h, src.ctypes.data, len(data), blocks.ctypes.data, n, out.ctypes.data, out.nbytes, off.ctypes.data), "sk_bgzf_deflate")
+        return out[:int(off[n])].tobytes()
 
     # ---- B1 on the device: BGZF inflate, record walk (all pointers are device addresses) ----
     BGZF_BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8"), ("crc32", "<u4"), ("reserved", "<u4")])

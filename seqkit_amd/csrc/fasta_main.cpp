@@ -876,9 +876,11 @@ static int demultiplex(int argc, char **argv)
 			else if (sm.barcode.size() != barcode_len) error("Barcodes in sample sheet must all be of same length.");   // :71-73
 			if (dry_run > 0) {
 			} else if (paired_end) {                                        // :79-83
+				host::gz_deflate_on_device(true);                        // (this command has the GPU anyway: the per-sample members are deflated there)
 				sm.out[0].reset(new host::GzWriter(sm.name + "_1.fq.gz"));
 				sm.out[1].reset(new host::GzWriter(sm.name + "_2.fq.gz"));
 			} else {                                                        // :84-87
+				host::gz_deflate_on_device(true);
 				sm.out[0].reset(new host::GzWriter(sm.name + ".fq.gz"));
 			}
 			samples.push_back(std::move(sm));

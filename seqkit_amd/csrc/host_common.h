@@ -74,6 +74,10 @@ private:
 // Replaces GzipWriter (src/common.rs:49-81: an unbuffered pipe into one `gzip`/`pigz` child per file).  Output is cut
 // into blocks that a shared pool of threads deflates into independent gzip members (a valid .gz is any concatenation
 // of members; `gunzip`/zlib read them transparently); each file's members are written in submission order.
+// Where the members are deflated: on the CPU threads (the default), or on the device (include/seqkit_hip.h:
+// sk_bgzf_deflate) — a command that uses the GPU anyway asks for that BEFORE its first writer writes; SEQKIT_GPU_DEFLATE=0 / 1
+// overrides either way.  The decompressed streams are the same bytes.
+void gz_deflate_on_device(bool on);
 class GzWriter {
 public:
 	explicit GzWriter(const std::string &path);          // "Cannot open file {} for writing."

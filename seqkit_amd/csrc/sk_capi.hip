@@ -48,6 +48,8 @@ struct sk_ctx {
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
+	uint8_t *pin = nullptr;            // a pinned landing area (sk_bgzf_deflate: the compressed slots come back here)
+	size_t pin_bytes = 0;
 	sk::Census *census = nullptr;
 	ncclComm_t comm = nullptr;         // one-process-per-GPU communicator (sk_comm_init_rank)
 	int comm_ranks = 0;
@@ -208,6 +210,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_counts_wide) (void)hipFree(c->d_counts_wide);
 	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
+	if (c->pin) (void)hipHostFree(c->pin);
 	if (c->census) sk::census_destroy(c->census);
 	if (c->comm) (void)sk_comm_destroy(c);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
@@ -1324,6 +1327,79 @@ int sk_bam_walk_reduce_dev(sk_ctx *c, const uint8_t *stream, uint64_t stream_len
 	return SK_OK;
 }
 
+
+// ---- F2 on the device (sk_deflate.hip) -------------------------------------------------------------------------------
+int sk_bgzf_deflate_dev(sk_ctx *c, const uint8_t *in, const sk_deflate_block *blocks, int64_t n_blocks, uint8_t *slots, uint32_t slot_stride,
+                        uint32_t *tokens, uint32_t *result, uint32_t *crc)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_blocks < 0) return fail(c, SK_ERR_INVALID, "n_blocks = %lld", (long long)n_blocks);
+	if (n_blocks == 0) return SK_OK;
+	if (!in || !blocks || !slots || !tokens || !result || !crc) return fail(c, SK_ERR_INVALID, "NULL in, blocks, slots, tokens, result or crc");
+	if (slot_stride < SK_DEFLATE_SLOT || (slot_stride & 3u) || ((uintptr_t)slots & 3u)) return fail(c, SK_ERR_INVALID, "slot_stride = %u (>= %d, a multiple of 4), slots 4-byte aligned", slot_stride, SK_DEFLATE_SLOT);
+	if (int r = bind(c)) return r;
+	SK_HIP(c, sk::launch_bgzf_deflate(in, blocks, n_blocks, slots, slot_stride, tokens, result, crc, c->n_cu, c->stream));
+	return SK_OK;
+}
+
+int sk_bgzf_deflate(sk_ctx *c, const uint8_t *in, size_t in_bytes, const sk_deflate_block *blocks, int64_t n_blocks, uint8_t *out, size_t out_cap, uint64_t *out_off)
+{
+	if (!c) return SK_ERR_INVALID;
+	if (n_blocks < 0 || !out_off) return fail(c, SK_ERR_INVALID, "n_blocks = %lld, out_off %p", (long long)n_blocks, (void *)out_off);
+	out_off[0] = 0;
+	if (n_blocks == 0) return SK_OK;
+	if (!in || !blocks || !out) return fail(c, SK_ERR_INVALID, "NULL in, blocks or out");
+	for (int64_t i = 0; i < n_blocks; i++)
+		if (blocks[i].in_len > SK_DEFLATE_MAX_IN || blocks[i].in_off + blocks[i].in_len > in_bytes)
+			return fail(c, SK_ERR_INVALID, "block %lld: %u bytes at %llu of %zu (at most %d a block)", (long long)i, blocks[i].in_len, (unsigned long long)blocks[i].in_off, in_bytes, SK_DEFLATE_MAX_IN);
+	if (int r = bind(c)) return r;
+	const size_t n = (size_t)n_blocks;
+	const size_t b_in = up256(in_bytes + 8), b_blk = up256(n * sizeof(sk_deflate_block)), b_slots = up256(n * (size_t)SK_DEFLATE_SLOT);
+	const size_t b_tok = up256(n * (size_t)SK_DEFLATE_MAX_IN * 4), b_res = up256(n * 8), b_crc = up256(n * 4);
+	if (int r = ensure_ws(c, b_in + b_blk + b_slots + b_tok + b_res + b_crc)) return r;
+	uint8_t *d_in = c->ws, *d_blk = d_in + b_in, *d_slots = d_blk + b_blk, *d_tok = d_slots + b_slots, *d_res = d_tok + b_tok, *d_crc = d_res + b_res;
+	// a pinned landing area for the slots (the ctx keeps it)
+	if (c->pin_bytes < b_slots) {
+		if (c->pin) { SK_HIP(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+		SK_HIP(c, hipHostMalloc((void **)&c->pin, b_slots + (b_slots >> 2), hipHostMallocDefault));
+		c->pin_bytes = b_slots + (b_slots >> 2);
+	}
+	SK_HIP(c, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+	SK_HIP(c, hipMemsetAsync(d_in + in_bytes, 0, 8, c->stream));
+	SK_HIP(c, hipMemcpyAsync(d_blk, blocks, n * sizeof(sk_deflate_block), hipMemcpyHostToDevice, c->stream));
+	SK_HIP(c, sk::launch_bgzf_deflate(d_in, d_blk, n_blocks, d_slots, SK_DEFLATE_SLOT, (uint32_t *)d_tok, (uint32_t *)d_res, (uint32_t *)d_crc, c->n_cu, c->stream));
+	std::vector<uint32_t> res(2 * n), crc(n);
+	SK_HIP(c, hipMemcpyAsync(res.data(), d_res, n * 8, hipMemcpyDeviceToHost, c->stream));
+	SK_HIP(c, hipMemcpyAsync(crc.data(), d_crc, n * 4, hipMemcpyDeviceToHost, c->stream));
+	SK_HIP(c, hipMemcpyAsync(c->pin, d_slots, n * (size_t)SK_DEFLATE_SLOT, hipMemcpyDeviceToHost, c->stream));
+	SK_HIP(c, hipStreamSynchronize(c->stream));
+	static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+	size_t at = 0;
+	for (size_t i = 0; i < n; i++) {
+		const uint32_t len = blocks[i].in_len, pay = res[2 * i];
+		const bool stored = pay >= len + 5u || pay + 26u > SK_DEFLATE_MAX_MEMBER;
+		const size_t clen = stored ? (size_t)len + 5 : pay;
+		const size_t bsize = 18 + clen + 8;
+		if (at + bsize > out_cap) return fail(c, SK_ERR_INVALID, "out_cap = %zu is too small (block %zu ends at %zu)", out_cap, i, at + bsize);
+		uint8_t *m = out + at;
+		memcpy(m, head, 16);
+		m[16] = (uint8_t)((bsize - 1) & 0xff);
+		m[17] = (uint8_t)((bsize - 1) >> 8);
+		if (stored) {
+			m[18] = 1;                                                    // BFINAL = 1, BTYPE = 00
+			m[19] = (uint8_t)(len & 0xff); m[20] = (uint8_t)(len >> 8);
+			m[21] = (uint8_t)(~len & 0xff); m[22] = (uint8_t)((~len >> 8) & 0xff);
+			memcpy(m + 23, in + blocks[i].in_off, len);
+		} else {
+			memcpy(m + 18, c->pin + i * (size_t)SK_DEFLATE_SLOT, pay);
+		}
+		uint8_t *t = m + 18 + clen;
+		for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc[i] >> (8 * k)); t[4 + k] = (uint8_t)(len >> (8 * k)); }
+		at += bsize;
+		out_off[i + 1] = at;
+	}
+	return SK_OK;
+}
 
 // ---- f2: sam fragments filter ----------------------------------------------------------------------------------
 int sk_bam_fragments_dev(sk_ctx *c, const uint16_t *flag, const int32_t *tid, const int32_t *mtid, const int32_t *tlen,

@@ -148,6 +148,13 @@ hipError_t launch_bam_walk(const uint8_t *stream, uint64_t stream_len, const uin
 hipError_t launch_bam_walk_reduce(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, const uint64_t *entry, int64_t n, int32_t max_frag,
                                   int want_counters, int want_hist, unsigned long long *out, hipStream_t st);
 
+// ---- BGZF deflate on the device (sk_deflate.hip) ----
+// blocks: device array of sk_deflate_block; out: n_blocks slots of out_stride bytes (a block's payload from the slot's first byte on);
+// tokens: device u32[n_blocks * deflate_tokens_per_block()] scratch; result: device u32[2 n] (payload bytes, tokens); crc: device u32[n]
+hipError_t launch_bgzf_deflate(const uint8_t *in, const void *blocks, int64_t n_blocks, uint8_t *out, uint32_t out_stride, uint32_t *tokens, uint32_t *result,
+                               uint32_t *crc, int n_cu, hipStream_t st);
+size_t deflate_tokens_per_block();
+
 // ---- barcode census (sk_census.hip) ----
 struct Census;
 struct CensusEntry {            // == sk_census_entry of include/seqkit_hip.h
