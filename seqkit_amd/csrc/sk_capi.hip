@@ -48,6 +48,10 @@ struct sk_ctx {
 	// workspace for the host-pointer entry points
 	uint8_t *ws = nullptr;
 	size_t ws_bytes = 0;
+	// sk_fused_pass_many_dev: the batch descriptors of a many-batch launch travel through a ring of pinned / device slots
+	sk::ManyBatch *many_pin = nullptr, *many_dev = nullptr;
+	hipEvent_t many_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	int many_next = 0;
 	uint8_t *pin = nullptr;            // a pinned landing area (sk_bgzf_deflate: the compressed slots come back here)
 	size_t pin_bytes = 0;
 	sk::Census *census = nullptr;
@@ -65,6 +69,8 @@ struct sk_ctx {
 };
 
 static thread_local std::string g_create_err;
+
+static constexpr int kManySlots = 8, kManyMax = 256;     // sk_fused_pass_many_dev: descriptor slots in the ring, batches per launch
 
 static int fail(sk_ctx *c, int code, const char *fmt, ...)
 {
@@ -211,6 +217,9 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->pin) (void)hipHostFree(c->pin);
+	if (c->many_pin) (void)hipHostFree(c->many_pin);
+	if (c->many_dev) (void)hipFree(c->many_dev);
+	for (hipEvent_t e : c->many_ev) if (e) (void)hipEventDestroy(e);
 	if (c->census) sk::census_destroy(c->census);
 	if (c->comm) (void)sk_comm_destroy(c);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
@@ -826,12 +835,11 @@ static void one_mate(sk_fused_args &a, const uint8_t *seq, const uint8_t *qual, 
 // Many independent batches in one call: every batch is checked, the sheet's table goes up once, and the launches
 // follow each other on the ctx stream with nothing between them — what a host that has its batches at hand gets without a call,
 // an argument check and an event per batch (bench.py: `frac_many` against `frac`, one event pair per call).
-// What this does NOT yet do is run the batches as ONE persistent launch.  Measured first (round 6, gpurun_out/r06_l): the batches
-// dealt to four streams behind one fork event, so that a batch's workgroups start on the CUs its predecessor has left — SLOWER
-// than one stream (10 M x 8 bp: 0.47 of the HBM peak against 0.58 per call and 0.62 back to back; 96 dual-index 0.46 / 0.53 / 0.56):
-// two lookup kernels on a CU are thirty-two waves where sixteen stream best (launch_tile_pass), and every batch pays two more
-// events.  The remaining form — the quads of all batches dealt to one launch's waves, tables staged once — needs the batch
-// boundary inside the lookup kernels' prefetch and is not built.
+// Lookups of one shape (demultiplex alone, a table in LDS) run as ONE launch: the steps of all batches are dealt to the launch's
+// waves, the table is staged once, the next batch's rows are fetched while the last of this one are looked up (ManyBatch,
+// demux_lut8x2_kernel).  Measured before that (round 6, gpurun_out/r06_l): the batches dealt to four streams behind one fork event
+// — SLOWER than one stream (10 M x 8 bp: 0.47 of the HBM peak against 0.58 per call and 0.62 back to back): two lookup kernels
+// on a CU are thirty-two waves where sixteen stream best, and every batch pays two more events.
 int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batches)
 {
 	if (!c) return SK_ERR_INVALID;
@@ -839,6 +847,62 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 	if (n_batches == 0) return SK_OK;
 	if (int r = bind(c)) return r;
 	for (int i = 0; i < n_batches; i++) if (int r = check_fused(c, &batches[i], true)) return r;
+	// ONE launch for all of them when they are lookups of one shape: demultiplex alone into the ctx's counters, the same pitch and the
+	// same set of output columns, served by a table in LDS (launch_tile_pass says no for any other shape: the loop below)
+	{
+		bool same = n_batches >= 2;
+		int64_t rows = 0;
+		for (int i = 0; i < n_batches && same; i++) {
+			const sk_fused_args &a = batches[i], &f = batches[0];
+			bool mates = false;
+			for (int m = 0; m < a.n_mates; m++) mates = mates || a.mate[m].out_seq || a.mate[m].lowest_k;
+			same = !mates && a.bc && !a.counts && a.bc_stride == f.bc_stride && !a.lowest_diff == !f.lowest_diff && !a.first_idx == !f.first_idx && !a.last_idx == !f.last_idx;
+			rows += ((a.n + 255) / 256) * 256;
+		}
+		if (same && rows > 0 && rows < ((int64_t)1 << 31) && n_batches <= kManyMax) {
+			if (int r = prepare_demux(c, &batches[0])) return r;
+			if (!c->many_pin) {
+				SK_HIP(c, hipHostMalloc((void **)&c->many_pin, kManySlots * kManyMax * sizeof(sk::ManyBatch), hipHostMallocDefault));
+				SK_HIP(c, hipMalloc((void **)&c->many_dev, kManySlots * kManyMax * sizeof(sk::ManyBatch)));
+				for (int k = 0; k < kManySlots; k++) SK_HIP(c, hipEventCreateWithFlags(&c->many_ev[k], hipEventDisableTiming));
+			}
+			const int slot = c->many_next++ % kManySlots;
+			SK_HIP(c, hipEventSynchronize(c->many_ev[slot]));                // (the launch that read this slot eight calls ago: long done)
+			sk::ManyBatch *hb = c->many_pin + (size_t)slot * kManyMax, *db = c->many_dev + (size_t)slot * kManyMax;
+			int64_t q0 = 0;
+			int nb = 0;
+			for (int i = 0; i < n_batches; i++) {
+				const sk_fused_args &a = batches[i];
+				if (a.n == 0) continue;
+				const int64_t r0 = q0 * 256;
+				sk::ManyBatch &m = hb[nb++];
+				m.bc = a.bc - r0 * a.bc_stride;
+				m.assign = a.assign - r0;
+				m.lowest_diff = a.lowest_diff ? a.lowest_diff - r0 : nullptr;
+				m.first_idx = a.first_idx ? a.first_idx - r0 : nullptr;
+				m.last_idx = a.last_idx ? a.last_idx - r0 : nullptr;
+				m.row_end = (uint32_t)(r0 + a.n);
+				q0 += (a.n + 255) / 256;
+				m.q_end = (int32_t)q0;
+			}
+			if (nb > 0) {
+				// (the kernel reads the descriptors where they lie, in pinned host memory: a wave reads one when its cursor moves to the next
+				// batch — a copy of 200 bytes in front of the launch was 10 us on the stream, a tenth of what four batches take)
+				(void)db;
+				sk_fused_args first = batches[0];
+				for (int i = 0; i < n_batches; i++) if (batches[i].n > 0) { first = batches[i]; break; }
+				sk::TileArgs t = tile_args_of(c, &first);
+				t.n = q0 * 256;
+				t.many = hb; t.n_many = nb; t.many_quads = (int)q0;
+				if (t.counts_wide) c->wide_dirty = true;
+				const hipError_t e = sk::launch_tile_pass(t, c->n_cu, c->stream);
+				SK_HIP(c, hipEventRecord(c->many_ev[slot], c->stream));
+				if (e == hipSuccess) return SK_OK;
+				if (e != hipErrorNotSupported) return fail(c, SK_ERR_HIP, "launch_tile_pass (many batches): %s", hipGetErrorString(e));
+				(void)hipGetLastError();
+			} else return SK_OK;
+		}
+	}
 	for (int i = 0; i < n_batches; i++) {
 		const sk_fused_args *a = &batches[i];
 		if (a->n == 0) continue;

@@ -57,6 +57,19 @@ constexpr int kCountReplicas = 16;
 constexpr int kMaxBitSlicedLen = 31;     // 5 counter planes
 constexpr int kMaxBitSlicedBytes = 24 * 1024;
 
+// One batch of a many-batch lookup launch (TileArgs::many).  The launch numbers the steps (256 rows each) of all batches in a row:
+// batch b's are [q_begin_b, q_end).  Its pointers are BIASED by its first step — bc - q_begin * 256 * bc_stride, assign - q_begin *
+// 256 and so on — so that the kernel's address of launch step gq, row r lands on the batch's own step gq - q_begin; its rows end at
+// launch row row_end = q_begin * 256 + n (the launch's rows stay below 2^31).
+struct ManyBatch {
+	const uint8_t *bc;
+	int32_t *assign;
+	uint8_t *lowest_diff;
+	int16_t *first_idx, *last_idx;
+	uint32_t row_end;
+	int32_t q_end;
+};
+
 struct TileArgs {
 	int64_t n;
 	int n_mates;
@@ -79,6 +92,8 @@ struct TileArgs {
 	                                    // S + 3, a workgroup adds to row blockIdx.x % rows — a thousand counters at a line each are a thousand
 	                                    // uncoalesced atomics per workgroup, 17 us at the end of a 10 M-pair call of a 1 000-sample sheet
 	int counts_wide_rows;
+	const ManyBatch *many;          // or nullptr.  Device array of n_many batches: the lookup kernels then walk the steps of all of them in one launch
+	int n_many, many_quads;         // (n = the rows of all batches, for the launch's shape; bc / assign / detail pointers above are not used)
 };
 constexpr int kCountWideShift = 4;
 constexpr int kCountDenseFrom = 160;     // S + 3 above this: dense rows

@@ -1432,7 +1432,7 @@ template <int N> __device__ __forceinline__ void gather_dwords(rsrc_t rb, int of
 // ---------------------------------------------------------------------------------------------------
 //   PAIR   : the factored form of sk_lut.h (a sheet `i7+i5` whose full-key table would not fit the LDS): one lookup per half
 //            (-> half id, distance) and one of the pair of ids (-> first / last sample); three small tables in one LDS blob
-template <int W1, int W2, bool DIRECT, bool LDSTAB, bool DETAIL, bool PAIR = false>
+template <int W1, int W2, bool DIRECT, bool LDSTAB, bool DETAIL, bool PAIR = false, bool MANY = false>
 __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const TileArgs a, const LdsPlan lp)
 {
 	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
 	const LutDev &t = a.table.nbr;
 	const int S = a.table.S;
-	const int64_t ntiles = (a.n + kTileRows - 1) / kTileRows;
+	const int64_t ntiles = MANY ? 4 * (int64_t)a.many_quads : (a.n + kTileRows - 1) / kTileRows;      // (MANY: demux_lut8x2_kernel's note; a quad here is four tiles)
 	const int bstride = a.bc_stride;
 	// tiles of a wave on their way: two (a quad's four tiles take the register slots in turn: 1, 2 or 4; replayed on on-die rows
 	// at 10 M pairs more were slower in round 4, from HBM 1 / 2 / 4 take the same time); four for the factored form, whose three
@@ -1466,9 +1466,33 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	// tiles are counted in 32 bits (launch_tile_pass checks); a tile past the last clips to nothing (zero-record descriptors)
 	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kTileRows);
 	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kTileRows : (ti == nt32 - 1 ? last_rows : 0); };
+	auto rows_many = [&](int ti, u32 row_end) {
+		const int left = (int)(row_end - (u32)ti * (u32)kTileRows);
+		return left <= 0 ? 0 : (left < kTileRows ? left : kTileRows);
+	};
+	struct BatchView { const uint8_t *bc; u32 row_end; int q_end; };      // (read when a cursor moves, not per tile: demux_lut8x2_kernel's note)
+	int cb = 0, fb = 0;                                                  // MANY: the batch of the quad at hand / of the quad behind it in the wave's sequence
+	BatchView cv = {nullptr, 0u, 0}, fv = {nullptr, 0u, 0};
+	int32_t *c_assign = nullptr;
+	uint8_t *c_low = nullptr;
+	int16_t *c_first = nullptr, *c_last = nullptr;
+	auto view_of = [&](int i) { const ManyBatch &m = a.many[i]; return BatchView{m.bc, m.row_end, m.q_end}; };
+	auto seek = [&](int gq, int &cur, BatchView &v) {
+		bool moved = false;
+		while (cur + 1 < a.n_many && gq >= v.q_end) { cur++; v = view_of(cur); moved = true; }
+		return moved;
+	};
+	if (MANY) {
+		cv = fv = view_of(0);
+		c_assign = a.many[0].assign; c_low = a.many[0].lowest_diff; c_first = a.many[0].first_idx; c_last = a.many[0].last_idx;
+	}
+	int cur_quad = 0;                                                    // MANY: fetch() takes a tile of this quad from batch cb, any other from fb
 	auto fetch = [&](int ti, int s) {
-		const int rows = rows_of(ti);
-		const rsrc_t rb = make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kTileRows * bstride), (rows * bstride + 3) & ~3);
+		const bool mine = (ti >> 2) == cur_quad;
+		const u32 m_end = mine ? cv.row_end : fv.row_end;
+		const uint8_t *m_bc = mine ? cv.bc : fv.bc;
+		const int rows = MANY ? rows_many(ti, m_end) : rows_of(ti);
+		const rsrc_t rb = make_rsrc(MANY ? m_bc : a.bc, (int64_t)(rows ? ti : 0) * (kTileRows * bstride), (rows * bstride + 3) & ~3);
 		if (DIRECT) {
 			if (W == 2) {
 				const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rb, lane * bstride, 0, kLutAux);
@@ -1489,6 +1513,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	// order, so nothing waits but the read's consumer).
 	const int qstep = (int)gridDim.x * nwave;
 	int qb = (int)blockIdx.x * nwave + wave;
+	if (MANY) { seek(qb, cb, cv); fb = cb; fv = cv; seek(qb + qstep, fb, fv); cur_quad = qb; if (cb != 0) { const ManyBatch &mb = a.many[cb]; c_assign = mb.assign; c_low = mb.lowest_diff; c_first = mb.first_idx; c_last = mb.last_idx; } }
 	for (int s = 0; s < kDepth; s++) fetch(4 * qb + s, s);
 	
 	// the table and the histogram while the first tiles are on their way
@@ -1536,12 +1561,22 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 	const int nq32 = (nt32 + 3) >> 2;
 	for (; qb < nq32; qb += qstep) {
 		int code[4], dtot[4], dfirst[4], dlast[4];
+		u32 q_row_end = (u32)a.n;
+		int32_t *q_assign = a.assign;
+		uint8_t *q_low = a.lowest_diff;
+		int16_t *q_first = a.first_idx, *q_last = a.last_idx;
+		if (MANY) {
+			if (seek(qb, cb, cv)) { const ManyBatch &mb = a.many[cb]; c_assign = mb.assign; c_low = mb.lowest_diff; c_first = mb.first_idx; c_last = mb.last_idx; }
+			cur_quad = qb;
+			q_row_end = cv.row_end; q_assign = c_assign; q_low = c_low; q_first = c_first; q_last = c_last;
+			seek(qb + qstep, fb, fv);
+		}
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			constexpr int kD = kDepth;
 			const int s = j % kD;
 			const int ti = 4 * qb + j;
-			const int rows = rows_of(ti);
+			const int rows = MANY ? rows_many(ti, q_row_end) : rows_of(ti);
 			const bool active = lane < rows;
 			const int nj = j + kD;                                       // the tile that takes this one's register slot
 			const int tnext = nj < 4 ? 4 * qb + nj : 4 * (qb + qstep) + (nj - 4);
@@ -1629,12 +1664,13 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 		}
 		// the quad's outputs
 		const int64_t ro = (int64_t)qb * (4 * kTileRows);
-		const int rows_q = (int)(a.n - ro < 4 * kTileRows ? a.n - ro : 4 * kTileRows);
+		const int rows_q = MANY ? rows_many(4 * qb, q_row_end) + rows_many(4 * qb + 1, q_row_end) + rows_many(4 * qb + 2, q_row_end) + rows_many(4 * qb + 3, q_row_end)
+		                        : (int)(a.n - ro < 4 * kTileRows ? a.n - ro : 4 * kTileRows);
 #pragma unroll
 		for (int j = 0; j < 4; j++) tp[kTileRows * j + lane] = (u32)code[j];
 		wave_lds_fence();
 		const u32x4 cv = *reinterpret_cast<const u32x4 *>(tp + 4 * lane);
-		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(a.assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
+		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(q_assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
 		if (DETAIL) {
 			if (rows_q == 4 * kTileRows) {
 				// (the same exchange for the three narrow columns, one after the other through the same 1 KiB: 4 bytes, 8 and 8 per lane)
@@ -1644,20 +1680,20 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				for (int j = 0; j < 4; j++) tp8[kTileRows * j + lane] = (uint8_t)dtot[j];
 				wave_lds_fence();
 				const u32 dv = tp[lane];
-				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(a.lowest_diff, ro, rows_q), lane * 4, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(q_low, ro, rows_q), lane * 4, 0, kLutStAux);
 				wave_lds_fence();
 				unsigned short *tp16 = reinterpret_cast<unsigned short *>(tp);
 #pragma unroll
 				for (int j = 0; j < 4; j++) tp16[kTileRows * j + lane] = (unsigned short)dfirst[j];
 				wave_lds_fence();
 				const u32x2_t fv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
-				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(a.first_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(q_first, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
 				wave_lds_fence();
 #pragma unroll
 				for (int j = 0; j < 4; j++) tp16[kTileRows * j + lane] = (unsigned short)dlast[j];
 				wave_lds_fence();
 				const u32x2_t lv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
-				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(a.last_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(q_last, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
 				wave_lds_fence();
 			} else {
 				// the call's last, partial quad: a descriptor clips whole elements, so the narrow columns go row by row
@@ -1665,9 +1701,9 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 				for (int j = 0; j < 4; j++) {
 					const int rj = rows_q - kTileRows * j < 0 ? 0 : (rows_q - kTileRows * j > kTileRows ? kTileRows : rows_q - kTileRows * j);
 					const int64_t rt = ro + kTileRows * j;
-					__builtin_amdgcn_raw_buffer_store_b8((uint8_t)dtot[j], make_rsrc(a.lowest_diff, rj ? rt : 0, rj), lane, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dfirst[j], make_rsrc(a.first_idx, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dlast[j], make_rsrc(a.last_idx, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b8((uint8_t)dtot[j], make_rsrc(q_low, rj ? rt : 0, rj), lane, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dfirst[j], make_rsrc(q_first, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)dlast[j], make_rsrc(q_last, (rj ? rt : 0) * 2, rj * 2), lane * 2, 0, 0);
 				}
 			}
 		}
@@ -1686,7 +1722,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut_kernel(const Ti
 // its two rows with one 16-byte load (1 KiB per wave instruction instead of 512 B, nt: read once); a wave's step is two
 // consecutive tiles, whose four codes per lane leave as one 16-byte store after changing lanes through LDS; the per-tile scalar
 // work (descriptors, clipping, counters) is paid once per 128 rows.  Everything per row is as above.
-template <bool LDSTAB, bool DETAIL>
+template <bool LDSTAB, bool DETAIL, bool MANY = false>
 __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const TileArgs a, const LdsPlan lp)
 {
 	typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
@@ -1697,12 +1733,43 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	u32 *hist = reinterpret_cast<u32 *>(sk_smem + lp.hist_off);
 	const LutDev &t = a.table.nbr;
 	const int S = a.table.S;
-	const int64_t ntiles = (a.n + kRows - 1) / kRows;
+	// MANY (round 6; TileArgs::many): the steps of SEVERAL batches in one launch — a batch's pointers are biased so that step gq of the
+	// launch addresses the batch's own rows with the launch's indices (ManyBatch), its rows end at row_end; a wave's steps go up, so
+	// two cursors (the batch of the step at hand, the batch of the step being fetched) only move forward.  The table is staged
+	// once, no wave waits at a batch's end, and the next batch's first rows are on their way while the last of this one are looked up.
+	const int64_t ntiles = MANY ? 2 * (int64_t)a.many_quads : (a.n + kRows - 1) / kRows;
 	const int nt32 = (int)ntiles, last_rows = (int)(a.n - (ntiles - 1) * kRows);
 	auto rows_of = [&](int ti) { return ti < nt32 - 1 ? kRows : (ti == nt32 - 1 ? last_rows : 0); };
+	auto rows_many = [&](int ti, u32 row_end) {
+		const int left = (int)(row_end - (u32)ti * (u32)kRows);
+		return left <= 0 ? 0 : (left < kRows ? left : kRows);
+	};
+	// (a batch's fields are read when a cursor moves — once per batch and wave —, not per step: a scalar load per fetch waited for the
+	// LDS as well, and the many-batch launch ran at 0.47 of the HBM peak where the calls back to back did 0.58)
+	struct BatchView { const uint8_t *bc; u32 row_end; int q_end; };
+	int cb = 0, fb = 0;                                                  // MANY: the batch of the step at hand / of the step being fetched
+	BatchView cv = {nullptr, 0u, 0}, fv = {nullptr, 0u, 0};
+	int32_t *c_assign = nullptr;
+	uint8_t *c_low = nullptr;
+	int16_t *c_first = nullptr, *c_last = nullptr;
+	auto view_of = [&](int i) { const ManyBatch &m = a.many[i]; return BatchView{m.bc, m.row_end, m.q_end}; };
+	auto seek = [&](int gq, int &cur, BatchView &v) {
+		bool moved = false;
+		while (cur + 1 < a.n_many && gq >= v.q_end) { cur++; v = view_of(cur); moved = true; }
+		return moved;
+	};
+	if (MANY) {
+		cv = fv = view_of(0);
+		c_assign = a.many[0].assign; c_low = a.many[0].lowest_diff; c_first = a.many[0].first_idx; c_last = a.many[0].last_idx;
+	}
 	constexpr int kDepth = 2;                                            // halves of a step on their way (one step = 2 KiB per wave)
 	u32x4 raw[kDepth];
 	auto fetch = [&](int ti, int s) {
+		if (MANY) {
+			const int rows = rows_many(ti, fv.row_end);
+			raw[s] = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(fv.bc, (int64_t)(rows ? ti : 0) * (kRows * 8), rows * 8), lane * 16, 0, kLut8Aux);
+			return;
+		}
 		const int rows = rows_of(ti);
 		raw[s] = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.bc, (int64_t)(rows ? ti : 0) * (kRows * 8), rows * 8), lane * 16, 0, kLut8Aux);
 	};
@@ -1710,6 +1777,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	// demux_lut_kernel's quads: two ds_write_b64, one ds_read_b128 through 1 KiB of LDS per wave)
 	const int qstep = (int)gridDim.x * nwave;
 	int qb = (int)blockIdx.x * nwave + wave;
+	if (MANY) seek(qb, fb, fv);
 #pragma unroll
 	for (int s = 0; s < kDepth; s++) fetch(2 * qb + s, s);
 	for (int i = threadIdx.x; i < S + 3; i += blockDim.x) hist[i] = 0u;
@@ -1754,10 +1822,20 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 	const int nq32 = (nt32 + 1) >> 1;
 	for (; qb < nq32; qb += qstep) {
 		int code[2][2], tot[2][2], first[2][2], last[2][2];
+		// where this step's rows end and its outputs go (MANY: the batch's; else the call's)
+		u32 q_row_end = (u32)a.n;
+		int32_t *q_assign = a.assign;
+		uint8_t *q_low = a.lowest_diff;
+		int16_t *q_first = a.first_idx, *q_last = a.last_idx;
+		if (MANY) {
+			if (seek(qb, cb, cv)) { const ManyBatch &mb = a.many[cb]; c_assign = mb.assign; c_low = mb.lowest_diff; c_first = mb.first_idx; c_last = mb.last_idx; }
+			q_row_end = cv.row_end; q_assign = c_assign; q_low = c_low; q_first = c_first; q_last = c_last;
+			seek(qb + qstep, fb, fv);
+		}
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
 			const int ti = 2 * qb + s;
-			const int rows = rows_of(ti);
+			const int rows = MANY ? rows_many(ti, q_row_end) : rows_of(ti);
 			const u32x4 d = raw[s];
 			fetch(2 * (qb + qstep) + s, s);
 #pragma unroll
@@ -1796,7 +1874,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 		}
 		// the step's outputs: lane l holds rows 2 l, 2 l + 1 of either tile; it leaves with rows 4 l ... 4 l + 3 of the step
 		const int64_t ro = (int64_t)qb * (2 * kRows);
-		const int rows_q = (int)(a.n - ro < 2 * kRows ? a.n - ro : 2 * kRows);
+		const int rows_q = MANY ? rows_many(2 * qb, q_row_end) + rows_many(2 * qb + 1, q_row_end) : (int)(a.n - ro < 2 * kRows ? a.n - ro : 2 * kRows);
 #pragma unroll
 		for (int s = 0; s < 2; s++) {
 			u32x2_t v;
@@ -1805,7 +1883,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 		}
 		wave_lds_fence();
 		const u32x4 cv = *reinterpret_cast<const u32x4 *>(tp + 4 * lane);
-		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(a.assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
+		__builtin_amdgcn_raw_buffer_store_b128(cv, make_rsrc(q_assign, ro * 4, rows_q * 4), lane * 16, 0, kLutStAux);
 		if (DETAIL) {
 			if (rows_q == 2 * kRows) {
 				wave_lds_fence();
@@ -1814,19 +1892,19 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				for (int s = 0; s < 2; s++) tp16[(kRows * s) / 2 + lane] = (unsigned short)((tot[s][0] & 0xff) | (tot[s][1] << 8));
 				wave_lds_fence();
 				const u32 dv = tp[lane];
-				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(a.lowest_diff, ro, rows_q), lane * 4, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b32(dv, make_rsrc(q_low, ro, rows_q), lane * 4, 0, kLutStAux);
 				wave_lds_fence();
 #pragma unroll
 				for (int s = 0; s < 2; s++) tp[(kRows * s) / 2 + lane] = ((u32)first[s][0] & 0xffffu) | ((u32)first[s][1] << 16);
 				wave_lds_fence();
 				const u32x2_t fv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
-				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(a.first_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b64(fv, make_rsrc(q_first, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
 				wave_lds_fence();
 #pragma unroll
 				for (int s = 0; s < 2; s++) tp[(kRows * s) / 2 + lane] = ((u32)last[s][0] & 0xffffu) | ((u32)last[s][1] << 16);
 				wave_lds_fence();
 				const u32x2_t lv = *reinterpret_cast<const u32x2_t *>(tp + 2 * lane);
-				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(a.last_idx, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
+				__builtin_amdgcn_raw_buffer_store_b64(lv, make_rsrc(q_last, ro * 2, rows_q * 2), lane * 8, 0, kLutStAux);
 				wave_lds_fence();
 			} else {
 				// the call's last, partial step: a descriptor clips whole elements, so the narrow columns go row by row
@@ -1834,7 +1912,7 @@ __global__ __launch_bounds__(LDSTAB ? 1024 : 256) void demux_lut8x2_kernel(const
 				for (int s = 0; s < 2; s++) {
 					const int rj = rows_q - kRows * s < 0 ? 0 : (rows_q - kRows * s > kRows ? kRows : rows_q - kRows * s);
 					const int64_t rt = rj ? ro + kRows * s : 0;
-					const rsrc_t rd = make_rsrc(a.lowest_diff, rt, rj), rf = make_rsrc(a.first_idx, rt * 2, rj * 2), rl = make_rsrc(a.last_idx, rt * 2, rj * 2);
+					const rsrc_t rd = make_rsrc(q_low, rt, rj), rf = make_rsrc(q_first, rt * 2, rj * 2), rl = make_rsrc(q_last, rt * 2, rj * 2);
 #pragma unroll
 					for (int r = 0; r < 2; r++) {
 						__builtin_amdgcn_raw_buffer_store_b8((uint8_t)tot[s][r], rd, lane * 2 + r, 0, 0);
@@ -2071,6 +2149,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		const bool by_table = (b.table.nbr.tab || b.table.nbr.pair.tab) && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
 		hipError_t e;
 		TileArgs bb = b;
+		if (b.many && !by_table) return hipErrorNotSupported;      // (many batches in one launch: the table's kernels only)
 		if (by_table) {
 			const LutDev &t = b.table.nbr;
 			// rows on dword boundaries whose key is one or two dwords: lane r loads row r as it lies (one 8 B/lane load for 8-byte
@@ -2094,6 +2173,15 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			                                 : (want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<false, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<false, false>)))
 			                 : ldstab ? (want_detail ? demux_lut_fn<true, true>(t.W1, t.W2, direct) : demux_lut_fn<true, false>(t.W1, t.W2, direct))
 			                          : (want_detail ? demux_lut_fn<false, true>(t.W1, t.W2, direct) : demux_lut_fn<false, false>(t.W1, t.W2, direct));
+			if (b.many) {
+				// many batches in one launch: the two kernels that serve the benchmark's sheets have the form; any other shape is the caller's loop
+				if (!ldstab) return hipErrorNotSupported;
+				if (rows2) fn = want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false, true>);
+				else if (!direct && t.W1 == 2 && t.W2 == 2)
+					fn = pair ? (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, true, true>))
+					          : (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, false, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, false, true>));
+				else return hipErrorNotSupported;
+			}
 			LdsPlan lp{};
 			lp.use_lds_hist = 1;                                      // S + 3 <= kMaxLdsHist
 			lp.hist_off = 0;
@@ -2134,7 +2222,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			if (ldstab && wg > 1) wg = 1;
 			if (env_wg >= 1) wg = env_wg;
 			const int tile_rows = 4 * kTileRows;                      // a wave's unit: 256 rows in either kernel
-			const int64_t ntiles = (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
+			const int64_t ntiles = b.many ? (int64_t)b.many_quads : (b.n + tile_rows - 1) / tile_rows, want = (ntiles + nw - 1) / nw, cap = (int64_t)n_cu * wg;
 			const int64_t grid = want < cap ? want : cap;
 			// a few hundred workgroups add to the counters directly; thousands go through the spread copies and the fold
 			if (grid <= 512 || bb.counts_wide) bb.table.count_rep = nullptr;
