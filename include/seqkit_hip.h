@@ -168,9 +168,12 @@ typedef struct {
 int sk_fused_pass(sk_ctx *ctx, const sk_fused_args *args);
 int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
 /* Many independent batches in one call: what n_batches calls of sk_fused_pass_dev compute (same outputs; counters are sums, so
- * their order does not matter) — checked once, the sheet's table uploaded once, the launches back to back on the ctx stream
- * (src/fasta_demultiplex.rs:154-194, src/fasta_trim_by_quality.rs:28-42 work per read: reads are independent, so are
- * batches).  Asynchronous like the _dev calls; sk_sync() waits.  The two conveniences below build the argument blocks. */
+ * their order does not matter) — checked once, the sheet's table uploaded once.  Batches that are barcode assignment alone
+ * and whose sheet is served by a table in LDS (sk_barcode_table_info) run as ONE launch whose waves walk the steps of all
+ * batches (at most 256 batches a launch; the table staged once, ramp and tail paid once); every other shape is the
+ * batches' launches back to back on the ctx stream (src/fasta_demultiplex.rs:154-194, src/fasta_trim_by_quality.rs:28-42
+ * work per read: reads are independent, so are batches).  Asynchronous like the _dev calls; sk_sync() waits.  The two
+ * conveniences below build the argument blocks. */
 int sk_fused_pass_many_dev(sk_ctx *ctx, const sk_fused_args *batches, int n_batches);
 typedef struct sk_demux_batch {
 	const uint8_t *bc;          /* n x bc_stride */
