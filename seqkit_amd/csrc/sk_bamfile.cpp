@@ -34,9 +34,11 @@ namespace {
 struct Cleanup {                                 // frees what was allocated, whichever way the function is left
 	std::vector<void *> dev, pinned;
 	std::vector<hipEvent_t> events;
+	std::vector<hipStream_t> streams;
 	int fd = -1;
 	~Cleanup()
 	{
+		for (hipStream_t s : streams) (void)hipStreamDestroy(s);
 		for (void *p : dev) if (p) (void)hipFree(p);
 		for (void *p : pinned) if (p) (void)hipHostFree(p);
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -177,8 +179,25 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	cl.dev.push_back(d_status);
 
 	const double t_alloc = now_ms();
-	size_t min_batch = 8192;
+	// A launch is a wave per block, and a CU holds 16 of them: a batch is a whole number of such rounds (what is left over of
+	// 8 192 + a chunk's blocks would be a last round that fills a fifth of the chip for as long as a full one takes: 16 ms for a
+	// block of literals), and batches alternate between two streams, so that one batch's last waves and the next one's first
+	// share the chip.
+	const size_t slots = (size_t)sk::ctx_n_cu(c) * 16;
+	size_t min_batch = 2 * slots;
 	if (const char *ev = getenv("SK_BAMFILE_BATCH")) { const int v = atoi(ev); if (v >= 1) min_batch = (size_t)v; }
+	bool whole_rounds = true, two_streams = true;
+	if (const char *ev = getenv("SK_BAMFILE_ROUNDS")) whole_rounds = atoi(ev) != 0;
+	if (const char *ev = getenv("SK_BAMFILE_STREAMS")) two_streams = atoi(ev) >= 2;
+	hipStream_t st_b = st;
+	hipEvent_t ev_b = nullptr;
+	if (two_streams) {
+		BF_HIP(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking));
+		cl.streams.push_back(st_b);
+		BF_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+		cl.events.push_back(ev_b);
+	}
+	int n_batches = 0;
 	uint64_t scan = 0, out_off = 0;                                     // the next header's file offset; bytes of the stream so far
 	size_t launched = 0;                                                // blocks handed to the device
 	bool eof_block_last = false;
@@ -237,15 +256,23 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		// a batch of blocks: copied on st2, inflated on st behind the copy.  A launch wants thousands of blocks (a wave per block,
 		// 16 waves per CU: 4 096 in flight): the blocks of several chunks go together
 		(void)first_new;
-		const size_t n_new = blocks.size() - launched;
-		if (n_new && (n_new >= min_batch || k + 1 == n_chunks)) {
+		size_t n_new = blocks.size() - launched;
+		const bool last = k + 1 == n_chunks;
+		if (n_new && (n_new >= min_batch || last)) {
+			if (!last && whole_rounds && n_new >= slots) n_new -= n_new % slots;      // (what is left over goes with the next batch)
 			const size_t first_new = launched;
+			hipStream_t sb = (n_batches & 1) ? st_b : st;
 			BF_HIP(hipMemcpyAsync(d_blocks + first_new, blocks.data() + first_new, n_new * sizeof(sk_bgzf_block), hipMemcpyHostToDevice, st2));
 			BF_HIP(hipEventRecord(ev_batch, st2));
-			BF_HIP(hipStreamWaitEvent(st, ev_batch, 0));
-			if (int r = sk_bgzf_inflate_dev(c, d_comp, d_blocks + first_new, (int64_t)n_new, d_out, d_status + first_new, 1)) return r;
-			launched = blocks.size();
+			BF_HIP(hipStreamWaitEvent(sb, ev_batch, 0));
+			BF_HIP(sk::launch_bgzf_inflate(d_comp, d_blocks + first_new, (int64_t)n_new, d_out, d_status + first_new, 1, sk::ctx_n_cu(c), sb));
+			launched += n_new;
+			n_batches++;
 		}
+	}
+	if (two_streams) {                                                   // what follows on st comes behind both streams' batches
+		BF_HIP(hipEventRecord(ev_b, st_b));
+		BF_HIP(hipStreamWaitEvent(st, ev_b, 0));
 	}
 	if (scan != fsize) BF_LEAVE(13);                                     // bytes behind the last whole block: a file cut short, or not BGZF to its end
 	(void)eof_block_last;                                               // (htslib only warns when the EOF marker is missing; the data are the same)

@@ -351,6 +351,284 @@ __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, cons
 	return r;
 }
 
+#ifndef SK_INF_GROUPS
+#define SK_INF_GROUPS 1
+#endif
+// The symbols of one DEFLATE block (round 6, second form): GROUPS of symbols per table access, BATCHES of matches per copy.
+//
+// What the first form (inf_symbols, kept for -DSK_INF_GROUPS=0) spent its time on, measured: a block of BAM records with uniformly
+// drawn bases and qualities is 26 500 literals and 9 200 matches of 4 bytes on average, and four matches in five reach further back
+// than the 1-2 KiB the ring holds: each of those was a load from memory (~2 us) that the wave sat out — 7 300 of them are the
+// block's 14 ms.  And decoding one symbol per table access is a chain of latencies of its own (LDS read, v_readfirstlane, scalar
+// arithmetic, the byte's ds_write: a hand-written loop of 13 scalar instructions instead of the compiler's 45 gained 16 %).
+//   * groups: the tables are read ONCE for every bit offset of the buffer — lane j looks up the 10 bits at offset j, and the distance
+//     table's 8 bits there — and the symbols of the buffer's 33-64 bits follow from registers (v_readlane at the offset the symbol
+//     before ended at), no memory access in between.  A code is taken only if all its bits are in the buffer (o + length <= cnt): a
+//     lane that looked at bits beyond the buffer's end is never believed.  The literals of a group are written together: the lanes
+//     at which a literal began (a mask built by the chain) store their bytes at ring positions given by their rank in the mask.  The
+//     chain is gfx950 assembly: 1 vector + 5 scalar instructions and two branches a literal.
+//   * batches: decoding does not need the matches' bytes, so a match is only NOTED (position, length, distance: lane k of three
+//     registers holds token k) while decoding goes on, up to 64 of them within one unit of the ring.  Then the matches whose source was
+//     flushed long ago — final bytes, no dependence on anything pending — are copied all at once, a lane per match: one trip to
+//     memory per batch instead of one per match; the others follow in order through the ring.
+// The ring is four units of kRing / 4: the unit being written, two of history (a match source is in the ring iff it is not below the
+// current unit's base - 2 units), and one that is free, so that a group's literals may run past the unit's end (by at most 63 bytes)
+// while matches of the batch are still pending.
+// -DSK_INF_STAMPS (diagnostic builds only, tools/r06/inflate_stamps.py): shader cycles (s_memtime) per phase, summed over all waves
+#ifdef SK_INF_STAMPS
+__device__ u64 g_inf_stamps[16];
+#define SK_ISTAMP(i) do { const u64 now_ = __builtin_amdgcn_s_memtime(); ist_acc[i] += now_ - ist_last; ist_last = now_; } while (0)
+#else
+#define SK_ISTAMP(i) do { } while (0)
+#endif
+constexpr u32 kUnit = kRing / 4u;
+static_assert(kUnit >= 512u, "a unit holds a longest match and a group's literals");
+__device__ __forceinline__ u64 inf_shr(u64 v, u32 n) { return n >= 64u ? 0ull : v >> n; }      // (n may be all 64 bits: the hardware would shift modulo 64)
+__device__ __forceinline__ void inf_drop(InfBits &b, u32 n) { b.bb = inf_shr(b.bb, n); b.cnt -= n; }
+// inclusive prefix sum over the wave's 64 lanes on DPP (gfx9: row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 and 31 across them)
+__device__ __forceinline__ u32 inf_wave_scan(u32 x)
+{
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+
+__device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun r, const uint8_t *in_base, u32 in_range, u32 a0, u32 out_len, uint8_t *dst, int lane)
+{
+	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[inf_uniform((u32)wave)];
+	InfBits b = r.b;
+	b.bb = inf_uniform64(b.bb); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
+	in_base = reinterpret_cast<const uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)in_base));
+	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(in_base), 0, (int)inf_uniform(in_range), 0x00020000);
+	u32 op = inf_uniform(r.op), flushed = inf_uniform(r.flushed), err = 0u;
+	a0 = inf_uniform(a0); out_len = inf_uniform(out_len);
+	dst = reinterpret_cast<uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)dst));
+#ifdef SK_INF_STAMPS
+	u64 ist_acc[16] = {};
+	u64 ist_last = __builtin_amdgcn_s_memtime();
+#endif
+	// the batch's tokens (position | length << 16, distance) live where the block's header was decoded: nobody reads that now
+	u32 *tokA = reinterpret_cast<u32 *>(L.pre), *tokB = reinterpret_cast<u32 *>(L.lens);
+	static_assert(sizeof(L.pre) >= 256 && sizeof(L.lens) >= 256, "64 tokens");
+	// the output is in another unit of the ring than what was flushed last: the units behind leave
+	auto flush_crossed = [&]() {
+		const u32 boundary = ((a0 + op) & ~(kUnit - 1u)) - a0;                 // position of the current unit's first byte ("negative" in the block's first unit: nothing crossed)
+		if ((int)(boundary - flushed) > 0) { SK_ISTAMP(9); inf_flush(L, dst, a0, flushed, boundary, lane); flushed = boundary; SK_ISTAMP(6); }
+	};
+	auto unit_end = [&]() { return (((a0 + op) | (kUnit - 1u)) + 1u) - a0; };  // position behind the current unit's last byte
+	// bytes [j0, j0 + n) of the match that begins at position m0 (all of them in one unit): from the ring, or from what was flushed
+	auto copy_part = [&](u32 m0, u32 len, u32 dist, u32 j0, u32 n) {
+		const u32 floor_addr = ((a0 + m0 + j0) & ~(kUnit - 1u)) - 2u * kUnit;
+		const u32 src0 = m0 - dist;
+		inf_lds_fence();
+		if (dist >= len) {
+			for (u32 k = (u32)lane; k < n; k += 64u) {
+				const u32 sp = src0 + j0 + k, sa = a0 + sp;
+				uint8_t v;
+				if ((int)(sa - floor_addr) >= 0) v = L.ring[sa & (kRing - 1u)];
+				else v = __hip_atomic_load(dst + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // flushed long ago: from L2, past the vector cache
+				L.ring[(a0 + m0 + j0 + k) & (kRing - 1u)] = v;
+			}
+		} else {                                                           // an overlapping match repeats its first dist bytes (dist < 258: in the ring)
+			for (u32 k = (u32)lane; k < n; k += 64u) {
+				const u32 sp = src0 + (j0 + k) % dist, sa = a0 + sp;
+				uint8_t v;
+				if ((int)(sa - floor_addr) >= 0) v = L.ring[sa & (kRing - 1u)];
+				else v = __hip_atomic_load(dst + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				L.ring[(a0 + m0 + j0 + k) & (kRing - 1u)] = v;
+			}
+		}
+	};
+	u32 ntok = 0u;
+	u32 ue = unit_end();
+	auto finish_batch = [&]() {
+		SK_ISTAMP(8);
+		if (ntok != 0u) {
+			inf_lds_fence();
+			u32 tpos = 0u, tlen = 0u, tdist = 0u;
+			if ((u32)lane < ntok) { const u32 w = tokA[lane]; tpos = w & 0xffffu; tlen = w >> 16; tdist = tokB[lane]; }
+			// the matches whose whole source was flushed: a lane each, all at once
+			const u32 fl = tpos - tdist + tlen <= flushed ? tlen : 0u;
+			if (__builtin_amdgcn_ballot_w64(fl != 0u) != 0ull) {
+				const uint8_t *src = dst + (tpos - tdist);
+				for (u32 j = 0u; j < fl; j += 8u) {
+					uint8_t v[8];
+#pragma unroll
+					for (u32 i = 0u; i < 8u; i++) v[i] = j + i < fl ? __hip_atomic_load(src + j + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+#pragma unroll
+					for (u32 i = 0u; i < 8u; i++) if (j + i < fl) L.ring[(a0 + tpos + j + i) & (kRing - 1u)] = v[i];
+				}
+				if (fl != 0u) tlen = 0u;
+			}
+			SK_ISTAMP(4);
+			// the others in order, through the ring
+			u64 todo = __builtin_amdgcn_ballot_w64(tlen != 0u);
+			while (todo != 0ull) {
+				const u32 k = (u32)__builtin_ctzll(todo);
+				todo &= todo - 1ull;
+				copy_part((u32)__builtin_amdgcn_readlane((int)tpos, (int)k), (u32)__builtin_amdgcn_readlane((int)tlen, (int)k), (u32)__builtin_amdgcn_readlane((int)tdist, (int)k), 0u,
+				          (u32)__builtin_amdgcn_readlane((int)tlen, (int)k));
+			}
+			ntok = 0u;
+			SK_ISTAMP(5);
+		}
+		flush_crossed();
+		ue = unit_end();
+	};
+	// a match of len bytes from dist back, at op: a token of the batch, or — across the unit's end — at once, in two parts
+	auto emit_match = [&](u32 len, u32 dist) {
+		if (op + len > ue) {
+			finish_batch();                                                  // (what is pending first; the unit may have been left by literals: then it is flushed and ue moves on)
+		}
+		if (op + len > ue) {
+			const u32 m0 = op, part = ue - op;
+			copy_part(m0, len, dist, 0u, part);
+			op += part;
+			flush_crossed();
+			copy_part(m0, len, dist, part, len - part);
+			op += len - part;
+			ue = unit_end();
+			SK_ISTAMP(7);
+		} else {
+			if (ntok == 64u) finish_batch();
+			if (lane == 0) { tokA[ntok] = op | (len << 16); tokB[ntok] = dist; }
+			op += len;
+			ntok++;
+			if (op >= ue) finish_batch();
+		}
+	};
+	bool done = false;
+	while (!done && !err) {
+		inf_refill(b, lane);
+		// ---- the group: lane j decodes the symbol that would begin at bit j of the buffer — a literal, or a whole match (length code,
+		// extra bits, distance code, extra bits: at most 36 bits when both codes are within their tables' index bits)
+		const u64 sh = b.bb >> (u32)lane;
+		const u32 w0 = (u32)sh, w1 = (u32)(sh >> 32);
+		const u32 e = L.lit[w0 & ((1u << kInfLitBits) - 1u)];
+		const u32 ll = e & 15u, x = (e >> 4) & 15u, kind = (e >> 8) & 7u;
+		const u32 len_v = (e >> 16) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, ll), 0u, x);
+		const u32 s2 = ll + x;                                              // <= 15: the table's index bits + 5
+		const u32 de = L.dist[__builtin_amdgcn_alignbit(w1, w0, s2) & ((1u << kInfDistBits) - 1u)];
+		const u32 dl = de & 15u, dx = (de >> 4) & 15u, dkind = (de >> 8) & 7u;
+		const u32 s3 = s2 + dl;                                             // <= 23
+		const u32 dist_v = (de >> 16) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, s3), 0u, dx);
+		const bool is_lit = kind == kKindLiteral, is_match = kind == kKindBase && dkind == kKindBase;
+		const u32 vtot = is_lit ? ll : (is_match ? s3 + dx : 0x100u);        // the symbol's bits; "longer than any buffer" for what this path does not take
+		const u32 vout = is_lit ? 1u : len_v;
+		u32 o = 0u;
+#ifdef SK_INF_STAMPS
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		SK_ISTAMP(1);
+		ist_acc[10]++;
+#endif
+		for (;;) {
+			// ---- where the symbols begin, from offset o on, until one whose bits are not all in the buffer (or that this path does not take)
+			u64 mask;
+			u32 t;
+			asm volatile(
+				"s_mov_b64 %[mask], 0\n"
+				"1:\n\t"
+				"v_readlane_b32 %[t], %[vtot], %[o]\n\t"
+				"s_add_u32 %[t], %[t], %[o]\n\t"
+				"s_cmp_gt_u32 %[t], %[cnt]\n\t"
+				"s_cbranch_scc1 2f\n\t"
+				"s_bitset1_b64 %[mask], %[o]\n\t"
+				"s_mov_b32 %[o], %[t]\n\t"
+				"s_branch 1b\n"
+				"2:"
+				: [mask] "=&s"(mask), [t] "=&s"(t), [o] "+s"(o)
+				: [vtot] "v"(vtot), [cnt] "s"(b.cnt)
+				: "scc");
+			SK_ISTAMP(2);
+			if (mask != 0ull) {
+				// ---- their places in the output: a prefix sum of the bytes they make
+				const bool sym = (mask >> (u32)lane) & 1ull;
+				const u32 incl = inf_wave_scan(sym ? vout : 0u);
+				u32 pos = op + incl - (sym ? vout : 0u);
+				u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+				const bool m_here = sym && !is_lit;
+				// a match that would end behind the unit ends the group before it; it is taken alone, below
+				const u64 crossing = __builtin_amdgcn_ballot_w64(m_here && pos + vout > ue);
+				bool alone = false;
+				u32 c = 0u;
+				if (crossing != 0ull) {
+					c = (u32)__builtin_ctzll(crossing);
+					alone = true;
+					mask &= (1ull << c) - 1ull;
+					total = (u32)__builtin_amdgcn_readlane((int)pos, (int)c) - op;
+				}
+				const bool take = (mask >> (u32)lane) & 1ull;
+				const bool m_take = take && !is_lit;
+				if (op + total > out_len) { err = 6u; break; }
+				if (__builtin_amdgcn_ballot_w64(m_take && dist_v > pos) != 0ull) { err = 5u; break; }
+				const u64 mm = __builtin_amdgcn_ballot_w64(m_take);
+				const u32 nm = (u32)__builtin_popcountll(mm);
+				if (ntok + nm > 64u) finish_batch();
+				if (take && is_lit) L.ring[(a0 + pos) & (kRing - 1u)] = (uint8_t)(e >> 16);
+				if (m_take) {
+					const u32 k = ntok + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+					tokA[k] = pos | (len_v << 16);
+					tokB[k] = dist_v;
+				}
+				ntok += nm;
+				op += total;
+				SK_ISTAMP(3);
+				if (op >= ue) finish_batch();
+				if (alone) {
+					const u32 len = (u32)__builtin_amdgcn_readlane((int)len_v, (int)c), dist = (u32)__builtin_amdgcn_readlane((int)dist_v, (int)c);
+					if (dist > op) { err = 5u; break; }
+					if (len > out_len - op) { err = 6u; break; }
+					emit_match(len, dist);
+					o = c + (u32)__builtin_amdgcn_readlane((int)vtot, (int)c);
+					continue;                                                  // (the group's registers stand: on with the symbol behind it)
+				}
+			}
+			// ---- the chain stopped at o: out of bits (the next group), or a symbol for the long way
+			if (o != 0u) break;
+			{
+				// the end of the block, a code longer than its table's index, or no code at all: this symbol bit by bit, and the next group behind it
+				u32 e1 = inf_uniform(L.lit[(u32)b.bb & ((1u << kInfLitBits) - 1u)]);
+				if (((e1 >> 8) & 7u) == kKindLong) e1 = inf_long_code<0, kInfLitBits>(L, b.bb);
+				const u32 k1 = (e1 >> 8) & 7u;
+				inf_take(b, e1 & 15u);
+				if (k1 == kKindLiteral) {
+					if (op >= out_len) { err = 6u; break; }
+					if (lane == 0) L.ring[(a0 + op) & (kRing - 1u)] = (uint8_t)(e1 >> 16);
+					op++;
+					if (op >= ue) finish_batch();
+					break;
+				}
+				if (k1 == kKindEob) { done = true; break; }
+				if (k1 != kKindBase) { err = 4u; break; }
+				const u32 len = (e1 >> 16) + inf_take(b, (e1 >> 4) & 15u);
+				inf_refill(b, lane);
+				u32 d = inf_uniform(L.dist[(u32)b.bb & ((1u << kInfDistBits) - 1u)]);
+				if (((d >> 8) & 7u) == kKindLong) d = inf_long_code<1, kInfDistBits>(L, b.bb);
+				if (((d >> 8) & 7u) != kKindBase) { err = 4u; break; }
+				inf_take(b, d & 15u);
+				inf_refill(b, lane);
+				const u32 dist = (d >> 16) + inf_take(b, (d >> 4) & 15u);
+				if (dist > op) { err = 5u; break; }
+				if (len > out_len - op) { err = 6u; break; }
+				emit_match(len, dist);
+				break;
+			}
+		}
+		if (o != 0u) inf_drop(b, o);
+		SK_ISTAMP(3);
+	}
+	if (!err) finish_batch();
+#ifdef SK_INF_STAMPS
+	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_inf_stamps[i], ist_acc[i]);
+#endif
+	r.b = b; r.op = op; r.flushed = flushed; r.err = err;
+	return r;
+}
+
 struct InfBlock { u64 in_off; u32 in_len, out_len; u64 out_off; u32 crc, pad; };
 static_assert(sizeof(InfBlock) == 32, "== sk_bgzf_block");
 
@@ -449,7 +727,11 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, int wave, const uint8_t *com
 			{
 				InfRun r;
 				r.b = b; r.op = op; r.flushed = flushed; r.err = 0u;
+#if SK_INF_GROUPS
+				r = inf_symbols_groups(wave, r, comp + in4, range, a0, out_len, out + blk.out_off, lane);
+#else
 				r = inf_symbols(wave, r, comp + in4, range, a0, out_len, out + blk.out_off, lane);
+#endif
 				b = r.b; op = r.op; flushed = r.flushed; err = r.err;
 			}
 			if (err) break;
@@ -485,7 +767,13 @@ __global__ __launch_bounds__(kInfWaves * 64) void bgzf_inflate_kernel(const uint
 			blk.crc = 0u; blk.pad = 0u;
 		}
 		u32 st = 0u;
+#ifdef SK_INF_STAMPS
+		const u64 t_blk = __builtin_amdgcn_s_memtime();
+#endif
 		if (blk.out_len != 0u || blk.in_len != 0u) st = inf_block(L, wave, comp, blk, out, lane);
+#ifdef SK_INF_STAMPS
+		if (lane == 0) { atomicAdd(&g_inf_stamps[15], __builtin_amdgcn_s_memtime() - t_blk); atomicAdd(&g_inf_stamps[14], 1ull); }
+#endif
 		if (lane == 0) status[bi] = st;
 		inf_lds_fence();
 	}
@@ -791,3 +1079,15 @@ hipError_t launch_bam_walk_reduce(const uint8_t *stream, uint64_t stream_len, co
 }
 
 }  // namespace sk
+
+#ifdef SK_INF_STAMPS
+extern "C" int sk_debug_inflate_stamps(unsigned long long *out, int reset)
+{
+	hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(sk::g_inf_stamps), sizeof(unsigned long long) * 16);
+	if (e == hipSuccess && reset) {
+		unsigned long long z[16] = {};
+		e = hipMemcpyToSymbol(HIP_SYMBOL(sk::g_inf_stamps), z, sizeof z);
+	}
+	return (int)e;
+}
+#endif

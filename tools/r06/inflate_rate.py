@@ -79,5 +79,19 @@ for kind in ("random", "sorted"):
         ms = sorted(ts[1:])[1]
         print(f"{kind:7s} crc={int(crc)}: {n} blocks, {len(comp_all) / 1e6:.0f} MB -> {out_off / 1e6:.0f} MB (1 : {out_off / len(comp_all):.2f}); {ms:.2f} ms = "
               f"{out_off / ms / 1e6:.1f} GB/s inflated, {len(comp_all) / ms / 1e6:.1f} GB/s compressed; {n / ms / 1e3:.2f} M blocks/s; bad status {int((st != 0).sum())}", flush=True)
+    if hasattr(ctx._lib, "sk_debug_inflate_stamps"):                 # a -DSK_INF_STAMPS build: shader cycles per phase of the symbol loop, summed over the waves
+        import ctypes as C
+        acc = (C.c_ulonglong * 16)()
+        ctx._lib.sk_debug_inflate_stamps(acc, 1)
+        ctx.bgzf_inflate_dev(d_comp, d_blocks, n, d_out, d_status, False); ctx.sync()
+        ctx._lib.sk_debug_inflate_stamps(acc, 1)
+        names = {0: "-", 1: "refill + the group's table reads", 2: "chain + the literals' stores", 3: "match decode + the rest of the loop", 4: "batch: matches from flushed bytes", 5: "batch: matches through the ring",
+                 6: "flush", 7: "a match across the unit's end", 8: "(into finish_batch)", 9: "(into flush)"}
+        blocks_done, total = acc[14], acc[15]
+        print(f"   stamps: {blocks_done} blocks, {total / max(1, blocks_done):.0f} cycles per block; groups per block {acc[10] / max(1, blocks_done):.0f}")
+        inside = sum(acc[i] for i in range(10))
+        print(f"   outside the symbol loop (headers, tables, final flush): {(total - inside) / max(1, blocks_done):.0f} cycles per block = {100 * (total - inside) / max(1, total):.1f} %")
+        for i in range(1, 10):
+            print(f"   {names[i]:42s} {acc[i] / max(1, blocks_done):10.0f} cycles per block  {100 * acc[i] / max(1, total):5.1f} %")
     for p in (d_comp, d_blocks, d_out, d_status):
         ctx.free_device(p)
