@@ -272,7 +272,13 @@ static int statistics(int argc, char **argv)
 	if (targets_path.empty() && bam_path != "-" && !getenv("SEQKIT_HOST_INFLATE")) {
 		int handled = 0;
 		uint64_t fc[3] = {0, 0, 0};
-		check(sk_bam_file_reduce(host::gpu(), bam_path.c_str(), 0, fc, nullptr, nullptr, &handled, nullptr), "sk_bam_file_reduce");
+		const bool trace = getenv("SK_BAMFILE_TRACE") != nullptr;
+		auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+		const double t0 = now_ms();
+		sk_ctx *c = host::gpu();
+		const double t1 = now_ms();
+		check(sk_bam_file_reduce(c, bam_path.c_str(), 0, fc, nullptr, nullptr, &handled, nullptr), "sk_bam_file_reduce");
+		if (trace) fprintf(stderr, "sam statistics: waited %.1f ms for the device contexts, sk_bam_file_reduce %.1f ms\n", t1 - t0, now_ms() - t1);
 		if (handled) { print_counters(fc); return 0; }
 	}
 	BamStream bam(bam_path);

@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -354,6 +355,9 @@ __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, cons
 #ifndef SK_INF_GROUPS
 #define SK_INF_GROUPS 1
 #endif
+#ifndef SK_INF_ASM_GROUPS
+#define SK_INF_ASM_GROUPS 1
+#endif
 // The symbols of one DEFLATE block (round 6, second form): GROUPS of symbols per table access, BATCHES of matches per copy.
 //
 // What the first form (inf_symbols, kept for -DSK_INF_GROUPS=0) spent its time on, measured: a block of BAM records with uniformly
@@ -502,6 +506,229 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 		}
 	};
 	bool done = false;
+#if SK_INF_ASM_GROUPS
+	// The groups in gfx950 assembly (the C++ statement of the same steps is the #else branch below: as compiled, its scalar state
+	// was copied from register to register at every branch — 13 s_mov at the loop's edges alone — and the scalar unit, one per CU for
+	// its 16 waves, is what this kernel waits for).  One pass of the loop is one group: refill, the per-lane decode (34 vector
+	// instructions, two table reads), the chain of symbol starts, the symbols' places (a prefix sum on DPP), the matches' tokens and
+	// the literals' bytes stored, the buffer moved on.  It leaves the loop (why) for what is rare: 1 the window is used up, 2 the
+	// symbol at the buffer's first bit is not one this path takes (a long code, the end of the block, a match that ends behind the
+	// unit: bit by bit below), 3 the unit is full or the batch is, 4 / 5 a distance or a length the block cannot have.
+	static_assert(kRing == 2048u && kInfLitBits == 10 && kInfDistBits == 8, "the assembly below has these as literals");
+	static_assert(offsetof(InfLds, dist) - offsetof(InfLds, lit) == 4096 && offsetof(InfLds, lens) - offsetof(InfLds, pre) == 1088, "and these offsets");
+	const u32 lit_base = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&L.lit[0];
+	const u32 tok_base = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&L.pre[0];
+	const u32 ring_base = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&L.ring[0];
+	while (!done && !err) {
+		u32 why;
+		asm volatile(
+			"s_mov_b64 s[94:95], exec\n"
+			"1:\n\t"
+			"s_cmp_gt_u32 %[cnt], 32\n\t"
+			"s_cbranch_scc1 2f\n\t"
+			"v_readlane_b32 s86, %[vin], %[widx]\n\t"
+			"s_mov_b32 s87, 0\n\t"
+			"s_lshl_b64 s[86:87], s[86:87], %[cnt]\n\t"
+			"s_or_b64 s[84:85], s[84:85], s[86:87]\n\t"
+			"s_add_u32 %[cnt], %[cnt], 32\n\t"
+			"s_add_u32 %[taken], %[taken], 1\n\t"
+			"s_add_u32 %[widx], %[widx], 1\n\t"
+			"s_cmp_eq_u32 %[widx], 64\n\t"
+			"s_cbranch_scc1 20f\n"
+			"2:\n\t"                                          // lane j: v60:61 = the buffer from bit j on; v41 entry, v42 code bits, v43 extra bits, v44 length
+			"v_lshrrev_b64 v[60:61], %[vlane], s[84:85]\n\t"
+			"v_and_b32 v40, 0x3ff, v60\n\t"
+			"v_lshl_add_u32 v40, v40, 2, %[lit]\n\t"
+			"ds_read_b32 v41, v40\n\t"
+			"s_waitcnt lgkmcnt(0)\n\t"
+			"v_and_b32 v42, 15, v41\n\t"
+			"v_bfe_u32 v43, v41, 4, 4\n\t"
+			"v_alignbit_b32 v40, v61, v60, v42\n\t"
+			"v_bfe_u32 v40, v40, 0, v43\n\t"
+			"v_lshrrev_b32 v44, 16, v41\n\t"
+			"v_add_u32 v44, v44, v40\n\t"
+			"v_add_u32 v45, v42, v43\n\t"
+			"v_alignbit_b32 v40, v61, v60, v45\n\t"
+			"v_and_b32 v40, 0xff, v40\n\t"
+			"v_lshl_add_u32 v40, v40, 2, %[lit]\n\t"
+			"ds_read_b32 v46, v40 offset:4096\n\t"              // v46 distance entry, v47 code bits, v48 extra bits, v50 distance, v49 the match's bits
+			"s_waitcnt lgkmcnt(0)\n\t"
+			"v_and_b32 v47, 15, v46\n\t"
+			"v_bfe_u32 v48, v46, 4, 4\n\t"
+			"v_add_u32 v49, v45, v47\n\t"
+			"v_alignbit_b32 v40, v61, v60, v49\n\t"
+			"v_bfe_u32 v40, v40, 0, v48\n\t"
+			"v_lshrrev_b32 v50, 16, v46\n\t"
+			"v_add_u32 v50, v50, v40\n\t"
+			"v_add_u32 v49, v49, v48\n\t"
+			"v_and_b32 v40, 0x700, v41\n\t"
+			"v_cmp_eq_u32_e64 s[90:91], 0, v40\n\t"              // s90:91 the lanes that see a literal
+			"v_and_b32 v56, 0x700, v46\n\t"
+			"v_lshl_or_b32 v40, v56, 4, v40\n\t"
+			"v_cmp_eq_u32_e32 vcc, 0x1100, v40\n\t"              // a length and a distance, both from their tables
+			"v_mov_b32 v51, 0x100\n\t"
+			"v_cndmask_b32_e32 v51, v51, v49, vcc\n\t"
+			"v_cndmask_b32_e64 v51, v51, v42, s[90:91]\n\t"      // v51 the symbol's bits (0x100: not for this path), v52 the bytes it makes
+			"v_cndmask_b32_e64 v52, v44, 1, s[90:91]\n\t"
+			"s_mov_b32 s60, 0\n\t"
+			"s_mov_b64 s[88:89], 0\n"
+			"3:\n\t"                                          // the chain: s60 the offset, s88:89 the lanes at which a symbol begins
+			"v_readlane_b32 s61, v51, s60\n\t"
+			"s_add_u32 s61, s61, s60\n\t"
+			"s_cmp_gt_u32 s61, %[cnt]\n\t"
+			"s_cbranch_scc1 4f\n\t"
+			"s_bitset1_b64 s[88:89], s60\n\t"
+			"s_mov_b32 s60, s61\n\t"
+			"s_branch 3b\n"
+			"4:\n\t"
+			"s_cmp_eq_u64 s[88:89], 0\n\t"
+			"s_cbranch_scc1 21f\n\t"
+			"v_cndmask_b32_e64 v53, 0, v52, s[88:89]\n\t"        // the symbols' places: v54 inclusive prefix sum of their bytes, v55 position
+			"v_mov_b32 v54, v53\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+			"s_nop 1\n\t"
+			"v_add_u32_dpp v54, v54, v54 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+			"v_sub_u32 v55, v54, v53\n\t"
+			"v_add_u32 v55, %[op], v55\n\t"
+			"v_readlane_b32 s62, v54, 63\n\t"                    // s62 the group's bytes
+			"v_add_u32 v40, v55, v52\n\t"
+			"v_cmp_lt_u32_e32 vcc, %[ue], v40\n\t"
+			"s_andn2_b64 s[92:93], s[88:89], s[90:91]\n\t"       // s92:93 the matches among the symbols
+			"s_mov_b32 s64, 0\n\t"
+			"s_and_b64 s[86:87], vcc, s[92:93]\n\t"              // ... that end behind the unit: the first of them ends the group
+			"s_cbranch_scc0 5f\n\t"
+			"s_ff1_i32_b64 s63, s[86:87]\n\t"
+			"s_lshl_b64 s[86:87], 1, s63\n\t"
+			"s_add_u32 s86, s86, -1\n\t"
+			"s_addc_u32 s87, s87, -1\n\t"
+			"s_and_b64 s[88:89], s[88:89], s[86:87]\n\t"
+			"s_and_b64 s[92:93], s[92:93], s[86:87]\n\t"
+			"v_readlane_b32 s62, v55, s63\n\t"
+			"s_sub_u32 s62, s62, %[op]\n\t"
+			"s_mov_b32 s60, s63\n\t"
+			"s_mov_b32 s64, 1\n"
+			"5:\n\t"
+			"s_add_u32 s61, %[op], s62\n\t"
+			"s_cmp_gt_u32 s61, %[olen]\n\t"
+			"s_cbranch_scc1 25f\n\t"
+			"s_cmp_eq_u64 s[92:93], 0\n\t"
+			"s_cbranch_scc1 6f\n\t"
+			"v_cmp_gt_u32_e32 vcc, v50, v55\n\t"
+			"s_and_b64 s[86:87], vcc, s[92:93]\n\t"
+			"s_cbranch_scc1 24f\n\t"
+			"s_bcnt1_i32_b64 s65, s[92:93]\n\t"
+			"s_add_u32 s66, %[ntok], s65\n\t"
+			"s_cmp_gt_u32 s66, 64\n\t"
+			"s_cbranch_scc1 22f\n\t"
+			"s_mov_b64 exec, s[92:93]\n\t"                       // the matches' tokens: position | length << 16, distance
+			"v_mbcnt_lo_u32_b32 v56, s92, 0\n\t"
+			"v_mbcnt_hi_u32_b32 v56, s93, v56\n\t"
+			"v_add_u32 v56, %[ntok], v56\n\t"
+			"v_lshl_add_u32 v56, v56, 2, %[tok]\n\t"
+			"v_lshl_or_b32 v40, v44, 16, v55\n\t"
+			"ds_write_b32 v56, v40\n\t"
+			"ds_write_b32 v56, v50 offset:1088\n\t"
+			"s_mov_b64 exec, s[94:95]\n\t"
+			"s_mov_b32 %[ntok], s66\n"
+			"6:\n\t"
+			"s_and_b64 s[86:87], s[88:89], s[90:91]\n\t"         // the literals' bytes
+			"s_cbranch_scc0 7f\n\t"
+			"s_mov_b64 exec, s[86:87]\n\t"
+			"v_add_u32 v40, %[a0], v55\n\t"
+			"v_and_b32 v40, 0x7ff, v40\n\t"
+			"v_add_u32 v40, %[ring], v40\n\t"
+			"ds_write_b8_d16_hi v40, v41\n\t"
+			"s_mov_b64 exec, s[94:95]\n"
+			"7:\n\t"
+			"s_add_u32 %[op], %[op], s62\n\t"
+			"s_cmp_lt_u32 s60, 64\n\t"                           // the buffer moves on by s60 bits (all 64: a shift the hardware takes modulo 64)
+			"s_cbranch_scc1 8f\n\t"
+			"s_mov_b64 s[84:85], 0\n\t"
+			"s_branch 9f\n"
+			"8:\n\t"
+			"s_lshr_b64 s[84:85], s[84:85], s60\n"
+			"9:\n\t"
+			"s_sub_u32 %[cnt], %[cnt], s60\n\t"
+			"s_cmp_lg_u32 s64, 0\n\t"
+			"s_cbranch_scc1 21f\n\t"
+			"s_cmp_ge_u32 %[op], %[ue]\n\t"
+			"s_cbranch_scc1 22f\n\t"
+			"s_branch 1b\n"
+			"20:\n\t"
+			"s_mov_b32 %[why], 1\n\t"
+			"s_branch 29f\n"
+			"21:\n\t"
+			"s_mov_b32 %[why], 2\n\t"
+			"s_branch 29f\n"
+			"22:\n\t"
+			"s_mov_b32 %[why], 3\n\t"
+			"s_branch 29f\n"
+			"24:\n\t"
+			"s_mov_b32 %[why], 4\n\t"
+			"s_branch 29f\n"
+			"25:\n\t"
+			"s_mov_b32 %[why], 5\n"
+			"29:\n\t"
+			"s_mov_b64 exec, s[94:95]\n\t"
+			"s_waitcnt lgkmcnt(0)"
+			: [bb] "+{s[84:85]}"(b.bb), [cnt] "+s"(b.cnt), [widx] "+s"(b.widx), [taken] "+s"(b.taken), [op] "+s"(op), [ntok] "+s"(ntok), [why] "=&s"(why)
+			: [vin] "v"(b.vin), [vlane] "v"(lane), [ue] "s"(ue), [olen] "s"(out_len), [a0] "s"(a0), [lit] "s"(lit_base), [tok] "s"(tok_base), [ring] "s"(ring_base)
+			: "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+			  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v60", "v61",
+			  "vcc", "scc", "memory");
+		SK_ISTAMP(1);
+		if (why == 1u) {                                                    // the window behind, and the one after it on its way
+			b.vin = b.vnext;
+			b.vnext = __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)(b.next_off + 4u * (u32)lane), 0, 0);
+			b.next_off += 256u;
+			b.widx = 0u;
+			continue;
+		}
+		if (why == 4u) { err = 5u; break; }
+		if (why == 5u) { err = 6u; break; }
+		if (why == 3u || op >= ue) finish_batch();
+		if (why != 2u) continue;
+		{
+			// the symbol at the buffer's first bit, bit by bit: the end of the block, a code longer than its table's index or no code at
+			// all, a match that ends behind the unit (or one whose 36 bits the buffer did not hold)
+			inf_refill(b, lane);
+			u32 e1 = inf_uniform(L.lit[(u32)b.bb & ((1u << kInfLitBits) - 1u)]);
+			if (((e1 >> 8) & 7u) == kKindLong) e1 = inf_long_code<0, kInfLitBits>(L, b.bb);
+			const u32 k1 = (e1 >> 8) & 7u;
+			inf_take(b, e1 & 15u);
+			if (k1 == kKindLiteral) {
+				if (op >= out_len) { err = 6u; break; }
+				if (lane == 0) L.ring[(a0 + op) & (kRing - 1u)] = (uint8_t)(e1 >> 16);
+				op++;
+				if (op >= ue) finish_batch();
+				continue;
+			}
+			if (k1 == kKindEob) { done = true; break; }
+			if (k1 != kKindBase) { err = 4u; break; }
+			const u32 len = (e1 >> 16) + inf_take(b, (e1 >> 4) & 15u);
+			inf_refill(b, lane);
+			u32 d = inf_uniform(L.dist[(u32)b.bb & ((1u << kInfDistBits) - 1u)]);
+			if (((d >> 8) & 7u) == kKindLong) d = inf_long_code<1, kInfDistBits>(L, b.bb);
+			if (((d >> 8) & 7u) != kKindBase) { err = 4u; break; }
+			inf_take(b, d & 15u);
+			inf_refill(b, lane);
+			const u32 dist = (d >> 16) + inf_take(b, (d >> 4) & 15u);
+			if (dist > op) { err = 5u; break; }
+			if (len > out_len - op) { err = 6u; break; }
+			emit_match(len, dist);
+			SK_ISTAMP(3);
+		}
+	}
+#else
 	while (!done && !err) {
 		inf_refill(b, lane);
 		// ---- the group: lane j decodes the symbol that would begin at bit j of the buffer — a literal, or a whole match (length code,
@@ -621,6 +848,7 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 		if (o != 0u) inf_drop(b, o);
 		SK_ISTAMP(3);
 	}
+#endif
 	if (!err) finish_batch();
 #ifdef SK_INF_STAMPS
 	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_inf_stamps[i], ist_acc[i]);
