@@ -60,6 +60,16 @@ constexpr int kInfLitBits = 10, kInfDistBits = 8, kInfPreBits = 7;
 #ifndef SK_INF_RING
 #define SK_INF_RING 2048
 #endif
+// build knobs (A/B builds only): the second form of the symbol loop (groups and batches), its group loop in assembly, nt stores for the flush
+#ifndef SK_INF_GROUPS
+#define SK_INF_GROUPS 1
+#endif
+#ifndef SK_INF_ASM_GROUPS
+#define SK_INF_ASM_GROUPS 1
+#endif
+#ifndef SK_INF_FLUSH_NT
+#define SK_INF_FLUSH_NT 1
+#endif
 constexpr u32 kRing = SK_INF_RING, kHalf = kRing / 2;
 static_assert((kRing & (kRing - 1)) == 0 && kHalf >= 1024, "ring: a power of two, a half holds a longest match");
 
@@ -277,7 +287,11 @@ __device__ __forceinline__ void inf_flush(const InfLds &L, uint8_t *dst, u32 a0,
 	if ((u32)lane < ntail) dst[hi - ntail + (u32)lane] = L.ring[(body_hi + (u32)lane) & (kRing - 1u)];
 	for (u32 a = body_lo + 16u * (u32)lane; a < body_hi; a += 1024u) {
 		const u32x4 v = *reinterpret_cast<const u32x4 *>(&L.ring[a & (kRing - 1u)]);
+#if SK_INF_FLUSH_NT
 		__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst + (lo + (a - alo))));
+#else
+		*reinterpret_cast<u32x4 *>(dst + (lo + (a - alo))) = v;
+#endif
 	}
 }
 
@@ -352,12 +366,6 @@ __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, cons
 	return r;
 }
 
-#ifndef SK_INF_GROUPS
-#define SK_INF_GROUPS 1
-#endif
-#ifndef SK_INF_ASM_GROUPS
-#define SK_INF_ASM_GROUPS 1
-#endif
 // The symbols of one DEFLATE block (round 6, second form): GROUPS of symbols per table access, BATCHES of matches per copy.
 //
 // What the first form (inf_symbols, kept for -DSK_INF_GROUPS=0) spent its time on, measured: a block of BAM records with uniformly
@@ -455,19 +463,41 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 			inf_lds_fence();
 			u32 tpos = 0u, tlen = 0u, tdist = 0u;
 			if ((u32)lane < ntok) { const u32 w = tokA[lane]; tpos = w & 0xffffu; tlen = w >> 16; tdist = tokB[lane]; }
-			// the matches whose whole source was flushed: a lane each, all at once
+			// the matches whose whole source was flushed, all at once: the short ones a lane each (one trip to memory for all of them) ...
 			const u32 fl = tpos - tdist + tlen <= flushed ? tlen : 0u;
-			if (__builtin_amdgcn_ballot_w64(fl != 0u) != 0ull) {
+			if (__builtin_amdgcn_ballot_w64(fl != 0u && fl <= 8u) != 0ull) {
 				const uint8_t *src = dst + (tpos - tdist);
-				for (u32 j = 0u; j < fl; j += 8u) {
-					uint8_t v[8];
+				const u32 n = fl <= 8u ? fl : 0u;
+				uint8_t v[8];
 #pragma unroll
-					for (u32 i = 0u; i < 8u; i++) v[i] = j + i < fl ? __hip_atomic_load(src + j + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+				for (u32 i = 0u; i < 8u; i++) v[i] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
 #pragma unroll
-					for (u32 i = 0u; i < 8u; i++) if (j + i < fl) L.ring[(a0 + tpos + j + i) & (kRing - 1u)] = v[i];
-				}
-				if (fl != 0u) tlen = 0u;
+				for (u32 i = 0u; i < 8u; i++) if (i < n) L.ring[(a0 + tpos + i) & (kRing - 1u)] = v[i];
 			}
+			// ... the longer ones eight lanes each, eight matches a round, 32 bytes of each a trip (a lane each, the longest of 64 matches
+			// set the number of trips: 13 for reads in position order, where a match is 23 bytes on average and some are 100)
+			const u64 longm = __builtin_amdgcn_ballot_w64(fl > 8u);
+			if (longm != 0ull) {
+				uint8_t *idx = L.lens + 256;                                   // (the tokens' 64 x 4 bytes end there)
+				if (fl > 8u) idx[__builtin_amdgcn_mbcnt_hi((u32)(longm >> 32), __builtin_amdgcn_mbcnt_lo((u32)longm, 0u))] = (uint8_t)lane;
+				inf_lds_fence();
+				const u32 nlong = (u32)__builtin_popcountll(longm);
+				for (u32 r0 = 0u; r0 < nlong; r0 += 8u) {
+					const u32 r = r0 + ((u32)lane >> 3);
+					if (r < nlong) {
+						const u32 k = idx[r], w = tokA[k], p = w & 0xffffu, n = w >> 16;
+						const uint8_t *src = dst + (p - tokB[k]);
+						for (u32 j = (u32)lane & 7u; j < n; j += 32u) {
+							uint8_t v[4];
+#pragma unroll
+							for (u32 i = 0u; i < 4u; i++) v[i] = j + 8u * i < n ? __hip_atomic_load(src + j + 8u * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+#pragma unroll
+							for (u32 i = 0u; i < 4u; i++) if (j + 8u * i < n) L.ring[(a0 + p + j + 8u * i) & (kRing - 1u)] = v[i];
+						}
+					}
+				}
+			}
+			if (fl != 0u) tlen = 0u;
 			SK_ISTAMP(4);
 			// the others in order, through the ring
 			u64 todo = __builtin_amdgcn_ballot_w64(tlen != 0u);
