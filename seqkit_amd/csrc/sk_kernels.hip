@@ -2176,8 +2176,12 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 			if (b.many) {
 				// many batches in one launch: the two kernels that serve the benchmark's sheets have the form; any other shape is the caller's loop
 				if (!ldstab) return hipErrorNotSupported;
+				// (the gathered-row kernel has the form too and keeps it for A/B — SK_LUT_MANY_GATHER=1 — but its many-batch launch is SLOWER than its
+				// launches back to back, which is what the caller's loop does: 96 dual-index, 4 x 10 M rows from HBM, 0.51 of the HBM peak against 0.56)
+				const char *mg = getenv("SK_LUT_MANY_GATHER");
+				const bool many_gather = mg && atoi(mg) != 0;
 				if (rows2) fn = want_detail ? reinterpret_cast<const void *>(demux_lut8x2_kernel<true, true, true>) : reinterpret_cast<const void *>(demux_lut8x2_kernel<true, false, true>);
-				else if (!direct && t.W1 == 2 && t.W2 == 2)
+				else if (many_gather && !direct && t.W1 == 2 && t.W2 == 2)
 					fn = pair ? (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, true, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, true, true>))
 					          : (want_detail ? reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, true, false, true>) : reinterpret_cast<const void *>(demux_lut_kernel<2, 2, false, true, false, false, true>));
 				else return hipErrorNotSupported;

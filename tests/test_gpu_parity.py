@@ -1606,12 +1606,16 @@ def test_errors_are_codes_not_crashes(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gather_form", [False, True])
 @pytest.mark.parametrize("shape", ["16 x 8", "96 x 8+8", "384 x 8+8", "130 x 12"])
-def test_many_batches_in_one_call_equal_the_single_calls_and_the_oracle(ctx, oracle, shape):
+def test_many_batches_in_one_call_equal_the_single_calls_and_the_oracle(ctx, oracle, shape, gather_form, monkeypatch):
     """sk_demux_assign_many_dev: ragged batches (empty ones among them), with and without the detail columns of
-    matched rows, spread over the ctx's lanes — every batch's outputs are what its own call gives and what the oracle says
-    (src/fasta_demultiplex.rs:154-194), the counters are the sum over the batches."""
+    matched rows — every batch's outputs are what its own call gives and what the oracle says (src/fasta_demultiplex.rs:154-194), the
+    counters are the sum over the batches.  gather_form: the gathered-row kernel's one-launch form too (SK_LUT_MANY_GATHER=1; the
+    product runs those sheets' batches back to back, which is faster)."""
     from seqkit_amd import capi, synth
+    if gather_form:
+        monkeypatch.setenv("SK_LUT_MANY_GATHER", "1")
     S = int(shape.split(" x ")[0])
     dual = "+" in shape
     L = int(shape.split(" x ")[1].split("+")[0])
