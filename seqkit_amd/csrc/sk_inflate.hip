@@ -8,23 +8,30 @@
 // streams, and the compressed bytes are a third of what crosses PCIe when the host inflates.
 //
 // bgzf_inflate_kernel — ONE WAVE PER BLOCK.  DEFLATE decoding is a chain: a symbol's first bit is known only when the one
-// before it has been decoded.  So a wave decodes like one thread — every value of the decoder (bit buffer, table entry,
-// positions) is wave-uniform and lives in scalar registers — and brings its 64 lanes to bear on what IS parallel: building
-// the decoding tables of a block, copying a match, moving the output.  Throughput comes from thousands of waves decoding
-// their own blocks at once (8 per CU), not from one fast decoder.
+// before it has been decoded.  So a wave decodes like one thread — the decoder's state (bit buffer, positions) is wave-uniform
+// and lives in scalar registers — and brings its 64 lanes to bear on what IS parallel.  Throughput comes from thousands of
+// waves decoding their own blocks at once (16 per CU), and — since the scalar unit is one per CU — from keeping the scalar
+// instructions per symbol few.
 //   * input: 64 dwords of the compressed stream sit in ONE vector register (lane i: dword i of the window), the next window
 //     in a second one, loaded with one coalesced raw-buffer load each (clipped by its descriptor: beyond the payload it
-//     reads zeros); the bit buffer takes its next dword with v_readlane (lane index in a scalar register) — no memory
-//     access per symbol on the input side.
-//   * tables (LDS, per wave): the literal/length code resolved by its first 10 bits, the distance code by its first 8 — one
-//     ds_read per symbol; longer codes (rare by construction) are walked bit by bit against the canonical code's
-//     first-code / count arrays.  A block's tables are built by the whole wave: ranks of the symbols within their code
-//     length by ballots, then every lane resolves the table indices it owns by the canonical rule.
-//   * output: the wave keeps the last 1-2 KiB it produced in an LDS ring addressed by the OUTPUT address (mod the ring),
-//     so that a half of the ring is a 16-byte-aligned piece of the output: literals are one ds_write_b8, a match is
-//     ds_read_u8 / ds_write_b8 across the lanes (any overlap: lane k reads byte k mod dist of the source), and whenever the
-//     output crosses a half's boundary that half leaves for HBM as coalesced 16-byte stores.  A match that reaches back
-//     beyond the ring (the other half is already overwritten) reads what was flushed, from L2.
+//     reads zeros); the bit buffer takes its next dword with v_readlane — no memory access per symbol on the input side.
+//   * tables (LDS, per wave): the literal/length code resolved by its first 10 bits, the distance code by its first 8;
+//     longer codes (rare by construction) are walked bit by bit against the canonical code's first-code / count arrays.  A
+//     block's tables are built by the whole wave: ranks of the symbols within their code length by ballots, then every lane
+//     resolves the table indices it owns by the canonical rule.
+//   * symbols, a GROUP per table access (inf_symbols_groups): lane j decodes the symbol that would begin at bit j of the
+//     buffer — a literal, or a whole match: length code, extra bits, distance code, extra bits — and a short scalar chain
+//     (v_readlane of the symbol's bit count at the offset the symbol before ended at) finds which lanes are real symbol
+//     starts: one LDS latency per 3-5 symbols instead of one (or two) per symbol, 7 scalar instructions a symbol.  The symbols'
+//     places in the output are a prefix sum (DPP) of the bytes they make; literals are stored by their lanes.
+//   * matches, a BATCH per copy: decoding does not need a match's bytes, so matches are noted as tokens while decoding goes
+//     on (up to 64, within one unit of the ring) and copied afterwards — those whose source was flushed long ago all at
+//     once (a lane, or eight, per match: ONE trip to memory per batch where the first form of this kernel made one per
+//     match and sat it out: four matches in five of a literal-heavy BAM block reach further back than the ring), the others in
+//     order through the ring.
+//   * output: the wave keeps the last 1-1.5 KiB it produced in an LDS ring addressed by the OUTPUT address (mod the ring), four
+//     units of 512 bytes: the one being written, two of history, one free for a group's literals to run into; a unit that is
+//     complete leaves for HBM as coalesced 16-byte stores (a 16-byte-aligned piece of the output, by the addressing).
 // Anything irregular — a code that is over-subscribed or incomplete, a distance before the block's first byte, output or
 // input that ends early or late — gives the block a non-zero status, and the caller inflates THAT block on the CPU with
 // zlib, whose verdict stands: the device never decides that a file is corrupt.
