@@ -615,6 +615,7 @@ static std::vector<Sample> *g_samples = nullptr;
 static void close_outputs()
 {
 	if (!g_samples) return;
+	for (auto &s : *g_samples) for (auto &o : s.out) if (o) o->flush_tail();        // all the tails first: one batch for the pool
 	for (auto &s : *g_samples) for (auto &o : s.out) if (o) o->close();
 }
 
@@ -1038,8 +1039,8 @@ static int demultiplex(int argc, char **argv)
 	}
 	close_outputs();
 	host::out().flush();
-	if (prof) fprintf(stderr, "demultiplex: block loop %.3f s (reader thread: read and cut %.3f; main thread: wait for a cut block %.3f, wait for the oldest "
-	                          "result %.3f, hand it on %.3f), finishing the outputs %.3f s\n", t_loop1 - t_loop0, t_read, t_cut_wait, t_wait, t_hand, now() - t_loop1);
+	if (prof) fprintf(stderr, "demultiplex: %.3f s of the process before the block loop, block loop %.3f s (reader thread: read and cut %.3f; main thread: wait for a cut block %.3f, wait for the oldest "
+	                          "result %.3f, hand it on %.3f), finishing the outputs %.3f s\n", t_loop0 - host::process_start_s(), t_loop1 - t_loop0, t_read, t_cut_wait, t_wait, t_hand, now() - t_loop1);
 	fprintf(stderr, "%llu / %llu (%s%%) clusters carried a barcode matching one of the provided samples.\n",      // :263-264
 	        (unsigned long long)identified_reads, (unsigned long long)total_reads,
 	        host::fmt_pct((double)identified_reads / (double)total_reads * 100.0).c_str());

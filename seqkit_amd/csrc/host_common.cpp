@@ -973,7 +973,7 @@ void Pool::start()
 		// a few batching threads, each with a context of its own: while one waits for the device, another lays its batch out and a
 		// third writes its members to their files (one thread did all three in turn: 2.8 s for 8 M reads into 96 files, where the
 		// CPU pool takes 2.6 — at 6 CPU-seconds instead of 28)
-		int nt = 3;
+		int nt = 2;                                            // (round 6, after the writers' tails went in together: 2 threads 1.57 s, 3 1.65, 4 1.71, 6 2.03 for the same 8 M reads)
 		if (const char *e = getenv("SEQKIT_GPU_DEFLATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nt = v; }
 		for (int i = 0; i < nt; i++) threads.emplace_back([this] { run_gpu(); });
 		return;
@@ -1034,8 +1034,14 @@ void Pool::run_gpu()
 	std::vector<uint8_t> outbuf;
 	std::vector<sk_deflate_block> blocks;
 	std::vector<uint64_t> off;
+	// SEQKIT_PROF=1: where this batching thread's time went
+	const bool prof = getenv("SEQKIT_PROF") != nullptr;
+	auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+	double t_idle = 0, t_ctx = 0, t_lay = 0, t_call = 0, t_hand = 0;
+	size_t n_batches = 0, n_blocks = 0, n_bytes = 0;
 	for (;;) {
 		std::vector<Job> batch;
+		const double tw0 = now();
 		{
 			std::unique_lock<std::mutex> lk(m);
 			cv_job.wait(lk, [this] { return stop || !q.empty(); });
@@ -1047,11 +1053,15 @@ void Pool::run_gpu()
 		}
 		std::vector<std::string> comp(batch.size());
 		bool done = false;
+		const double tb0 = now();
+		t_idle += tb0 - tw0;
+		double tb1 = tb0, tb2 = tb0, tb3 = tb0;
 		if (!broken) {
 			if (!ctx) {
 				const int dev = getenv("SEQKIT_GPU") ? atoi(getenv("SEQKIT_GPU")) : 0;
 				if (sk_create(dev, &ctx) != SK_OK) { ctx = nullptr; broken = true; }
 			}
+			tb1 = tb2 = tb3 = now();
 			if (ctx) {
 				in.clear();
 				blocks.clear();
@@ -1066,7 +1076,10 @@ void Pool::run_gpu()
 				in.resize(in.size() + 8);
 				outbuf.resize(blocks.size() * (size_t)SK_DEFLATE_MAX_MEMBER + 64);
 				off.assign(blocks.size() + 1, 0);
+				tb2 = now();
 				const int rc = blocks.empty() ? SK_OK : sk_bgzf_deflate(ctx, in.data(), in.size() - 8, blocks.data(), (int64_t)blocks.size(), outbuf.data(), outbuf.size(), off.data());
+				tb3 = now();
+				n_batches++; n_blocks += blocks.size(); n_bytes += in.size();
 				if (rc == SK_OK) {
 					for (size_t j = 0; j < batch.size(); j++)
 						comp[j].assign(reinterpret_cast<const char *>(outbuf.data() + off[first[j]]), (size_t)(off[first[j + 1]] - off[first[j]]));
@@ -1090,8 +1103,12 @@ void Pool::run_gpu()
 			in_flight -= batch.size();
 			cv_room.notify_all();
 		}
+		t_ctx += tb1 - tb0; t_lay += tb2 - tb1; t_call += tb3 - tb2; t_hand += now() - tb3;
 	}
+	const double td0 = now();
 	if (ctx) sk_destroy(ctx);
+	if (prof) fprintf(stderr, "deflate batcher: %zu batches, %zu blocks, %.0f MB; waiting for jobs %.3f s, context %.3f, laying the batch out %.3f, sk_bgzf_deflate %.3f, members to their files %.3f, sk_destroy %.3f\n",
+	                  n_batches, n_blocks, n_bytes / 1e6, t_idle, t_ctx, t_lay, t_call, t_hand, now() - td0);
 }
 
 Pool::~Pool()
@@ -1146,6 +1163,14 @@ void GzWriter::write(std::string &&s)
 	impl_->parts.push_back(std::move(s));
 	impl_->open_tail = false;
 	if (impl_->bytes >= kGzBlock) impl_->submit();
+}
+
+// what is buffered goes to the pool now; nothing is waited for (a command that closes many files hands in all their tails first: closing
+// them one after the other made every tail a launch of its own on the device path — 96 files, 7 ms each)
+void GzWriter::flush_tail()
+{
+	if (!impl_ || impl_->fd < 0) return;
+	if (impl_->bytes > 0) impl_->submit();
 }
 
 void GzWriter::close()
@@ -1233,6 +1258,18 @@ static GpuInit create_ctxs()
 }
 static std::mutex g_warm_m;
 static std::shared_future<GpuInit> g_warm;
+
+static const double g_process_start = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }();
+double process_start_s() { return g_process_start; }
+static const struct ExitProf {                    // SEQKIT_PROF: when the process is through with its static destructors
+	~ExitProf()
+	{
+		if (!getenv("SEQKIT_PROF")) return;
+		timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		fprintf(stderr, "process: %.3f s from static initialisation to the last static destructor of host_common\n", ts.tv_sec + ts.tv_nsec * 1e-9 - g_process_start);
+	}
+} g_exit_prof;
 
 void gpu_warmup()
 {

@@ -87,6 +87,7 @@ public:
 	void write(const char *p, size_t n);
 	void write(const std::string &s) { write(s.data(), s.size()); }
 	void write(std::string &&s);                         // takes the string over: the copy into the member happens on a pool thread
+	void flush_tail();                                   // hand what is buffered to the pool, wait for nothing
 	void close();                                        // flush, wait for this file's blocks, close the descriptor
 	struct Impl;
 private:
@@ -146,7 +147,8 @@ Out &out();
 // is used by one thread at a time: a worker holds a GpuLease around its sk_* calls.  Blocks are dealt to the slots
 // round-robin; the results are handed on in input order by the callers, whichever slot computed them.
 sk_ctx *gpu();                                           // slot 0: set-up calls and single-threaded commands
-void gpu_warmup();                                       // start creating the contexts in the background (silent on failure)
+void gpu_warmup();
+double process_start_s();          // CLOCK_MONOTONIC seconds at this library's static initialisation (SEQKIT_PROF lines)                                       // start creating the contexts in the background (silent on failure)
 size_t gpu_slots();                                      // number of contexts
 sk_ctx *gpu_slot(size_t i);
 void gpu_for_each(const std::function<void(sk_ctx *)> &fn);      // every slot, in order (sk_set_barcodes, ...)
