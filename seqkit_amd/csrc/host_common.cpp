@@ -1030,7 +1030,8 @@ void Pool::run_gpu()
 {
 	sk_ctx *ctx = nullptr;
 	bool broken = false;
-	std::vector<uint8_t> in;
+	uint8_t *in = nullptr;                               // page-locked (sk_malloc_pinned): the batch's bytes go to the device by DMA from where they were laid out
+	size_t in_cap = 0;
 	std::vector<uint8_t> outbuf;
 	std::vector<sk_deflate_block> blocks;
 	std::vector<uint64_t> off;
@@ -1063,23 +1064,35 @@ void Pool::run_gpu()
 			}
 			tb1 = tb2 = tb3 = now();
 			if (ctx) {
-				in.clear();
 				blocks.clear();
+				size_t in_bytes = 0;
+				for (const Job &jb : batch) for (const std::string &p : jb.parts) in_bytes += p.size();
+				int rc = SK_OK;
+				if (in_bytes + 8 > in_cap) {
+					if (in) (void)sk_free_pinned(ctx, in);
+					in = nullptr;
+					in_cap = std::max<size_t>(in_bytes + in_bytes / 4 + 8, (size_t)32 << 20);
+					void *pp = nullptr;
+					rc = sk_malloc_pinned(ctx, in_cap, &pp);
+					in = (uint8_t *)pp;
+					if (rc != SK_OK) in_cap = 0;
+				}
 				std::vector<size_t> first(batch.size() + 1, 0);            // a job's first block
-				for (size_t j = 0; j < batch.size(); j++) {
+				size_t fill = 0;
+				for (size_t j = 0; j < batch.size() && rc == SK_OK; j++) {
 					first[j] = blocks.size();
-					size_t at = in.size(), total = 0;
-					for (const std::string &p : batch[j].parts) { in.insert(in.end(), p.begin(), p.end()); total += p.size(); }
+					const size_t at = fill;
+					size_t total = 0;
+					for (const std::string &p : batch[j].parts) { memcpy(in + fill, p.data(), p.size()); fill += p.size(); total += p.size(); }
 					for (size_t o = 0; o < total; o += kBgzfInput) blocks.push_back({(uint64_t)(at + o), (uint32_t)std::min(kBgzfInput, total - o), 0u});
 				}
 				first[batch.size()] = blocks.size();
-				in.resize(in.size() + 8);
 				outbuf.resize(blocks.size() * (size_t)SK_DEFLATE_MAX_MEMBER + 64);
 				off.assign(blocks.size() + 1, 0);
 				tb2 = now();
-				const int rc = blocks.empty() ? SK_OK : sk_bgzf_deflate(ctx, in.data(), in.size() - 8, blocks.data(), (int64_t)blocks.size(), outbuf.data(), outbuf.size(), off.data());
+				if (rc == SK_OK && !blocks.empty()) rc = sk_bgzf_deflate(ctx, in, fill, blocks.data(), (int64_t)blocks.size(), outbuf.data(), outbuf.size(), off.data());
 				tb3 = now();
-				n_batches++; n_blocks += blocks.size(); n_bytes += in.size();
+				n_batches++; n_blocks += blocks.size(); n_bytes += fill;
 				if (rc == SK_OK) {
 					for (size_t j = 0; j < batch.size(); j++)
 						comp[j].assign(reinterpret_cast<const char *>(outbuf.data() + off[first[j]]), (size_t)(off[first[j + 1]] - off[first[j]]));
@@ -1106,6 +1119,7 @@ void Pool::run_gpu()
 		t_ctx += tb1 - tb0; t_lay += tb2 - tb1; t_call += tb3 - tb2; t_hand += now() - tb3;
 	}
 	const double td0 = now();
+	if (ctx && in) (void)sk_free_pinned(ctx, in);
 	if (ctx) sk_destroy(ctx);
 	if (prof) fprintf(stderr, "deflate batcher: %zu batches, %zu blocks, %.0f MB; waiting for jobs %.3f s, context %.3f, laying the batch out %.3f, sk_bgzf_deflate %.3f, members to their files %.3f, sk_destroy %.3f\n",
 	                  n_batches, n_blocks, n_bytes / 1e6, t_idle, t_ctx, t_lay, t_call, t_hand, now() - td0);
