@@ -138,6 +138,16 @@ def corpus(rng):
         mix += rng.integers(0, 256, d, dtype=np.uint8).tobytes() * int(rng.integers(1, 9))
     out.append(("short periods", bytes(mix[:64000]), {"level": 6}))
     out.append(("max block", (recs * 2)[:65536], {"level": 4}))
+    # many short matches with short codes (round 6's group decode: up to a few dozen symbols in one 64-bit buffer, more matches in a group
+    # than the batch has room left for), and literals between long matches at every offset of the ring's 512-byte units
+    out.append(("binary noise: dense short matches", rng.integers(0, 2, 65000, dtype=np.uint8).tobytes(), {"level": 9}))
+    out.append(("four letters, level 1", rng.integers(0, 4, 65000, dtype=np.uint8).tobytes(), {"level": 1}))
+    steps = bytearray()
+    k = 0
+    while len(steps) < 64000:
+        steps += bytes([65 + k % 26]) * (200 + 13 * (k % 23)) + rng.integers(0, 256, k % 5, dtype=np.uint8).tobytes()
+        k += 1
+    out.append(("runs of 200-500 with a few literals between", bytes(steps[:64000]), {"level": 6}))
     return out
 
 

@@ -4,7 +4,7 @@
 set -eu
 T=${1:-r06}; G=gpurun_out; P=profiles
 for f in bench.json traced_bench.json pmc_summary.txt pmc_traffic.json rocprof_kernel_stats.csv rocprof_kernel_trace_head.csv rocprof_timed_steps.txt \
-         two_ranks_same_device.json cli_demux_kernel_stats.csv cli_demux_kernel_trace_head.csv rates.txt bam_host.txt gpu_tests.txt insert_exp.txt lut_cold.txt lut_repro.txt many_rate.txt inflate_rate.txt deflate_rate.txt bam_gpu.txt deflate_e2e.txt; do cp $G/$T/$f $P/${T}_$f; done
+         two_ranks_same_device.json cli_demux_kernel_stats.csv cli_demux_kernel_trace_head.csv rates.txt bam_host.txt gpu_tests.txt insert_exp.txt lut_cold.txt lut_repro.txt many_rate.txt inflate_rate.txt inflate_stamps.txt deflate_rate.txt bam_gpu.txt deflate_e2e.txt demux_prof.txt; do cp $G/$T/$f $P/${T}_$f; done
 cp $G/$T/pmc_traffic.json $P/pmc_traffic.json
 grep -v amdgpu.ids $G/$T/census_stamps.txt > $P/${T}_census_stamps.txt
 cp $G/${T}_census/kernels.txt $P/${T}_census_kernels.txt

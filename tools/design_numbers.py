@@ -6,7 +6,7 @@ import os
 import re
 import sys
 
-tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r05")
+tag = next((a for a in sys.argv[1:] if not a.startswith("-")), "r06")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench.json")).read().strip().splitlines()[-1])
 bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "25 µs of streaming + 6 µs of launch and events per call", "cfg2 read": "HBM", "fused single-end:": "HBM",
@@ -14,9 +14,9 @@ bound = {"cfg1": "HBM", "cfg2 worst": "scan issue, then HBM", "cfg2: trim": "25 
          "cfg3 sheet": "memory side as placed (§3.2b)", "demultiplex only 10M x 17ch, 96 dual-index, a mixed": "as the 384-sample sheet: three lookups per read",
          "demultiplex only 10M x 17ch, 96": "memory side as placed + the call's fixed part", "96 dual-index with": "the same", "96 dual-index, 100M": "memory side as placed (§3.2b)",
          "demultiplex only 10M x 17ch, 384": "three lookups per read, then the memory side", "cfg5": "HBM", "f2:": "HBM", "f4:": "HBM as placed (LDS-tile kernel, §3.8)",
-         "f3: census 32M rows (1 M drawn rows x 32), clean": "front kernel (LDS pipe + issue) 0.18 ms + combine 0.05 ms",
-         "f3: census 32M rows (1 M drawn rows x 32), noisy": "front kernel 0.19–0.21 ms + combine 0.11 ms (§8)",
-         "f3: census 32M independently": "the distinct keys' inserts into the HBM table",
+         "f3: census 32M rows (1 M drawn rows x 32: rounds 3-5's input), clean": "front kernel (LDS pipe + issue) 0.18 ms + combine 0.05 ms",
+         "f3: census 32M rows (1 M drawn rows x 32: rounds 3-5's input), noisy": "front kernel 0.19–0.21 ms + combine 0.11 ms",
+         "f3: census 32M independently": "the distinct keys' inserts into the HBM table: ≈ 25 G scattered agent-scope operations/s chip-wide (§8)",
          "f3: census 32M rows, every": "memory side: one CAS + two stores per new key"}
 rows = []
 for x in d["extra"]["rates"]:
@@ -24,6 +24,10 @@ for x in d["extra"]["rates"]:
     placed = f" (as placed {x['frac_as_placed']:.3f})" if x.get("frac_as_placed") else ""
     if "frac_warm" in x:                                       # rows timed from HBM: buffer sets in rotation, one event pair per call
         placed += f" from HBM; pipelined {x['frac_pipelined']:.3f}, on-die replay {x['frac_warm']:.3f} ({x['ms_warm'] * 1000:.1f} µs)"
+    if "frac_many" in x:                                       # the buffer sets as the batches of ONE many-batch call
+        placed += f"; per batch of one many-batch call {x['frac_many']:.3f} ({x['ms_many'] * 1000:.1f} µs)"
+    if "reset_ms" in x:                                        # census: sk_census_reset before the count
+        placed += f"; reset {x['reset_ms'] * 1000:.0f} µs, reset + count {x['reset_plus_count_ms'] * 1000:.0f} µs"
     rows.append(f"| {x['config']} | {x['ms'] * 1000:.1f} µs, {x['G_units_per_s']:.1f} G units/s | {x['frac']:.3f}{placed} | {b} |")
 table = "| config (device-resident; `bench.py` `extra.rates`) | rate | of 8 TB/s | bound |\n|---|---|---|---|\n" + "\n".join(rows)
 r = d["roofline"]
@@ -33,6 +37,8 @@ print("placement:", d["config"]["placement"].get("ms_before"), "->", d["config"]
 print("cpu all cores:", d["cpu_baseline"].get("all_cores"))
 print("cpu:", d["cpu_baseline"]["value"], {k: v["M_reads_per_s"] for k, v in d["cpu_baseline"].get("faithful", {}).items() if isinstance(v, dict)})
 print(table)
+for x in d["extra"].get("bam_files", []):
+    print(f"bam file: {x['ms']:.1f} ms, {x['M_records_per_s']:.1f} M records/s, {x['compressed_GBps']:.2f} GB/s compressed, {x['inflated_GBps']:.1f} GB/s inflated; {x['config']}")
 if "--write" in sys.argv:
     p = os.path.join(root, "DESIGN.md")
     s = open(p).read()

@@ -25,6 +25,9 @@ bash tools/census_trace.sh ${TAG}_census > $OUT/census_trace.log 2>&1
 ( cd seqkit_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSK_CENSUS_STAMPS -o ../../tools/ab/census_stamps.so sk_kernels.hip sk_census.hip sk_inflate.hip sk_deflate.hip sk_capi.hip sk_bamfile.cpp sk_lut.cpp -ldl -lz -pthread ) > $OUT/census_stamps_build.log 2>&1
 SK_STAMPS_CASES=exact,clean,noisy,noisy_indep python3 tools/census_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/census_stamps.txt
 bash tools/r06/census_attr.sh ${TAG}_census_indep > $OUT/census_indep.log 2>&1
+# (round 6) where the inflater's waves spend their cycles: the -DSK_INF_STAMPS build
+( cd seqkit_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSK_INF_STAMPS -o ../../tools/ab/inf_stamps.so sk_kernels.hip sk_census.hip sk_inflate.hip sk_deflate.hip sk_capi.hip sk_bamfile.cpp sk_lut.cpp -ldl -lz -pthread ) > $OUT/inf_stamps_build.log 2>&1
+python3 tools/r06/inflate_rate.py 1024 tools/ab/inf_stamps.so 2>&1 | grep -v amdgpu.ids > $OUT/inflate_stamps.txt
 # (round 6) every secondary kernel whose fraction is quoted: a kernel trace and the PMC passes (tools/r06/kernel_one.py)
 for K in mask bam fragments sequence152 sequence148 inflate_random inflate_sorted deflate; do
   bash tools/profile_cmd.sh ${TAG}_k_$K "sk::" tools/r06/kernel_one.py $K > $OUT/k_$K.log 2>&1
@@ -35,6 +38,7 @@ python3 tools/r06/inflate_rate.py 1024 2>&1 | grep -v amdgpu.ids > $OUT/inflate_
 python3 tools/r06/deflate_rate.py 256 2>&1 | grep -v amdgpu.ids > $OUT/deflate_rate.txt
 bash tools/r06/bam_gpu.sh $OUT > $OUT/bam_gpu.log 2>&1
 bash tools/r06/deflate_e2e.sh $OUT 80 > $OUT/deflate_e2e.log 2>&1
+DEMUX_PROF_QUIET=1 bash tools/r06/demux_prof.sh $TAG 80 > $OUT/demux_prof.log 2>&1
 { tools/ab/insert_exp; } > $OUT/insert_exp.txt 2>&1
 {
   echo "== tools/rates.py"; python3 tools/rates.py 2>&1 | grep -v amdgpu.ids

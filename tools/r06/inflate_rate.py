@@ -85,13 +85,13 @@ for kind in ("random", "sorted"):
         ctx._lib.sk_debug_inflate_stamps(acc, 1)
         ctx.bgzf_inflate_dev(d_comp, d_blocks, n, d_out, d_status, False); ctx.sync()
         ctx._lib.sk_debug_inflate_stamps(acc, 1)
-        names = {0: "-", 1: "refill + the group's table reads", 2: "chain + the literals' stores", 3: "match decode + the rest of the loop", 4: "batch: matches from flushed bytes", 5: "batch: matches through the ring",
-                 6: "flush", 7: "a match across the unit's end", 8: "(into finish_batch)", 9: "(into flush)"}
+        names = {0: "-", 1: "the group loop (refill, per-lane decode, chain, places, stores)", 2: "-", 3: "a symbol bit by bit (long codes, end of block, a match across the unit's end)",
+                 4: "batch: matches from flushed bytes", 5: "batch: matches through the ring", 6: "flush", 7: "a match across the unit's end: its copy", 8: "(into finish_batch)", 9: "(into flush)"}
         blocks_done, total = acc[14], acc[15]
-        print(f"   stamps: {blocks_done} blocks, {total / max(1, blocks_done):.0f} cycles per block; groups per block {acc[10] / max(1, blocks_done):.0f}")
+        print(f"   stamps: {blocks_done} blocks, {total / max(1, blocks_done):.0f} cycles per block")
         inside = sum(acc[i] for i in range(10))
         print(f"   outside the symbol loop (headers, tables, final flush): {(total - inside) / max(1, blocks_done):.0f} cycles per block = {100 * (total - inside) / max(1, total):.1f} %")
-        for i in range(1, 10):
-            print(f"   {names[i]:42s} {acc[i] / max(1, blocks_done):10.0f} cycles per block  {100 * acc[i] / max(1, total):5.1f} %")
+        for i in (1, 3, 4, 5, 6, 7, 8, 9):
+            print(f"   {names[i]:80s} {acc[i] / max(1, blocks_done):10.0f} cycles per block  {100 * acc[i] / max(1, total):5.1f} %")
     for p in (d_comp, d_blocks, d_out, d_status):
         ctx.free_device(p)
