@@ -34,11 +34,13 @@ namespace {
 struct Cleanup {                                 // frees what was allocated, whichever way the function is left
 	std::vector<void *> dev, pinned;
 	std::vector<hipEvent_t> events;
-	std::vector<hipStream_t> streams;
+	std::vector<hipStream_t> streams, wait_for;
 	int fd = -1;
 	~Cleanup()
 	{
-		for (hipStream_t s : streams) (void)hipStreamDestroy(s);
+		// (the big buffers stay with the ctx: nothing of this call may still be running on them when the next one starts)
+		for (hipStream_t s : wait_for) (void)hipStreamSynchronize(s);
+		for (hipStream_t s : streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
 		for (void *p : dev) if (p) (void)hipFree(p);
 		for (void *p : pinned) if (p) (void)hipHostFree(p);
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -114,22 +116,30 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	const uint64_t fsize = (uint64_t)sb.st_size;
 	const double t0 = now_ms();
 	hipStream_t st = sk::ctx_stream(c), st2 = sk::ctx_stream2(c);
+	cl.wait_for = {st, st2};
 
 	// ---- device buffers: the compressed file, and room for the inflated stream (its size is known only when the last
-	// trailer has been read: six times the file — a BAM inflates three- to fourfold — or what the device has left)
-	uint8_t *d_comp = nullptr, *d_out = nullptr;
-	BF_HIP(hipMalloc((void **)&d_comp, fsize + 64));
-	cl.dev.push_back(d_comp);
-	size_t free_b = 0, total_b = 0;
-	BF_HIP(hipMemGetInfo(&free_b, &total_b));
+	// trailer has been read: six times the file — a BAM inflates three- to fourfold — or what the device has left).  They STAY WITH
+	// THE CTX from one call to the next (sk::ctx_keep; sk_destroy frees them): a process that gave 20 GB back and asked for them again
+	// found one call in three waiting 1.3-2.4 s in its reading loop — the copies queue behind what the driver does with memory
+	// that changes hands (with a third of the room: none in nine calls; the first call of a process: never).
+	enum { kKeepComp = 0, kKeepOut = 1, kKeepPin = 2, kKeepTable = 3, kKeepBlocks = 4, kKeepStatus = 5 };
+	int krc = SK_OK;
+	uint8_t *d_comp = (uint8_t *)sk::ctx_keep(c, kKeepComp, fsize + 64, false, &krc);
+	if (!d_comp) return krc;
 	uint64_t out_cap = std::max<uint64_t>(fsize * 6, (uint64_t)256 << 20);
 	if (const char *ev = getenv("SK_BAMFILE_OUT_FACTOR")) { const int f = atoi(ev); if (f >= 1 && f <= 1100) out_cap = std::max<uint64_t>(fsize * (uint64_t)f, (uint64_t)1 << 20); }
-	out_cap = std::min<uint64_t>(out_cap, (uint64_t)(free_b * 0.8));
-	{
-		hipError_t e = hipMalloc((void **)&d_out, out_cap + 64);
-		if (e != hipSuccess) { (void)hipGetLastError(); BF_LEAVE(3); }
+	uint8_t *d_out = nullptr;
+	if (sk::ctx_kept_bytes(c, kKeepOut) >= out_cap + 64) {
+		out_cap = sk::ctx_kept_bytes(c, kKeepOut) - 64;                   // (what an earlier call took: all of it is room)
+		d_out = (uint8_t *)sk::ctx_keep(c, kKeepOut, out_cap + 64, false, &krc);
+	} else {
+		size_t free_b = 0, total_b = 0;
+		BF_HIP(hipMemGetInfo(&free_b, &total_b));
+		out_cap = std::min<uint64_t>(out_cap, (uint64_t)((free_b + sk::ctx_kept_bytes(c, kKeepOut)) * 0.8));
+		d_out = (uint8_t *)sk::ctx_keep(c, kKeepOut, out_cap + 64, false, &krc);
+		if (!d_out) BF_LEAVE(3);
 	}
-	cl.dev.push_back(d_out);
 
 	// ---- read, ship, follow the headers; inflate batch by batch
 	size_t chunk = (size_t)8 << 20;                                      // (8 MiB x 3 pinned buffers: 6 ms to allocate where 32 MiB took 17-20; the call's time is the same)
@@ -140,11 +150,12 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	constexpr int kBufs = 3;
 	uint8_t *pin[kBufs];
 	hipEvent_t ev_copied[kBufs];
+	{
+		uint8_t *p = (uint8_t *)sk::ctx_keep(c, kKeepPin, kBufs * chunk, true, &krc);
+		if (!p) return krc;
+		for (int i = 0; i < kBufs; i++) pin[i] = p + (size_t)i * chunk;
+	}
 	for (int i = 0; i < kBufs; i++) {
-		void *p = nullptr;
-		BF_HIP(hipHostMalloc(&p, chunk, hipHostMallocDefault));
-		cl.pinned.push_back(p);
-		pin[i] = (uint8_t *)p;
 		BF_HIP(hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming));
 		cl.events.push_back(ev_copied[i]);
 	}
@@ -162,22 +173,16 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		sk_bgzf_block *data() const { return p; }
 		sk_bgzf_block &operator[](size_t i) const { return p[i]; }
 	} blocks;
-	{
-		void *p = nullptr;
-		BF_HIP(hipHostMalloc(&p, tab_cap * sizeof(sk_bgzf_block), hipHostMallocDefault));
-		cl.pinned.push_back(p);
-		blocks.p = (sk_bgzf_block *)p;
-	}
+	blocks.p = (sk_bgzf_block *)sk::ctx_keep(c, kKeepTable, tab_cap * sizeof(sk_bgzf_block), true, &krc);
+	if (!blocks.p) return krc;
 	std::vector<uint64_t> bend;
 	bend.reserve(tab_cap);
 	const double t_alloc_pre = now_ms();
 	(void)t_alloc_pre;
-	sk_bgzf_block *d_blocks = nullptr;
-	uint32_t *d_status = nullptr;
-	BF_HIP(hipMalloc((void **)&d_blocks, tab_cap * sizeof(sk_bgzf_block)));
-	cl.dev.push_back(d_blocks);
-	BF_HIP(hipMalloc((void **)&d_status, tab_cap * sizeof(uint32_t)));
-	cl.dev.push_back(d_status);
+	sk_bgzf_block *d_blocks = (sk_bgzf_block *)sk::ctx_keep(c, kKeepBlocks, tab_cap * sizeof(sk_bgzf_block), false, &krc);
+	if (!d_blocks) return krc;
+	uint32_t *d_status = (uint32_t *)sk::ctx_keep(c, kKeepStatus, tab_cap * sizeof(uint32_t), false, &krc);
+	if (!d_status) return krc;
 
 	const double t_alloc = now_ms();
 	// A launch is a wave per block, and a CU holds 16 of them: a batch is a whole number of such rounds (what is left over of

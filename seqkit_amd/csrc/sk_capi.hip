@@ -54,6 +54,8 @@ struct sk_ctx {
 	int many_next = 0;
 	uint8_t *pin = nullptr;            // a pinned landing area (sk_bgzf_deflate: the compressed slots come back here)
 	size_t pin_bytes = 0;
+	// buffers that stay with the ctx from one call to the next (sk::ctx_keep: sk_bam_file_reduce's device and pinned buffers)
+	struct Kept { void *p = nullptr; size_t cap = 0; bool pinned = false; } kept[8];
 	sk::Census *census = nullptr;
 	ncclComm_t comm = nullptr;         // one-process-per-GPU communicator (sk_comm_init_rank)
 	int comm_ranks = 0;
@@ -113,6 +115,21 @@ namespace sk {
 hipStream_t ctx_stream(sk_ctx *c) { return c->stream; }
 hipStream_t ctx_stream2(sk_ctx *c) { return c->stream2; }
 int ctx_n_cu(sk_ctx *c) { return c->n_cu; }
+// a buffer of at least `bytes` that stays with the ctx (slot 0..7; device memory or page-locked host memory); its contents are not kept
+// when it has to grow.  nullptr + an error code in *rc when the allocation fails (the slot is then empty).
+void *ctx_keep(sk_ctx *c, int slot, size_t bytes, bool pinned, int *rc)
+{
+	*rc = SK_OK;
+	auto &k = c->kept[slot];
+	if (k.p && k.cap >= bytes && k.pinned == pinned) return k.p;
+	if (k.p) { if (k.pinned) (void)hipHostFree(k.p); else (void)hipFree(k.p); k.p = nullptr; k.cap = 0; }
+	void *p = nullptr;
+	const hipError_t e = pinned ? hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) : hipMalloc(&p, bytes ? bytes : 1);
+	if (e != hipSuccess) { (void)hipGetLastError(); *rc = fail(c, SK_ERR_NOMEM, "%zu bytes of %s memory: %s", bytes, pinned ? "page-locked" : "device", hipGetErrorString(e)); return nullptr; }
+	k.p = p; k.cap = bytes; k.pinned = pinned;
+	return p;
+}
+size_t ctx_kept_bytes(sk_ctx *c, int slot) { return c->kept[slot].p ? c->kept[slot].cap : 0; }
 int ctx_bind(sk_ctx *c) { return bind(c); }
 int ctx_fail(sk_ctx *c, int code, const char *fmt, ...)
 {
@@ -217,6 +234,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->d_count_rep) (void)hipFree(c->d_count_rep);
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->pin) (void)hipHostFree(c->pin);
+	for (auto &k : c->kept) if (k.p) { if (k.pinned) (void)hipHostFree(k.p); else (void)hipFree(k.p); }
 	if (c->many_pin) (void)hipHostFree(c->many_pin);
 	if (c->many_dev) (void)hipFree(c->many_dev);
 	for (hipEvent_t e : c->many_ev) if (e) (void)hipEventDestroy(e);

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import seqkit_amd  # noqa: E402
 
 ctx = seqkit_amd.Context(0)
-for _ in range(3):
+for _ in range(int(os.environ.get("BAM_INFO_REPS", "3"))):
     t0 = time.perf_counter()
     handled, counters, hist, total, info = ctx.bam_file_reduce(sys.argv[1], 5000)
     dt = time.perf_counter() - t0
