@@ -14,6 +14,8 @@
 // gathered into batches (fixed-stride SoA), the batch goes through the C-ABI, and the results are emitted
 // in input order; an input error that the reference would hit at record i is raised after records < i have
 // been emitted, exactly where the reference would have stopped.
+#include <unistd.h>
+#include <malloc.h>
 #include <algorithm>
 #include <cstring>
 #include <deque>
@@ -1051,6 +1053,14 @@ bool fasta_text_command(int argc, char **argv, bool before_trim_by_quality, int 
 
 int main(int argc, char **argv)
 {
+	// blocks, per-sample strings and gzip jobs are hundreds of KiB each: above glibc's default mmap threshold every one of them was a
+	// mapping of its own, faulted in page by page and given back when freed (2.3 s of system time in a demultiplex of 8 M reads).  From
+	// the arenas they are recycled.  (SEQKIT_MALLOC_DEFAULT=1: glibc's defaults, for A/B)
+	if (!getenv("SEQKIT_MALLOC_DEFAULT")) {
+		mallopt(M_MMAP_THRESHOLD, 32 << 20);
+		mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		mallopt(M_TOP_PAD, 64 << 20);
+	}
 	int rc = 0;
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
 	// the order of src/fasta_main.rs:45-81 ("trim by quality" is tested before "trim")
@@ -1065,5 +1075,9 @@ int main(int argc, char **argv)
 	else if (argc >= 2 && is(1, "statistics")) rc = statistics(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);
 	host::out().flush();
+	// everything is written and closed: what is left is taking the process apart (static destructors, the HIP runtime's exit handlers,
+	// gigabytes of heap) — 0.16 s of a demultiplex of 8 M reads.  That is left to the kernel, as on the error path (host::error);
+	// SEQKIT_SLOW_EXIT=1 (and SEQKIT_PROF, whose last lines are printed by destructors) returns from main instead.
+	if (!getenv("SEQKIT_SLOW_EXIT") && !getenv("SEQKIT_PROF")) { host::flush_for_exit(); fflush(stdout); fflush(stderr); _exit(rc); }
 	return rc;
 }

@@ -52,6 +52,7 @@ unsigned cpu_budget()
 
 static void (*g_flush)() = nullptr;
 void at_exit_flush(void (*fn)()) { g_flush = fn; }
+void flush_for_exit() { out().flush(); }          // (the commands close their own outputs before they return: the registered flush belongs to a command's lifetime)
 
 // error! of src/common.rs:11-16: eprint!("ERROR: "); eprintln!(...); exit(-1)
 void error(const char *fmt, ...)

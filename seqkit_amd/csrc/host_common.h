@@ -25,6 +25,7 @@ namespace host {
 [[noreturn]] void error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));   // "ERROR: ...\n", status 255
 [[noreturn]] void panic(const char *what);                                              // a Rust panic: status 101
 void at_exit_flush(void (*fn)());                                                       // run before error()/panic() exit
+void flush_for_exit();                                   // stdout's buffer, before a main() leaves through _exit
 
 // ---- Rust std text semantics used on the path --------------------------------------------------------
 bool utf8_valid(const uint8_t *s, size_t n);             // what BufRead::read_line accepts

@@ -11,6 +11,8 @@
 // series of gzip members; after the header every record is block_size:u32 + a 32-byte fixed core) and hands the core
 // columns flag / refID / next_refID / tlen to the device as SoA batches.  Order-dependent pieces stay here, as
 // SURVEY.md §8(e) lists them: the --reads=N early stop and the --on-target sweep (S2, not part of the device path).
+#include <unistd.h>
+#include <malloc.h>
 #include <fcntl.h>
 
 #include <algorithm>
@@ -795,6 +797,14 @@ static int to_reads(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
+	// blocks, per-sample strings and gzip jobs are hundreds of KiB each: above glibc's default mmap threshold every one of them was a
+	// mapping of its own, faulted in page by page and given back when freed (2.3 s of system time in a demultiplex of 8 M reads).  From
+	// the arenas they are recycled.  (SEQKIT_MALLOC_DEFAULT=1: glibc's defaults, for A/B)
+	if (!getenv("SEQKIT_MALLOC_DEFAULT")) {
+		mallopt(M_MMAP_THRESHOLD, 32 << 20);
+		mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		mallopt(M_TOP_PAD, 64 << 20);
+	}
 	int rc = 0;
 	auto is = [&](int i, const char *w) { return argc > i && strcmp(argv[i], w) == 0; };
 	if (argc >= 2 && is(1, "count")) rc = count(argc, argv);
@@ -805,5 +815,9 @@ int main(int argc, char **argv)
 	else if (argc >= 4 && is(1, "to") && is(2, "interleaved") && (is(3, "raw") || is(3, "fasta") || is(3, "fastq"))) rc = to_reads(argc, argv);
 	else fprintf(stderr, "%s\n", USAGE_TOP);
 	host::out().flush();
+	// everything is written and closed: what is left is taking the process apart (static destructors, the HIP runtime's exit handlers,
+	// gigabytes of heap) — 0.16 s of a demultiplex of 8 M reads.  That is left to the kernel, as on the error path (host::error);
+	// SEQKIT_SLOW_EXIT=1 (and SEQKIT_PROF, whose last lines are printed by destructors) returns from main instead.
+	if (!getenv("SEQKIT_SLOW_EXIT") && !getenv("SEQKIT_PROF")) { host::flush_for_exit(); fflush(stdout); fflush(stderr); _exit(rc); }
 	return rc;
 }
