@@ -772,6 +772,17 @@ static void demux_block(const DemuxCfg &cfg, const host::Bytes *blk /* fastq1, f
 	};
 
 	// ---- emit in input order (src/fasta_demultiplex.rs:168-238) ------------------------------------------------------
+	if (!cfg.dry_run && nb > 0) {
+		// room for every sample's share of the block at once (grown append by append, a sample's string was copied over and over)
+		std::vector<uint32_t> share((size_t)S, 0u);
+		for (size_t i = 0; i < nb; i++) if (assign[i] >= 0) share[(size_t)assign[i]]++;
+		const size_t per1 = blk[0].size() / nb + 32, per2 = cfg.paired_end ? blk[1].size() / nb + 32 : 0;
+		for (int s = 0; s < S; s++) {
+			if (!share[(size_t)s]) continue;
+			res.out1[(size_t)s].reserve((size_t)share[(size_t)s] * per1 + 64);
+			if (cfg.paired_end) res.out2[(size_t)s].reserve((size_t)share[(size_t)s] * per2 + 64);
+		}
+	}
 	std::string umi;
 	char wbuf[1024];
 	for (size_t i = 0; i < nb; i++) {

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 {
-  ENVS=("" "SEQKIT_FAST_EXIT=1" "" "SEQKIT_FAST_EXIT=1" "SEQKIT_MALLOC_DEFAULT=1" "SEQKIT_GPU_DEFLATE=0")
+  ENVS=("" "" "SEQKIT_SLOW_EXIT=1" "SEQKIT_MALLOC_DEFAULT=1" "SEQKIT_GPU_DEFLATE=0")
   for ENV in "${ENVS[@]}"; do
     echo "== demultiplex $ENV"
     env $ENV SEQKIT_PROF=1 E2E_STDERR=1 E2E_NO_ORACLE=1 E2E_ONLY="demultiplex (96" timeout -k 10 600 python3 tools/cli_e2e.py $REPS 2>&1 | grep -v "amdgpu.ids\|clusters carried\|Reading sample\|Starting demul" | tail -10
