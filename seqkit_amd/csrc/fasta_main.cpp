@@ -836,6 +836,7 @@ static void demux_block(const DemuxCfg &cfg, const host::Bytes *blk /* fastq1, f
 }
 
 static const size_t kDemuxBlockRecords = 1u << 15;
+static const size_t kCutsAhead = 32;                     // blocks the reader thread may be ahead of the workers (a block of 32 k records of 150 bases is 11 MB)
 
 static int demultiplex(int argc, char **argv)
 {
@@ -986,7 +987,7 @@ static int demultiplex(int argc, char **argv)
 			ahead += want;                           // a short block is the last one
 			{
 				std::unique_lock<std::mutex> lk(cm);
-				cv_room.wait(lk, [&] { return cuts.size() < 4; });
+				cv_room.wait(lk, [&] { return cuts.size() < kCutsAhead; });      // (the reader runs ahead while the device contexts come up: 0.25 s in which it cuts a third of an 8 M-read file)
 				cuts.push_back({data, want});
 			}
 			cv_cut.notify_one();
