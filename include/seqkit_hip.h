@@ -319,8 +319,9 @@ int sk_bam_flag_tlen_dev(sk_ctx *ctx, const uint16_t *flag, const int32_t *tid, 
  * sk_bam_flag_tlen (ADDED to; either may be NULL).  *handled = 0 (and nothing added): the file is not one this path
  * serves — not a regular file, not BGZF, cut short, a record chain that does not verify, a block zlib rejects too —
  * and the caller falls back to its record-at-a-time reader, which produces the reference's output and messages.
- * The device and page-locked buffers of a call (the compressed file, six times its size for the inflated stream) stay with
- * the ctx for the next call; sk_destroy frees them.
+ * The device and page-locked buffers of a call (the compressed file; for the inflated stream a reserved address range of six
+ * times the file's size into which memory is mapped as far as the file inflates) stay with the ctx for the next call;
+ * sk_destroy frees them.
  * info (may be NULL): [0] compressed bytes, [1] inflated bytes, [2] BGZF blocks, [3] records, [4] blocks inflated by
  * zlib on the host, [5] walk rounds, [6] ms reading + copying, [7] ms of device work behind the last copy.          */
 typedef struct sk_bgzf_block {

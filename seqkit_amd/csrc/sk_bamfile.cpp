@@ -22,7 +22,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -93,6 +95,63 @@ inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 		return SK_OK;                                                                                                   \
 	} while (0)
 
+// The inflated stream's room: its size is known only when the file's last trailer has been read, and six times the file — what a
+// well-compressed BAM needs — is 22 GB for a 3.6 GB file of which 5.5 are used.  Memory of that size given back and taken again is
+// what the next call, or the next PROCESS, then waits behind (tools/r06/stall_exp.sh).  So the range is only RESERVED (virtual
+// addresses), and physical memory is mapped into it piece by piece as the inflater's frontier moves (hipMemCreate / hipMemMap): what a
+// file takes is what it inflates to.  The mapping stays with the ctx.  Where the runtime refuses any of this, plain hipMalloc serves.
+struct OutRange {
+	uint8_t *va = nullptr;
+	size_t reserved = 0, mapped = 0, gran = 0, piece = 0;
+	int device = 0;
+	std::vector<hipMemGenericAllocationHandle_t> handles;
+	bool reserve(size_t bytes, int dev)
+	{
+		hipMemAllocationProp prop{};
+		prop.type = hipMemAllocationTypePinned;
+		prop.location.type = hipMemLocationTypeDevice;
+		prop.location.id = dev;
+		size_t g = 0;
+		if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) { (void)hipGetLastError(); return false; }
+		gran = g;
+		piece = (((size_t)512 << 20) + g - 1) / g * g;
+		const size_t want = (bytes + piece - 1) / piece * piece;
+		void *p = nullptr;
+		if (hipMemAddressReserve(&p, want, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+		va = (uint8_t *)p; reserved = want; mapped = 0; device = dev;
+		return true;
+	}
+	bool ensure(size_t bytes)                                            // [0, bytes) is backed by memory
+	{
+		while (mapped < bytes) {
+			if (mapped + piece > reserved) return false;
+			hipMemAllocationProp prop{};
+			prop.type = hipMemAllocationTypePinned;
+			prop.location.type = hipMemLocationTypeDevice;
+			prop.location.id = device;
+			hipMemGenericAllocationHandle_t h;
+			if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+			if (hipMemMap(va + mapped, piece, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+			hipMemAccessDesc acc{};
+			acc.location.type = hipMemLocationTypeDevice;
+			acc.location.id = device;
+			acc.flags = hipMemAccessFlagsProtReadWrite;
+			if (hipMemSetAccess(va + mapped, piece, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(va + mapped, piece); (void)hipMemRelease(h); return false; }
+			handles.push_back(h);
+			mapped += piece;
+		}
+		return true;
+	}
+	void release()
+	{
+		for (size_t i = 0; i < handles.size(); i++) { (void)hipMemUnmap(va + i * piece, piece); (void)hipMemRelease(handles[i]); }
+		handles.clear();
+		if (va) (void)hipMemAddressFree(va, reserved);
+		va = nullptr; reserved = mapped = 0;
+	}
+	static void destroy(void *p) { OutRange *r = (OutRange *)p; r->release(); delete r; }
+};
+
 #define BF_HIP(call)                                                                                                    \
 	do {                                                                                                                \
 		hipError_t e_ = (call);                                                                                         \
@@ -130,7 +189,55 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	uint64_t out_cap = std::max<uint64_t>(fsize * 6, (uint64_t)256 << 20);
 	if (const char *ev = getenv("SK_BAMFILE_OUT_FACTOR")) { const int f = atoi(ev); if (f >= 1 && f <= 1100) out_cap = std::max<uint64_t>(fsize * (uint64_t)f, (uint64_t)1 << 20); }
 	uint8_t *d_out = nullptr;
-	if (sk::ctx_kept_bytes(c, kKeepOut) >= out_cap + 64) {
+	OutRange *range = (OutRange *)sk::ctx_ext(c);
+	if (!getenv("SK_BAMFILE_NO_VMM")) {
+		if (range && range->reserved < out_cap + 64) { sk::ctx_set_ext(c, nullptr, nullptr); OutRange::destroy(range); range = nullptr; }
+		if (!range) {
+			int dev = 0;
+			BF_HIP(hipGetDevice(&dev));
+			range = new OutRange;
+			if (range->reserve(out_cap + 64, dev)) sk::ctx_set_ext(c, range, OutRange::destroy);
+			else { delete range; range = nullptr; }
+		}
+	} else range = nullptr;
+	// (mapping a piece takes ~12 ms — the driver hands out cleared memory —: a thread of its own maps ahead of the inflater's frontier
+	// while this one reads the file)
+	struct Mapper {
+		OutRange *r = nullptr;
+		std::thread th;
+		std::mutex m;
+		std::condition_variable cv;
+		size_t want = 0, have = 0;
+		bool stop = false, failed = false;
+		void start(OutRange *range)
+		{
+			r = range; have = r->mapped;
+			th = std::thread([this] {
+				(void)hipSetDevice(r->device);
+				std::unique_lock<std::mutex> lk(m);
+				for (;;) {
+					cv.wait(lk, [this] { return stop || want > have; });
+					if (stop) return;
+					const size_t next = have + 1;
+					lk.unlock();
+					const bool ok = r->ensure(next);                         // one piece
+					lk.lock();
+					if (!ok) { failed = true; cv.notify_all(); return; }
+					have = r->mapped;
+					cv.notify_all();
+				}
+			});
+		}
+		void ask(size_t bytes) { std::lock_guard<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } }
+		bool wait_for(size_t bytes) { std::unique_lock<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } cv.wait(lk, [&] { return failed || have >= bytes; }); return !failed; }
+		~Mapper() { if (th.joinable()) { { std::lock_guard<std::mutex> lk(m); stop = true; cv.notify_all(); } th.join(); } }
+	} mapper;
+	if (range) {
+		out_cap = range->reserved - 256;                                 // (a batch asks for its last byte + 128)
+		d_out = range->va;
+		mapper.start(range);
+		mapper.ask(std::min<size_t>((size_t)fsize * 2, range->reserved));   // (a BAM inflates at least that far: on its way before the first byte is read)
+	} else if (sk::ctx_kept_bytes(c, kKeepOut) >= out_cap + 64) {
 		out_cap = sk::ctx_kept_bytes(c, kKeepOut) - 64;                   // (what an earlier call took: all of it is room)
 		d_out = (uint8_t *)sk::ctx_keep(c, kKeepOut, out_cap + 64, false, &krc);
 	} else {
@@ -267,6 +374,11 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		if (n_new && (n_new >= min_batch || last)) {
 			if (!last && whole_rounds && n_new >= slots) n_new -= n_new % slots;      // (what is left over goes with the next batch)
 			const size_t first_new = launched;
+			if (range) {
+				const size_t upto = (size_t)(blocks[first_new + n_new - 1].out_off + blocks[first_new + n_new - 1].out_len) + 128;
+				mapper.ask(upto + ((size_t)3 << 29));                        // (three pieces ahead)
+				if (!mapper.wait_for(upto)) BF_LEAVE(3);
+			}
 			hipStream_t sb = (n_batches & 1) ? st_b : st;
 			BF_HIP(hipMemcpyAsync(d_blocks + first_new, blocks.data() + first_new, n_new * sizeof(sk_bgzf_block), hipMemcpyHostToDevice, st2));
 			BF_HIP(hipEventRecord(ev_batch, st2));

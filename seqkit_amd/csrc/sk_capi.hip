@@ -56,6 +56,8 @@ struct sk_ctx {
 	size_t pin_bytes = 0;
 	// buffers that stay with the ctx from one call to the next (sk::ctx_keep: sk_bam_file_reduce's device and pinned buffers)
 	struct Kept { void *p = nullptr; size_t cap = 0; bool pinned = false; } kept[8];
+	void *ext = nullptr;               // an object another translation unit keeps with the ctx (sk_bamfile.cpp: its mapped output range), and how to free it
+	void (*ext_free)(void *) = nullptr;
 	sk::Census *census = nullptr;
 	ncclComm_t comm = nullptr;         // one-process-per-GPU communicator (sk_comm_init_rank)
 	int comm_ranks = 0;
@@ -130,6 +132,8 @@ void *ctx_keep(sk_ctx *c, int slot, size_t bytes, bool pinned, int *rc)
 	return p;
 }
 size_t ctx_kept_bytes(sk_ctx *c, int slot) { return c->kept[slot].p ? c->kept[slot].cap : 0; }
+void *ctx_ext(sk_ctx *c) { return c->ext; }
+void ctx_set_ext(sk_ctx *c, void *p, void (*free_fn)(void *)) { c->ext = p; c->ext_free = free_fn; }
 int ctx_bind(sk_ctx *c) { return bind(c); }
 int ctx_fail(sk_ctx *c, int code, const char *fmt, ...)
 {
@@ -235,6 +239,7 @@ void sk_destroy(sk_ctx *c)
 	if (c->ws) (void)hipFree(c->ws);
 	if (c->pin) (void)hipHostFree(c->pin);
 	for (auto &k : c->kept) if (k.p) { if (k.pinned) (void)hipHostFree(k.p); else (void)hipFree(k.p); }
+	if (c->ext && c->ext_free) c->ext_free(c->ext);
 	if (c->many_pin) (void)hipHostFree(c->many_pin);
 	if (c->many_dev) (void)hipFree(c->many_dev);
 	for (hipEvent_t e : c->many_ev) if (e) (void)hipEventDestroy(e);

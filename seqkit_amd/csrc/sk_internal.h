@@ -198,6 +198,8 @@ hipStream_t ctx_stream2(sk_ctx *c);
 int ctx_n_cu(sk_ctx *c);
 void *ctx_keep(sk_ctx *c, int slot, size_t bytes, bool pinned, int *rc);      // a buffer that stays with the ctx from call to call (freed by sk_destroy)
 size_t ctx_kept_bytes(sk_ctx *c, int slot);
+void *ctx_ext(sk_ctx *c);                                       // an object kept with the ctx (freed by sk_destroy through free_fn)
+void ctx_set_ext(sk_ctx *c, void *p, void (*free_fn)(void *));
 int ctx_bind(sk_ctx *c);                                        // hipSetDevice; SK_OK or an error code with the message set
 int ctx_fail(sk_ctx *c, int code, const char *fmt, ...);       // sets sk_last_error, returns code
 }  // namespace sk
