@@ -346,8 +346,10 @@ def test_bam_file_reduce_matches_the_readers(ctx, oracle, tmp_path, monkeypatch)
     _, recs = bam_spec.read_bam(path)
     e_stats = bam_spec.statistics(recs)
     e_hist = bam_spec.fragment_lengths(recs, 5000)
-    for chunk_log2 in (None, "12", "16"):
-        if chunk_log2:
+    for chunk_log2 in (None, "12", "16", "novmm"):                # (the last: the inflated stream's room from hipMalloc, not a mapped range)
+        if chunk_log2 == "novmm":
+            monkeypatch.setenv("SK_BAMFILE_NO_VMM", "1")
+        elif chunk_log2:
             monkeypatch.setenv("SK_BAMFILE_CHUNK_LOG2", chunk_log2)
         handled, counters, hist, total, info = ctx.bam_file_reduce(path, 5000)
         assert handled, info
@@ -355,6 +357,7 @@ def test_bam_file_reduce_matches_the_readers(ctx, oracle, tmp_path, monkeypatch)
         assert [int(x) for x in hist] == e_hist[0] and total == e_hist[1]
         assert info[3] == len(recs) and info[4] == 0
     monkeypatch.delenv("SK_BAMFILE_CHUNK_LOG2")
+    monkeypatch.delenv("SK_BAMFILE_NO_VMM")
     # not handled: a truncated file, a file that is not BGZF, a missing file
     data = open(path, "rb").read()
     for name, blob in (("cut.bam", data[:len(data) // 2]), ("plain.bam", b"BAM\1" + bytes(100)), ("gz.bam", zlib.compress(b"BAM\1" + bytes(1000)))):
