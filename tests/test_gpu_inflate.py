@@ -369,6 +369,22 @@ def test_bam_file_reduce_matches_the_readers(ctx, oracle, tmp_path, monkeypatch)
     assert not handled
 
 
+def test_bam_file_reduce_keeps_and_regrows_its_buffers(ctx, oracle, tmp_path):
+    """The call's buffers stay with the ctx (the compressed file's, the mapped range for the inflated stream): a small file, then one
+    whose stream needs a bigger range than the first call reserved, then the small one again — every call equals the oracle."""
+    from seqkit_amd import synth
+    files = []
+    for name, n_rec, unit, kind in (("small.bam", 20_000, 20_000, "sorted"), ("big.bam", 320_000, 80_000, "random"), ("small2.bam", 30_000, 30_000, "random")):
+        path = str(tmp_path / name)
+        n, flag, tid, mtid, tlen, reps = synth.write_bam_file(path, n_rec, seed=11, kind=kind, unit_records=unit)
+        files.append((path, n, oracle.bam_flag_tlen(flag, tid, mtid, tlen, 5000), reps))
+    assert os.path.getsize(files[1][0]) * 6 > 256 << 20            # (more than the first call's reservation)
+    for path, n, (e_counters, e_hist, e_total), reps in files + files[::-1]:
+        handled, counters, hist, total, info = ctx.bam_file_reduce(path, 5000)
+        assert handled and info[3] == n and info[4] == 0
+        assert (counters == e_counters * np.uint64(reps)).all() and (hist == e_hist * np.uint64(reps)).all() and total == e_total * reps
+
+
 def test_inflate_across_4_gib_of_output(ctx):
     """A block whose output straddles 2^32 in the inflated stream (the 66 000th block of a 3.6 GB BAM): the kernel's address
     arithmetic is modular and must not notice."""
