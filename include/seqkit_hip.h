@@ -171,7 +171,8 @@ int sk_fused_pass_dev(sk_ctx *ctx, const sk_fused_args *args);
  * their order does not matter) — checked once, the sheet's table uploaded once.  Batches that are barcode assignment alone
  * and whose sheet is served by a table in LDS (sk_barcode_table_info) run as ONE launch whose waves walk the steps of all
  * batches (at most 256 batches a launch; the table staged once, ramp and tail paid once); every other shape is the
- * batches' launches back to back on the ctx stream (src/fasta_demultiplex.rs:154-194, src/fasta_trim_by_quality.rs:28-42
+ * batches' launches back to back on the ctx stream — on the ctx's two streams in turn when no batch has a barcode phase (trim /
+ * mask alone): sk_sync() waits for both — (src/fasta_demultiplex.rs:154-194, src/fasta_trim_by_quality.rs:28-42
  * work per read: reads are independent, so are batches).  Asynchronous like the _dev calls; sk_sync() waits.  The two
  * conveniences below build the argument blocks. */
 int sk_fused_pass_many_dev(sk_ctx *ctx, const sk_fused_args *batches, int n_batches);

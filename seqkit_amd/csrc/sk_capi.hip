@@ -882,6 +882,7 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 			same = !mates && a.bc && !a.counts && a.bc_stride == f.bc_stride && !a.lowest_diff == !f.lowest_diff && !a.first_idx == !f.first_idx && !a.last_idx == !f.last_idx;
 			rows += ((a.n + 255) / 256) * 256;
 		}
+		if (const char *ev = getenv("SK_MANY_ONE_LAUNCH")) same = same && atoi(ev) != 0;      // (A/B: the batches' own launches instead)
 		if (same && rows > 0 && rows < ((int64_t)1 << 31) && n_batches <= kManyMax) {
 			if (int r = prepare_demux(c, &batches[0])) return r;
 			if (!c->many_pin) {
@@ -926,13 +927,40 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 			} else return SK_OK;
 		}
 	}
+	// batches without a barcode phase (trim / mask alone: nothing but their own outputs is written, no counters) alternate between the
+	// ctx's two streams, so that one batch's last tiles and the next one's first share the chip: cfg 2's 1 M-read batches from HBM 39.0 ->
+	// 31.5 us each = 0.49 -> 0.60 of the HBM peak (SK_MANY_TWO_STREAMS=0: one stream).  (Batches with a barcode phase stay on one stream:
+	// their launches fold per-workgroup counter copies that the next launch is already adding to.)
+	bool two = n_batches >= 2;
+	int two_mode = 1;
+	if (const char *ev = getenv("SK_MANY_TWO_STREAMS")) { two_mode = atoi(ev); two = two && two_mode != 0; }
+	for (int i = 0; i < n_batches && two; i++) {
+		if (batches[i].bc == nullptr) continue;
+		// (A/B, SK_MANY_TWO_STREAMS=2: barcode-only batches whose launches take the lookup table and add to the ctx's wide counters)
+		bool mates = false;
+		for (int m = 0; m < batches[i].n_mates; m++) mates = mates || batches[i].mate[m].out_seq || batches[i].mate[m].lowest_k;
+		if (two_mode < 2 || mates || batches[i].counts) { two = false; break; }
+		if (int r = prepare_demux(c, &batches[i])) return r;
+		const sk::TileArgs t = tile_args_of(c, &batches[i]);
+		two = t.counts_wide != nullptr && sk::tile_pass_demux_by_table(t);
+	}
+	if (two) {
+		SK_HIP(c, hipEventRecord(c->ev_pipe, c->stream));
+		SK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pipe, 0));
+	}
+	int k = 0;
 	for (int i = 0; i < n_batches; i++) {
 		const sk_fused_args *a = &batches[i];
 		if (a->n == 0) continue;
 		if (int r = prepare_demux(c, a)) return r;
 		sk::TileArgs t = tile_args_of(c, a);
 		if (t.bc && t.counts_wide) c->wide_dirty = true;
-		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, c->stream));
+		SK_HIP(c, sk::launch_tile_pass(t, c->n_cu, (two && (k & 1)) ? c->stream2 : c->stream));
+		k++;
+	}
+	if (two) {
+		SK_HIP(c, hipEventRecord(c->ev_pipe, c->stream2));
+		SK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pipe, 0));
 	}
 	return SK_OK;
 }

@@ -157,6 +157,7 @@ hipError_t launch_bam_sequence(const uint8_t *seq4, int seq4_stride, const uint8
 
 // ---- BGZF inflate and the BAM record walk on the device (sk_inflate.hip) ----
 // blocks: device array of sk_bgzf_block; status: device u32 per block (0 = inflated; 1..8 the decoder gave up; | 0x100 CRC mismatch)
+bool tile_pass_demux_by_table(const TileArgs &b);
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int64_t n_blocks, uint8_t *out, uint32_t *status, int check_crc, int n_cu, hipStream_t st);
 hipError_t launch_bam_walk(const uint8_t *stream, uint64_t stream_len, const uint64_t *bend, uint64_t *entry, uint64_t *exitp, uint32_t *nrec, int64_t n,
                            uint64_t first, uint32_t *changed, int fix_round /* 0 first walk, 1 fix, 2 guess */, int32_t n_ref, hipStream_t st);

@@ -2112,6 +2112,15 @@ bool tile_pass_fuses_demux(bool has_bc, bool any_mate, int stride, bool has_bits
 	return has_bc && any_mate && stride <= kMaxTileStride && has_bitsliced && G <= 4 && S > 0 && kTileRows * bc_stride <= 2048 && !env_no_fuse;
 }
 
+// does a barcode-phase launch of these arguments take the sheet's lookup table (one lookup per read; with the ctx's wide counters its
+// adds are atomics into lines of their own and nothing is folded per launch)?
+bool tile_pass_demux_by_table(const TileArgs &b)
+{
+	const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
+	const bool want_detail = b.lowest_diff || b.first_idx || b.last_idx;
+	return (b.table.nbr.tab || b.table.nbr.pair.tab) && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
+}
+
 hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 {
 	if (a.n <= 0) return hipSuccess;
@@ -2146,7 +2155,7 @@ hipError_t launch_tile_pass(const TileArgs &a, int n_cu, hipStream_t st)
 		// only (TileArgs::detail_matched): one lookup per read
 		const bool env_no_hash = getenv("SK_NO_HASH_DEMUX") != nullptr;
 		const bool want_detail = b.lowest_diff || b.first_idx || b.last_idx;
-		const bool by_table = (b.table.nbr.tab || b.table.nbr.pair.tab) && (!want_detail || b.detail_matched) && kTileRows * b.bc_stride <= 2048 && !env_no_hash;
+		const bool by_table = tile_pass_demux_by_table(b);
 		hipError_t e;
 		TileArgs bb = b;
 		if (b.many && !by_table) return hipErrorNotSupported;      // (many batches in one launch: the table's kernels only)
