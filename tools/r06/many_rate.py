@@ -24,9 +24,13 @@ for name, S, dual, L, bpu, detail in (("cfg3 16 x 8", 16, False, 8, 12, False), 
     bc = torch.from_numpy(bc_np).to(dev).repeat(10, 1).contiguous()
     k = bench.cold_sets(n * bpu)
     keep, calls = [], []
+    one_alloc = os.environ.get("MANY_ONE_ALLOC") == "1"                # (A/B: the sets as slices of ONE allocation per array)
+    if one_alloc:
+        big_b = bc.repeat(k, 1).contiguous()
+        big_o = torch.empty((k * n,), dtype=torch.int32, device=dev)
     for i in range(k):
-        b = bc if i == 0 else bc.clone()
-        o = [torch.empty((n,), dtype=torch.int32, device=dev)]
+        b = (big_b[i * n:(i + 1) * n] if one_alloc else (bc if i == 0 else bc.clone()))
+        o = [big_o[i * n:(i + 1) * n] if one_alloc else torch.empty((n,), dtype=torch.int32, device=dev)]
         if detail:
             o += [torch.empty((n,), dtype=torch.uint8, device=dev), torch.empty((n,), dtype=torch.int16, device=dev), torch.empty((n,), dtype=torch.int16, device=dev)]
         keep.append((b, o))
@@ -54,11 +58,12 @@ for name, S, dual, L, bpu, detail in (("cfg3 16 x 8", 16, False, 8, 12, False), 
     piped = one_pair(lambda: [f() for f in calls], k)
     many(); ctx.sync()
     m = one_pair(many, k)
+    m3 = one_pair(lambda: [many() for _ in range(3)], 3 * k)        # three calls inside one event pair: the host's part of a call hides behind the launch before
     # the many-batch call's outputs equal the single calls'
     for b, o in keep[:2]:
         ref = torch.empty_like(o[0])
         ctx.demux_assign_dev(b.data_ptr(), L, n, ref.data_ptr()) if not detail else None
     frac = lambda t: n * bpu / t / 1e6 / 8000
-    print(f"{name:36s} {k} sets: per call {ms * 1e3:6.1f} us = {frac(ms):.3f}; back to back {piped * 1e3:6.1f} us = {frac(piped):.3f}; ONE many-batch call {m * 1e3:6.1f} us = {frac(m):.3f}", flush=True)
+    print(f"{name:36s} {k} sets: per call {ms * 1e3:6.1f} us = {frac(ms):.3f}; back to back {piped * 1e3:6.1f} us = {frac(piped):.3f}; ONE many-batch call {m * 1e3:6.1f} us = {frac(m):.3f}, three such calls in a row {m3 * 1e3:6.1f} us = {frac(m3):.3f}", flush=True)
     ctx.set_detail_mode(capi.SK_DETAIL_FULL)
     del keep, calls
