@@ -152,6 +152,44 @@ struct OutRange {
 	static void destroy(void *p) { OutRange *r = (OutRange *)p; r->release(); delete r; }
 };
 
+// (mapping a piece takes ~12 ms — the driver hands out cleared memory —: a thread of its own maps ahead of the frontier while the
+// caller's thread reads the file)
+struct Mapper {
+	OutRange *r = nullptr;
+	std::thread th;
+	std::mutex m;
+	std::condition_variable cv;
+	size_t want = 0, have = 0;
+	bool stop = false, failed = false;
+	void start(OutRange *range)
+	{
+		r = range; have = r->mapped;
+		th = std::thread([this] {
+			(void)hipSetDevice(r->device);
+			std::unique_lock<std::mutex> lk(m);
+			for (;;) {
+				cv.wait(lk, [this] { return stop || want > have; });
+				if (stop) return;
+				const size_t next = have + 1;
+				lk.unlock();
+				const bool ok = r->ensure(next);                             // one piece
+				lk.lock();
+				if (!ok) { failed = true; cv.notify_all(); return; }
+				have = r->mapped;
+				cv.notify_all();
+			}
+		});
+	}
+	void ask(size_t bytes) { std::lock_guard<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } }
+	bool wait_for(size_t bytes) { std::unique_lock<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } cv.wait(lk, [&] { return failed || have >= bytes; }); return !failed; }
+	~Mapper() { if (th.joinable()) { { std::lock_guard<std::mutex> lk(m); stop = true; cv.notify_all(); } th.join(); } }
+};
+// what stays with the ctx: the range of the compressed file and the range of the inflated stream
+struct Ranges {
+	OutRange comp, out;
+	static void destroy(void *p) { Ranges *r = (Ranges *)p; r->comp.release(); r->out.release(); delete r; }
+};
+
 #define BF_HIP(call)                                                                                                    \
 	do {                                                                                                                \
 		hipError_t e_ = (call);                                                                                         \
@@ -184,63 +222,36 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	// that changes hands (with a third of the room: none in nine calls; the first call of a process: never).
 	enum { kKeepComp = 0, kKeepOut = 1, kKeepPin = 2, kKeepTable = 3, kKeepBlocks = 4, kKeepStatus = 5 };
 	int krc = SK_OK;
-	uint8_t *d_comp = (uint8_t *)sk::ctx_keep(c, kKeepComp, fsize + 64, false, &krc);
-	if (!d_comp) return krc;
 	uint64_t out_cap = std::max<uint64_t>(fsize * 6, (uint64_t)256 << 20);
 	if (const char *ev = getenv("SK_BAMFILE_OUT_FACTOR")) { const int f = atoi(ev); if (f >= 1 && f <= 1100) out_cap = std::max<uint64_t>(fsize * (uint64_t)f, (uint64_t)1 << 20); }
-	uint8_t *d_out = nullptr;
-	OutRange *range = (OutRange *)sk::ctx_ext(c);
+	uint8_t *d_out = nullptr, *d_comp = nullptr;
+	Ranges *both = (Ranges *)sk::ctx_ext(c);
+	OutRange *range = nullptr, *crange = nullptr;
 	if (!getenv("SK_BAMFILE_NO_VMM")) {
-		if (range && range->reserved < out_cap + 64) { sk::ctx_set_ext(c, nullptr, nullptr); OutRange::destroy(range); range = nullptr; }
-		if (!range) {
-			int dev = 0;
-			BF_HIP(hipGetDevice(&dev));
-			range = new OutRange;
-			if (range->reserve(out_cap + 64, dev)) sk::ctx_set_ext(c, range, OutRange::destroy);
-			else { delete range; range = nullptr; }
-		}
-	} else range = nullptr;
-	// (mapping a piece takes ~12 ms — the driver hands out cleared memory —: a thread of its own maps ahead of the inflater's frontier
-	// while this one reads the file)
-	struct Mapper {
-		OutRange *r = nullptr;
-		std::thread th;
-		std::mutex m;
-		std::condition_variable cv;
-		size_t want = 0, have = 0;
-		bool stop = false, failed = false;
-		void start(OutRange *range)
-		{
-			r = range; have = r->mapped;
-			th = std::thread([this] {
-				(void)hipSetDevice(r->device);
-				std::unique_lock<std::mutex> lk(m);
-				for (;;) {
-					cv.wait(lk, [this] { return stop || want > have; });
-					if (stop) return;
-					const size_t next = have + 1;
-					lk.unlock();
-					const bool ok = r->ensure(next);                         // one piece
-					lk.lock();
-					if (!ok) { failed = true; cv.notify_all(); return; }
-					have = r->mapped;
-					cv.notify_all();
-				}
-			});
-		}
-		void ask(size_t bytes) { std::lock_guard<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } }
-		bool wait_for(size_t bytes) { std::unique_lock<std::mutex> lk(m); if (bytes > want) { want = std::min(bytes, r->reserved); cv.notify_all(); } cv.wait(lk, [&] { return failed || have >= bytes; }); return !failed; }
-		~Mapper() { if (th.joinable()) { { std::lock_guard<std::mutex> lk(m); stop = true; cv.notify_all(); } th.join(); } }
-	} mapper;
+		int dev = 0;
+		BF_HIP(hipGetDevice(&dev));
+		if (!both) { both = new Ranges; sk::ctx_set_ext(c, both, Ranges::destroy); }
+		if (both->out.va && both->out.reserved < out_cap + 256) both->out.release();
+		if (both->comp.va && both->comp.reserved < fsize + 64) both->comp.release();
+		if ((both->out.va || both->out.reserve(out_cap + 256, dev)) && (both->comp.va || both->comp.reserve(fsize + 64, dev))) { range = &both->out; crange = &both->comp; }
+	}
+	Mapper mapper, cmapper;
 	if (range) {
 		out_cap = range->reserved - 256;                                 // (a batch asks for its last byte + 128)
 		d_out = range->va;
+		d_comp = crange->va;
+		cmapper.start(crange);
+		cmapper.ask((size_t)fsize + 64);                                  // (all of the file's range, ahead of the readers)
 		mapper.start(range);
 		mapper.ask(std::min<size_t>((size_t)fsize * 2, range->reserved));   // (a BAM inflates at least that far: on its way before the first byte is read)
 	} else if (sk::ctx_kept_bytes(c, kKeepOut) >= out_cap + 64) {
 		out_cap = sk::ctx_kept_bytes(c, kKeepOut) - 64;                   // (what an earlier call took: all of it is room)
 		d_out = (uint8_t *)sk::ctx_keep(c, kKeepOut, out_cap + 64, false, &krc);
+		d_comp = (uint8_t *)sk::ctx_keep(c, kKeepComp, fsize + 64, false, &krc);
+		if (!d_comp) return krc;
 	} else {
+		d_comp = (uint8_t *)sk::ctx_keep(c, kKeepComp, fsize + 64, false, &krc);
+		if (!d_comp) return krc;
 		size_t free_b = 0, total_b = 0;
 		BF_HIP(hipMemGetInfo(&free_b, &total_b));
 		out_cap = std::min<uint64_t>(out_cap, (uint64_t)((free_b + sk::ctx_kept_bytes(c, kKeepOut)) * 0.8));
@@ -322,6 +333,7 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		uint8_t *buf = pin[k % kBufs];
 		if (k >= kBufs) BF_HIP(hipEventSynchronize(ev_copied[k % kBufs]));
 		if (!read_parallel(cl.fd, buf, c_len, c_off, threads)) BF_LEAVE(4);
+		if (crange && !cmapper.wait_for((size_t)(c_off + c_len) + 64)) BF_LEAVE(3);
 		BF_HIP(hipMemcpyAsync(d_comp + c_off, buf, c_len, hipMemcpyHostToDevice, st2));
 		BF_HIP(hipEventRecord(ev_copied[k % kBufs], st2));
 		// the blocks that are complete with this chunk
