@@ -45,3 +45,68 @@ if "--write" in sys.argv:
     s2 = re.sub(r"(<!-- rates:begin -->\n).*?(\n<!-- rates:end -->)", lambda m: m.group(1) + table + m.group(2), s, flags=re.S)
     assert s2 != s or table in s, "markers not found"
     open(p, "w").write(s2)
+
+# ---- the facts DESIGN.md §6's paragraphs quote, from the same profile set (printed, not written: the paragraphs are prose)
+import csv
+import glob
+
+
+def kstat(name, pick=None):
+    rows = list(csv.reader(open(os.path.join(root, "profiles", f"{tag}_{name}_rocprof_kernel_stats.csv"))))[1:]
+    for r in rows:
+        if r[1] and r[3] and (pick is None or pick in r[0]):
+            return int(r[1]), float(r[3]) / 1e3, float(r[5]) / 1e3, float(r[6]) / 1e3
+    return None
+
+
+def pmc(name, kernel=None):
+    out, cur = {}, None
+    for line in open(os.path.join(root, "profiles", f"{tag}_{name}_pmc_summary.txt")):
+        if not line.startswith(" "):
+            cur = line.strip()
+            continue
+        if kernel is None or kernel in (cur or ""):
+            k, _, rest = line.strip().partition(" ")
+            out.setdefault(k, float(rest.split("mean=")[1]))
+    return out
+
+
+print("\n== facts for §6")
+print(open(os.path.join(root, "profiles", f"{tag}_rocprof_timed_steps.txt")).read().strip())
+for name, gb, label in (("lut_cfg3_100m", 1.2, "cfg3 sheet 100 M"), ("lut_dual_100m", 2.1, "96 dual-index 100 M"), ("k_mask", 7.2, "mask_flat"), ("k_bam", 2.8, "bam_flag_tlen"),
+                        ("k_fragments", 2.825, "bam_fragments"), ("k_sequence152", 6.144, "sequence pitch 152"), ("k_sequence148", 6.007, "sequence pitch 148")):
+    n, mean, lo, hi = kstat(name)
+    p = pmc(name)
+    traffic = (p.get("FETCH_SIZE", 0) * 2048 + p.get("WRITE_SIZE", 0) * 1024) / 1e9
+    wait = p.get("SQ_WAIT_ANY", 0) / p["SQ_WAVE_CYCLES"] if p.get("SQ_WAVE_CYCLES") else float("nan")
+    print(f"{label}: {mean:.1f} us mean of {n} ({lo:.1f}-{hi:.1f}) = {gb / mean * 1e6 / 8000:.3f} of 8 TB/s; traffic {traffic:.2f} GB = {traffic / gb:.2f} x; waves wait {wait:.2f}")
+for name in ("k_inflate_random", "k_inflate_sorted", "k_deflate"):
+    for pick in ("inflate_kernel", "crc", "deflate_kernel"):
+        r = kstat(name, pick)
+        if r:
+            print(f"{name} {pick}: {r[1] / 1e3:.2f} ms mean of {r[0]}")
+    p = pmc(name)
+    print(f"   traffic of the first kernel: {p.get('FETCH_SIZE', 0) * 2048 / 1e9:.2f} GB read + {p.get('WRITE_SIZE', 0) * 1024 / 1e9:.2f} GB written")
+p = {}
+cur = None
+for line in open(os.path.join(root, "profiles", f"{tag}_census_indep_pmc_noisy_indep.txt")):
+    if not line.startswith(" "):
+        cur = line.strip()
+    elif "FETCH_SIZE" in line or "WRITE_SIZE" in line or "LDS_BANK" in line or "ACTIVE_INST_LDS" in line:
+        p[(cur, line.split()[0])] = float(line.split("mean=")[1])
+tot = 0.0
+for k in sorted({c for c, _ in p}):
+    rd, wr = p.get((k, "FETCH_SIZE"), 0) * 2048 / 1e6, p.get((k, "WRITE_SIZE"), 0) * 1024 / 1e6
+    tot += rd + wr
+    print(f"census indep noisy {k}: {rd:.0f} + {wr:.0f} MB; bank conflict cycles {p.get((k, 'SQ_LDS_BANK_CONFLICT'), 0) / 1e6:.1f} M, LDS instructions {p.get((k, 'SQ_ACTIVE_INST_LDS'), 0) / 1e6:.1f} M")
+print(f"   total {tot / 1e3:.2f} GB = {tot / 544:.2f} x of 544 MB")
+print("".join(open(os.path.join(root, "profiles", f"{tag}_census_indep_trace_noisy_indep.txt")).readlines()[-6:]).rstrip())
+for f in ("lut_repro.txt", "many_rate.txt", "inflate_rate.txt", "deflate_rate.txt"):
+    print(f"-- {f}")
+    print("".join(open(os.path.join(root, "profiles", f"{tag}_{f}")).readlines()[-6:]).rstrip()[:1500])
+for f, pat in (("bam_gpu.txt", ("wall", "handled", "waited")), ("deflate_e2e.txt", ("hip  ", "cpu user", "==")), ("demux_prof.txt", ("==", "hip  ", "demultiplex:", "process:")), ("inflate_stamps.txt", ("group loop", "flushed bytes", "outside")),
+               ("gpu_tests.txt", ("passed",))):
+    print(f"-- {f}")
+    for line in open(os.path.join(root, "profiles", f"{tag}_{f}")):
+        if any(x in line for x in pat):
+            print("  " + line.rstrip()[:230])
