@@ -1665,9 +1665,12 @@ def test_many_batches_in_one_call_equal_the_single_calls_and_the_oracle(ctx, ora
 
 
 @pytest.mark.gpu
-def test_trim_many_batches_equal_the_oracle(ctx, oracle):
-    """sk_trim_by_quality_many_dev: batches of cfg 2's classes with and without row lengths (src/fasta_trim_by_quality.rs:28-42)."""
+@pytest.mark.parametrize("two_streams", ["1", "0"])
+def test_trim_many_batches_equal_the_oracle(ctx, oracle, two_streams, monkeypatch):
+    """sk_trim_by_quality_many_dev: batches of cfg 2's classes with and without row lengths (src/fasta_trim_by_quality.rs:28-42), their
+    launches on the ctx's two streams in turn (the default) and on one."""
     from seqkit_amd import synth
+    monkeypatch.setenv("SK_MANY_TWO_STREAMS", two_streams)
     stride = 150
     ptrs, batches, expect = [], [], []
     try:
