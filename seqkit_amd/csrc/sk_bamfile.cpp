@@ -68,22 +68,6 @@ bool pread_full(int fd, uint8_t *dst, size_t n, uint64_t off)
 }
 
 // [off, off + n) of the file into dst, by `threads` threads
-bool read_parallel(int fd, uint8_t *dst, size_t n, uint64_t off, int threads)
-{
-	if (threads <= 1 || n < ((size_t)4 << 20)) return pread_full(fd, dst, n, off);
-	std::vector<std::thread> th;
-	std::vector<char> ok((size_t)threads, 1);
-	const size_t piece = ((n + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
-	for (int t = 0; t < threads; t++) {
-		const size_t lo = std::min(n, piece * (size_t)t), hi = std::min(n, lo + piece);
-		if (hi <= lo) break;
-		th.emplace_back([=, &ok] { ok[(size_t)t] = pread_full(fd, dst + lo, hi - lo, off + lo) ? 1 : 0; });
-	}
-	for (auto &t : th) t.join();
-	for (char o : ok) if (!o) return false;
-	return true;
-}
-
 inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 }  // namespace
@@ -190,6 +174,73 @@ struct Ranges {
 	static void destroy(void *p) { Ranges *r = (Ranges *)p; r->comp.release(); r->out.release(); delete r; }
 };
 
+// The readers: threads that pread the file's chunks, in order, into a ring of page-locked buffers — chunk k into slot k mod R, once the
+// copy of chunk k - R out of that slot has been issued and is done — while the caller's thread takes the chunks in order, issues their
+// copies and follows the BGZF headers in them.  (A thread per piece of every chunk, started and joined chunk by chunk, left the file
+// unread while the headers of a chunk were followed: 3 600 thread starts for a 3.6 GB file.)
+struct Readers {
+	int fd = -1;
+	uint8_t *ring = nullptr;
+	size_t chunk = 0;
+	uint64_t fsize = 0, n_chunks = 0;
+	int R = 0;
+	std::vector<hipEvent_t> ev;                  // slot s: the copy out of it
+	std::vector<int64_t> ready, copied;          // slot s: the chunk whose bytes are in it / whose copy has been issued (and its headers followed)
+	std::vector<std::thread> th;
+	std::mutex m;
+	std::condition_variable cv;
+	uint64_t next = 0;
+	bool stop = false, failed = false;
+	int device = 0;
+	void start(int threads)
+	{
+		ready.assign((size_t)R, -1); copied.assign((size_t)R, -1);
+		for (int t = 0; t < threads; t++) th.emplace_back([this] {
+			(void)hipSetDevice(device);
+			for (;;) {
+				uint64_t k;
+				{
+					std::unique_lock<std::mutex> lk(m);
+					if (stop || next >= n_chunks) return;
+					k = next++;
+					const int s = (int)(k % (uint64_t)R);
+					if (k >= (uint64_t)R) {
+						cv.wait(lk, [&] { return stop || copied[(size_t)s] == (int64_t)(k - (uint64_t)R); });
+						if (stop) return;
+					}
+				}
+				const int s = (int)(k % (uint64_t)R);
+				if (k >= (uint64_t)R) (void)hipEventSynchronize(ev[(size_t)s]);     // (outside the lock: the copy out of the slot)
+				const uint64_t off = k * chunk;
+				const size_t len = (size_t)std::min<uint64_t>(chunk, fsize - off);
+				const bool ok = pread_full(fd, ring + (size_t)s * chunk, len, off);
+				std::lock_guard<std::mutex> lk(m);
+				if (!ok) failed = true;
+				ready[(size_t)s] = (int64_t)k;
+				cv.notify_all();
+			}
+		});
+	}
+	bool wait_ready(uint64_t k)                   // chunk k is in its slot (false: a read failed)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		const int s = (int)(k % (uint64_t)R);
+		cv.wait(lk, [&] { return failed || ready[(size_t)s] == (int64_t)k; });
+		return !failed;
+	}
+	void done_with(uint64_t k)                    // its copy is issued (and recorded in ev), nobody reads the slot any more
+	{
+		std::lock_guard<std::mutex> lk(m);
+		copied[(size_t)(k % (uint64_t)R)] = (int64_t)k;
+		cv.notify_all();
+	}
+	~Readers()
+	{
+		{ std::lock_guard<std::mutex> lk(m); stop = true; cv.notify_all(); }
+		for (auto &t : th) t.join();
+	}
+};
+
 #define BF_HIP(call)                                                                                                    \
 	do {                                                                                                                \
 		hipError_t e_ = (call);                                                                                         \
@@ -233,15 +284,27 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 		if (!both) { both = new Ranges; sk::ctx_set_ext(c, both, Ranges::destroy); }
 		if (both->out.va && both->out.reserved < out_cap + 256) both->out.release();
 		if (both->comp.va && both->comp.reserved < fsize + 64) both->comp.release();
-		if ((both->out.va || both->out.reserve(out_cap + 256, dev)) && (both->comp.va || both->comp.reserve(fsize + 64, dev))) { range = &both->out; crange = &both->comp; }
+		// (the compressed file's range only for big files: mapping costs ~12 ms per 512 MiB whoever asks, a plain allocation of a few GB
+		// 6-20 ms — it was an 18 GB one that waited 1.6 s behind another process's exit)
+		const bool comp_mapped = fsize > ((uint64_t)8 << 30);
+		if (!comp_mapped && both->comp.va) both->comp.release();
+		if ((both->out.va || both->out.reserve(out_cap + 256, dev)) && (!comp_mapped || both->comp.va || both->comp.reserve(fsize + 64, dev))) {
+			range = &both->out;
+			crange = comp_mapped ? &both->comp : nullptr;
+		}
 	}
 	Mapper mapper, cmapper;
 	if (range) {
 		out_cap = range->reserved - 256;                                 // (a batch asks for its last byte + 128)
 		d_out = range->va;
-		d_comp = crange->va;
-		cmapper.start(crange);
-		cmapper.ask((size_t)fsize + 64);                                  // (all of the file's range, ahead of the readers)
+		if (crange) {
+			d_comp = crange->va;
+			cmapper.start(crange);
+			cmapper.ask((size_t)fsize + 64);                              // (all of the file's range, ahead of the readers)
+		} else {
+			d_comp = (uint8_t *)sk::ctx_keep(c, kKeepComp, fsize + 64, false, &krc);
+			if (!d_comp) return krc;
+		}
 		mapper.start(range);
 		mapper.ask(std::min<size_t>((size_t)fsize * 2, range->reserved));   // (a BAM inflates at least that far: on its way before the first byte is read)
 	} else if (sk::ctx_kept_bytes(c, kKeepOut) >= out_cap + 64) {
@@ -260,22 +323,22 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	}
 
 	// ---- read, ship, follow the headers; inflate batch by batch
-	size_t chunk = (size_t)8 << 20;                                      // (8 MiB x 3 pinned buffers: 6 ms to allocate where 32 MiB took 17-20; the call's time is the same)
+	size_t chunk = (size_t)4 << 20;                                      // (a ring of 4 MiB page-locked buffers, one and a half per reader: 48 MiB for 8 readers)
 	if (const char *ev = getenv("SK_BAMFILE_CHUNK_LOG2")) { const int lg = atoi(ev); if (lg >= 12 && lg <= 30) chunk = (size_t)1 << lg; }
 	int threads = 8;                                                    // (3.6 GB from the page cache: 165-185 ms with 4 readers, 130-155 with 8, the same with 12)
 	{ const unsigned hc = std::thread::hardware_concurrency(); if (hc >= 1 && hc < 8) threads = (int)hc; }
 	if (const char *ev = getenv("SK_BAMFILE_THREADS")) { const int t = atoi(ev); if (t >= 1 && t <= 64) threads = t; }
-	constexpr int kBufs = 3;
-	uint8_t *pin[kBufs];
-	hipEvent_t ev_copied[kBufs];
-	{
-		uint8_t *p = (uint8_t *)sk::ctx_keep(c, kKeepPin, kBufs * chunk, true, &krc);
-		if (!p) return krc;
-		for (int i = 0; i < kBufs; i++) pin[i] = p + (size_t)i * chunk;
-	}
+	const int kBufs = threads + threads / 2 + 1;
+	Readers rd;
+	rd.fd = cl.fd; rd.chunk = chunk; rd.fsize = fsize; rd.R = kBufs;
+	rd.ring = (uint8_t *)sk::ctx_keep(c, kKeepPin, (size_t)kBufs * chunk, true, &krc);
+	if (!rd.ring) return krc;
+	BF_HIP(hipGetDevice(&rd.device));
 	for (int i = 0; i < kBufs; i++) {
-		BF_HIP(hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming));
-		cl.events.push_back(ev_copied[i]);
+		hipEvent_t e;
+		BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		cl.events.push_back(e);
+		rd.ev.push_back(e);
 	}
 	hipEvent_t ev_batch;
 	BF_HIP(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
@@ -327,15 +390,16 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 	bool eof_block_last = false;
 	const uint64_t n_chunks = (fsize + chunk - 1) / chunk;
 	uint8_t carry[65536 + 64];                                          // a header or trailer that straddles two chunks is read again (pread: rare, and cached)
+	rd.n_chunks = n_chunks;
+	rd.start(threads);
 	for (uint64_t k = 0; k < n_chunks; k++) {
 		const uint64_t c_off = k * chunk;
 		const size_t c_len = (size_t)std::min<uint64_t>(chunk, fsize - c_off);
-		uint8_t *buf = pin[k % kBufs];
-		if (k >= kBufs) BF_HIP(hipEventSynchronize(ev_copied[k % kBufs]));
-		if (!read_parallel(cl.fd, buf, c_len, c_off, threads)) BF_LEAVE(4);
+		uint8_t *buf = rd.ring + (size_t)(k % (uint64_t)kBufs) * chunk;
+		if (!rd.wait_ready(k)) BF_LEAVE(4);
 		if (crange && !cmapper.wait_for((size_t)(c_off + c_len) + 64)) BF_LEAVE(3);
 		BF_HIP(hipMemcpyAsync(d_comp + c_off, buf, c_len, hipMemcpyHostToDevice, st2));
-		BF_HIP(hipEventRecord(ev_copied[k % kBufs], st2));
+		BF_HIP(hipEventRecord(rd.ev[(size_t)(k % (uint64_t)kBufs)], st2));
 		// the blocks that are complete with this chunk
 		const uint64_t have = c_off + c_len;
 		auto bytes = [&](uint64_t off, size_t n) -> const uint8_t * {   // n bytes of the file at off (off + n <= have)
@@ -399,6 +463,7 @@ extern "C" int sk_bam_file_reduce(sk_ctx *c, const char *path, int32_t max_frag,
 			launched += n_new;
 			n_batches++;
 		}
+		rd.done_with(k);                                                  // (the chunk's headers have been followed: its slot may be read into again once the copy is through)
 	}
 	if (two_streams) {                                                   // what follows on st comes behind both streams' batches
 		BF_HIP(hipEventRecord(ev_b, st_b));
