@@ -212,6 +212,7 @@ __device__ __forceinline__ u32 inf_build(InfLds &L, const uint8_t *lens, int nsy
 // the bit reader: everything wave-uniform except the two windows
 struct InfBits {
 	u64 bb;                  // bits not yet consumed, the next one lowest
+	u64 bx;                  // ... and bits 64 and up: the assembly's group loop keeps up to 128 (everything else refills to 64 at most and finds bx zero, or shifts it along)
 	u32 cnt;                 // how many
 	u32 vin, vnext;          // (vector) the window the buffer is fed from, and the one behind it
 	u32 widx;                // the next dword of vin
@@ -238,8 +239,11 @@ __device__ __forceinline__ void inf_refill(InfBits &b, int lane)
 __device__ __forceinline__ u32 inf_take(InfBits &b, u32 n)
 {
 	const u32 v = (u32)b.bb & ((1u << n) - 1u);
-	b.bb >>= n;
-	b.cnt -= n;
+	if (n != 0u) {                                                      // (n <= 16 here)
+		b.bb = (b.bb >> n) | (b.bx << (64u - n));
+		b.bx >>= n;
+		b.cnt -= n;
+	}
 	return v;
 }
 // position the reader at byte `at` of the descriptor's range
@@ -251,6 +255,7 @@ __device__ __forceinline__ void inf_seek(InfBits &b, u32 at, int lane)
 	b.next_off = a4 + 512u;
 	b.widx = 0u;
 	b.bb = 0ull;
+	b.bx = 0ull;
 	b.cnt = 0u;
 	b.taken = a4 >> 2;
 	inf_refill(b, lane);
@@ -309,13 +314,20 @@ extern __shared__ __attribute__((aligned(16))) uint8_t inf_smem[];      // kInfW
 // the allocator kept the bit buffer's count, the window index and the output position in lanes of a spill VGPR and moved them
 // in and out with v_readlane / v_writelane on every symbol (a 64 KiB block of literals took 1 300 cycles per symbol).  Arguments
 // of a device function arrive in vector registers: the state is made scalar again on entry (it is wave-uniform by construction).
-struct InfRun { InfBits b; u32 op, flushed, err; };
+// what crosses the call: plain words (the buffer descriptor is made again inside: a value of its type does not travel through a call's registers)
+struct InfRun {
+	u64 bb, bx;
+	u32 cnt, vin, vnext, widx, next_off, taken, op, flushed, err;
+	__device__ __forceinline__ void put(const InfBits &b) { bb = b.bb; bx = b.bx; cnt = b.cnt; vin = b.vin; vnext = b.vnext; widx = b.widx; next_off = b.next_off; taken = b.taken; }
+	__device__ __forceinline__ void get(InfBits &b) const { b.bb = bb; b.bx = bx; b.cnt = cnt; b.vin = vin; b.vnext = vnext; b.widx = widx; b.next_off = next_off; b.taken = taken; }
+};
 __device__ __forceinline__ u64 inf_uniform64(u64 v) { return (u64)inf_uniform((u32)v) | ((u64)inf_uniform((u32)(v >> 32)) << 32); }
 __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, const uint8_t *in_base, u32 in_range, u32 a0, u32 out_len, uint8_t *dst, int lane)
 {
 	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[inf_uniform((u32)wave)];      // (by index: a pointer argument would arrive as a generic address, and every table read as a flat load)
-	InfBits b = r.b;
-	b.bb = inf_uniform64(b.bb); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
+	InfBits b;
+	r.get(b);
+	b.bb = inf_uniform64(b.bb); b.bx = inf_uniform64(b.bx); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
 	in_base = reinterpret_cast<const uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)in_base));
 	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(in_base), 0, (int)inf_uniform(in_range), 0x00020000);      // (the descriptor, made again from scalars)
 	u32 op = inf_uniform(r.op), flushed = inf_uniform(r.flushed), err = 0u;
@@ -369,7 +381,7 @@ __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, cons
 			if (((a0 + op) & (kHalf - 1u)) == 0u) { inf_flush(L, dst, a0, flushed, op, lane); flushed = op; }
 		}
 	}
-	r.b = b; r.op = op; r.flushed = flushed; r.err = err;
+	r.put(b); r.op = op; r.flushed = flushed; r.err = err;
 	return r;
 }
 
@@ -403,7 +415,13 @@ __device__ u64 g_inf_stamps[16];
 constexpr u32 kUnit = kRing / 4u;
 static_assert(kUnit >= 512u, "a unit holds a longest match and a group's literals");
 __device__ __forceinline__ u64 inf_shr(u64 v, u32 n) { return n >= 64u ? 0ull : v >> n; }      // (n may be all 64 bits: the hardware would shift modulo 64)
-__device__ __forceinline__ void inf_drop(InfBits &b, u32 n) { b.bb = inf_shr(b.bb, n); b.cnt -= n; }
+__device__ __forceinline__ void inf_drop(InfBits &b, u32 n)          // n of the buffer's (up to 128) bits are done with
+{
+	if (n == 0u) return;
+	if (n < 64u) { b.bb = (b.bb >> n) | (b.bx << (64u - n)); b.bx >>= n; }
+	else { b.bb = inf_shr(b.bx, n - 64u); b.bx = 0ull; }
+	b.cnt -= n;
+}
 // inclusive prefix sum over the wave's 64 lanes on DPP (gfx9: row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast 15 and 31 across them)
 __device__ __forceinline__ u32 inf_wave_scan(u32 x)
 {
@@ -419,8 +437,9 @@ __device__ __forceinline__ u32 inf_wave_scan(u32 x)
 __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun r, const uint8_t *in_base, u32 in_range, u32 a0, u32 out_len, uint8_t *dst, int lane)
 {
 	InfLds &L = reinterpret_cast<InfLds *>(inf_smem)[inf_uniform((u32)wave)];
-	InfBits b = r.b;
-	b.bb = inf_uniform64(b.bb); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
+	InfBits b;
+	r.get(b);
+	b.bb = inf_uniform64(b.bb); b.bx = inf_uniform64(b.bx); b.cnt = inf_uniform(b.cnt); b.widx = inf_uniform(b.widx); b.next_off = inf_uniform(b.next_off); b.taken = inf_uniform(b.taken);
 	in_base = reinterpret_cast<const uint8_t *>((uintptr_t)inf_uniform64((u64)(uintptr_t)in_base));
 	b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(in_base), 0, (int)inf_uniform(in_range), 0x00020000);
 	u32 op = inf_uniform(r.op), flushed = inf_uniform(r.flushed), err = 0u;
@@ -558,22 +577,45 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 	const u32 ring_base = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&L.ring[0];
 	while (!done && !err) {
 		u32 why;
+		u64 bx_s = inf_uniform64(b.bx);                                    // (the compiler does not take b.bx for uniform on every path into here)
 		asm volatile(
-			"s_mov_b64 s[94:95], exec\n"
-			"1:\n\t"
-			"s_cmp_gt_u32 %[cnt], 32\n\t"
+			"s_mov_b64 s[94:95], exec\n\t"
+			"v_sub_u32 v57, 64, %[vlane]\n\t"                    // (lane 0 never takes part in the shift that uses it: its v62:63 stay zero)
+			"v_mov_b32 v62, 0\n\t"
+			"v_mov_b32 v63, 0\n"
+			"1:\n\t"                                          // the buffer: s84:85 bits 0-63, s82:83 bits 64-127; filled to more than 96 bits, a dword at a time
+			"s_cmp_gt_u32 %[cnt], 96\n\t"
 			"s_cbranch_scc1 2f\n\t"
 			"v_readlane_b32 s86, %[vin], %[widx]\n\t"
 			"s_mov_b32 s87, 0\n\t"
-			"s_lshl_b64 s[86:87], s[86:87], %[cnt]\n\t"
-			"s_or_b64 s[84:85], s[84:85], s[86:87]\n\t"
+			"s_cmp_lt_u32 %[cnt], 64\n\t"
+			"s_cbranch_scc0 10f\n\t"
+			"s_lshl_b64 s[88:89], s[86:87], %[cnt]\n\t"          // the dword's bits below bit 64 ...
+			"s_or_b64 s[84:85], s[84:85], s[88:89]\n\t"
+			"s_cmp_le_u32 %[cnt], 32\n\t"
+			"s_cbranch_scc1 11f\n\t"
+			"s_sub_u32 s88, 64, %[cnt]\n\t"                      // ... and those above it (cnt 33-63: a shift by 31-1)
+			"s_lshr_b32 s88, s86, s88\n\t"
+			"s_or_b32 s82, s82, s88\n\t"
+			"s_branch 11f\n"
+			"10:\n\t"
+			"s_sub_u32 s90, %[cnt], 64\n\t"
+			"s_lshl_b64 s[88:89], s[86:87], s90\n\t"
+			"s_or_b64 s[82:83], s[82:83], s[88:89]\n"
+			"11:\n\t"
 			"s_add_u32 %[cnt], %[cnt], 32\n\t"
 			"s_add_u32 %[taken], %[taken], 1\n\t"
 			"s_add_u32 %[widx], %[widx], 1\n\t"
 			"s_cmp_eq_u32 %[widx], 64\n\t"
-			"s_cbranch_scc1 20f\n"
-			"2:\n\t"                                          // lane j: v60:61 = the buffer from bit j on; v41 entry, v42 code bits, v43 extra bits, v44 length
+			"s_cbranch_scc1 20f\n\t"
+			"s_branch 1b\n"
+			"2:\n\t"                                          // lane j: v60:61 = the 64 bits from bit j on; v41 entry, v42 code bits, v43 extra bits, v44 length
 			"v_lshrrev_b64 v[60:61], %[vlane], s[84:85]\n\t"
+			"s_mov_b64 exec, -2\n\t"
+			"v_lshlrev_b64 v[62:63], v57, s[82:83]\n\t"
+			"s_mov_b64 exec, s[94:95]\n\t"
+			"v_or_b32 v60, v60, v62\n\t"
+			"v_or_b32 v61, v61, v63\n\t"
 			"v_and_b32 v40, 0x3ff, v60\n\t"
 			"v_lshl_add_u32 v40, v40, 2, %[lit]\n\t"
 			"ds_read_b32 v41, v40\n\t"
@@ -616,7 +658,8 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 			"s_cbranch_scc1 4f\n\t"
 			"s_bitset1_b64 s[88:89], s60\n\t"
 			"s_mov_b32 s60, s61\n\t"
-			"s_branch 3b\n"
+			"s_cmp_lt_u32 s60, 64\n\t"                           // (a lane per offset: 64 of them)
+			"s_cbranch_scc1 3b\n"
 			"4:\n\t"
 			"s_cmp_eq_u64 s[88:89], 0\n\t"
 			"s_cbranch_scc1 21f\n\t"
@@ -687,12 +730,20 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 			"s_mov_b64 exec, s[94:95]\n"
 			"7:\n\t"
 			"s_add_u32 %[op], %[op], s62\n\t"
-			"s_cmp_lt_u32 s60, 64\n\t"                           // the buffer moves on by s60 bits (all 64: a shift the hardware takes modulo 64)
+			"s_cmp_lt_u32 s60, 64\n\t"                           // the buffer moves on by s60 bits (up to 99)
 			"s_cbranch_scc1 8f\n\t"
-			"s_mov_b64 s[84:85], 0\n\t"
+			"s_sub_u32 s61, s60, 64\n\t"
+			"s_lshr_b64 s[84:85], s[82:83], s61\n\t"
+			"s_mov_b64 s[82:83], 0\n\t"
 			"s_branch 9f\n"
 			"8:\n\t"
-			"s_lshr_b64 s[84:85], s[84:85], s60\n"
+			"s_cmp_eq_u32 s60, 0\n\t"
+			"s_cbranch_scc1 9f\n\t"
+			"s_lshr_b64 s[84:85], s[84:85], s60\n\t"
+			"s_sub_u32 s61, 64, s60\n\t"
+			"s_lshl_b64 s[86:87], s[82:83], s61\n\t"
+			"s_or_b64 s[84:85], s[84:85], s[86:87]\n\t"
+			"s_lshr_b64 s[82:83], s[82:83], s60\n"
 			"9:\n\t"
 			"s_sub_u32 %[cnt], %[cnt], s60\n\t"
 			"s_cmp_lg_u32 s64, 0\n\t"
@@ -717,11 +768,12 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 			"29:\n\t"
 			"s_mov_b64 exec, s[94:95]\n\t"
 			"s_waitcnt lgkmcnt(0)"
-			: [bb] "+{s[84:85]}"(b.bb), [cnt] "+s"(b.cnt), [widx] "+s"(b.widx), [taken] "+s"(b.taken), [op] "+s"(op), [ntok] "+s"(ntok), [why] "=&s"(why)
+			: [bb] "+{s[84:85]}"(b.bb), [bx] "+{s[82:83]}"(bx_s), [cnt] "+s"(b.cnt), [widx] "+s"(b.widx), [taken] "+s"(b.taken), [op] "+s"(op), [ntok] "+s"(ntok), [why] "=&s"(why)
 			: [vin] "v"(b.vin), [vlane] "v"(lane), [ue] "s"(ue), [olen] "s"(out_len), [a0] "s"(a0), [lit] "s"(lit_base), [tok] "s"(tok_base), [ring] "s"(ring_base)
 			: "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-			  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v60", "v61",
+			  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v60", "v61", "v62", "v63",
 			  "vcc", "scc", "memory");
+		b.bx = bx_s;
 		SK_ISTAMP(1);
 		if (why == 1u) {                                                    // the window behind, and the one after it on its way
 			b.vin = b.vnext;
@@ -890,7 +942,7 @@ __device__ __attribute__((noinline)) InfRun inf_symbols_groups(int wave, InfRun 
 #ifdef SK_INF_STAMPS
 	if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_inf_stamps[i], ist_acc[i]);
 #endif
-	r.b = b; r.op = op; r.flushed = flushed; r.err = err;
+	r.put(b); r.op = op; r.flushed = flushed; r.err = err;
 	return r;
 }
 
@@ -991,13 +1043,13 @@ __device__ __forceinline__ u32 inf_block(InfLds &L, int wave, const uint8_t *com
 			// ---- the symbols of the block (a function of its own: see inf_symbols)
 			{
 				InfRun r;
-				r.b = b; r.op = op; r.flushed = flushed; r.err = 0u;
+				r.put(b); r.op = op; r.flushed = flushed; r.err = 0u;
 #if SK_INF_GROUPS
 				r = inf_symbols_groups(wave, r, comp + in4, range, a0, out_len, out + blk.out_off, lane);
 #else
 				r = inf_symbols(wave, r, comp + in4, range, a0, out_len, out + blk.out_off, lane);
 #endif
-				b = r.b; op = r.op; flushed = r.flushed; err = r.err;
+				r.get(b); op = r.op; flushed = r.flushed; err = r.err;
 			}
 			if (err) break;
 		} else {
