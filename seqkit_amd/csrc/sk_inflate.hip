@@ -22,7 +22,8 @@
 //   * symbols, a GROUP per table access (inf_symbols_groups): lane j decodes the symbol that would begin at bit j of the
 //     buffer — a literal, or a whole match: length code, extra bits, distance code, extra bits — and a short scalar chain
 //     (v_readlane of the symbol's bit count at the offset the symbol before ended at) finds which lanes are real symbol
-//     starts: one LDS latency per 3-5 symbols instead of one (or two) per symbol, 7 scalar instructions a symbol.  The symbols'
+//     starts: one LDS latency per ~6 symbols (the buffer holds up to 128 bits) instead of one (or two) per symbol, 8 scalar
+//     instructions a symbol.  The symbols'
 //     places in the output are a prefix sum (DPP) of the bytes they make; literals are stored by their lanes.
 //   * matches, a BATCH per copy: decoding does not need a match's bytes, so matches are noted as tokens while decoding goes
 //     on (up to 64, within one unit of the ring) and copied afterwards — those whose source was flushed long ago all at
