@@ -394,7 +394,7 @@ __device__ __attribute__((noinline)) InfRun inf_symbols(int wave, InfRun r, cons
 // block's 14 ms.  And decoding one symbol per table access is a chain of latencies of its own (LDS read, v_readfirstlane, scalar
 // arithmetic, the byte's ds_write: a hand-written loop of 13 scalar instructions instead of the compiler's 45 gained 16 %).
 //   * groups: the tables are read ONCE for every bit offset of the buffer — lane j looks up the 10 bits at offset j, and the distance
-//     table's 8 bits there — and the symbols of the buffer's 33-64 bits follow from registers (v_readlane at the offset the symbol
+//     table's 8 bits there — and the symbols of the buffer's bits (33-64 of them here, 97-128 in the assembly's loop) follow from registers (v_readlane at the offset the symbol
 //     before ended at), no memory access in between.  A code is taken only if all its bits are in the buffer (o + length <= cnt): a
 //     lane that looked at bits beyond the buffer's end is never believed.  The literals of a group are written together: the lanes
 //     at which a literal began (a mask built by the chain) store their bytes at ring positions given by their rank in the mask.  The
