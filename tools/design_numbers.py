@@ -25,7 +25,7 @@ for x in d["extra"]["rates"]:
     if "frac_warm" in x:                                       # rows timed from HBM: buffer sets in rotation, one event pair per call
         placed += f" from HBM; pipelined {x['frac_pipelined']:.3f}, on-die replay {x['frac_warm']:.3f} ({x['ms_warm'] * 1000:.1f} µs)"
     if "frac_many" in x:                                       # the buffer sets as the batches of ONE many-batch call
-        placed += f"; per batch of one many-batch call {x['frac_many']:.3f} ({x['ms_many'] * 1000:.1f} µs)"
+        placed += f"; per batch of one many-batch call {x['frac_many']:.3f} ({x['ms_many'] * 1000:.1f} µs)" + (f", three such calls pipelined {x['frac_many_pipelined']:.3f}" if "frac_many_pipelined" in x else "")
     if "reset_ms" in x:                                        # census: sk_census_reset before the count
         placed += f"; reset {x['reset_ms'] * 1000:.0f} µs, reset + count {x['reset_plus_count_ms'] * 1000:.0f} µs"
     rows.append(f"| {x['config']} | {x['ms'] * 1000:.1f} µs, {x['G_units_per_s']:.1f} G units/s | {x['frac']:.3f}{placed} | {b} |")
