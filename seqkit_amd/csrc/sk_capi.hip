@@ -52,6 +52,10 @@ struct sk_ctx {
 	sk::ManyBatch *many_pin = nullptr, *many_dev = nullptr;
 	hipEvent_t many_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	int many_next = 0;
+	// the sheet / pitch / output set for which launch_tile_pass last said "no one-launch form": the next many-batch call of that shape goes
+	// straight to its batches' own launches (the refused attempt cost an event and the descriptors: 3 us a call)
+	const void *many_no_tab = nullptr;
+	int many_no_stride = 0, many_no_detail = -1;
 	uint8_t *pin = nullptr;            // a pinned landing area (sk_bgzf_deflate: the compressed slots come back here)
 	size_t pin_bytes = 0;
 	// buffers that stay with the ctx from one call to the next (sk::ctx_keep: sk_bam_file_reduce's device and pinned buffers)
@@ -354,6 +358,7 @@ int sk_set_barcodes(sk_ctx *c, const uint8_t *table, int S, int L, int max_diff)
 	if (c->d_lut) { SK_HIP(c, hipFree(c->d_lut)); c->d_lut = nullptr; }
 	if (c->d_bs) { SK_HIP(c, hipFree(c->d_bs)); c->d_bs = nullptr; }
 	if (c->d_nbr) { SK_HIP(c, hipFree(c->d_nbr)); c->d_nbr = nullptr; }
+	c->many_no_tab = nullptr;
 	c->nbr = sk::LutDev{};
 	c->bs_bytes = c->bs_mm_off = c->G = 0;
 	if (c->d_counts) { SK_HIP(c, hipFree(c->d_counts)); c->d_counts = nullptr; }
@@ -883,6 +888,8 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 			rows += ((a.n + 255) / 256) * 256;
 		}
 		if (const char *ev = getenv("SK_MANY_ONE_LAUNCH")) same = same && atoi(ev) != 0;      // (A/B: the batches' own launches instead)
+		const int want_detail_key = same ? ((batches[0].lowest_diff ? 1 : 0) | (batches[0].first_idx ? 2 : 0) | (batches[0].last_idx ? 4 : 0) | (c->detail_mode << 3)) : 0;
+		if (same && c->many_no_tab && c->many_no_tab == (const void *)c->d_nbr && c->many_no_stride == batches[0].bc_stride && c->many_no_detail == want_detail_key && !getenv("SK_LUT_MANY_GATHER")) same = false;
 		if (same && rows > 0 && rows < ((int64_t)1 << 31) && n_batches <= kManyMax) {
 			if (int r = prepare_demux(c, &batches[0])) return r;
 			if (!c->many_pin) {
@@ -924,6 +931,7 @@ int sk_fused_pass_many_dev(sk_ctx *c, const sk_fused_args *batches, int n_batche
 				if (e == hipSuccess) return SK_OK;
 				if (e != hipErrorNotSupported) return fail(c, SK_ERR_HIP, "launch_tile_pass (many batches): %s", hipGetErrorString(e));
 				(void)hipGetLastError();
+				if (t.n >= 1500000) { c->many_no_tab = (const void *)c->d_nbr; c->many_no_stride = batches[0].bc_stride; c->many_no_detail = want_detail_key; }      // (below that the answer may depend on the size)
 			} else return SK_OK;
 		}
 	}
